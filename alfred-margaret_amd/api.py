@@ -1,0 +1,377 @@
+"""ctypes front-end over libam.so (C ABI, include/am.h) and libam_host.so (C++ host mirror).
+
+The classes mirror the reference modules (same names and argument meaning):
+  Automaton  ~ Data.Text.AhoCorasick.Automaton  (build, run_with_case / run_text / run_lower, count_matches)
+  Searcher   ~ Data.Text.AhoCorasick.Searcher   (build, contains_any, contains_all, set_case_sensitivity)
+  Replacer   ~ Data.Text.AhoCorasick.Replacer   (build, run, run_with_limit)
+Every match position comes from the HIP kernels; there is no Python or CPU matching path, and
+importing this module fails loudly if the native libraries are missing and cannot be built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+CASE_SENSITIVE = 0
+IGNORE_CASE = 1
+
+AM_OK = 0
+AM_ERR_INVALID, AM_ERR_NO_DEVICE, AM_ERR_HIP, AM_ERR_OOM, AM_ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+
+
+class AmError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libam error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Slice(C.Structure):          # am_slice
+    _fields_ = [("ptr", C.c_void_p), ("off", C.c_size_t), ("len", C.c_size_t)]
+
+
+MATCH_DTYPE = np.dtype([("end_pos", np.uint64), ("haystack", np.uint32), ("state", np.uint32)])   # am_match
+
+_u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+_vp, _sz = C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes): every symbol include/am.h declares
+ABI = {
+    "am_last_error": (C.c_char_p, []),
+    "am_automaton_create": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp, C.POINTER(_vp)]),
+    "am_automaton_destroy": (None, [_vp]),
+    "am_automaton_set_kernel": (C.c_int, [_vp, C.c_int]),
+    "am_count": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
+    "am_contains_any": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
+    "am_run": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp)]),
+    "am_batch_upload": (C.c_int, [C.POINTER(Slice), _sz, C.POINTER(_vp)]),
+    "am_batch_from_device": (C.c_int, [_vp, _vp, _sz, C.c_uint64, C.POINTER(_vp)]),
+    "am_batch_destroy": (None, [_vp]),
+    "am_batch_total_bytes": (C.c_uint64, [_vp]),
+    "am_count_batch": (C.c_int, [_vp, C.c_int, _vp, _vp, _u64p]),
+    "am_contains_any_batch": (C.c_int, [_vp, C.c_int, _vp, _vp]),
+    "am_run_batch": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(_vp)]),
+    "am_matches_size": (C.c_uint64, [_vp]),
+    "am_matches_data": (_vp, [_vp]),
+    "am_matches_device_data": (_vp, [_vp]),
+    "am_matches_free": (None, [_vp]),
+    "am_automaton_image_size": (C.c_int, [_vp, C.c_int, C.POINTER(_sz)]),
+    "am_automaton_image_copy": (C.c_int, [_vp, C.c_int, _vp, _sz]),
+    "am_automaton_from_image": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
+    "am_unlower_code_point": (_sz, [C.c_uint32, _vp, _sz]),
+    "am_set_stream": (C.c_int, [_vp]),
+    "am_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_sz), C.c_char_p, _sz]),
+    "am_profile_enable": (C.c_int, [C.c_int]),
+    "am_profile_reset": (C.c_int, []),
+    "am_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), _u64p]),
+}
+
+_HOST = {
+    "amh_last_error": (C.c_char_p, []),
+    "amh_build": (C.c_int, [C.c_char_p, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "amh_free": (None, [_vp]),
+    "amh_num_states": (_sz, [_vp]),
+    "amh_num_transitions": (_sz, [_vp]),
+    "amh_transitions": (_u64p, [_vp]),
+    "amh_offsets": (_u32p, [_vp]),
+    "amh_root_ascii": (_u64p, [_vp]),
+    "amh_values_off": (_u64p, [_vp]),
+    "amh_values": (_u32p, [_vp]),
+    "amh_device": (_vp, [_vp]),
+    "amh_run_list": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp, _vp, _vp, C.c_uint64, _u64p]),
+    "amh_count": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
+    "amh_searcher_build": (C.c_int, [C.c_int, C.c_char_p, _vp, _sz, C.POINTER(_vp)]),
+    "amh_searcher_free": (None, [_vp]),
+    "amh_searcher_set_case": (None, [_vp, C.c_int]),
+    "amh_searcher_contains_any": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
+    "amh_searcher_contains_all": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
+    "amh_replacer_build": (C.c_int, [C.c_int, C.c_char_p, _vp, C.c_char_p, _vp, _sz, C.POINTER(_vp)]),
+    "amh_replacer_free": (None, [_vp]),
+    "amh_replacer_run_batch": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
+    "amh_free_blob": (None, [_vp]),
+    "amh_skip_code_points_backwards": (C.c_int64, [C.c_char_p, _sz, _sz, _sz]),
+    "amh_lower_utf8": (_sz, [C.c_char_p, _sz, _vp, _sz]),
+}
+
+_libam = None
+_libhost = None
+
+
+def _bind(lib, table):
+    for name, (rt, at) in table.items():
+        fn = getattr(lib, name)      # AttributeError = missing export: fail loudly
+        fn.restype = rt
+        fn.argtypes = at
+    return lib
+
+
+def libam():
+    """The product library.  Built in-tree by build.py (hipcc --offload-arch=gfx950); never replaced by a fallback."""
+    global _libam
+    if _libam is None:
+        path = os.path.join(_build.LIB, "libam.so")
+        if not os.path.exists(path):
+            path = _build.build_libam()
+        _libam = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), ABI)
+    return _libam
+
+
+def libhost():
+    global _libhost
+    if _libhost is None:
+        libam()
+        path = os.path.join(_build.LIB, "libam_host.so")
+        if not os.path.exists(path):
+            path = _build.build_host()
+        _libhost = _bind(C.CDLL(path), _HOST)
+    return _libhost
+
+
+def check(rc):
+    if rc != AM_OK:
+        raise AmError(rc, (libam().am_last_error() or b"").decode("utf-8", "replace"))
+
+
+def _hcheck(rc):
+    if rc != AM_OK:
+        raise AmError(rc, (libhost().amh_last_error() or b"").decode("utf-8", "replace"))
+
+
+def _as_bytes(t):
+    return t.encode("utf-8") if isinstance(t, str) else bytes(t)
+
+
+def pack_texts(texts):
+    bs = [_as_bytes(t) for t in texts]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    return b"".join(bs), offs
+
+
+class _Slices:
+    """Keeps the Python buffers alive while C borrows them.  Accepts str/bytes or (bytes, off, len)."""
+
+    def __init__(self, texts):
+        self.keep = []
+        self.n = len(texts)
+        self.arr = (Slice * max(self.n, 1))()
+        for i, t in enumerate(texts):
+            off, ln = 0, None
+            if isinstance(t, tuple):
+                t, off, ln = t
+            if isinstance(t, np.ndarray):
+                assert t.dtype == np.uint8 and t.flags["C_CONTIGUOUS"]
+                ptr, size = t.ctypes.data, t.size
+                self.keep.append(t)
+            else:
+                b = _as_bytes(t)
+                buf = C.create_string_buffer(b, len(b) + 1)
+                self.keep.append(buf)
+                ptr, size = C.addressof(buf), len(b)
+            self.arr[i] = Slice(ptr, off, size - off if ln is None else ln)
+
+
+class Automaton:
+    """AcMachine v with v = uint32 handles (needle index by default)."""
+
+    def __init__(self, needles, values=None):
+        blob, offs = pack_texts(needles)
+        self.needles = [_as_bytes(n) for n in needles]
+        vptr = None
+        if values is not None:
+            self._vals = np.ascontiguousarray(values, dtype=np.uint32)
+            vptr = self._vals.ctypes.data
+        h = _vp()
+        _hcheck(libhost().amh_build(blob, offs.ctypes.data, len(needles), vptr, C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def build(cls, needles_with_values):
+        """Automaton.hs:176 build :: [(Text, v)] -> AcMachine v (v = uint32)."""
+        return cls([n for n, _ in needles_with_values], [v for _, v in needles_with_values])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libhost().amh_free(self._h)
+            self._h = None
+
+    @property
+    def device(self):
+        return libhost().amh_device(self._h)
+
+    @property
+    def n_states(self):
+        return libhost().amh_num_states(self._h)
+
+    def transitions(self):
+        return np.ctypeslib.as_array(libhost().amh_transitions(self._h), shape=(libhost().amh_num_transitions(self._h),)).copy()
+
+    def offsets(self):
+        return np.ctypeslib.as_array(libhost().amh_offsets(self._h), shape=(self.n_states + 1,)).copy()
+
+    def root_ascii(self):
+        return np.ctypeslib.as_array(libhost().amh_root_ascii(self._h), shape=(128,)).copy()
+
+    def values_off(self):
+        return np.ctypeslib.as_array(libhost().amh_values_off(self._h), shape=(self.n_states + 1,)).copy()
+
+    def values(self):
+        n = int(self.values_off()[-1])
+        return np.ctypeslib.as_array(libhost().amh_values(self._h), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+    def set_kernel(self, k):
+        check(libam().am_automaton_set_kernel(self.device, k))
+
+    def run_batch_with_case(self, case, texts):
+        """Per-haystack list fold of runWithCase: returns (haystack, matchPos, value) arrays in fold order."""
+        s = _Slices(texts)
+        n = C.c_uint64(0)
+        _hcheck(libhost().amh_run_list(self._h, case, s.arr, s.n, None, None, None, 0, C.byref(n)))
+        k = int(n.value)
+        hay, pos, val = np.zeros(max(k, 1), np.uint32), np.zeros(max(k, 1), np.uint64), np.zeros(max(k, 1), np.uint32)
+        _hcheck(libhost().amh_run_list(self._h, case, s.arr, s.n, hay.ctypes.data, pos.ctypes.data, val.ctypes.data, k, C.byref(n)))
+        return hay[:k], pos[:k], val[:k]
+
+    def run_with_case(self, case, text):
+        _, pos, val = self.run_batch_with_case(case, [text])
+        return pos, val
+
+    def run_text(self, text):
+        return self.run_with_case(CASE_SENSITIVE, text)
+
+    def run_lower(self, text):
+        return self.run_with_case(IGNORE_CASE, text)
+
+    def count_matches(self, case, texts):
+        """countMatches (benchmark/haskell/app/Main.hs:67-76) per haystack."""
+        s = _Slices(texts)
+        out = np.zeros(max(s.n, 1), np.uint64)
+        _hcheck(libhost().amh_count(self._h, case, s.arr, s.n, out.ctypes.data))
+        return out[:s.n]
+
+    def run_records(self, case, texts):
+        """Raw am_match records straight from the C ABI (am_run)."""
+        s = _Slices(texts)
+        m = _vp()
+        check(libam().am_run(self.device, case, s.arr, s.n, C.byref(m)))
+        try:
+            return matches_to_numpy(m)
+        finally:
+            libam().am_matches_free(m)
+
+
+def matches_to_numpy(m):
+    n = int(libam().am_matches_size(m))
+    if n == 0:
+        return np.zeros(0, MATCH_DTYPE)
+    p = libam().am_matches_data(m)
+    if not p:
+        raise AmError(AM_ERR_HIP, (libam().am_last_error() or b"").decode())
+    return np.frombuffer((C.c_char * (n * MATCH_DTYPE.itemsize)).from_address(p), dtype=MATCH_DTYPE).copy()
+
+
+class Searcher:
+    def __init__(self, case, needles):
+        blob, offs = pack_texts(needles)
+        h = _vp()
+        _hcheck(libhost().amh_searcher_build(case, blob, offs.ctypes.data, len(needles), C.byref(h)))
+        self._h = h
+        self.case = case
+
+    build = classmethod(lambda cls, case, needles: cls(case, needles))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libhost().amh_searcher_free(self._h)
+            self._h = None
+
+    def set_case_sensitivity(self, case):
+        libhost().amh_searcher_set_case(self._h, case)
+        self.case = case
+
+    def contains_any_batch(self, texts):
+        s = _Slices(texts)
+        out = np.zeros(max(s.n, 1), np.uint8)
+        _hcheck(libhost().amh_searcher_contains_any(self._h, s.arr, s.n, out.ctypes.data))
+        return out[:s.n].astype(bool)
+
+    def contains_any(self, text):
+        return bool(self.contains_any_batch([text])[0])
+
+    def contains_all_batch(self, texts):
+        s = _Slices(texts)
+        out = np.zeros(max(s.n, 1), np.uint8)
+        _hcheck(libhost().amh_searcher_contains_all(self._h, s.arr, s.n, out.ctypes.data))
+        return out[:s.n].astype(bool)
+
+    def contains_all(self, text):
+        return bool(self.contains_all_batch([text])[0])
+
+
+class Replacer:
+    def __init__(self, case, pairs):
+        nb, no = pack_texts([p[0] for p in pairs])
+        rb, ro = pack_texts([p[1] for p in pairs])
+        h = _vp()
+        _hcheck(libhost().amh_replacer_build(case, nb, no.ctypes.data, rb, ro.ctypes.data, len(pairs), C.byref(h)))
+        self._h = h
+
+    build = classmethod(lambda cls, case, pairs: cls(case, pairs))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libhost().amh_replacer_free(self._h)
+            self._h = None
+
+    def run_batch(self, texts, max_len=-1):
+        s = _Slices(texts)
+        blob = _vp()
+        offs = np.zeros(s.n + 1, np.uint64)
+        nothing = np.zeros(max(s.n, 1), np.uint8)
+        _hcheck(libhost().amh_replacer_run_batch(self._h, s.arr, s.n, max_len, C.byref(blob), offs.ctypes.data, nothing.ctypes.data))
+        try:
+            raw = C.string_at(blob, int(offs[-1]))
+        finally:
+            libhost().amh_free_blob(blob)
+        return [None if nothing[i] else raw[int(offs[i]):int(offs[i + 1])] for i in range(s.n)]
+
+    def run(self, text):
+        return self.run_batch([text])[0]
+
+    def run_with_limit(self, max_len, text):
+        return self.run_batch([text], max_len)[0]
+
+
+def lower_code_point(cp):
+    return int(libam().am_lower_code_point(cp))
+
+
+def unlower_code_point(cp):
+    buf = (C.c_uint32 * 16)()
+    n = libam().am_unlower_code_point(cp, buf, 16)
+    return [int(buf[i]) for i in range(n)]
+
+
+def lower_utf8(text):
+    b = _as_bytes(text)
+    out = C.create_string_buffer(len(b) * 4 + 4)
+    n = libhost().amh_lower_utf8(b, len(b), out, len(b) * 4 + 4)
+    return out.raw[:n]
+
+
+def skip_code_points_backwards(text, index, n):
+    b = _as_bytes(text)
+    r = libhost().amh_skip_code_points_backwards(b, len(b), index, n)
+    if r < 0:
+        raise IndexError("Invalid use of skipCodePointsBackwards")
+    return int(r)
+
+
+def device_info():
+    n_cu, hbm = C.c_int(0), C.c_size_t(0)
+    name = C.create_string_buffer(64)
+    check(libam().am_device_info(C.byref(n_cu), C.byref(hbm), name, 64))
+    return {"n_cu": n_cu.value, "hbm_bytes": hbm.value, "arch": name.value.decode()}

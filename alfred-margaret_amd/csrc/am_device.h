@@ -1,0 +1,36 @@
+// am_device.h -- interface between the C-ABI layer (am_abi.cpp) and the kernels (am_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "am_image.h"
+
+namespace am {
+namespace dev {
+
+constexpr int kModeCount = 0;   // unit_counts[u] = records of unit u; optional per-haystack value counts; total values
+constexpr int kModeEmit = 1;    // write records at unit_offsets[u]
+constexpr int kModeAny = 2;     // flags[haystack] = 1 if anything matches
+
+// 16-byte match record in HBM.  Same layout as am_match in include/am.h.
+struct alignas(16) Record { uint64_t end_pos; uint32_t haystack; uint32_t state; };
+
+struct ScanOut {
+    uint32_t* unit_counts;        // count mode
+    const uint64_t* unit_offsets; // emit mode
+    Record* records;              // emit mode
+    uint64_t* hay_counts;         // count mode, may be null
+    uint64_t* total_values;       // count mode
+    uint8_t* flags;               // any mode
+};
+
+hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st);
+uint64_t sf_units(const BatchView& b);
+uint64_t ac_units(const AcView& a, const BatchView& b);
+size_t sf_lds_bytes(const SfView& s);
+hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
+hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
+hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st);
+
+}  // namespace dev
+}  // namespace am

@@ -1,0 +1,365 @@
+// am_flatten.cpp -- host side of `Automaton.build`'s new second half: take the reference's packed
+// automaton (Automaton.hs:108-123 AcMachine: Word64 transitions, Word32 offsets, root ASCII table,
+// per-state value-list lengths) and flatten it into the device image described in am_image.h.
+// The reference's `build` (Automaton.hs:176-200) stays authoritative for state numbering and
+// value order; nothing here changes what a match means.
+#include "am_flatten.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace am {
+
+// ------------------------------------------------------------------ simple lowercase (Unicode 13.0)
+
+namespace {
+struct LowerPair { uint32_t from, to; };
+const LowerPair kLower[] = {
+#include "unicode_lower_tbl.inc"
+};
+constexpr size_t kNLower = sizeof(kLower) / sizeof(kLower[0]);
+
+const std::unordered_multimap<uint32_t, uint32_t>& inverse_lower()
+{
+    static const std::unordered_multimap<uint32_t, uint32_t> inv = [] {
+        std::unordered_multimap<uint32_t, uint32_t> m;
+        for (size_t i = 0; i < kNLower; i++) m.emplace(kLower[i].to, kLower[i].from);
+        return m;
+    }();
+    return inv;
+}
+}  // namespace
+
+// Utf8.hs:145-151 lowerCodePoint; non-ASCII = Data.Char.toLower (simple mapping, Unicode 13.0 here).
+uint32_t simple_lower(uint32_t cp)
+{
+    size_t lo = 0, hi = kNLower;
+    while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if (kLower[mid].from < cp) lo = mid + 1; else hi = mid;
+    }
+    return (lo < kNLower && kLower[lo].from == cp) ? kLower[lo].to : cp;
+}
+
+// Utf8/Unlower.hs:26-40 unlowerCodePoint: every code point whose lowercase is `cp` (as a set).
+void unlower(uint32_t cp, std::vector<uint32_t>& out)
+{
+    out.clear();
+    if (simple_lower(cp) == cp) out.push_back(cp);
+    auto range = inverse_lower().equal_range(cp);
+    for (auto it = range.first; it != range.second; ++it) out.push_back(it->second);
+    std::sort(out.begin(), out.end());
+}
+
+static void append_utf8(uint32_t c, std::string& out)   // Utf8.hs:154-160 unicode2utf8
+{
+    if (c < 0x80) { out.push_back((char)c); }
+    else if (c < 0x800) { out.push_back((char)(0xc0 | (c >> 6))); out.push_back((char)(0x80 | (c & 0x3f))); }
+    else if (c < 0x10000) { out.push_back((char)(0xe0 | (c >> 12))); out.push_back((char)(0x80 | ((c >> 6) & 0x3f))); out.push_back((char)(0x80 | (c & 0x3f))); }
+    else { out.push_back((char)(0xf0 | (c >> 18))); out.push_back((char)(0x80 | ((c >> 12) & 0x3f))); out.push_back((char)(0x80 | ((c >> 6) & 0x3f))); out.push_back((char)(0x80 | (c & 0x3f))); }
+}
+
+// Byte strings (forward order) a haystack may contain where the lowered haystack has needle code
+// point `c`.  IgnoreCase: UTF-8 of every x with lower(x) == c, ASCII bytes folded to lower case
+// (the kernels fold haystack bytes the same way).  CaseSensitive: just UTF-8 of c.
+static void variants_of(uint32_t c, bool ignore_case, std::vector<std::string>& out)
+{
+    out.clear();
+    if (!ignore_case) { std::string s; append_utf8(c, s); out.push_back(s); return; }
+    std::vector<uint32_t> xs;
+    unlower(c, xs);
+    for (uint32_t x : xs) {
+        std::string s;
+        append_utf8(x < 128 ? fold_byte(x) : x, s);
+        if (std::find(out.begin(), out.end(), s) == out.end()) out.push_back(s);
+    }
+}
+
+// ------------------------------------------------------------------ image assembly
+
+namespace {
+
+struct Blob {
+    std::vector<uint8_t> bytes;
+    uint64_t reserve_section(size_t nbytes)
+    {
+        size_t off = (bytes.size() + 255) & ~(size_t)255;
+        bytes.resize(off + nbytes, 0);
+        return off;
+    }
+    template <class T> uint64_t put(const std::vector<T>& v)
+    {
+        uint64_t off = reserve_section(v.size() * sizeof(T));
+        if (!v.empty()) std::memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+};
+
+uint32_t log2_ceil(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
+
+struct TierEntry { uint32_t key, node; };
+
+}  // namespace
+
+int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err)
+{
+    const size_t S = ref.n_states;
+    const bool ic = case_mode == 1;
+    if (case_mode != 0 && case_mode != 1) { err = "case_mode must be 0 (CaseSensitive) or 1 (IgnoreCase)"; return -1; }
+    if (S == 0 || !ref.transitions || !ref.offsets || !ref.root_ascii || !ref.values_len) { err = "null or empty automaton arrays"; return -1; }
+    if (S >= 0xFFFFFFFEull) { err = "too many states"; return -1; }
+
+    // ---- read the trie back out of the packed transitions (Automaton.hs:166-172,190-192)
+    std::vector<uint32_t> parent(S, kNone), cp_in(S, 0), fallback(S, 0), depth(S, 0);
+    std::vector<uint32_t> edge_begin(S), edge_count(S);
+    for (size_t s = 0; s < S; s++) {
+        uint64_t i = ref.offsets[s];
+        edge_begin[s] = (uint32_t)i;
+        for (;; i++) {
+            if (i >= ref.n_transitions) { err = "transition list of a state is not wildcard-terminated"; return -1; }
+            const uint64_t t = ref.transitions[i];
+            const uint32_t next = (uint32_t)(t >> 32);
+            if (next >= S) { err = "transition to a state out of range"; return -1; }
+            if (t & kWildcard) { fallback[s] = next; break; }
+            if (next == 0 || parent[next] != kNone) { err = "goto edges do not form a trie"; return -1; }
+            parent[next] = (uint32_t)s;
+            cp_in[next] = (uint32_t)(t & 0x1fffffu);
+        }
+        edge_count[s] = (uint32_t)(i - edge_begin[s]);
+    }
+    std::vector<uint32_t> bfs; bfs.reserve(S); bfs.push_back(0);
+    for (size_t q = 0; q < bfs.size(); q++) {
+        const uint32_t s = bfs[q];
+        for (uint32_t k = 0; k < edge_count[s]; k++) {
+            const uint32_t nx = (uint32_t)(ref.transitions[edge_begin[s] + k] >> 32);
+            depth[nx] = depth[s] + 1;
+            bfs.push_back(nx);
+        }
+    }
+    if (bfs.size() != S) { err = "unreachable states in the automaton"; return -1; }
+
+    // own values / canonical output state (Automaton.hs:367-380: values[s] = own ++ values[fallback s])
+    std::vector<uint32_t> canon(S, 0), vlen(ref.values_len, ref.values_len + S);
+    std::vector<uint8_t> owns(S, 0);
+    uint32_t max_needle_cps = 0;
+    for (uint32_t s : bfs) {
+        if (s == 0) { owns[0] = vlen[0] > 0; continue; }
+        if (depth[fallback[s]] >= depth[s]) { err = "fallback edge does not point to a shallower state"; return -1; }
+        if (vlen[s] < vlen[fallback[s]]) { err = "values_len is not consistent with the fallback chain"; return -1; }
+        owns[s] = vlen[s] > vlen[fallback[s]];
+        canon[s] = owns[s] ? s : canon[fallback[s]];
+        if (owns[s]) max_needle_cps = std::max(max_needle_cps, depth[s]);
+    }
+
+    ImageHeader h;
+    std::memset(&h, 0, sizeof(h));
+    h.magic = kImageMagic; h.version = kImageVersion; h.case_mode = (uint32_t)case_mode;
+    h.n_states = (uint32_t)S; h.max_needle_cps = max_needle_cps; h.root_vlen = vlen[0];
+    {
+        const uint64_t warm = 4ull * (max_needle_cps ? max_needle_cps : 1) + 4;
+        uint64_t chunk = 256;
+        while (chunk < 4 * warm && chunk < (1u << 20)) chunk <<= 1;
+        h.ac_chunk = (uint32_t)chunk;
+    }
+
+    Blob blob;
+    blob.reserve_section(sizeof(ImageHeader));
+
+    // ---- AC section: the reference's arrays verbatim
+    h.n_transitions = ref.n_transitions;
+    h.off_transitions = blob.reserve_section(ref.n_transitions * 8);
+    std::memcpy(blob.bytes.data() + h.off_transitions, ref.transitions, ref.n_transitions * 8);
+    h.off_offsets = blob.reserve_section((S + 1) * 4);
+    std::memcpy(blob.bytes.data() + h.off_offsets, ref.offsets, (S + 1) * 4);
+    h.off_root_ascii = blob.reserve_section(128 * 8);
+    std::memcpy(blob.bytes.data() + h.off_root_ascii, ref.root_ascii, 128 * 8);
+    h.off_canon = blob.put(canon);
+    h.off_vlen = blob.put(vlen);
+    if (ic) {
+        const uint32_t n_lower = (kLower[kNLower - 1].from + 256u) & ~255u;
+        std::vector<int32_t> delta(n_lower, 0);
+        for (size_t i = 0; i < kNLower; i++) delta[kLower[i].from] = (int32_t)kLower[i].to - (int32_t)kLower[i].from;
+        h.n_lower = n_lower;
+        h.off_lower = blob.put(delta);
+    } else {
+        h.n_lower = 0;
+        h.off_lower = blob.reserve_section(16);
+    }
+
+    // ---- SF section.  The empty needle (values on the root, reported after every successful goto,
+    // Automaton.hs:373-376,502-503) needs the true AC state, so such automata use the AC kernel.
+    h.sf_enabled = vlen[0] == 0 ? 1u : 0u;
+    std::vector<uint32_t> terminals;
+    for (size_t s = 1; s < S; s++) if (owns[s]) terminals.push_back((uint32_t)s);
+
+    std::vector<u32x4> nodes;
+    std::vector<u32x2> edges_out;
+    std::vector<TierEntry> tier_entries[4];
+
+    if (h.sf_enabled && !terminals.empty()) {
+        // reversed needles as code point strings: walking parent links yields c_n, c_(n-1), ..., c_1
+        std::vector<uint32_t> pool; std::vector<uint64_t> str_off(terminals.size() + 1, 0);
+        for (size_t k = 0; k < terminals.size(); k++) {
+            for (uint32_t s = terminals[k]; s != 0; s = parent[s]) pool.push_back(cp_in[s]);
+            str_off[k + 1] = pool.size();
+        }
+        std::vector<uint32_t> order(terminals.size());
+        for (size_t k = 0; k < order.size(); k++) order[k] = (uint32_t)k;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return std::lexicographical_compare(pool.begin() + str_off[a], pool.begin() + str_off[a + 1],
+                                                pool.begin() + str_off[b], pool.begin() + str_off[b + 1]);
+        });
+
+        // code-point trie of the reversed needles, nodes created in preorder
+        struct CpEdge { uint32_t src, cp, dst; };
+        std::vector<CpEdge> cp_edges;
+        std::vector<uint32_t> term_state(1, kNone);     // per cp-node: reference state or kNone
+        std::vector<uint32_t> path(1, 0);               // node ids along the previous string
+        const uint32_t* prev = nullptr; size_t prev_len = 0;
+        for (uint32_t k : order) {
+            const uint32_t* str = pool.data() + str_off[k]; const size_t len = (size_t)(str_off[k + 1] - str_off[k]);
+            size_t lcp = 0;
+            while (lcp < len && lcp < prev_len && str[lcp] == prev[lcp]) lcp++;
+            path.resize(lcp + 1);
+            for (size_t j = lcp; j < len; j++) {
+                const uint32_t id = (uint32_t)term_state.size();
+                term_state.push_back(kNone);
+                cp_edges.push_back({path.back(), str[j], id});
+                path.push_back(id);
+            }
+            term_state[path.back()] = terminals[k];
+            prev = str; prev_len = len;
+        }
+        const size_t n_cp_nodes = term_state.size();
+
+        // group cp edges by source (stable: children stay in ascending code point order)
+        std::vector<uint32_t> cp_first(n_cp_nodes + 1, 0);
+        for (const CpEdge& e : cp_edges) cp_first[e.src + 1]++;
+        for (size_t i = 0; i < n_cp_nodes; i++) cp_first[i + 1] += cp_first[i];
+        std::vector<CpEdge> cp_sorted(cp_edges.size());
+        { std::vector<uint32_t> cur(cp_first.begin(), cp_first.end() - 1);
+          for (const CpEdge& e : cp_edges) cp_sorted[cur[e.src]++] = e; }
+
+        // expand every code point edge into its (reversed, folded) UTF-8 variants
+        struct ByteEdge { uint32_t src, byte, dst; };
+        std::vector<ByteEdge> bedges; bedges.reserve(cp_edges.size() + cp_edges.size() / 4);
+        uint32_t n_byte_nodes = (uint32_t)n_cp_nodes;
+        std::unordered_map<uint32_t, std::vector<std::string>> variant_cache;
+        std::vector<ByteEdge> local;
+        for (size_t u = 0; u < n_cp_nodes; u++) {
+            local.clear();
+            for (uint32_t e = cp_first[u]; e < cp_first[u + 1]; e++) {
+                const uint32_t c = cp_sorted[e].cp, v = cp_sorted[e].dst;
+                auto it = variant_cache.find(c);
+                if (it == variant_cache.end()) { std::vector<std::string> vs; variants_of(c, ic, vs); it = variant_cache.emplace(c, std::move(vs)).first; }
+                for (const std::string& var : it->second) {
+                    uint32_t cur = (uint32_t)u;
+                    for (size_t j = var.size(); j-- > 1;) {            // last byte first; all but the lead byte
+                        const uint32_t b = (uint8_t)var[j];
+                        uint32_t next = kNone;
+                        for (const ByteEdge& le : local) if (le.src == cur && le.byte == b) { next = le.dst; break; }
+                        if (next == kNone) { next = n_byte_nodes++; local.push_back({cur, b, next}); bedges.push_back({cur, b, next}); }
+                        cur = next;
+                    }
+                    bedges.push_back({cur, (uint32_t)(uint8_t)var[0], v});
+                }
+            }
+        }
+        if (n_byte_nodes >= 0xFFFFFFF0u) { err = "automaton too large for 32-bit node ids"; return -1; }
+
+        // adjacency of the byte graph, children sorted by byte
+        std::vector<uint32_t> b_first(n_byte_nodes + 1, 0);
+        for (const ByteEdge& e : bedges) b_first[e.src + 1]++;
+        for (size_t i = 0; i < n_byte_nodes; i++) b_first[i + 1] += b_first[i];
+        std::vector<ByteEdge> b_sorted(bedges.size());
+        { std::vector<uint32_t> cur(b_first.begin(), b_first.end() - 1);
+          for (const ByteEdge& e : bedges) b_sorted[cur[e.src]++] = e; }
+        for (size_t i = 0; i < n_byte_nodes; i++)
+            std::sort(b_sorted.begin() + b_first[i], b_sorted.begin() + b_first[i + 1],
+                      [](const ByteEdge& a, const ByteEdge& b) { return a.byte < b.byte; });
+
+        // renumber in DFS preorder so that unary chains are consecutive records in HBM
+        std::vector<uint32_t> new_id(n_byte_nodes, kNone), stack;
+        uint32_t next_id = 0;
+        stack.push_back(0);
+        while (!stack.empty()) {
+            const uint32_t x = stack.back(); stack.pop_back();
+            if (new_id[x] != kNone) continue;
+            new_id[x] = next_id++;
+            for (uint32_t e = b_first[x + 1]; e-- > b_first[x];) if (new_id[b_sorted[e].dst] == kNone) stack.push_back(b_sorted[e].dst);
+        }
+        nodes.assign(next_id, u32x4{0, 0, 0, 0});
+        for (uint32_t x = 0; x < n_byte_nodes; x++) {
+            if (new_id[x] == kNone) continue;
+            u32x4& rec = nodes[new_id[x]];
+            if (x < n_cp_nodes && term_state[x] != kNone) { rec.x = term_state[x] + 1; rec.y = vlen[term_state[x]]; }
+            const uint32_t n = b_first[x + 1] - b_first[x];
+            if (n > 0xFFFF) { err = "node fan-out exceeds 65535"; return -1; }
+            if (n == 1) {
+                rec.z = new_id[b_sorted[b_first[x]].dst];
+                rec.w = 1u | (b_sorted[b_first[x]].byte << 24);
+            } else if (n > 1) {
+                rec.z = (uint32_t)edges_out.size();
+                rec.w = n;
+                for (uint32_t e = b_first[x]; e < b_first[x + 1]; e++) edges_out.push_back(u32x2{b_sorted[e].byte, new_id[b_sorted[e].dst]});
+            }
+        }
+
+        // suffix tables: every byte path of length <= 4 from the root
+        struct Frame { uint32_t node, depth, key; };
+        std::vector<Frame> fs; fs.push_back({0, 0, 0});
+        while (!fs.empty()) {
+            const Frame f = fs.back(); fs.pop_back();
+            for (uint32_t e = b_first[f.node]; e < b_first[f.node + 1]; e++) {
+                const uint32_t d = f.depth + 1, child = b_sorted[e].dst;
+                const uint32_t key = f.key | (b_sorted[e].byte << (32u - 8u * d));
+                if (d == 4) { tier_entries[3].push_back({key, new_id[child]}); continue; }
+                if (child < n_cp_nodes && term_state[child] != kNone) tier_entries[d - 1].push_back({key >> (8u * (4u - d)), new_id[child]});
+                fs.push_back({child, d, key});
+            }
+        }
+    }
+
+    h.sf_n_nodes = (uint32_t)nodes.size();
+    h.n_edges = edges_out.size();
+    h.sf_tiers = 0;
+    size_t total_keys = 0;
+    for (int t = 0; t < 4; t++) { if (!tier_entries[t].empty()) h.sf_tiers |= 1u << t; total_keys += tier_entries[t].size(); }
+    {
+        uint32_t lw = log2_ceil((total_keys * 16 + 31) / 32);
+        lw = std::max(8u, std::min(15u, lw));
+        h.sf_bloom_log2_words = lw;
+        std::vector<uint32_t> bloom((size_t)1 << lw, 0);
+        for (int t = 0; t < 4; t++)
+            for (const TierEntry& e : tier_entries[t]) { uint32_t word, mask; bloom_slot(e.key, (uint32_t)t + 1, lw, word, mask); bloom[word] |= mask; }
+        h.off_bloom = blob.put(bloom);
+    }
+    for (int t = 0; t < 4; t++) {
+        const uint32_t lc = std::max(4u, log2_ceil(tier_entries[t].size() * 2 + 1));
+        if (lc > 31) { err = "suffix table too large"; return -1; }
+        h.tier_log2_cap[t] = lc;
+        std::vector<u32x2> tab((size_t)1 << lc, u32x2{0, kNone});
+        const uint32_t cap_mask = (1u << lc) - 1;
+        for (const TierEntry& e : tier_entries[t]) {
+            uint32_t i = tier_slot(e.key, lc);
+            while (tab[i].y != kNone) {
+                if (tab[i].x == e.key) { err = "duplicate suffix key (internal error)"; return -1; }
+                i = (i + 1) & cap_mask;
+            }
+            tab[i] = u32x2{e.key, e.node};
+        }
+        h.off_tier[t] = blob.put(tab);
+    }
+    h.off_nodes = blob.put(nodes);
+    h.off_edges = blob.put(edges_out);
+    blob.reserve_section(16);      // tail padding
+    h.total_bytes = blob.bytes.size();
+    std::memcpy(blob.bytes.data(), &h, sizeof(h));
+    image.swap(blob.bytes);
+    return 0;
+}
+
+}  // namespace am

@@ -1,0 +1,342 @@
+// am_image.h -- layout of the flattened automaton image in HBM and the per-position walk
+// logic shared by the HIP kernels (am_kernels.hip) and the host-side image checker
+// (am_imgcheck.cpp, test-only).  Everything here is position-independent: the image is one
+// contiguous blob of byte offsets, so it can be broadcast between GPUs over RCCL as-is.
+//
+// Two structures live in one image (one image per case mode):
+//
+//  * "AC" section  -- the reference's own packed arrays (Automaton.hs:108-123: Word64
+//    transitions, Word32 offsets, 128-entry root table) plus canon[]/vlen[] and the simple
+//    lowercase table.  Walked by the general kernel (one lane per chunk, warm-up overlap).
+//
+//  * "SF" section  -- suffix-filter structures for the failureless fast path: a trie of the
+//    REVERSED needles over (case-folded) UTF-8 bytes, so one lane per END position walks
+//    backwards; a Bloom filter over the last 1..4 bytes that is staged into LDS; exact
+//    hash tables for those suffixes.  No failure links are needed (position parallelism
+//    replaces them), and case-insensitivity is baked into the byte edges, so the haystack is
+//    never re-encoded and match positions are original byte offsets by construction.
+//
+// Record semantics (both kernels): at most ONE record per end position -- (haystack,
+// end_pos, state) where `state` is the canonical reference state whose machineValues list is
+// exactly what the reference's collectMatches (Automaton.hs:522-534) would fold at that
+// position.  canon[s] = deepest state on s's fallback chain (s included) that owns values.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define AM_HD __host__ __device__ __forceinline__
+#else
+#define AM_HD inline
+#endif
+
+namespace am {
+
+constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
+constexpr uint32_t kImageVersion = 1;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
+constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
+constexpr uint32_t kSfChunk = 1024;             // bytes per wavefront step in the SF kernel (64 lanes x 16 B)
+
+struct ImageHeader {
+    uint32_t magic, version, case_mode, flags;
+    uint64_t total_bytes;
+    uint32_t n_states, max_needle_cps, root_vlen, ac_chunk;
+    // AC section (byte offsets from the image base)
+    uint64_t off_transitions, n_transitions;
+    uint64_t off_offsets;       // u32[n_states + 1]
+    uint64_t off_root_ascii;    // u64[128]
+    uint64_t off_canon;         // u32[n_states]
+    uint64_t off_vlen;          // u32[n_states] = length machineValues[s]
+    uint64_t off_lower;         // i32[n_lower]: lower(cp) = cp + delta[cp] for cp < n_lower
+    uint32_t n_lower, sf_enabled;
+    // SF section
+    uint32_t sf_tiers;          // bit t-1 set: some needle variant is exactly t bytes (t=1..3); bit 3: >= 4 bytes
+    uint32_t sf_bloom_log2_words;
+    uint32_t sf_n_nodes, sf_pad;
+    uint64_t off_bloom;         // u32[1 << sf_bloom_log2_words]
+    uint64_t off_tier[4];       // uint2{key, node}[1 << tier_log2_cap[t]]
+    uint32_t tier_log2_cap[4];
+    uint64_t off_nodes;         // uint4[sf_n_nodes]
+    uint64_t off_edges;         // uint2{byte, child}[n_edges]
+    uint64_t n_edges;
+    uint64_t reserved[4];
+};
+
+// Resolved pointers, passed to kernels by value (SGPRs).
+struct AcView {
+    const uint64_t* transitions;
+    const uint32_t* offsets;
+    const uint64_t* root_ascii;
+    const uint32_t* canon;
+    const uint32_t* vlen;
+    const int32_t* lower;
+    uint32_t n_lower, max_needle_cps, chunk, root_vlen;
+};
+
+struct alignas(8) u32x2 { uint32_t x, y; };
+struct alignas(16) u32x4 { uint32_t x, y, z, w; };
+
+struct SfView {
+    const uint32_t* bloom;
+    const u32x2* tier[4];
+    const u32x4* nodes;      // x = canonical state + 1 (0: not terminal), y = vlen, z = child | edge index, w = n_edges | byte << 24
+    const u32x2* edges;
+    uint32_t bloom_log2_words, tiers;
+    uint32_t tier_log2_cap[4];
+};
+
+struct BatchView {
+    const uint8_t* text;       // concatenated haystack bytes, 16-B aligned, readable up to round_up(total, 16)
+    const uint64_t* offsets;   // n_hay + 1
+    const uint32_t* hidx;      // (total >> 10) + 2 entries: haystack containing byte min(k << 10, total - 1)
+    uint64_t total;
+    uint32_t n_hay, pad;
+};
+
+inline AcView make_ac_view(const void* base, const ImageHeader& h)
+{
+    const uint8_t* b = (const uint8_t*)base;
+    AcView v;
+    v.transitions = (const uint64_t*)(b + h.off_transitions);
+    v.offsets = (const uint32_t*)(b + h.off_offsets);
+    v.root_ascii = (const uint64_t*)(b + h.off_root_ascii);
+    v.canon = (const uint32_t*)(b + h.off_canon);
+    v.vlen = (const uint32_t*)(b + h.off_vlen);
+    v.lower = (const int32_t*)(b + h.off_lower);
+    v.n_lower = h.n_lower; v.max_needle_cps = h.max_needle_cps; v.chunk = h.ac_chunk; v.root_vlen = h.root_vlen;
+    return v;
+}
+
+inline SfView make_sf_view(const void* base, const ImageHeader& h)
+{
+    const uint8_t* b = (const uint8_t*)base;
+    SfView v;
+    v.bloom = (const uint32_t*)(b + h.off_bloom);
+    for (int t = 0; t < 4; t++) { v.tier[t] = (const u32x2*)(b + h.off_tier[t]); v.tier_log2_cap[t] = h.tier_log2_cap[t]; }
+    v.nodes = (const u32x4*)(b + h.off_nodes);
+    v.edges = (const u32x2*)(b + h.off_edges);
+    v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers;
+    return v;
+}
+
+// ------------------------------------------------------------------ small helpers
+
+AM_HD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+
+// ASCII A-Z -> a-z on one byte.  Safe on raw UTF-8: bytes 0x41..0x5A only occur as ASCII.
+AM_HD uint32_t fold_byte(uint32_t b) { return (b - 0x41u < 26u) ? b + 0x20u : b; }
+
+// The same on four packed bytes (SWAR).
+AM_HD uint32_t fold_dword(uint32_t x)
+{
+    uint32_t hept = x & 0x7f7f7f7fu;
+    uint32_t ge_a = hept + 0x3f3f3f3fu;      // bit 7 set iff heptet >= 0x41
+    uint32_t gt_z = hept + 0x25252525u;      // bit 7 set iff heptet >  0x5A
+    uint32_t up = ge_a & ~gt_z & ~x & 0x80808080u;
+    return x | (up >> 2);
+}
+
+// Bloom probe for (tier, key): one 32-bit word, two bits in it.
+AM_HD void bloom_slot(uint32_t key, uint32_t tier, uint32_t log2_words, uint32_t& word, uint32_t& mask)
+{
+    uint32_t x = key + tier * 0x7F4A7C15u;
+    uint32_t lo = x * 0x9E3779B1u;
+    uint32_t hi = mulhi32(x, 0x9E3779B1u);
+    word = lo >> (32u - log2_words);
+    mask = (1u << (hi & 31u)) | (1u << ((hi >> 5) & 31u));
+}
+
+AM_HD uint32_t tier_slot(uint32_t key, uint32_t log2_cap) { return (key * 0x85EBCA6Bu) >> (32u - log2_cap); }
+
+// Exact suffix table lookup: open addressing, linear probing, empty = {*, kNone}.
+AM_HD uint32_t tier_lookup(const u32x2* tab, uint32_t log2_cap, uint32_t key)
+{
+    const uint32_t cap_mask = (1u << log2_cap) - 1u;
+    uint32_t i = tier_slot(key, log2_cap);
+    for (;;) {
+        u32x2 e = tab[i];
+        if (e.y == kNone) return kNone;
+        if (e.x == key) return e.y;
+        i = (i + 1u) & cap_mask;
+    }
+}
+
+// Largest h with offsets[h] <= pos (pos < total), bracketed by the 1-KiB haystack index.
+AM_HD uint32_t find_haystack(const BatchView& b, uint64_t pos)
+{
+    const uint64_t k = pos >> kHidxShift;
+    uint32_t lo = b.hidx[k], hi = b.hidx[k + 1];
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo + 1u) / 2u;
+        if (b.offsets[mid] <= pos) lo = mid; else hi = mid - 1u;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------ SF: verify one end position
+//
+// `gpos` = global index of the LAST byte of the candidate match, `avail` = bytes of its haystack up
+// to and including gpos.  Finds the deepest terminal of the reversed-needle trie along
+// text[gpos], text[gpos-1], ...  Returns true and (state, vlen) if any needle ends here.
+template <bool IC>
+AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
+{
+    // last up-to-4 bytes, newest byte in the top byte (same packing as the filter windows)
+    uint32_t w = 0;
+    const uint32_t n = avail < 4 ? (uint32_t)avail : 4u;
+    for (uint32_t j = 0; j < n; j++) {
+        uint32_t b = text[gpos - j];
+        if (IC) b = fold_byte(b);
+        w |= b << (24u - 8u * j);
+    }
+    uint32_t best = 0, best_vlen = 0;
+    if ((s.tiers & 8u) && avail >= 4) {
+        uint32_t node = tier_lookup(s.tier[3], s.tier_log2_cap[3], w);
+        uint64_t depth = 4;
+        while (node != kNone) {
+            const u32x4 rec = s.nodes[node];
+            if (rec.x) { best = rec.x; best_vlen = rec.y; }
+            if (depth == avail) break;
+            const uint32_t n_edges = rec.w & 0xFFFFu;
+            if (n_edges == 0) break;
+            uint32_t b = text[gpos - depth];
+            if (IC) b = fold_byte(b);
+            if (n_edges == 1) {
+                node = ((rec.w >> 24) == b) ? rec.z : kNone;
+            } else {
+                uint32_t lo = rec.z, hi = rec.z + n_edges;   // edges sorted by byte
+                node = kNone;
+                while (lo < hi) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    u32x2 e = s.edges[mid];
+                    if (e.x == b) { node = e.y; break; }
+                    if (e.x < b) lo = mid + 1; else hi = mid;
+                }
+            }
+            depth++;
+        }
+    }
+    if (!best) {
+        for (uint32_t t = 3; t >= 1; t--) {
+            if ((s.tiers & (1u << (t - 1))) && avail >= t) {
+                uint32_t node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w >> (8u * (4u - t)));
+                if (node != kNone) { const u32x4 rec = s.nodes[node]; best = rec.x; best_vlen = rec.y; break; }
+            }
+        }
+    }
+    if (!best) return false;
+    state = best - 1u; vlen = best_vlen;
+    return true;
+}
+
+// Bloom test of one window for every active tier; returns true if any tier may match.
+// `bloom` may point to LDS (device) or to the image (host checker).
+AM_HD bool sf_filter_window(const uint32_t* bloom, uint32_t log2_words, uint32_t tiers, uint32_t w)
+{
+    bool hit = false;
+    if (tiers & 8u) {
+        uint32_t word, mask; bloom_slot(w, 4, log2_words, word, mask);
+        hit = (bloom[word] & mask) == mask;
+    }
+    if (tiers & 7u) {
+        for (uint32_t t = 1; t <= 3; t++) {
+            if (tiers & (1u << (t - 1))) {
+                uint32_t word, mask; bloom_slot(w >> (8u * (4u - t)), t, log2_words, word, mask);
+                hit = hit || ((bloom[word] & mask) == mask);
+            }
+        }
+    }
+    return hit;
+}
+
+// ------------------------------------------------------------------ AC: the reference's state machine
+
+AM_HD uint32_t lower_cp(const AcView& a, uint32_t cp)
+{
+    // Utf8.hs:145-151 lowerCodePoint (ASCII fast path, else the simple-lowercase table)
+    if (cp < 128u) return fold_byte(cp);
+    return cp < a.n_lower ? (uint32_t)((int32_t)cp + a.lower[cp]) : cp;
+}
+
+// Automaton.hs:482-520 followCodePoint / lookupTransition / lookupRootAsciiTransition.
+// Returns true iff a goto edge was taken (then collectMatches applies to the new state).
+AM_HD bool ac_step(const AcView& a, uint32_t& state, uint32_t cp)
+{
+    for (;;) {
+        if (state == 0 && cp < 128u) {
+            const uint64_t t = a.root_ascii[cp];
+            if (t & kWildcard) return false;
+            state = (uint32_t)(t >> 32);
+            return true;
+        }
+        uint32_t i = a.offsets[state];
+        for (;;) {
+            const uint64_t t = a.transitions[i];
+            if (t & kWildcard) {
+                if (state == 0) return false;
+                state = (uint32_t)(t >> 32);
+                break;
+            }
+            if ((uint32_t)(t & 0x1fffffu) == cp) { state = (uint32_t)(t >> 32); return true; }
+            i++;
+        }
+    }
+}
+
+// One lane's unit of the general kernel: bytes [unit*chunk, (unit+1)*chunk) of the batch.  The lane
+// owns every match whose LAST byte lies in its chunk; it warms the state up from root over
+// >= max_needle_cps code points before the chunk (the AC state depends only on that much history),
+// clipped to the haystack start.  emit(haystack, end_pos_in_haystack, canon_state, vlen).
+template <bool IC, class Emit>
+AM_HD void ac_scan_unit(const AcView& a, const BatchView& b, uint64_t unit, Emit& emit)
+{
+    const uint64_t cs = unit * a.chunk;
+    if (cs >= b.total) return;
+    const uint64_t ce = (cs + a.chunk < b.total) ? cs + a.chunk : b.total;
+    uint32_t h = find_haystack(b, cs);
+    uint64_t hs = b.offsets[h], he = b.offsets[h + 1];
+    const uint64_t warm = 4ull * (a.max_needle_cps ? a.max_needle_cps : 1u) + 4ull;
+    uint64_t offset = (cs - hs > warm) ? cs - warm : hs;
+    if (offset > hs) while (offset < cs && (b.text[offset] & 0xC0u) == 0x80u) offset++;   // snap to a code point start
+    uint32_t state = 0;
+    while (offset < ce) {
+        if (offset >= he) {                       // next non-empty haystack starts here: fresh run
+            do { h++; hs = he; he = b.offsets[h + 1]; } while (he == hs);
+            state = 0;
+        }
+        // Utf8.hs:337-350 decodeN, reads guarded by the haystack end
+        const uint32_t cu0 = b.text[offset];
+        const uint32_t units = cu0 < 0xc0u ? 1u : cu0 < 0xe0u ? 2u : cu0 < 0xf0u ? 3u : 4u;
+        uint64_t nend = offset + units;
+        if (nend > he) nend = he;
+        if (nend > ce) break;                     // its last byte belongs to the next unit
+        uint32_t cp = cu0;
+        if (units > 1) {
+            const uint32_t cu1 = offset + 1 < he ? b.text[offset + 1] : 0u;
+            const uint32_t cu2 = (units > 2 && offset + 2 < he) ? b.text[offset + 2] : 0u;
+            const uint32_t cu3 = (units > 3 && offset + 3 < he) ? b.text[offset + 3] : 0u;
+            cp = units == 2 ? ((cu0 & 0x1fu) << 6) | (cu1 & 0x3fu)
+               : units == 3 ? ((cu0 & 0xfu) << 12) | ((cu1 & 0x3fu) << 6) | (cu2 & 0x3fu)
+                            : ((cu0 & 0x7u) << 18) | ((cu1 & 0x3fu) << 12) | ((cu2 & 0x3fu) << 6) | (cu3 & 0x3fu);
+        }
+        if (IC) cp = lower_cp(a, cp);
+        const bool collected = ac_step(a, state, cp);
+        offset = nend;
+        if (collected && nend > cs) {
+            const uint32_t v = a.vlen[state];
+            if (v) emit((uint32_t)h, nend - hs, a.canon[state], v);
+        }
+    }
+}
+
+}  // namespace am

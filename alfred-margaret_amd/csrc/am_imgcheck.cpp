@@ -1,0 +1,108 @@
+// am_imgcheck.cpp -- TEST-ONLY host interpreter of the device image (libam_imgcheck.so).
+//
+// Runs the very same per-position walk code the HIP kernels run (am_image.h) on the CPU, so the
+// flattener and the walk logic can be differential-tested against the oracle in the GPU-less
+// container.  It is NOT part of libam.so and no product entry point reaches it: the product has no
+// CPU execution path at all (am_abi.cpp fails with AM_ERR_NO_DEVICE without a GPU).
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "am_flatten.h"
+
+using namespace am;
+
+namespace {
+struct Rec { uint32_t hay; uint32_t state; uint64_t end_pos; uint32_t vlen; };
+struct Collect {
+    std::vector<Rec>* out;
+    void operator()(uint32_t hay, uint64_t end_pos, uint32_t state, uint32_t vlen) { out->push_back({hay, state, end_pos, vlen}); }
+};
+}  // namespace
+
+extern "C" {
+
+// Flatten only: returns image size (or -1) -- lets tests inspect the header.
+long long amchk_flatten(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
+                        const uint64_t* root_ascii, const uint32_t* values_len, int case_mode,
+                        uint8_t* image_out, size_t image_cap, char* err_out, size_t err_cap)
+{
+    std::vector<uint8_t> img; std::string err;
+    RefArrays ref{transitions, n_transitions, offsets, n_states, root_ascii, values_len};
+    if (flatten(ref, case_mode, img, err) != 0) {
+        if (err_out && err_cap) { std::strncpy(err_out, err.c_str(), err_cap - 1); err_out[err_cap - 1] = 0; }
+        return -1;
+    }
+    if (image_out && image_cap >= img.size()) std::memcpy(image_out, img.data(), img.size());
+    return (long long)img.size();
+}
+
+// Interpret an image over a batch.  which: 0 = AC walk (general kernel's logic), 1 = SF (filter +
+// verify, fast kernel's logic), 2 = SF without the Bloom filter (every position verified: separates
+// filter bugs from table bugs).  Fills up to cap records sorted by (haystack, end_pos); returns the
+// record count, or -2 if the image has no SF section (empty needle present).
+long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const uint64_t* offsets, uint32_t n_hay,
+                     uint32_t* hay_out, uint32_t* state_out, uint64_t* end_out, uint32_t* vlen_out, size_t cap)
+{
+    ImageHeader h; std::memcpy(&h, image, sizeof(h));
+    if (h.magic != kImageMagic) return -1;
+    const bool ic = h.case_mode == 1;
+    const uint64_t total = offsets[n_hay];
+    std::vector<Rec> recs;
+    if (total > 0) {
+        // padded private copy of the text, as the device batch guarantees
+        std::vector<uint8_t> padded((size_t)((total + 15) & ~15ull) + 16, 0);
+        std::memcpy(padded.data(), text, (size_t)total);
+        std::vector<uint32_t> hidx((size_t)(total >> kHidxShift) + 2);
+        for (size_t k = 0; k < hidx.size(); k++) {
+            uint64_t p = std::min<uint64_t>((uint64_t)k << kHidxShift, total - 1);
+            uint32_t lo = 0, hi = n_hay - 1;
+            while (lo < hi) { uint32_t mid = lo + (hi - lo + 1) / 2; if (offsets[mid] <= p) lo = mid; else hi = mid - 1; }
+            hidx[k] = lo;
+        }
+        BatchView b{padded.data(), offsets, hidx.data(), total, n_hay, 0};
+        if (which == 0) {
+            AcView a = make_ac_view(image, h);
+            Collect c{&recs};
+            const uint64_t units = (total + a.chunk - 1) / a.chunk;
+            for (uint64_t u = 0; u < units; u++) { if (ic) ac_scan_unit<true>(a, b, u, c); else ac_scan_unit<false>(a, b, u, c); }
+        } else {
+            if (!h.sf_enabled) return -2;
+            SfView s = make_sf_view(image, h);
+            if (s.tiers) {
+                for (uint64_t p = 0; p < total; p++) {
+                    // window of the 4 bytes ending at p, exactly as the kernel builds it from dwords
+                    uint32_t w = 0;
+                    for (uint32_t j = 0; j < 4; j++) {
+                        uint32_t byte = p >= j ? padded[(size_t)(p - j)] : 0u;
+                        w |= byte << (24u - 8u * j);
+                    }
+                    if (ic) w = fold_dword(w);
+                    if (which == 1 && !sf_filter_window(s.bloom, s.bloom_log2_words, s.tiers, w)) continue;
+                    const uint32_t hay = find_haystack(b, p);
+                    uint32_t state, vlen;
+                    const bool found = ic ? sf_verify<true>(s, padded.data(), p, p - offsets[hay] + 1, state, vlen)
+                                          : sf_verify<false>(s, padded.data(), p, p - offsets[hay] + 1, state, vlen);
+                    if (found) recs.push_back({hay, state, p - offsets[hay] + 1, vlen});
+                }
+            }
+        }
+    }
+    const size_t n = recs.size();
+    for (size_t i = 0; i < n && i < cap; i++) {
+        hay_out[i] = recs[i].hay; state_out[i] = recs[i].state; end_out[i] = recs[i].end_pos; vlen_out[i] = recs[i].vlen;
+    }
+    return (long long)n;
+}
+
+uint32_t amchk_simple_lower(uint32_t cp) { return simple_lower(cp); }
+
+size_t amchk_unlower(uint32_t cp, uint32_t* out, size_t cap)
+{
+    std::vector<uint32_t> v; unlower(cp, v);
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
+    return v.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,290 @@
+// am_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X / CDNA4), wave64.
+//
+//  k_sf   "suffix filter" fast path (failureless Aho-Corasick, end-position parallel):
+//         each wavefront streams 1 KiB of haystack per step with one coalesced 16 B load per lane,
+//         builds the 16 four-byte suffix windows per lane in registers (v_alignbyte), probes a Bloom
+//         filter of needle suffixes that lives in LDS (up to 128 KiB of the CU's 160 KiB), compacts
+//         the surviving positions into a per-wave LDS queue with a wave prefix sum, then verifies
+//         64 candidates at a time against the exact suffix tables + reversed-needle trie in HBM/L2.
+//         Match records are compacted with ballot + popcount into the unit's output slab.
+//  k_ac   general path: the reference's own packed automaton walked by one lane per chunk with a
+//         warm-up overlap (needed for automata containing the empty needle; also the A/B baseline).
+//  k_hidx 1-KiB haystack index (position -> haystack id bracket).
+//
+// No MFMA anywhere: this is integer pointer chasing; the roofline is HBM bandwidth
+// (1 B read per haystack byte + 16 B per record).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "am_device.h"
+
+namespace am {
+namespace dev {
+
+// ------------------------------------------------------------------ haystack index
+
+__global__ void k_hidx(const uint64_t* __restrict__ offsets, uint32_t n_hay, uint64_t total, uint32_t* __restrict__ hidx, uint64_t n_entries)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_entries) return;
+    uint64_t p = k << kHidxShift;
+    if (p > total - 1) p = total - 1;
+    uint32_t lo = 0, hi = n_hay - 1;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+        if (offsets[mid] <= p) lo = mid; else hi = mid - 1u;
+    }
+    hidx[k] = lo;
+}
+
+// ------------------------------------------------------------------ wave helpers (wave64)
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x, uint32_t lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
+    return x;   // valid in lane 0
+}
+
+// order LDS traffic between lanes of one wavefront (DS ops of a wave execute in issue order;
+// this only stops the compiler from moving them)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------ SF kernel
+
+constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
+constexpr int kSfWaves = kSfThreads / 64;
+constexpr int kSfQueue = kSfChunk;               // worst case: every position of the chunk is a candidate
+
+template <bool IC, int MODE>
+__global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t words = 1u << s.bloom_log2_words;
+    uint32_t* bloom = lds;
+    uint16_t* queues = reinterpret_cast<uint16_t*>(lds + words);
+
+    for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
+    __syncthreads();
+
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint16_t* q = queues + wave * kSfQueue;
+    const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
+    const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
+    uint64_t nval = 0;
+
+    for (uint64_t c = (uint64_t)blockIdx.x * kSfWaves + wave; c < n_chunks; c += n_waves) {
+        const uint64_t p0 = c * kSfChunk + lane * 16u;
+        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
+        if (p0 < b.total) {
+            const uint4 v = *reinterpret_cast<const uint4*>(b.text + p0);      // 1 KiB per wave instruction
+            d1 = v.x; d2 = v.y; d3 = v.z; d4 = v.w;
+            if (p0 >= 4) d0 = *reinterpret_cast<const uint32_t*>(b.text + p0 - 4);
+            if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+        }
+        const uint32_t d[5] = {d0, d1, d2, d3, d4};
+        uint32_t cand = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int j = k >> 2, sh = k & 3;      // window = bytes k-3..k of the lane's 16, newest byte on top
+            const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
+            if (sf_filter_window(bloom, log2_words, tiers, w)) cand |= 1u << k;
+        }
+        if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
+
+        // compact candidate positions into the wave's LDS queue, in position order
+        const uint32_t n = __popc(cand);
+        const uint32_t incl = wave_inclusive_sum(n, lane);
+        const uint32_t n_cand = __shfl(incl, 63, 64);
+        uint32_t idx = incl - n;
+        while (cand) {
+            const uint32_t k = __builtin_ctz(cand);
+            cand &= cand - 1u;
+            q[idx++] = (uint16_t)(lane * 16u + k);
+        }
+        wave_lds_fence();
+
+        uint32_t nrec = 0;
+        const uint64_t out_base = MODE == kModeEmit ? o.unit_offsets[c] : 0;
+        for (uint32_t base = 0; base < n_cand; base += 64) {
+            bool found = false;
+            uint32_t state = 0, vlen = 0, hay = 0;
+            uint64_t end_pos = 0;
+            if (base + lane < n_cand) {
+                const uint64_t gpos = c * kSfChunk + q[base + lane];
+                hay = find_haystack(b, gpos);
+                end_pos = gpos - b.offsets[hay] + 1;
+                found = sf_verify<IC>(s, b.text, gpos, end_pos, state, vlen);
+            }
+            const uint64_t ballot = __ballot(found);
+            if (found) {
+                if (MODE == kModeCount) {
+                    nval += vlen;
+                    if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
+                } else if (MODE == kModeEmit) {
+                    const uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
+                    o.records[out_base + nrec + rank] = Record{end_pos, hay, state};
+                } else {
+                    o.flags[hay] = 1;
+                }
+            }
+            nrec += (uint32_t)__popcll(ballot);
+        }
+        if (MODE == kModeCount && lane == 0) o.unit_counts[c] = nrec;
+        wave_lds_fence();      // the queue is rewritten by the next chunk
+    }
+    if (MODE == kModeCount) {
+        nval = wave_sum_u64(nval);
+        if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+    }
+}
+
+// ------------------------------------------------------------------ AC kernel
+
+struct EmitCount {
+    uint32_t nrec; uint64_t nval; uint64_t* hay_counts;
+    __device__ __forceinline__ void operator()(uint32_t hay, uint64_t, uint32_t, uint32_t vlen)
+    {
+        nrec++; nval += vlen;
+        if (hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(hay_counts + hay), (unsigned long long)vlen);
+    }
+};
+struct EmitWrite {
+    Record* out;
+    __device__ __forceinline__ void operator()(uint32_t hay, uint64_t end_pos, uint32_t state, uint32_t) { *out++ = Record{end_pos, hay, state}; }
+};
+struct EmitFlag {
+    uint8_t* flags;
+    __device__ __forceinline__ void operator()(uint32_t hay, uint64_t, uint32_t, uint32_t) { flags[hay] = 1; }
+};
+
+template <bool IC, int MODE>
+__global__ __launch_bounds__(256) void k_ac(AcView a, BatchView b, ScanOut o, uint64_t n_units)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t nval = 0;
+    if (u < n_units) {
+        if (MODE == kModeCount) {
+            EmitCount e{0, 0, o.hay_counts};
+            ac_scan_unit<IC>(a, b, u, e);
+            o.unit_counts[u] = e.nrec;
+            nval = e.nval;
+        } else if (MODE == kModeEmit) {
+            EmitWrite e{o.records + o.unit_offsets[u]};
+            ac_scan_unit<IC>(a, b, u, e);
+        } else {
+            EmitFlag e{o.flags};
+            ac_scan_unit<IC>(a, b, u, e);
+        }
+    }
+    if (MODE == kModeCount) {
+        nval = wave_sum_u64(nval);
+        if (lane_id() == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+
+hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st)
+{
+    const uint32_t blocks = (uint32_t)((n_entries + 255) / 256);
+    hipLaunchKernelGGL(k_hidx, dim3(blocks), dim3(256), 0, st, b.offsets, b.n_hay, b.total, hidx, n_entries);
+    return hipGetLastError();
+}
+
+uint64_t sf_units(const BatchView& b) { return (b.total + kSfChunk - 1) / kSfChunk; }
+uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
+
+size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * kSfQueue * sizeof(uint16_t); }
+
+template <bool IC, int MODE>
+static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+{
+    const size_t lds = sf_lds_bytes(s);
+    static bool attr_set = false;     // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint64_t n_chunks = sf_units(b);
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    uint64_t blocks = (uint64_t)n_cu * per_cu;
+    const uint64_t need = (n_chunks + kSfWaves - 1) / kSfWaves;
+    if (blocks > need) blocks = need;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_sf<IC, MODE>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
+    return hipGetLastError();
+}
+
+hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+{
+    if (ic) {
+        if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);
+        if (mode == kModeEmit) return launch_sf_t<true, kModeEmit>(s, b, o, n_cu, st);
+        return launch_sf_t<true, kModeAny>(s, b, o, n_cu, st);
+    }
+    if (mode == kModeCount) return launch_sf_t<false, kModeCount>(s, b, o, n_cu, st);
+    if (mode == kModeEmit) return launch_sf_t<false, kModeEmit>(s, b, o, n_cu, st);
+    return launch_sf_t<false, kModeAny>(s, b, o, n_cu, st);
+}
+
+template <bool IC, int MODE>
+static hipError_t launch_ac_t(const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st)
+{
+    const uint64_t n_units = ac_units(a, b);
+    if (n_units == 0) return hipSuccess;
+    const uint64_t blocks = (n_units + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_ac<IC, MODE>), dim3((uint32_t)blocks), dim3(256), 0, st, a, b, o, n_units);
+    return hipGetLastError();
+}
+
+hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st)
+{
+    if (ic) {
+        if (mode == kModeCount) return launch_ac_t<true, kModeCount>(a, b, o, st);
+        if (mode == kModeEmit) return launch_ac_t<true, kModeEmit>(a, b, o, st);
+        return launch_ac_t<true, kModeAny>(a, b, o, st);
+    }
+    if (mode == kModeCount) return launch_ac_t<false, kModeCount>(a, b, o, st);
+    if (mode == kModeEmit) return launch_ac_t<false, kModeEmit>(a, b, o, st);
+    return launch_ac_t<false, kModeAny>(a, b, o, st);
+}
+
+// exclusive prefix sum of n u32 counts into n u64 offsets (n includes the trailing zero pad, so
+// offsets[n-1] is the total)
+struct CastU64 { __host__ __device__ uint64_t operator()(uint32_t x) const { return x; } };
+
+hipError_t scan_temp_bytes(uint64_t n, size_t* bytes)
+{
+    hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> in((const uint32_t*)nullptr, CastU64());
+    *bytes = 0;
+    return hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, in, (uint64_t*)nullptr, (int)n, (hipStream_t)0);
+}
+
+hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st)
+{
+    hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> in(counts, CastU64());
+    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, offsets, (int)n, st);
+}
+
+}  // namespace dev
+}  // namespace am

@@ -1,0 +1,215 @@
+// automaton.hpp -- host mirror of Data.Text.AhoCorasick.Automaton (reference:
+// src/Data/Text/AhoCorasick/Automaton.hs).  Same names, same argument meaning:
+//   build        :176-200   needles with values -> AcMachine (packed exactly like the reference)
+//   runWithCase  :442-534   strict left fold over matches with early exit (Next = Done | Step)
+//   runText/runLower :539-553
+// The only difference from the reference is WHERE the body of runWithCase executes: the match
+// positions come from libam (HIP kernels on the MI355X) through the C ABI in include/am.h, and the
+// fold function is applied on the host to the returned records, in the reference's order.
+// There is no host matching loop in this file.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "am.h"
+#include "utf8.hpp"
+
+namespace alfred_margaret {
+
+using utf8::Text;
+
+enum class CaseSensitivity { CaseSensitive = AM_CASE_SENSITIVE, IgnoreCase = AM_IGNORE_CASE };   // CaseSensitivity.hs:14-22
+
+using CodeUnitIndex = size_t;   // Utf8.hs:106-114
+
+template <class V> struct Match { CodeUnitIndex matchPos; const V& matchValue; };   // Automaton.hs:98-105
+
+template <class A> struct Next {   // Automaton.hs:398
+    bool done; A value;
+    static Next Done(A a) { return Next{true, std::move(a)}; }
+    static Next Step(A a) { return Next{false, std::move(a)}; }
+};
+
+struct AmError : std::runtime_error {
+    int code;
+    AmError(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+inline void amCheck(int rc) { if (rc != AM_OK) throw AmError(rc, std::string("libam: ") + am_last_error()); }
+
+namespace detail {
+
+constexpr uint64_t kWildcard = 0x200000ull;   // Automaton.hs:130-131
+
+// The packed automaton without the values (Automaton.hs:108-123) + which needles end where.
+struct Packed {
+    std::vector<uint64_t> transitions;       // machineTransitions
+    std::vector<uint32_t> offsets;           // machineOffsets (numStates + 1)
+    std::vector<uint64_t> rootAscii;         // machineRootAsciiTransitions (128)
+    std::vector<std::vector<uint32_t>> valueIdx;   // per state: needle indices in report order
+};
+
+// Automaton.hs:176-200 build and its helpers (:249-292, :336-362, :367-380, :166-172, :301-306).
+// State ids are allocated in needle order, depth first along each needle, exactly as the reference.
+inline Packed buildPacked(const std::vector<Text>& needles)
+{
+    struct StateTmp { std::vector<std::pair<uint32_t, uint32_t>> kids; };   // (code point, next), unsorted
+    std::vector<StateTmp> st(1);
+    std::unordered_map<uint64_t, uint32_t> edge;    // (state << 21 | cp) -> next
+    edge.reserve(needles.size() * 8);
+    std::vector<std::vector<uint32_t>> own(1);
+    for (size_t i = 0; i < needles.size(); i++) {
+        const uint8_t* d = needles[i].begin(); const size_t n = needles[i].len;
+        uint32_t s = 0;
+        for (size_t k = 0; k < n;) {
+            size_t u; const uint32_t cp = utf8::decodeAt(d, k, n, u);
+            const uint64_t key = ((uint64_t)s << 21) | cp;
+            auto it = edge.find(key);
+            if (it != edge.end()) s = it->second;
+            else {
+                const uint32_t nx = (uint32_t)st.size();
+                st.emplace_back(); own.emplace_back();
+                st[s].kids.emplace_back(cp, nx);
+                edge.emplace(key, nx);
+                s = nx;
+            }
+            k += u;
+        }
+        own[s].insert(own[s].begin(), (uint32_t)i);      // insertWith (++): newest first (:263)
+    }
+    const size_t S = st.size();
+    for (auto& x : st) std::sort(x.kids.begin(), x.kids.end());
+    auto findKid = [&](uint32_t s, uint32_t cp) -> int64_t {
+        auto it = edge.find(((uint64_t)s << 21) | cp);
+        return it == edge.end() ? -1 : (int64_t)it->second;
+    };
+    // level order: fallbacks (:336-362) and values (:367-380) only look at shallower states
+    std::vector<uint32_t> order; order.reserve(S); order.push_back(0);
+    std::vector<uint32_t> fallback(S, 0);
+    Packed p;
+    p.valueIdx.resize(S);
+    p.valueIdx[0] = own[0];
+    for (size_t q = 0; q < order.size(); q++) {
+        const uint32_t s = order[q];
+        for (auto& kid : st[s].kids) {
+            const uint32_t cp = kid.first, nx = kid.second;
+            uint32_t fb = 0;
+            for (uint32_t t = s; t != 0;) {               // getFallback (:342-352)
+                const uint32_t f = fallback[t];
+                const int64_t j = findKid(f, cp);
+                if (j >= 0) { fb = (uint32_t)j; break; }
+                t = f;
+            }
+            fallback[nx] = fb;
+            p.valueIdx[nx] = own[nx];
+            p.valueIdx[nx].insert(p.valueIdx[nx].end(), p.valueIdx[fb].begin(), p.valueIdx[fb].end());
+            order.push_back(nx);
+        }
+    }
+    // makeTransitions + packTransitions (:190-192, :166-172): descending code point, wildcard last
+    p.offsets.resize(S + 1);
+    size_t total = 0;
+    for (size_t s = 0; s < S; s++) total += st[s].kids.size() + 1;
+    p.transitions.reserve(total);
+    for (size_t s = 0; s < S; s++) {
+        p.offsets[s] = (uint32_t)p.transitions.size();
+        for (size_t k = st[s].kids.size(); k-- > 0;) p.transitions.push_back(((uint64_t)st[s].kids[k].second << 32) | st[s].kids[k].first);
+        p.transitions.push_back(((uint64_t)fallback[s] << 32) | kWildcard);
+    }
+    p.offsets[S] = (uint32_t)p.transitions.size();
+    p.rootAscii.assign(128, kWildcard);                    // wildcard -> state 0 (:301-306)
+    for (auto& kid : st[0].kids) if (kid.first < 128) p.rootAscii[kid.first] = ((uint64_t)kid.second << 32) | kid.first;
+    return p;
+}
+
+struct AutomatonDeleter { void operator()(am_automaton* a) const { am_automaton_destroy(a); } };
+
+}  // namespace detail
+
+// Automaton.hs:108-123 AcMachine v
+template <class V> struct AcMachine {
+    std::vector<std::vector<V>> machineValues;
+    std::vector<uint64_t> machineTransitions;
+    std::vector<uint32_t> machineOffsets;
+    std::vector<uint64_t> machineRootAsciiTransitions;
+    std::shared_ptr<am_automaton> device;     // flattened copy in HBM, owned by libam
+
+    size_t numStates() const { return machineValues.size(); }
+};
+
+// Automaton.hs:176  build :: [(Text, v)] -> AcMachine v
+template <class V> AcMachine<V> build(const std::vector<std::pair<Text, V>>& needlesWithValues)
+{
+    std::vector<Text> needles; needles.reserve(needlesWithValues.size());
+    for (auto& nv : needlesWithValues) needles.push_back(nv.first);
+    detail::Packed p = detail::buildPacked(needles);
+    AcMachine<V> m;
+    m.machineValues.resize(p.valueIdx.size());
+    std::vector<uint32_t> valuesLen(p.valueIdx.size());
+    for (size_t s = 0; s < p.valueIdx.size(); s++) {
+        valuesLen[s] = (uint32_t)p.valueIdx[s].size();
+        m.machineValues[s].reserve(p.valueIdx[s].size());
+        for (uint32_t i : p.valueIdx[s]) m.machineValues[s].push_back(needlesWithValues[i].second);
+    }
+    m.machineTransitions = std::move(p.transitions);
+    m.machineOffsets = std::move(p.offsets);
+    m.machineRootAsciiTransitions = std::move(p.rootAscii);
+    am_automaton* a = nullptr;
+    amCheck(am_automaton_create(m.machineTransitions.data(), m.machineTransitions.size(), m.machineOffsets.data(), m.numStates(),
+                                m.machineRootAsciiTransitions.data(), valuesLen.data(), &a));
+    m.device.reset(a, detail::AutomatonDeleter());
+    return m;
+}
+
+// Fold the records of ONE haystack in the reference's order; returns false after a Done.
+template <class A, class V, class F>
+bool foldRecords(A& acc, F& f, const AcMachine<V>& machine, const am_match* recs, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; i++) {
+        for (const V& v : machine.machineValues[recs[i].state]) {           // collectMatches (:522-534)
+            Next<A> nx = f(std::move(acc), Match<V>{(CodeUnitIndex)recs[i].end_pos, v});
+            acc = std::move(nx.value);
+            if (nx.done) return false;
+        }
+    }
+    return true;
+}
+
+// Automaton.hs:442-534 runWithCase, for a batch of independent haystacks (one fold per haystack).
+template <class A, class V, class F>
+std::vector<A> runBatchWithCase(CaseSensitivity cs, const A& seed, F f, const AcMachine<V>& machine, const std::vector<Text>& texts)
+{
+    std::vector<am_slice> slices(texts.size());
+    for (size_t i = 0; i < texts.size(); i++) slices[i] = am_slice{texts[i].data, texts[i].off, texts[i].len};
+    am_matches* ms = nullptr;
+    amCheck(am_run(machine.device.get(), (int)cs, slices.data(), slices.size(), &ms));
+    std::unique_ptr<am_matches, void (*)(am_matches*)> guard(ms, am_matches_free);
+    const uint64_t n = am_matches_size(ms);
+    const am_match* recs = am_matches_data(ms);
+    if (n && !recs) throw AmError(AM_ERR_HIP, am_last_error());
+    std::vector<A> out(texts.size(), seed);
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && recs[j].haystack == recs[i].haystack) j++;
+        foldRecords(out[recs[i].haystack], f, machine, recs + i, j - i);
+        i = j;
+    }
+    return out;
+}
+
+// Automaton.hs:443 runWithCase :: CaseSensitivity -> a -> (a -> Match v -> Next a) -> AcMachine v -> Text -> a
+template <class A, class V, class F>
+A runWithCase(CaseSensitivity cs, A seed, F f, const AcMachine<V>& machine, const Text& text)
+{
+    return std::move(runBatchWithCase(cs, seed, f, machine, std::vector<Text>{text})[0]);
+}
+
+template <class A, class V, class F> A runText(A seed, F f, const AcMachine<V>& m, const Text& t) { return runWithCase(CaseSensitivity::CaseSensitive, std::move(seed), f, m, t); }   // :539-541
+template <class A, class V, class F> A runLower(A seed, F f, const AcMachine<V>& m, const Text& t) { return runWithCase(CaseSensitivity::IgnoreCase, std::move(seed), f, m, t); }     // :551-553
+
+}  // namespace alfred_margaret

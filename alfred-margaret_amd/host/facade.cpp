@@ -1,0 +1,145 @@
+// facade.cpp -- flat C entry points over the C++ host mirror (automaton.hpp / searcher.hpp /
+// replacer.hpp) so that Python (ctypes) tests and bench.py can drive it.  Values are uint32 handles.
+#include <cstring>
+#include <string>
+
+#include "replacer.hpp"
+
+using namespace alfred_margaret;
+
+namespace {
+thread_local std::string g_err;
+struct MachineBox {
+    AcMachine<uint32_t> m;
+    std::vector<uint64_t> valuesOff; std::vector<uint32_t> valuesFlat;   // flattened machineValues for inspection
+};
+std::vector<Text> sliceTexts(const am_slice* hay, size_t n)
+{
+    std::vector<Text> t(n);
+    for (size_t i = 0; i < n; i++) t[i] = Text(hay[i].ptr, hay[i].off, hay[i].len);
+    return t;
+}
+template <class Fn> int guarded(Fn fn)
+{
+    try { fn(); return 0; }
+    catch (const AmError& e) { g_err = e.what(); return e.code; }
+    catch (const std::exception& e) { g_err = e.what(); return AM_ERR_INVALID; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* amh_last_error(void) { return g_err.c_str(); }
+
+// Automaton.build; values[i] (or i when values == NULL) is the payload handle of needle i
+int amh_build(const uint8_t* bytes, const uint64_t* offs, size_t n, const uint32_t* values, void** out)
+{
+    *out = nullptr;
+    return guarded([&] {
+        std::vector<std::pair<Text, uint32_t>> nv(n);
+        for (size_t i = 0; i < n; i++) nv[i] = {Text(bytes, (size_t)offs[i], (size_t)(offs[i + 1] - offs[i])), values ? values[i] : (uint32_t)i};
+        auto* box = new MachineBox{build(nv), {}, {}};
+        box->valuesOff.assign(1, 0);
+        for (auto& vs : box->m.machineValues) { box->valuesFlat.insert(box->valuesFlat.end(), vs.begin(), vs.end()); box->valuesOff.push_back(box->valuesFlat.size()); }
+        *out = box;
+    });
+}
+void amh_free(void* h) { delete static_cast<MachineBox*>(h); }
+size_t amh_num_states(void* h) { return static_cast<MachineBox*>(h)->m.numStates(); }
+size_t amh_num_transitions(void* h) { return static_cast<MachineBox*>(h)->m.machineTransitions.size(); }
+const uint64_t* amh_transitions(void* h) { return static_cast<MachineBox*>(h)->m.machineTransitions.data(); }
+const uint32_t* amh_offsets(void* h) { return static_cast<MachineBox*>(h)->m.machineOffsets.data(); }
+const uint64_t* amh_root_ascii(void* h) { return static_cast<MachineBox*>(h)->m.machineRootAsciiTransitions.data(); }
+const uint64_t* amh_values_off(void* h) { return static_cast<MachineBox*>(h)->valuesOff.data(); }
+const uint32_t* amh_values(void* h) { return static_cast<MachineBox*>(h)->valuesFlat.data(); }
+am_automaton* amh_device(void* h) { return static_cast<MachineBox*>(h)->m.device.get(); }
+
+// runWithCase with a list-building fold over a batch: triples (haystack, matchPos, value) in fold
+// order.  Call with cap = 0 to get the count.
+int amh_run_list(void* h, int case_mode, const am_slice* hay, size_t n_hay, uint32_t* hay_out, uint64_t* pos_out, uint32_t* val_out,
+                 uint64_t cap, uint64_t* n_out)
+{
+    return guarded([&] {
+        struct Acc { std::vector<std::pair<uint64_t, uint32_t>> v; };
+        auto f = [](Acc a, const Match<uint32_t>& m) { a.v.emplace_back(m.matchPos, m.matchValue); return Next<Acc>::Step(std::move(a)); };
+        auto accs = runBatchWithCase((CaseSensitivity)case_mode, Acc{}, f, static_cast<MachineBox*>(h)->m, sliceTexts(hay, n_hay));
+        uint64_t k = 0;
+        for (size_t i = 0; i < accs.size(); i++)
+            for (auto& pv : accs[i].v) { if (k < cap) { hay_out[k] = (uint32_t)i; pos_out[k] = pv.first; val_out[k] = pv.second; } k++; }
+        *n_out = k;
+    });
+}
+
+// countMatches (benchmark/haskell/app/Main.hs:67-76) per haystack
+int amh_count(void* h, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out)
+{
+    return guarded([&] { amCheck(am_count(static_cast<MachineBox*>(h)->m.device.get(), case_mode, hay, n_hay, counts_out)); });
+}
+
+// ---- Searcher
+int amh_searcher_build(int case_mode, const uint8_t* bytes, const uint64_t* offs, size_t n, void** out)
+{
+    *out = nullptr;
+    return guarded([&] {
+        std::vector<std::string> ns(n);
+        for (size_t i = 0; i < n; i++) ns[i].assign((const char*)bytes + offs[i], (size_t)(offs[i + 1] - offs[i]));
+        *out = new Searcher<int>(buildNeedleIdSearcher((CaseSensitivity)case_mode, ns));
+    });
+}
+void amh_searcher_free(void* s) { delete static_cast<Searcher<int>*>(s); }
+void amh_searcher_set_case(void* s, int case_mode) { static_cast<Searcher<int>*>(s)->setCaseSensitivity((CaseSensitivity)case_mode); }
+int amh_searcher_contains_any(void* s, const am_slice* hay, size_t n_hay, uint8_t* out)
+{
+    return guarded([&] { auto r = containsAnyBatch(*static_cast<Searcher<int>*>(s), sliceTexts(hay, n_hay)); for (size_t i = 0; i < n_hay; i++) out[i] = r[i]; });
+}
+int amh_searcher_contains_all(void* s, const am_slice* hay, size_t n_hay, uint8_t* out)
+{
+    return guarded([&] { auto r = containsAllBatch(*static_cast<Searcher<int>*>(s), sliceTexts(hay, n_hay)); for (size_t i = 0; i < n_hay; i++) out[i] = r[i]; });
+}
+
+// ---- Replacer
+int amh_replacer_build(int case_mode, const uint8_t* nbytes, const uint64_t* noffs, const uint8_t* rbytes, const uint64_t* roffs, size_t n, void** out)
+{
+    *out = nullptr;
+    return guarded([&] {
+        std::vector<std::pair<std::string, std::string>> pairs(n);
+        for (size_t i = 0; i < n; i++) {
+            pairs[i].first.assign((const char*)nbytes + noffs[i], (size_t)(noffs[i + 1] - noffs[i]));
+            pairs[i].second.assign((const char*)rbytes + roffs[i], (size_t)(roffs[i + 1] - roffs[i]));
+        }
+        *out = new Replacer((CaseSensitivity)case_mode, pairs);
+    });
+}
+void amh_replacer_free(void* r) { delete static_cast<Replacer*>(r); }
+// Runs a batch; results are returned as one malloc'd blob + offsets (n+1); is_nothing[i] = 1 where the
+// reference returns Nothing.  max_len < 0 = maxBound.
+int amh_replacer_run_batch(void* r, const am_slice* hay, size_t n_hay, long long max_len, uint8_t** blob_out, uint64_t* offs_out, uint8_t* is_nothing)
+{
+    *blob_out = nullptr;
+    return guarded([&] {
+        std::vector<std::string> in(n_hay);
+        for (size_t i = 0; i < n_hay; i++) in[i].assign((const char*)hay[i].ptr + hay[i].off, hay[i].len);
+        auto res = static_cast<Replacer*>(r)->runBatchWithLimit(in, max_len < 0 ? SIZE_MAX : (size_t)max_len);
+        uint64_t total = 0;
+        for (size_t i = 0; i < n_hay; i++) { offs_out[i] = total; is_nothing[i] = !res[i].has_value(); if (res[i]) total += res[i]->size(); }
+        offs_out[n_hay] = total;
+        uint8_t* blob = (uint8_t*)malloc(total ? total : 1);
+        for (size_t i = 0; i < n_hay; i++) if (res[i] && !res[i]->empty()) std::memcpy(blob + offs_out[i], res[i]->data(), res[i]->size());
+        *blob_out = blob;
+    });
+}
+void amh_free_blob(uint8_t* p) { free(p); }
+
+// ---- Utf8 helpers
+int64_t amh_skip_code_points_backwards(const uint8_t* d, size_t len, size_t index, size_t n)
+{
+    try { return (int64_t)utf8::skipCodePointsBackwards(Text(d, 0, len), index, n); } catch (...) { return -1; }
+}
+size_t amh_lower_utf8(const uint8_t* d, size_t len, uint8_t* out, size_t cap)
+{
+    std::string s = utf8::lowerUtf8(Text(d, 0, len));
+    if (s.size() <= cap) std::memcpy(out, s.data(), s.size());
+    return s.size();
+}
+
+}  // extern "C"

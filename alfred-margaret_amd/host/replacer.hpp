@@ -1,0 +1,139 @@
+// replacer.hpp -- host mirror of Data.Text.AhoCorasick.Replacer (reference:
+// src/Data/Text/AhoCorasick/Replacer.hs): sequential multi-needle replace with priorities.
+//   Payload :59-70, build :97-116, compose :120-133, run :200-201, runWithLimit :203-274,
+//   removeOverlap :191-198, replace :163-180, replacementLength :183-187.
+// Each pass = one full scan of the (rewritten) haystacks on the GPU through libam (am_run on the
+// whole batch of still-active haystacks); priority filtering, sort, overlap removal and the
+// splice stay on the host, as in BASELINE config 5.
+#pragma once
+#include <climits>
+#include <optional>
+
+#include "searcher.hpp"
+
+namespace alfred_margaret {
+
+struct Payload {                        // Replacer.hs:59-70
+    long long needlePriority;
+    size_t needleLengthBytes;
+    size_t needleLengthCodePoints;
+    std::string needleReplacement;
+};
+
+class Replacer {
+public:
+    // Replacer.hs:97-116 build: needle i has priority -i; IgnoreCase lower-cases the needle, the
+    // payload lengths are those of the ORIGINAL needle.
+    Replacer(CaseSensitivity cs, const std::vector<std::pair<std::string, std::string>>& replaces)
+        : searcher_(cs, mapNeedles(cs, replaces)) {}
+
+    CaseSensitivity caseSensitivity() const { return searcher_.caseSensitivity(); }
+    const Searcher<Payload>& searcher() const { return searcher_; }
+
+    // Replacer.hs:120-133 compose (same case sensitivity required)
+    static std::optional<Replacer> compose(const Replacer& a, const Replacer& b)
+    {
+        if (a.caseSensitivity() != b.caseSensitivity()) return std::nullopt;
+        std::vector<std::pair<std::string, Payload>> ns = a.searcher_.needles();
+        ns.insert(ns.end(), b.searcher_.needles().begin(), b.searcher_.needles().end());
+        for (size_t i = 0; i < ns.size(); i++) ns[i].second.needlePriority = -(long long)i;
+        return Replacer(Searcher<Payload>(a.caseSensitivity(), std::move(ns)));
+    }
+
+    // Replacer.hs:203-274 runWithLimit on a batch; nullopt where the reference returns Nothing.
+    std::vector<std::optional<std::string>> runBatchWithLimit(const std::vector<std::string>& inputs, size_t maxLength) const
+    {
+        struct RMatch { size_t pos, len; const std::string* repl; };                       // Replacer.hs:159
+        const bool ic = caseSensitivity() == CaseSensitivity::IgnoreCase;
+        const long long minPriority = 1 - (long long)searcher_.numNeedles();               // :217
+        std::vector<std::optional<std::string>> cur(inputs.begin(), inputs.end());
+        std::vector<long long> threshold(inputs.size(), 1);                                // :211
+        std::vector<size_t> active(inputs.size());
+        for (size_t i = 0; i < active.size(); i++) active[i] = i;
+        struct Acc { long long pBest; std::vector<RMatch> matches; const std::string* hay; long long threshold; };
+        while (!active.empty()) {
+            std::vector<Text> texts; texts.reserve(active.size());
+            for (size_t i : active) texts.emplace_back(*cur[i]);
+            // one GPU scan of every active haystack; the fold below is prependMatch (:252-260)
+            std::vector<am_slice> slices(texts.size());
+            for (size_t k = 0; k < texts.size(); k++) slices[k] = am_slice{texts[k].data, texts[k].off, texts[k].len};
+            am_matches* ms = nullptr;
+            amCheck(am_run(searcher_.automaton().device.get(), (int)caseSensitivity(), slices.data(), slices.size(), &ms));
+            std::unique_ptr<am_matches, void (*)(am_matches*)> guard(ms, am_matches_free);
+            const uint64_t n = am_matches_size(ms);
+            const am_match* recs = am_matches_data(ms);
+            if (n && !recs) throw AmError(AM_ERR_HIP, am_last_error());
+            std::vector<Acc> accs(active.size());
+            for (size_t k = 0; k < active.size(); k++) accs[k] = Acc{LLONG_MIN, {}, &*cur[active[k]], threshold[active[k]]};
+            auto f = [ic](Acc acc, const Match<Payload>& m) {
+                const Payload& p = m.matchValue;
+                if (p.needlePriority < acc.threshold && p.needlePriority >= acc.pBest) {
+                    if (p.needlePriority > acc.pBest) { acc.pBest = p.needlePriority; acc.matches.clear(); }
+                    RMatch rm;                                                              // makeMatch (:264-274)
+                    if (!ic) { rm.pos = m.matchPos - p.needleLengthBytes; rm.len = p.needleLengthBytes; }
+                    else {
+                        const size_t start = utf8::skipCodePointsBackwards(Text(*acc.hay), m.matchPos - 1, p.needleLengthCodePoints - 1);
+                        rm.pos = start; rm.len = m.matchPos - start;
+                    }
+                    rm.repl = &p.needleReplacement;
+                    acc.matches.push_back(rm);
+                }
+                return Next<Acc>::Step(std::move(acc));
+            };
+            for (uint64_t i = 0; i < n;) {
+                uint64_t j = i;
+                while (j < n && recs[j].haystack == recs[i].haystack) j++;
+                foldRecords(accs[recs[i].haystack], f, searcher_.automaton(), recs + i, j - i);
+                i = j;
+            }
+            std::vector<size_t> next;
+            for (size_t k = 0; k < active.size(); k++) {
+                const size_t idx = active[k];
+                Acc& acc = accs[k];
+                if (acc.matches.empty()) continue;                                          // (_, []) -> Just haystack (:230)
+                const std::string& hay = *cur[idx];
+                long long newLen = (long long)hay.size();                                   // replacementLength (:183-187)
+                for (auto& m : acc.matches) newLen += (long long)m.repl->size() - (long long)m.len;
+                if (newLen > (long long)maxLength && maxLength != SIZE_MAX) { cur[idx] = std::nullopt; continue; }   // :240
+                std::sort(acc.matches.begin(), acc.matches.end(), [](const RMatch& a, const RMatch& b) {   // derived Ord (:159)
+                    if (a.pos != b.pos) return a.pos < b.pos;
+                    if (a.len != b.len) return a.len < b.len;
+                    return *a.repl < *b.repl;
+                });
+                std::string out; out.reserve((size_t)std::max<long long>(newLen, 0));
+                size_t at = 0, lastEnd = 0; bool any = false;
+                for (auto& m : acc.matches) {                                               // removeOverlap (:191-198) + replace (:163-180)
+                    if (any && m.pos < lastEnd) continue;
+                    out.append(hay, at, m.pos - at);
+                    out.append(*m.repl);
+                    at = m.pos + m.len; lastEnd = at; any = true;
+                }
+                out.append(hay, at, std::string::npos);
+                cur[idx] = std::move(out);
+                if (acc.pBest != minPriority) { threshold[idx] = acc.pBest; next.push_back(idx); }   // :241-242
+            }
+            active.swap(next);
+        }
+        return cur;
+    }
+
+    // Replacer.hs:200-201 run
+    std::string run(const std::string& text) const { return *runBatchWithLimit({text}, SIZE_MAX)[0]; }
+    std::optional<std::string> runWithLimit(size_t maxLength, const std::string& text) const { return runBatchWithLimit({text}, maxLength)[0]; }
+
+private:
+    explicit Replacer(Searcher<Payload> s) : searcher_(std::move(s)) {}
+    static std::vector<std::pair<std::string, Payload>> mapNeedles(CaseSensitivity cs, const std::vector<std::pair<std::string, std::string>>& replaces)
+    {
+        std::vector<std::pair<std::string, Payload>> out; out.reserve(replaces.size());
+        for (size_t i = 0; i < replaces.size(); i++) {
+            const std::string& needle = replaces[i].first;
+            Payload p{-(long long)i, needle.size(), utf8::lengthCodePoints(Text(needle)), replaces[i].second};
+            out.emplace_back(cs == CaseSensitivity::IgnoreCase ? utf8::lowerUtf8(Text(needle)) : needle, std::move(p));
+        }
+        return out;
+    }
+    Searcher<Payload> searcher_;
+};
+
+}  // namespace alfred_margaret

@@ -1,0 +1,80 @@
+// searcher.hpp -- host mirror of Data.Text.AhoCorasick.Searcher (reference:
+// src/Data/Text/AhoCorasick/Searcher.hs): needles + case mode + automaton.
+//   build / buildWithValues :110-118, containsAny :156-164, buildNeedleIdSearcher :167-169,
+//   containsAll :173-187, setCaseSensitivity :142-145.
+// containsAny dispatches to libam's flag kernel; containsAll folds the returned records.
+#pragma once
+#include "automaton.hpp"
+
+namespace alfred_margaret {
+
+template <class V> class Searcher {
+public:
+    Searcher(CaseSensitivity cs, std::vector<std::pair<std::string, V>> needlesWithValues)
+        : case_(cs), needles_(std::move(needlesWithValues))
+    {
+        std::vector<std::pair<Text, V>> nv; nv.reserve(needles_.size());
+        for (auto& p : needles_) nv.emplace_back(Text(p.first), p.second);
+        automaton_ = alfred_margaret::build(nv);                  // Searcher.hs:118  Aho.build ns
+    }
+    CaseSensitivity caseSensitivity() const { return case_; }
+    void setCaseSensitivity(CaseSensitivity cs) { case_ = cs; }   // Searcher.hs:142-145: needles untouched
+    const std::vector<std::pair<std::string, V>>& needles() const { return needles_; }
+    size_t numNeedles() const { return needles_.size(); }
+    const AcMachine<V>& automaton() const { return automaton_; }
+
+private:
+    CaseSensitivity case_;
+    std::vector<std::pair<std::string, V>> needles_;
+    AcMachine<V> automaton_;
+};
+
+struct Unit {};
+
+// Searcher.hs:110-111 build :: CaseSensitivity -> [Text] -> Searcher ()
+inline Searcher<Unit> buildSearcher(CaseSensitivity cs, const std::vector<std::string>& needles)
+{
+    std::vector<std::pair<std::string, Unit>> nv; nv.reserve(needles.size());
+    for (auto& n : needles) nv.emplace_back(n, Unit{});
+    return Searcher<Unit>(cs, std::move(nv));
+}
+
+// Searcher.hs:167-169 buildNeedleIdSearcher
+inline Searcher<int> buildNeedleIdSearcher(CaseSensitivity cs, const std::vector<std::string>& needles)
+{
+    std::vector<std::pair<std::string, int>> nv; nv.reserve(needles.size());
+    for (size_t i = 0; i < needles.size(); i++) nv.emplace_back(needles[i], (int)i);
+    return Searcher<int>(cs, std::move(nv));
+}
+
+// Searcher.hs:156-164 containsAny, for a batch of haystacks (one Bool each)
+template <class V>
+std::vector<bool> containsAnyBatch(const Searcher<V>& s, const std::vector<Text>& texts)
+{
+    std::vector<am_slice> slices(texts.size());
+    for (size_t i = 0; i < texts.size(); i++) slices[i] = am_slice{texts[i].data, texts[i].off, texts[i].len};
+    std::vector<uint8_t> flags(texts.size() ? texts.size() : 1, 0);
+    amCheck(am_contains_any(s.automaton().device.get(), (int)s.caseSensitivity(), slices.data(), slices.size(), flags.data()));
+    return std::vector<bool>(flags.begin(), flags.begin() + texts.size());
+}
+
+template <class V> bool containsAny(const Searcher<V>& s, const Text& text) { return containsAnyBatch(s, std::vector<Text>{text})[0]; }
+
+// Searcher.hs:173-187 containsAll: delete each reported needle id from the set, Done when empty
+inline std::vector<bool> containsAllBatch(const Searcher<int>& s, const std::vector<Text>& texts)
+{
+    struct Acc { std::vector<uint8_t> present; size_t remaining; };
+    Acc seed{std::vector<uint8_t>(s.numNeedles(), 1), s.numNeedles()};
+    auto f = [](Acc acc, const Match<int>& m) {
+        if (acc.present[m.matchValue]) { acc.present[m.matchValue] = 0; acc.remaining--; }
+        return acc.remaining == 0 ? Next<Acc>::Done(std::move(acc)) : Next<Acc>::Step(std::move(acc));
+    };
+    std::vector<Acc> accs = runBatchWithCase(s.caseSensitivity(), seed, f, s.automaton(), texts);
+    std::vector<bool> out(texts.size());
+    for (size_t i = 0; i < texts.size(); i++) out[i] = accs[i].remaining == 0;
+    return out;
+}
+
+inline bool containsAll(const Searcher<int>& s, const Text& text) { return containsAllBatch(s, std::vector<Text>{text})[0]; }
+
+}  // namespace alfred_margaret

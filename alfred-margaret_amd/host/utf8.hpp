@@ -1,0 +1,83 @@
+// utf8.hpp -- host mirror of the parts of Data.Text.Utf8 that sit on the Aho-Corasick path
+// (reference: src/Data/Text/Utf8.hs).  Header-only; lower-casing defers to libam's table.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#include "am.h"
+
+namespace alfred_margaret {
+namespace utf8 {
+
+// Data.Text.Internal.Text: array + offset + length in code units (bytes)
+struct Text {
+    const uint8_t* data = nullptr;
+    size_t off = 0;
+    size_t len = 0;
+    Text() = default;
+    Text(const uint8_t* d, size_t o, size_t l) : data(d), off(o), len(l) {}
+    Text(const std::string& s) : data(reinterpret_cast<const uint8_t*>(s.data())), off(0), len(s.size()) {}
+    const uint8_t* begin() const { return data + off; }
+};
+
+// Utf8.hs:337-350 unsafeIndexCodePoint' / decodeN (reads guarded by `end`)
+inline uint32_t decodeAt(const uint8_t* d, size_t idx, size_t end, size_t& units)
+{
+    const uint32_t cu0 = d[idx];
+    const uint32_t cu1 = idx + 1 < end ? d[idx + 1] : 0, cu2 = idx + 2 < end ? d[idx + 2] : 0, cu3 = idx + 3 < end ? d[idx + 3] : 0;
+    if (cu0 < 0xc0) { units = 1; return cu0; }
+    if (cu0 < 0xe0) { units = 2; return ((cu0 & 0x1f) << 6) | (cu1 & 0x3f); }
+    if (cu0 < 0xf0) { units = 3; return ((cu0 & 0xf) << 12) | ((cu1 & 0x3f) << 6) | (cu2 & 0x3f); }
+    units = 4;
+    return ((cu0 & 0x7) << 18) | ((cu1 & 0x3f) << 12) | ((cu2 & 0x3f) << 6) | (cu3 & 0x3f);
+}
+
+// Utf8.hs:154-160 unicode2utf8
+inline void encode(uint32_t c, std::string& out)
+{
+    if (c < 0x80) out.push_back((char)c);
+    else if (c < 0x800) { out.push_back((char)(0xc0 | (c >> 6))); out.push_back((char)(0x80 | (c & 0x3f))); }
+    else if (c < 0x10000) { out.push_back((char)(0xe0 | (c >> 12))); out.push_back((char)(0x80 | ((c >> 6) & 0x3f))); out.push_back((char)(0x80 | (c & 0x3f))); }
+    else { out.push_back((char)(0xf0 | (c >> 18))); out.push_back((char)(0x80 | ((c >> 12) & 0x3f))); out.push_back((char)(0x80 | ((c >> 6) & 0x3f))); out.push_back((char)(0x80 | (c & 0x3f))); }
+}
+
+// Utf8.hs:145-151 lowerCodePoint
+inline uint32_t lowerCodePoint(uint32_t cp) { return am_lower_code_point(cp); }
+
+// Utf8.hs:138-140 lowerUtf8
+inline std::string lowerUtf8(const Text& t)
+{
+    std::string out;
+    out.reserve(t.len);
+    const uint8_t* d = t.begin();
+    for (size_t i = 0; i < t.len;) { size_t u; uint32_t cp = decodeAt(d, i, t.len, u); encode(lowerCodePoint(cp), out); i += u; }
+    return out;
+}
+
+// Text.length: code points
+inline size_t lengthCodePoints(const Text& t)
+{
+    size_t n = 0;
+    const uint8_t* d = t.begin();
+    for (size_t i = 0; i < t.len;) { size_t u; (void)decodeAt(d, i, t.len, u); i += u; n++; }
+    return n;
+}
+
+// Utf8.hs:256-276 skipCodePointsBackwards; throws where the reference calls `error`
+inline size_t skipCodePointsBackwards(const Text& t, size_t index0, size_t n0)
+{
+    if (index0 >= t.len) throw std::out_of_range("Invalid use of skipCodePointsBackwards");
+    const uint8_t* d = t.begin();
+    long long index = (long long)index0; size_t n = n0;
+    for (;;) {
+        if (index >= 0 && (d[index] & 0xC0) == 0x80) { index--; continue; }
+        if (index < 0) throw std::out_of_range("Invalid use of skipCodePointsBackwards");
+        if (n == 0) return (size_t)index;
+        index--; n--;
+    }
+}
+
+}  // namespace utf8
+}  // namespace alfred_margaret

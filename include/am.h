@@ -1,0 +1,150 @@
+/*
+ * am.h -- C ABI of libam.so, the MI355X-native drop-in for the hot path of
+ * channable/alfred-margaret's Data.Text.AhoCorasick.Automaton.
+ *
+ * The reference is a pure Haskell library with no FFI layer of its own on this path; its only
+ * precedent for a C boundary is benchmark/rust-ffi (app/Main.hs:28-52: `foreign import ccall
+ * unsafe "perform_ac"`, slices passed as {ptr, off, len}, pinned byte arrays, callee borrows).
+ * This header keeps that slice convention.  Each entry point names the reference function whose
+ * body it replaces (paths relative to the reference repository root); INTEGRATION.md shows the
+ * `foreign import ccall` stubs a maintainer would add.
+ *
+ * Division of labour (unchanged semantics):
+ *   Haskell keeps   build (Automaton.hs:176-200)  -> state numbering, value lists, value order
+ *                   the fold function f, Done/Step (Automaton.hs:398,522-534)
+ *   libam replaces  the body of runWithCase (Automaton.hs:442-534): decode, lower-case,
+ *                   transition lookup and the "is there anything to report here" test,
+ *                   for a whole batch of haystacks at once on the GPU.
+ *
+ * Result format: one am_match per (haystack, end position) at which the reference would call
+ * the fold function at least once.  `state` is a reference state id such that
+ * `machineValues ! state` (Automaton.hs:109) is exactly the list of values the reference folds
+ * at that position, in the reference's order.  Records are sorted by (haystack, end_pos), which
+ * is the order of the reference's left fold.  So
+ *     runWithCase cs seed f machine text
+ *  == foldl over records r, then over (machineValues ! r.state), of f acc (Match r.end_pos v),
+ *     stopping at the first Done.
+ *
+ * Conventions: every function returns AM_OK (0) or a negative AM_ERR_* code and never throws or
+ * aborts; am_last_error() gives a thread-local message.  Inputs are borrowed for the duration of
+ * the call only.  Handles are immutable after creation and may be shared between threads; calls
+ * serialise on the library's HIP stream.  There is no CPU execution path: without a usable
+ * MI355X every run entry point returns AM_ERR_NO_DEVICE.
+ */
+#ifndef AM_H
+#define AM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Data.Text.CaseSensitivity (src/Data/Text/CaseSensitivity.hs:14-22) */
+#define AM_CASE_SENSITIVE 0
+#define AM_IGNORE_CASE 1
+
+#define AM_OK 0
+#define AM_ERR_INVALID (-1)      /* malformed arguments / automaton arrays */
+#define AM_ERR_NO_DEVICE (-2)    /* no usable HIP device */
+#define AM_ERR_HIP (-3)          /* HIP runtime error, see am_last_error() */
+#define AM_ERR_OOM (-4)
+#define AM_ERR_UNSUPPORTED (-5)
+
+typedef struct am_automaton am_automaton;
+typedef struct am_batch am_batch;
+typedef struct am_matches am_matches;
+
+/* A Text slice: bytes ptr[off .. off+len).  Same shape as U8Slice in
+ * benchmark/rust-ffi/app/Main.hs:34-45 (= Data.Text.Internal.Text array/offset/length). */
+typedef struct am_slice {
+    const uint8_t* ptr;
+    size_t off;
+    size_t len;
+} am_slice;
+
+/* One reportable position.  end_pos = matchPos (Automaton.hs:99-102): code unit index one past the
+ * match, relative to the START OF THE SLICE (Automaton.hs:452,530), not to the array. */
+typedef struct am_match {
+    uint64_t end_pos;
+    uint32_t haystack;   /* index into the batch */
+    uint32_t state;      /* fold (machineValues ! state) here */
+} am_match;
+
+const char* am_last_error(void);
+
+/* ---- automaton ------------------------------------------------------------------------------
+ * am_automaton_create: second half of `build` (Automaton.hs:176-200).  Takes the AcMachine fields
+ * exactly as the reference packs them (Automaton.hs:108-123, bit layout :75-94):
+ *   transitions   machineTransitions, n_transitions entries
+ *   offsets       machineOffsets, n_states + 1 entries (scanl, :170)
+ *   root_ascii    machineRootAsciiTransitions, 128 entries
+ *   values_len    length (machineValues ! s) for every state (the values themselves stay in Haskell)
+ * and flattens them into the device image (column-major suffix tables, reversed-needle trie, LDS
+ * filter).  The image for each case mode is built and uploaded on first use. */
+int am_automaton_create(const uint64_t* transitions, size_t n_transitions,
+                        const uint32_t* offsets, size_t n_states,
+                        const uint64_t* root_ascii,
+                        const uint32_t* values_len,
+                        am_automaton** out);
+void am_automaton_destroy(am_automaton* a);
+/* Route k: 0 = automatic, 1 = force the general AC kernel, 2 = force the suffix-filter kernel
+ * (fails with AM_ERR_UNSUPPORTED at run time for automata that contain the empty needle). */
+int am_automaton_set_kernel(am_automaton* a, int k);
+
+/* ---- one-shot entry points on host slices (what the Haskell shim binds) ----------------------
+ * am_count:        runWithCase cs 0 (\n _ -> Step (n+1))  per haystack
+ *                  (benchmark/haskell/app/Main.hs:67-76 countMatches; counts VALUES, i.e. fold calls)
+ * am_contains_any: Searcher.containsAny (Searcher.hs:156-164) per haystack
+ * am_run:          runWithCase / runText / runLower (Automaton.hs:442-553): all records */
+int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out);
+int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
+int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out);
+
+/* ---- device-resident batches (bulk callers; what bench.py times) ----------------------------- */
+int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out);
+/* Borrow a batch that already lives in HBM: d_bytes = concatenated haystacks (16-byte aligned,
+ * readable up to round_up(total, 16) bytes), d_offsets = n_hay + 1 ascending uint64 byte offsets
+ * with d_offsets[0] == 0 and d_offsets[n_hay] == total_bytes. */
+int am_batch_from_device(const void* d_bytes, const void* d_offsets, size_t n_hay, uint64_t total_bytes, am_batch** out);
+void am_batch_destroy(am_batch* b);
+uint64_t am_batch_total_bytes(const am_batch* b);
+
+int am_count_batch(const am_automaton* a, int case_mode, const am_batch* b, uint64_t* counts_out /* n_hay, nullable */, uint64_t* total_out /* nullable */);
+int am_contains_any_batch(const am_automaton* a, int case_mode, const am_batch* b, uint8_t* flags_out);
+int am_run_batch(const am_automaton* a, int case_mode, const am_batch* b, am_matches** out);
+
+/* ---- results ----------------------------------------------------------------------------------
+ * Records are produced in HBM; am_matches_data copies them to the host on first use. */
+uint64_t am_matches_size(const am_matches* m);
+const am_match* am_matches_data(am_matches* m);           /* host pointer, owned by m; NULL on error */
+const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
+void am_matches_free(am_matches* m);
+
+/* ---- multi-GPU: move the flattened automaton between devices -----------------------------------
+ * The image is one position-independent blob, so rank 0 flattens once and the blob is broadcast
+ * over xGMI (RCCL broadcast of a byte tensor); every other rank attaches to its received copy. */
+int am_automaton_image_size(const am_automaton* a, int case_mode, size_t* nbytes);
+int am_automaton_image_copy(const am_automaton* a, int case_mode, void* d_dst, size_t nbytes);   /* device -> device */
+int am_automaton_from_image(const void* d_image, size_t nbytes, am_automaton** out);            /* copies the blob */
+
+/* ---- UTF-8 helpers on the path -------------------------------------------------------------------
+ * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151), simple mapping, Unicode 13.0.
+ * am_unlower_code_point: Utf8.unlowerCodePoint (src/Data/Text/Utf8/Unlower.hs:26-28) as an ascending set;
+ * returns the set size (may exceed cap). */
+uint32_t am_lower_code_point(uint32_t cp);
+size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
+
+/* ---- runtime knobs ------------------------------------------------------------------------------ */
+int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches; NULL = library stream */
+int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
+/* Per-kernel timing with HIP events on the launch stream (off by default). */
+int am_profile_enable(int on);
+int am_profile_reset(void);
+int am_profile_read(const char* kernel /* "sf" | "ac" | "hidx" | "scan" */, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AM_H */

@@ -1,0 +1,67 @@
+"""Flattener + per-position walk logic (the code the HIP kernels execute, am_image.h) interpreted on
+the CPU by the test-only libam_imgcheck.so and compared with the oracle.  CPU only."""
+import random
+
+import pytest
+
+import alfred_margaret_amd as am
+from oracle import oracle
+from tests.helpers import ImgCheck, expand_records, fragment_case, oracle_triples
+
+
+@pytest.fixture(scope="module")
+def chk():
+    return ImgCheck()
+
+
+def _check(chk, needles, hays, case, chunks=(None,)):
+    o = oracle.Machine(needles)
+    p = am.Automaton(needles)          # product build feeds the flattener, as in production
+    img = chk.flatten(p, case)
+    exp = oracle_triples(o, case, hays)
+    vo, vals = o.values_off(), o.values()
+    for which in (0, 1, 2):            # AC walk, SF filter+verify, SF verify-everything
+        for chunk in (chunks if which == 0 else (None,)):
+            if chunk:
+                chk.set_ac_chunk(img, chunk)
+            n, recs = chk.scan(img, which, hays)
+            if n == -2:
+                assert "" in needles   # SF is disabled only for automata with the empty needle
+                continue
+            assert n >= 0
+            assert expand_records(vo, vals, recs[0], recs[1], recs[2]) == exp, (which, chunk, case, needles, hays)
+            assert all(int(vo[s + 1] - vo[s]) == int(v) for s, v in zip(recs[1], recs[3]))
+
+
+def test_golden_counts_and_lists(chk, golden):
+    for row in golden["count_matches"] + golden["match_lists"] + golden["contains_any"]:
+        if row["needles"]:
+            _check(chk, row["needles"], [row["haystack"]], 0 if row["case"] == "CaseSensitive" else 1)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fragment_pool(chk, seed):
+    rng = random.Random(seed)
+    for _ in range(40):
+        needles, hays = fragment_case(rng)
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if (case and rng.random() < 0.8) else needles
+            _check(chk, ns, hays, case)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_chunk_boundaries(chk, seed):
+    # tiny AC chunks force unit boundaries inside code points, matches and warm-up regions
+    rng = random.Random(100 + seed)
+    for _ in range(10):
+        needles, hays = fragment_case(rng, n_hay_max=4, hay_frags=300)
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+            _check(chk, ns, hays, case, chunks=(1, 3, 16, 64))
+
+
+def test_header_fields(chk):
+    p = am.Automaton(["abc", "", "xyzw"])
+    h = chk.header(chk.flatten(p, 1))
+    assert h["magic"] == 0x31474D41 and h["case_mode"] == 1 and h["n_states"] == p.n_states
+    assert h["max_needle_cps"] == 4 and h["root_vlen"] == 1 and h["ac_chunk"] >= 256
