@@ -6,6 +6,7 @@
 #include "am_flatten.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -330,7 +331,9 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     for (int t = 0; t < 4; t++) { if (!tier_entries[t].empty()) h.sf_tiers |= 1u << t; total_keys += tier_entries[t].size(); }
     {
         uint32_t lw = log2_ceil((total_keys * 16 + 31) / 32);
-        lw = std::max(8u, std::min(15u, lw));
+        uint32_t max_lw = 15;                                  // 128 KiB of the CU's 160 KiB LDS
+        if (const char* env = std::getenv("AM_SF_MAX_BLOOM_LOG2_WORDS")) { int v = std::atoi(env); if (v >= 8 && v <= 15) max_lw = (uint32_t)v; }
+        lw = std::max(8u, std::min(max_lw, lw));
         h.sf_bloom_log2_words = lw;
         std::vector<uint32_t> bloom((size_t)1 << lw, 0);
         for (int t = 0; t < 4; t++)

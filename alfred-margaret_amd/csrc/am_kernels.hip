@@ -220,8 +220,9 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
     const size_t lds = sf_lds_bytes(s);
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
+        // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            (void)hipGetLastError();
         attr_set = true;
     }
     const uint64_t n_chunks = sf_units(b);
