@@ -196,8 +196,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     std::vector<uint32_t> terminals;
     for (size_t s = 1; s < S; s++) if (owns[s]) terminals.push_back((uint32_t)s);
 
-    std::vector<u32x4> nodes;
-    std::vector<u32x2> edges_out;
+    std::vector<SfNode> nodes;
+    std::vector<SfEdge> edges_out;
     std::vector<TierEntry> tier_entries[4];
 
     if (h.sf_enabled && !terminals.empty()) {
@@ -282,7 +282,55 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             std::sort(b_sorted.begin() + b_first[i], b_sorted.begin() + b_first[i + 1],
                       [](const ByteEdge& a, const ByteEdge& b) { return a.byte < b.byte; });
 
-        // renumber in DFS preorder so that unary chains are consecutive records in HBM
+        // ---- path compression.  A node is absorbed into its incoming edge when it has exactly one
+        // parent, exactly one child, no needle ends at it, and no path reaches it with <= 4 bytes
+        // (every node within 4 bytes of the root stays explicit: the suffix tables point at them).
+        std::vector<uint32_t> indeg(n_byte_nodes, 0), min_depth(n_byte_nodes, 0xFFFFFFFFu);
+        for (const ByteEdge& e : b_sorted) indeg[e.dst]++;
+        {
+            std::vector<uint32_t> bq; bq.push_back(0); min_depth[0] = 0;
+            for (size_t qi = 0; qi < bq.size(); qi++) {
+                const uint32_t x = bq[qi];
+                for (uint32_t e = b_first[x]; e < b_first[x + 1]; e++) {
+                    const uint32_t y = b_sorted[e].dst;
+                    if (min_depth[y] == 0xFFFFFFFFu) { min_depth[y] = min_depth[x] + 1; bq.push_back(y); }
+                }
+            }
+        }
+        auto is_terminal = [&](uint32_t x) { return x < n_cp_nodes && term_state[x] != kNone; };
+        auto mergeable = [&](uint32_t x) {
+            return indeg[x] == 1 && b_first[x + 1] - b_first[x] == 1 && !is_terminal(x) && min_depth[x] != 0xFFFFFFFFu && min_depth[x] > 4;
+        };
+        struct CEdge { uint32_t src, byte, dst; std::vector<uint8_t> skip; };    // skip bytes in walk order
+        std::vector<CEdge> cedges;
+        std::vector<uint8_t> explicit_node(n_byte_nodes, 0);
+        {
+            std::vector<uint32_t> work; work.push_back(0); explicit_node[0] = 1;
+            while (!work.empty()) {
+                const uint32_t u = work.back(); work.pop_back();
+                for (uint32_t e = b_first[u]; e < b_first[u + 1]; e++) {
+                    CEdge ce{u, b_sorted[e].byte, b_sorted[e].dst, {}};
+                    while (mergeable(ce.dst) && ce.skip.size() < kMaxSkip) {
+                        const ByteEdge& nx = b_sorted[b_first[ce.dst]];
+                        ce.skip.push_back((uint8_t)nx.byte);
+                        ce.dst = nx.dst;
+                    }
+                    if (!explicit_node[ce.dst]) { explicit_node[ce.dst] = 1; work.push_back(ce.dst); }
+                    cedges.push_back(std::move(ce));
+                }
+            }
+        }
+        // adjacency of the compressed graph (edges of one source stay in selector-byte order)
+        std::vector<uint32_t> c_first(n_byte_nodes + 1, 0);
+        for (const CEdge& e : cedges) c_first[e.src + 1]++;
+        for (size_t i = 0; i < n_byte_nodes; i++) c_first[i + 1] += c_first[i];
+        std::vector<uint32_t> c_order(cedges.size());
+        { std::vector<uint32_t> cur(c_first.begin(), c_first.end() - 1);
+          for (uint32_t i = 0; i < cedges.size(); i++) c_order[cur[cedges[i].src]++] = i; }
+        for (size_t i = 0; i < n_byte_nodes; i++)
+            std::sort(c_order.begin() + c_first[i], c_order.begin() + c_first[i + 1], [&](uint32_t a, uint32_t b) { return cedges[a].byte < cedges[b].byte; });
+
+        // renumber explicit nodes in DFS preorder (a needle's tail is a run of consecutive records)
         std::vector<uint32_t> new_id(n_byte_nodes, kNone), stack;
         uint32_t next_id = 0;
         stack.push_back(0);
@@ -290,35 +338,51 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             const uint32_t x = stack.back(); stack.pop_back();
             if (new_id[x] != kNone) continue;
             new_id[x] = next_id++;
-            for (uint32_t e = b_first[x + 1]; e-- > b_first[x];) if (new_id[b_sorted[e].dst] == kNone) stack.push_back(b_sorted[e].dst);
+            for (uint32_t e = c_first[x + 1]; e-- > c_first[x];) { const uint32_t y = cedges[c_order[e]].dst; if (new_id[y] == kNone) stack.push_back(y); }
         }
-        nodes.assign(next_id, u32x4{0, 0, 0, 0});
+        auto pack_label = [](const std::vector<uint8_t>& skip, uint32_t (&label)[4]) {
+            // walk order = backwards in the haystack; store in text order, right-aligned in 16 bytes
+            uint8_t bytes[kMaxSkip] = {0};
+            const size_t n = skip.size();
+            for (size_t j = 0; j < n; j++) bytes[kMaxSkip - 1 - j] = skip[j];
+            for (int i = 0; i < 4; i++) label[i] = (uint32_t)bytes[4 * i] | ((uint32_t)bytes[4 * i + 1] << 8) | ((uint32_t)bytes[4 * i + 2] << 16) | ((uint32_t)bytes[4 * i + 3] << 24);
+        };
+        nodes.assign(next_id, SfNode{0, 0, 0, 0, {0, 0, 0, 0}});
         for (uint32_t x = 0; x < n_byte_nodes; x++) {
             if (new_id[x] == kNone) continue;
-            u32x4& rec = nodes[new_id[x]];
-            if (x < n_cp_nodes && term_state[x] != kNone) { rec.x = term_state[x] + 1; rec.y = vlen[term_state[x]]; }
-            const uint32_t n = b_first[x + 1] - b_first[x];
+            SfNode& rec = nodes[new_id[x]];
+            if (is_terminal(x)) { rec.x = term_state[x] + 1; rec.y = vlen[term_state[x]]; }
+            const uint32_t n = c_first[x + 1] - c_first[x];
             if (n > 0xFFFF) { err = "node fan-out exceeds 65535"; return -1; }
             if (n == 1) {
-                rec.z = new_id[b_sorted[b_first[x]].dst];
-                rec.w = 1u | (b_sorted[b_first[x]].byte << 24);
+                const CEdge& ce = cedges[c_order[c_first[x]]];
+                rec.z = new_id[ce.dst];
+                rec.w = 1u | (ce.byte << 16) | ((uint32_t)ce.skip.size() << 24);
+                pack_label(ce.skip, rec.label);
             } else if (n > 1) {
                 rec.z = (uint32_t)edges_out.size();
                 rec.w = n;
-                for (uint32_t e = b_first[x]; e < b_first[x + 1]; e++) edges_out.push_back(u32x2{b_sorted[e].byte, new_id[b_sorted[e].dst]});
+                for (uint32_t e = c_first[x]; e < c_first[x + 1]; e++) {
+                    const CEdge& ce = cedges[c_order[e]];
+                    SfEdge ed{ce.byte, new_id[ce.dst], (uint32_t)ce.skip.size(), 0, {0, 0, 0, 0}};
+                    pack_label(ce.skip, ed.label);
+                    edges_out.push_back(ed);
+                }
             }
         }
 
-        // suffix tables: every byte path of length <= 4 from the root
+        // suffix tables: every byte path of length <= 4 from the root (never inside a compressed edge)
         struct Frame { uint32_t node, depth, key; };
         std::vector<Frame> fs; fs.push_back({0, 0, 0});
         while (!fs.empty()) {
             const Frame f = fs.back(); fs.pop_back();
-            for (uint32_t e = b_first[f.node]; e < b_first[f.node + 1]; e++) {
-                const uint32_t d = f.depth + 1, child = b_sorted[e].dst;
-                const uint32_t key = f.key | (b_sorted[e].byte << (32u - 8u * d));
+            for (uint32_t e = c_first[f.node]; e < c_first[f.node + 1]; e++) {
+                const CEdge& ce = cedges[c_order[e]];
+                if (!ce.skip.empty()) { err = "compressed edge within 4 bytes of the root (internal error)"; return -1; }
+                const uint32_t d = f.depth + 1, child = ce.dst;
+                const uint32_t key = f.key | (ce.byte << (32u - 8u * d));
                 if (d == 4) { tier_entries[3].push_back({key, new_id[child]}); continue; }
-                if (child < n_cp_nodes && term_state[child] != kNone) tier_entries[d - 1].push_back({key >> (8u * (4u - d)), new_id[child]});
+                if (is_terminal(child)) tier_entries[d - 1].push_back({key >> (8u * (4u - d)), new_id[child]});
                 fs.push_back({child, d, key});
             }
         }
@@ -342,19 +406,34 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     }
     for (int t = 0; t < 4; t++) {
         const uint32_t lc = std::max(4u, log2_ceil(tier_entries[t].size() * 2 + 1));
-        if (lc > 31) { err = "suffix table too large"; return -1; }
+        if (lc > 28) { err = "suffix table too large"; return -1; }
         h.tier_log2_cap[t] = lc;
-        std::vector<u32x2> tab((size_t)1 << lc, u32x2{0, kNone});
         const uint32_t cap_mask = (1u << lc) - 1;
-        for (const TierEntry& e : tier_entries[t]) {
+        std::vector<uint32_t> slot_of(tier_entries[t].size());
+        std::vector<uint8_t> used((size_t)1 << lc, 0);
+        std::vector<uint32_t> key_at((size_t)1 << lc, 0);
+        for (size_t k = 0; k < tier_entries[t].size(); k++) {
+            const TierEntry& e = tier_entries[t][k];
             uint32_t i = tier_slot(e.key, lc);
-            while (tab[i].y != kNone) {
-                if (tab[i].x == e.key) { err = "duplicate suffix key (internal error)"; return -1; }
+            while (used[i]) {
+                if (key_at[i] == e.key) { err = "duplicate suffix key (internal error)"; return -1; }
                 i = (i + 1) & cap_mask;
             }
-            tab[i] = u32x2{e.key, e.node};
+            used[i] = 1; key_at[i] = e.key; slot_of[k] = i;
         }
-        h.off_tier[t] = blob.put(tab);
+        if (t < 3) {
+            std::vector<u32x2> tab((size_t)1 << lc, u32x2{0, kNone});
+            for (size_t k = 0; k < tier_entries[t].size(); k++) tab[slot_of[k]] = u32x2{tier_entries[t][k].key, tier_entries[t][k].node};
+            h.off_tier[t] = blob.put(tab);
+        } else {
+            // 16-byte entries: the depth-4 node's terminal flag and edge summary ride along with the key
+            std::vector<u32x4> tab((size_t)1 << lc, u32x4{0, kNone, 0, 0});
+            for (size_t k = 0; k < tier_entries[t].size(); k++) {
+                const TierEntry& e = tier_entries[t][k];
+                tab[slot_of[k]] = u32x4{e.key, e.node, nodes[e.node].x, nodes[e.node].w};
+            }
+            h.off_tier[t] = blob.put(tab);
+        }
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);

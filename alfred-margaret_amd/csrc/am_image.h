@@ -57,10 +57,10 @@ struct ImageHeader {
     uint32_t sf_bloom_log2_words;
     uint32_t sf_n_nodes, sf_pad;
     uint64_t off_bloom;         // u32[1 << sf_bloom_log2_words]
-    uint64_t off_tier[4];       // uint2{key, node}[1 << tier_log2_cap[t]]
+    uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}; tier 4: u32x4{key, node, state + 1, node meta}; [1 << tier_log2_cap[t]]
     uint32_t tier_log2_cap[4];
-    uint64_t off_nodes;         // uint4[sf_n_nodes]
-    uint64_t off_edges;         // uint2{byte, child}[n_edges]
+    uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
+    uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
     uint64_t n_edges;
     uint64_t reserved[4];
 };
@@ -79,11 +79,30 @@ struct AcView {
 struct alignas(8) u32x2 { uint32_t x, y; };
 struct alignas(16) u32x4 { uint32_t x, y, z, w; };
 
+// Path-compressed ("Patricia") trie of the reversed needles.  An edge = one selector byte (the next
+// haystack byte going backwards) + up to 16 further bytes that must match (`skip`), stored in TEXT
+// order, right-aligned in a 16-byte slot, so one unaligned 16 B haystack load + one 16 B label load
+// verify the whole edge.  Long unary chains (the tails of the needles) are 1-2 edges instead of one
+// dependent load per byte.
+struct alignas(32) SfNode {
+    uint32_t x;          // canonical reference state + 1 (0: no needle ends here)
+    uint32_t y;          // vlen = length machineValues[state]
+    uint32_t z;          // n_edges == 1: child node; n_edges > 1: first SfEdge index
+    uint32_t w;          // n_edges (bits 0-15) | selector byte of the single edge (16-23) | its skip length (24-31)
+    uint32_t label[4];   // skip bytes of the single edge
+};
+struct alignas(32) SfEdge {
+    uint32_t byte, child, skip, pad;
+    uint32_t label[4];
+};
+constexpr uint32_t kMaxSkip = 16;
+
 struct SfView {
     const uint32_t* bloom;
-    const u32x2* tier[4];
-    const u32x4* nodes;      // x = canonical state + 1 (0: not terminal), y = vlen, z = child | edge index, w = n_edges | byte << 24
-    const u32x2* edges;
+    const u32x2* tier[3];    // exact tables for needles (variants) of exactly 1, 2, 3 bytes
+    const u32x4* tier4;      // exact table of 4-byte suffixes: {key, node, state + 1 of that node, its SfNode.w}: one 16 B load decides most candidates
+    const SfNode* nodes;
+    const SfEdge* edges;
     uint32_t bloom_log2_words, tiers;
     uint32_t tier_log2_cap[4];
 };
@@ -115,14 +134,28 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     const uint8_t* b = (const uint8_t*)base;
     SfView v;
     v.bloom = (const uint32_t*)(b + h.off_bloom);
-    for (int t = 0; t < 4; t++) { v.tier[t] = (const u32x2*)(b + h.off_tier[t]); v.tier_log2_cap[t] = h.tier_log2_cap[t]; }
-    v.nodes = (const u32x4*)(b + h.off_nodes);
-    v.edges = (const u32x2*)(b + h.off_edges);
+    for (int t = 0; t < 3; t++) v.tier[t] = (const u32x2*)(b + h.off_tier[t]);
+    v.tier4 = (const u32x4*)(b + h.off_tier[3]);
+    for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
+    v.nodes = (const SfNode*)(b + h.off_nodes);
+    v.edges = (const SfEdge*)(b + h.off_edges);
     v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers;
     return v;
 }
 
 // ------------------------------------------------------------------ small helpers
+
+// one 16-byte load (global_load_dwordx4 on the device: a single request per lane instead of up to four)
+AM_HD u32x4 load16(const u32x4* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // keep it ONE dwordx4: stop load narrowing/splitting
+    return u32x4{v.x, v.y, v.z, v.w};
+#else
+    return *p;
+#endif
+}
 
 AM_HD uint32_t mulhi32(uint32_t a, uint32_t b)
 {
@@ -188,55 +221,197 @@ AM_HD uint32_t find_haystack(const BatchView& b, uint64_t pos)
 // `gpos` = global index of the LAST byte of the candidate match, `avail` = bytes of its haystack up
 // to and including gpos.  Finds the deepest terminal of the reversed-needle trie along
 // text[gpos], text[gpos-1], ...  Returns true and (state, vlen) if any needle ends here.
+// Memory traffic per candidate is what bounds the kernel (address-divergent loads), so the common
+// case is two loads: the last 8 haystack bytes (one unaligned 8 B load) and one 16 B table entry
+// that already carries the depth-4 node's terminal flag and its single outgoing edge byte.
+
+// last 8 bytes ending at gpos: w = bytes gpos-3..gpos, w2 = bytes gpos-7..gpos-4, newest byte on top
+AM_HD void load_suffix8(const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& w, uint32_t& w2)
+{
+    if (avail >= 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
+        w2 = *reinterpret_cast<const u32_unaligned*>(text + gpos - 7);
+        w = *reinterpret_cast<const u32_unaligned*>(text + gpos - 3);
+#else
+        w = 0; w2 = 0;
+        for (uint32_t j = 0; j < 4; j++) { w |= (uint32_t)text[gpos - j] << (24u - 8u * j); w2 |= (uint32_t)text[gpos - 4 - j] << (24u - 8u * j); }
+#endif
+    } else {
+        w = 0; w2 = 0;
+        for (uint32_t j = 0; j < 8 && j < avail; j++) {
+            const uint32_t b = text[gpos - j];
+            if (j < 4) w |= b << (24u - 8u * j); else w2 |= b << (24u - 8u * (j - 4u));
+        }
+    }
+}
+
+// 16 haystack bytes ending just before global index `end` (text order, dword 3 = the newest four)
+AM_HD void load_text16(const uint8_t* text, uint64_t end, uint32_t (&t)[4])
+{
+    if (end >= 16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+        const u32x4_u v = *reinterpret_cast<const u32x4_u*>(text + end - 16);
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+#else
+        for (int i = 0; i < 4; i++) { t[i] = 0; for (int j = 0; j < 4; j++) t[i] |= (uint32_t)text[end - 16 + 4 * i + j] << (8 * j); }
+#endif
+    } else {
+        for (int i = 0; i < 4; i++) {
+            t[i] = 0;
+            for (int j = 0; j < 4; j++) { const uint64_t off = 4u * i + j; if (end + off >= 16) t[i] |= (uint32_t)text[end + off - 16] << (8 * j); }
+        }
+    }
+}
+
+// do the last `skip` (1..16) bytes of t equal the right-aligned label?
+AM_HD bool label_match(const uint32_t (&t)[4], const uint32_t (&l)[4], uint32_t skip)
+{
+    const uint32_t r = kMaxSkip - skip;      // leading bytes to ignore
+    uint32_t diff = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t g = r > 4u * i ? (r - 4u * i < 4u ? r - 4u * i : 4u) : 0u;
+        const uint32_t mask = g >= 4u ? 0u : 0xFFFFFFFFu << (8u * g);
+        diff |= (t[i] ^ l[i]) & mask;
+    }
+    return diff == 0;
+}
+
+AM_HD void load_node(const SfNode* p, SfNode& n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint4 a = reinterpret_cast<const uint4*>(p)[0], b = reinterpret_cast<const uint4*>(p)[1];   // same 32-byte sector
+    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w));
+    n.x = a.x; n.y = a.y; n.z = a.z; n.w = a.w; n.label[0] = b.x; n.label[1] = b.y; n.label[2] = b.z; n.label[3] = b.w;
+#else
+    n = *p;
+#endif
+}
+
+// N candidates per lane at once: the loads of all N are issued back to back before any result is
+// consumed (memory-level parallelism; the chain text -> table entry -> [node ...] is latency bound).
+template <bool IC, int N>
+AM_HD void sf_verify_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail)[N],
+                       const bool (&valid)[N], bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N])
+{
+    uint32_t w[N], w2[N], slot[N];
+    bool probe[N];
+    u32x4 e[N];
+    const uint32_t cap_mask = (1u << s.tier_log2_cap[3]) - 1u;
+#pragma unroll
+    for (int k = 0; k < N; k++) { w[k] = 0; w2[k] = 0; if (valid[k]) load_suffix8(text, gpos[k], avail[k], w[k], w2[k]); }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
+        probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
+        slot[k] = tier_slot(w[k], s.tier_log2_cap[3]);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint4 raw[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) { raw[k] = make_uint4(0, kNone, 0, 0); if (probe[k]) raw[k] = *reinterpret_cast<const uint4*>(s.tier4 + slot[k]); }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w));   // one dwordx4 each, all in flight together
+            e[k] = u32x4{raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+        }
+    }
+#else
+    for (int k = 0; k < N; k++) e[k] = probe[k] ? s.tier4[slot[k]] : u32x4{0, kNone, 0, 0};
+#endif
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint32_t best_state = 0, best_vlen = 0;          // state + 1
+        uint32_t short_node = kNone;
+        found[k] = false;
+        if (!valid[k]) continue;
+        if (probe[k]) {
+            uint32_t i = slot[k];
+            u32x4 en = e[k];
+            while (en.y != kNone && en.x != w[k]) {           // linear probing past a collision (uncommon)
+                i = (i + 1u) & cap_mask;
+                en = load16(s.tier4 + i);
+            }
+            if (en.y != kNone) {
+                uint32_t node = en.y;
+                bool at_entry_terminal = en.z != 0;          // a 4-byte needle (variant) ends here
+                // does the trie continue with the next haystack byte?  (decided from the entry alone)
+                bool go = false;
+                if (avail[k] > 4) {
+                    const uint32_t n_edges = en.w & 0xFFFFu;
+                    go = n_edges > 1u || (n_edges == 1u && ((en.w >> 16) & 0xFFu) == (w2[k] >> 24));
+                }
+                uint64_t depth = 4;
+                SfNode rec;
+                if (go || at_entry_terminal) {
+                    load_node(s.nodes + node, rec);
+                    if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
+                }
+                while (go) {
+                    const uint32_t n_edges = rec.w & 0xFFFFu;
+                    uint32_t b;
+                    if (depth < 8) b = (w2[k] >> (8u * (7u - (uint32_t)depth))) & 0xFFu;
+                    else { b = text[gpos[k] - depth]; if (IC) b = fold_byte(b); }
+                    uint32_t next = kNone, skip = 0;
+                    uint32_t label[4] = {rec.label[0], rec.label[1], rec.label[2], rec.label[3]};
+                    if (n_edges == 1) {
+                        if (((rec.w >> 16) & 0xFFu) == b) { next = rec.z; skip = rec.w >> 24; }
+                    } else {
+                        uint32_t lo = rec.z, hi = rec.z + n_edges;   // edges sorted by selector byte
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            const uint32_t eb = s.edges[mid].byte;
+                            if (eb == b) {
+                                const SfEdge ed = s.edges[mid];
+                                next = ed.child; skip = ed.skip;
+                                label[0] = ed.label[0]; label[1] = ed.label[1]; label[2] = ed.label[2]; label[3] = ed.label[3];
+                                break;
+                            }
+                            if (eb < b) lo = mid + 1; else hi = mid;
+                        }
+                    }
+                    if (next == kNone) break;
+                    if (skip) {
+                        if (depth + 1 + skip > avail[k]) break;
+                        uint32_t t[4];
+                        load_text16(text, gpos[k] - depth, t);       // the 16 bytes before the selector byte
+                        if (IC) { t[0] = fold_dword(t[0]); t[1] = fold_dword(t[1]); t[2] = fold_dword(t[2]); t[3] = fold_dword(t[3]); }
+                        if (!label_match(t, label, skip)) break;
+                    }
+                    node = next; depth += 1u + skip;
+                    load_node(s.nodes + node, rec);
+                    if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
+                    go = depth < avail[k] && (rec.w & 0xFFFFu) != 0;
+                }
+            }
+        }
+        if (!best_state && (s.tiers & 7u)) {
+            for (uint32_t t = 3; t >= 1; t--) {
+                if ((s.tiers & (1u << (t - 1))) && avail[k] >= t) {
+                    short_node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w[k] >> (8u * (4u - t)));
+                    if (short_node != kNone) break;
+                }
+            }
+            if (short_node != kNone) { best_state = s.nodes[short_node].x; best_vlen = s.nodes[short_node].y; }
+        }
+        if (!best_state) continue;
+        state[k] = best_state - 1u; vlen[k] = best_vlen;
+        found[k] = true;
+    }
+}
+
 template <bool IC>
 AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
 {
-    // last up-to-4 bytes, newest byte in the top byte (same packing as the filter windows)
-    uint32_t w = 0;
-    const uint32_t n = avail < 4 ? (uint32_t)avail : 4u;
-    for (uint32_t j = 0; j < n; j++) {
-        uint32_t b = text[gpos - j];
-        if (IC) b = fold_byte(b);
-        w |= b << (24u - 8u * j);
-    }
-    uint32_t best = 0, best_vlen = 0;
-    if ((s.tiers & 8u) && avail >= 4) {
-        uint32_t node = tier_lookup(s.tier[3], s.tier_log2_cap[3], w);
-        uint64_t depth = 4;
-        while (node != kNone) {
-            const u32x4 rec = s.nodes[node];
-            if (rec.x) { best = rec.x; best_vlen = rec.y; }
-            if (depth == avail) break;
-            const uint32_t n_edges = rec.w & 0xFFFFu;
-            if (n_edges == 0) break;
-            uint32_t b = text[gpos - depth];
-            if (IC) b = fold_byte(b);
-            if (n_edges == 1) {
-                node = ((rec.w >> 24) == b) ? rec.z : kNone;
-            } else {
-                uint32_t lo = rec.z, hi = rec.z + n_edges;   // edges sorted by byte
-                node = kNone;
-                while (lo < hi) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    u32x2 e = s.edges[mid];
-                    if (e.x == b) { node = e.y; break; }
-                    if (e.x < b) lo = mid + 1; else hi = mid;
-                }
-            }
-            depth++;
-        }
-    }
-    if (!best) {
-        for (uint32_t t = 3; t >= 1; t--) {
-            if ((s.tiers & (1u << (t - 1))) && avail >= t) {
-                uint32_t node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w >> (8u * (4u - t)));
-                if (node != kNone) { const u32x4 rec = s.nodes[node]; best = rec.x; best_vlen = rec.y; break; }
-            }
-        }
-    }
-    if (!best) return false;
-    state = best - 1u; vlen = best_vlen;
-    return true;
+    const uint64_t g[1] = {gpos}, a[1] = {avail};
+    const bool v[1] = {true};
+    bool f[1]; uint32_t st[1] = {0}, vl[1] = {0};
+    sf_verify_n<IC, 1>(s, text, g, a, v, f, st, vl);
+    state = st[0]; vlen = vl[0];
+    return f[0];
 }
 
 // Bloom test of one window for every active tier; returns true if any tier may match.

@@ -71,6 +71,9 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
             if (!h.sf_enabled) return -2;
             SfView s = make_sf_view(image, h);
             if (s.tiers) {
+                // candidates exactly as the kernel finds them, then verified two at a time (which == 1:
+                // the ILP path) or one at a time without the Bloom filter (which == 2)
+                std::vector<uint64_t> cands;
                 for (uint64_t p = 0; p < total; p++) {
                     // window of the 4 bytes ending at p, exactly as the kernel builds it from dwords
                     uint32_t w = 0;
@@ -80,11 +83,21 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                     }
                     if (ic) w = fold_dword(w);
                     if (which == 1 && !sf_filter_window(s.bloom, s.bloom_log2_words, s.tiers, w)) continue;
-                    const uint32_t hay = find_haystack(b, p);
-                    uint32_t state, vlen;
-                    const bool found = ic ? sf_verify<true>(s, padded.data(), p, p - offsets[hay] + 1, state, vlen)
-                                          : sf_verify<false>(s, padded.data(), p, p - offsets[hay] + 1, state, vlen);
-                    if (found) recs.push_back({hay, state, p - offsets[hay] + 1, vlen});
+                    cands.push_back(p);
+                }
+                for (size_t i = 0; i < cands.size(); i += 2) {
+                    uint64_t g[2] = {cands[i], i + 1 < cands.size() ? cands[i + 1] : 0}, a[2] = {0, 0};
+                    bool valid[2] = {true, i + 1 < cands.size()}, found[2] = {false, false};
+                    uint32_t hay[2] = {0, 0}, st[2] = {0, 0}, vl[2] = {0, 0};
+                    for (int k = 0; k < 2; k++) if (valid[k]) { hay[k] = find_haystack(b, g[k]); a[k] = g[k] - offsets[hay[k]] + 1; }
+                    if (which == 1) {
+                        if (ic) sf_verify_n<true, 2>(s, padded.data(), g, a, valid, found, st, vl);
+                        else sf_verify_n<false, 2>(s, padded.data(), g, a, valid, found, st, vl);
+                    } else {
+                        for (int k = 0; k < 2; k++) if (valid[k])
+                            found[k] = ic ? sf_verify<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_verify<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);
+                    }
+                    for (int k = 0; k < 2; k++) if (valid[k] && found[k]) recs.push_back({hay[k], st[k], a[k], vl[k]});
                 }
             }
         }

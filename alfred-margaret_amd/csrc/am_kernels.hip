@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "am_device.h"
 
 namespace am {
@@ -73,7 +75,9 @@ constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB fil
 constexpr int kSfWaves = kSfThreads / 64;
 constexpr int kSfQueue = kSfChunk;               // worst case: every position of the chunk is a candidate
 
-template <bool IC, int MODE>
+// ILP = candidates verified per lane per round (their loads are in flight together);
+// NT  = stream the haystack with non-temporal loads so it does not evict the tables from L2.
+template <bool IC, int MODE, int ILP, bool NT>
 __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -90,15 +94,37 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
     uint64_t nval = 0;
 
-    for (uint64_t c = (uint64_t)blockIdx.x * kSfWaves + wave; c < n_chunks; c += n_waves) {
-        const uint64_t p0 = c * kSfChunk + lane * 16u;
-        uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, d4 = 0;
-        if (p0 < b.total) {
-            const uint4 v = *reinterpret_cast<const uint4*>(b.text + p0);      // 1 KiB per wave instruction
-            d1 = v.x; d2 = v.y; d3 = v.z; d4 = v.w;
-            if (p0 >= 4) d0 = *reinterpret_cast<const uint32_t*>(b.text + p0 - 4);
-            if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+    // software pipeline: the next chunk's 16 B per lane (+ the 4 bytes before them) are requested
+    // before the current chunk is filtered and verified, so HBM latency hides behind that work
+    auto fetch = [&](uint64_t cc, uint4& v, uint32_t& prev) {
+        const uint64_t p = cc * kSfChunk + lane * 16u;
+        v = make_uint4(0, 0, 0, 0); prev = 0;
+        if (cc < n_chunks && p < b.total) {
+            typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
+            const u32x4_native* src = reinterpret_cast<const u32x4_native*>(b.text + p);
+            const u32x4_native t = NT ? __builtin_nontemporal_load(src) : *src;     // global_load_dwordx4 [nt]
+            v = make_uint4(t.x, t.y, t.z, t.w);
+            if (p >= 4) prev = *reinterpret_cast<const uint32_t*>(b.text + p - 4);
         }
+    };
+    uint64_t c = (uint64_t)blockIdx.x * kSfWaves + wave;
+    uint4 cur_v; uint32_t cur_prev;
+    fetch(c, cur_v, cur_prev);
+
+    for (; c < n_chunks; c += n_waves) {
+        uint4 next_v; uint32_t next_prev;
+        fetch(c + n_waves, next_v, next_prev);
+
+        const uint64_t c0 = c * kSfChunk;
+        const uint64_t p0 = c0 + lane * 16u;
+        // haystack of the chunk's first byte (same address in every lane: one request per load); almost
+        // every chunk lies inside one haystack, then no candidate needs its own lookup
+        const uint32_t hay0 = find_haystack(b, c0);
+        const uint64_t hs0 = b.offsets[hay0], he0 = b.offsets[hay0 + 1];
+        const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
+
+        uint32_t d0 = cur_prev, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+        if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
         const uint32_t d[5] = {d0, d1, d2, d3, d4};
         uint32_t cand = 0;
 #pragma unroll
@@ -123,32 +149,40 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 
         uint32_t nrec = 0;
         const uint64_t out_base = MODE == kModeEmit ? o.unit_offsets[c] : 0;
-        for (uint32_t base = 0; base < n_cand; base += 64) {
-            bool found = false;
-            uint32_t state = 0, vlen = 0, hay = 0;
-            uint64_t end_pos = 0;
-            if (base + lane < n_cand) {
-                const uint64_t gpos = c * kSfChunk + q[base + lane];
-                hay = find_haystack(b, gpos);
-                end_pos = gpos - b.offsets[hay] + 1;
-                found = sf_verify<IC>(s, b.text, gpos, end_pos, state, vlen);
+        for (uint32_t base = 0; base < n_cand; base += 64 * ILP) {
+            uint64_t gpos[ILP], avail[ILP];
+            uint32_t hay[ILP], state[ILP], vlen[ILP];
+            bool valid[ILP], found[ILP];
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                const uint32_t e = base + 64u * k + lane;
+                valid[k] = e < n_cand;
+                gpos[k] = c0 + (valid[k] ? q[e] : 0u);
+                hay[k] = hay0; avail[k] = gpos[k] - hs0 + 1;
+                state[k] = 0; vlen[k] = 0;
+                if (valid[k] && !single) { hay[k] = find_haystack(b, gpos[k]); avail[k] = gpos[k] - b.offsets[hay[k]] + 1; }
             }
-            const uint64_t ballot = __ballot(found);
-            if (found) {
-                if (MODE == kModeCount) {
-                    nval += vlen;
-                    if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
-                } else if (MODE == kModeEmit) {
-                    const uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
-                    o.records[out_base + nrec + rank] = Record{end_pos, hay, state};
-                } else {
-                    o.flags[hay] = 1;
+            sf_verify_n<IC, ILP>(s, b.text, gpos, avail, valid, found, state, vlen);
+#pragma unroll
+            for (int k = 0; k < ILP; k++) {
+                const uint64_t ballot = __ballot(found[k]);
+                if (found[k]) {
+                    if (MODE == kModeCount) {
+                        nval += vlen[k];
+                        if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)vlen[k]);
+                    } else if (MODE == kModeEmit) {
+                        const uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
+                        o.records[out_base + nrec + rank] = Record{avail[k], hay[k], state[k]};    // avail == end_pos
+                    } else {
+                        o.flags[hay[k]] = 1;
+                    }
                 }
+                nrec += (uint32_t)__popcll(ballot);
             }
-            nrec += (uint32_t)__popcll(ballot);
         }
         if (MODE == kModeCount && lane == 0) o.unit_counts[c] = nrec;
         wave_lds_fence();      // the queue is rewritten by the next chunk
+        cur_v = next_v; cur_prev = next_prev;
     }
     if (MODE == kModeCount) {
         nval = wave_sum_u64(nval);
@@ -214,14 +248,14 @@ uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chu
 
 size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * kSfQueue * sizeof(uint16_t); }
 
-template <bool IC, int MODE>
-static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+template <bool IC, int MODE, int ILP, bool NT>
+static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const size_t lds = sf_lds_bytes(s);
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
@@ -231,8 +265,28 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
     const uint64_t need = (n_chunks + kSfWaves - 1) / kSfWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_sf<IC, MODE>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
+    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, NT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
     return hipGetLastError();
+}
+
+// tuning variant: AM_SF_VARIANT = ilp * 10 + nt  (ilp in {1,2,4}, nt in {0,1}); default 21
+static int sf_variant()
+{
+    static int v = [] { const char* e = std::getenv("AM_SF_VARIANT"); return e ? std::atoi(e) : 21; }();
+    return v;
+}
+
+template <bool IC, int MODE>
+static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+{
+    switch (sf_variant()) {
+        case 10: return launch_sf_v<IC, MODE, 1, false>(s, b, o, n_cu, st);
+        case 11: return launch_sf_v<IC, MODE, 1, true>(s, b, o, n_cu, st);
+        case 20: return launch_sf_v<IC, MODE, 2, false>(s, b, o, n_cu, st);
+        case 40: return launch_sf_v<IC, MODE, 4, false>(s, b, o, n_cu, st);
+        case 41: return launch_sf_v<IC, MODE, 4, true>(s, b, o, n_cu, st);
+        default: return launch_sf_v<IC, MODE, 2, true>(s, b, o, n_cu, st);
+    }
 }
 
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)

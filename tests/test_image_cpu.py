@@ -65,3 +65,30 @@ def test_header_fields(chk):
     h = chk.header(chk.flatten(p, 1))
     assert h["magic"] == 0x31474D41 and h["case_mode"] == 1 and h["n_states"] == p.n_states
     assert h["max_needle_cps"] == 4 and h["root_vlen"] == 1 and h["ac_chunk"] >= 256
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_long_needles_compressed_edges(chk, seed):
+    # needles far longer than one compressed edge (16 skip bytes) with shared tails and needles that
+    # are suffixes of other needles: exercises label splitting, mid-chain terminals and the
+    # haystack-start clipping of the 16-byte label compare
+    rng = random.Random(500 + seed)
+    for _ in range(8):
+        alphabet = rng.choice(["ab", "abcdefgh", "aéß𝄞", "aAkKK"])
+        base = ["".join(rng.choice(alphabet) for _ in range(rng.randint(20, 90))) for _ in range(4)]
+        needles = []
+        for b in base:
+            needles.append(b)
+            for _ in range(3):
+                needles.append(b[rng.randint(1, len(b) - 4):])                    # suffix of a longer needle
+            needles.append("".join(rng.choice(alphabet) for _ in range(rng.randint(1, 6))) + b[len(b) // 2:])   # shared tail, other head
+        hays = []
+        for _ in range(4):
+            parts = []
+            for _ in range(rng.randint(1, 6)):
+                parts.append(rng.choice(needles) if rng.random() < 0.7 else "".join(rng.choice(alphabet) for _ in range(rng.randint(1, 30))))
+            hays.append("".join(parts))
+        hays.append(needles[0][3:])        # starts inside a needle: clipped at the haystack start
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+            _check(chk, ns, hays, case)
