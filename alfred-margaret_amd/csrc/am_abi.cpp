@@ -377,6 +377,7 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
     o.unit_counts = (uint32_t*)b->unit_counts.p;
     o.total_values = (uint64_t*)b->small.p;
     HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(b->unit_counts.p, 0, (p.n_units + 1) * sizeof(uint32_t), st));
     if (counts_out) {
         AM_TRY(b->hay_counts.ensure((size_t)b->n_hay * sizeof(uint64_t)));
         HIP_TRY(hipMemsetAsync(b->hay_counts.p, 0, (size_t)b->n_hay * sizeof(uint64_t), st));
@@ -438,7 +439,7 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
         o.unit_counts = (uint32_t*)b->unit_counts.p;
         o.total_values = (uint64_t*)b->small.p;
         HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
-        HIP_TRY(hipMemsetAsync((uint32_t*)b->unit_counts.p + p.n_units, 0, sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(b->unit_counts.p, 0, n * sizeof(uint32_t), st));   // k_sf adds per chunk; [n_units] stays 0
         AM_TRY(build_hidx(p, b, st));
         AM_TRY(launch_scan_kernel(p, kModeCount, o, st));
         { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }

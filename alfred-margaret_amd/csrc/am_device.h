@@ -21,6 +21,7 @@ struct ScanOut {
     uint64_t* hay_counts;         // count mode, may be null
     uint64_t* total_values;       // count mode
     uint8_t* flags;               // any mode
+    uint32_t ablate;              // timing experiments only (AM_SF_ABLATE); 0 in production
 };
 
 hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st);

@@ -404,36 +404,52 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             for (const TierEntry& e : tier_entries[t]) { uint32_t word, mask; bloom_slot(e.key, (uint32_t)t + 1, lw, word, mask); bloom[word] |= mask; }
         h.off_bloom = blob.put(bloom);
     }
-    for (int t = 0; t < 4; t++) {
+    for (int t = 0; t < 3; t++) {       // 1..3-byte needles: plain open addressing (rare)
         const uint32_t lc = std::max(4u, log2_ceil(tier_entries[t].size() * 2 + 1));
         if (lc > 28) { err = "suffix table too large"; return -1; }
         h.tier_log2_cap[t] = lc;
         const uint32_t cap_mask = (1u << lc) - 1;
-        std::vector<uint32_t> slot_of(tier_entries[t].size());
-        std::vector<uint8_t> used((size_t)1 << lc, 0);
-        std::vector<uint32_t> key_at((size_t)1 << lc, 0);
-        for (size_t k = 0; k < tier_entries[t].size(); k++) {
-            const TierEntry& e = tier_entries[t][k];
+        std::vector<u32x2> tab((size_t)1 << lc, u32x2{0, kNone});
+        for (const TierEntry& e : tier_entries[t]) {
             uint32_t i = tier_slot(e.key, lc);
-            while (used[i]) {
-                if (key_at[i] == e.key) { err = "duplicate suffix key (internal error)"; return -1; }
+            while (tab[i].y != kNone) {
+                if (tab[i].x == e.key) { err = "duplicate suffix key (internal error)"; return -1; }
                 i = (i + 1) & cap_mask;
             }
-            used[i] = 1; key_at[i] = e.key; slot_of[k] = i;
+            tab[i] = u32x2{e.key, e.node};
         }
-        if (t < 3) {
-            std::vector<u32x2> tab((size_t)1 << lc, u32x2{0, kNone});
-            for (size_t k = 0; k < tier_entries[t].size(); k++) tab[slot_of[k]] = u32x2{tier_entries[t][k].key, tier_entries[t][k].node};
-            h.off_tier[t] = blob.put(tab);
-        } else {
-            // 16-byte entries: the depth-4 node's terminal flag and edge summary ride along with the key
-            std::vector<u32x4> tab((size_t)1 << lc, u32x4{0, kNone, 0, 0});
-            for (size_t k = 0; k < tier_entries[t].size(); k++) {
-                const TierEntry& e = tier_entries[t][k];
-                tab[slot_of[k]] = u32x4{e.key, e.node, nodes[e.node].x, nodes[e.node].w};
+        h.off_tier[t] = blob.put(tab);
+    }
+    {
+        // 4-byte suffixes: 2-choice cuckoo table of 16-byte entries {key, node, state + 1, node.w}; the
+        // depth-4 node's terminal flag and edge summary ride along with the key, so one fetch of both
+        // candidate slots decides almost every probe without touching the node.
+        const std::vector<TierEntry>& ents = tier_entries[3];
+        uint32_t lc = std::max(4u, log2_ceil(ents.size() * 2 + 1));
+        std::vector<uint32_t> slot_owner;
+        for (;; lc++) {
+            if (lc > 28) { err = "suffix table too large"; return -1; }
+            slot_owner.assign((size_t)1 << lc, kNone);
+            bool ok = true;
+            for (uint32_t k = 0; k < ents.size() && ok; k++) {
+                uint32_t cur = k;
+                uint32_t pos = tier4_slot_a(ents[cur].key, lc);
+                for (int kicks = 0;; kicks++) {
+                    if (slot_owner[pos] == kNone) { slot_owner[pos] = cur; break; }
+                    if (ents[slot_owner[pos]].key == ents[cur].key) { err = "duplicate suffix key (internal error)"; return -1; }
+                    if (kicks > 500) { ok = false; break; }
+                    std::swap(cur, slot_owner[pos]);          // evict the resident, move it to its other slot
+                    const uint32_t a = tier4_slot_a(ents[cur].key, lc), b = tier4_slot_b(ents[cur].key, lc);
+                    pos = (pos == a) ? b : a;
+                }
             }
-            h.off_tier[t] = blob.put(tab);
+            if (ok) break;
         }
+        h.tier_log2_cap[3] = lc;
+        std::vector<u32x4> tab((size_t)1 << lc, u32x4{0, kNone, 0, 0});
+        for (size_t i = 0; i < slot_owner.size(); i++)
+            if (slot_owner[i] != kNone) { const TierEntry& e = ents[slot_owner[i]]; tab[i] = u32x4{e.key, e.node, nodes[e.node].x, nodes[e.node].w}; }
+        h.off_tier[3] = blob.put(tab);
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);

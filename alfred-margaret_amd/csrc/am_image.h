@@ -290,117 +290,142 @@ AM_HD void load_node(const SfNode* p, SfNode& n)
 #endif
 }
 
-// N candidates per lane at once: the loads of all N are issued back to back before any result is
-// consumed (memory-level parallelism; the chain text -> table entry -> [node ...] is latency bound).
+// The 4-byte suffix table is a 2-choice cuckoo table: a key lives in slot_a(key) or slot_b(key), both
+// entries are fetched together, and there is no probe loop (nothing data-dependent to diverge on).
+AM_HD uint32_t tier4_slot_a(uint32_t key, uint32_t log2_cap) { return (key * 0x85EBCA6Bu) >> (32u - log2_cap); }
+AM_HD uint32_t tier4_slot_b(uint32_t key, uint32_t log2_cap) { return ((key ^ (key >> 15)) * 0xC2B2AE35u) >> (32u - log2_cap); }
+
+constexpr uint32_t kShortOnly = 0xFFFFFFFEu;    // "no depth-4 node, but the 1..3-byte tables must be consulted"
+
+// Phase 1, N candidates per lane at once (all loads of all N in flight together): the last 8 haystack
+// bytes and the two table entries decide almost every candidate.  node[k] = kNone: nothing ends at
+// this position.  Otherwise the candidate must be resolved by sf_resolve (a needle may end here):
+// node[k] = the depth-4 trie node to continue from, or kShortOnly.
 template <bool IC, int N>
-AM_HD void sf_verify_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail)[N],
-                       const bool (&valid)[N], bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N])
+AM_HD void sf_probe_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail)[N],
+                      const bool (&valid)[N], uint32_t (&node)[N], uint32_t ablate = 0)
 {
-    uint32_t w[N], w2[N], slot[N];
+    uint32_t w[N], w2[N];
     bool probe[N];
-    u32x4 e[N];
-    const uint32_t cap_mask = (1u << s.tier_log2_cap[3]) - 1u;
+    u32x4 ea[N], eb[N];
 #pragma unroll
     for (int k = 0; k < N; k++) { w[k] = 0; w2[k] = 0; if (valid[k]) load_suffix8(text, gpos[k], avail[k], w[k], w2[k]); }
 #pragma unroll
     for (int k = 0; k < N; k++) {
         if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
         probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
-        slot[k] = tier_slot(w[k], s.tier_log2_cap[3]);
+        node[k] = kNone;
     }
+    if (ablate == 2) { for (int k = 0; k < N; k++) if (valid[k] && w[k] == 0x12345678u && w2[k] == 0x9abcdef0u) node[k] = 0; return; }   // timing experiment only
 #if defined(__HIP_DEVICE_COMPILE__)
     {
-        uint4 raw[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) { raw[k] = make_uint4(0, kNone, 0, 0); if (probe[k]) raw[k] = *reinterpret_cast<const uint4*>(s.tier4 + slot[k]); }
+        uint4 ra[N], rb[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            asm volatile("" : "+v"(raw[k].x), "+v"(raw[k].y), "+v"(raw[k].z), "+v"(raw[k].w));   // one dwordx4 each, all in flight together
-            e[k] = u32x4{raw[k].x, raw[k].y, raw[k].z, raw[k].w};
+            ra[k] = make_uint4(0, kNone, 0, 0); rb[k] = ra[k];
+            if (probe[k]) {
+                ra[k] = *reinterpret_cast<const uint4*>(s.tier4 + tier4_slot_a(w[k], s.tier_log2_cap[3]));
+                rb[k] = *reinterpret_cast<const uint4*>(s.tier4 + tier4_slot_b(w[k], s.tier_log2_cap[3]));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            asm volatile("" : "+v"(ra[k].x), "+v"(ra[k].y), "+v"(ra[k].z), "+v"(ra[k].w), "+v"(rb[k].x), "+v"(rb[k].y), "+v"(rb[k].z), "+v"(rb[k].w));
+            ea[k] = u32x4{ra[k].x, ra[k].y, ra[k].z, ra[k].w};
+            eb[k] = u32x4{rb[k].x, rb[k].y, rb[k].z, rb[k].w};
         }
     }
 #else
-    for (int k = 0; k < N; k++) e[k] = probe[k] ? s.tier4[slot[k]] : u32x4{0, kNone, 0, 0};
+    for (int k = 0; k < N; k++) {
+        ea[k] = probe[k] ? s.tier4[tier4_slot_a(w[k], s.tier_log2_cap[3])] : u32x4{0, kNone, 0, 0};
+        eb[k] = probe[k] ? s.tier4[tier4_slot_b(w[k], s.tier_log2_cap[3])] : u32x4{0, kNone, 0, 0};
+    }
 #endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        uint32_t best_state = 0, best_vlen = 0;          // state + 1
-        uint32_t short_node = kNone;
-        found[k] = false;
         if (!valid[k]) continue;
-        if (probe[k]) {
-            uint32_t i = slot[k];
-            u32x4 en = e[k];
-            while (en.y != kNone && en.x != w[k]) {           // linear probing past a collision (uncommon)
-                i = (i + 1u) & cap_mask;
-                en = load16(s.tier4 + i);
+        const bool hit_a = ea[k].y != kNone && ea[k].x == w[k];
+        const bool hit_b = eb[k].y != kNone && eb[k].x == w[k];
+        if (hit_a || hit_b) {
+            const u32x4 en = hit_a ? ea[k] : eb[k];
+            bool go = en.z != 0;                             // a 4-byte needle (variant) ends here
+            if (avail[k] > 4) {                              // or the trie continues with the next haystack byte
+                const uint32_t n_edges = en.w & 0xFFFFu;
+                go = go || n_edges > 1u || (n_edges == 1u && ((en.w >> 16) & 0xFFu) == (w2[k] >> 24));
             }
-            if (en.y != kNone) {
-                uint32_t node = en.y;
-                bool at_entry_terminal = en.z != 0;          // a 4-byte needle (variant) ends here
-                // does the trie continue with the next haystack byte?  (decided from the entry alone)
-                bool go = false;
-                if (avail[k] > 4) {
-                    const uint32_t n_edges = en.w & 0xFFFFu;
-                    go = n_edges > 1u || (n_edges == 1u && ((en.w >> 16) & 0xFFu) == (w2[k] >> 24));
-                }
-                uint64_t depth = 4;
-                SfNode rec;
-                if (go || at_entry_terminal) {
-                    load_node(s.nodes + node, rec);
-                    if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
-                }
-                while (go) {
-                    const uint32_t n_edges = rec.w & 0xFFFFu;
-                    uint32_t b;
-                    if (depth < 8) b = (w2[k] >> (8u * (7u - (uint32_t)depth))) & 0xFFu;
-                    else { b = text[gpos[k] - depth]; if (IC) b = fold_byte(b); }
-                    uint32_t next = kNone, skip = 0;
-                    uint32_t label[4] = {rec.label[0], rec.label[1], rec.label[2], rec.label[3]};
-                    if (n_edges == 1) {
-                        if (((rec.w >> 16) & 0xFFu) == b) { next = rec.z; skip = rec.w >> 24; }
-                    } else {
-                        uint32_t lo = rec.z, hi = rec.z + n_edges;   // edges sorted by selector byte
-                        while (lo < hi) {
-                            const uint32_t mid = (lo + hi) >> 1;
-                            const uint32_t eb = s.edges[mid].byte;
-                            if (eb == b) {
-                                const SfEdge ed = s.edges[mid];
-                                next = ed.child; skip = ed.skip;
-                                label[0] = ed.label[0]; label[1] = ed.label[1]; label[2] = ed.label[2]; label[3] = ed.label[3];
-                                break;
-                            }
-                            if (eb < b) lo = mid + 1; else hi = mid;
-                        }
-                    }
-                    if (next == kNone) break;
-                    if (skip) {
-                        if (depth + 1 + skip > avail[k]) break;
-                        uint32_t t[4];
-                        load_text16(text, gpos[k] - depth, t);       // the 16 bytes before the selector byte
-                        if (IC) { t[0] = fold_dword(t[0]); t[1] = fold_dword(t[1]); t[2] = fold_dword(t[2]); t[3] = fold_dword(t[3]); }
-                        if (!label_match(t, label, skip)) break;
-                    }
-                    node = next; depth += 1u + skip;
-                    load_node(s.nodes + node, rec);
-                    if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
-                    go = depth < avail[k] && (rec.w & 0xFFFFu) != 0;
-                }
-            }
+            if (go) node[k] = en.y;
         }
-        if (!best_state && (s.tiers & 7u)) {
-            for (uint32_t t = 3; t >= 1; t--) {
-                if ((s.tiers & (1u << (t - 1))) && avail[k] >= t) {
-                    short_node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w[k] >> (8u * (4u - t)));
-                    if (short_node != kNone) break;
-                }
-            }
-            if (short_node != kNone) { best_state = s.nodes[short_node].x; best_vlen = s.nodes[short_node].y; }
-        }
-        if (!best_state) continue;
-        state[k] = best_state - 1u; vlen[k] = best_vlen;
-        found[k] = true;
+        if (node[k] == kNone && (s.tiers & 7u)) node[k] = kShortOnly;
     }
+    if (ablate == 3) { for (int k = 0; k < N; k++) if (node[k] != kNone && ea[k].x != 0x12345678u) node[k] = kNone; }   // timing experiment only
+}
+
+// Phase 2: walk the compressed trie from the depth-4 node along the haystack (backwards) and return the
+// deepest needle end; falls back to the 1..3-byte tables.  Data-dependent loops live only here, and
+// the kernel batches these rare items so that a whole wavefront resolves them together.
+template <bool IC>
+AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t node, uint32_t& state, uint32_t& vlen)
+{
+    uint32_t w, w2;
+    load_suffix8(text, gpos, avail, w, w2);
+    if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
+    uint32_t best_state = 0, best_vlen = 0;          // state + 1
+    if (node != kShortOnly) {
+        uint64_t depth = 4;
+        SfNode rec;
+        load_node(s.nodes + node, rec);
+        if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
+        bool go = depth < avail && (rec.w & 0xFFFFu) != 0;
+        while (go) {
+            const uint32_t n_edges = rec.w & 0xFFFFu;
+            uint32_t b;
+            if (depth < 8) b = (w2 >> (8u * (7u - (uint32_t)depth))) & 0xFFu;
+            else { b = text[gpos - depth]; if (IC) b = fold_byte(b); }
+            uint32_t next = kNone, skip = 0;
+            uint32_t label[4] = {rec.label[0], rec.label[1], rec.label[2], rec.label[3]};
+            if (n_edges == 1) {
+                if (((rec.w >> 16) & 0xFFu) == b) { next = rec.z; skip = rec.w >> 24; }
+            } else {
+                uint32_t lo = rec.z, hi = rec.z + n_edges;   // edges sorted by selector byte
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t eb = s.edges[mid].byte;
+                    if (eb == b) {
+                        const SfEdge ed = s.edges[mid];
+                        next = ed.child; skip = ed.skip;
+                        label[0] = ed.label[0]; label[1] = ed.label[1]; label[2] = ed.label[2]; label[3] = ed.label[3];
+                        break;
+                    }
+                    if (eb < b) lo = mid + 1; else hi = mid;
+                }
+            }
+            if (next == kNone) break;
+            if (skip) {
+                if (depth + 1 + skip > avail) break;
+                uint32_t t[4];
+                load_text16(text, gpos - depth, t);       // the 16 bytes before the selector byte
+                if (IC) { t[0] = fold_dword(t[0]); t[1] = fold_dword(t[1]); t[2] = fold_dword(t[2]); t[3] = fold_dword(t[3]); }
+                if (!label_match(t, label, skip)) break;
+            }
+            node = next; depth += 1u + skip;
+            load_node(s.nodes + node, rec);
+            if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
+            go = depth < avail && (rec.w & 0xFFFFu) != 0;
+        }
+    }
+    if (!best_state && (s.tiers & 7u)) {
+        uint32_t short_node = kNone;
+        for (uint32_t t = 3; t >= 1; t--) {
+            if ((s.tiers & (1u << (t - 1))) && avail >= t) {
+                short_node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w >> (8u * (4u - t)));
+                if (short_node != kNone) break;
+            }
+        }
+        if (short_node != kNone) { best_state = s.nodes[short_node].x; best_vlen = s.nodes[short_node].y; }
+    }
+    if (!best_state) return false;
+    state = best_state - 1u; vlen = best_vlen;
+    return true;
 }
 
 template <bool IC>
@@ -408,10 +433,10 @@ AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64
 {
     const uint64_t g[1] = {gpos}, a[1] = {avail};
     const bool v[1] = {true};
-    bool f[1]; uint32_t st[1] = {0}, vl[1] = {0};
-    sf_verify_n<IC, 1>(s, text, g, a, v, f, st, vl);
-    state = st[0]; vlen = vl[0];
-    return f[0];
+    uint32_t node[1];
+    sf_probe_n<IC, 1>(s, text, g, a, v, node);
+    if (node[0] == kNone) return false;
+    return sf_resolve<IC>(s, text, gpos, avail, node[0], state, vlen);
 }
 
 // Bloom test of one window for every active tier; returns true if any tier may match.

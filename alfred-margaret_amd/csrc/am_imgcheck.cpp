@@ -91,8 +91,10 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                     uint32_t hay[2] = {0, 0}, st[2] = {0, 0}, vl[2] = {0, 0};
                     for (int k = 0; k < 2; k++) if (valid[k]) { hay[k] = find_haystack(b, g[k]); a[k] = g[k] - offsets[hay[k]] + 1; }
                     if (which == 1) {
-                        if (ic) sf_verify_n<true, 2>(s, padded.data(), g, a, valid, found, st, vl);
-                        else sf_verify_n<false, 2>(s, padded.data(), g, a, valid, found, st, vl);
+                        uint32_t node[2];
+                        if (ic) sf_probe_n<true, 2>(s, padded.data(), g, a, valid, node); else sf_probe_n<false, 2>(s, padded.data(), g, a, valid, node);
+                        for (int k = 0; k < 2; k++) if (valid[k] && node[k] != kNone)
+                            found[k] = ic ? sf_resolve<true>(s, padded.data(), g[k], a[k], node[k], st[k], vl[k]) : sf_resolve<false>(s, padded.data(), g[k], a[k], node[k], st[k], vl[k]);
                     } else {
                         for (int k = 0; k < 2; k++) if (valid[k])
                             found[k] = ic ? sf_verify<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_verify<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);

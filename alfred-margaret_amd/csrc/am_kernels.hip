@@ -73,29 +73,88 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
-constexpr int kSfQueue = kSfChunk;               // worst case: every position of the chunk is a candidate
+constexpr int kSfQ1 = 256;                       // per-wave queue of candidate positions (u16); larger chunks take several sub-passes
+constexpr int kSfQ2 = 192;                       // per-wave ring of deferred items (2 x u32): candidates that need the trie walk
 
-// ILP = candidates verified per lane per round (their loads are in flight together);
-// NT  = stream the haystack with non-temporal loads so it does not evict the tables from L2.
+// ILP = candidates probed per lane per round (their loads are in flight together);
+// NT  = stream the haystack with non-temporal loads.
+//
+// Structure of one wavefront's loop (everything between two filter steps is wave-synchronous):
+//   filter   16 positions per lane against the LDS Bloom filter                      (LDS + VALU only)
+//   probe    surviving positions, 64*ILP at a time: last 8 haystack bytes + both cuckoo slots; no
+//            data-dependent loop, so every lane runs the same three loads            (phase 1)
+//   resolve  the few candidates that hit the suffix table AND continue in the trie (or end a needle)
+//            are parked in a ring and walked 64 at a time, across chunk boundaries   (phase 2)
+// Phase 2 is FIFO, so records of a chunk come out in position order without atomics or sorting.
 template <bool IC, int MODE, int ILP, bool NT>
 __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* bloom = lds;
-    uint16_t* queues = reinterpret_cast<uint16_t*>(lds + words);
+    uint2* q2_all = reinterpret_cast<uint2*>(lds + words);
+    uint16_t* q1_all = reinterpret_cast<uint16_t*>(q2_all + kSfWaves * kSfQ2);
 
     for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint16_t* q = queues + wave * kSfQueue;
+    uint16_t* q1 = q1_all + wave * kSfQ1;
+    uint2* q2 = q2_all + wave * kSfQ2;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
+    const uint64_t c_first = (uint64_t)blockIdx.x * kSfWaves + wave;
     uint64_t nval = 0;
+    uint32_t q2_head = 0, q2_tail = 0;                   // monotonic; slot = index % kSfQ2
+    uint32_t carry_seq = 0xFFFFFFFFu, carry_cnt = 0;     // emit mode: records already written for the newest chunk seen
+
+    // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items
+    auto resolve_batch = [&](uint32_t nb) {
+        const bool valid = lane < nb;
+        bool found = false;
+        uint32_t state = 0, vlen = 0, hay = 0, seq_i = 0;
+        uint64_t end_pos = 0, chunk_i = 0;
+        if (valid) {
+            const uint2 item = q2[(q2_head + lane) % kSfQ2];
+            seq_i = item.y >> 10;
+            chunk_i = c_first + (uint64_t)seq_i * n_waves;
+            const uint64_t gpos = chunk_i * kSfChunk + (item.y & 1023u);
+            hay = find_haystack(b, gpos);
+            end_pos = gpos - b.offsets[hay] + 1;
+            found = sf_resolve<IC>(s, b.text, gpos, end_pos, item.x, state, vlen);
+        }
+        const uint64_t found_mask = __ballot(found);
+        if (MODE == kModeCount) {
+            if (found) {
+                atomicAdd(o.unit_counts + chunk_i, 1u);     // zeroed by the host; only this wave touches it
+                nval += vlen;
+                if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
+            }
+        } else if (MODE == kModeEmit) {
+            // items are in position order (FIFO), so a record's slot inside its chunk is the number of
+            // earlier records of that chunk: those in earlier lanes of its segment + the carry
+            const uint32_t prev_seq = __shfl_up(seq_i, 1, 64);
+            const uint64_t head_mask = __ballot(valid && (lane == 0 || seq_i != prev_seq));
+            const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+            const uint32_t my_head = 63u - (uint32_t)__builtin_clzll(head_mask & le);
+            const uint64_t below_me = (1ull << lane) - 1ull, below_head = (1ull << my_head) - 1ull;
+            const uint32_t rank = (uint32_t)__popcll(found_mask & below_me & ~below_head);
+            if (found) {
+                const uint32_t base_cnt = seq_i == carry_seq ? carry_cnt : 0u;
+                o.records[o.unit_offsets[chunk_i] + base_cnt + rank] = Record{end_pos, hay, state};
+            }
+            const uint32_t seq_last = __shfl(seq_i, (int)nb - 1, 64), head_last = __shfl(my_head, (int)nb - 1, 64);
+            const uint32_t seg_found = (uint32_t)__popcll(found_mask & ~((1ull << head_last) - 1ull));
+            carry_cnt = (seq_last == carry_seq ? carry_cnt : 0u) + seg_found;
+            carry_seq = seq_last;
+        } else {
+            if (found) o.flags[hay] = 1;
+        }
+        q2_head += nb;
+    };
 
     // software pipeline: the next chunk's 16 B per lane (+ the 4 bytes before them) are requested
-    // before the current chunk is filtered and verified, so HBM latency hides behind that work
+    // before the current chunk is filtered and probed, so HBM latency hides behind that work
     auto fetch = [&](uint64_t cc, uint4& v, uint32_t& prev) {
         const uint64_t p = cc * kSfChunk + lane * 16u;
         v = make_uint4(0, 0, 0, 0); prev = 0;
@@ -107,11 +166,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (p >= 4) prev = *reinterpret_cast<const uint32_t*>(b.text + p - 4);
         }
     };
-    uint64_t c = (uint64_t)blockIdx.x * kSfWaves + wave;
+    uint64_t c = c_first;
     uint4 cur_v; uint32_t cur_prev;
     fetch(c, cur_v, cur_prev);
 
-    for (; c < n_chunks; c += n_waves) {
+    for (uint32_t seq = 0; c < n_chunks; c += n_waves, seq++) {
         uint4 next_v; uint32_t next_prev;
         fetch(c + n_waves, next_v, next_prev);
 
@@ -134,56 +193,55 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (sf_filter_window(bloom, log2_words, tiers, w)) cand |= 1u << k;
         }
         if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
+        if (o.ablate == 1) cand = 0;               // timing experiment only
 
-        // compact candidate positions into the wave's LDS queue, in position order
-        const uint32_t n = __popc(cand);
-        const uint32_t incl = wave_inclusive_sum(n, lane);
-        const uint32_t n_cand = __shfl(incl, 63, 64);
-        uint32_t idx = incl - n;
-        while (cand) {
-            const uint32_t k = __builtin_ctz(cand);
-            cand &= cand - 1u;
-            q[idx++] = (uint16_t)(lane * 16u + k);
-        }
-        wave_lds_fence();
-
-        uint32_t nrec = 0;
-        const uint64_t out_base = MODE == kModeEmit ? o.unit_offsets[c] : 0;
-        for (uint32_t base = 0; base < n_cand; base += 64 * ILP) {
-            uint64_t gpos[ILP], avail[ILP];
-            uint32_t hay[ILP], state[ILP], vlen[ILP];
-            bool valid[ILP], found[ILP];
-#pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                const uint32_t e = base + 64u * k + lane;
-                valid[k] = e < n_cand;
-                gpos[k] = c0 + (valid[k] ? q[e] : 0u);
-                hay[k] = hay0; avail[k] = gpos[k] - hs0 + 1;
-                state[k] = 0; vlen[k] = 0;
-                if (valid[k] && !single) { hay[k] = find_haystack(b, gpos[k]); avail[k] = gpos[k] - b.offsets[hay[k]] + 1; }
+        for (;;) {
+            // compact (up to kSfQ1) candidate positions into the wave's LDS queue, in position order
+            const uint32_t n = __popc(cand);
+            const uint32_t incl = wave_inclusive_sum(n, lane);
+            const uint32_t total = __shfl(incl, 63, 64);
+            if (total == 0) break;
+            uint32_t idx = incl - n;
+            while (cand && idx < (uint32_t)kSfQ1) {
+                const uint32_t k = __builtin_ctz(cand);
+                cand &= cand - 1u;
+                q1[idx++] = (uint16_t)(lane * 16u + k);
             }
-            sf_verify_n<IC, ILP>(s, b.text, gpos, avail, valid, found, state, vlen);
+            const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
+            wave_lds_fence();
+
+            for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
+                uint64_t gpos[ILP], avail[ILP];
+                uint32_t pos[ILP], node[ILP];
+                bool valid[ILP];
 #pragma unroll
-            for (int k = 0; k < ILP; k++) {
-                const uint64_t ballot = __ballot(found[k]);
-                if (found[k]) {
-                    if (MODE == kModeCount) {
-                        nval += vlen[k];
-                        if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)vlen[k]);
-                    } else if (MODE == kModeEmit) {
-                        const uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
-                        o.records[out_base + nrec + rank] = Record{avail[k], hay[k], state[k]};    // avail == end_pos
-                    } else {
-                        o.flags[hay[k]] = 1;
-                    }
+                for (int k = 0; k < ILP; k++) {
+                    const uint32_t e = base + 64u * k + lane;
+                    valid[k] = e < n_q1;
+                    pos[k] = valid[k] ? q1[e] : 0u;
+                    gpos[k] = c0 + pos[k];
+                    avail[k] = gpos[k] - hs0 + 1;
+                    if (valid[k] && !single) avail[k] = gpos[k] - b.offsets[find_haystack(b, gpos[k])] + 1;
                 }
-                nrec += (uint32_t)__popcll(ballot);
+                sf_probe_n<IC, ILP>(s, b.text, gpos, avail, valid, node, o.ablate);
+#pragma unroll
+                for (int k = 0; k < ILP; k++) {
+                    const bool defer = valid[k] && node[k] != kNone;
+                    const uint64_t m = __ballot(defer);
+                    if (defer) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = make_uint2(node[k], (seq << 10) | pos[k]);
+                    q2_tail += (uint32_t)__popcll(m);
+                }
+                wave_lds_fence();
+                while (q2_tail - q2_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }   // keeps room for the next round
             }
+            if (total <= (uint32_t)kSfQ1) break;
+            wave_lds_fence();
         }
-        if (MODE == kModeCount && lane == 0) o.unit_counts[c] = nrec;
-        wave_lds_fence();      // the queue is rewritten by the next chunk
         cur_v = next_v; cur_prev = next_prev;
     }
+    wave_lds_fence();
+    while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u ? nb : 64u); }
+
     if (MODE == kModeCount) {
         nval = wave_sum_u64(nval);
         if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
@@ -246,7 +304,7 @@ hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, h
 uint64_t sf_units(const BatchView& b) { return (b.total + kSfChunk - 1) / kSfChunk; }
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
-size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * kSfQueue * sizeof(uint16_t); }
+size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint2)); }
 
 template <bool IC, int MODE, int ILP, bool NT>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
@@ -289,8 +347,11 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
     }
 }
 
-hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o_in, int n_cu, hipStream_t st)
 {
+    ScanOut o = o_in;
+    static const uint32_t ablate = [] { const char* e = std::getenv("AM_SF_ABLATE"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    o.ablate = ablate;
     if (ic) {
         if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);
         if (mode == kModeEmit) return launch_sf_t<true, kModeEmit>(s, b, o, n_cu, st);
