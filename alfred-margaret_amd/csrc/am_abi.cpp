@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -143,7 +144,7 @@ struct am_batch {
     bool owns = false;
     uint64_t total = 0; uint32_t n_hay = 0;
     std::mutex mu;              // guards the workspaces below (calls on one batch serialise)
-    DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags;
+    DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
 };
 
 struct am_matches {
@@ -313,7 +314,7 @@ extern "C" void am_batch_destroy(am_batch* b)
 {
     if (!b) return;
     if (b->owns) { if (b->d_text) (void)hipFree(b->d_text); if (b->d_offsets) (void)hipFree(b->d_offsets); }
-    for (DevBuf* d : {&b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags}) d->release();
+    for (DevBuf* d : {&b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next}) d->release();
     delete b;
 }
 
@@ -324,7 +325,7 @@ extern "C" uint64_t am_batch_total_bytes(const am_batch* b) { return b ? b->tota
 namespace {
 
 struct Plan {
-    const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units;
+    const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks;
     AcView ac; SfView sf; BatchView bv;
 };
 
@@ -341,7 +342,8 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     // no goto edge at all (no needles, or only empty needles): the reference never reports anything
     const bool no_edges = p.f->h.n_transitions == p.f->h.n_states;
     p.nothing = b->total == 0 || no_edges || (p.use_sf && p.f->h.sf_tiers == 0);
-    p.n_units = p.nothing ? 0 : (p.use_sf ? sf_units(p.bv) : ac_units(p.ac, p.bv));
+    p.unit_chunks = p.use_sf ? sf_unit_chunks(p.bv, g_rt.n_cu) : 0;
+    p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
     if (p.n_units >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "batch too large for one launch; split it");
     return AM_OK;
 }
@@ -371,13 +373,12 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
     if (p.nothing) return AM_OK;
     std::lock_guard<std::mutex> lk(b->mu);
     hipStream_t st; AM_TRY(get_stream(&st));
-    AM_TRY(b->unit_counts.ensure((p.n_units + 1) * sizeof(uint32_t)));
     AM_TRY(b->small.ensure(64));
     ScanOut o{};
-    o.unit_counts = (uint32_t*)b->unit_counts.p;
+    o.unit_chunks = p.unit_chunks;
+    if (!p.use_sf) { AM_TRY(b->unit_counts.ensure((p.n_units + 1) * sizeof(uint32_t))); o.unit_counts = (uint32_t*)b->unit_counts.p; }
     o.total_values = (uint64_t*)b->small.p;
     HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
-    HIP_TRY(hipMemsetAsync(b->unit_counts.p, 0, (p.n_units + 1) * sizeof(uint32_t), st));
     if (counts_out) {
         AM_TRY(b->hay_counts.ensure((size_t)b->n_hay * sizeof(uint64_t)));
         HIP_TRY(hipMemsetAsync(b->hay_counts.p, 0, (size_t)b->n_hay * sizeof(uint64_t), st));
@@ -405,6 +406,7 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     AM_TRY(b->flags.ensure(b->n_hay));
     HIP_TRY(hipMemsetAsync(b->flags.p, 0, b->n_hay, st));
     ScanOut o{};
+    o.unit_chunks = p.unit_chunks;
     o.flags = (uint8_t*)b->flags.p;
     AM_TRY(build_hidx(p, b, st));
     AM_TRY(launch_scan_kernel(p, kModeAny, o, st));
@@ -434,12 +436,18 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
     if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return bail(fail(AM_ERR_HIP, "hipcub scan sizing failed"));
     if ((rc = b->scan_tmp.ensure(tmp_bytes + 16)) != AM_OK) return bail(rc);
 
-    auto body = [&]() -> int {
+    auto alloc_records = [&](uint64_t total) -> int {
+        hipError_t e = hipMalloc((void**)&m->d_records, total * sizeof(Record));
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e));
+        return AM_OK;
+    };
+    // general kernel: count pass -> exclusive scan -> emit pass (unit = one lane's chunk)
+    auto body_ac = [&]() -> int {
         ScanOut o{};
         o.unit_counts = (uint32_t*)b->unit_counts.p;
         o.total_values = (uint64_t*)b->small.p;
         HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
-        HIP_TRY(hipMemsetAsync(b->unit_counts.p, 0, n * sizeof(uint32_t), st));   // k_sf adds per chunk; [n_units] stays 0
+        HIP_TRY(hipMemsetAsync((uint32_t*)b->unit_counts.p + p.n_units, 0, sizeof(uint32_t), st));
         AM_TRY(build_hidx(p, b, st));
         AM_TRY(launch_scan_kernel(p, kModeCount, o, st));
         { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
@@ -448,8 +456,7 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
         HIP_TRY(hipStreamSynchronize(st));
         m->n = total;
         if (total == 0) return AM_OK;
-        hipError_t e = hipMalloc((void**)&m->d_records, total * sizeof(Record));
-        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e));
+        AM_TRY(alloc_records(total));
         ScanOut w{};
         w.unit_offsets = (const uint64_t*)b->unit_offsets.p;
         w.records = m->d_records;
@@ -457,6 +464,47 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
         HIP_TRY(hipStreamSynchronize(st));
         return AM_OK;
     };
+    // suffix-filter kernel: ONE scan pass writes records into pool blocks (chained per unit), then
+    // scan(unit_counts) + k_permute put them in order.  The pool size is a guess (1 record per 128
+    // haystack bytes + one block per unit); if it overflows the kernel still counts, and the pass is
+    // repeated once with the exact number of blocks.
+    auto body_sf = [&]() -> int {
+        AM_TRY(b->unit_first.ensure(p.n_units * sizeof(uint32_t)));
+        uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024;
+        if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
+        if (const char* env = std::getenv("AM_SF_POOL_BLOCKS")) { long v = std::atol(env); if (v > 0) want_blocks = (uint64_t)v; }   // tests: force the overflow/retry path
+        for (int attempt = 0; attempt < 3; attempt++) {
+            if (want_blocks >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
+            AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
+            AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
+            ScanOut o{};
+            o.unit_chunks = p.unit_chunks;
+            o.unit_counts = (uint32_t*)b->unit_counts.p;
+            o.unit_first = (uint32_t*)b->unit_first.p;
+            o.pool = (Record*)b->pool.p;
+            o.block_next = (uint32_t*)b->block_next.p;
+            o.pool_ctrl = (uint32_t*)b->small.p + 4;            // small: [0..1] total_values, [4] block counter, [5] overflow
+            o.n_blocks = (uint32_t)want_blocks;
+            HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
+            HIP_TRY(hipMemsetAsync((uint32_t*)b->unit_counts.p + p.n_units, 0, sizeof(uint32_t), st));
+            AM_TRY(build_hidx(p, b, st));
+            AM_TRY(launch_scan_kernel(p, kModeEmit, o, st));
+            { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
+            uint64_t total = 0; uint32_t ctrl[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64; continue; }    // pool too small: ctrl[0] = blocks actually needed
+            m->n = total;
+            if (total == 0) return AM_OK;
+            AM_TRY(alloc_records(total));
+            { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, m->d_records, p.n_units, st)); }
+            HIP_TRY(hipStreamSynchronize(st));
+            return AM_OK;
+        }
+        return fail(AM_ERR_HIP, "record pool overflowed repeatedly (internal error)");
+    };
+    auto body = [&]() -> int { return p.use_sf ? body_sf() : body_ac(); };
     rc = body();
     if (rc != AM_OK) return bail(rc);
     *out = m;

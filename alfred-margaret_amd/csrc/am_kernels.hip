@@ -79,13 +79,15 @@ constexpr int kSfQ2 = 192;                       // per-wave ring of deferred it
 // ILP = candidates probed per lane per round (their loads are in flight together);
 // NT  = stream the haystack with non-temporal loads.
 //
+// Work unit = `unit_chunks` consecutive 1-KiB chunks; units are dealt round-robin to wavefronts.
 // Structure of one wavefront's loop (everything between two filter steps is wave-synchronous):
 //   filter   16 positions per lane against the LDS Bloom filter                      (LDS + VALU only)
 //   probe    surviving positions, 64*ILP at a time: last 8 haystack bytes + both cuckoo slots; no
 //            data-dependent loop, so every lane runs the same three loads            (phase 1)
 //   resolve  the few candidates that hit the suffix table AND continue in the trie (or end a needle)
 //            are parked in a ring and walked 64 at a time, across chunk boundaries   (phase 2)
-// Phase 2 is FIFO, so records of a chunk come out in position order without atomics or sorting.
+// Phase 2 is FIFO, so the records of a unit come out in position order: ballot + popcount rank them,
+// and they are appended to the unit's chain of 64-record pool blocks (one atomic per block).
 template <bool IC, int MODE, int ILP, bool NT>
 __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
@@ -103,22 +105,24 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     uint2* q2 = q2_all + wave * kSfQ2;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
-    const uint64_t c_first = (uint64_t)blockIdx.x * kSfWaves + wave;
+    const uint32_t UC = o.unit_chunks;
+    const uint64_t n_units = (n_chunks + UC - 1) / UC;
     uint64_t nval = 0;
     uint32_t q2_head = 0, q2_tail = 0;                   // monotonic; slot = index % kSfQ2
-    uint32_t carry_seq = 0xFFFFFFFFu, carry_cnt = 0;     // emit mode: records already written for the newest chunk seen
+    // emit mode: state of the unit being written
+    uint64_t unit_base_chunk = 0;
+    uint32_t unit_count = 0, cur_block = kNone, first_block = kNone;
+    bool pool_ok = true;
 
-    // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items
+    // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items (all belong to the current unit)
     auto resolve_batch = [&](uint32_t nb) {
         const bool valid = lane < nb;
         bool found = false;
-        uint32_t state = 0, vlen = 0, hay = 0, seq_i = 0;
-        uint64_t end_pos = 0, chunk_i = 0;
+        uint32_t state = 0, vlen = 0, hay = 0;
+        uint64_t end_pos = 0;
         if (valid) {
             const uint2 item = q2[(q2_head + lane) % kSfQ2];
-            seq_i = item.y >> 10;
-            chunk_i = c_first + (uint64_t)seq_i * n_waves;
-            const uint64_t gpos = chunk_i * kSfChunk + (item.y & 1023u);
+            const uint64_t gpos = (unit_base_chunk + (item.y >> 10)) * kSfChunk + (item.y & 1023u);
             hay = find_haystack(b, gpos);
             end_pos = gpos - b.offsets[hay] + 1;
             found = sf_resolve<IC>(s, b.text, gpos, end_pos, item.x, state, vlen);
@@ -126,27 +130,35 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         const uint64_t found_mask = __ballot(found);
         if (MODE == kModeCount) {
             if (found) {
-                atomicAdd(o.unit_counts + chunk_i, 1u);     // zeroed by the host; only this wave touches it
                 nval += vlen;
                 if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
             }
         } else if (MODE == kModeEmit) {
-            // items are in position order (FIFO), so a record's slot inside its chunk is the number of
-            // earlier records of that chunk: those in earlier lanes of its segment + the carry
-            const uint32_t prev_seq = __shfl_up(seq_i, 1, 64);
-            const uint64_t head_mask = __ballot(valid && (lane == 0 || seq_i != prev_seq));
-            const uint64_t le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
-            const uint32_t my_head = 63u - (uint32_t)__builtin_clzll(head_mask & le);
-            const uint64_t below_me = (1ull << lane) - 1ull, below_head = (1ull << my_head) - 1ull;
-            const uint32_t rank = (uint32_t)__popcll(found_mask & below_me & ~below_head);
-            if (found) {
-                const uint32_t base_cnt = seq_i == carry_seq ? carry_cnt : 0u;
-                o.records[o.unit_offsets[chunk_i] + base_cnt + rank] = Record{end_pos, hay, state};
+            const uint32_t F = (uint32_t)__popcll(found_mask);
+            if (F) {
+                const uint32_t r = unit_count & (kPoolBlock - 1u);      // fill of the current block
+                const bool need_new = r == 0u || r + F > kPoolBlock;
+                uint32_t new_block = kNone;
+                if (need_new) {
+                    uint32_t id = 0;
+                    if (lane == 0) id = atomicAdd(o.pool_ctrl, 1u);
+                    id = __builtin_amdgcn_readfirstlane(id);
+                    if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }   // keep counting, host retries with a larger pool
+                    else {
+                        new_block = id;
+                        if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
+                        if (first_block == kNone) first_block = id;
+                    }
+                }
+                if (found && pool_ok) {
+                    const uint32_t p = r + (uint32_t)__popcll(found_mask & ((1ull << lane) - 1ull));
+                    const Record rec{end_pos, hay, state};
+                    if (r != 0u && p < kPoolBlock) o.pool[(uint64_t)cur_block * kPoolBlock + p] = rec;
+                    else o.pool[(uint64_t)new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p)] = rec;
+                }
+                if (need_new) cur_block = new_block;
+                unit_count += F;
             }
-            const uint32_t seq_last = __shfl(seq_i, (int)nb - 1, 64), head_last = __shfl(my_head, (int)nb - 1, 64);
-            const uint32_t seg_found = (uint32_t)__popcll(found_mask & ~((1ull << head_last) - 1ull));
-            carry_cnt = (seq_last == carry_seq ? carry_cnt : 0u) + seg_found;
-            carry_seq = seq_last;
         } else {
             if (found) o.flags[hay] = 1;
         }
@@ -166,85 +178,108 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (p >= 4) prev = *reinterpret_cast<const uint32_t*>(b.text + p - 4);
         }
     };
-    uint64_t c = c_first;
+    uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
     uint4 cur_v; uint32_t cur_prev;
-    fetch(c, cur_v, cur_prev);
+    fetch(u * UC, cur_v, cur_prev);
 
-    for (uint32_t seq = 0; c < n_chunks; c += n_waves, seq++) {
-        uint4 next_v; uint32_t next_prev;
-        fetch(c + n_waves, next_v, next_prev);
+    for (; u < n_units; u += n_waves) {
+        unit_base_chunk = u * UC;
+        unit_count = 0; cur_block = kNone; first_block = kNone;
+        const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
+        for (uint32_t ci = 0; ci < n_in_unit; ci++) {
+            const uint64_t c = unit_base_chunk + ci;
+            uint4 next_v; uint32_t next_prev;
+            fetch(ci + 1 < n_in_unit ? c + 1 : (u + n_waves) * UC, next_v, next_prev);
 
-        const uint64_t c0 = c * kSfChunk;
-        const uint64_t p0 = c0 + lane * 16u;
-        // haystack of the chunk's first byte (same address in every lane: one request per load); almost
-        // every chunk lies inside one haystack, then no candidate needs its own lookup
-        const uint32_t hay0 = find_haystack(b, c0);
-        const uint64_t hs0 = b.offsets[hay0], he0 = b.offsets[hay0 + 1];
-        const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
+            const uint64_t c0 = c * kSfChunk;
+            const uint64_t p0 = c0 + lane * 16u;
+            // haystack of the chunk's first byte (same address in every lane: one request per load); almost
+            // every chunk lies inside one haystack, then no candidate needs its own lookup
+            const uint32_t hay0 = find_haystack(b, c0);
+            const uint64_t hs0 = b.offsets[hay0], he0 = b.offsets[hay0 + 1];
+            const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
 
-        uint32_t d0 = cur_prev, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
-        if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
-        const uint32_t d[5] = {d0, d1, d2, d3, d4};
-        uint32_t cand = 0;
+            uint32_t d0 = cur_prev, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+            if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+            const uint32_t d[5] = {d0, d1, d2, d3, d4};
+            uint32_t cand = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int j = k >> 2, sh = k & 3;      // window = bytes k-3..k of the lane's 16, newest byte on top
-            const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
-            if (sf_filter_window(bloom, log2_words, tiers, w)) cand |= 1u << k;
-        }
-        if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
-        if (o.ablate == 1) cand = 0;               // timing experiment only
-
-        for (;;) {
-            // compact (up to kSfQ1) candidate positions into the wave's LDS queue, in position order
-            const uint32_t n = __popc(cand);
-            const uint32_t incl = wave_inclusive_sum(n, lane);
-            const uint32_t total = __shfl(incl, 63, 64);
-            if (total == 0) break;
-            uint32_t idx = incl - n;
-            while (cand && idx < (uint32_t)kSfQ1) {
-                const uint32_t k = __builtin_ctz(cand);
-                cand &= cand - 1u;
-                q1[idx++] = (uint16_t)(lane * 16u + k);
+            for (int k = 0; k < 16; k++) {
+                const int j = k >> 2, sh = k & 3;      // window = bytes k-3..k of the lane's 16, newest byte on top
+                const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
+                if (sf_filter_window(bloom, log2_words, tiers, w)) cand |= 1u << k;
             }
-            const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
-            wave_lds_fence();
+            if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
+            if (o.ablate == 1) cand = 0;               // timing experiment only
 
-            for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
-                uint64_t gpos[ILP], avail[ILP];
-                uint32_t pos[ILP], node[ILP];
-                bool valid[ILP];
-#pragma unroll
-                for (int k = 0; k < ILP; k++) {
-                    const uint32_t e = base + 64u * k + lane;
-                    valid[k] = e < n_q1;
-                    pos[k] = valid[k] ? q1[e] : 0u;
-                    gpos[k] = c0 + pos[k];
-                    avail[k] = gpos[k] - hs0 + 1;
-                    if (valid[k] && !single) avail[k] = gpos[k] - b.offsets[find_haystack(b, gpos[k])] + 1;
+            for (;;) {
+                // compact (up to kSfQ1) candidate positions into the wave's LDS queue, in position order
+                const uint32_t n = __popc(cand);
+                const uint32_t incl = wave_inclusive_sum(n, lane);
+                const uint32_t total = __shfl(incl, 63, 64);
+                if (total == 0) break;
+                uint32_t idx = incl - n;
+                while (cand && idx < (uint32_t)kSfQ1) {
+                    const uint32_t k = __builtin_ctz(cand);
+                    cand &= cand - 1u;
+                    q1[idx++] = (uint16_t)(lane * 16u + k);
                 }
-                sf_probe_n<IC, ILP>(s, b.text, gpos, avail, valid, node, o.ablate);
-#pragma unroll
-                for (int k = 0; k < ILP; k++) {
-                    const bool defer = valid[k] && node[k] != kNone;
-                    const uint64_t m = __ballot(defer);
-                    if (defer) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = make_uint2(node[k], (seq << 10) | pos[k]);
-                    q2_tail += (uint32_t)__popcll(m);
-                }
+                const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
                 wave_lds_fence();
-                while (q2_tail - q2_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }   // keeps room for the next round
+
+                for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
+                    uint64_t gpos[ILP], avail[ILP];
+                    uint32_t pos[ILP], node[ILP];
+                    bool valid[ILP];
+#pragma unroll
+                    for (int k = 0; k < ILP; k++) {
+                        const uint32_t e = base + 64u * k + lane;
+                        valid[k] = e < n_q1;
+                        pos[k] = valid[k] ? q1[e] : 0u;
+                        gpos[k] = c0 + pos[k];
+                        avail[k] = gpos[k] - hs0 + 1;
+                        if (valid[k] && !single) avail[k] = gpos[k] - b.offsets[find_haystack(b, gpos[k])] + 1;
+                    }
+                    sf_probe_n<IC, ILP>(s, b.text, gpos, avail, valid, node, o.ablate);
+#pragma unroll
+                    for (int k = 0; k < ILP; k++) {
+                        const bool defer = valid[k] && node[k] != kNone;
+                        const uint64_t m = __ballot(defer);
+                        if (defer) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = make_uint2(node[k], (ci << 10) | pos[k]);
+                        q2_tail += (uint32_t)__popcll(m);
+                    }
+                    wave_lds_fence();
+                    while (q2_tail - q2_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }   // keeps room for the next round
+                }
+                if (total <= (uint32_t)kSfQ1) break;
+                wave_lds_fence();
             }
-            if (total <= (uint32_t)kSfQ1) break;
-            wave_lds_fence();
+            cur_v = next_v; cur_prev = next_prev;
         }
-        cur_v = next_v; cur_prev = next_prev;
+        // end of unit: drain the ring so that every item of a batch belongs to one unit
+        wave_lds_fence();
+        while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u ? nb : 64u); }
+        if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; }
     }
-    wave_lds_fence();
-    while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u ? nb : 64u); }
 
     if (MODE == kModeCount) {
         nval = wave_sum_u64(nval);
         if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+    }
+}
+
+// copy every unit's chain of pool blocks to its final place (one wavefront per unit)
+__global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __restrict__ unit_offsets, Record* __restrict__ out, uint64_t n_units)
+{
+    const uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (u >= n_units) return;
+    const uint32_t n = o.unit_counts[u];
+    const uint64_t base = unit_offsets[u];
+    uint32_t blk = o.unit_first[u];
+    for (uint32_t done = 0; done < n; done += kPoolBlock) {
+        if (done + lane < n) out[base + done + lane] = o.pool[(uint64_t)blk * kPoolBlock + lane];
+        blk = o.block_next[blk];
     }
 }
 
@@ -301,7 +336,25 @@ hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, h
     return hipGetLastError();
 }
 
-uint64_t sf_units(const BatchView& b) { return (b.total + kSfChunk - 1) / kSfChunk; }
+uint64_t sf_chunks(const BatchView& b) { return (b.total + kSfChunk - 1) / kSfChunk; }
+
+// chunks per work unit: 64 KiB units for big batches, smaller ones when that would leave wavefronts idle
+uint32_t sf_unit_chunks(const BatchView& b, int n_cu)
+{
+    const uint64_t n_chunks = sf_chunks(b), waves = (uint64_t)n_cu * kSfWaves * 4;
+    uint64_t uc = n_chunks / (waves ? waves : 1);
+    if (uc < 1) uc = 1;
+    if (uc > 64) uc = 64;
+    return (uint32_t)uc;
+}
+
+hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record* out, uint64_t n_units, hipStream_t st)
+{
+    if (n_units == 0) return hipSuccess;
+    const uint64_t blocks = (n_units * 64 + 255) / 256;
+    hipLaunchKernelGGL(k_permute, dim3((uint32_t)blocks), dim3(256), 0, st, o, unit_offsets, out, n_units);
+    return hipGetLastError();
+}
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
 size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint2)); }
@@ -317,10 +370,11 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
             (void)hipGetLastError();
         attr_set = true;
     }
-    const uint64_t n_chunks = sf_units(b);
+    const uint64_t n_chunks = sf_chunks(b);
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     uint64_t blocks = (uint64_t)n_cu * per_cu;
-    const uint64_t need = (n_chunks + kSfWaves - 1) / kSfWaves;
+    const uint64_t n_units = (n_chunks + o.unit_chunks - 1) / o.unit_chunks;
+    const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL((k_sf<IC, MODE, ILP, NT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);

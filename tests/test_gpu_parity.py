@@ -109,6 +109,14 @@ def test_edge_shapes():
     check_all_paths(["é", "éé", "日本", "𝄞"], ["éééé日本語𝄞𝄞", "日", "𝄞"], 0)                  # 1-4 byte needles: all suffix tiers
 
 
+def test_record_pool_overflow_retry(monkeypatch):
+    # the single-pass emit guesses its record pool; force a 1-block pool so the retry path runs
+    monkeypatch.setenv("AM_SF_POOL_BLOCKS", "1")
+    check_all_paths(["a", "aa", "aaa", "ab"], ["a" * 3000 + "b" + "a" * 500, "ab" * 700, "", "a"], 0)
+    monkeypatch.delenv("AM_SF_POOL_BLOCKS")
+    check_all_paths(["a", "aa", "aaa", "ab"], ["a" * 3000 + "b" + "a" * 500, "ab" * 700, "", "a"], 0)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_fragment_pool(seed):
     rng = random.Random(seed)
