@@ -88,7 +88,7 @@ constexpr int kSfQ2 = 192;                       // per-wave ring of deferred it
 //            are parked in a ring and walked 64 at a time, across chunk boundaries   (phase 2)
 // Phase 2 is FIFO, so the records of a unit come out in position order: ballot + popcount rank them,
 // and they are appended to the unit's chain of 64-record pool blocks (one atomic per block).
-template <bool IC, int MODE, int ILP, bool NT>
+template <bool IC, int MODE, int ILP, bool NT, bool SHORT>
 __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -203,11 +203,29 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
             const uint32_t d[5] = {d0, d1, d2, d3, d4};
             uint32_t cand = 0;
+            {
+                // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 16 LDS reads are all in
+                // flight before the first one is tested
+                uint32_t h[16], v[16];
+                const uint32_t sh_word = 32u - log2_words;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int j = k >> 2, sh = k & 3;      // window = bytes k-3..k of the lane's 16, newest byte on top
-                const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
-                if (sf_filter_window(bloom, log2_words, tiers, w)) cand |= 1u << k;
+                for (int k = 0; k < 16; k++) {
+                    const int j = k >> 2, sh = k & 3;      // window = bytes k-3..k of the lane's 16, newest byte on top
+                    const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
+                    h[k] = w * kBloomMul;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) v[k] = bloom[h[k] >> sh_word];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { const uint32_t m = bloom_mask(h[k]); if ((v[k] & m) == m) cand |= 1u << k; }
+            }
+            if (SHORT) {                                   // automata with 1..3-byte needles: extra probes per position
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int j = k >> 2, sh = k & 3;
+                    const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
+                    if (sf_filter_short(bloom, log2_words, tiers, w)) cand |= 1u << k;
+                }
             }
             if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
             if (o.ablate == 1) cand = 0;               // timing experiment only
@@ -359,14 +377,14 @@ uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chu
 
 size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint2)); }
 
-template <bool IC, int MODE, int ILP, bool NT>
+template <bool IC, int MODE, int ILP, bool NT, bool SHORT>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const size_t lds = sf_lds_bytes(s);
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, NT, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
@@ -377,27 +395,25 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, NT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
+    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, NT, SHORT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
     return hipGetLastError();
 }
 
-// tuning variant: AM_SF_VARIANT = ilp * 10 + nt  (ilp in {1,2,4}, nt in {0,1}); default 21
+// tuning variant: AM_SF_VARIANT = ilp * 10 + nt; default 20
 static int sf_variant()
 {
-    static int v = [] { const char* e = std::getenv("AM_SF_VARIANT"); return e ? std::atoi(e) : 21; }();
+    static int v = [] { const char* e = std::getenv("AM_SF_VARIANT"); return e ? std::atoi(e) : 20; }();
     return v;
 }
 
 template <bool IC, int MODE>
 static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
+    if (s.tiers & 7u) return launch_sf_v<IC, MODE, 2, false, true>(s, b, o, n_cu, st);     // needles shorter than 4 bytes present
     switch (sf_variant()) {
-        case 10: return launch_sf_v<IC, MODE, 1, false>(s, b, o, n_cu, st);
-        case 11: return launch_sf_v<IC, MODE, 1, true>(s, b, o, n_cu, st);
-        case 20: return launch_sf_v<IC, MODE, 2, false>(s, b, o, n_cu, st);
-        case 40: return launch_sf_v<IC, MODE, 4, false>(s, b, o, n_cu, st);
-        case 41: return launch_sf_v<IC, MODE, 4, true>(s, b, o, n_cu, st);
-        default: return launch_sf_v<IC, MODE, 2, true>(s, b, o, n_cu, st);
+        case 10: return launch_sf_v<IC, MODE, 1, false, false>(s, b, o, n_cu, st);
+        case 21: return launch_sf_v<IC, MODE, 2, true, false>(s, b, o, n_cu, st);
+        default: return launch_sf_v<IC, MODE, 2, false, false>(s, b, o, n_cu, st);
     }
 }
 
