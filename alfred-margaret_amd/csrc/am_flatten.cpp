@@ -421,35 +421,62 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         h.off_tier[t] = blob.put(tab);
     }
     {
-        // 4-byte suffixes: 2-choice cuckoo table of 16-byte entries {key, node, state + 1, node.w}; the
-        // depth-4 node's terminal flag and edge summary ride along with the key, so one fetch of both
-        // candidate slots decides almost every probe without touching the node.
+        // 4-byte suffixes: (2,4) cuckoo hashing -- 2 candidate buckets of 4 slots per key, ~85 % full.
+        // HOT side: 4 bytes per slot (fingerprint, single-edge selector byte, flags) = 16 B per bucket;
+        // for 100k needles that is 0.5 MiB, resident in every XCD's L2 next to the streamed haystack.
+        // COLD side: full key + node id per slot, touched only when a needle may really end there.
         const std::vector<TierEntry>& ents = tier_entries[3];
-        uint32_t lc = std::max(4u, log2_ceil(ents.size() * 2 + 1));
-        std::vector<uint32_t> slot_owner;
-        for (;; lc++) {
-            if (lc > 28) { err = "suffix table too large"; return -1; }
-            slot_owner.assign((size_t)1 << lc, kNone);
+        uint32_t lb = 2;
+        while (((uint64_t)4 << lb) * 85 < (uint64_t)ents.size() * 100) lb++;
+        std::vector<uint32_t> owner;          // slot -> entry index
+        for (;; lb++) {
+            if (lb > 26) { err = "suffix table too large"; return -1; }
+            owner.assign((size_t)4 << lb, kNone);
             bool ok = true;
+            uint32_t rng = 0x12345u;
             for (uint32_t k = 0; k < ents.size() && ok; k++) {
                 uint32_t cur = k;
-                uint32_t pos = tier4_slot_a(ents[cur].key, lc);
+                uint32_t bucket = t4_bucket(t4_hash_a(ents[cur].key), lb);
                 for (int kicks = 0;; kicks++) {
-                    if (slot_owner[pos] == kNone) { slot_owner[pos] = cur; break; }
-                    if (ents[slot_owner[pos]].key == ents[cur].key) { err = "duplicate suffix key (internal error)"; return -1; }
-                    if (kicks > 500) { ok = false; break; }
-                    std::swap(cur, slot_owner[pos]);          // evict the resident, move it to its other slot
-                    const uint32_t a = tier4_slot_a(ents[cur].key, lc), b = tier4_slot_b(ents[cur].key, lc);
-                    pos = (pos == a) ? b : a;
+                    const uint32_t ba = t4_bucket(t4_hash_a(ents[cur].key), lb), bb = t4_bucket(t4_hash_b(ents[cur].key), lb);
+                    bool placed = false;
+                    for (uint32_t bsel : {ba, bb}) {
+                        for (uint32_t j = 0; j < 4 && !placed; j++) {
+                            uint32_t& o = owner[4u * bsel + j];
+                            if (o != kNone && ents[o].key == ents[cur].key) { err = "duplicate suffix key (internal error)"; return -1; }
+                            if (o == kNone) { o = cur; placed = true; }
+                        }
+                        if (placed) break;
+                    }
+                    if (placed) break;
+                    if (kicks > 1000) { ok = false; break; }
+                    // evict a pseudo-random resident of the bucket we did not come from
+                    bucket = (bucket == ba) ? bb : ba;
+                    rng = rng * 1664525u + 1013904223u;
+                    std::swap(cur, owner[4u * bucket + (rng >> 30)]);
                 }
             }
             if (ok) break;
         }
-        h.tier_log2_cap[3] = lc;
-        std::vector<u32x4> tab((size_t)1 << lc, u32x4{0, kNone, 0, 0});
-        for (size_t i = 0; i < slot_owner.size(); i++)
-            if (slot_owner[i] != kNone) { const TierEntry& e = ents[slot_owner[i]]; tab[i] = u32x4{e.key, e.node, nodes[e.node].x, nodes[e.node].w}; }
-        h.off_tier[3] = blob.put(tab);
+        h.tier_log2_cap[3] = lb;
+        std::vector<u32x4> hot((size_t)1 << lb, u32x4{0, 0, 0, 0});
+        std::vector<uint32_t> cold_keys((size_t)4 << lb, 0), cold_nodes((size_t)4 << lb, kNone);
+        for (size_t sl = 0; sl < owner.size(); sl++) {
+            if (owner[sl] == kNone) continue;
+            const TierEntry& e = ents[owner[sl]];
+            const SfNode& nd = nodes[e.node];
+            const uint32_t n_edges = nd.w & 0xFFFFu;
+            uint32_t word = t4_fingerprint(t4_hash_a(e.key), lb) | kT4Occupied;
+            if (nd.x) word |= kT4Terminal;
+            if (n_edges == 1) word |= kT4Single | (((nd.w >> 16) & 0xFFu) << 16);
+            else if (n_edges > 1) word |= kT4Multi;
+            uint32_t* bw = &hot[sl >> 2].x;
+            bw[sl & 3] = word;
+            cold_keys[sl] = e.key; cold_nodes[sl] = e.node;
+        }
+        h.off_tier[3] = blob.put(hot);
+        h.off_t4_keys = blob.put(cold_keys);
+        h.off_t4_nodes = blob.put(cold_nodes);
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);

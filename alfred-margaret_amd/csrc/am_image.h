@@ -57,12 +57,14 @@ struct ImageHeader {
     uint32_t sf_bloom_log2_words;
     uint32_t sf_n_nodes, sf_pad;
     uint64_t off_bloom;         // u32[1 << sf_bloom_log2_words]
-    uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}; tier 4: u32x4{key, node, state + 1, node meta}; [1 << tier_log2_cap[t]]
+    uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}[1 << cap]; tier 4: hot fingerprint buckets u32x4[1 << cap] (4 slots each)
     uint32_t tier_log2_cap[4];
     uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
     uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
     uint64_t n_edges;
-    uint64_t reserved[4];
+    uint64_t off_t4_keys;       // cold side of tier 4: full 4-byte key of every slot, u32[4 << cap]
+    uint64_t off_t4_nodes;      // and its depth-4 trie node,                       u32[4 << cap]
+    uint64_t reserved[2];
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -100,7 +102,13 @@ constexpr uint32_t kMaxSkip = 16;
 struct SfView {
     const uint32_t* bloom;
     const u32x2* tier[3];    // exact tables for needles (variants) of exactly 1, 2, 3 bytes
-    const u32x4* tier4;      // exact table of 4-byte suffixes: {key, node, state + 1 of that node, its SfNode.w}: one 16 B load decides most candidates
+    // 4-byte suffixes: (2,4) cuckoo table.  A key lives in one of the 4 slots of bucket_a(key) or
+    // bucket_b(key).  HOT side (what the probe reads, 16 B per bucket, ~0.5 MiB for 100k needles, so
+    // it stays in each XCD's L2): per slot a 16-bit fingerprint, the selector byte of the node's
+    // single edge, and flags.  COLD side (read only by sf_resolve): the full key and the node id.
+    const u32x4* t4_hot;
+    const uint32_t* t4_keys;
+    const uint32_t* t4_nodes;
     const SfNode* nodes;
     const SfEdge* edges;
     uint32_t bloom_log2_words, tiers;
@@ -135,7 +143,9 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     SfView v;
     v.bloom = (const uint32_t*)(b + h.off_bloom);
     for (int t = 0; t < 3; t++) v.tier[t] = (const u32x2*)(b + h.off_tier[t]);
-    v.tier4 = (const u32x4*)(b + h.off_tier[3]);
+    v.t4_hot = (const u32x4*)(b + h.off_tier[3]);
+    v.t4_keys = (const uint32_t*)(b + h.off_t4_keys);
+    v.t4_nodes = (const uint32_t*)(b + h.off_t4_nodes);
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
     v.edges = (const SfEdge*)(b + h.off_edges);
@@ -289,87 +299,114 @@ AM_HD void load_node(const SfNode* p, SfNode& n)
 #endif
 }
 
-// The 4-byte suffix table is a 2-choice cuckoo table: a key lives in slot_a(key) or slot_b(key), both
-// entries are fetched together, and there is no probe loop (nothing data-dependent to diverge on).
-AM_HD uint32_t tier4_slot_a(uint32_t key, uint32_t log2_cap) { return (key * 0x85EBCA6Bu) >> (32u - log2_cap); }
-AM_HD uint32_t tier4_slot_b(uint32_t key, uint32_t log2_cap) { return ((key ^ (key >> 15)) * 0xC2B2AE35u) >> (32u - log2_cap); }
+// Tier-4 hashing.  One multiply gives bucket A (top bits) and the fingerprint (the 16 bits below
+// them); a second, differently mixed multiply gives bucket B.
+AM_HD uint32_t t4_hash_a(uint32_t key) { return key * 0x85EBCA6Bu; }
+AM_HD uint32_t t4_hash_b(uint32_t key) { return (key ^ (key >> 15)) * 0xC2B2AE35u; }
+AM_HD uint32_t t4_bucket(uint32_t h, uint32_t log2_buckets) { return h >> (32u - log2_buckets); }
+AM_HD uint32_t t4_fingerprint(uint32_t ha, uint32_t log2_buckets) { return (ha >> (log2_buckets < 16u ? 16u - log2_buckets : 0u)) & 0xFFFFu; }
+// hot slot word: fingerprint (0-15) | selector byte of the node's single edge (16-23) | flags (24-31)
+constexpr uint32_t kT4Occupied = 1u << 24;    // slot in use
+constexpr uint32_t kT4Terminal = 1u << 25;    // a 4-byte needle (variant) ends at the node
+constexpr uint32_t kT4Single = 1u << 26;      // the node has exactly one outgoing edge (selector byte valid)
+constexpr uint32_t kT4Multi = 1u << 27;       // the node has several outgoing edges
 
-constexpr uint32_t kShortOnly = 0xFFFFFFFEu;    // "no depth-4 node, but the 1..3-byte tables must be consulted"
-
-// Phase 1, N candidates per lane at once (all loads of all N in flight together): the last 8 haystack
-// bytes and the two table entries decide almost every candidate.  node[k] = kNone: nothing ends at
-// this position.  Otherwise the candidate must be resolved by sf_resolve (a needle may end here):
-// node[k] = the depth-4 trie node to continue from, or kShortOnly.
-template <bool IC, int N>
-AM_HD void sf_probe_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail)[N],
-                      const bool (&valid)[N], uint32_t (&node)[N], uint32_t ablate = 0)
+// can this hot slot word belong to a needle ending at a position whose last 4 bytes hash to `fp`
+// and whose preceding byte is `nb` (ignored when the haystack has no more bytes: more == false)?
+AM_HD bool t4_slot_may_match(uint32_t slot, uint32_t fp, uint32_t nb, bool more)
 {
-    uint32_t w[N], w2[N];
+    if ((slot & (kT4Occupied | 0xFFFFu)) != (kT4Occupied | fp)) return false;
+    if (slot & kT4Terminal) return true;
+    if (!more) return false;
+    return (slot & kT4Multi) || ((slot & kT4Single) && ((slot >> 16) & 0xFFu) == nb);
+}
+
+// Phase 1, N candidates per lane at once.  Inputs come straight from the filter stage's registers
+// (w = the 4 bytes ending at the position, nb = the byte before them, both case-folded), so the only
+// memory traffic is the two hot buckets, both in flight together, no data-dependent loop.
+// defer[k] = true: a needle may end here, sf_resolve must look (exactly).
+template <int N>
+AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nb)[N], const uint64_t (&avail)[N],
+                      const bool (&valid)[N], bool (&defer)[N], uint32_t ablate = 0)
+{
+    u32x4 ba[N], bb[N];
+    uint32_t fp[N];
     bool probe[N];
-    u32x4 ea[N], eb[N];
+    const uint32_t lb = s.tier_log2_cap[3];
 #pragma unroll
-    for (int k = 0; k < N; k++) { w[k] = 0; w2[k] = 0; if (valid[k]) load_suffix8(text, gpos[k], avail[k], w[k], w2[k]); }
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-        if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
-        probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
-        node[k] = kNone;
-    }
-    if (ablate == 2) { for (int k = 0; k < N; k++) if (valid[k] && w[k] == 0x12345678u && w2[k] == 0x9abcdef0u) node[k] = 0; return; }   // timing experiment only
+    for (int k = 0; k < N; k++) probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
+    if (ablate == 2) { for (int k = 0; k < N; k++) defer[k] = valid[k] && w[k] == 0x12345678u && nb[k] == 0x9au; return; }   // timing experiment only
 #if defined(__HIP_DEVICE_COMPILE__)
     {
         uint4 ra[N], rb[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            ra[k] = make_uint4(0, kNone, 0, 0); rb[k] = ra[k];
+            const uint32_t ha = t4_hash_a(w[k]), hb = t4_hash_b(w[k]);
+            fp[k] = t4_fingerprint(ha, lb);
+            ra[k] = make_uint4(0, 0, 0, 0); rb[k] = ra[k];
             if (probe[k]) {
-                ra[k] = *reinterpret_cast<const uint4*>(s.tier4 + tier4_slot_a(w[k], s.tier_log2_cap[3]));
-                rb[k] = *reinterpret_cast<const uint4*>(s.tier4 + tier4_slot_b(w[k], s.tier_log2_cap[3]));
+                ra[k] = *reinterpret_cast<const uint4*>(s.t4_hot + t4_bucket(ha, lb));
+                rb[k] = *reinterpret_cast<const uint4*>(s.t4_hot + t4_bucket(hb, lb));
             }
         }
 #pragma unroll
         for (int k = 0; k < N; k++) {
             asm volatile("" : "+v"(ra[k].x), "+v"(ra[k].y), "+v"(ra[k].z), "+v"(ra[k].w), "+v"(rb[k].x), "+v"(rb[k].y), "+v"(rb[k].z), "+v"(rb[k].w));
-            ea[k] = u32x4{ra[k].x, ra[k].y, ra[k].z, ra[k].w};
-            eb[k] = u32x4{rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+            ba[k] = u32x4{ra[k].x, ra[k].y, ra[k].z, ra[k].w};
+            bb[k] = u32x4{rb[k].x, rb[k].y, rb[k].z, rb[k].w};
         }
     }
 #else
     for (int k = 0; k < N; k++) {
-        ea[k] = probe[k] ? s.tier4[tier4_slot_a(w[k], s.tier_log2_cap[3])] : u32x4{0, kNone, 0, 0};
-        eb[k] = probe[k] ? s.tier4[tier4_slot_b(w[k], s.tier_log2_cap[3])] : u32x4{0, kNone, 0, 0};
+        const uint32_t ha = t4_hash_a(w[k]), hb = t4_hash_b(w[k]);
+        fp[k] = t4_fingerprint(ha, lb);
+        ba[k] = probe[k] ? s.t4_hot[t4_bucket(ha, lb)] : u32x4{0, 0, 0, 0};
+        bb[k] = probe[k] ? s.t4_hot[t4_bucket(hb, lb)] : u32x4{0, 0, 0, 0};
     }
 #endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
+        defer[k] = false;
         if (!valid[k]) continue;
-        const bool hit_a = ea[k].y != kNone && ea[k].x == w[k];
-        const bool hit_b = eb[k].y != kNone && eb[k].x == w[k];
-        if (hit_a || hit_b) {
-            const u32x4 en = hit_a ? ea[k] : eb[k];
-            bool go = en.z != 0;                             // a 4-byte needle (variant) ends here
-            if (avail[k] > 4) {                              // or the trie continues with the next haystack byte
-                const uint32_t n_edges = en.w & 0xFFFFu;
-                go = go || n_edges > 1u || (n_edges == 1u && ((en.w >> 16) & 0xFFu) == (w2[k] >> 24));
-            }
-            if (go) node[k] = en.y;
+        if (probe[k]) {
+            const bool more = avail[k] > 4;
+            defer[k] = t4_slot_may_match(ba[k].x, fp[k], nb[k], more) || t4_slot_may_match(ba[k].y, fp[k], nb[k], more) ||
+                       t4_slot_may_match(ba[k].z, fp[k], nb[k], more) || t4_slot_may_match(ba[k].w, fp[k], nb[k], more) ||
+                       t4_slot_may_match(bb[k].x, fp[k], nb[k], more) || t4_slot_may_match(bb[k].y, fp[k], nb[k], more) ||
+                       t4_slot_may_match(bb[k].z, fp[k], nb[k], more) || t4_slot_may_match(bb[k].w, fp[k], nb[k], more);
         }
-        if (node[k] == kNone && (s.tiers & 7u)) node[k] = kShortOnly;
+        if (s.tiers & 7u) defer[k] = true;               // 1..3-byte needles: always consult their tables
+        if (ablate == 3 && ba[k].x != 0x12345678u) defer[k] = false;   // timing experiment only
     }
-    if (ablate == 3) { for (int k = 0; k < N; k++) if (node[k] != kNone && ea[k].x != 0x12345678u) node[k] = kNone; }   // timing experiment only
+}
+
+// exact lookup of a 4-byte suffix on the cold side: the depth-4 trie node, or kNone
+AM_HD uint32_t t4_lookup(const SfView& s, uint32_t w)
+{
+    const uint32_t lb = s.tier_log2_cap[3];
+    const uint32_t b2[2] = {t4_bucket(t4_hash_a(w), lb), t4_bucket(t4_hash_b(w), lb)};
+    for (int side = 0; side < 2; side++) {
+        const u32x4 hot = s.t4_hot[b2[side]];
+        const uint32_t slots[4] = {hot.x, hot.y, hot.z, hot.w};
+        for (int j = 0; j < 4; j++)
+            if ((slots[j] & kT4Occupied) && s.t4_keys[4u * b2[side] + j] == w) return s.t4_nodes[4u * b2[side] + j];
+    }
+    return kNone;
 }
 
 // Phase 2: walk the compressed trie from the depth-4 node along the haystack (backwards) and return the
 // deepest needle end; falls back to the 1..3-byte tables.  Data-dependent loops live only here, and
 // the kernel batches these rare items so that a whole wavefront resolves them together.
 template <bool IC>
-AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t node, uint32_t& state, uint32_t& vlen)
+AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
 {
     uint32_t w, w2;
     load_suffix8(text, gpos, avail, w, w2);
     if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
     uint32_t best_state = 0, best_vlen = 0;          // state + 1
-    if (node != kShortOnly) {
+    uint32_t node = kNone;
+    if ((s.tiers & 8u) && avail >= 4) node = t4_lookup(s, w);
+    if (node != kNone) {
         uint64_t depth = 4;
         SfNode rec;
         load_node(s.nodes + node, rec);
@@ -427,15 +464,20 @@ AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint6
     return true;
 }
 
+// probe + resolve for one position (host checker, and the reference for what the kernel computes)
 template <bool IC>
 AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
 {
-    const uint64_t g[1] = {gpos}, a[1] = {avail};
+    uint32_t w, w2;
+    load_suffix8(text, gpos, avail, w, w2);
+    if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
+    const uint32_t wa[1] = {w}, nba[1] = {w2 >> 24};
+    const uint64_t a[1] = {avail};
     const bool v[1] = {true};
-    uint32_t node[1];
-    sf_probe_n<IC, 1>(s, text, g, a, v, node);
-    if (node[0] == kNone) return false;
-    return sf_resolve<IC>(s, text, gpos, avail, node[0], state, vlen);
+    bool defer[1];
+    sf_probe_n<1>(s, wa, nba, a, v, defer);
+    if (!defer[0]) return false;
+    return sf_resolve<IC>(s, text, gpos, avail, state, vlen);
 }
 
 // Bloom test of one window for every active tier; returns true if any tier may match.

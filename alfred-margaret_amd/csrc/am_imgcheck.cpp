@@ -91,10 +91,17 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                     uint32_t hay[2] = {0, 0}, st[2] = {0, 0}, vl[2] = {0, 0};
                     for (int k = 0; k < 2; k++) if (valid[k]) { hay[k] = find_haystack(b, g[k]); a[k] = g[k] - offsets[hay[k]] + 1; }
                     if (which == 1) {
-                        uint32_t node[2];
-                        if (ic) sf_probe_n<true, 2>(s, padded.data(), g, a, valid, node); else sf_probe_n<false, 2>(s, padded.data(), g, a, valid, node);
-                        for (int k = 0; k < 2; k++) if (valid[k] && node[k] != kNone)
-                            found[k] = ic ? sf_resolve<true>(s, padded.data(), g[k], a[k], node[k], st[k], vl[k]) : sf_resolve<false>(s, padded.data(), g[k], a[k], node[k], st[k], vl[k]);
+                        // what the kernel does: w / nb from the (folded) haystack bytes, two candidates per probe call
+                        uint32_t wv[2] = {0, 0}, nbv[2] = {0, 0};
+                        bool defer[2];
+                        for (int k = 0; k < 2; k++) if (valid[k]) {
+                            for (uint32_t j = 0; j < 4; j++) { uint32_t byte = g[k] >= j ? padded[(size_t)(g[k] - j)] : 0u; wv[k] |= byte << (24u - 8u * j); }
+                            nbv[k] = g[k] >= 4 ? padded[(size_t)(g[k] - 4)] : 0u;
+                            if (ic) { wv[k] = fold_dword(wv[k]); nbv[k] = fold_byte(nbv[k]); }
+                        }
+                        sf_probe_n<2>(s, wv, nbv, a, valid, defer);
+                        for (int k = 0; k < 2; k++) if (valid[k] && defer[k])
+                            found[k] = ic ? sf_resolve<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_resolve<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);
                     } else {
                         for (int k = 0; k < 2; k++) if (valid[k])
                             found[k] = ic ? sf_verify<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_verify<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);

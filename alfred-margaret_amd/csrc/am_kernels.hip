@@ -73,8 +73,8 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
-constexpr int kSfQ1 = 256;                       // per-wave queue of candidate positions (u16); larger chunks take several sub-passes
-constexpr int kSfQ2 = 192;                       // per-wave ring of deferred items (2 x u32): candidates that need the trie walk
+constexpr int kSfQ1 = 128;                       // per-wave queue of candidates {4-byte window, position | previous byte}; more take several sub-passes
+constexpr int kSfQ2 = 192;                       // per-wave ring of deferred positions: candidates that need the exact lookup + trie walk
 
 // ILP = candidates probed per lane per round (their loads are in flight together);
 // NT  = stream the haystack with non-temporal loads.
@@ -94,15 +94,15 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* bloom = lds;
-    uint2* q2_all = reinterpret_cast<uint2*>(lds + words);
-    uint16_t* q1_all = reinterpret_cast<uint16_t*>(q2_all + kSfWaves * kSfQ2);
+    uint2* q1_all = reinterpret_cast<uint2*>(lds + words);
+    uint32_t* q2_all = reinterpret_cast<uint32_t*>(q1_all + kSfWaves * kSfQ1);
 
     for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint16_t* q1 = q1_all + wave * kSfQ1;
-    uint2* q2 = q2_all + wave * kSfQ2;
+    uint2* q1 = q1_all + wave * kSfQ1;
+    uint32_t* q2 = q2_all + wave * kSfQ2;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
     const uint32_t UC = o.unit_chunks;
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         uint32_t state = 0, vlen = 0, hay = 0;
         uint64_t end_pos = 0;
         if (valid) {
-            const uint2 item = q2[(q2_head + lane) % kSfQ2];
-            const uint64_t gpos = (unit_base_chunk + (item.y >> 10)) * kSfChunk + (item.y & 1023u);
+            const uint32_t item = q2[(q2_head + lane) % kSfQ2];
+            const uint64_t gpos = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
             hay = find_haystack(b, gpos);
             end_pos = gpos - b.offsets[hay] + 1;
-            found = sf_resolve<IC>(s, b.text, gpos, end_pos, item.x, state, vlen);
+            found = sf_resolve<IC>(s, b.text, gpos, end_pos, state, vlen);
         }
         const uint64_t found_mask = __ballot(found);
         if (MODE == kModeCount) {
@@ -238,32 +238,39 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 if (total == 0) break;
                 uint32_t idx = incl - n;
                 while (cand && idx < (uint32_t)kSfQ1) {
+                    // queue the candidate with its (already folded) window and the byte before it, so that
+                    // the probe needs no haystack load: bytes k+1..k+4 and k of the lane's 20-byte array
                     const uint32_t k = __builtin_ctz(cand);
                     cand &= cand - 1u;
-                    q1[idx++] = (uint16_t)(lane * 16u + k);
+                    const uint32_t j = k >> 2, sh = k & 3u;
+                    const uint32_t lo = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
+                    const uint32_t hi = j == 0 ? d1 : j == 1 ? d2 : j == 2 ? d3 : d4;
+                    const uint32_t w = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (sh + 1u)));
+                    const uint32_t nb = (lo >> (8u * sh)) & 0xFFu;
+                    q1[idx++] = make_uint2(w, (lane * 16u + k) | (nb << 16));
                 }
                 const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
                 wave_lds_fence();
 
                 for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
-                    uint64_t gpos[ILP], avail[ILP];
-                    uint32_t pos[ILP], node[ILP];
-                    bool valid[ILP];
+                    uint64_t avail[ILP];
+                    uint32_t pos[ILP], w[ILP], nb[ILP];
+                    bool valid[ILP], defer[ILP];
 #pragma unroll
                     for (int k = 0; k < ILP; k++) {
                         const uint32_t e = base + 64u * k + lane;
                         valid[k] = e < n_q1;
-                        pos[k] = valid[k] ? q1[e] : 0u;
-                        gpos[k] = c0 + pos[k];
-                        avail[k] = gpos[k] - hs0 + 1;
-                        if (valid[k] && !single) avail[k] = gpos[k] - b.offsets[find_haystack(b, gpos[k])] + 1;
+                        const uint2 ent = valid[k] ? q1[e] : make_uint2(0u, 0u);
+                        w[k] = ent.x; pos[k] = ent.y & 1023u; nb[k] = ent.y >> 16;
+                        const uint64_t gpos = c0 + pos[k];
+                        avail[k] = gpos - hs0 + 1;
+                        if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                     }
-                    sf_probe_n<IC, ILP>(s, b.text, gpos, avail, valid, node, o.ablate);
+                    sf_probe_n<ILP>(s, w, nb, avail, valid, defer, o.ablate);
 #pragma unroll
                     for (int k = 0; k < ILP; k++) {
-                        const bool defer = valid[k] && node[k] != kNone;
-                        const uint64_t m = __ballot(defer);
-                        if (defer) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = make_uint2(node[k], (ci << 10) | pos[k]);
+                        const uint64_t m = __ballot(defer[k]);
+                        if (defer[k]) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = (ci << 10) | pos[k];
                         q2_tail += (uint32_t)__popcll(m);
                     }
                     wave_lds_fence();
@@ -375,7 +382,7 @@ hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record
 }
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
-size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint2)); }
+size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint2) + kSfQ2 * sizeof(uint32_t)); }
 
 template <bool IC, int MODE, int ILP, bool NT, bool SHORT>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
