@@ -599,6 +599,14 @@ extern "C" int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t n
     return AM_OK;
 }
 
+// debug only (not declared in am.h): cycle sums per k_sf phase for launches made under AM_SF_ABLATE=9
+extern "C" int am_debug_sf_phase_cycles(uint64_t* out5)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(read_sf_phase_cycles(out5));
+    return AM_OK;
+}
+
 extern "C" int am_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_rt.mu); g_rt.prof_on = on != 0; return AM_OK; }
 
 static void drain_profile_locked()

@@ -33,6 +33,7 @@ struct ScanOut {
     uint64_t* total_values;       // count mode
     uint8_t* flags;               // any mode
     uint32_t ablate;              // timing experiments only (AM_SF_ABLATE); 0 in production
+    uint64_t* dbg;                // timing experiments only: per-phase cycle sums
 };
 
 constexpr uint32_t kPoolBlock = 64;   // records per pool block (1 KiB)
@@ -45,6 +46,7 @@ uint64_t ac_units(const AcView& a, const BatchView& b);
 size_t sf_lds_bytes(const SfView& s);
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
+hipError_t read_sf_phase_cycles(uint64_t* out5);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st);
 

@@ -460,7 +460,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         }
         h.tier_log2_cap[3] = lb;
         std::vector<u32x4> hot((size_t)1 << lb, u32x4{0, 0, 0, 0});
-        std::vector<uint32_t> cold_keys((size_t)4 << lb, 0), cold_nodes((size_t)4 << lb, kNone);
+        std::vector<u32x4> cold((size_t)2 << lb);
+        for (size_t bk = 0; bk < ((size_t)1 << lb); bk++) { cold[2 * bk] = u32x4{0, 0, 0, 0}; cold[2 * bk + 1] = u32x4{kNone, kNone, kNone, kNone}; }
         for (size_t sl = 0; sl < owner.size(); sl++) {
             if (owner[sl] == kNone) continue;
             const TierEntry& e = ents[owner[sl]];
@@ -472,11 +473,11 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             else if (n_edges > 1) word |= kT4Multi;
             uint32_t* bw = &hot[sl >> 2].x;
             bw[sl & 3] = word;
-            cold_keys[sl] = e.key; cold_nodes[sl] = e.node;
+            (&cold[2 * (sl >> 2)].x)[sl & 3] = e.key;
+            (&cold[2 * (sl >> 2) + 1].x)[sl & 3] = e.node;
         }
         h.off_tier[3] = blob.put(hot);
-        h.off_t4_keys = blob.put(cold_keys);
-        h.off_t4_nodes = blob.put(cold_nodes);
+        h.off_t4_cold = blob.put(cold);
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);

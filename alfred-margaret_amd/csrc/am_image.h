@@ -62,9 +62,8 @@ struct ImageHeader {
     uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
     uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
     uint64_t n_edges;
-    uint64_t off_t4_keys;       // cold side of tier 4: full 4-byte key of every slot, u32[4 << cap]
-    uint64_t off_t4_nodes;      // and its depth-4 trie node,                       u32[4 << cap]
-    uint64_t reserved[2];
+    uint64_t off_t4_cold;       // cold side of tier 4, 32 B per bucket: the 4 full keys, then the 4 depth-4 node ids (kNone: empty slot)
+    uint64_t reserved[3];
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -107,8 +106,7 @@ struct SfView {
     // it stays in each XCD's L2): per slot a 16-bit fingerprint, the selector byte of the node's
     // single edge, and flags.  COLD side (read only by sf_resolve): the full key and the node id.
     const u32x4* t4_hot;
-    const uint32_t* t4_keys;
-    const uint32_t* t4_nodes;
+    const u32x4* t4_cold;    // [2 * bucket] = keys, [2 * bucket + 1] = nodes
     const SfNode* nodes;
     const SfEdge* edges;
     uint32_t bloom_log2_words, tiers;
@@ -144,8 +142,7 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     v.bloom = (const uint32_t*)(b + h.off_bloom);
     for (int t = 0; t < 3; t++) v.tier[t] = (const u32x2*)(b + h.off_tier[t]);
     v.t4_hot = (const u32x4*)(b + h.off_tier[3]);
-    v.t4_keys = (const uint32_t*)(b + h.off_t4_keys);
-    v.t4_nodes = (const uint32_t*)(b + h.off_t4_nodes);
+    v.t4_cold = (const u32x4*)(b + h.off_t4_cold);
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
     v.edges = (const SfEdge*)(b + h.off_edges);
@@ -234,10 +231,12 @@ AM_HD uint32_t find_haystack(const BatchView& b, uint64_t pos)
 // case is two loads: the last 8 haystack bytes (one unaligned 8 B load) and one 16 B table entry
 // that already carries the depth-4 node's terminal flag and its single outgoing edge byte.
 
-// last 8 bytes ending at gpos: w = bytes gpos-3..gpos, w2 = bytes gpos-7..gpos-4, newest byte on top
-AM_HD void load_suffix8(const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& w, uint32_t& w2)
+// last 8 bytes ending at global index gpos: w = bytes gpos-3..gpos, w2 = bytes gpos-7..gpos-4, newest
+// byte on top.  Bytes that lie before the haystack's start (in the previous haystack, or before the
+// buffer: zeros) are never interpreted: every use is guarded by `avail`.
+AM_HD void load_suffix8(const uint8_t* text, uint64_t gpos, uint32_t& w, uint32_t& w2)
 {
-    if (avail >= 8) {
+    if (gpos >= 7) {
 #if defined(__HIP_DEVICE_COMPILE__)
         typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
         w2 = *reinterpret_cast<const u32_unaligned*>(text + gpos - 7);
@@ -248,7 +247,7 @@ AM_HD void load_suffix8(const uint8_t* text, uint64_t gpos, uint64_t avail, uint
 #endif
     } else {
         w = 0; w2 = 0;
-        for (uint32_t j = 0; j < 8 && j < avail; j++) {
+        for (uint32_t j = 0; j < 8 && j <= gpos; j++) {
             const uint32_t b = text[gpos - j];
             if (j < 4) w |= b << (24u - 8u * j); else w2 |= b << (24u - 8u * (j - 4u));
         }
@@ -369,43 +368,56 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
         defer[k] = false;
         if (!valid[k]) continue;
         if (probe[k]) {
-            const bool more = avail[k] > 4;
-            defer[k] = t4_slot_may_match(ba[k].x, fp[k], nb[k], more) || t4_slot_may_match(ba[k].y, fp[k], nb[k], more) ||
-                       t4_slot_may_match(ba[k].z, fp[k], nb[k], more) || t4_slot_may_match(ba[k].w, fp[k], nb[k], more) ||
-                       t4_slot_may_match(bb[k].x, fp[k], nb[k], more) || t4_slot_may_match(bb[k].y, fp[k], nb[k], more) ||
-                       t4_slot_may_match(bb[k].z, fp[k], nb[k], more) || t4_slot_may_match(bb[k].w, fp[k], nb[k], more);
+            // cheap test first (2 ops per slot): does any of the 8 slots carry this fingerprint at all?
+            const uint32_t want = kT4Occupied | fp[k], sel = kT4Occupied | 0xFFFFu;
+            const bool any_fp = (ba[k].x & sel) == want || (ba[k].y & sel) == want || (ba[k].z & sel) == want || (ba[k].w & sel) == want ||
+                                (bb[k].x & sel) == want || (bb[k].y & sel) == want || (bb[k].z & sel) == want || (bb[k].w & sel) == want;
+            if (any_fp) {
+                const bool more = avail[k] > 4;
+                defer[k] = t4_slot_may_match(ba[k].x, fp[k], nb[k], more) || t4_slot_may_match(ba[k].y, fp[k], nb[k], more) ||
+                           t4_slot_may_match(ba[k].z, fp[k], nb[k], more) || t4_slot_may_match(ba[k].w, fp[k], nb[k], more) ||
+                           t4_slot_may_match(bb[k].x, fp[k], nb[k], more) || t4_slot_may_match(bb[k].y, fp[k], nb[k], more) ||
+                           t4_slot_may_match(bb[k].z, fp[k], nb[k], more) || t4_slot_may_match(bb[k].w, fp[k], nb[k], more);
+            }
         }
         if (s.tiers & 7u) defer[k] = true;               // 1..3-byte needles: always consult their tables
         if (ablate == 3 && ba[k].x != 0x12345678u) defer[k] = false;   // timing experiment only
     }
 }
 
-// exact lookup of a 4-byte suffix on the cold side: the depth-4 trie node, or kNone
-AM_HD uint32_t t4_lookup(const SfView& s, uint32_t w)
+// Phase 2a: everything that depends only on the position: the last 8 haystack bytes, then the exact
+// (cold-side) lookup of the 4-byte suffix -- four independent 16-byte loads, no loop.  node = kNone
+// if no needle (variant) has this 4-byte suffix.
+template <bool IC>
+AM_HD void sf_resolve_lookup(const SfView& s, const uint8_t* text, uint64_t gpos, uint32_t& w, uint32_t& w2, uint32_t& node)
 {
-    const uint32_t lb = s.tier_log2_cap[3];
-    const uint32_t b2[2] = {t4_bucket(t4_hash_a(w), lb), t4_bucket(t4_hash_b(w), lb)};
-    for (int side = 0; side < 2; side++) {
-        const u32x4 hot = s.t4_hot[b2[side]];
-        const uint32_t slots[4] = {hot.x, hot.y, hot.z, hot.w};
-        for (int j = 0; j < 4; j++)
-            if ((slots[j] & kT4Occupied) && s.t4_keys[4u * b2[side] + j] == w) return s.t4_nodes[4u * b2[side] + j];
+    load_suffix8(text, gpos, w, w2);
+    if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
+    node = kNone;
+    if (s.tiers & 8u) {
+        const uint32_t lb = s.tier_log2_cap[3];
+        const uint32_t ba = t4_bucket(t4_hash_a(w), lb), bb = t4_bucket(t4_hash_b(w), lb);
+        const u32x4 ka = s.t4_cold[2u * ba], na = s.t4_cold[2u * ba + 1u], kb = s.t4_cold[2u * bb], nb = s.t4_cold[2u * bb + 1u];
+        if (ka.x == w && na.x != kNone) node = na.x;
+        if (ka.y == w && na.y != kNone) node = na.y;
+        if (ka.z == w && na.z != kNone) node = na.z;
+        if (ka.w == w && na.w != kNone) node = na.w;
+        if (kb.x == w && nb.x != kNone) node = nb.x;
+        if (kb.y == w && nb.y != kNone) node = nb.y;
+        if (kb.z == w && nb.z != kNone) node = nb.z;
+        if (kb.w == w && nb.w != kNone) node = nb.w;
     }
-    return kNone;
 }
 
-// Phase 2: walk the compressed trie from the depth-4 node along the haystack (backwards) and return the
-// deepest needle end; falls back to the 1..3-byte tables.  Data-dependent loops live only here, and
-// the kernel batches these rare items so that a whole wavefront resolves them together.
+// Phase 2b: walk the compressed trie from the depth-4 node along the haystack (backwards) and return
+// the deepest needle end; falls back to the 1..3-byte tables.  Data-dependent loops live only here,
+// and the kernel batches these rare items so that a whole wavefront resolves them together.
 template <bool IC>
-AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
+AM_HD bool sf_resolve_walk(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t w, uint32_t w2, uint32_t node,
+                           uint32_t& state, uint32_t& vlen)
 {
-    uint32_t w, w2;
-    load_suffix8(text, gpos, avail, w, w2);
-    if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
     uint32_t best_state = 0, best_vlen = 0;          // state + 1
-    uint32_t node = kNone;
-    if ((s.tiers & 8u) && avail >= 4) node = t4_lookup(s, w);
+    if (avail < 4) node = kNone;
     if (node != kNone) {
         uint64_t depth = 4;
         SfNode rec;
@@ -464,12 +476,20 @@ AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint6
     return true;
 }
 
+template <bool IC>
+AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
+{
+    uint32_t w, w2, node;
+    sf_resolve_lookup<IC>(s, text, gpos, w, w2, node);
+    return sf_resolve_walk<IC>(s, text, gpos, avail, w, w2, node, state, vlen);
+}
+
 // probe + resolve for one position (host checker, and the reference for what the kernel computes)
 template <bool IC>
 AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
 {
     uint32_t w, w2;
-    load_suffix8(text, gpos, avail, w, w2);
+    load_suffix8(text, gpos, w, w2);
     if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
     const uint32_t wa[1] = {w}, nba[1] = {w2 >> 24};
     const uint64_t a[1] = {avail};

@@ -123,9 +123,14 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         if (valid) {
             const uint32_t item = q2[(q2_head + lane) % kSfQ2];
             const uint64_t gpos = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
-            hay = find_haystack(b, gpos);
+            // independent loads first (haystack bracket, last 8 bytes -> cold buckets), then what depends on them
+            const uint32_t hlo = b.hidx[gpos >> kHidxShift], hhi = b.hidx[(gpos >> kHidxShift) + 1];
+            uint32_t w, w2, node;
+            sf_resolve_lookup<IC>(s, b.text, gpos, w, w2, node);
+            hay = hlo;
+            if (hlo != hhi) hay = find_haystack(b, gpos);
             end_pos = gpos - b.offsets[hay] + 1;
-            found = sf_resolve<IC>(s, b.text, gpos, end_pos, state, vlen);
+            found = sf_resolve_walk<IC>(s, b.text, gpos, end_pos, w, w2, node, state, vlen);
         }
         const uint64_t found_mask = __ballot(found);
         if (MODE == kModeCount) {
@@ -178,7 +183,13 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (p >= 4) prev = *reinterpret_cast<const uint32_t*>(b.text + p - 4);
         }
     };
+    // optional phase timing (AM_SF_ABLATE=9): s_memtime deltas per wavefront, summed into o.dbg
+    const bool timing = o.dbg != nullptr;
+    uint64_t t_filter = 0, t_compact = 0, t_probe = 0, t_resolve = 0, t_probe_pre = 0, t_mark = 0;
+    auto tick = [&](uint64_t& acc) { if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc += now - t_mark; t_mark = now; } };
+    if (timing) t_mark = __builtin_amdgcn_s_memtime();
     uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
+    uint32_t hay0 = 0; uint64_t hs0 = 1, he0 = 0;       // cached haystack bracket [hs0, he0): empty until the first lookup
     uint4 cur_v; uint32_t cur_prev;
     fetch(u * UC, cur_v, cur_prev);
 
@@ -188,16 +199,18 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
-            uint4 next_v; uint32_t next_prev;
-            fetch(ci + 1 < n_in_unit ? c + 1 : (u + n_waves) * UC, next_v, next_prev);
+            uint4 next_v = make_uint4(0, 0, 0, 0); uint32_t next_prev = 0;
+            if (o.ablate == 8) fetch(c, cur_v, cur_prev);          // timing experiment only: no prefetch, expose HBM latency in the filter phase
+            else fetch(ci + 1 < n_in_unit ? c + 1 : (u + n_waves) * UC, next_v, next_prev);
 
             const uint64_t c0 = c * kSfChunk;
             const uint64_t p0 = c0 + lane * 16u;
-            // haystack of the chunk's first byte (same address in every lane: one request per load); almost
-            // every chunk lies inside one haystack, then no candidate needs its own lookup
-            const uint32_t hay0 = find_haystack(b, c0);
-            const uint64_t hs0 = b.offsets[hay0], he0 = b.offsets[hay0 + 1];
+            // the haystack that contains the chunk's first byte is looked up only when the chunk leaves
+            // the one found last time (same address in every lane: one request per load); almost every
+            // chunk lies inside one haystack, then no candidate needs its own lookup either
+            if (c0 >= he0 || c0 < hs0) { hay0 = find_haystack(b, c0); hs0 = b.offsets[hay0]; he0 = b.offsets[hay0 + 1]; }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
+            (void)hay0;
 
             uint32_t d0 = cur_prev, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
             if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             }
             if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
             if (o.ablate == 1) cand = 0;               // timing experiment only
+            if (timing) { asm volatile("" :: "v"(cand)); tick(t_filter); }
 
             for (;;) {
                 // compact (up to kSfQ1) candidate positions into the wave's LDS queue, in position order
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 }
                 const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
                 wave_lds_fence();
+                tick(t_compact);
 
                 for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
                     uint64_t avail[ILP];
@@ -266,6 +281,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                         avail[k] = gpos - hs0 + 1;
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                     }
+                    if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
                     sf_probe_n<ILP>(s, w, nb, avail, valid, defer, o.ablate);
 #pragma unroll
                     for (int k = 0; k < ILP; k++) {
@@ -274,7 +290,9 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                         q2_tail += (uint32_t)__popcll(m);
                     }
                     wave_lds_fence();
+                    tick(t_probe);
                     while (q2_tail - q2_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }   // keeps room for the next round
+                    tick(t_resolve);
                 }
                 if (total <= (uint32_t)kSfQ1) break;
                 wave_lds_fence();
@@ -283,8 +301,18 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         }
         // end of unit: drain the ring so that every item of a batch belongs to one unit
         wave_lds_fence();
+        tick(t_compact);
         while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u ? nb : 64u); }
+        tick(t_resolve);
         if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; }
+    }
+    if (timing && lane == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 0), (unsigned long long)t_filter);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 1), (unsigned long long)t_compact);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 2), (unsigned long long)t_probe);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 3), (unsigned long long)t_resolve);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 4), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 5), (unsigned long long)t_probe_pre);
     }
 
     if (MODE == kModeCount) {
@@ -406,6 +434,17 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     return hipGetLastError();
 }
 
+static uint64_t* g_sf_dbg = nullptr;
+// debug: per-phase s_memtime sums of k_sf launches run with AM_SF_ABLATE=9 (filter, compact, probe, resolve, waves)
+hipError_t read_sf_phase_cycles(uint64_t* out5)
+{
+    for (int i = 0; i < 6; i++) out5[i] = 0;
+    if (!g_sf_dbg) return hipSuccess;
+    hipError_t e = hipMemcpy(out5, g_sf_dbg, 48, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemset(g_sf_dbg, 0, 64);
+    return e;
+}
+
 // tuning variant: AM_SF_VARIANT = ilp * 10 + nt; default 20
 static int sf_variant()
 {
@@ -429,6 +468,12 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     ScanOut o = o_in;
     static const uint32_t ablate = [] { const char* e = std::getenv("AM_SF_ABLATE"); return e ? (uint32_t)std::atoi(e) : 0u; }();
     o.ablate = ablate;
+    static uint64_t* dbg = nullptr;
+    if (ablate >= 8) {
+        if (!dbg) { if (hipMalloc((void**)&dbg, 64) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 64); }
+        o.dbg = dbg;
+        g_sf_dbg = dbg;
+    }
     if (ic) {
         if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);
         if (mode == kModeEmit) return launch_sf_t<true, kModeEmit>(s, b, o, n_cu, st);
