@@ -42,6 +42,7 @@ def main():
     import torch.distributed as dist
 
     import alfred_margaret_amd as am
+    from alfred_margaret_amd import dist as amdist
     from alfred_margaret_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,13 +75,12 @@ def main():
         am.api.check(lib.am_automaton_image_size(handle, case, C.byref(nbytes)))
     build_s = time.time() - t0
     if world > 1:
-        size_t = torch.tensor([nbytes.value if rank == 0 else 0], dtype=torch.int64, device=dev)
-        dist.broadcast(size_t, 0)
-        image = torch.empty(int(size_t.item()), dtype=torch.uint8, device=dev)
+        image = None
         if rank == 0:
+            image = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
             am.api.check(lib.am_automaton_image_copy(handle, case, image.data_ptr(), image.numel()))
-        torch.cuda.synchronize(dev)
-        dist.broadcast(image, 0)                       # automaton over xGMI
+            torch.cuda.synchronize(dev)
+        image = amdist.broadcast_image(image, dev, src=0)        # automaton over xGMI (RCCL broadcast)
         torch.cuda.synchronize(dev)
         if rank != 0:
             handle = C.c_void_p()
@@ -119,20 +119,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     am.api.check(lib.am_profile_enable(0))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = amdist.allreduce_max(elapsed, dev)
 
     # values folded (= reference's countMatches) via the count-only entry point, summed over ranks
     total_values = C.c_uint64(0)
     t1 = time.perf_counter()
     am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total_values)))
     count_only_s = time.perf_counter() - t1
-    tot = torch.tensor([int(total_values.value), n_records], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)     # final gather of match counts
-    total_matches, total_records = int(tot[0].item()), int(tot[1].item())
+    total_matches, total_records = amdist.allreduce_sum([int(total_values.value), n_records], dev)   # final gather of match counts
 
     kname = b"sf" if args.kernel != 1 else b"ac"
     ms, launches = C.c_double(0), C.c_uint64(0)
@@ -153,6 +147,17 @@ def main():
         per_step = launches_n / float(args.steps)
         alg_bytes = n_bytes + (16.0 / per_step) * n_records + 16.0 * n_hay
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM traffic per launch: not measurable from inside this process; taken from the committed PMC
+        # profile of the same kernel + workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
+        # MI355X_MICROARCH.md prescribes), scaled to this launch's bytes.  null if there is no such profile.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("workload") == args.workload and pt.get("kernel") == "k_" + kname.decode():
+                traffic = int(pt["hbm_bytes_per_scanned_byte"] * n_bytes)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "GiB/s haystack bytes scanned (match-emitting runLower, 100k-needle automaton)" if "cfg3" in args.workload
                       else "GiB/s haystack bytes scanned (match-emitting run)",
@@ -167,7 +172,7 @@ def main():
             "matches_per_step": total_matches, "records_per_step": total_records,
             "count_only_gibps": round(n_bytes / float(1 << 30) / count_only_s, 3),
             "roofline": {"bound": "hbm", "kernel": "k_" + kname.decode(), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes)},
         }
         if world == 1 and not args.no_cpu_baseline:
