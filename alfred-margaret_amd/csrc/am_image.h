@@ -111,6 +111,7 @@ struct SfView {
     const SfEdge* edges;
     uint32_t bloom_log2_words, tiers;
     uint32_t tier_log2_cap[4];
+    uint32_t n_nodes;
 };
 
 struct BatchView {
@@ -146,7 +147,7 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
     v.edges = (const SfEdge*)(b + h.off_edges);
-    v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers;
+    v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers; v.n_nodes = h.sf_n_nodes;
     return v;
 }
 
@@ -311,13 +312,14 @@ constexpr uint32_t kT4Single = 1u << 26;      // the node has exactly one outgoi
 constexpr uint32_t kT4Multi = 1u << 27;       // the node has several outgoing edges
 
 // can this hot slot word belong to a needle ending at a position whose last 4 bytes hash to `fp`
-// and whose preceding byte is `nb` (ignored when the haystack has no more bytes: more == false)?
-AM_HD bool t4_slot_may_match(uint32_t slot, uint32_t fp, uint32_t nb, bool more)
+// and whose preceding byte is `nb` (ignored when the haystack has no more bytes: more == 0)?
+// Pure bit arithmetic on purpose: the probe runs this 8 times per candidate and must not branch.
+AM_HD uint32_t t4_slot_may_match(uint32_t slot, uint32_t fp, uint32_t nb, uint32_t more)
 {
-    if ((slot & (kT4Occupied | 0xFFFFu)) != (kT4Occupied | fp)) return false;
-    if (slot & kT4Terminal) return true;
-    if (!more) return false;
-    return (slot & kT4Multi) || ((slot & kT4Single) && ((slot >> 16) & 0xFFu) == nb);
+    const uint32_t fp_ok = (uint32_t)((slot & (kT4Occupied | 0xFFFFu)) == (kT4Occupied | fp));
+    const uint32_t term = (slot >> 25) & 1u, single = (slot >> 26) & 1u, multi = (slot >> 27) & 1u;
+    const uint32_t sel_ok = (uint32_t)(((slot >> 16) & 0xFFu) == nb);
+    return fp_ok & (term | (more & (multi | (single & sel_ok))));
 }
 
 // Phase 1, N candidates per lane at once.  Inputs come straight from the filter stage's registers
@@ -365,23 +367,15 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
 #endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        defer[k] = false;
-        if (!valid[k]) continue;
-        if (probe[k]) {
-            // cheap test first (2 ops per slot): does any of the 8 slots carry this fingerprint at all?
-            const uint32_t want = kT4Occupied | fp[k], sel = kT4Occupied | 0xFFFFu;
-            const bool any_fp = (ba[k].x & sel) == want || (ba[k].y & sel) == want || (ba[k].z & sel) == want || (ba[k].w & sel) == want ||
-                                (bb[k].x & sel) == want || (bb[k].y & sel) == want || (bb[k].z & sel) == want || (bb[k].w & sel) == want;
-            if (any_fp) {
-                const bool more = avail[k] > 4;
-                defer[k] = t4_slot_may_match(ba[k].x, fp[k], nb[k], more) || t4_slot_may_match(ba[k].y, fp[k], nb[k], more) ||
-                           t4_slot_may_match(ba[k].z, fp[k], nb[k], more) || t4_slot_may_match(ba[k].w, fp[k], nb[k], more) ||
-                           t4_slot_may_match(bb[k].x, fp[k], nb[k], more) || t4_slot_may_match(bb[k].y, fp[k], nb[k], more) ||
-                           t4_slot_may_match(bb[k].z, fp[k], nb[k], more) || t4_slot_may_match(bb[k].w, fp[k], nb[k], more);
-            }
-        }
-        if (s.tiers & 7u) defer[k] = true;               // 1..3-byte needles: always consult their tables
-        if (ablate == 3 && ba[k].x != 0x12345678u) defer[k] = false;   // timing experiment only
+        const uint32_t more = (uint32_t)(avail[k] > 4);
+        uint32_t hit = t4_slot_may_match(ba[k].x, fp[k], nb[k], more) | t4_slot_may_match(ba[k].y, fp[k], nb[k], more) |
+                       t4_slot_may_match(ba[k].z, fp[k], nb[k], more) | t4_slot_may_match(ba[k].w, fp[k], nb[k], more) |
+                       t4_slot_may_match(bb[k].x, fp[k], nb[k], more) | t4_slot_may_match(bb[k].y, fp[k], nb[k], more) |
+                       t4_slot_may_match(bb[k].z, fp[k], nb[k], more) | t4_slot_may_match(bb[k].w, fp[k], nb[k], more);
+        hit &= (uint32_t)probe[k];                               // empty buckets were substituted for non-probes anyway
+        hit |= (uint32_t)((s.tiers & 7u) != 0u);                 // 1..3-byte needles: always consult their tables
+        if (ablate == 3) hit &= (uint32_t)(ba[k].x == 0x12345678u);   // timing experiment only
+        defer[k] = valid[k] & (hit != 0u);
     }
 }
 
@@ -409,19 +403,47 @@ AM_HD void sf_resolve_lookup(const SfView& s, const uint8_t* text, uint64_t gpos
     }
 }
 
+// Speculative loads for phase 2b, issued together so that a typical needle (<= 21 bytes, its tail one
+// compressed edge, child numbered right after its parent by the DFS renumbering) resolves without any
+// further dependent load: the depth-4 node, the record after it, and the 16 haystack bytes the first
+// edge label would be compared with.
+struct SfPre {
+    uint32_t node;         // kNone: nothing preloaded
+    SfNode n0, n1;
+    uint32_t t16[4];       // raw (unfolded) bytes text[gpos-20 .. gpos-5]
+};
+
+template <bool IC>
+AM_HD void sf_resolve_preload(const SfView& s, const uint8_t* text, uint64_t gpos, uint32_t node, SfPre& pre)
+{
+    pre.node = node;
+    if (node == kNone) return;
+    const uint32_t next = node + 1u < s.n_nodes ? node + 1u : node;
+    load_node(s.nodes + node, pre.n0);
+    load_node(s.nodes + next, pre.n1);
+    pre.t16[0] = pre.t16[1] = pre.t16[2] = pre.t16[3] = 0;
+    if (gpos >= 4) load_text16(text, gpos - 4, pre.t16);      // fewer than 5 bytes before: no edge label can be compared anyway
+    if (IC) { pre.t16[0] = fold_dword(pre.t16[0]); pre.t16[1] = fold_dword(pre.t16[1]); pre.t16[2] = fold_dword(pre.t16[2]); pre.t16[3] = fold_dword(pre.t16[3]); }
+}
+
 // Phase 2b: walk the compressed trie from the depth-4 node along the haystack (backwards) and return
 // the deepest needle end; falls back to the 1..3-byte tables.  Data-dependent loops live only here,
 // and the kernel batches these rare items so that a whole wavefront resolves them together.
 template <bool IC>
 AM_HD bool sf_resolve_walk(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t w, uint32_t w2, uint32_t node,
-                           uint32_t& state, uint32_t& vlen)
+                           const SfPre& pre, uint32_t& state, uint32_t& vlen)
 {
     uint32_t best_state = 0, best_vlen = 0;          // state + 1
     if (avail < 4) node = kNone;
     if (node != kNone) {
+        auto fetch_node = [&](uint32_t id, SfNode& out) {
+            if (pre.node != kNone && id == pre.node) out = pre.n0;
+            else if (pre.node != kNone && id == pre.node + 1u && pre.node + 1u < s.n_nodes) out = pre.n1;
+            else load_node(s.nodes + id, out);
+        };
         uint64_t depth = 4;
         SfNode rec;
-        load_node(s.nodes + node, rec);
+        fetch_node(node, rec);
         if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
         bool go = depth < avail && (rec.w & 0xFFFFu) != 0;
         while (go) {
@@ -451,12 +473,15 @@ AM_HD bool sf_resolve_walk(const SfView& s, const uint8_t* text, uint64_t gpos, 
             if (skip) {
                 if (depth + 1 + skip > avail) break;
                 uint32_t t[4];
-                load_text16(text, gpos - depth, t);       // the 16 bytes before the selector byte
-                if (IC) { t[0] = fold_dword(t[0]); t[1] = fold_dword(t[1]); t[2] = fold_dword(t[2]); t[3] = fold_dword(t[3]); }
+                if (pre.node != kNone && depth == 4) { t[0] = pre.t16[0]; t[1] = pre.t16[1]; t[2] = pre.t16[2]; t[3] = pre.t16[3]; }
+                else {
+                    load_text16(text, gpos - depth, t);       // the 16 bytes before the selector byte
+                    if (IC) { t[0] = fold_dword(t[0]); t[1] = fold_dword(t[1]); t[2] = fold_dword(t[2]); t[3] = fold_dword(t[3]); }
+                }
                 if (!label_match(t, label, skip)) break;
             }
             node = next; depth += 1u + skip;
-            load_node(s.nodes + node, rec);
+            fetch_node(node, rec);
             if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
             go = depth < avail && (rec.w & 0xFFFFu) != 0;
         }
@@ -481,7 +506,9 @@ AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint6
 {
     uint32_t w, w2, node;
     sf_resolve_lookup<IC>(s, text, gpos, w, w2, node);
-    return sf_resolve_walk<IC>(s, text, gpos, avail, w, w2, node, state, vlen);
+    SfPre pre;
+    sf_resolve_preload<IC>(s, text, gpos, node, pre);      // same order of operations as the kernel
+    return sf_resolve_walk<IC>(s, text, gpos, avail, w, w2, node, pre, state, vlen);
 }
 
 // probe + resolve for one position (host checker, and the reference for what the kernel computes)

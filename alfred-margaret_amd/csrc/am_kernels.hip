@@ -43,13 +43,16 @@ __global__ void k_hidx(const uint64_t* __restrict__ offsets, uint32_t n_hay, uin
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x, uint32_t lane)
+// inclusive prefix sum over the 64 lanes with DPP adds (no LDS round trips): Kogge-Stone inside each
+// 16-lane row (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x, uint32_t /*lane*/)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if (lane >= (uint32_t)d) x += y;
-    }
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return x;
 }
 
@@ -74,7 +77,7 @@ __device__ __forceinline__ void wave_lds_fence()
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
 constexpr int kSfQ1 = 128;                       // per-wave queue of candidates {4-byte window, position | previous byte}; more take several sub-passes
-constexpr int kSfQ2 = 192;                       // per-wave ring of deferred positions: candidates that need the exact lookup + trie walk
+constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions: candidates that need the exact lookup + trie walk
 
 // ILP = candidates probed per lane per round (their loads are in flight together);
 // NT  = stream the haystack with non-temporal loads.
@@ -129,8 +132,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             sf_resolve_lookup<IC>(s, b.text, gpos, w, w2, node);
             hay = hlo;
             if (hlo != hhi) hay = find_haystack(b, gpos);
-            end_pos = gpos - b.offsets[hay] + 1;
-            found = sf_resolve_walk<IC>(s, b.text, gpos, end_pos, w, w2, node, state, vlen);
+            const uint64_t hs = b.offsets[hay];
+            SfPre pre;
+            sf_resolve_preload<IC>(s, b.text, gpos, node, pre);     // node, node + 1, 16 label bytes: all in flight with offsets[hay]
+            end_pos = gpos - hs + 1;
+            found = sf_resolve_walk<IC>(s, b.text, gpos, end_pos, w, w2, node, pre, state, vlen);
         }
         const uint64_t found_mask = __ballot(found);
         if (MODE == kModeCount) {
