@@ -421,17 +421,16 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         h.off_tier[t] = blob.put(tab);
     }
     {
-        // 4-byte suffixes: (2,4) cuckoo hashing -- 2 candidate buckets of 4 slots per key, ~85 % full.
-        // HOT side: 4 bytes per slot (fingerprint, single-edge selector byte, flags) = 16 B per bucket;
-        // for 100k needles that is 0.5 MiB, resident in every XCD's L2 next to the streamed haystack.
-        // COLD side: full key + node id per slot, touched only when a needle may really end there.
+        // 4-byte suffixes: (2,2) cuckoo hashing -- 2 candidate buckets of 2 slots per key, ~75 % full.
+        // HOT side: 4 bytes per slot = 8 B per bucket; for 100k needles that is 0.5 MiB, resident in
+        // every XCD's L2 next to the streamed haystack.  COLD side: full keys + node ids, 16 B per bucket.
         const std::vector<TierEntry>& ents = tier_entries[3];
         uint32_t lb = 2;
-        while (((uint64_t)4 << lb) * 85 < (uint64_t)ents.size() * 100) lb++;
+        while (((uint64_t)2 << lb) * 75 < (uint64_t)ents.size() * 100) lb++;
         std::vector<uint32_t> owner;          // slot -> entry index
         for (;; lb++) {
-            if (lb > 26) { err = "suffix table too large"; return -1; }
-            owner.assign((size_t)4 << lb, kNone);
+            if (lb > 27) { err = "suffix table too large"; return -1; }
+            owner.assign((size_t)2 << lb, kNone);
             bool ok = true;
             uint32_t rng = 0x12345u;
             for (uint32_t k = 0; k < ents.size() && ok; k++) {
@@ -441,27 +440,26 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     const uint32_t ba = t4_bucket(t4_hash_a(ents[cur].key), lb), bb = t4_bucket(t4_hash_b(ents[cur].key), lb);
                     bool placed = false;
                     for (uint32_t bsel : {ba, bb}) {
-                        for (uint32_t j = 0; j < 4 && !placed; j++) {
-                            uint32_t& o = owner[4u * bsel + j];
+                        for (uint32_t j = 0; j < 2 && !placed; j++) {
+                            uint32_t& o = owner[2u * bsel + j];
                             if (o != kNone && ents[o].key == ents[cur].key) { err = "duplicate suffix key (internal error)"; return -1; }
                             if (o == kNone) { o = cur; placed = true; }
                         }
                         if (placed) break;
                     }
                     if (placed) break;
-                    if (kicks > 1000) { ok = false; break; }
+                    if (kicks > 2000) { ok = false; break; }
                     // evict a pseudo-random resident of the bucket we did not come from
                     bucket = (bucket == ba) ? bb : ba;
                     rng = rng * 1664525u + 1013904223u;
-                    std::swap(cur, owner[4u * bucket + (rng >> 30)]);
+                    std::swap(cur, owner[2u * bucket + (rng >> 31)]);
                 }
             }
             if (ok) break;
         }
         h.tier_log2_cap[3] = lb;
-        std::vector<u32x4> hot((size_t)1 << lb, u32x4{0, 0, 0, 0});
-        std::vector<u32x4> cold((size_t)2 << lb);
-        for (size_t bk = 0; bk < ((size_t)1 << lb); bk++) { cold[2 * bk] = u32x4{0, 0, 0, 0}; cold[2 * bk + 1] = u32x4{kNone, kNone, kNone, kNone}; }
+        std::vector<u32x2> hot((size_t)1 << lb, u32x2{0, 0});
+        std::vector<u32x4> cold((size_t)1 << lb, u32x4{0, 0, kNone, kNone});
         for (size_t sl = 0; sl < owner.size(); sl++) {
             if (owner[sl] == kNone) continue;
             const TierEntry& e = ents[owner[sl]];
@@ -469,12 +467,21 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             const uint32_t n_edges = nd.w & 0xFFFFu;
             uint32_t word = t4_fingerprint(t4_hash_a(e.key), lb) | kT4Occupied;
             if (nd.x) word |= kT4Terminal;
-            if (n_edges == 1) word |= kT4Single | (((nd.w >> 16) & 0xFFu) << 16);
-            else if (n_edges > 1) word |= kT4Multi;
-            uint32_t* bw = &hot[sl >> 2].x;
-            bw[sl & 3] = word;
-            (&cold[2 * (sl >> 2)].x)[sl & 3] = e.key;
-            (&cold[2 * (sl >> 2) + 1].x)[sl & 3] = e.node;
+            if (n_edges > 1) word |= kT4Multi;
+            if (n_edges == 1) {
+                word |= kT4Single | (((nd.w >> 16) & 0xFFu) << 16);
+                // second required byte: the first skip byte of the edge, or (no skip) the selector of the
+                // child's single edge provided no needle ends at the child
+                const uint32_t skip = nd.w >> 24;
+                if (skip >= 1) word |= kT4Single2 | ((nd.label[3] >> 24) << 24);       // walk order byte 0 = last label byte in text order
+                else {
+                    const SfNode& ch = nodes[nd.z];
+                    if (!ch.x && (ch.w & 0xFFFFu) == 1u) word |= kT4Single2 | (((ch.w >> 16) & 0xFFu) << 24);
+                }
+            }
+            (&hot[sl >> 1].x)[sl & 1] = word;
+            (&cold[sl >> 1].x)[sl & 1] = e.key;
+            (&cold[sl >> 1].z)[sl & 1] = e.node;
         }
         h.off_tier[3] = blob.put(hot);
         h.off_t4_cold = blob.put(cold);

@@ -57,12 +57,12 @@ struct ImageHeader {
     uint32_t sf_bloom_log2_words;
     uint32_t sf_n_nodes, sf_pad;
     uint64_t off_bloom;         // u32[1 << sf_bloom_log2_words]
-    uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}[1 << cap]; tier 4: hot fingerprint buckets u32x4[1 << cap] (4 slots each)
+    uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}[1 << cap]; tier 4: hot fingerprint buckets u32x2[1 << cap] (2 slots each)
     uint32_t tier_log2_cap[4];
     uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
     uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
     uint64_t n_edges;
-    uint64_t off_t4_cold;       // cold side of tier 4, 32 B per bucket: the 4 full keys, then the 4 depth-4 node ids (kNone: empty slot)
+    uint64_t off_t4_cold;       // cold side of tier 4, 16 B per bucket: the 2 full keys, then the 2 depth-4 node ids (kNone: empty slot)
     uint64_t reserved[3];
 };
 
@@ -101,12 +101,13 @@ constexpr uint32_t kMaxSkip = 16;
 struct SfView {
     const uint32_t* bloom;
     const u32x2* tier[3];    // exact tables for needles (variants) of exactly 1, 2, 3 bytes
-    // 4-byte suffixes: (2,4) cuckoo table.  A key lives in one of the 4 slots of bucket_a(key) or
-    // bucket_b(key).  HOT side (what the probe reads, 16 B per bucket, ~0.5 MiB for 100k needles, so
-    // it stays in each XCD's L2): per slot a 16-bit fingerprint, the selector byte of the node's
-    // single edge, and flags.  COLD side (read only by sf_resolve): the full key and the node id.
-    const u32x4* t4_hot;
-    const u32x4* t4_cold;    // [2 * bucket] = keys, [2 * bucket + 1] = nodes
+    // 4-byte suffixes: (2,2) cuckoo table.  A key lives in one of the 2 slots of bucket_a(key) or
+    // bucket_b(key).  HOT side (what the probe reads, 8 B per bucket, ~0.5 MiB for 100k needles, so
+    // it stays in each XCD's L2): per slot an 11-bit fingerprint, flags, and the next TWO bytes the
+    // trie requires after the 4-byte suffix when it is a plain chain there.  COLD side (read only
+    // when a needle may really end at the position): the full keys and the node ids.
+    const u32x2* t4_hot;
+    const u32x4* t4_cold;    // {key0, key1, node0, node1}
     const SfNode* nodes;
     const SfEdge* edges;
     uint32_t bloom_log2_words, tiers;
@@ -142,7 +143,7 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     SfView v;
     v.bloom = (const uint32_t*)(b + h.off_bloom);
     for (int t = 0; t < 3; t++) v.tier[t] = (const u32x2*)(b + h.off_tier[t]);
-    v.t4_hot = (const u32x4*)(b + h.off_tier[3]);
+    v.t4_hot = (const u32x2*)(b + h.off_tier[3]);
     v.t4_cold = (const u32x4*)(b + h.off_t4_cold);
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
@@ -299,79 +300,81 @@ AM_HD void load_node(const SfNode* p, SfNode& n)
 #endif
 }
 
-// Tier-4 hashing.  One multiply gives bucket A (top bits) and the fingerprint (the 16 bits below
-// them); a second, differently mixed multiply gives bucket B.
+// Tier-4 hashing.  One multiply gives bucket A (top bits) and the fingerprint (11 bits below them); a
+// second, differently mixed multiply gives bucket B.
 AM_HD uint32_t t4_hash_a(uint32_t key) { return key * 0x85EBCA6Bu; }
 AM_HD uint32_t t4_hash_b(uint32_t key) { return (key ^ (key >> 15)) * 0xC2B2AE35u; }
 AM_HD uint32_t t4_bucket(uint32_t h, uint32_t log2_buckets) { return h >> (32u - log2_buckets); }
-AM_HD uint32_t t4_fingerprint(uint32_t ha, uint32_t log2_buckets) { return (ha >> (log2_buckets < 16u ? 16u - log2_buckets : 0u)) & 0xFFFFu; }
-// hot slot word: fingerprint (0-15) | selector byte of the node's single edge (16-23) | flags (24-31)
-constexpr uint32_t kT4Occupied = 1u << 24;    // slot in use
-constexpr uint32_t kT4Terminal = 1u << 25;    // a 4-byte needle (variant) ends at the node
-constexpr uint32_t kT4Single = 1u << 26;      // the node has exactly one outgoing edge (selector byte valid)
-constexpr uint32_t kT4Multi = 1u << 27;       // the node has several outgoing edges
+AM_HD uint32_t t4_fingerprint(uint32_t ha, uint32_t log2_buckets) { return (ha >> (log2_buckets < 21u ? 21u - log2_buckets : 0u)) & 0x7FFu; }
+// hot slot word: fingerprint (bits 0-10) | flags (11-15) | sel1 (16-23) | sel2 (24-31)
+constexpr uint32_t kT4Occupied = 1u << 11;    // slot in use
+constexpr uint32_t kT4Terminal = 1u << 12;    // a 4-byte needle (variant) ends at the depth-4 node
+constexpr uint32_t kT4Single = 1u << 13;      // the node has exactly one outgoing edge; sel1 = its selector byte
+constexpr uint32_t kT4Multi = 1u << 14;       // the node has several outgoing edges
+constexpr uint32_t kT4Single2 = 1u << 15;     // ... and after sel1 the trie is still a plain chain with no needle end: the next byte must be sel2
 
-// can this hot slot word belong to a needle ending at a position whose last 4 bytes hash to `fp`
-// and whose preceding byte is `nb` (ignored when the haystack has no more bytes: more == 0)?
-// Pure bit arithmetic on purpose: the probe runs this 8 times per candidate and must not branch.
-AM_HD uint32_t t4_slot_may_match(uint32_t slot, uint32_t fp, uint32_t nb, uint32_t more)
+// can this hot slot word belong to a needle ending at a position whose last 4 bytes hash to `fp` and
+// whose two preceding bytes are nb (nearest) and nb2?  more1 / more2: the haystack has at least 5 / 6
+// bytes up to the position.  Pure bit arithmetic on purpose: the probe must not branch.
+AM_HD uint32_t t4_slot_may_match(uint32_t slot, uint32_t fp, uint32_t nb, uint32_t nb2, uint32_t more1, uint32_t more2)
 {
-    const uint32_t fp_ok = (uint32_t)((slot & (kT4Occupied | 0xFFFFu)) == (kT4Occupied | fp));
-    const uint32_t term = (slot >> 25) & 1u, single = (slot >> 26) & 1u, multi = (slot >> 27) & 1u;
-    const uint32_t sel_ok = (uint32_t)(((slot >> 16) & 0xFFu) == nb);
-    return fp_ok & (term | (more & (multi | (single & sel_ok))));
+    const uint32_t fp_ok = (uint32_t)((slot & 0xFFFu) == (kT4Occupied | fp));
+    const uint32_t term = (slot >> 12) & 1u, single = (slot >> 13) & 1u, multi = (slot >> 14) & 1u, single2 = (slot >> 15) & 1u;
+    const uint32_t sel1_ok = (uint32_t)(((slot >> 16) & 0xFFu) == nb), sel2_ok = (uint32_t)((slot >> 24) == nb2);
+    const uint32_t chain = single & sel1_ok & ((single2 ^ 1u) | (more2 & sel2_ok));
+    return fp_ok & (term | (more1 & (multi | chain)));
 }
 
 // Phase 1, N candidates per lane at once.  Inputs come straight from the filter stage's registers
-// (w = the 4 bytes ending at the position, nb = the byte before them, both case-folded), so the only
-// memory traffic is the two hot buckets, both in flight together, no data-dependent loop.
-// defer[k] = true: a needle may end here, sf_resolve must look (exactly).
+// (w = the 4 bytes ending at the position, nbs = the two bytes before them: nearest in bits 0-7, the
+// other in bits 8-15; all case-folded), so the only memory traffic is the two hot buckets, both in
+// flight together, no data-dependent loop.
+// defer[k] = true: a needle may end here, phase 2 must look (exactly).
 template <int N>
-AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nb)[N], const uint64_t (&avail)[N],
+AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N],
                       const bool (&valid)[N], bool (&defer)[N], uint32_t ablate = 0)
 {
-    u32x4 ba[N], bb[N];
+    u32x2 ba[N], bb[N];
     uint32_t fp[N];
     bool probe[N];
     const uint32_t lb = s.tier_log2_cap[3];
 #pragma unroll
     for (int k = 0; k < N; k++) probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
-    if (ablate == 2) { for (int k = 0; k < N; k++) defer[k] = valid[k] && w[k] == 0x12345678u && nb[k] == 0x9au; return; }   // timing experiment only
+    if (ablate == 2) { for (int k = 0; k < N; k++) defer[k] = valid[k] && w[k] == 0x12345678u && nbs[k] == 0x9au; return; }   // timing experiment only
 #if defined(__HIP_DEVICE_COMPILE__)
     {
-        uint4 ra[N], rb[N];
+        uint2 ra[N], rb[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const uint32_t ha = t4_hash_a(w[k]), hb = t4_hash_b(w[k]);
             fp[k] = t4_fingerprint(ha, lb);
-            ra[k] = make_uint4(0, 0, 0, 0); rb[k] = ra[k];
+            ra[k] = make_uint2(0, 0); rb[k] = ra[k];
             if (probe[k]) {
-                ra[k] = *reinterpret_cast<const uint4*>(s.t4_hot + t4_bucket(ha, lb));
-                rb[k] = *reinterpret_cast<const uint4*>(s.t4_hot + t4_bucket(hb, lb));
+                ra[k] = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(ha, lb));
+                rb[k] = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(hb, lb));
             }
         }
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            asm volatile("" : "+v"(ra[k].x), "+v"(ra[k].y), "+v"(ra[k].z), "+v"(ra[k].w), "+v"(rb[k].x), "+v"(rb[k].y), "+v"(rb[k].z), "+v"(rb[k].w));
-            ba[k] = u32x4{ra[k].x, ra[k].y, ra[k].z, ra[k].w};
-            bb[k] = u32x4{rb[k].x, rb[k].y, rb[k].z, rb[k].w};
+            asm volatile("" : "+v"(ra[k].x), "+v"(ra[k].y), "+v"(rb[k].x), "+v"(rb[k].y));     // all loads in flight before the first use
+            ba[k] = u32x2{ra[k].x, ra[k].y};
+            bb[k] = u32x2{rb[k].x, rb[k].y};
         }
     }
 #else
     for (int k = 0; k < N; k++) {
         const uint32_t ha = t4_hash_a(w[k]), hb = t4_hash_b(w[k]);
         fp[k] = t4_fingerprint(ha, lb);
-        ba[k] = probe[k] ? s.t4_hot[t4_bucket(ha, lb)] : u32x4{0, 0, 0, 0};
-        bb[k] = probe[k] ? s.t4_hot[t4_bucket(hb, lb)] : u32x4{0, 0, 0, 0};
+        ba[k] = probe[k] ? s.t4_hot[t4_bucket(ha, lb)] : u32x2{0, 0};
+        bb[k] = probe[k] ? s.t4_hot[t4_bucket(hb, lb)] : u32x2{0, 0};
     }
 #endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const uint32_t more = (uint32_t)(avail[k] > 4);
-        uint32_t hit = t4_slot_may_match(ba[k].x, fp[k], nb[k], more) | t4_slot_may_match(ba[k].y, fp[k], nb[k], more) |
-                       t4_slot_may_match(ba[k].z, fp[k], nb[k], more) | t4_slot_may_match(ba[k].w, fp[k], nb[k], more) |
-                       t4_slot_may_match(bb[k].x, fp[k], nb[k], more) | t4_slot_may_match(bb[k].y, fp[k], nb[k], more) |
-                       t4_slot_may_match(bb[k].z, fp[k], nb[k], more) | t4_slot_may_match(bb[k].w, fp[k], nb[k], more);
+        const uint32_t more1 = (uint32_t)(avail[k] > 4), more2 = (uint32_t)(avail[k] > 5);
+        const uint32_t nb = nbs[k] & 0xFFu, nb2 = (nbs[k] >> 8) & 0xFFu;
+        uint32_t hit = t4_slot_may_match(ba[k].x, fp[k], nb, nb2, more1, more2) | t4_slot_may_match(ba[k].y, fp[k], nb, nb2, more1, more2) |
+                       t4_slot_may_match(bb[k].x, fp[k], nb, nb2, more1, more2) | t4_slot_may_match(bb[k].y, fp[k], nb, nb2, more1, more2);
         hit &= (uint32_t)probe[k];                               // empty buckets were substituted for non-probes anyway
         hit |= (uint32_t)((s.tiers & 7u) != 0u);                 // 1..3-byte needles: always consult their tables
         if (ablate == 3) hit &= (uint32_t)(ba[k].x == 0x12345678u);   // timing experiment only
@@ -391,15 +394,11 @@ AM_HD void sf_resolve_lookup(const SfView& s, const uint8_t* text, uint64_t gpos
     if (s.tiers & 8u) {
         const uint32_t lb = s.tier_log2_cap[3];
         const uint32_t ba = t4_bucket(t4_hash_a(w), lb), bb = t4_bucket(t4_hash_b(w), lb);
-        const u32x4 ka = s.t4_cold[2u * ba], na = s.t4_cold[2u * ba + 1u], kb = s.t4_cold[2u * bb], nb = s.t4_cold[2u * bb + 1u];
-        if (ka.x == w && na.x != kNone) node = na.x;
-        if (ka.y == w && na.y != kNone) node = na.y;
-        if (ka.z == w && na.z != kNone) node = na.z;
-        if (ka.w == w && na.w != kNone) node = na.w;
-        if (kb.x == w && nb.x != kNone) node = nb.x;
-        if (kb.y == w && nb.y != kNone) node = nb.y;
-        if (kb.z == w && nb.z != kNone) node = nb.z;
-        if (kb.w == w && nb.w != kNone) node = nb.w;
+        const u32x4 ca = s.t4_cold[ba], cb = s.t4_cold[bb];          // {key0, key1, node0, node1}
+        if (ca.x == w && ca.z != kNone) node = ca.z;
+        if (ca.y == w && ca.w != kNone) node = ca.w;
+        if (cb.x == w && cb.z != kNone) node = cb.z;
+        if (cb.y == w && cb.w != kNone) node = cb.w;
     }
 }
 
@@ -518,7 +517,7 @@ AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64
     uint32_t w, w2;
     load_suffix8(text, gpos, w, w2);
     if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
-    const uint32_t wa[1] = {w}, nba[1] = {w2 >> 24};
+    const uint32_t wa[1] = {w}, nba[1] = {(w2 >> 24) | (((w2 >> 16) & 0xFFu) << 8)};
     const uint64_t a[1] = {avail};
     const bool v[1] = {true};
     bool defer[1];

@@ -96,8 +96,9 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                         bool defer[2];
                         for (int k = 0; k < 2; k++) if (valid[k]) {
                             for (uint32_t j = 0; j < 4; j++) { uint32_t byte = g[k] >= j ? padded[(size_t)(g[k] - j)] : 0u; wv[k] |= byte << (24u - 8u * j); }
-                            nbv[k] = g[k] >= 4 ? padded[(size_t)(g[k] - 4)] : 0u;
-                            if (ic) { wv[k] = fold_dword(wv[k]); nbv[k] = fold_byte(nbv[k]); }
+                            uint32_t b1 = g[k] >= 4 ? padded[(size_t)(g[k] - 4)] : 0u, b2 = g[k] >= 5 ? padded[(size_t)(g[k] - 5)] : 0u;
+                            if (ic) { wv[k] = fold_dword(wv[k]); b1 = fold_byte(b1); b2 = fold_byte(b2); }
+                            nbv[k] = b1 | (b2 << 8);
                         }
                         sf_probe_n<2>(s, wv, nbv, a, valid, defer);
                         for (int k = 0; k < 2; k++) if (valid[k] && defer[k])

@@ -178,15 +178,15 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 
     // software pipeline: the next chunk's 16 B per lane (+ the 4 bytes before them) are requested
     // before the current chunk is filtered and probed, so HBM latency hides behind that work
-    auto fetch = [&](uint64_t cc, uint4& v, uint32_t& prev) {
+    auto fetch = [&](uint64_t cc, uint4& v, uint2& prev) {
         const uint64_t p = cc * kSfChunk + lane * 16u;
-        v = make_uint4(0, 0, 0, 0); prev = 0;
+        v = make_uint4(0, 0, 0, 0); prev = make_uint2(0, 0);
         if (cc < n_chunks && p < b.total) {
             typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
             const u32x4_native* src = reinterpret_cast<const u32x4_native*>(b.text + p);
             const u32x4_native t = NT ? __builtin_nontemporal_load(src) : *src;     // global_load_dwordx4 [nt]
             v = make_uint4(t.x, t.y, t.z, t.w);
-            if (p >= 4) prev = *reinterpret_cast<const uint32_t*>(b.text + p - 4);
+            if (p >= 8) prev = *reinterpret_cast<const uint2*>(b.text + p - 8);     // the 8 bytes before the lane's 16
         }
     };
     // optional phase timing (AM_SF_ABLATE=9): s_memtime deltas per wavefront, summed into o.dbg
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     if (timing) t_mark = __builtin_amdgcn_s_memtime();
     uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
     uint32_t hay0 = 0; uint64_t hs0 = 1, he0 = 0;       // cached haystack bracket [hs0, he0): empty until the first lookup
-    uint4 cur_v; uint32_t cur_prev;
+    uint4 cur_v; uint2 cur_prev;
     fetch(u * UC, cur_v, cur_prev);
 
     for (; u < n_units; u += n_waves) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
-            uint4 next_v = make_uint4(0, 0, 0, 0); uint32_t next_prev = 0;
+            uint4 next_v = make_uint4(0, 0, 0, 0); uint2 next_prev = make_uint2(0, 0);
             if (o.ablate == 8) fetch(c, cur_v, cur_prev);          // timing experiment only: no prefetch, expose HBM latency in the filter phase
             else fetch(ci + 1 < n_in_unit ? c + 1 : (u + n_waves) * UC, next_v, next_prev);
 
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
             (void)hay0;
 
-            uint32_t d0 = cur_prev, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
-            if (IC) { d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+            uint32_t dm = cur_prev.x, d0 = cur_prev.y, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+            if (IC) { dm = fold_dword(dm); d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
             const uint32_t d[5] = {d0, d1, d2, d3, d4};
             uint32_t cand = 0;
             {
@@ -258,16 +258,19 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 if (total == 0) break;
                 uint32_t idx = incl - n;
                 while (cand && idx < (uint32_t)kSfQ1) {
-                    // queue the candidate with its (already folded) window and the byte before it, so that
-                    // the probe needs no haystack load: bytes k+1..k+4 and k of the lane's 20-byte array
+                    // queue the candidate with its (already folded) window and the two bytes before it, so that
+                    // the probe needs no haystack load: with A = the lane's 24 bytes (8 before + its 16),
+                    // window = A[k+5..k+8], nearest previous byte = A[k+4], the one before = A[k+3]
                     const uint32_t k = __builtin_ctz(cand);
                     cand &= cand - 1u;
                     const uint32_t j = k >> 2, sh = k & 3u;
+                    const uint32_t pl = j == 0 ? dm : j == 1 ? d0 : j == 2 ? d1 : d2;
                     const uint32_t lo = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
                     const uint32_t hi = j == 0 ? d1 : j == 1 ? d2 : j == 2 ? d3 : d4;
                     const uint32_t w = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (sh + 1u)));
-                    const uint32_t nb = (lo >> (8u * sh)) & 0xFFu;
-                    q1[idx++] = make_uint2(w, (lane * 16u + k) | (nb << 16));
+                    const uint32_t two = (uint32_t)((((uint64_t)lo << 32) | pl) >> (8u * (sh + 3u))) & 0xFFFFu;   // A[k+3] | A[k+4] << 8
+                    const uint32_t nbs = (two >> 8) | ((two & 0xFFu) << 8);                                       // nearest byte in bits 0-7
+                    q1[idx++] = make_uint2(w, (lane * 16u + k) | (nbs << 16));
                 }
                 const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
                 wave_lds_fence();
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                         const uint32_t e = base + 64u * k + lane;
                         valid[k] = e < n_q1;
                         const uint2 ent = valid[k] ? q1[e] : make_uint2(0u, 0u);
-                        w[k] = ent.x; pos[k] = ent.y & 1023u; nb[k] = ent.y >> 16;
+                        w[k] = ent.x; pos[k] = ent.y & 1023u; nb[k] = ent.y >> 16;      // nb = previous two bytes
                         const uint64_t gpos = c0 + pos[k];
                         avail[k] = gpos - hs0 + 1;
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
