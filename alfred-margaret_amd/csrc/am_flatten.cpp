@@ -362,6 +362,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             } else if (n > 1) {
                 rec.z = (uint32_t)edges_out.size();
                 rec.w = n;
+                if (n <= 4) for (uint32_t i = 0; i < n; i++) rec.label[0] |= cedges[c_order[c_first[x] + i]].byte << (8u * i);   // inline selectors
                 for (uint32_t e = c_first[x]; e < c_first[x + 1]; e++) {
                     const CEdge& ce = cedges[c_order[e]];
                     SfEdge ed{ce.byte, new_id[ce.dst], (uint32_t)ce.skip.size(), 0, {0, 0, 0, 0}};

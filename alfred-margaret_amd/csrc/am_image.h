@@ -90,7 +90,7 @@ struct alignas(32) SfNode {
     uint32_t y;          // vlen = length machineValues[state]
     uint32_t z;          // n_edges == 1: child node; n_edges > 1: first SfEdge index
     uint32_t w;          // n_edges (bits 0-15) | selector byte of the single edge (16-23) | its skip length (24-31)
-    uint32_t label[4];   // skip bytes of the single edge
+    uint32_t label[4];   // n_edges == 1: skip bytes of the single edge; 2..4 edges: label[0] = their selector bytes (edge i in byte i)
 };
 struct alignas(32) SfEdge {
     uint32_t byte, child, skip, pad;
@@ -238,22 +238,19 @@ AM_HD uint32_t find_haystack(const BatchView& b, uint64_t pos)
 // buffer: zeros) are never interpreted: every use is guarded by `avail`.
 AM_HD void load_suffix8(const uint8_t* text, uint64_t gpos, uint32_t& w, uint32_t& w2)
 {
-    if (gpos >= 7) {
+    // branch-free: always one 8-byte read; for the first 7 bytes of the batch read text[0..7] and shift
+    const uint64_t base = gpos >= 7 ? gpos - 7 : 0;
+    const uint32_t drop = gpos >= 7 ? 0u : (uint32_t)(7 - gpos);     // missing leading bytes
+    uint64_t v;
 #if defined(__HIP_DEVICE_COMPILE__)
-        typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
-        w2 = *reinterpret_cast<const u32_unaligned*>(text + gpos - 7);
-        w = *reinterpret_cast<const u32_unaligned*>(text + gpos - 3);
+    typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+    v = *reinterpret_cast<const u64_unaligned*>(text + base);
 #else
-        w = 0; w2 = 0;
-        for (uint32_t j = 0; j < 4; j++) { w |= (uint32_t)text[gpos - j] << (24u - 8u * j); w2 |= (uint32_t)text[gpos - 4 - j] << (24u - 8u * j); }
+    v = 0;
+    for (uint32_t j = 0; j < 8; j++) v |= (uint64_t)text[base + j] << (8u * j);
 #endif
-    } else {
-        w = 0; w2 = 0;
-        for (uint32_t j = 0; j < 8 && j <= gpos; j++) {
-            const uint32_t b = text[gpos - j];
-            if (j < 4) w |= b << (24u - 8u * j); else w2 |= b << (24u - 8u * (j - 4u));
-        }
-    }
+    v = drop ? (v << (8u * drop)) : v;          // byte gpos ends up in the top byte, bytes before the buffer are zero
+    w2 = (uint32_t)v; w = (uint32_t)(v >> 32);
 }
 
 // 16 haystack bytes ending just before global index `end` (text order, dword 3 = the newest four)
@@ -382,132 +379,184 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
     }
 }
 
-// Phase 2a: everything that depends only on the position: the last 8 haystack bytes, then the exact
-// (cold-side) lookup of the 4-byte suffix -- four independent 16-byte loads, no loop.  node = kNone
-// if no needle (variant) has this 4-byte suffix.
-template <bool IC>
-AM_HD void sf_resolve_lookup(const SfView& s, const uint8_t* text, uint64_t gpos, uint32_t& w, uint32_t& w2, uint32_t& node)
+// ---------------------------------------------------------------------------------------------------
+// Phase 2 ("resolve"): exact answer for the few positions that survived filter + probe, N positions
+// per lane in lock step.  Every step issues the loads of all N items before any of them is consumed,
+// so the N dependent-load chains (haystack bytes -> cold bucket -> trie node -> [edge -> child ...])
+// overlap instead of adding up.  Data-dependent loops live only here.
+
+AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
 {
-    load_suffix8(text, gpos, w, w2);
-    if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
-    node = kNone;
-    if (s.tiers & 8u) {
+    n.x = a.x; n.y = a.y; n.z = a.z; n.w = a.w; n.label[0] = b.x; n.label[1] = b.y; n.label[2] = b.z; n.label[3] = b.w;
+}
+
+template <bool IC, int N>
+AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail)[N], const bool (&valid)[N],
+                        bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N])
+{
+    const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
+    const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 2 x 16 B per edge
+    uint32_t w[N], w2[N], node[N];
+    // ---- step 1: last 8 haystack bytes
+#pragma unroll
+    for (int k = 0; k < N; k++) { w[k] = 0; w2[k] = 0; if (valid[k]) load_suffix8(text, gpos[k], w[k], w2[k]); }
+#pragma unroll
+    for (int k = 0; k < N; k++) if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
+    // ---- step 2: exact lookup of the 4-byte suffix on the cold side of the cuckoo table
+    {
+        u32x4 ca[N], cb[N];
         const uint32_t lb = s.tier_log2_cap[3];
-        const uint32_t ba = t4_bucket(t4_hash_a(w), lb), bb = t4_bucket(t4_hash_b(w), lb);
-        const u32x4 ca = s.t4_cold[ba], cb = s.t4_cold[bb];          // {key0, key1, node0, node1}
-        if (ca.x == w && ca.z != kNone) node = ca.z;
-        if (ca.y == w && ca.w != kNone) node = ca.w;
-        if (cb.x == w && cb.z != kNone) node = cb.z;
-        if (cb.y == w && cb.w != kNone) node = cb.w;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const bool look = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
+            const uint32_t ba = look ? t4_bucket(t4_hash_a(w[k]), lb) : 0u, bb = look ? t4_bucket(t4_hash_b(w[k]), lb) : 0u;
+            ca[k] = s.t4_cold[ba]; cb[k] = s.t4_cold[bb];              // {key0, key1, node0, node1}
+            if (!look) { ca[k].z = ca[k].w = cb[k].z = cb[k].w = kNone; }
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            node[k] = kNone;
+            if (ca[k].x == w[k] && ca[k].z != kNone) node[k] = ca[k].z;
+            if (ca[k].y == w[k] && ca[k].w != kNone) node[k] = ca[k].w;
+            if (cb[k].x == w[k] && cb[k].z != kNone) node[k] = cb[k].z;
+            if (cb[k].y == w[k] && cb[k].w != kNone) node[k] = cb[k].w;
+        }
     }
-}
-
-// Speculative loads for phase 2b, issued together so that a typical needle (<= 21 bytes, its tail one
-// compressed edge, child numbered right after its parent by the DFS renumbering) resolves without any
-// further dependent load: the depth-4 node, the record after it, and the 16 haystack bytes the first
-// edge label would be compared with.
-struct SfPre {
-    uint32_t node;         // kNone: nothing preloaded
-    SfNode n0, n1;
-    uint32_t t16[4];       // raw (unfolded) bytes text[gpos-20 .. gpos-5]
-};
-
-template <bool IC>
-AM_HD void sf_resolve_preload(const SfView& s, const uint8_t* text, uint64_t gpos, uint32_t node, SfPre& pre)
-{
-    pre.node = node;
-    if (node == kNone) return;
-    const uint32_t next = node + 1u < s.n_nodes ? node + 1u : node;
-    load_node(s.nodes + node, pre.n0);
-    load_node(s.nodes + next, pre.n1);
-    pre.t16[0] = pre.t16[1] = pre.t16[2] = pre.t16[3] = 0;
-    if (gpos >= 4) load_text16(text, gpos - 4, pre.t16);      // fewer than 5 bytes before: no edge label can be compared anyway
-    if (IC) { pre.t16[0] = fold_dword(pre.t16[0]); pre.t16[1] = fold_dword(pre.t16[1]); pre.t16[2] = fold_dword(pre.t16[2]); pre.t16[3] = fold_dword(pre.t16[3]); }
-}
-
-// Phase 2b: walk the compressed trie from the depth-4 node along the haystack (backwards) and return
-// the deepest needle end; falls back to the 1..3-byte tables.  Data-dependent loops live only here,
-// and the kernel batches these rare items so that a whole wavefront resolves them together.
-template <bool IC>
-AM_HD bool sf_resolve_walk(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t w, uint32_t w2, uint32_t node,
-                           const SfPre& pre, uint32_t& state, uint32_t& vlen)
-{
-    uint32_t best_state = 0, best_vlen = 0;          // state + 1
-    if (avail < 4) node = kNone;
-    if (node != kNone) {
-        auto fetch_node = [&](uint32_t id, SfNode& out) {
-            if (pre.node != kNone && id == pre.node) out = pre.n0;
-            else if (pre.node != kNone && id == pre.node + 1u && pre.node + 1u < s.n_nodes) out = pre.n1;
-            else load_node(s.nodes + id, out);
-        };
-        uint64_t depth = 4;
-        SfNode rec;
-        fetch_node(node, rec);
-        if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
-        bool go = depth < avail && (rec.w & 0xFFFFu) != 0;
-        while (go) {
-            const uint32_t n_edges = rec.w & 0xFFFFu;
+    // ---- step 3: speculative loads -- the depth-4 node, the record after it (the DFS renumbering puts
+    // a single child right after its parent) and the 16 haystack bytes the first edge label would be
+    // compared with.  A typical needle (<= 21 bytes) then resolves without further loads.
+    SfNode rec[N], nxt[N];
+    uint32_t t16[N][4];
+    {
+        u32x4 r0[N], r1[N], r2[N], r3[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const uint32_t id = node[k] != kNone ? node[k] : 0u;
+            const uint32_t id1 = id + 1u < s.n_nodes ? id + 1u : id;
+            r0[k] = nodes16[2u * id]; r1[k] = nodes16[2u * id + 1u]; r2[k] = nodes16[2u * id1]; r3[k] = nodes16[2u * id1 + 1u];
+            t16[k][0] = t16[k][1] = t16[k][2] = t16[k][3] = 0;
+            if (node[k] != kNone && gpos[k] >= 4) load_text16(text, gpos[k] - 4, t16[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            node_from_raw(r0[k], r1[k], rec[k]); node_from_raw(r2[k], r3[k], nxt[k]);
+            if (IC) { t16[k][0] = fold_dword(t16[k][0]); t16[k][1] = fold_dword(t16[k][1]); t16[k][2] = fold_dword(t16[k][2]); t16[k][3] = fold_dword(t16[k][3]); }
+        }
+    }
+    // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
+    uint32_t best_state[N], best_vlen[N], pre_node[N];
+    uint64_t depth[N];
+    bool go[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        best_state[k] = 0; best_vlen[k] = 0; depth[k] = 4; pre_node[k] = node[k]; go[k] = false;
+        if (node[k] != kNone) {
+            if (rec[k].x) { best_state[k] = rec[k].x; best_vlen[k] = rec[k].y; }
+            go[k] = depth[k] < avail[k] && (rec[k].w & 0xFFFFu) != 0;
+        }
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < N; k++) any = any || go[k];
+        if (!any) break;
+        // 4a: which edge?  (selector bytes are inline for nodes with <= 4 edges; the edge record itself
+        //     is only needed for multi-edge nodes and is loaded for all N items together)
+        uint32_t which[N], next[N], skip[N], label[N][4];
+        u32x4 e0[N], e1[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            which[k] = kNone; next[k] = kNone; skip[k] = 0;
+            label[k][0] = rec[k].label[0]; label[k][1] = rec[k].label[1]; label[k][2] = rec[k].label[2]; label[k][3] = rec[k].label[3];
+            e0[k] = u32x4{0, 0, 0, 0}; e1[k] = e0[k];
+            if (!go[k]) continue;
+            const uint32_t n_edges = rec[k].w & 0xFFFFu;
             uint32_t b;
-            if (depth < 8) b = (w2 >> (8u * (7u - (uint32_t)depth))) & 0xFFu;
-            else { b = text[gpos - depth]; if (IC) b = fold_byte(b); }
-            uint32_t next = kNone, skip = 0;
-            uint32_t label[4] = {rec.label[0], rec.label[1], rec.label[2], rec.label[3]};
+            if (depth[k] < 8) b = (w2[k] >> (8u * (7u - (uint32_t)depth[k]))) & 0xFFu;
+            else { b = text[gpos[k] - depth[k]]; if (IC) b = fold_byte(b); }
             if (n_edges == 1) {
-                if (((rec.w >> 16) & 0xFFu) == b) { next = rec.z; skip = rec.w >> 24; }
+                if (((rec[k].w >> 16) & 0xFFu) == b) { next[k] = rec[k].z; skip[k] = rec[k].w >> 24; }
+            } else if (n_edges <= 4) {
+                for (uint32_t i = 0; i < n_edges; i++) if (((rec[k].label[0] >> (8u * i)) & 0xFFu) == b) which[k] = rec[k].z + i;
             } else {
-                uint32_t lo = rec.z, hi = rec.z + n_edges;   // edges sorted by selector byte
+                uint32_t lo = rec[k].z, hi = rec[k].z + n_edges;   // edges sorted by selector byte (rare: > 4 children below depth 4)
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
                     const uint32_t eb = s.edges[mid].byte;
-                    if (eb == b) {
-                        const SfEdge ed = s.edges[mid];
-                        next = ed.child; skip = ed.skip;
-                        label[0] = ed.label[0]; label[1] = ed.label[1]; label[2] = ed.label[2]; label[3] = ed.label[3];
-                        break;
-                    }
+                    if (eb == b) { which[k] = mid; break; }
                     if (eb < b) lo = mid + 1; else hi = mid;
                 }
             }
-            if (next == kNone) break;
-            if (skip) {
-                if (depth + 1 + skip > avail) break;
-                uint32_t t[4];
-                if (pre.node != kNone && depth == 4) { t[0] = pre.t16[0]; t[1] = pre.t16[1]; t[2] = pre.t16[2]; t[3] = pre.t16[3]; }
-                else {
-                    load_text16(text, gpos - depth, t);       // the 16 bytes before the selector byte
-                    if (IC) { t[0] = fold_dword(t[0]); t[1] = fold_dword(t[1]); t[2] = fold_dword(t[2]); t[3] = fold_dword(t[3]); }
+            if (which[k] != kNone) { e0[k] = edges16[2u * which[k]]; e1[k] = edges16[2u * which[k] + 1u]; }
+        }
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            if (which[k] != kNone) {
+                next[k] = e0[k].y; skip[k] = e0[k].z;                       // SfEdge {byte, child, skip, pad, label[4]}
+                label[k][0] = e1[k].x; label[k][1] = e1[k].y; label[k][2] = e1[k].z; label[k][3] = e1[k].w;
+            }
+            if (next[k] == kNone || depth[k] + 1 + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
+        }
+        // 4b: child record + the 16 bytes to compare with the label, for all N items together
+        SfNode child[N];
+        uint32_t t[N][4];
+        {
+            u32x4 c0[N], c1[N];
+            bool from_mem[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                from_mem[k] = false;
+                c0[k] = u32x4{0, 0, 0, 0}; c1[k] = c0[k];
+                t[k][0] = t16[k][0]; t[k][1] = t16[k][1]; t[k][2] = t16[k][2]; t[k][3] = t16[k][3];
+                if (!go[k]) continue;
+                const bool is_next = pre_node[k] != kNone && next[k] == pre_node[k] + 1u && pre_node[k] + 1u < s.n_nodes;
+                if (!is_next) { from_mem[k] = true; c0[k] = nodes16[2u * next[k]]; c1[k] = nodes16[2u * next[k] + 1u]; }
+                if (skip[k] && depth[k] != 4) {
+                    load_text16(text, gpos[k] - depth[k], t[k]);       // the 16 bytes before the selector byte
+                    if (IC) { t[k][0] = fold_dword(t[k][0]); t[k][1] = fold_dword(t[k][1]); t[k][2] = fold_dword(t[k][2]); t[k][3] = fold_dword(t[k][3]); }
                 }
-                if (!label_match(t, label, skip)) break;
             }
-            node = next; depth += 1u + skip;
-            fetch_node(node, rec);
-            if (rec.x) { best_state = rec.x; best_vlen = rec.y; }
-            go = depth < avail && (rec.w & 0xFFFFu) != 0;
+#pragma unroll
+            for (int k = 0; k < N; k++) { if (from_mem[k]) node_from_raw(c0[k], c1[k], child[k]); else child[k] = nxt[k]; }
+        }
+        // 4c: compare the label, advance
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            if (!go[k]) continue;
+            if (skip[k] && !label_match(t[k], label[k], skip[k])) { go[k] = false; continue; }
+            depth[k] += 1u + skip[k];
+            rec[k] = child[k];
+            if (rec[k].x) { best_state[k] = rec[k].x; best_vlen[k] = rec[k].y; }
+            go[k] = depth[k] < avail[k] && (rec[k].w & 0xFFFFu) != 0;
         }
     }
-    if (!best_state && (s.tiers & 7u)) {
-        uint32_t short_node = kNone;
-        for (uint32_t t = 3; t >= 1; t--) {
-            if ((s.tiers & (1u << (t - 1))) && avail >= t) {
-                short_node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w >> (8u * (4u - t)));
-                if (short_node != kNone) break;
+    // ---- step 5: needles of 1..3 bytes (only if nothing longer ends here)
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (valid[k] && !best_state[k] && (s.tiers & 7u)) {
+            uint32_t short_node = kNone;
+            for (uint32_t t = 3; t >= 1; t--) {
+                if ((s.tiers & (1u << (t - 1))) && avail[k] >= t) {
+                    short_node = tier_lookup(s.tier[t - 1], s.tier_log2_cap[t - 1], w[k] >> (8u * (4u - t)));
+                    if (short_node != kNone) break;
+                }
             }
+            if (short_node != kNone) { best_state[k] = s.nodes[short_node].x; best_vlen[k] = s.nodes[short_node].y; }
         }
-        if (short_node != kNone) { best_state = s.nodes[short_node].x; best_vlen = s.nodes[short_node].y; }
+        found[k] = valid[k] && best_state[k] != 0;
+        state[k] = best_state[k] - 1u; vlen[k] = best_vlen[k];
     }
-    if (!best_state) return false;
-    state = best_state - 1u; vlen = best_vlen;
-    return true;
 }
 
 template <bool IC>
 AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
 {
-    uint32_t w, w2, node;
-    sf_resolve_lookup<IC>(s, text, gpos, w, w2, node);
-    SfPre pre;
-    sf_resolve_preload<IC>(s, text, gpos, node, pre);      // same order of operations as the kernel
-    return sf_resolve_walk<IC>(s, text, gpos, avail, w, w2, node, pre, state, vlen);
+    const uint64_t g[1] = {gpos}, a[1] = {avail};
+    const bool v[1] = {true};
+    bool f[1]; uint32_t st[1], vl[1];
+    sf_resolve_n<IC, 1>(s, text, g, a, v, f, st, vl);
+    state = st[0]; vlen = vl[0];
+    return f[0];
 }
 
 // probe + resolve for one position (host checker, and the reference for what the kernel computes)

@@ -101,8 +101,10 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                             nbv[k] = b1 | (b2 << 8);
                         }
                         sf_probe_n<2>(s, wv, nbv, a, valid, defer);
-                        for (int k = 0; k < 2; k++) if (valid[k] && defer[k])
-                            found[k] = ic ? sf_resolve<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_resolve<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);
+                        // phase 2, two items in lock step as in the kernel
+                        bool todo[2] = {valid[0] && defer[0], valid[1] && defer[1]};
+                        if (ic) sf_resolve_n<true, 2>(s, padded.data(), g, a, todo, found, st, vl);
+                        else sf_resolve_n<false, 2>(s, padded.data(), g, a, todo, found, st, vl);
                     } else {
                         for (int k = 0; k < 2; k++) if (valid[k])
                             found[k] = ic ? sf_verify<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_verify<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);

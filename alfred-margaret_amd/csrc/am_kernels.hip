@@ -117,61 +117,75 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     uint32_t unit_count = 0, cur_block = kNone, first_block = kNone;
     bool pool_ok = true;
 
-    // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items (all belong to the current unit)
+    // optional phase timing (AM_SF_ABLATE>=8): s_memtime deltas per wavefront, summed into o.dbg
+    const bool timing = o.dbg != nullptr;
+    uint64_t t_filter = 0, t_compact = 0, t_probe = 0, t_resolve = 0, t_probe_pre = 0, t_mark = 0;
+    uint64_t t_r0 = 0, t_r1 = 0, t_r2 = 0, t_r3 = 0, n_batches = 0;
+    auto tick = [&](uint64_t& acc) { if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc += now - t_mark; t_mark = now; } };
+
+    // ---- phase 2: resolve the oldest `nb` (<= 64 * RN) deferred items, RN per lane in lock step (all
+    // belong to the current unit).  Item j of the batch sits in lane j % 64, slot j / 64, so ranks by
+    // (slot, lane) reproduce the FIFO = position order.
+    constexpr int RN = 1;      // 2 halves the number of latency chains but spills registers (measured: 2x slower overall)
     auto resolve_batch = [&](uint32_t nb) {
-        const bool valid = lane < nb;
-        bool found = false;
-        uint32_t state = 0, vlen = 0, hay = 0;
-        uint64_t end_pos = 0;
-        if (valid) {
-            const uint32_t item = q2[(q2_head + lane) % kSfQ2];
-            const uint64_t gpos = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
-            // independent loads first (haystack bracket, last 8 bytes -> cold buckets), then what depends on them
-            const uint32_t hlo = b.hidx[gpos >> kHidxShift], hhi = b.hidx[(gpos >> kHidxShift) + 1];
-            uint32_t w, w2, node;
-            sf_resolve_lookup<IC>(s, b.text, gpos, w, w2, node);
-            hay = hlo;
-            if (hlo != hhi) hay = find_haystack(b, gpos);
-            const uint64_t hs = b.offsets[hay];
-            SfPre pre;
-            sf_resolve_preload<IC>(s, b.text, gpos, node, pre);     // node, node + 1, 16 label bytes: all in flight with offsets[hay]
-            end_pos = gpos - hs + 1;
-            found = sf_resolve_walk<IC>(s, b.text, gpos, end_pos, w, w2, node, pre, state, vlen);
+        uint64_t gpos[RN], end_pos[RN];
+        uint32_t hay[RN], state[RN], vlen[RN], hlo[RN], hhi[RN];
+        bool valid[RN], found[RN];
+        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; }
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            valid[k] = 64u * k + lane < nb;
+            const uint32_t item = valid[k] ? q2[(q2_head + 64u * k + lane) % kSfQ2] : 0u;
+            gpos[k] = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
+            hlo[k] = 0; hhi[k] = 0;
+            if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
         }
-        const uint64_t found_mask = __ballot(found);
-        if (MODE == kModeCount) {
-            if (found) {
-                nval += vlen;
-                if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
-            }
-        } else if (MODE == kModeEmit) {
-            const uint32_t F = (uint32_t)__popcll(found_mask);
-            if (F) {
-                const uint32_t r = unit_count & (kPoolBlock - 1u);      // fill of the current block
-                const bool need_new = r == 0u || r + F > kPoolBlock;
-                uint32_t new_block = kNone;
-                if (need_new) {
-                    uint32_t id = 0;
-                    if (lane == 0) id = atomicAdd(o.pool_ctrl, 1u);
-                    id = __builtin_amdgcn_readfirstlane(id);
-                    if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }   // keep counting, host retries with a larger pool
-                    else {
-                        new_block = id;
-                        if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
-                        if (first_block == kNone) first_block = id;
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            hay[k] = hlo[k];
+            if (valid[k] && hlo[k] != hhi[k]) hay[k] = find_haystack(b, gpos[k]);
+            end_pos[k] = valid[k] ? gpos[k] - b.offsets[hay[k]] + 1 : 0;
+        }
+        if (timing) { asm volatile("" :: "v"((uint32_t)end_pos[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r1 += now - t_mark; t_mark = now; }
+        sf_resolve_n<IC, RN>(s, b.text, gpos, end_pos, valid, found, state, vlen);
+        if (timing) { asm volatile("" :: "v"((uint32_t)found[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; n_batches++; }
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            const uint64_t found_mask = __ballot(found[k]);
+            if (MODE == kModeCount) {
+                if (found[k]) {
+                    nval += vlen[k];
+                    if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)vlen[k]);
+                }
+            } else if (MODE == kModeEmit) {
+                const uint32_t F = (uint32_t)__popcll(found_mask);
+                if (F) {
+                    const uint32_t r = unit_count & (kPoolBlock - 1u);      // fill of the current block
+                    const bool need_new = r == 0u || r + F > kPoolBlock;
+                    uint32_t new_block = kNone;
+                    if (need_new) {
+                        uint32_t id = 0;
+                        if (lane == 0) id = atomicAdd(o.pool_ctrl, 1u);
+                        id = __builtin_amdgcn_readfirstlane(id);
+                        if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }   // keep counting, host retries with a larger pool
+                        else {
+                            new_block = id;
+                            if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
+                            if (first_block == kNone) first_block = id;
+                        }
                     }
+                    if (found[k] && pool_ok) {
+                        const uint32_t p = r + (uint32_t)__popcll(found_mask & ((1ull << lane) - 1ull));
+                        const Record rec{end_pos[k], hay[k], state[k]};
+                        if (r != 0u && p < kPoolBlock) o.pool[(uint64_t)cur_block * kPoolBlock + p] = rec;
+                        else o.pool[(uint64_t)new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p)] = rec;
+                    }
+                    if (need_new) cur_block = new_block;
+                    unit_count += F;
                 }
-                if (found && pool_ok) {
-                    const uint32_t p = r + (uint32_t)__popcll(found_mask & ((1ull << lane) - 1ull));
-                    const Record rec{end_pos, hay, state};
-                    if (r != 0u && p < kPoolBlock) o.pool[(uint64_t)cur_block * kPoolBlock + p] = rec;
-                    else o.pool[(uint64_t)new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p)] = rec;
-                }
-                if (need_new) cur_block = new_block;
-                unit_count += F;
+            } else {
+                if (found[k]) o.flags[hay[k]] = 1;
             }
-        } else {
-            if (found) o.flags[hay] = 1;
         }
         q2_head += nb;
     };
@@ -189,10 +203,6 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (p >= 8) prev = *reinterpret_cast<const uint2*>(b.text + p - 8);     // the 8 bytes before the lane's 16
         }
     };
-    // optional phase timing (AM_SF_ABLATE=9): s_memtime deltas per wavefront, summed into o.dbg
-    const bool timing = o.dbg != nullptr;
-    uint64_t t_filter = 0, t_compact = 0, t_probe = 0, t_resolve = 0, t_probe_pre = 0, t_mark = 0;
-    auto tick = [&](uint64_t& acc) { if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc += now - t_mark; t_mark = now; } };
     if (timing) t_mark = __builtin_amdgcn_s_memtime();
     uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
     uint32_t hay0 = 0; uint64_t hs0 = 1, he0 = 0;       // cached haystack bracket [hs0, he0): empty until the first lookup
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     }
                     wave_lds_fence();
                     tick(t_probe);
-                    while (q2_tail - q2_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }   // keeps room for the next round
+                    while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }   // keeps room for the next round
                     tick(t_resolve);
                 }
                 if (total <= (uint32_t)kSfQ1) break;
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         // end of unit: drain the ring so that every item of a batch belongs to one unit
         wave_lds_fence();
         tick(t_compact);
-        while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u ? nb : 64u); }
+        while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u * RN ? nb : 64u * RN); }
         tick(t_resolve);
         if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; }
     }
@@ -322,6 +332,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 3), (unsigned long long)t_resolve);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 4), 1ull);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 5), (unsigned long long)t_probe_pre);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 6), (unsigned long long)n_batches);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 7), (unsigned long long)t_r0);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 8), (unsigned long long)t_r1);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 9), (unsigned long long)t_r2);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 10), (unsigned long long)t_r3);
     }
 
     if (MODE == kModeCount) {
@@ -447,10 +462,10 @@ static uint64_t* g_sf_dbg = nullptr;
 // debug: per-phase s_memtime sums of k_sf launches run with AM_SF_ABLATE=9 (filter, compact, probe, resolve, waves)
 hipError_t read_sf_phase_cycles(uint64_t* out5)
 {
-    for (int i = 0; i < 6; i++) out5[i] = 0;
+    for (int i = 0; i < 11; i++) out5[i] = 0;
     if (!g_sf_dbg) return hipSuccess;
-    hipError_t e = hipMemcpy(out5, g_sf_dbg, 48, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemset(g_sf_dbg, 0, 64);
+    hipError_t e = hipMemcpy(out5, g_sf_dbg, 88, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemset(g_sf_dbg, 0, 128);
     return e;
 }
 
@@ -479,7 +494,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     o.ablate = ablate;
     static uint64_t* dbg = nullptr;
     if (ablate >= 8) {
-        if (!dbg) { if (hipMalloc((void**)&dbg, 64) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 64); }
+        if (!dbg) { if (hipMalloc((void**)&dbg, 128) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 128); }
         o.dbg = dbg;
         g_sf_dbg = dbg;
     }

@@ -18,7 +18,7 @@ offs = torch.arange(n_hay + 1, dtype=torch.int64, device="cuda:0") * w["hay_byte
 lib = am.api.libam()
 b = C.c_void_p()
 am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(b)))
-out = (C.c_uint64 * 6)()
+out = (C.c_uint64 * 11)()
 for mode in ("count", "emit"):
     for rep in range(2):
         if mode == "count":
@@ -29,5 +29,7 @@ for mode in ("count", "emit"):
     waves = max(out[4], 1)
     chunks = n_bytes / 1024 / waves
     tot_c = sum(out[i] for i in range(4))
+    nbat = max(out[6], 1)
+    print("   resolve batches/wave %.1f, cycles per batch: pre %.0f lookup %.0f preload %.0f walk %.0f" % (out[6] / waves, out[7] / nbat, out[8] / nbat, out[9] / nbat, out[10] / nbat))
     print("%s %s: waves %d, chunks/wave %.0f, cycles/chunk: filter %.0f compact %.0f probe-setup %.0f probe-mem %.0f resolve %.0f  total %.0f" % (
         wl, mode, waves, chunks, out[0] / waves / chunks, out[1] / waves / chunks, out[5] / waves / chunks, out[2] / waves / chunks, out[3] / waves / chunks, (tot_c + out[5]) / waves / chunks))
