@@ -50,11 +50,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libam has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AM_BENCH_SAME_DEVICE=1 + AM_BENCH_BACKEND=gloo: development aid to exercise the N-rank code path
+    # (image broadcast, attach, sharding, all-reduce) on a box with a single GPU; never used for numbers
+    same_device = os.environ.get("AM_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("AM_BENCH_BACKEND", "nccl")
+    dev_index = 0 if same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     w = synth.WORKLOADS[args.workload]

@@ -127,6 +127,18 @@ def test_fragment_pool(seed):
             check_all_paths(ns, hays, case)
 
 
+def test_synthetic_vectors_fixture():
+    """Product vs the committed vectors (no oracle involved at run time)."""
+    import json, os
+    from tests.conftest import ROOT
+    data = json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_vectors.json")))
+    for c in data["cases"]:
+        a = am.Automaton(c["needles"])
+        for k in ((0, 1) if "" in c["needles"] else (2, 1)):
+            a.set_kernel(k)
+            assert product_triples(a, c["case"], c["haystacks"]) == [tuple(t) for t in c["triples"]], (k, c["needles"])
+
+
 def test_slices_with_offsets():
     # TestInstances.hs:26-33 arbitraryOffset: positions are relative to the slice, not the array
     needles = ["tshirt", "shirts"]

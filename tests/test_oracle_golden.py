@@ -155,3 +155,15 @@ def test_replacer_limit():
     r = oracle.Replacer(0, [("a", "bbbb")])
     assert r.run("aa", max_len=8) == b"bbbbbbbb"
     assert r.run("aa", max_len=7) is None
+
+
+def test_synthetic_vectors_match_oracle():
+    """The committed synthetic vectors (tests/golden/synthetic_vectors.json) are reproduced by the oracle."""
+    import json, os
+    from tests.conftest import ROOT
+    from tests.helpers import oracle_triples
+    data = json.load(open(os.path.join(ROOT, "tests", "golden", "synthetic_vectors.json")))
+    assert len(data["cases"]) >= 100
+    for c in data["cases"]:
+        m = oracle.Machine(c["needles"])
+        assert oracle_triples(m, c["case"], c["haystacks"]) == [tuple(t) for t in c["triples"]]
