@@ -275,13 +275,24 @@ extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out
     }
     const uint64_t total = offs[n_hay];
     const size_t padded = (size_t)((total + 15) & ~15ull) + 16;
-    std::vector<uint8_t> stage(padded, 0);
-    for (size_t i = 0; i < n_hay; i++) if (hay[i].len) std::memcpy(stage.data() + offs[i], hay[i].ptr + hay[i].off, hay[i].len);
+    // gather the slices into a pinned staging buffer (kept for the next call) so that the H2D copy is one DMA
+    static std::mutex stage_mu;
+    static uint8_t* stage = nullptr;
+    static size_t stage_cap = 0;
+    std::lock_guard<std::mutex> stage_lk(stage_mu);
+    if (padded > stage_cap) {
+        if (stage) { (void)hipHostFree(stage); stage = nullptr; stage_cap = 0; }
+        const size_t want = padded + padded / 4;
+        if (hipHostMalloc((void**)&stage, want, hipHostMallocDefault) != hipSuccess) { stage = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc(staging) failed"); }
+        stage_cap = want;
+    }
+    for (size_t i = 0; i < n_hay; i++) if (hay[i].len) std::memcpy(stage + offs[i], hay[i].ptr + hay[i].off, hay[i].len);
+    std::memset(stage + total, 0, padded - (size_t)total);
     am_batch* b = new am_batch();
     b->owns = true; b->total = total; b->n_hay = (uint32_t)n_hay;
     hipError_t e = hipMalloc(&b->d_text, padded);
     if (e == hipSuccess) e = hipMalloc((void**)&b->d_offsets, offs.size() * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemcpy(b->d_text, stage.data(), padded, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(b->d_text, stage, padded, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_offsets, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     int rc = e == hipSuccess ? finish_batch(b) : fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e));
     if (rc != AM_OK) { am_batch_destroy(b); return rc; }
