@@ -91,6 +91,10 @@ _HOST = {
     "amh_replacer_free": (None, [_vp]),
     "amh_replacer_run_batch": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
     "amh_free_blob": (None, [_vp]),
+    "amh_splitter_build": (C.c_int, [C.c_char_p, _sz, C.POINTER(_vp)]),
+    "amh_splitter_free": (None, [_vp]),
+    "amh_splitter_split_batch": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp), C.POINTER(_vp), _u64p, _vp]),
+    "amh_free_u64": (None, [_vp]),
     "amh_skip_code_points_backwards": (C.c_int64, [C.c_char_p, _sz, _sz, _sz]),
     "amh_lower_utf8": (_sz, [C.c_char_p, _sz, _vp, _sz]),
 }
@@ -343,6 +347,47 @@ class Replacer:
 
     def run_with_limit(self, max_len, text):
         return self.run_batch([text], max_len)[0]
+
+
+class Splitter:
+    """Data.Text.AhoCorasick.Splitter (build :64-67, split :84-85, splitIgnoreCase :96-97)."""
+
+    def __init__(self, separator):
+        b = _as_bytes(separator)
+        h = _vp()
+        _hcheck(libhost().amh_splitter_build(b, len(b), C.byref(h)))
+        self._h = h
+
+    build = classmethod(lambda cls, separator: cls(separator))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libhost().amh_splitter_free(self._h)
+            self._h = None
+
+    def split_batch(self, texts, ignore_case=False):
+        s = _Slices(texts)
+        blob, offs = _vp(), _vp()
+        nf = C.c_uint64(0)
+        per = np.zeros(max(s.n, 1), np.uint32)
+        _hcheck(libhost().amh_splitter_split_batch(self._h, 1 if ignore_case else 0, s.arr, s.n, C.byref(blob), C.byref(offs), C.byref(nf), per.ctypes.data))
+        try:
+            o = np.ctypeslib.as_array(C.cast(offs, _u64p), shape=(nf.value + 1,)).copy()
+            raw = C.string_at(blob, int(o[-1]))
+        finally:
+            libhost().amh_free_blob(blob)
+            libhost().amh_free_u64(offs)
+        out, k = [], 0
+        for i in range(s.n):
+            out.append([raw[int(o[k + j]):int(o[k + j + 1])] for j in range(int(per[i]))])
+            k += int(per[i])
+        return out
+
+    def split(self, text):
+        return self.split_batch([text], False)[0]
+
+    def split_ignore_case(self, text):
+        return self.split_batch([text], True)[0]
 
 
 def lower_code_point(cp):

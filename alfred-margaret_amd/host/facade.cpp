@@ -4,6 +4,7 @@
 #include <string>
 
 #include "replacer.hpp"
+#include "splitter.hpp"
 
 using namespace alfred_margaret;
 
@@ -129,6 +130,37 @@ int amh_replacer_run_batch(void* r, const am_slice* hay, size_t n_hay, long long
     });
 }
 void amh_free_blob(uint8_t* p) { free(p); }
+
+// ---- Splitter
+int amh_splitter_build(const uint8_t* sep, size_t len, void** out)
+{
+    *out = nullptr;
+    return guarded([&] { *out = new Splitter(std::string((const char*)sep, len)); });
+}
+void amh_splitter_free(void* s) { delete static_cast<Splitter*>(s); }
+// fragments of all haystacks concatenated: blob + fragment offsets (n_frag + 1) + per-haystack fragment counts
+int amh_splitter_split_batch(void* sp, int ignore_case, const am_slice* hay, size_t n_hay, uint8_t** blob_out, uint64_t** offs_out,
+                             uint64_t* n_frag_out, uint32_t* frags_per_hay)
+{
+    *blob_out = nullptr; *offs_out = nullptr;
+    return guarded([&] {
+        std::vector<std::string> in(n_hay);
+        for (size_t i = 0; i < n_hay; i++) in[i].assign((const char*)hay[i].ptr + hay[i].off, hay[i].len);
+        auto res = static_cast<Splitter*>(sp)->splitBatch(in, ignore_case != 0);
+        uint64_t nf = 0, total = 0;
+        for (auto& r : res) { nf += r.size(); for (auto& f : r) total += f.size(); }
+        uint8_t* blob = (uint8_t*)malloc(total ? total : 1);
+        uint64_t* offs = (uint64_t*)malloc((nf + 1) * sizeof(uint64_t));
+        uint64_t k = 0, at = 0;
+        for (size_t i = 0; i < n_hay; i++) {
+            frags_per_hay[i] = (uint32_t)res[i].size();
+            for (auto& f : res[i]) { offs[k++] = at; if (!f.empty()) std::memcpy(blob + at, f.data(), f.size()); at += f.size(); }
+        }
+        offs[k] = at;
+        *blob_out = blob; *offs_out = offs; *n_frag_out = nf;
+    });
+}
+void amh_free_u64(uint64_t* p) { free(p); }
 
 // ---- Utf8 helpers
 int64_t amh_skip_code_points_backwards(const uint8_t* d, size_t len, size_t index, size_t n)

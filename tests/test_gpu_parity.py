@@ -236,6 +236,27 @@ def test_full_size_properties():
         lib.am_batch_destroy(b)
 
 
+def test_benchmark_file_protocol(golden):
+    """tools/acbench.py: the reference's needles/blank-line/haystack file format and output protocol."""
+    import os, subprocess, sys
+    from tests.conftest import ROOT
+    path = os.path.join(ROOT, "tests", "golden", "benchmark_example.txt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "acbench.py"), path], capture_output=True, text=True, check=True)
+    assert int(r.stderr.strip().splitlines()[-1]) == golden["benchmark_example_file"]["count_naive"]
+    assert len(r.stdout.strip().split("\t")) == 5
+
+
+def test_golden_splitter(golden):
+    # AhoCorasickSpec.hs:224-244
+    for row in golden["splitter"]:
+        sp = am.Splitter(row["sep"])
+        got = sp.split_ignore_case(row["haystack"]) if row["ignore_case"] else sp.split(row["haystack"])
+        assert [g.decode("utf-8") for g in got] == row["expected"], row["src"]
+    # overlapping separators are ignored (Splitter.hs:163-165), empty fragments are kept
+    assert am.Splitter("aa").split("aaaXaa") == [b"", b"aX", b""]
+    assert am.Splitter(",").split_batch(["a,b,,c", "", ","]) == [[b"a", b"b", b"", b"c"], [b""], [b"", b""]]
+
+
 def test_replacer_properties():
     rng = random.Random(5)
     for _ in range(30):
