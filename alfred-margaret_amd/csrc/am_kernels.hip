@@ -17,6 +17,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "am_device.h"
 
@@ -286,12 +287,15 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 wave_lds_fence();
                 tick(t_compact);
 
-                for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
-                    uint64_t avail[ILP];
-                    uint32_t pos[ILP], w[ILP], nb[ILP];
-                    bool valid[ILP], defer[ILP];
+                // one probe round: up to 64 * W survivors, W per lane with their loads in flight together.
+                // The common case (<= 64 survivors left) takes the 1-wide instance: half the instructions.
+                auto probe_round = [&](uint32_t base, auto width_tag) {
+                    constexpr int W = decltype(width_tag)::value;
+                    uint64_t avail[W];
+                    uint32_t pos[W], w[W], nb[W];
+                    bool valid[W], defer[W];
 #pragma unroll
-                    for (int k = 0; k < ILP; k++) {
+                    for (int k = 0; k < W; k++) {
                         const uint32_t e = base + 64u * k + lane;
                         valid[k] = e < n_q1;
                         const uint2 ent = valid[k] ? q1[e] : make_uint2(0u, 0u);
@@ -301,13 +305,17 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                     }
                     if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
-                    sf_probe_n<ILP>(s, w, nb, avail, valid, defer, o.ablate);
+                    sf_probe_n<W>(s, w, nb, avail, valid, defer, o.ablate);
 #pragma unroll
-                    for (int k = 0; k < ILP; k++) {
+                    for (int k = 0; k < W; k++) {
                         const uint64_t m = __ballot(defer[k]);
                         if (defer[k]) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = (ci << 10) | pos[k];
                         q2_tail += (uint32_t)__popcll(m);
                     }
+                };
+                for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
+                    if (ILP == 1 || n_q1 - base <= 64u) probe_round(base, std::integral_constant<int, 1>());
+                    else probe_round(base, std::integral_constant<int, ILP>());
                     wave_lds_fence();
                     tick(t_probe);
                     while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }   // keeps room for the next round
