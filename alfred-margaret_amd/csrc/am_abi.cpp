@@ -134,6 +134,7 @@ struct am_automaton {
     std::vector<uint64_t> transitions, root_ascii;
     std::vector<uint32_t> offsets, values_len;
     bool has_ref = false;        // false for handles attached to a received image
+    std::vector<uint8_t> cs_image;   // CaseSensitive image flattened (= validated) at creation, uploaded on first use
     int kernel_pref = 0;
     std::mutex mu;
     Flavor fl[2];
@@ -165,8 +166,11 @@ static int prepare(const am_automaton* ca, int case_mode, const Flavor** out)
         if (!a->has_ref) return fail(AM_ERR_UNSUPPORTED, "this handle was attached to an image of the other case mode");
         AM_TRY(ensure_device());
         std::vector<uint8_t> img; std::string err;
-        RefArrays ref{a->transitions.data(), a->transitions.size(), a->offsets.data(), a->offsets.size() - 1, a->root_ascii.data(), a->values_len.data()};
-        if (flatten(ref, case_mode, img, err) != 0) return fail(AM_ERR_INVALID, err);
+        if (case_mode == AM_CASE_SENSITIVE && !a->cs_image.empty()) img.swap(a->cs_image);
+        else {
+            RefArrays ref{a->transitions.data(), a->transitions.size(), a->offsets.data(), a->offsets.size() - 1, a->root_ascii.data(), a->values_len.data()};
+            if (flatten(ref, case_mode, img, err) != 0) return fail(AM_ERR_INVALID, err);
+        }
         void* d = nullptr;
         hipError_t e = hipMalloc(&d, img.size());
         if (e != hipSuccess) return fail(AM_ERR_OOM, std::string("hipMalloc(image): ") + hipGetErrorString(e));
@@ -187,13 +191,15 @@ extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transit
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!transitions || !offsets || !root_ascii || !values_len || n_states == 0) return fail(AM_ERR_INVALID, "null or empty automaton arrays");
-    // validate on the host right away (flatten checks every index); the device image is built lazily
+    // validate on the host right away (flatten checks every index); the image is uploaded on first use
+    std::vector<uint8_t> img;
     {
-        std::vector<uint8_t> img; std::string err;
+        std::string err;
         RefArrays ref{transitions, n_transitions, offsets, n_states, root_ascii, values_len};
         if (flatten(ref, AM_CASE_SENSITIVE, img, err) != 0) return fail(AM_ERR_INVALID, err);
     }
     am_automaton* a = new am_automaton();
+    a->cs_image.swap(img);
     a->transitions.assign(transitions, transitions + n_transitions);
     a->offsets.assign(offsets, offsets + n_states + 1);
     a->root_ascii.assign(root_ascii, root_ascii + 128);
