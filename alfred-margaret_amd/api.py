@@ -56,6 +56,15 @@ ABI = {
     "am_matches_data": (_vp, [_vp]),
     "am_matches_device_data": (_vp, [_vp]),
     "am_matches_free": (None, [_vp]),
+    "am_replacer_create": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _sz, _vp, _sz, C.c_int64, C.POINTER(_vp)]),
+    "am_replacer_destroy": (None, [_vp]),
+    "am_replacer_run": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_uint64, C.POINTER(_vp)]),
+    "am_replacer_run_batch": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "am_replaced_size": (C.c_uint64, [_vp]),
+    "am_replaced_get": (C.c_int, [_vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]),
+    "am_replaced_passes": (C.c_uint64, [_vp]),
+    "am_replaced_scanned_bytes": (C.c_uint64, [_vp]),
+    "am_replaced_free": (None, [_vp]),
     "am_automaton_image_size": (C.c_int, [_vp, C.c_int, C.POINTER(_sz)]),
     "am_automaton_image_copy": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "am_automaton_from_image": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
@@ -90,6 +99,9 @@ _HOST = {
     "amh_replacer_build": (C.c_int, [C.c_int, C.c_char_p, _vp, C.c_char_p, _vp, _sz, C.POINTER(_vp)]),
     "amh_replacer_free": (None, [_vp]),
     "amh_replacer_run_batch": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
+    "amh_replacer_run_batch_host_splice": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
+    "amh_replacer_last_stats": (None, [_vp, _vp, _vp]),
+    "amh_replacer_device": (C.c_int, [_vp, C.POINTER(_vp)]),
     "amh_free_blob": (None, [_vp]),
     "amh_splitter_build": (C.c_int, [C.c_char_p, _sz, C.POINTER(_vp)]),
     "amh_splitter_free": (None, [_vp]),
@@ -330,17 +342,33 @@ class Replacer:
             libhost().amh_replacer_free(self._h)
             self._h = None
 
-    def run_batch(self, texts, max_len=-1):
+    def run_batch(self, texts, max_len=-1, host_splice=False):
+        """Replacer.run / runWithLimit on a batch.  host_splice=True keeps only the scans on the GPU
+        (fold, sort and splice on the host) -- an independent cross-check of the device passes."""
         s = _Slices(texts)
         blob = _vp()
         offs = np.zeros(s.n + 1, np.uint64)
         nothing = np.zeros(max(s.n, 1), np.uint8)
-        _hcheck(libhost().amh_replacer_run_batch(self._h, s.arr, s.n, max_len, C.byref(blob), offs.ctypes.data, nothing.ctypes.data))
+        fn = libhost().amh_replacer_run_batch_host_splice if host_splice else libhost().amh_replacer_run_batch
+        _hcheck(fn(self._h, s.arr, s.n, max_len, C.byref(blob), offs.ctypes.data, nothing.ctypes.data))
         try:
             raw = C.string_at(blob, int(offs[-1]))
         finally:
             libhost().amh_free_blob(blob)
         return [None if nothing[i] else raw[int(offs[i]):int(offs[i + 1])] for i in range(s.n)]
+
+    @property
+    def device(self):
+        """am_replacer* for the raw ABI (am_replacer_run_batch on device-resident batches)."""
+        h = _vp()
+        _hcheck(libhost().amh_replacer_device(self._h, C.byref(h)))
+        return h.value
+
+    def last_stats(self):
+        """(passes, haystack bytes scanned over all passes) of the last run_batch."""
+        a = np.zeros(2, np.uint64)
+        libhost().amh_replacer_last_stats(self._h, a[0:].ctypes.data, a[1:].ctypes.data)
+        return int(a[0]), int(a[1])
 
     def run(self, text):
         return self.run_batch([text])[0]

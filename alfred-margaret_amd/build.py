@@ -46,7 +46,7 @@ def _glob_deps(*dirs):
 def build_libam(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libam.so")
-    srcs = [os.path.join(CSRC, f) for f in ("am_abi.cpp", "am_flatten.cpp", "am_kernels.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("am_abi.cpp", "am_flatten.cpp", "am_kernels.hip", "am_replace.hip")]
     deps = _glob_deps(CSRC) + [os.path.join(ROOT, "include", "am.h")]
     if force or _stale(target, deps):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -4,8 +4,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -432,32 +436,23 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     return AM_OK;
 }
 
-extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out)
+// The whole scan: leaves every record of the batch, sorted by (haystack, end_pos), in device memory
+// obtained from `sink(total, &ptr)` (called once, only when total > 0); *n_out = number of records.
+static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink, uint64_t* n_out)
 {
-    if (!out) return fail(AM_ERR_INVALID, "out is null");
-    *out = nullptr;
-    am_batch* b = const_cast<am_batch*>(cb);
+    *n_out = 0;
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
-    am_matches* m = new am_matches();
-    if (p.nothing) { *out = m; return AM_OK; }
+    if (p.nothing) return AM_OK;
     std::lock_guard<std::mutex> lk(b->mu);
-    hipStream_t st;
-    int rc = get_stream(&st);
-    auto bail = [&](int code) { am_matches_free(m); return code; };
-    if (rc != AM_OK) return bail(rc);
+    hipStream_t st; AM_TRY(get_stream(&st));
     const uint64_t n = p.n_units + 1;           // trailing zero: offsets[n_units] = total
-    if ((rc = b->unit_counts.ensure(n * sizeof(uint32_t))) != AM_OK) return bail(rc);
-    if ((rc = b->unit_offsets.ensure(n * sizeof(uint64_t))) != AM_OK) return bail(rc);
-    if ((rc = b->small.ensure(64)) != AM_OK) return bail(rc);
+    AM_TRY(b->unit_counts.ensure(n * sizeof(uint32_t)));
+    AM_TRY(b->unit_offsets.ensure(n * sizeof(uint64_t)));
+    AM_TRY(b->small.ensure(64));
     size_t tmp_bytes = 0;
-    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return bail(fail(AM_ERR_HIP, "hipcub scan sizing failed"));
-    if ((rc = b->scan_tmp.ensure(tmp_bytes + 16)) != AM_OK) return bail(rc);
-
-    auto alloc_records = [&](uint64_t total) -> int {
-        hipError_t e = hipMalloc((void**)&m->d_records, total * sizeof(Record));
-        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e));
-        return AM_OK;
-    };
+    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
+    Record* d_records = nullptr;
     // general kernel: count pass -> exclusive scan -> emit pass (unit = one lane's chunk)
     auto body_ac = [&]() -> int {
         ScanOut o{};
@@ -471,12 +466,12 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
         uint64_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        m->n = total;
+        *n_out = total;
         if (total == 0) return AM_OK;
-        AM_TRY(alloc_records(total));
+        AM_TRY(sink(total, &d_records));
         ScanOut w{};
         w.unit_offsets = (const uint64_t*)b->unit_offsets.p;
-        w.records = m->d_records;
+        w.records = d_records;
         AM_TRY(launch_scan_kernel(p, kModeEmit, w, st));
         HIP_TRY(hipStreamSynchronize(st));
         return AM_OK;
@@ -512,18 +507,32 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
             HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64; continue; }    // pool too small: ctrl[0] = blocks actually needed
-            m->n = total;
+            *n_out = total;
             if (total == 0) return AM_OK;
-            AM_TRY(alloc_records(total));
-            { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, m->d_records, p.n_units, st)); }
+            AM_TRY(sink(total, &d_records));
+            { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, d_records, p.n_units, st)); }
             HIP_TRY(hipStreamSynchronize(st));
             return AM_OK;
         }
         return fail(AM_ERR_HIP, "record pool overflowed repeatedly (internal error)");
     };
-    auto body = [&]() -> int { return p.use_sf ? body_sf() : body_ac(); };
-    rc = body();
-    if (rc != AM_OK) return bail(rc);
+    return p.use_sf ? body_sf() : body_ac();
+}
+
+extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!cb) return fail(AM_ERR_INVALID, "null batch");
+    am_matches* m = new am_matches();
+    auto sink = [&](uint64_t total, Record** ptr) -> int {
+        hipError_t e = hipMalloc((void**)&m->d_records, total * sizeof(Record));
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e));
+        *ptr = m->d_records;
+        return AM_OK;
+    };
+    const int rc = run_records(a, case_mode, const_cast<am_batch*>(cb), sink, &m->n);
+    if (rc != AM_OK) { am_matches_free(m); return rc; }
     *out = m;
     return AM_OK;
 }
@@ -656,3 +665,287 @@ extern "C" int am_profile_read(const char* kernel, double* total_ms, uint64_t* l
     if (launches) *launches = it == g_rt.prof.end() ? 0 : it->second.second;
     return AM_OK;
 }
+
+// ------------------------------------------------------------------ Replacer (Replacer.hs:97-274), device-resident passes
+
+static_assert(sizeof(am_payload) == sizeof(RpPayload) && offsetof(am_payload, repl_off) == offsetof(RpPayload, repl_off) &&
+                  offsetof(am_payload, len_code_points) == offsetof(RpPayload, len_code_points) && offsetof(am_payload, repl_len) == offsetof(RpPayload, repl_len),
+              "am_payload must mirror the device payload");
+
+struct am_replacer {
+    const am_automaton* a = nullptr;
+    int case_mode = 0;
+    DevBuf vals_off, vals, payloads, repl;
+    RpTables t{};
+};
+
+// Finished texts are copied D2H straight into pinned slabs that the result object keeps (no second host
+// copy); am_replaced_free hands the slabs back to a small process-wide pool so that repeated calls do
+// not pay for pinning again.
+namespace {
+struct Slab { uint8_t* p = nullptr; size_t cap = 0, used = 0; };
+struct SlabPool {
+    std::mutex mu;
+    std::vector<Slab> free_list;
+    static constexpr size_t kSlab = 256ull << 20, kKeep = 8;
+    int take(size_t need, Slab* out)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].cap >= need) { *out = free_list[i]; out->used = 0; free_list.erase(free_list.begin() + i); return AM_OK; }
+        }
+        Slab s; s.cap = need > kSlab ? need : kSlab;
+        if (hipHostMalloc((void**)&s.p, s.cap, hipHostMallocDefault) != hipSuccess) return fail(AM_ERR_OOM, "hipHostMalloc(result slab) failed");
+        *out = s;
+        return AM_OK;
+    }
+    void give(const Slab& s)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free_list.size() < kKeep) { free_list.push_back(s); return; }
+        }
+        (void)hipHostFree(s.p);
+    }
+};
+SlabPool g_slabs;
+}  // namespace
+
+struct am_replaced {
+    struct Item { const uint8_t* p = nullptr; size_t len = 0; };
+    std::vector<Item> text;
+    std::vector<uint8_t> just;
+    std::vector<Slab> slabs;
+    uint64_t passes = 0, scanned = 0;
+    ~am_replaced() { for (const Slab& s : slabs) g_slabs.give(s); }
+    // room for n contiguous bytes in the current slab, or a new slab
+    int room(size_t n, uint8_t** out)
+    {
+        if (slabs.empty() || slabs.back().cap - slabs.back().used < n) { Slab s; AM_TRY(g_slabs.take(n, &s)); slabs.push_back(s); }
+        *out = slabs.back().p + slabs.back().used;
+        slabs.back().used += (n + 63) & ~(size_t)63;
+        if (slabs.back().used > slabs.back().cap) slabs.back().used = slabs.back().cap;
+        return AM_OK;
+    }
+};
+
+extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const uint64_t* values_offsets, const uint32_t* values,
+                                  const am_payload* payloads, size_t n_payloads, const uint8_t* repl_bytes, size_t n_repl_bytes,
+                                  int64_t min_priority, am_replacer** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    const Flavor* f = nullptr;
+    AM_TRY(prepare(a, case_mode, &f));
+    const uint64_t n_states = f->h.n_states;
+    if (!values_offsets || values_offsets[0] != 0) return fail(AM_ERR_INVALID, "values_offsets[0] must be 0");
+    const uint64_t n_values = values_offsets[n_states];
+    if ((n_values && !values) || (n_payloads && !payloads) || (n_repl_bytes && !repl_bytes)) return fail(AM_ERR_INVALID, "null table");
+    for (uint64_t s = 0; s < n_states; s++) {
+        if (values_offsets[s + 1] < values_offsets[s]) return fail(AM_ERR_INVALID, "values_offsets must be non-decreasing");
+        if (a->has_ref && values_offsets[s + 1] - values_offsets[s] != a->values_len[s])
+            return fail(AM_ERR_INVALID, "values_offsets disagrees with the values_len given to am_automaton_create");
+    }
+    for (uint64_t k = 0; k < n_values; k++) if (values[k] >= n_payloads) return fail(AM_ERR_INVALID, "payload index out of range");
+    {
+        // Replacer.hs:100-104 / :127-131: priorities are 0, -1, -2, ...; the device pass relies on them being distinct
+        std::vector<int64_t> pr(n_payloads);
+        for (size_t i = 0; i < n_payloads; i++) {
+            pr[i] = payloads[i].priority;
+            if (pr[i] > 0) return fail(AM_ERR_INVALID, "priorities must be <= 0 (the initial threshold is 1, Replacer.hs:211)");
+            if ((uint64_t)payloads[i].repl_off + payloads[i].repl_len > n_repl_bytes) return fail(AM_ERR_INVALID, "replacement slice out of range");
+            if (case_mode == AM_IGNORE_CASE && payloads[i].len_code_points == 0)
+                return fail(AM_ERR_UNSUPPORTED, "empty needle under IgnoreCase: the reference's skipCodePointsBackwards has no answer (Utf8.hs:259)");
+        }
+        std::sort(pr.begin(), pr.end());
+        for (size_t i = 1; i < n_payloads; i++) if (pr[i] == pr[i - 1]) return fail(AM_ERR_INVALID, "payload priorities must be distinct");
+    }
+    am_replacer* r = new am_replacer();
+    r->a = a; r->case_mode = case_mode;
+    auto up = [&](DevBuf& d, const void* src, size_t bytes) -> int {
+        AM_TRY(d.ensure(bytes + 64));
+        if (bytes) HIP_TRY(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
+        return AM_OK;
+    };
+    int rc = up(r->vals_off, values_offsets, (n_states + 1) * sizeof(uint64_t));
+    if (rc == AM_OK) rc = up(r->vals, values, n_values * sizeof(uint32_t));
+    if (rc == AM_OK) rc = up(r->payloads, payloads, n_payloads * sizeof(am_payload));
+    if (rc == AM_OK && n_payloads == 0) { hipError_t e = hipMemset(r->payloads.p, 0, sizeof(am_payload)); if (e != hipSuccess) rc = fail(AM_ERR_HIP, hipGetErrorString(e)); }
+    if (rc == AM_OK) rc = up(r->repl, repl_bytes, n_repl_bytes);
+    if (rc != AM_OK) { am_replacer_destroy(r); return rc; }
+    r->t = RpTables{(const uint64_t*)r->vals_off.p, (const uint32_t*)r->vals.p, (const RpPayload*)r->payloads.p, (const uint8_t*)r->repl.p, min_priority};
+    *out = r;
+    return AM_OK;
+}
+
+extern "C" void am_replacer_destroy(am_replacer* r)
+{
+    if (!r) return;
+    for (DevBuf* d : {&r->vals_off, &r->vals, &r->payloads, &r->repl}) d->release();
+    delete r;
+}
+
+namespace {
+
+struct RpSession {
+    DevBuf text[2], offs[2], orig[2], thr[2];
+    DevBuf totals; uint64_t* tot_host = nullptr;       // the five per-pass totals, read back through pinned memory
+    DevBuf records, rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
+    am_batch ws;                         // workspace holder for the scans; never owns its text
+    ~RpSession()
+    {
+        for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &records, &rec_first, &kept, &hs, &len_next, &len_fin,
+                          &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta}) d->release();
+        if (tot_host) (void)hipHostFree(tot_host);
+        for (DevBuf* d : {&ws.hidx, &ws.unit_counts, &ws.unit_offsets, &ws.scan_tmp, &ws.small, &ws.hay_counts, &ws.flags, &ws.unit_first, &ws.pool, &ws.block_next}) d->release();
+    }
+};
+
+size_t padded_text(uint64_t total) { return (size_t)((total + 15) & ~15ull) + 16; }
+
+// Replacer.hs:203-242 runWithLimit for every haystack of `in`, all passes on the device.
+int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res)
+{
+    const uint32_t n_hay = in->n_hay;
+    res->text.assign(n_hay, am_replaced::Item());
+    res->just.assign(n_hay, 1);
+    if (n_hay == 0) return AM_OK;
+    hipStream_t st; AM_TRY(get_stream(&st));
+    RpSession s;
+    AM_TRY(s.totals.ensure(64));
+    if (hipHostMalloc((void**)&s.tot_host, 64, hipHostMallocDefault) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    // pass 0 reads the caller's batch in place; afterwards the text ping-pongs between s.text[0] and s.text[1]
+    const uint8_t* cur_text = (const uint8_t*)in->d_text;
+    const uint64_t* cur_offs = in->d_offsets;
+    uint64_t total = in->total;
+    uint32_t n_act = n_hay;
+    int nxt = 0;
+    DevBuf first_orig, first_thr;
+    struct Release { DevBuf &a, &b; ~Release() { a.release(); b.release(); } } rel{first_orig, first_thr};
+    {
+        std::vector<uint32_t> o(n_hay); std::vector<int64_t> t(n_hay, 1);      // initialThreshold = 1 (Replacer.hs:211)
+        for (uint32_t i = 0; i < n_hay; i++) o[i] = i;
+        AM_TRY(first_orig.ensure(n_hay * sizeof(uint32_t))); AM_TRY(first_thr.ensure(n_hay * sizeof(int64_t)));
+        HIP_TRY(hipMemcpy(first_orig.p, o.data(), n_hay * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(first_thr.p, t.data(), n_hay * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    const uint32_t* cur_orig = (const uint32_t*)first_orig.p;
+    const int64_t* cur_thr = (const int64_t*)first_thr.p;
+    std::vector<RpFin> fin_host;
+    // AM_RP_TRACE=1: wall-clock split of the loop on stderr (development aid)
+    const bool trace = std::getenv("AM_RP_TRACE") != nullptr;
+    double t_scan = 0, t_fold = 0, t_splice = 0, t_home = 0;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    struct Report { bool on; double &a, &b, &c, &d; ~Report() { if (on) std::fprintf(stderr, "[am_replacer] scan %.1f ms, fold+scans %.1f ms, splice+D2H %.1f ms, scatter %.1f ms\n", a * 1e3, b * 1e3, c * 1e3, d * 1e3); } } report{trace, t_scan, t_fold, t_splice, t_home};
+
+    while (n_act > 0) {
+        double t0 = now();
+        res->passes++; res->scanned += total;
+        // ---- the scan (Replacer.hs:223-225)
+        s.ws.d_text = const_cast<uint8_t*>(cur_text); s.ws.d_offsets = const_cast<uint64_t*>(cur_offs); s.ws.owns = false;
+        s.ws.total = total; s.ws.n_hay = n_act;
+        AM_TRY(finish_batch(&s.ws));
+        uint64_t n_rec = 0;
+        auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.records.ensure(n * sizeof(Record))); *ptr = (Record*)s.records.p; return AM_OK; };
+        AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &n_rec));
+        t_scan += now() - t0; t0 = now();
+        // ---- per-haystack fold of the records
+        const uint64_t n1 = (uint64_t)n_act + 1;
+        AM_TRY(s.rec_first.ensure(n1 * 8)); AM_TRY(s.kept.ensure((n_rec + 1) * sizeof(RpKept))); AM_TRY(s.hs.ensure(n1 * sizeof(RpHay)));
+        AM_TRY(s.len_next.ensure(n1 * 8)); AM_TRY(s.len_fin.ensure(n1 * 8)); AM_TRY(s.tiles.ensure(n1 * 4)); AM_TRY(s.act.ensure(n1 * 4)); AM_TRY(s.fin.ensure(n1 * 4));
+        AM_TRY(s.off_next.ensure(n1 * 8)); AM_TRY(s.off_fin.ensure(n1 * 8)); AM_TRY(s.tile_off.ensure(n1 * 8)); AM_TRY(s.act_idx.ensure(n1 * 8)); AM_TRY(s.fin_idx.ensure(n1 * 8));
+        size_t t32 = 0, t64 = 0;
+        if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+        const size_t tmp_bytes = t32 > t64 ? t32 : t64;
+        AM_TRY(s.scan_tmp.ensure(tmp_bytes + 16));
+        AM_TRY(s.records.ensure(sizeof(Record)));          // a valid pointer even when nothing matched
+        RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
+        { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)s.records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
+        { Prof pr("rp_pass", st);
+          HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)s.records.p, (const uint64_t*)s.rec_first.p, cur_thr,
+                                 max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, st)); }
+        { Prof pr("rp_scans", st);
+          HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_next, (uint64_t*)s.off_next.p, n1, st));
+          HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_fin, (uint64_t*)s.off_fin.p, n1, st));
+          HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.tiles, (uint64_t*)s.tile_off.p, n1, st));
+          HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.act, (uint64_t*)s.act_idx.p, n1, st));
+          HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.fin, (uint64_t*)s.fin_idx.p, n1, st)); }
+        // bytes of next text, bytes of finished text, tiles, haystacks still active, haystacks finished
+        RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
+        HIP_TRY(launch_rp_totals(rt, n_act, (uint64_t*)s.totals.p, st));
+        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 40, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint64_t* tot = s.tot_host;
+        const uint64_t total_next = tot[0], total_fin = tot[1], n_tiles = tot[2], n_next = tot[3], n_fin = tot[4];
+        t_fold += now() - t0; t0 = now();
+        if (n_tiles >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "replacement output too large for one launch; split the batch");
+        // ---- replace (Replacer.hs:163-180) into the next batch / the finished buffer
+        AM_TRY(s.text[nxt].ensure(padded_text(total_next))); AM_TRY(s.offs[nxt].ensure((n_next + 1) * 8));
+        AM_TRY(s.orig[nxt].ensure((n_next + 1) * 4)); AM_TRY(s.thr[nxt].ensure((n_next + 1) * 8));
+        AM_TRY(s.fin_text.ensure(total_fin + 16)); AM_TRY(s.fin_meta.ensure((n_fin + 1) * sizeof(RpFin)));
+        { Prof pr("rp_route", st);
+          HIP_TRY(launch_rp_route((const RpHay*)s.hs.p, rt, cur_orig, n_act, (uint64_t*)s.offs[nxt].p, (uint32_t*)s.orig[nxt].p, (int64_t*)s.thr[nxt].p, (RpFin*)s.fin_meta.p, st)); }
+        { Prof pr("rp_splice", st);
+          HIP_TRY(launch_rp_splice(r->t, cur_text, cur_offs, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, rt, n_act, n_tiles,
+                                   (uint8_t*)s.text[nxt].p, (uint8_t*)s.fin_text.p, st)); }
+        HIP_TRY(hipMemsetAsync((uint8_t*)s.text[nxt].p + total_next, 0, padded_text(total_next) - (size_t)total_next, st));
+        // ---- finished haystacks go home
+        uint8_t* home = nullptr;
+        if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
+        fin_host.resize(n_fin);
+        if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, st));
+        if (n_fin) HIP_TRY(hipMemcpyAsync(fin_host.data(), s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        t_splice += now() - t0; t0 = now();
+        for (const RpFin& f : fin_host) {
+            if (f.orig >= n_hay || f.off + f.len > total_fin) return fail(AM_ERR_HIP, "replacer pass produced inconsistent metadata (internal error)");
+            if (f.status == kRpNothing) res->just[f.orig] = 0;
+            else res->text[f.orig] = am_replaced::Item{home + f.off, (size_t)f.len};
+        }
+        cur_text = (const uint8_t*)s.text[nxt].p; cur_offs = (const uint64_t*)s.offs[nxt].p;
+        cur_orig = (const uint32_t*)s.orig[nxt].p; cur_thr = (const int64_t*)s.thr[nxt].p;
+        total = total_next; n_act = (uint32_t)n_next; nxt ^= 1;
+        t_home += now() - t0;
+    }
+    return AM_OK;
+}
+
+}  // namespace
+
+extern "C" int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!r || !b) return fail(AM_ERR_INVALID, "null replacer or batch");
+    AM_TRY(ensure_device());
+    am_replaced* res = new am_replaced();
+    const int rc = replacer_run(r, b, max_length, res);
+    if (rc != AM_OK) { delete res; return rc; }
+    *out = res;
+    return AM_OK;
+}
+
+extern "C" int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    am_batch* b = nullptr;
+    AM_TRY(am_batch_upload(hay, n_hay, &b));
+    const int rc = am_replacer_run_batch(r, b, max_length, out);
+    am_batch_destroy(b);
+    return rc;
+}
+
+extern "C" uint64_t am_replaced_size(const am_replaced* r) { return r ? r->text.size() : 0; }
+extern "C" uint64_t am_replaced_passes(const am_replaced* r) { return r ? r->passes : 0; }
+extern "C" uint64_t am_replaced_scanned_bytes(const am_replaced* r) { return r ? r->scanned : 0; }
+
+extern "C" int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len)
+{
+    if (!r || i >= r->text.size() || !ptr || !len) return fail(AM_ERR_INVALID, "bad argument");
+    *ptr = r->text[i].p ? r->text[i].p : (const uint8_t*)""; *len = r->text[i].len;
+    return r->just[i] ? 1 : 0;
+}
+
+extern "C" void am_replaced_free(am_replaced* r) { delete r; }

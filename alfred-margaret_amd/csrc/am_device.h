@@ -50,5 +50,30 @@ hipError_t read_sf_phase_cycles(uint64_t* out5);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st);
 
+
+// ---- Replacer pass (am_replace.hip) ----------------------------------------------------------
+// same layout as am_payload in include/am.h (Replacer.hs:59-70 Payload, replacement text as a slice of one blob)
+struct RpPayload { int64_t priority; uint32_t len_bytes; uint32_t len_code_points; uint64_t repl_off; uint32_t repl_len; uint32_t reserved; };
+// machineValues of the Replacer's automaton in CSR form: the list of state s is payloads[vals[vals_off[s] .. vals_off[s+1])]
+struct RpTables { const uint64_t* vals_off; const uint32_t* vals; const RpPayload* payloads; const uint8_t* repl; int64_t min_priority; };
+struct RpKept { uint64_t src_start, src_len, dst; };     // a match that survives removeOverlap; dst = where its replacement starts in the new text
+constexpr uint32_t kRpActive = 0, kRpFinished = 1, kRpNothing = 2;
+struct RpHay { uint64_t newlen; int64_t best; uint32_t status, nkept, payload, pad; };
+struct RpFin { uint64_t off, len; uint32_t orig, status; };
+struct RpRoute { uint64_t* len_next; uint64_t* len_fin; uint32_t* tiles; uint32_t* act; uint32_t* fin; };                       // per haystack, written by k_rp_pass
+struct RpRouted { const uint64_t* off_next; const uint64_t* off_fin; const uint64_t* tile_off; const uint64_t* act_idx; const uint64_t* fin_idx; };   // their exclusive sums
+constexpr uint64_t kRpTile = 16384;                      // bytes of new text per k_rp_splice workgroup
+
+hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
+hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, uint64_t* out5, hipStream_t st);
+hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
+                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, hipStream_t st);
+hipError_t launch_rp_route(const RpHay* hs, const RpRouted& rt, const uint32_t* orig, uint32_t n_act, uint64_t* next_offsets, uint32_t* next_orig,
+                           int64_t* next_thr, RpFin* fin, hipStream_t st);
+hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64_t* offsets, const uint64_t* rec_first, const RpKept* kept,
+                            const RpHay* hs, const RpRouted& rt, uint32_t n_act, uint64_t n_tiles, uint8_t* text_next, uint8_t* text_fin, hipStream_t st);
+hipError_t scan64_temp_bytes(uint64_t n, size_t* bytes);
+hipError_t launch_scan64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t st);
+
 }  // namespace dev
 }  // namespace am

@@ -1,0 +1,296 @@
+// am_replace.hip -- device side of one Replacer pass (reference: src/Data/Text/AhoCorasick/Replacer.hs:203-274).
+//
+// The scan itself is k_sf / k_ac (am_kernels.hip): it leaves one record per (haystack, end position),
+// sorted.  The kernels here do what `runWithLimit.go` does with the fold result, for every active
+// haystack of the batch at once, without the records ever leaving HBM:
+//   k_rp_ranges   record range of every haystack (binary search on the sorted records)
+//   k_rp_pass     one wavefront per haystack: prependMatch (:252-260) = best priority below the
+//                 haystack's threshold and the matches that carry it; makeMatch (:264-274) = start and
+//                 length of each; replacementLength (:183-187) over all of them; removeOverlap
+//                 (:191-198) greedily in position order; the new length and what happens next (:228-242)
+//   k_rp_route    where every haystack's next text goes (next pass / finished), thresholds for the next pass
+//   k_rp_splice   replace (:163-180): copies gaps and replacements into the new text, 16 KiB tiles
+// Priorities are distinct (Replacer.hs:100-104 assigns -index; compose :127-131 renumbers), so all matches
+// chosen in one pass of one haystack belong to ONE payload: they have the same code-point length, hence
+// their start positions are ordered like their end positions and the derived-Ord sort (:159, :241) is the
+// identity on the record order.  am_replacer_create rejects payload tables with duplicate priorities.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "am_device.h"
+
+namespace am {
+namespace dev {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int64_t o = __shfl_xor(v, d, kWave); v = o > v ? o : v; }
+    return v;
+}
+
+__device__ __forceinline__ int64_t wave_sum_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+__device__ __forceinline__ int64_t wave_inclusive_sum_i64(int64_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) { const int64_t o = __shfl_up(v, d, kWave); if (lane >= d) v += o; }
+    return v;
+}
+
+// Utf8.hs:256-276 skipCodePointsBackwards, relative to the haystack start; never leaves the haystack.
+__device__ __forceinline__ uint64_t skip_code_points_backwards(const uint8_t* hay, uint64_t index, uint64_t n)
+{
+    int64_t i = (int64_t)index;
+    for (;;) {
+        while (i > 0 && (hay[i] & 0xC0u) == 0x80u) i--;      // atTrailingByte
+        if (n == 0 || i <= 0) return (uint64_t)(i < 0 ? 0 : i);
+        i--; n--;
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_rp_ranges(const Record* __restrict__ recs, uint64_t n_rec, uint64_t* __restrict__ rec_first, RpRoute route, uint32_t n_act)
+{
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_act) return;
+    if (h == n_act) { route.len_next[h] = 0; route.len_fin[h] = 0; route.tiles[h] = 0; route.act[h] = 0; route.fin[h] = 0; }   // the scans' trailing element
+    uint64_t lo = 0, hi = n_rec;                     // first record whose haystack >= h
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (recs[mid].haystack < h) lo = mid + 1; else hi = mid; }
+    rec_first[h] = lo;
+}
+
+template <bool IC>
+__global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets,
+                                                 const Record* __restrict__ recs, const uint64_t* __restrict__ rec_first,
+                                                 const int64_t* __restrict__ thr, uint64_t max_len, RpKept* __restrict__ kept,
+                                                 RpHay* __restrict__ hs, RpRoute route, uint32_t n_act)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_act) return;
+    const uint64_t r0 = rec_first[h], r1 = rec_first[h + 1];
+    const uint64_t hoff = offsets[h], curlen = offsets[h + 1] - hoff;
+    const int64_t threshold = thr[h];
+
+    // ---- prependMatch, first half: the best priority below the threshold (Replacer.hs:255-258)
+    int64_t best = INT64_MIN;
+    for (uint64_t r = r0 + lane; r < r1; r += kWave) {
+        const uint32_t st = recs[r].state;
+        for (uint64_t k = t.vals_off[st], ke = t.vals_off[st + 1]; k < ke; k++) {
+            const int64_t p = t.payloads[t.vals[k]].priority;
+            if (p < threshold && p > best) best = p;
+        }
+    }
+    best = wave_max_i64(best);
+
+    uint32_t status = kRpFinished, nkept = 0, payload = 0;
+    uint64_t newlen = curlen;
+    if (best != INT64_MIN) {
+        // ---- second half: the matches that carry it, makeMatch, removeOverlap
+        int64_t delta_all = 0, delta_kept = 0;
+        uint64_t last_end = 0;
+        for (uint64_t base = r0; base < r1; base += kWave) {
+            const uint64_t r = base + lane;
+            bool sel = false; uint32_t pl = 0; uint64_t end_pos = 0;
+            if (r < r1) {
+                const Record rec = recs[r];
+                end_pos = rec.end_pos;
+                for (uint64_t k = t.vals_off[rec.state], ke = t.vals_off[rec.state + 1]; k < ke; k++) {
+                    const uint32_t v = t.vals[k];
+                    if (t.payloads[v].priority == best) { sel = true; pl = v; }
+                }
+            }
+            uint64_t start = 0, len = 0; int64_t delta = 0;
+            if (sel) {
+                const RpPayload pp = t.payloads[pl];
+                if (!IC) { len = pp.len_bytes; start = end_pos - len; }                       // Replacer.hs:266-267
+                else {                                                                        // :268-274
+                    start = pp.len_code_points == 0 ? end_pos : skip_code_points_backwards(text + hoff, end_pos - 1, pp.len_code_points - 1);
+                    len = end_pos - start;
+                }
+                delta = (int64_t)pp.repl_len - (int64_t)len;
+            }
+            delta_all += delta;
+            // removeOverlap (:191-198): in position order keep a match iff it starts at or after the end of the last kept one
+            uint64_t pending = __ballot(sel);
+            bool keep = false;
+            while (pending) {
+                const uint64_t ok = __ballot(sel && start >= last_end) & pending;
+                if (!ok) break;
+                const int l = __ffsll((unsigned long long)ok) - 1;
+                if (lane == l) keep = true;
+                last_end = __shfl(start + len, l, kWave);
+                pending &= l == 63 ? 0ull : ~((2ull << l) - 1ull);
+            }
+            const uint64_t keepmask = __ballot(keep);
+            if (keepmask) {
+                const int64_t kd = keep ? delta : 0;
+                const int64_t incl = wave_inclusive_sum_i64(kd, lane);
+                if (keep) {
+                    const uint32_t rank = __popcll(keepmask & ((1ull << lane) - 1ull));
+                    RpKept e; e.src_start = start; e.src_len = len; e.dst = (uint64_t)((int64_t)start + delta_kept + (incl - kd));
+                    kept[r0 + nkept + rank] = e;
+                    payload = pl;
+                }
+                delta_kept += __shfl(incl, kWave - 1, kWave);
+                nkept += __popcll(keepmask);
+            }
+        }
+        delta_all = wave_sum_i64(delta_all);
+        payload = (uint32_t)wave_max_i64((int64_t)payload);     // uniform: every kept match has the same payload
+        const int64_t newlen_all = (int64_t)curlen + delta_all;                                // replacementLength over ALL matches (:240)
+        if (newlen_all > 0 && (uint64_t)newlen_all > max_len) { status = kRpNothing; newlen = 0; nkept = 0; }
+        else {
+            newlen = (uint64_t)((int64_t)curlen + delta_kept);
+            status = best == t.min_priority ? kRpFinished : kRpActive;                          // :241-242
+        }
+    }
+    if (lane == 0) {
+        RpHay o; o.newlen = newlen; o.best = best; o.status = status; o.nkept = nkept; o.payload = payload; o.pad = 0;
+        hs[h] = o;
+        route.len_next[h] = status == kRpActive ? newlen : 0;
+        route.len_fin[h] = status == kRpFinished ? newlen : 0;
+        route.tiles[h] = status == kRpNothing ? 0u : (uint32_t)((newlen + kRpTile - 1) / kRpTile);
+        route.act[h] = status == kRpActive ? 1u : 0u;
+        route.fin[h] = status == kRpActive ? 0u : 1u;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rp_route(const RpHay* __restrict__ hs, RpRouted rt, const uint32_t* __restrict__ orig, uint32_t n_act,
+                                                  uint64_t* __restrict__ next_offsets, uint32_t* __restrict__ next_orig, int64_t* __restrict__ next_thr,
+                                                  RpFin* __restrict__ fin)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_act) return;
+    if (h == n_act) { next_offsets[rt.act_idx[n_act]] = rt.off_next[n_act]; return; }
+    const RpHay s = hs[h];
+    if (s.status == kRpActive) {
+        const uint64_t j = rt.act_idx[h];
+        next_offsets[j] = rt.off_next[h]; next_orig[j] = orig[h]; next_thr[j] = s.best;
+    } else {
+        RpFin f; f.off = rt.off_fin[h]; f.len = s.newlen; f.orig = orig[h]; f.status = s.status;
+        fin[rt.fin_idx[h]] = f;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rp_splice(RpTables t, const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets,
+                                                   const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
+                                                   const RpHay* __restrict__ hs, RpRouted rt, uint32_t n_act,
+                                                   uint8_t* __restrict__ text_next, uint8_t* __restrict__ text_fin)
+{
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+    const uint64_t tile = blockIdx.x;
+    // haystack of this tile: the last h with tile_off[h] <= tile (haystacks without tiles share their successor's offset)
+    uint32_t lo = 0, hi = n_act;                  // invariant: tile_off[lo] <= tile < tile_off[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rt.tile_off[mid] <= tile) lo = mid; else hi = mid; }
+    const uint32_t h = lo;
+    const RpHay s = hs[h];
+    const uint8_t* src = text + offsets[h];
+    uint8_t* dst = s.status == kRpActive ? text_next + rt.off_next[h] : text_fin + rt.off_fin[h];
+    const RpKept* K = kept + rec_first[h];
+    const uint32_t nk = s.nkept;
+    const uint64_t newlen = s.newlen;
+    const RpPayload pp = t.payloads[s.payload];
+    const uint8_t* repl = t.repl + pp.repl_off;
+    const uint64_t repl_len = nk ? pp.repl_len : 0;
+    const uint64_t tbase = (tile - rt.tile_off[h]) * kRpTile;
+#pragma unroll 1
+    for (uint32_t it = 0; it < kRpTile / (256 * 16); it++) {
+        const uint64_t o = tbase + ((uint64_t)it * 256 + threadIdx.x) * 16;
+        if (o >= newlen) break;
+        const uint64_t end = o + 16 < newlen ? o + 16 : newlen;
+        if (nk == 0) {
+            if (end - o == 16) *reinterpret_cast<u32x4_u*>(dst + o) = *reinterpret_cast<const u32x4_u*>(src + o);
+            else for (uint64_t p = o; p < end; p++) dst[p] = src[p];
+            continue;
+        }
+        // last kept match whose replacement starts at or before o (-1: none)
+        int64_t k = -1;
+        { int64_t a = 0, b = nk; while (a < b) { const int64_t mid = (a + b) >> 1; if (K[mid].dst <= o) a = mid + 1; else b = mid; } k = a - 1; }
+        uint64_t p = o;
+        while (p < end) {
+            while (k + 1 < (int64_t)nk && K[k + 1].dst <= p) k++;
+            bool in_repl = false; uint64_t so = p, seg_end;
+            if (k < 0) seg_end = K[0].dst;
+            else {
+                const RpKept e = K[k];
+                const uint64_t re = e.dst + repl_len;
+                if (p < re) { in_repl = true; so = p - e.dst; seg_end = re; }
+                else { so = e.src_start + e.src_len + (p - re); seg_end = k + 1 < (int64_t)nk ? K[k + 1].dst : newlen; }
+            }
+            const uint64_t stop = seg_end < end ? seg_end : end;
+            const uint8_t* from = in_repl ? repl + so : src + so;
+            if (stop - p == 16) *reinterpret_cast<u32x4_u*>(dst + p) = *reinterpret_cast<const u32x4_u*>(from);
+            else for (uint64_t q = 0; q < stop - p; q++) dst[p + q] = from[q];
+            p = stop;
+        }
+    }
+}
+
+hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st)
+{
+    const uint32_t n = n_act + 1;
+    hipLaunchKernelGGL(k_rp_ranges, dim3((n + 255) / 256), dim3(256), 0, st, recs, n_rec, rec_first, route, n_act);
+    return hipGetLastError();
+}
+
+__global__ void k_rp_totals(RpRouted rt, uint32_t n_act, uint64_t* __restrict__ out5)
+{
+    out5[0] = rt.off_next[n_act]; out5[1] = rt.off_fin[n_act]; out5[2] = rt.tile_off[n_act]; out5[3] = rt.act_idx[n_act]; out5[4] = rt.fin_idx[n_act];
+}
+
+hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, uint64_t* out5, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, out5);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
+                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, hipStream_t st)
+{
+    const dim3 grid((n_act + 3) / 4), block(256);
+    if (ic) hipLaunchKernelGGL(k_rp_pass<true>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act);
+    else hipLaunchKernelGGL(k_rp_pass<false>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_route(const RpHay* hs, const RpRouted& rt, const uint32_t* orig, uint32_t n_act, uint64_t* next_offsets, uint32_t* next_orig,
+                           int64_t* next_thr, RpFin* fin, hipStream_t st)
+{
+    const uint32_t n = n_act + 1;
+    hipLaunchKernelGGL(k_rp_route, dim3((n + 255) / 256), dim3(256), 0, st, hs, rt, orig, n_act, next_offsets, next_orig, next_thr, fin);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64_t* offsets, const uint64_t* rec_first, const RpKept* kept,
+                            const RpHay* hs, const RpRouted& rt, uint32_t n_act, uint64_t n_tiles, uint8_t* text_next, uint8_t* text_fin, hipStream_t st)
+{
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rp_splice, dim3((uint32_t)n_tiles), dim3(256), 0, st, t, text, offsets, rec_first, kept, hs, rt, n_act, text_next, text_fin);
+    return hipGetLastError();
+}
+
+hipError_t scan64_temp_bytes(uint64_t n, size_t* bytes)
+{
+    *bytes = 0;
+    return hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, (hipStream_t)0);
+}
+
+hipError_t launch_scan64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t st)
+{
+    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, st);
+}
+
+}  // namespace dev
+}  // namespace am

@@ -114,13 +114,15 @@ int amh_replacer_build(int case_mode, const uint8_t* nbytes, const uint64_t* nof
 void amh_replacer_free(void* r) { delete static_cast<Replacer*>(r); }
 // Runs a batch; results are returned as one malloc'd blob + offsets (n+1); is_nothing[i] = 1 where the
 // reference returns Nothing.  max_len < 0 = maxBound.
-int amh_replacer_run_batch(void* r, const am_slice* hay, size_t n_hay, long long max_len, uint8_t** blob_out, uint64_t* offs_out, uint8_t* is_nothing)
+static int replacer_run_batch(void* r, bool host_splice, const am_slice* hay, size_t n_hay, long long max_len, uint8_t** blob_out, uint64_t* offs_out, uint8_t* is_nothing)
 {
     *blob_out = nullptr;
     return guarded([&] {
         std::vector<std::string> in(n_hay);
         for (size_t i = 0; i < n_hay; i++) in[i].assign((const char*)hay[i].ptr + hay[i].off, hay[i].len);
-        auto res = static_cast<Replacer*>(r)->runBatchWithLimit(in, max_len < 0 ? SIZE_MAX : (size_t)max_len);
+        const size_t lim = max_len < 0 ? SIZE_MAX : (size_t)max_len;
+        auto* rp = static_cast<Replacer*>(r);
+        auto res = host_splice ? rp->runBatchWithLimitHostSplice(in, lim) : rp->runBatchWithLimit(in, lim);
         uint64_t total = 0;
         for (size_t i = 0; i < n_hay; i++) { offs_out[i] = total; is_nothing[i] = !res[i].has_value(); if (res[i]) total += res[i]->size(); }
         offs_out[n_hay] = total;
@@ -128,6 +130,26 @@ int amh_replacer_run_batch(void* r, const am_slice* hay, size_t n_hay, long long
         for (size_t i = 0; i < n_hay; i++) if (res[i] && !res[i]->empty()) std::memcpy(blob + offs_out[i], res[i]->data(), res[i]->size());
         *blob_out = blob;
     });
+}
+int amh_replacer_run_batch(void* r, const am_slice* hay, size_t n_hay, long long max_len, uint8_t** blob_out, uint64_t* offs_out, uint8_t* is_nothing)
+{
+    return replacer_run_batch(r, false, hay, n_hay, max_len, blob_out, offs_out, is_nothing);
+}
+// same function with only the scans on the GPU (cross-check of the device passes)
+int amh_replacer_run_batch_host_splice(void* r, const am_slice* hay, size_t n_hay, long long max_len, uint8_t** blob_out, uint64_t* offs_out, uint8_t* is_nothing)
+{
+    return replacer_run_batch(r, true, hay, n_hay, max_len, blob_out, offs_out, is_nothing);
+}
+// the am_replacer* (flattened Searcher Payload in HBM) behind this Replacer, for callers that keep their batches on the device
+int amh_replacer_device(void* r, const void** out)
+{
+    *out = nullptr;
+    return guarded([&] { *out = static_cast<Replacer*>(r)->device(); });
+}
+void amh_replacer_last_stats(void* r, uint64_t* passes, uint64_t* scanned_bytes)
+{
+    const auto st = static_cast<Replacer*>(r)->lastStats();
+    *passes = st.passes; *scanned_bytes = st.scannedBytes;
 }
 void amh_free_blob(uint8_t* p) { free(p); }
 

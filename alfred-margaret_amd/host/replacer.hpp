@@ -2,11 +2,14 @@
 // src/Data/Text/AhoCorasick/Replacer.hs): sequential multi-needle replace with priorities.
 //   Payload :59-70, build :97-116, compose :120-133, run :200-201, runWithLimit :203-274,
 //   removeOverlap :191-198, replace :163-180, replacementLength :183-187.
-// Each pass = one full scan of the (rewritten) haystacks on the GPU through libam (am_run on the
-// whole batch of still-active haystacks); priority filtering, sort, overlap removal and the
-// splice stay on the host, as in BASELINE config 5.
+// runBatchWithLimit hands the whole multi-pass loop to libam (am_replacer_*): scan, priority fold,
+// overlap removal and splice all run in HBM, only finished haystacks come back.
+// runBatchWithLimitHostSplice is the same function with only the scans on the GPU (am_run on the
+// batch of still-active haystacks per pass) and the fold/sort/splice on the host; it is kept as an
+// independent cross-check of the device passes.
 #pragma once
 #include <climits>
+#include <mutex>
 #include <optional>
 
 #include "searcher.hpp"
@@ -40,8 +43,58 @@ public:
         return Replacer(Searcher<Payload>(a.caseSensitivity(), std::move(ns)));
     }
 
+    struct RunStats { uint64_t passes = 0, scannedBytes = 0; };
+    RunStats lastStats() const { return stats_; }
+
     // Replacer.hs:203-274 runWithLimit on a batch; nullopt where the reference returns Nothing.
     std::vector<std::optional<std::string>> runBatchWithLimit(const std::vector<std::string>& inputs, size_t maxLength) const
+    {
+        std::vector<am_slice> slices(inputs.size());
+        for (size_t k = 0; k < inputs.size(); k++) slices[k] = am_slice{(const uint8_t*)inputs[k].data(), 0, inputs[k].size()};
+        am_replaced* raw = nullptr;
+        amCheck(am_replacer_run(device(), slices.data(), slices.size(), maxLength == SIZE_MAX ? UINT64_MAX : (uint64_t)maxLength, &raw));
+        std::unique_ptr<am_replaced, void (*)(am_replaced*)> res(raw, am_replaced_free);
+        stats_ = RunStats{am_replaced_passes(raw), am_replaced_scanned_bytes(raw)};
+        std::vector<std::optional<std::string>> out(inputs.size());
+        for (size_t k = 0; k < inputs.size(); k++) {
+            const uint8_t* p = nullptr; size_t n = 0;
+            const int just = am_replaced_get(raw, k, &p, &n);
+            if (just < 0) throw AmError(just, am_last_error());
+            if (just) out[k] = std::string((const char*)p, n);
+        }
+        return out;
+    }
+
+    // The flattened Searcher Payload (machineValues in CSR form + payload table) in HBM, made on first use.
+    const am_replacer* device() const
+    {
+        std::lock_guard<std::mutex> lk(*mu_);
+        if (!device_) {
+            const auto& m = searcher_.automaton();
+            const auto& ns = searcher_.needles();
+            std::vector<am_payload> payloads(ns.size());
+            std::string repl;
+            for (size_t i = 0; i < ns.size(); i++) {
+                const Payload& p = ns[i].second;
+                if (p.needlePriority != -(long long)i) throw AmError(AM_ERR_INVALID, "Replacer payload priorities must be -index (Replacer.hs:100-104)");
+                payloads[i] = am_payload{p.needlePriority, (uint32_t)p.needleLengthBytes, (uint32_t)p.needleLengthCodePoints, repl.size(), (uint32_t)p.needleReplacement.size(), 0};
+                repl += p.needleReplacement;
+            }
+            std::vector<uint64_t> voff(m.machineValues.size() + 1, 0);
+            std::vector<uint32_t> vals;
+            for (size_t s = 0; s < m.machineValues.size(); s++) {
+                for (const Payload& p : m.machineValues[s]) vals.push_back((uint32_t)(-p.needlePriority));
+                voff[s + 1] = vals.size();
+            }
+            am_replacer* r = nullptr;
+            amCheck(am_replacer_create(m.device.get(), (int)caseSensitivity(), voff.data(), vals.data(), payloads.data(), payloads.size(),
+                                       (const uint8_t*)repl.data(), repl.size(), 1 - (long long)ns.size(), &r));
+            device_.reset(r, am_replacer_destroy);
+        }
+        return device_.get();
+    }
+
+    std::vector<std::optional<std::string>> runBatchWithLimitHostSplice(const std::vector<std::string>& inputs, size_t maxLength) const
     {
         struct RMatch { size_t pos, len; const std::string* repl; };                       // Replacer.hs:159
         const bool ic = caseSensitivity() == CaseSensitivity::IgnoreCase;
@@ -51,7 +104,10 @@ public:
         std::vector<size_t> active(inputs.size());
         for (size_t i = 0; i < active.size(); i++) active[i] = i;
         struct Acc { long long pBest; std::vector<RMatch> matches; const std::string* hay; long long threshold; };
+        stats_ = RunStats{};
         while (!active.empty()) {
+            stats_.passes++;
+            for (size_t i : active) stats_.scannedBytes += cur[i]->size();
             std::vector<Text> texts; texts.reserve(active.size());
             for (size_t i : active) texts.emplace_back(*cur[i]);
             // one GPU scan of every active haystack; the fold below is prependMatch (:252-260)
@@ -134,6 +190,9 @@ private:
         return out;
     }
     Searcher<Payload> searcher_;
+    std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
+    mutable std::shared_ptr<am_replacer> device_;
+    mutable RunStats stats_;
 };
 
 }  // namespace alfred_margaret

@@ -53,6 +53,8 @@ extern "C" {
 #define AM_ERR_UNSUPPORTED (-5)
 
 typedef struct am_automaton am_automaton;
+typedef struct am_replacer am_replacer;
+typedef struct am_replaced am_replaced;
 typedef struct am_batch am_batch;
 typedef struct am_matches am_matches;
 
@@ -122,6 +124,43 @@ const am_match* am_matches_data(am_matches* m);           /* host pointer, owned
 const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
 void am_matches_free(am_matches* m);
 
+/* ---- Replacer: all passes of Replacer.run on the device -----------------------------------------
+ * Replaces the loop `runWithLimit.go` (src/Data/Text/AhoCorasick/Replacer.hs:219-242) for a batch of
+ * haystacks: per pass one scan (:223-225), prependMatch/makeMatch (:252-274), the replacementLength
+ * check (:183-187, :240), sort + removeOverlap (:191-198, :241) and replace (:163-180) all run in HBM;
+ * only finished haystacks travel back.  The caller hands over machineValues of the Replacer's
+ * automaton (`Searcher Payload`, :72-77) in flat form:
+ *   values_offsets  n_states + 1 entries; the list of state s (in the reference's order) is
+ *                   payloads[values[values_offsets[s] .. values_offsets[s+1])]
+ *   payloads        Payload (:59-70) per needle: priority, lengths of the ORIGINAL needle in bytes
+ *                   and code points (:112-113), replacement = repl_bytes[repl_off .. +repl_len)
+ *   min_priority    1 - numNeedles (:217)
+ * Priorities must be distinct and <= 0, as build (:100-104) and compose (:127-131) make them.
+ * `a` must outlive the replacer.  case_mode is the Replacer's replacerCaseSensitivity. */
+typedef struct am_payload {
+    int64_t priority;
+    uint32_t len_bytes;
+    uint32_t len_code_points;
+    uint64_t repl_off;
+    uint32_t repl_len;
+    uint32_t reserved;
+} am_payload;
+int am_replacer_create(const am_automaton* a, int case_mode,
+                       const uint64_t* values_offsets, const uint32_t* values,
+                       const am_payload* payloads, size_t n_payloads,
+                       const uint8_t* repl_bytes, size_t n_repl_bytes,
+                       int64_t min_priority, am_replacer** out);
+void am_replacer_destroy(am_replacer* r);
+/* max_length: runWithLimit's maxLength (:203); UINT64_MAX = `run` (:200-201, maxBound). */
+int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out);
+int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);   /* b is not modified */
+uint64_t am_replaced_size(const am_replaced* r);
+/* Returns 1 and the text for `Just`, 0 for `Nothing` (longer than max_length), < 0 on error.  *ptr is owned by r. */
+int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len);
+uint64_t am_replaced_passes(const am_replaced* r);          /* scans that were needed (max over the batch) */
+uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes scanned over all passes */
+void am_replaced_free(am_replaced* r);
+
 /* ---- multi-GPU: move the flattened automaton between devices -----------------------------------
  * The image is one position-independent blob, so rank 0 flattens once and the blob is broadcast
  * over xGMI (RCCL broadcast of a byte tensor); every other rank attaches to its received copy. */
@@ -142,7 +181,7 @@ int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 int am_profile_enable(int on);
 int am_profile_reset(void);
-int am_profile_read(const char* kernel /* "sf" | "ac" | "hidx" | "scan" */, double* total_ms, uint64_t* launches);
+int am_profile_read(const char* kernel /* "sf" | "ac" | "hidx" | "scan" | "permute" | "rp_pass" | "rp_splice" | ... */, double* total_ms, uint64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -200,7 +200,7 @@ class Replacer:
                                            rb, ro.ctypes.data_as(C.POINTER(C.c_uint64)), len(pairs))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:      # module globals may be gone at interpreter exit
             lib().orc_replacer_free(self._h)
             self._h = None
 

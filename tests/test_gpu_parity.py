@@ -269,3 +269,77 @@ def test_replacer_properties():
             assert am.Replacer(case, pairs).run_batch(hays) == [oracle.Replacer(case, pairs).run(h) for h in hays]
     r = am.Replacer(0, [("a", "bbbb")])
     assert r.run_with_limit(8, "aa") == b"bbbbbbbb" and r.run_with_limit(7, "aa") is None
+
+
+def _replacer_three_ways(case, pairs, hays, max_len=-1):
+    """device passes (am_replacer_*) == scans on GPU + host splice == oracle (Replacer.hs:203-242)."""
+    r = am.Replacer(case, pairs)
+    dev = r.run_batch(hays, max_len)
+    dev_stats = r.last_stats()
+    host = r.run_batch(hays, max_len, host_splice=True)
+    assert r.last_stats() == dev_stats                       # same number of passes, same bytes scanned
+    o = oracle.Replacer(case, pairs)
+    exp = [o.run(h, max_len) for h in hays]
+    assert dev == exp, (case, pairs[:6], max_len)
+    assert host == exp
+    return dev
+
+
+def test_replacer_device_overlaps_and_long_match_lists():
+    # self-overlapping needles: removeOverlap (Replacer.hs:191-198) across many 64-record batches of one haystack
+    _replacer_three_ways(0, [("aa", "b")], ["a" * n for n in (0, 1, 2, 3, 64, 65, 127, 128, 129, 1000, 4097)])
+    _replacer_three_ways(0, [("abab", "X"), ("ab", "yy")], ["ab" * 300, "abab" * 77 + "a", "b" + "ab" * 129])
+    _replacer_three_ways(0, [("aaa", ""), ("a", "bbbbb")], ["a" * 500, "a" * 7 + "c" + "a" * 200])
+    # replacements of every length relation, chains through lower priorities (README.md:67-77 style)
+    _replacer_three_ways(0, [("a", "b"), ("b", "c"), ("c", "dd"), ("dd", "")], ["abcabc" * 50, "", "dddd", "x"])
+    _replacer_three_ways(0, [("b", "a"), ("a", "b")], ["abba" * 40])
+    # tiles: outputs longer than one 16 KiB splice tile, replacement straddling tile borders
+    big = ("x" * 1021 + "needle") * 40
+    _replacer_three_ways(0, [("needle", "R" * 37), ("xR", "<>")], [big, big[3:], big[:16384], big[:16385]])
+    _replacer_three_ways(0, [("x" * 16, "y")], ["x" * 40000])
+
+
+def test_replacer_device_ignore_case_length_changing():
+    # lower-casing that changes byte length inside matches (İ 2→1, ẞ 3→2, K 3→1, Å 3→2): makeMatch (:268-274)
+    pairs = [("i", "<I>"), ("ß", "ss"), ("k", "K!"), ("å", "")]
+    hays = ["İxİİ", "ẞßẞ", "KkK", "ÅåÅ" * 30, "İẞKÅ" * 100, "aİ" * 70]
+    _replacer_three_ways(1, pairs, hays)
+    rng = random.Random(11)
+    for _ in range(10):
+        pairs = [("".join(rng.choice("abikßå") for _ in range(rng.randint(1, 3))),
+                  "".join(rng.choice("xyİK") for _ in range(rng.randint(0, 3)))) for _ in range(rng.randint(1, 6))]
+        hays = ["".join(rng.choice("abikABIK" * 4 + "İẞKÅßå") for _ in range(rng.randint(0, 300))) for _ in range(9)]
+        _replacer_three_ways(1, pairs, hays)
+        _replacer_three_ways(0, pairs, hays)
+
+
+def test_replacer_device_limit_and_empty_needle():
+    r = [("a", "bbbb"), ("c", "")]
+    hays = ["aa", "a", "", "acac", "cccc", "aaaa" * 10]
+    for lim in (0, 1, 4, 7, 8, 9, 40, 160, 161):
+        got = _replacer_three_ways(0, r, hays, lim)
+        assert got[2] == b""
+    # replacementLength counts matches that removeOverlap drops afterwards (Replacer.hs:240 before :241)
+    _replacer_three_ways(0, [("aa", "bbb")], ["aaa"], 4)
+    _replacer_three_ways(0, [("aa", "bbb")], ["aaa"], 5)
+    # the empty needle (general kernel): fires after every successful goto only
+    _replacer_three_ways(0, [("", "-"), ("ab", "c")], ["abab", "", "xaby"])
+    with pytest.raises(am.AmError) as e:
+        am.Replacer(1, [("", "-")]).run("ab")
+    assert e.value.code == am.AM_ERR_UNSUPPORTED
+
+
+def test_replacer_device_many_haystacks_many_passes():
+    rng = random.Random(23)
+    alpha = "abcde "
+    pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(2, 4))), "".join(rng.choice("ABC" + alpha) for _ in range(rng.randint(0, 5))))
+             for _ in range(60)]
+    hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 1, 5, 100, 700, 3000)))) for _ in range(200)]
+    for case in (0, 1):
+        r = am.Replacer(case, pairs)
+        got = r.run_batch(hays)
+        passes, scanned = r.last_stats()
+        assert passes > 10 and scanned > sum(len(h) for h in hays)
+        o = oracle.Replacer(case, pairs)
+        assert got == [o.run(h) for h in hays]
+        assert got == r.run_batch(hays, host_splice=True)
