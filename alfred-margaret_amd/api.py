@@ -56,6 +56,10 @@ ABI = {
     "am_matches_data": (_vp, [_vp]),
     "am_matches_device_data": (_vp, [_vp]),
     "am_matches_free": (None, [_vp]),
+    "am_needle_ids_create": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
+    "am_needle_ids_destroy": (None, [_vp]),
+    "am_contains_all": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
+    "am_contains_all_batch": (C.c_int, [_vp, C.c_int, _vp, _vp]),
     "am_replacer_create": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _sz, _vp, _sz, C.c_int64, C.POINTER(_vp)]),
     "am_replacer_destroy": (None, [_vp]),
     "am_replacer_run": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_uint64, C.POINTER(_vp)]),
@@ -96,6 +100,7 @@ _HOST = {
     "amh_searcher_set_case": (None, [_vp, C.c_int]),
     "amh_searcher_contains_any": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
     "amh_searcher_contains_all": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
+    "amh_searcher_contains_all_host_fold": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
     "amh_replacer_build": (C.c_int, [C.c_int, C.c_char_p, _vp, C.c_char_p, _vp, _sz, C.POINTER(_vp)]),
     "amh_replacer_free": (None, [_vp]),
     "amh_replacer_run_batch": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
@@ -317,10 +322,12 @@ class Searcher:
     def contains_any(self, text):
         return bool(self.contains_any_batch([text])[0])
 
-    def contains_all_batch(self, texts):
+    def contains_all_batch(self, texts, host_fold=False):
+        """Searcher.containsAll per haystack.  host_fold=True folds the records on the host (cross-check)."""
         s = _Slices(texts)
         out = np.zeros(max(s.n, 1), np.uint8)
-        _hcheck(libhost().amh_searcher_contains_all(self._h, s.arr, s.n, out.ctypes.data))
+        fn = libhost().amh_searcher_contains_all_host_fold if host_fold else libhost().amh_searcher_contains_all
+        _hcheck(fn(self._h, s.arr, s.n, out.ctypes.data))
         return out[:s.n].astype(bool)
 
     def contains_all(self, text):

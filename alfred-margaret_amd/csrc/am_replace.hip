@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256) k_rp_ranges(const Record* __restrict__ re
 {
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h > n_act) return;
-    if (h == n_act) { route.len_next[h] = 0; route.len_fin[h] = 0; route.tiles[h] = 0; route.act[h] = 0; route.fin[h] = 0; }   // the scans' trailing element
+    if (h == n_act && route.len_next) { route.len_next[h] = 0; route.len_fin[h] = 0; route.tiles[h] = 0; route.act[h] = 0; route.fin[h] = 0; }   // the scans' trailing element
     uint64_t lo = 0, hi = n_rec;                     // first record whose haystack >= h
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (recs[mid].haystack < h) lo = mid + 1; else hi = mid; }
     rec_first[h] = lo;
@@ -278,6 +278,51 @@ hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64
 {
     if (n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_rp_splice, dim3((uint32_t)n_tiles), dim3(256), 0, st, t, text, offsets, rec_first, kept, hs, rt, n_act, text_next, text_fin);
+    return hipGetLastError();
+}
+
+// ---- Searcher.containsAll (Searcher.hs:173-187) on the records: the IntSet of needle ids still missing, as one
+// bitmap of `words` 32-bit words per haystack.  k_idset sets the bit of every reported id, k_idset_all tests
+// whether all n_needles bits of a haystack are set (IS.null of the final accumulator).
+__global__ void __launch_bounds__(256) k_idset(const Record* __restrict__ recs, uint64_t r0, uint64_t r1, const uint64_t* __restrict__ vals_off,
+                                               const uint32_t* __restrict__ vals, uint32_t n_needles, uint32_t hay0, uint32_t words, uint32_t* __restrict__ bits)
+{
+    const uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r1) return;
+    const Record rec = recs[r];
+    uint32_t* row = bits + (uint64_t)(rec.haystack - hay0) * words;
+    for (uint64_t k = vals_off[rec.state], ke = vals_off[rec.state + 1]; k < ke; k++) {
+        const uint32_t id = vals[k];
+        if (id >= n_needles) continue;                           // IS.delete of an absent key
+        const uint32_t m = 1u << (id & 31);
+        if (!(row[id >> 5] & m)) atomicOr(row + (id >> 5), m);      // a stale read only costs an extra atomic
+    }
+}
+
+__global__ void __launch_bounds__(256) k_idset_all(const uint32_t* __restrict__ bits, uint32_t words, uint32_t n_needles, uint32_t n_hay, uint8_t* __restrict__ flags)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_hay) return;
+    const uint32_t* row = bits + (uint64_t)h * words;
+    int64_t c = 0;
+    for (uint32_t w = lane; w < words; w += kWave) c += __popc(row[w]);
+    c = wave_sum_i64(c);
+    if (lane == 0) flags[h] = c == (int64_t)n_needles ? 1 : 0;
+}
+
+hipError_t launch_idset(const Record* recs, uint64_t r0, uint64_t r1, const uint64_t* vals_off, const uint32_t* vals, uint32_t n_needles,
+                        uint32_t hay0, uint32_t words, uint32_t* bits, hipStream_t st)
+{
+    if (r1 <= r0) return hipSuccess;
+    hipLaunchKernelGGL(k_idset, dim3((uint32_t)((r1 - r0 + 255) / 256)), dim3(256), 0, st, recs, r0, r1, vals_off, vals, n_needles, hay0, words, bits);
+    return hipGetLastError();
+}
+
+hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_needles, uint32_t n_hay, uint8_t* flags, hipStream_t st)
+{
+    if (n_hay == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_idset_all, dim3((n_hay + 3) / 4), dim3(256), 0, st, bits, words, n_needles, n_hay, flags);
     return hipGetLastError();
 }
 

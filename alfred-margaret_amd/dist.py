@@ -42,3 +42,33 @@ def allreduce_max(value, device):
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def split_single_haystack(text, world, max_needle_code_points):
+    """ONE haystack on `world` GPUs: rank r owns the end positions in (lo, hi] and scans
+    text[start:hi], where start = lo minus an overlap of one maximal match, moved back to a code-point
+    boundary.  Whether a needle ends at a position depends only on the max-needle-length bytes before
+    it, so a scan started `overlap` earlier reports exactly the reference's matches in (lo, hi].  The
+    overlap is 4 bytes per needle code point: under IgnoreCase a haystack code point may be longer than
+    the needle code point it lowers to (K, 3 bytes, lowers to k).  Returns [(start, lo, hi)] per rank."""
+    text = memoryview(text)
+    n = len(text)
+    overlap = 4 * max(int(max_needle_code_points), 1)
+    out = []
+    for r in range(world):
+        lo, hi = shard_bounds(n, r, world)
+        start = max(0, lo - overlap)
+        while start > 0 and (text[start] & 0xC0) == 0x80:
+            start -= 1
+        out.append((start, lo, hi))
+    return out
+
+
+def own_records(records, start, lo, hi):
+    """Filter + rebase the records of a scan of text[start:hi] to the rank's own range: keeps end
+    positions in (lo, hi] and makes them relative to the whole haystack."""
+    end = records["end_pos"] + start
+    keep = end > lo
+    out = records[keep].copy()
+    out["end_pos"] = end[keep]
+    return out

@@ -98,6 +98,11 @@ int amh_searcher_contains_all(void* s, const am_slice* hay, size_t n_hay, uint8_
     return guarded([&] { auto r = containsAllBatch(*static_cast<Searcher<int>*>(s), sliceTexts(hay, n_hay)); for (size_t i = 0; i < n_hay; i++) out[i] = r[i]; });
 }
 
+int amh_searcher_contains_all_host_fold(void* s, const am_slice* hay, size_t n_hay, uint8_t* out)
+{
+    return guarded([&] { auto r = containsAllBatchHostFold(*static_cast<Searcher<int>*>(s), sliceTexts(hay, n_hay)); for (size_t i = 0; i < n_hay; i++) out[i] = r[i]; });
+}
+
 // ---- Replacer
 int amh_replacer_build(int case_mode, const uint8_t* nbytes, const uint64_t* noffs, const uint8_t* rbytes, const uint64_t* roffs, size_t n, void** out)
 {

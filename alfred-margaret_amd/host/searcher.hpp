@@ -2,8 +2,11 @@
 // src/Data/Text/AhoCorasick/Searcher.hs): needles + case mode + automaton.
 //   build / buildWithValues :110-118, containsAny :156-164, buildNeedleIdSearcher :167-169,
 //   containsAll :173-187, setCaseSensitivity :142-145.
-// containsAny dispatches to libam's flag kernel; containsAll folds the returned records.
+// containsAny dispatches to libam's flag kernel; containsAll to libam's needle-id bitmap fold
+// (am_contains_all); containsAllBatchHostFold is the same function folding the records on the host.
 #pragma once
+#include <mutex>
+
 #include "automaton.hpp"
 
 namespace alfred_margaret {
@@ -22,8 +25,13 @@ public:
     const std::vector<std::pair<std::string, V>>& needles() const { return needles_; }
     size_t numNeedles() const { return needles_.size(); }
     const AcMachine<V>& automaton() const { return automaton_; }
+    // per-searcher device-side extras (flattened machineValues), created on first use by the functions below
+    std::shared_ptr<void>& deviceExtra() const { return extra_; }
+    std::mutex& deviceExtraMutex() const { return *extraMu_; }
 
 private:
+    mutable std::shared_ptr<void> extra_;
+    std::shared_ptr<std::mutex> extraMu_ = std::make_shared<std::mutex>();
     CaseSensitivity case_;
     std::vector<std::pair<std::string, V>> needles_;
     AcMachine<V> automaton_;
@@ -60,8 +68,35 @@ std::vector<bool> containsAnyBatch(const Searcher<V>& s, const std::vector<Text>
 
 template <class V> bool containsAny(const Searcher<V>& s, const Text& text) { return containsAnyBatch(s, std::vector<Text>{text})[0]; }
 
-// Searcher.hs:173-187 containsAll: delete each reported needle id from the set, Done when empty
+// Searcher.hs:173-187 containsAll on the device: the IntSet is a bitmap row per haystack in HBM
 inline std::vector<bool> containsAllBatch(const Searcher<int>& s, const std::vector<Text>& texts)
+{
+    am_needle_ids* ids = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(s.deviceExtraMutex());
+        if (!s.deviceExtra()) {
+            const auto& m = s.automaton();
+            std::vector<uint64_t> voff(m.machineValues.size() + 1, 0);
+            std::vector<uint32_t> vals;
+            for (size_t st = 0; st < m.machineValues.size(); st++) {
+                for (int id : m.machineValues[st]) vals.push_back(id < 0 ? UINT32_MAX : (uint32_t)id);
+                voff[st + 1] = vals.size();
+            }
+            am_needle_ids* raw = nullptr;
+            amCheck(am_needle_ids_create(m.device.get(), voff.data(), vals.data(), (uint32_t)s.numNeedles(), &raw));
+            s.deviceExtra() = std::shared_ptr<void>(raw, [](void* p) { am_needle_ids_destroy(static_cast<am_needle_ids*>(p)); });
+        }
+        ids = static_cast<am_needle_ids*>(s.deviceExtra().get());
+    }
+    std::vector<am_slice> slices(texts.size());
+    for (size_t k = 0; k < texts.size(); k++) slices[k] = am_slice{texts[k].data, texts[k].off, texts[k].len};
+    std::vector<uint8_t> flags(texts.size() ? texts.size() : 1, 0);
+    amCheck(am_contains_all(ids, (int)s.caseSensitivity(), slices.data(), slices.size(), flags.data()));
+    return std::vector<bool>(flags.begin(), flags.begin() + texts.size());
+}
+
+// the same function with only the scan on the GPU: delete each reported needle id from the set, Done when empty
+inline std::vector<bool> containsAllBatchHostFold(const Searcher<int>& s, const std::vector<Text>& texts)
 {
     struct Acc { std::vector<uint8_t> present; size_t remaining; };
     Acc seed{std::vector<uint8_t>(s.numNeedles(), 1), s.numNeedles()};

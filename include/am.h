@@ -54,6 +54,7 @@ extern "C" {
 
 typedef struct am_automaton am_automaton;
 typedef struct am_replacer am_replacer;
+typedef struct am_needle_ids am_needle_ids;
 typedef struct am_replaced am_replaced;
 typedef struct am_batch am_batch;
 typedef struct am_matches am_matches;
@@ -123,6 +124,16 @@ uint64_t am_matches_size(const am_matches* m);
 const am_match* am_matches_data(am_matches* m);           /* host pointer, owned by m; NULL on error */
 const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
 void am_matches_free(am_matches* m);
+
+/* ---- Searcher.containsAll (src/Data/Text/AhoCorasick/Searcher.hs:167-187) ------------------------
+ * For a `Searcher Int` made by buildNeedleIdSearcher (:167-169): machineValues in flat form (the list
+ * of state s is values[values_offsets[s] .. values_offsets[s+1]), needle ids 0 .. n_needles-1).  The
+ * IntSet fold (:175-183) becomes one bitmap row per haystack in HBM; flags_out[i] = 1 iff every id was
+ * reported in haystack i (IS.null of the final set; all ones when n_needles == 0).  `a` must outlive ids. */
+int am_needle_ids_create(const am_automaton* a, const uint64_t* values_offsets, const uint32_t* values, uint32_t n_needles, am_needle_ids** out);
+void am_needle_ids_destroy(am_needle_ids* ids);
+int am_contains_all(const am_needle_ids* ids, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
+int am_contains_all_batch(const am_needle_ids* ids, int case_mode, const am_batch* b, uint8_t* flags_out);
 
 /* ---- Replacer: all passes of Replacer.run on the device -----------------------------------------
  * Replaces the loop `runWithLimit.go` (src/Data/Text/AhoCorasick/Replacer.hs:219-242) for a batch of

@@ -343,3 +343,46 @@ def test_replacer_device_many_haystacks_many_passes():
         o = oracle.Replacer(case, pairs)
         assert got == [o.run(h) for h in hays]
         assert got == r.run_batch(hays, host_splice=True)
+
+
+def test_single_haystack_split_like_multi_gpu():
+    """one big haystack cut into per-rank ranges with a one-match overlap; the union of the ranks'
+    own records is the whole-haystack result (here the 'ranks' run one after the other on one GPU)."""
+    from alfred_margaret_amd import dist as amdist
+    for workload, case in (("cfg2_runText_10k_1GiB", 0), ("cfg3_runLower_100k_10GiB", 1)):
+        needles = synth.needles_for(workload)[:5000]
+        a = am.Automaton(needles)
+        text = bytes(synth.haystacks_host(needles, bool(case), 3, 700))
+        whole = a.run_records(case, [text])
+        assert len(whole) > 300
+        max_cps = max(len(n) if isinstance(n, str) else len(n.decode("utf-8")) for n in needles)
+        for world in (2, 5, 8):
+            parts = []
+            for start, lo, hi in amdist.split_single_haystack(text, world, max_cps):
+                parts.append(amdist.own_records(a.run_records(case, [text[start:hi]]), start, lo, hi))
+            got = np.concatenate(parts)
+            assert np.array_equal(got["end_pos"], whole["end_pos"]) and np.array_equal(got["state"], whole["state"])
+
+
+def test_contains_all_device_bitmap():
+    """Searcher.containsAll (Searcher.hs:173-187): device bitmap fold == host fold of the records == oracle,
+    incl. duplicates, the empty needle, no needles (vacuously True) and needle counts around the 32-bit words."""
+    rng = random.Random(31)
+    for it in range(25):
+        n = rng.choice((0, 1, 2, 5, 31, 32, 33, 70))
+        needles = ["".join(rng.choice("abcAB") for _ in range(rng.randint(0 if it % 5 == 0 else 1, 3))) for _ in range(n)]
+        hays = ["".join(rng.choice("abcABß") for _ in range(rng.choice((0, 3, 40, 400, 3000)))) for _ in range(12)]
+        hays.append("".join(needles))           # contains everything (case-sensitively) unless the empty-needle quirk bites
+        for case in (0, 1):
+            if "" in needles and not any(needles):
+                continue
+            s = am.Searcher.build_needle_id(case, needles) if hasattr(am.Searcher, "build_needle_id") else am.Searcher(case, needles)
+            o = oracle.Machine(needles)
+            exp = [o.contains_all(case, h) for h in hays]
+            assert [bool(x) for x in s.contains_all_batch(hays)] == exp, (case, needles)
+            assert [bool(x) for x in s.contains_all_batch(hays, host_fold=True)] == exp
+    # AhoCorasickSpec.hs:202-218: a haystack made of all needles contains all of them
+    needles = synth.needles_for("cfg2_runText_10k_1GiB")[:3000]
+    s = am.Searcher(0, needles)
+    joined = " ".join(n if isinstance(n, str) else n.decode() for n in needles)
+    assert list(s.contains_all_batch([joined, joined[: len(joined) // 2], ""])) == [True, False, False]

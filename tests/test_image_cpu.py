@@ -92,3 +92,34 @@ def test_long_needles_compressed_edges(chk, seed):
         for case in (0, 1):
             ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
             _check(chk, ns, hays, case)
+
+
+def test_single_haystack_split_across_ranks(chk):
+    """dist.split_single_haystack: scanning overlapping ranges and keeping each rank's own end
+    positions gives exactly the whole-haystack result, also with cuts inside code points and matches."""
+    import numpy as np
+    from alfred_margaret_amd import dist as amdist
+    rng = random.Random(77)
+    for it in range(12):
+        needles, hays = fragment_case(rng, n_hay_max=1, hay_frags=400)
+        text = max(hays, key=len) if hays else ""
+        b = text.encode("utf-8") if isinstance(text, str) else bytes(text)
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+            p = am.Automaton(ns)
+            img = chk.flatten(p, case)
+            max_cps = max([len(n) for n in ns] + [1])
+            which = 0 if "" in ns else 1
+            n, whole = chk.scan(img, which, [b])
+            assert n >= 0
+            exp = sorted(zip(whole[2].tolist(), whole[1].tolist()))
+            for world in (1, 2, 3, 7):
+                got = []
+                for start, lo, hi in amdist.split_single_haystack(b, world, max_cps):
+                    n, part = chk.scan(img, which, [b[start:hi]])
+                    assert n >= 0
+                    recs = np.zeros(len(part[0]), dtype=am.api.MATCH_DTYPE)
+                    recs["end_pos"], recs["state"] = part[2], part[1]
+                    own = amdist.own_records(recs, start, lo, hi)
+                    got += list(zip(own["end_pos"].tolist(), own["state"].tolist()))
+                assert got == exp, (world, case, ns, b)
