@@ -72,6 +72,8 @@ ABI = {
     "am_automaton_image_size": (C.c_int, [_vp, C.c_int, C.POINTER(_sz)]),
     "am_automaton_image_copy": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "am_automaton_from_image": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "am_automaton_image_read": (C.c_int, [_vp, C.c_int, _vp, _sz]),
+    "am_automaton_from_host_image": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
     "am_unlower_code_point": (_sz, [C.c_uint32, _vp, _sz]),
     "am_set_stream": (C.c_int, [_vp]),
@@ -246,6 +248,18 @@ class Automaton:
     def set_kernel(self, k):
         check(libam().am_automaton_set_kernel(self.device, k))
 
+    def image_bytes(self, case):
+        """The flattened automaton of one case mode as a serialisable blob (am_automaton_image_read)."""
+        n = C.c_size_t(0)
+        check(libam().am_automaton_image_size(self.device, case, C.byref(n)))
+        buf = (C.c_uint8 * n.value)()
+        check(libam().am_automaton_image_read(self.device, case, buf, n.value))
+        return bytes(buf)
+
+    def save_image(self, path, case):
+        with open(path, "wb") as f:
+            f.write(self.image_bytes(case))
+
     def run_batch_with_case(self, case, texts):
         """Per-haystack list fold of runWithCase: returns (haystack, matchPos, value) arrays in fold order."""
         s = _Slices(texts)
@@ -282,6 +296,47 @@ class Automaton:
             return matches_to_numpy(m)
         finally:
             libam().am_matches_free(m)
+
+
+class ImageAutomaton:
+    """A device automaton attached to a serialised image (am_automaton_from_host_image): no build, no
+    flatten.  It serves the image's case mode and returns raw records; machineValues stay with whoever
+    built the automaton."""
+
+    def __init__(self, image_bytes):
+        buf = bytes(image_bytes)
+        h = _vp()
+        check(libam().am_automaton_from_host_image(buf, len(buf), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def load(cls, path):
+        with open(path, "rb") as f:
+            return cls(f.read())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libam().am_automaton_destroy(self._h)
+            self._h = None
+
+    @property
+    def device(self):
+        return self._h.value
+
+    def run_records(self, case, texts):
+        s = _Slices(texts)
+        m = _vp()
+        check(libam().am_run(self._h, case, s.arr, s.n, C.byref(m)))
+        try:
+            return matches_to_numpy(m)
+        finally:
+            libam().am_matches_free(m)
+
+    def count_matches(self, case, texts):
+        s = _Slices(texts)
+        out = np.zeros(max(s.n, 1), np.uint64)
+        check(libam().am_count(self._h, case, s.arr, s.n, out.ctypes.data))
+        return out[:s.n]
 
 
 def matches_to_numpy(m):

@@ -251,10 +251,40 @@ extern "C" int am_automaton_from_image(const void* d_image, size_t nbytes, am_au
     if (!d_image || nbytes < sizeof(ImageHeader)) return fail(AM_ERR_INVALID, "image too small");
     ImageHeader h;
     HIP_TRY(hipMemcpy(&h, d_image, sizeof(h), hipMemcpyDeviceToHost));
-    if (h.magic != kImageMagic || h.version != kImageVersion || h.total_bytes > nbytes || h.case_mode > 1) return fail(AM_ERR_INVALID, "not an automaton image");
+    if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image");
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, h.total_bytes));
     hipError_t e = hipMemcpy(d, d_image, h.total_bytes, hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return fail(AM_ERR_HIP, hipGetErrorString(e)); }
+    am_automaton* a = new am_automaton();
+    Flavor& f = a->fl[h.case_mode];
+    f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.ready = true;
+    *out = a;
+    return AM_OK;
+}
+
+// Serialised form = the image blob itself (position independent; magic, version and a checksum in its header).
+extern "C" int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst, size_t nbytes)
+{
+    const Flavor* f; AM_TRY(prepare(a, case_mode, &f));
+    if (!host_dst || nbytes < f->bytes) return fail(AM_ERR_INVALID, "destination too small");
+    HIP_TRY(hipMemcpy(host_dst, f->d_image, f->bytes, hipMemcpyDeviceToHost));
+    return AM_OK;
+}
+
+extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!image || nbytes < sizeof(ImageHeader)) return fail(AM_ERR_INVALID, "image too small");
+    ImageHeader h;
+    std::memcpy(&h, image, sizeof(h));
+    if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image (magic, version or section bounds)");
+    if (image_checksum((const uint8_t*)image + sizeof(h), (size_t)h.total_bytes - sizeof(h)) != h.reserved[0]) return fail(AM_ERR_INVALID, "automaton image is corrupt (checksum)");
+    AM_TRY(ensure_device());
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, h.total_bytes));
+    hipError_t e = hipMemcpy(d, image, h.total_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(AM_ERR_HIP, hipGetErrorString(e)); }
     am_automaton* a = new am_automaton();
     Flavor& f = a->fl[h.case_mode];

@@ -491,9 +491,40 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     h.off_edges = blob.put(edges_out);
     blob.reserve_section(16);      // tail padding
     h.total_bytes = blob.bytes.size();
+    h.reserved[0] = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
     std::memcpy(blob.bytes.data(), &h, sizeof(h));
     image.swap(blob.bytes);
     return 0;
+}
+
+uint64_t image_checksum(const uint8_t* p, size_t n)
+{
+    // FNV-1a over 8-byte words (the tail bytes one by one): integrity of a stored image, not security
+    uint64_t x = 0xcbf29ce484222325ull;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); x = (x ^ w) * 0x100000001b3ull; }
+    for (; i < n; i++) x = (x ^ p[i]) * 0x100000001b3ull;
+    return x;
+}
+
+bool image_sections_in_bounds(const ImageHeader& h)
+{
+    const uint64_t T = h.total_bytes;
+    auto ok = [T](uint64_t off, uint64_t count, uint64_t elem) { return off <= T && count <= (T - off) / elem; };
+    if (h.magic != kImageMagic || h.version != kImageVersion || h.case_mode > 1 || T < sizeof(ImageHeader)) return false;
+    bool good = ok(h.off_transitions, h.n_transitions, 8) && ok(h.off_offsets, (uint64_t)h.n_states + 1, 4) && ok(h.off_root_ascii, 128, 8) &&
+                ok(h.off_canon, h.n_states, 4) && ok(h.off_vlen, h.n_states, 4) && ok(h.off_lower, h.n_lower, 4);
+    if (h.sf_enabled) {
+        if (h.sf_bloom_log2_words > 20) return false;
+        good = good && ok(h.off_bloom, 1ull << h.sf_bloom_log2_words, 4) && ok(h.off_nodes, h.sf_n_nodes, 32) && ok(h.off_edges, h.n_edges, 32);
+        for (int t = 0; t < 4; t++) {
+            if (!(h.sf_tiers & (1u << t))) continue;
+            if (h.tier_log2_cap[t] > 30) return false;
+            good = good && ok(h.off_tier[t], 1ull << h.tier_log2_cap[t], 8);
+            if (t == 3) good = good && ok(h.off_t4_cold, 1ull << h.tier_log2_cap[t], 16);
+        }
+    }
+    return good;
 }
 
 }  // namespace am

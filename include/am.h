@@ -178,6 +178,12 @@ void am_replaced_free(am_replaced* r);
 int am_automaton_image_size(const am_automaton* a, int case_mode, size_t* nbytes);
 int am_automaton_image_copy(const am_automaton* a, int case_mode, void* d_dst, size_t nbytes);   /* device -> device */
 int am_automaton_from_image(const void* d_image, size_t nbytes, am_automaton** out);            /* copies the blob */
+/* Serialised automaton: the same blob in host memory (write it to a file as is).  Loading checks the
+ * header (magic, version, every section inside the blob) and a checksum of the body, so a truncated or
+ * damaged file is refused; it skips build + flatten entirely (the reference's JSON instances store only
+ * the needles and rebuild, Searcher.hs:68-77).  A handle made from an image serves the image's case mode. */
+int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst, size_t nbytes);   /* device -> host */
+int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out);
 
 /* ---- UTF-8 helpers on the path -------------------------------------------------------------------
  * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151), simple mapping, Unicode 13.0.

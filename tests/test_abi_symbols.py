@@ -47,3 +47,32 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"(#include\s*[\"<][^\n]*oracle|import\s+oracle|from\s+oracle|liboracle|libam_oracle)", text):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_serialised_image_is_validated_before_any_device_work():
+    """am_automaton_from_host_image refuses damaged blobs with AM_ERR_INVALID (header, section bounds,
+    checksum) -- on a box without a GPU too, because the checks come first."""
+    import numpy as np
+    import torch
+    from tests.helpers import ImgCheck
+    lib = am.api.libam()
+    img = bytes(ImgCheck().flatten(am.Automaton(["tshirt", "shirts", "shorts"]), 1))
+
+    def load(blob):
+        h = C.c_void_p()
+        rc = lib.am_automaton_from_host_image(blob, len(blob), C.byref(h))
+        if h.value:
+            lib.am_automaton_destroy(h)
+        return rc
+
+    ok = am.AM_OK if torch.cuda.is_available() else am.AM_ERR_NO_DEVICE
+    assert load(img) == ok
+    assert load(img[:64]) == am.AM_ERR_INVALID                              # shorter than the header
+    assert load(img[:-32]) == am.AM_ERR_INVALID                             # truncated
+    assert load(b"XXXX" + img[4:]) == am.AM_ERR_INVALID                     # magic
+    flipped = bytearray(img); flipped[len(img) // 2] ^= 0x40
+    assert load(bytes(flipped)) == am.AM_ERR_INVALID                        # checksum
+    hdr = np.frombuffer(img[:256], dtype=np.uint64).copy()
+    bad = bytearray(img); bad[40:48] = np.uint64(1 << 40).tobytes()         # off_transitions far outside the blob
+    assert load(bytes(bad)) == am.AM_ERR_INVALID
+    assert b"image" in lib.am_last_error()

@@ -386,3 +386,20 @@ def test_contains_all_device_bitmap():
     s = am.Searcher(0, needles)
     joined = " ".join(n if isinstance(n, str) else n.decode() for n in needles)
     assert list(s.contains_all_batch([joined, joined[: len(joined) // 2], ""])) == [True, False, False]
+
+
+def test_serialised_image_round_trip(tmp_path):
+    """Automaton.save_image -> ImageAutomaton.load: same records without build or flatten."""
+    for workload, case in (("cfg2_runText_10k_1GiB", 0), ("cfg3_runLower_100k_10GiB", 1)):
+        needles = synth.needles_for(workload)[:4000] + (["", "x"] if case == 0 else [])
+        a = am.Automaton(needles)
+        hays = [bytes(synth.haystacks_host(needles[:4000], bool(case), 11, 64)), b"", b"xx"]
+        path = str(tmp_path / ("image%d.bin" % case))
+        a.save_image(path, case)
+        b = am.ImageAutomaton.load(path)
+        ra, rb = a.run_records(case, hays), b.run_records(case, hays)
+        assert len(ra) > 50 and np.array_equal(ra, rb)
+        assert np.array_equal(a.count_matches(case, hays), b.count_matches(case, hays))
+        with pytest.raises(am.AmError) as e:
+            b.run_records(1 - case, hays)          # an image serves its own case mode only
+        assert e.value.code == am.AM_ERR_UNSUPPORTED
