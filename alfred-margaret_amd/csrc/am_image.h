@@ -195,7 +195,18 @@ AM_HD uint32_t fold_dword(uint32_t x)
 constexpr uint32_t kBloomMul = 0x9E3779B1u;
 AM_HD uint32_t bloom_hash(uint32_t key, uint32_t tier) { return (key + (4u - tier) * 0x7F4A7C15u) * kBloomMul; }
 AM_HD uint32_t bloom_word(uint32_t h, uint32_t log2_words) { return h >> (32u - log2_words); }
-AM_HD uint32_t bloom_mask(uint32_t h) { return (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u)) | (1u << ((h >> 2) & 31u)); }
+// three bits of one 32-bit word; the fields sit where the kernel can use them as shift amounts with the fewest
+// instructions (a variable shift reads only the low 5 bits of its amount, so `h` itself serves as the third field)
+AM_HD uint32_t bloom_mask(uint32_t h) { return (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u)) | (1u << (h & 31u)); }
+// 1 iff all three bits of h are set in the filter word v
+AM_HD uint32_t bloom_hit(uint32_t v, uint32_t h)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, h >> 12, 1u) & (v >> ((h >> 7) & 31u)) & (v >> (h & 31u));
+#else
+    return ((v >> ((h >> 12) & 31u)) & (v >> ((h >> 7) & 31u)) & (v >> (h & 31u))) & 1u;
+#endif
+}
 
 AM_HD uint32_t tier_slot(uint32_t key, uint32_t log2_cap) { return (key * 0x85EBCA6Bu) >> (32u - log2_cap); }
 
@@ -584,16 +595,16 @@ AM_HD bool sf_filter_short(const uint32_t* bloom, uint32_t log2_words, uint32_t 
     bool hit = false;
     for (uint32_t t = 1; t <= 3; t++) {
         if (tiers & (1u << (t - 1))) {
-            const uint32_t h = bloom_hash(w >> (8u * (4u - t)), t), m = bloom_mask(h);
-            hit = hit || ((bloom[bloom_word(h, log2_words)] & m) == m);
+            const uint32_t h = bloom_hash(w >> (8u * (4u - t)), t);
+            hit = hit || bloom_hit(bloom[bloom_word(h, log2_words)], h);
         }
     }
     return hit;
 }
 AM_HD bool sf_filter_window(const uint32_t* bloom, uint32_t log2_words, uint32_t tiers, uint32_t w)
 {
-    const uint32_t h = bloom_hash(w, 4), m = bloom_mask(h);
-    bool hit = (tiers & 8u) && (bloom[bloom_word(h, log2_words)] & m) == m;
+    const uint32_t h = bloom_hash(w, 4);
+    bool hit = (tiers & 8u) && bloom_hit(bloom[bloom_word(h, log2_words)], h);
     if (tiers & 7u) hit = hit || sf_filter_short(bloom, log2_words, tiers, w);
     return hit;
 }

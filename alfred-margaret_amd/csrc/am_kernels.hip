@@ -77,8 +77,9 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
-constexpr int kSfQ1 = 128;                       // per-wave queue of candidates {4-byte window, position | previous byte}; more take several sub-passes
-constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions: candidates that need the exact lookup + trie walk
+constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
+constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 10 | offset): candidates that need the exact lookup + trie walk
+constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
 
 // ILP = candidates probed per lane per round (their loads are in flight together);
 // NT  = stream the haystack with non-temporal loads.
@@ -92,21 +93,26 @@ constexpr int kSfQ2 = 256;                       // per-wave ring of deferred po
 //            are parked in a ring and walked 64 at a time, across chunk boundaries   (phase 2)
 // Phase 2 is FIFO, so the records of a unit come out in position order: ballot + popcount rank them,
 // and they are appended to the unit's chain of 64-record pool blocks (one atomic per block).
-template <bool IC, int MODE, int ILP, bool NT, bool SHORT>
+// LW: log2 of the filter size in words when it is the usual 128 KiB (15), so that the word address is a
+// constant shift + constant mask (VOP2 with immediates issues at almost twice the rate of anything that
+// reads an SGPR or needs the VOP3 encoding on gfx950, tools/microbench/valu_rates*.hip); 0 = any size
+template <bool IC, int MODE, int ILP, int LW, bool SHORT>
 __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* bloom = lds;
-    uint2* q1_all = reinterpret_cast<uint2*>(lds + words);
-    uint32_t* q2_all = reinterpret_cast<uint32_t*>(q1_all + kSfWaves * kSfQ1);
+    uint8_t* stage_all = reinterpret_cast<uint8_t*>(lds + words);
+    uint16_t* q1_all = reinterpret_cast<uint16_t*>(stage_all + kSfWaves * kSfStage);
+    uint16_t* q2_all = q1_all + kSfWaves * kSfQ1;
 
     for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* q1 = q1_all + wave * kSfQ1;
-    uint32_t* q2 = q2_all + wave * kSfQ2;
+    uint8_t* stage = stage_all + wave * kSfStage;
+    uint16_t* q1 = q1_all + wave * kSfQ1;
+    uint16_t* q2 = q2_all + wave * kSfQ2;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
     const uint32_t UC = o.unit_chunks;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 #pragma unroll
         for (int k = 0; k < RN; k++) {
             valid[k] = 64u * k + lane < nb;
-            const uint32_t item = valid[k] ? q2[(q2_head + 64u * k + lane) % kSfQ2] : 0u;
+            const uint32_t item = valid[k] ? (uint32_t)q2[(q2_head + 64u * k + lane) % kSfQ2] : 0u;
             gpos[k] = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
             hlo[k] = 0; hhi[k] = 0;
             if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         if (cc < n_chunks && p < b.total) {
             typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
             const u32x4_native* src = reinterpret_cast<const u32x4_native*>(b.text + p);
-            const u32x4_native t = NT ? __builtin_nontemporal_load(src) : *src;     // global_load_dwordx4 [nt]
+            const u32x4_native t = *src;                                            // global_load_dwordx4
             v = make_uint4(t.x, t.y, t.z, t.w);
             if (p >= 8) prev = *reinterpret_cast<const uint2*>(b.text + p - 8);     // the 8 bytes before the lane's 16
         }
@@ -232,6 +238,8 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             uint32_t dm = cur_prev.x, d0 = cur_prev.y, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
             if (IC) { dm = fold_dword(dm); d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
             const uint32_t d[5] = {d0, d1, d2, d3, d4};
+            *reinterpret_cast<uint4*>(stage + 16u + lane * 16u) = make_uint4(d1, d2, d3, d4);
+            if (lane == 0) *reinterpret_cast<uint2*>(stage + 8u) = make_uint2(dm, d0);
             uint32_t cand = 0;
             {
                 // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 16 LDS reads are all in
@@ -245,9 +253,12 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     h[k] = w * kBloomMul;
                 }
 #pragma unroll
-                for (int k = 0; k < 16; k++) v[k] = bloom[h[k] >> sh_word];
+                for (int k = 0; k < 16; k++) {
+                    if (LW) v[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(bloom) + ((h[k] >> (30 - LW)) & (((1u << LW) - 1u) << 2)));
+                    else v[k] = bloom[h[k] >> sh_word];
+                }
 #pragma unroll
-                for (int k = 0; k < 16; k++) { const uint32_t m = bloom_mask(h[k]); if ((v[k] & m) == m) cand |= 1u << k; }
+                for (int k = 15; k >= 0; k--) cand = (cand << 1) | bloom_hit(v[k], h[k]);      // bit k of cand = position k
             }
             if (SHORT) {                                   // automata with 1..3-byte needles: extra probes per position
 #pragma unroll
@@ -268,20 +279,12 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 const uint32_t total = __shfl(incl, 63, 64);
                 if (total == 0) break;
                 uint32_t idx = incl - n;
+                // the loop runs as long as the busiest lane has candidates, so it only queues positions; the probe
+                // (dense, one candidate per lane) picks the window and the two bytes before it out of the staged chunk
                 while (cand && idx < (uint32_t)kSfQ1) {
-                    // queue the candidate with its (already folded) window and the two bytes before it, so that
-                    // the probe needs no haystack load: with A = the lane's 24 bytes (8 before + its 16),
-                    // window = A[k+5..k+8], nearest previous byte = A[k+4], the one before = A[k+3]
                     const uint32_t k = __builtin_ctz(cand);
                     cand &= cand - 1u;
-                    const uint32_t j = k >> 2, sh = k & 3u;
-                    const uint32_t pl = j == 0 ? dm : j == 1 ? d0 : j == 2 ? d1 : d2;
-                    const uint32_t lo = j == 0 ? d0 : j == 1 ? d1 : j == 2 ? d2 : d3;
-                    const uint32_t hi = j == 0 ? d1 : j == 1 ? d2 : j == 2 ? d3 : d4;
-                    const uint32_t w = (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (sh + 1u)));
-                    const uint32_t two = (uint32_t)((((uint64_t)lo << 32) | pl) >> (8u * (sh + 3u))) & 0xFFFFu;   // A[k+3] | A[k+4] << 8
-                    const uint32_t nbs = (two >> 8) | ((two & 0xFFu) << 8);                                       // nearest byte in bits 0-7
-                    q1[idx++] = make_uint2(w, (lane * 16u + k) | (nbs << 16));
+                    q1[idx++] = (uint16_t)(lane * 16u + k);
                 }
                 const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
                 wave_lds_fence();
@@ -298,8 +301,15 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     for (int k = 0; k < W; k++) {
                         const uint32_t e = base + 64u * k + lane;
                         valid[k] = e < n_q1;
-                        const uint2 ent = valid[k] ? q1[e] : make_uint2(0u, 0u);
-                        w[k] = ent.x; pos[k] = ent.y & 1023u; nb[k] = ent.y >> 16;      // nb = previous two bytes
+                        pos[k] = valid[k] ? (uint32_t)q1[e] : 0u;
+                        // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on
+                        // top), nb = the two before it, nearest in bits 0-7
+                        const uint32_t a = 11u + pos[k], sh = a & 3u;
+                        const uint32_t* sp = reinterpret_cast<const uint32_t*>(stage + (a & ~3u));
+                        const uint32_t x0 = sp[0], x1 = sp[1], x2 = sp[2];
+                        const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
+                        nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
+                        w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
                         const uint64_t gpos = c0 + pos[k];
                         avail[k] = gpos - hs0 + 1;
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 #pragma unroll
                     for (int k = 0; k < W; k++) {
                         const uint64_t m = __ballot(defer[k]);
-                        if (defer[k]) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = (ci << 10) | pos[k];
+                        if (defer[k]) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = (uint16_t)((ci << 10) | pos[k]);
                         q2_tail += (uint32_t)__popcll(m);
                     }
                 };
@@ -442,16 +452,16 @@ hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record
 }
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
-size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint2) + kSfQ2 * sizeof(uint32_t)); }
+size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
 
-template <bool IC, int MODE, int ILP, bool NT, bool SHORT>
+template <bool IC, int MODE, int ILP, int LW, bool SHORT>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const size_t lds = sf_lds_bytes(s);
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, NT, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
@@ -462,7 +472,7 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, NT, SHORT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
+    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
     return hipGetLastError();
 }
 
@@ -477,22 +487,14 @@ hipError_t read_sf_phase_cycles(uint64_t* out5)
     return e;
 }
 
-// tuning variant: AM_SF_VARIANT = ilp * 10 + nt; default 20
-static int sf_variant()
-{
-    static int v = [] { const char* e = std::getenv("AM_SF_VARIANT"); return e ? std::atoi(e) : 20; }();
-    return v;
-}
-
 template <bool IC, int MODE>
 static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
-    if (s.tiers & 7u) return launch_sf_v<IC, MODE, 2, false, true>(s, b, o, n_cu, st);     // needles shorter than 4 bytes present
-    switch (sf_variant()) {
-        case 10: return launch_sf_v<IC, MODE, 1, false, false>(s, b, o, n_cu, st);
-        case 21: return launch_sf_v<IC, MODE, 2, true, false>(s, b, o, n_cu, st);
-        default: return launch_sf_v<IC, MODE, 2, false, false>(s, b, o, n_cu, st);
+    const bool lw15 = s.bloom_log2_words == 15;
+    if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
+        return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
+    return lw15 ? launch_sf_v<IC, MODE, 2, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
 }
 
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o_in, int n_cu, hipStream_t st)

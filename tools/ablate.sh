@@ -2,7 +2,7 @@
 # timing experiment: AM_SF_ABLATE 0 = full, 1 = filter+compaction only, 2 = + haystack 8B load, 3 = + table entry load
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for a in $1; do
-  AM_SF_ABLATE=$a AM_SF_VARIANT=${2:-10} timeout 300 python $R/bench.py --hay-count 4096 --steps 3 --no-cpu-baseline 2>&1 | grep '^{' | python -c "
+  AM_SF_ABLATE=$a timeout 300 python $R/bench.py --hay-count 4096 --steps 3 --no-cpu-baseline 2>&1 | grep '^{' | python -c "
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); r = d['roofline']
