@@ -67,6 +67,16 @@ def needles_for(workload):
     return ns
 
 
+def replacer_pairs(workload):
+    """(needle, replacement) pairs of a Replacer workload (BASELINE config 5): the workload's needles, each with a
+    replacement of 0-16 upper-case letters -- an alphabet disjoint from the needles', so passes terminate quickly."""
+    w = WORKLOADS[workload]
+    needles = make_needles(w["n_needles"], w["mixed"], seed=NEEDLE_SEED + 5)
+    rng = np.random.default_rng(5)
+    repls = ["".join(chr(ord("A") + int(x)) for x in rng.integers(0, 26, size=int(rng.integers(0, 17)))) for _ in needles]
+    return list(zip(needles, repls))
+
+
 _lib = None
 
 

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--hay-count", type=int, default=0, help="override the number of haystacks per GPU (smaller runs)")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general AC kernel, 2 suffix-filter kernel")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (rank 0, N=1)")
+    ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores leg of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,6 +67,8 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     w = synth.WORKLOADS[args.workload]
+    if "replacer" in args.workload:
+        return bench_replacer(args, w, rank, world, dev)
     case = w["case"]
     n_hay = args.hay_count or w["n_hay"]
     hay_cells = w["hay_bytes"] // synth.CELL
@@ -193,6 +196,130 @@ def main():
         dist.destroy_process_group()
 
 
+def bench_replacer(args, w, rank, world, dev):
+    """--workload cfg5_replacer_50k_1GiB (BASELINE.json configs[4]): one step = Replacer.run over the whole batch,
+    every pass on the device (am_replacer_run_batch), results on the host as the ABI returns them.  Every rank
+    builds the same Replacer (0.4 s) and rewrites its own shard of haystacks; no collective on the data path."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import alfred_margaret_amd as am
+    from alfred_margaret_amd import dist as amdist
+    from alfred_margaret_amd import synth
+    lib = am.api.libam()
+    case = w["case"]
+    n_hay = args.hay_count or w["n_hay"]
+    hay_cells = w["hay_bytes"] // synth.CELL
+    pairs = synth.replacer_pairs(args.workload)
+    t0 = time.time()
+    rep = am.Replacer(case, pairs)
+    rdev = C.c_void_p(rep.device)
+    build_s = time.time() - t0
+    n_cells = n_hay * hay_cells
+    needles = [p[0] for p in pairs]
+    text, n_bytes = synth.haystacks_device(needles, w["mixed"], rank * n_cells, n_cells, dev)
+    offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * w["hay_bytes"]
+    batch = C.c_void_p()
+    am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(batch)))
+    last = {}
+
+    def step():
+        res = C.c_void_p()
+        am.api.check(lib.am_replacer_run_batch(rdev, batch, C.c_uint64(2**64 - 1), C.byref(res)))
+        if "res" in last:
+            lib.am_replaced_free(last["res"])
+        last["res"] = res
+        return int(lib.am_replaced_passes(res)), int(lib.am_replaced_scanned_bytes(res))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        passes, scanned = step()
+    fence()
+    elapsed = amdist.allreduce_max(time.perf_counter() - t0, dev)
+    am.api.check(lib.am_profile_enable(0))
+    prof = {}
+    for k in (b"sf", b"ac", b"rp_pass", b"rp_splice", b"rp_scans", b"permute"):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        am.api.check(lib.am_profile_read(k, C.byref(ms), C.byref(n)))
+        prof[k.decode()] = (ms.value, int(n.value))
+    total_scanned = amdist.allreduce_sum([scanned], dev)[0]
+    if rank == 0:
+        kname = "sf" if prof["sf"][1] else "ac"
+        avg_ms = prof[kname][0] / max(prof[kname][1], 1)
+        alg_bytes = scanned * args.steps / max(prof[kname][1], 1)          # haystack bytes one scan launch reads (records: < 1 %)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "GiB/s of input rewritten by Replacer.run (50k pairs, all passes)", "value": round(n_bytes * world / float(1 << 30) * args.steps / elapsed, 3),
+            "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": args.workload, "n_pairs": len(pairs), "case": "IgnoreCase" if case else "CaseSensitive", "haystacks_per_gpu": n_hay,
+                       "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": n_bytes, "parallelism": "haystack-sharded x%d" % world, "build_s": round(build_s, 2)},
+            "passes": passes, "scanned_gib_per_step": round(total_scanned / float(1 << 30), 2),
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]},
+            "roofline": {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": prof[kname][1],
+                         "alg_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            host = text[:min(n_bytes, 64 * w["hay_bytes"])].cpu().numpy()
+            orc = oracle.Replacer(case, pairs)
+            k, spent, ok = 0, 0.0, True
+            while spent < args.cpu_seconds and k < min(n_hay, 64):
+                hay = bytes(host[k * w["hay_bytes"]:(k + 1) * w["hay_bytes"]])
+                t1 = time.perf_counter(); exp = orc.run(hay); spent += time.perf_counter() - t1
+                p, n = C.c_void_p(), C.c_size_t(0)
+                just = lib.am_replaced_get(last["res"], k, C.byref(p), C.byref(n))
+                ok = ok and just == 1 and C.string_at(p, n.value) == exp
+                k += 1
+            if not ok:
+                raise SystemExit("PARITY FAILURE: device Replacer output differs from the oracle on the CPU-baseline sample")
+            out["cpu_baseline"] = {"value": round(k * w["hay_bytes"] / float(1 << 30) / spent, 6), "unit": "GiB/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d haystacks (%d KiB) of the same workload; outputs identical to the device's" % (k, k * w["hay_bytes"] >> 10)}
+        print(json.dumps(out), flush=True)
+    lib.am_replaced_free(last["res"])
+    lib.am_batch_destroy(batch)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def host_cores():
+    """Cores this process may actually use: the affinity mask, cut down to the cgroup CPU quota if there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, -(-int(parts[0]) // int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = int(f.read().split()[0])
+                if quota > 0:
+                    n = min(n, max(1, -(-quota // period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib):
     """The oracle (C restatement of the reference algorithm, 1 thread) on a bounded sample of the SAME
     workload: haystacks 0..k-1 of rank 0's shard, as many as fit the time budget.  Also a parity spot
@@ -218,8 +345,24 @@ def cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib):
     parity = [int(c) for c in gpu_counts[:k]] == counts
     if not parity:
         raise SystemExit("PARITY FAILURE: GPU counts differ from the oracle on the CPU-baseline sample")
-    return {"value": round(scanned / float(1 << 30) / spent, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
-            "sample": "first %d haystacks (%d MiB) of the same workload, run only; oracle build %.2fs; GPU counts on the sample identical" % (k, scanned >> 20, build_s)}
+    out = {"value": round(scanned / float(1 << 30) / spent, 5), "unit": "GiB/s", "cores": 1, "kind": "port",
+           "sample": "first %d haystacks (%d MiB) of the same workload, run only; oracle build %.2fs; GPU counts on the sample identical" % (k, scanned >> 20, build_s)}
+    # the same oracle on every host core of the box, one haystack per task (ctypes releases the GIL)
+    threads = min(host_cores(), 256)
+    if threads > 1 and not args.no_cpu_all_cores:
+        from concurrent.futures import ThreadPoolExecutor
+        per_hay = spent / max(k, 1)
+        n_tasks = min(n_hay, 1024, max(threads, int(threads * min(args.cpu_seconds, 10.0) / max(per_hay, 1e-6))))
+        hays = [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells) for i in range(n_tasks)]
+        with ThreadPoolExecutor(threads) as pool:
+            t1 = time.perf_counter()
+            mt_counts = list(pool.map(lambda h: o.count_matches(case, h), hays))
+            mt_s = time.perf_counter() - t1
+        if [int(c) for c in gpu_counts[:n_tasks]] != mt_counts:
+            raise SystemExit("PARITY FAILURE: GPU counts differ from the oracle on the all-cores CPU sample")
+        out["all_cores"] = {"value": round(sum(h.size for h in hays) / float(1 << 30) / mt_s, 4), "unit": "GiB/s", "cores": threads,
+                            "sample": "%d haystacks (%d MiB), one per task" % (n_tasks, sum(h.size for h in hays) >> 20)}
+    return out
 
 
 if __name__ == "__main__":

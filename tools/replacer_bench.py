@@ -28,7 +28,7 @@ lib = am.api.libam()
 rng = np.random.default_rng(5)
 needles = synth.make_needles(args.pairs, bool(args.case), seed=synth.NEEDLE_SEED + 5)
 repls = ["".join(chr(ord("A") + int(x)) for x in rng.integers(0, 26, size=int(rng.integers(0, 17)))) for _ in needles]
-pairs = list(zip(needles, repls))
+pairs = list(zip(needles, repls))       # = synth.replacer_pairs("cfg5_replacer_50k_1GiB") for the default arguments
 t0 = time.perf_counter(); r = am.Replacer(args.case, pairs); rdev = C.c_void_p(r.device); build_s = time.perf_counter() - t0
 
 cells = args.hay_kib
