@@ -403,3 +403,59 @@ def test_serialised_image_round_trip(tmp_path):
         with pytest.raises(am.AmError) as e:
             b.run_records(1 - case, hays)          # an image serves its own case mode only
         assert e.value.code == am.AM_ERR_UNSUPPORTED
+
+
+def _soak_case(rng):
+    """Mid-sized adversarial automaton + ragged batch: long needles sharing prefixes/suffixes, needles that are
+    substrings of others, every UTF-8 length, case variants, planted needles and near misses."""
+    letters = "abcdeABCDE0 " + "äÄßẞéÉσΣςяЯİKÅ" + "𝄞💩"
+    stems = ["".join(rng.choice(letters) for _ in range(rng.randint(1, 12))) for _ in range(40)]
+    needles = set()
+    while len(needles) < 1500:
+        n = "".join(rng.choice(stems) for _ in range(rng.randint(1, 4)))
+        cut = rng.random()
+        if cut < 0.3:
+            n = n[rng.randint(0, len(n) - 1):]            # proper suffixes of other needles
+        elif cut < 0.5:
+            n = n[:rng.randint(1, len(n))]                # prefixes
+        if n:
+            needles.add(n[:60])
+    needles = sorted(needles)
+    rng.shuffle(needles)
+    needles += [needles[3], needles[7]]                   # duplicates: value order
+    hays = []
+    for _ in range(rng.randint(20, 40)):
+        parts, size = [], rng.choice((0, 1, 7, 300, 5000, 60000))
+        while sum(len(p) for p in parts) < size:
+            r = rng.random()
+            if r < 0.35:
+                parts.append(rng.choice(needles))
+            elif r < 0.55:
+                n = rng.choice(needles)
+                i = rng.randrange(len(n))
+                parts.append(n[:i] + rng.choice(letters) + n[i + 1:])       # near miss
+            elif r < 0.75:
+                parts.append(rng.choice(needles).swapcase())
+            else:
+                parts.append("".join(rng.choice(letters) for _ in range(rng.randint(1, 30))))
+        hays.append("".join(parts))
+    return needles, hays
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_soak_random_automata(seed):
+    rng = random.Random(9000 + seed)
+    needles, hays = _soak_case(rng)
+    for case in (0, 1):
+        ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+        o = oracle.Machine(ns)
+        a = am.Automaton(ns)
+        exp = oracle_triples(o, case, hays)
+        assert len(exp) > 1000
+        recs = a.run_records(case, hays)
+        assert expand_records(o.values_off(), o.values(), recs["haystack"], recs["state"], recs["end_pos"]) == exp
+        assert [int(c) for c in a.count_matches(case, hays)] == [o.count_matches(case, h) for h in hays]
+        assert [bool(x) for x in am.Searcher(case, ns).contains_any_batch(hays)] == [o.contains_any(case, h) for h in hays]
+        a.set_kernel(1)                                       # the general kernel must agree as well
+        recs_ac = a.run_records(case, hays)
+        assert np.array_equal(recs_ac, recs)
