@@ -13,6 +13,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "am_device.h"
@@ -315,25 +316,68 @@ extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out
     }
     const uint64_t total = offs[n_hay];
     const size_t padded = (size_t)((total + 15) & ~15ull) + 16;
-    // gather the slices into a pinned staging buffer (kept for the next call) so that the H2D copy is one DMA
-    static std::mutex stage_mu;
-    static uint8_t* stage = nullptr;
-    static size_t stage_cap = 0;
-    std::lock_guard<std::mutex> stage_lk(stage_mu);
-    if (padded > stage_cap) {
-        if (stage) { (void)hipHostFree(stage); stage = nullptr; stage_cap = 0; }
-        const size_t want = padded + padded / 4;
-        if (hipHostMalloc((void**)&stage, want, hipHostMallocDefault) != hipSuccess) { stage = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc(staging) failed"); }
-        stage_cap = want;
-    }
-    for (size_t i = 0; i < n_hay; i++) if (hay[i].len) std::memcpy(stage + offs[i], hay[i].ptr + hay[i].off, hay[i].len);
-    std::memset(stage + total, 0, padded - (size_t)total);
     am_batch* b = new am_batch();
     b->owns = true; b->total = total; b->n_hay = (uint32_t)n_hay;
     hipError_t e = hipMalloc(&b->d_text, padded);
     if (e == hipSuccess) e = hipMalloc((void**)&b->d_offsets, offs.size() * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemcpy(b->d_text, stage, padded, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(b->d_offsets, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && total == 0) { e = hipMemset(b->d_text, 0, padded); if (e == hipSuccess) e = hipStreamSynchronize(nullptr); }
+    // The slices are gathered piece by piece (several threads) into two pinned staging buffers that take turns:
+    // while the DMA engine uploads one piece, the host fills the other.  The buffers stay for the next call.
+    if (e == hipSuccess && total > 0) {
+        static std::mutex stage_mu;
+        static uint8_t* stage[2] = {nullptr, nullptr};
+        static hipStream_t copy_stream = nullptr;
+        static hipEvent_t done[2] = {nullptr, nullptr};
+        constexpr size_t kPiece = 32u << 20;
+        std::lock_guard<std::mutex> stage_lk(stage_mu);
+        if (!stage[0]) {
+            if (hipHostMalloc((void**)&stage[0], kPiece, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&stage[1], kPiece, hipHostMallocDefault) != hipSuccess ||
+                hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&done[0]) != hipSuccess || hipEventCreate(&done[1]) != hipSuccess) {
+                if (stage[0]) (void)hipHostFree(stage[0]);
+                if (stage[1]) (void)hipHostFree(stage[1]);
+                stage[0] = stage[1] = nullptr;
+                am_batch_destroy(b);
+                return fail(AM_ERR_OOM, "pinned staging buffers / copy stream could not be created");
+            }
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned n_threads = std::max(1u, std::min(8u, hw ? hw : 1u));
+        // copies bytes [lo, hi) of the concatenated batch into dst
+        auto gather = [&](uint64_t lo, uint64_t hi, uint8_t* dst) {
+            size_t i = (size_t)(std::upper_bound(offs.begin(), offs.end(), lo) - offs.begin()) - 1;
+            uint64_t at = lo;
+            while (at < hi) {
+                while (offs[i + 1] <= at) i++;
+                const uint64_t stop = std::min<uint64_t>(hi, offs[i + 1]);
+                std::memcpy(dst + (at - lo), hay[i].ptr + hay[i].off + (at - offs[i]), (size_t)(stop - at));
+                at = stop;
+            }
+        };
+        bool used[2] = {false, false};
+        int turn = 0;
+        for (uint64_t lo = 0; lo < total && e == hipSuccess; lo += kPiece, turn ^= 1) {
+            const uint64_t hi = std::min<uint64_t>(total, lo + kPiece);
+            if (used[turn]) e = hipEventSynchronize(done[turn]);          // the previous upload out of this buffer has finished
+            if (e != hipSuccess) break;
+            const uint64_t len = hi - lo;
+            if (n_threads == 1 || len < (4u << 20)) gather(lo, hi, stage[turn]);
+            else {
+                std::vector<std::thread> pool;
+                const uint64_t step = (len + n_threads - 1) / n_threads;
+                for (unsigned t = 0; t < n_threads; t++) {
+                    const uint64_t a = lo + t * step, z = std::min<uint64_t>(hi, a + step);
+                    if (a < z) pool.emplace_back(gather, a, z, stage[turn] + (a - lo));
+                }
+                for (auto& th : pool) th.join();
+            }
+            e = hipMemcpyAsync((uint8_t*)b->d_text + lo, stage[turn], (size_t)len, hipMemcpyHostToDevice, copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(done[turn], copy_stream);
+            used[turn] = true;
+        }
+        if (e == hipSuccess) e = hipMemsetAsync((uint8_t*)b->d_text + total, 0, padded - (size_t)total, copy_stream);    // zero tail: kernels read whole 16-byte groups
+        if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
+    }
     int rc = e == hipSuccess ? finish_batch(b) : fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e));
     if (rc != AM_OK) { am_batch_destroy(b); return rc; }
     *out = b;
