@@ -150,6 +150,7 @@ struct am_batch {
     bool owns = false;
     uint64_t total = 0; uint32_t n_hay = 0;
     std::mutex mu;              // guards the workspaces below (calls on one batch serialise)
+    DevBuf text_buf, offs_buf;  // backing store of d_text / d_offsets when the batch owns them
     DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
 };
 
@@ -302,10 +303,9 @@ static int finish_batch(am_batch* b)
     return AM_OK;
 }
 
-extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out)
+// Uploads the slices into `b` (re-using its device buffers when they are large enough).
+static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b)
 {
-    if (!out) return fail(AM_ERR_INVALID, "out is null");
-    *out = nullptr;
     if (n_hay && !hay) return fail(AM_ERR_INVALID, "hay is null");
     if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
     AM_TRY(ensure_device());
@@ -316,11 +316,11 @@ extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out
     }
     const uint64_t total = offs[n_hay];
     const size_t padded = (size_t)((total + 15) & ~15ull) + 16;
-    am_batch* b = new am_batch();
+    AM_TRY(b->text_buf.ensure(padded));
+    AM_TRY(b->offs_buf.ensure(offs.size() * sizeof(uint64_t)));
     b->owns = true; b->total = total; b->n_hay = (uint32_t)n_hay;
-    hipError_t e = hipMalloc(&b->d_text, padded);
-    if (e == hipSuccess) e = hipMalloc((void**)&b->d_offsets, offs.size() * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMemcpy(b->d_offsets, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    b->d_text = b->text_buf.p; b->d_offsets = (uint64_t*)b->offs_buf.p;
+    hipError_t e = hipMemcpy(b->d_offsets, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e == hipSuccess && total == 0) { e = hipMemset(b->d_text, 0, padded); if (e == hipSuccess) e = hipStreamSynchronize(nullptr); }
     // The slices are gathered piece by piece (several threads) into two pinned staging buffers that take turns:
     // while the DMA engine uploads one piece, the host fills the other.  The buffers stay for the next call.
@@ -337,7 +337,6 @@ extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out
                 if (stage[0]) (void)hipHostFree(stage[0]);
                 if (stage[1]) (void)hipHostFree(stage[1]);
                 stage[0] = stage[1] = nullptr;
-                am_batch_destroy(b);
                 return fail(AM_ERR_OOM, "pinned staging buffers / copy stream could not be created");
             }
         }
@@ -378,11 +377,37 @@ extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out
         if (e == hipSuccess) e = hipMemsetAsync((uint8_t*)b->d_text + total, 0, padded - (size_t)total, copy_stream);    // zero tail: kernels read whole 16-byte groups
         if (e == hipSuccess) e = hipStreamSynchronize(copy_stream);
     }
-    int rc = e == hipSuccess ? finish_batch(b) : fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(e));
+    return finish_batch(b);
+}
+
+extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    am_batch* b = new am_batch();
+    const int rc = upload_slices(hay, n_hay, b);
     if (rc != AM_OK) { am_batch_destroy(b); return rc; }
     *out = b;
     return AM_OK;
 }
+
+// One-shot entry points keep one batch object (device text + workspaces) between calls, so that a caller that scans
+// one document per call does not pay a dozen hipMalloc/hipFree each time.  Anything larger than 256 MiB is let go.
+namespace {
+struct OneShot {
+    std::mutex mu;
+    am_batch* b = nullptr;
+    am_batch* get() { if (!b) b = new am_batch(); return b; }
+    void trim()
+    {
+        if (!b) return;
+        size_t held = b->text_buf.cap + b->pool.cap + b->hidx.cap + b->unit_offsets.cap + b->hay_counts.cap;
+        if (held > (256ull << 20)) { am_batch_destroy(b); b = nullptr; }
+    }
+};
+OneShot g_oneshot;
+}  // namespace
 
 extern "C" int am_batch_from_device(const void* d_bytes, const void* d_offsets, size_t n_hay, uint64_t total_bytes, am_batch** out)
 {
@@ -408,8 +433,7 @@ extern "C" int am_batch_from_device(const void* d_bytes, const void* d_offsets, 
 extern "C" void am_batch_destroy(am_batch* b)
 {
     if (!b) return;
-    if (b->owns) { if (b->d_text) (void)hipFree(b->d_text); if (b->d_offsets) (void)hipFree(b->d_offsets); }
-    for (DevBuf* d : {&b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next}) d->release();
+    for (DevBuf* d : {&b->text_buf, &b->offs_buf, &b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next}) d->release();
     delete b;
 }
 
@@ -616,28 +640,31 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
 extern "C" int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out)
 {
     if (n_hay && !counts_out) return fail(AM_ERR_INVALID, "counts_out is null");
-    am_batch* b = nullptr;
-    AM_TRY(am_batch_upload(hay, n_hay, &b));
-    int rc = am_count_batch(a, case_mode, b, counts_out, nullptr);
-    am_batch_destroy(b);
+    std::lock_guard<std::mutex> lk(g_oneshot.mu);
+    am_batch* b = g_oneshot.get();
+    int rc = upload_slices(hay, n_hay, b);
+    if (rc == AM_OK) rc = am_count_batch(a, case_mode, b, counts_out, nullptr);
+    g_oneshot.trim();
     return rc;
 }
 
 extern "C" int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out)
 {
-    am_batch* b = nullptr;
-    AM_TRY(am_batch_upload(hay, n_hay, &b));
-    int rc = am_contains_any_batch(a, case_mode, b, flags_out);
-    am_batch_destroy(b);
+    std::lock_guard<std::mutex> lk(g_oneshot.mu);
+    am_batch* b = g_oneshot.get();
+    int rc = upload_slices(hay, n_hay, b);
+    if (rc == AM_OK) rc = am_contains_any_batch(a, case_mode, b, flags_out);
+    g_oneshot.trim();
     return rc;
 }
 
 extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out)
 {
-    am_batch* b = nullptr;
-    AM_TRY(am_batch_upload(hay, n_hay, &b));
-    int rc = am_run_batch(a, case_mode, b, out);
-    am_batch_destroy(b);
+    std::lock_guard<std::mutex> lk(g_oneshot.mu);
+    am_batch* b = g_oneshot.get();
+    int rc = upload_slices(hay, n_hay, b);
+    if (rc == AM_OK) rc = am_run_batch(a, case_mode, b, out);
+    g_oneshot.trim();
     return rc;
 }
 

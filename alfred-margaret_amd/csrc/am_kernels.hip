@@ -133,6 +133,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     // ---- phase 2: resolve the oldest `nb` (<= 64 * RN) deferred items, RN per lane in lock step (all
     // belong to the current unit).  Item j of the batch sits in lane j % 64, slot j / 64, so ranks by
     // (slot, lane) reproduce the FIFO = position order.
+    uint32_t cnt_hay = kNone; uint64_t cnt_val = 0;          // count mode: running per-haystack sum of this wave
+    auto flush_count = [&]() {
+        if (cnt_hay != kNone && cnt_val && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + cnt_hay), (unsigned long long)cnt_val);
+        cnt_val = 0;
+    };
     constexpr int RN = 1;      // 2 halves the number of latency chains but spills registers (measured: 2x slower overall)
     auto resolve_batch = [&](uint32_t nb) {
         uint64_t gpos[RN], end_pos[RN];
@@ -160,9 +165,16 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         for (int k = 0; k < RN; k++) {
             const uint64_t found_mask = __ballot(found[k]);
             if (MODE == kModeCount) {
-                if (found[k]) {
-                    nval += vlen[k];
-                    if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)vlen[k]);
+                if (found[k]) nval += vlen[k];
+                if (o.hay_counts && found_mask) {
+                    // per-haystack counts: a batch almost always lies inside one haystack, then the wave adds its sum to a
+                    // running (haystack, count) pair that is flushed with ONE atomic when the haystack changes
+                    const uint32_t h0 = __shfl(hay[k], __ffsll((unsigned long long)found_mask) - 1, 64);
+                    if (__ballot(found[k] && hay[k] != h0) == 0) {
+                        const uint64_t sum = wave_sum_u64(found[k] ? (uint64_t)vlen[k] : 0ull);
+                        if (h0 != cnt_hay) { flush_count(); cnt_hay = h0; }
+                        cnt_val += sum;
+                    } else if (found[k]) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)vlen[k]);
                 }
             } else if (MODE == kModeEmit) {
                 const uint32_t F = (uint32_t)__popcll(found_mask);
@@ -358,6 +370,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     }
 
     if (MODE == kModeCount) {
+        if (o.hay_counts) flush_count();
         nval = wave_sum_u64(nval);
         if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
     }
