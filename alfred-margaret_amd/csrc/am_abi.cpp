@@ -282,7 +282,7 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
     ImageHeader h;
     std::memcpy(&h, image, sizeof(h));
     if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image (magic, version or section bounds)");
-    if (image_checksum((const uint8_t*)image + sizeof(h), (size_t)h.total_bytes - sizeof(h)) != h.reserved[0]) return fail(AM_ERR_INVALID, "automaton image is corrupt (checksum)");
+    if (image_checksum((const uint8_t*)image + sizeof(h), (size_t)h.total_bytes - sizeof(h)) != h.checksum) return fail(AM_ERR_INVALID, "automaton image is corrupt (checksum)");
     AM_TRY(ensure_device());
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, h.total_bytes));

@@ -179,6 +179,28 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     std::memcpy(blob.bytes.data() + h.off_root_ascii, ref.root_ascii, 128 * 8);
     h.off_canon = blob.put(canon);
     h.off_vlen = blob.put(vlen);
+    {
+        // goto hash + fallback array: what the kernel walks instead of the reference's per-state edge lists
+        uint64_t n_edges = ref.n_transitions >= S ? ref.n_transitions - S : 0;
+        uint32_t lc = 4;
+        while ((1ull << lc) < 2 * n_edges + 8) lc++;
+        if (lc > 31) { err = "automaton too large for the goto table"; return -1; }
+        std::vector<u32x4> tab((size_t)1 << lc, u32x4{0, 0, 0, 0});
+        std::vector<uint32_t> fail(S, 0);
+        const uint32_t mask = (1u << lc) - 1u;
+        for (uint32_t st = 0; st < (uint32_t)S; st++) {
+            for (uint64_t i = ref.offsets[st];; i++) {
+                const uint64_t t = ref.transitions[i];
+                if (t & kWildcard) { fail[st] = (uint32_t)(t >> 32); break; }
+                uint32_t slot = ac_goto_slot(st, (uint32_t)(t & 0x1fffffu), lc);
+                while (tab[slot].w) slot = (slot + 1u) & mask;
+                tab[slot] = u32x4{st, (uint32_t)(t & 0x1fffffu), (uint32_t)(t >> 32), 1u};
+            }
+        }
+        h.ac_goto_log2_cap = lc;
+        h.off_goto = blob.put(tab);
+        h.off_fail = blob.put(fail);
+    }
     if (ic) {
         const uint32_t n_lower = (kLower[kNLower - 1].from + 256u) & ~255u;
         std::vector<int32_t> delta(n_lower, 0);
@@ -491,7 +513,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     h.off_edges = blob.put(edges_out);
     blob.reserve_section(16);      // tail padding
     h.total_bytes = blob.bytes.size();
-    h.reserved[0] = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
+    h.checksum = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
     std::memcpy(blob.bytes.data(), &h, sizeof(h));
     image.swap(blob.bytes);
     return 0;
@@ -513,7 +535,8 @@ bool image_sections_in_bounds(const ImageHeader& h)
     auto ok = [T](uint64_t off, uint64_t count, uint64_t elem) { return off <= T && count <= (T - off) / elem; };
     if (h.magic != kImageMagic || h.version != kImageVersion || h.case_mode > 1 || T < sizeof(ImageHeader)) return false;
     bool good = ok(h.off_transitions, h.n_transitions, 8) && ok(h.off_offsets, (uint64_t)h.n_states + 1, 4) && ok(h.off_root_ascii, 128, 8) &&
-                ok(h.off_canon, h.n_states, 4) && ok(h.off_vlen, h.n_states, 4) && ok(h.off_lower, h.n_lower, 4);
+                ok(h.off_canon, h.n_states, 4) && ok(h.off_vlen, h.n_states, 4) && ok(h.off_lower, h.n_lower, 4) &&
+                h.ac_goto_log2_cap >= 4 && h.ac_goto_log2_cap <= 31 && ok(h.off_goto, 1ull << h.ac_goto_log2_cap, 16) && ok(h.off_fail, h.n_states, 4);
     if (h.sf_enabled) {
         if (h.sf_bloom_log2_words > 20) return false;
         good = good && ok(h.off_bloom, 1ull << h.sf_bloom_log2_words, 4) && ok(h.off_nodes, h.sf_n_nodes, 32) && ok(h.off_edges, h.n_edges, 32);

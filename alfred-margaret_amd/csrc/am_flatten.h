@@ -21,7 +21,7 @@ struct RefArrays {
 
 int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err);
 
-// ImageHeader::reserved[0]: checksum of everything after the header (checked when an image comes from the host)
+// ImageHeader::checksum: of everything after the header (checked when an image comes from the host)
 uint64_t image_checksum(const uint8_t* p, size_t n);
 // magic / version / every section inside total_bytes
 bool image_sections_in_bounds(const ImageHeader& h);

@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 1;
+constexpr uint32_t kImageVersion = 2;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -55,7 +55,8 @@ struct ImageHeader {
     // SF section
     uint32_t sf_tiers;          // bit t-1 set: some needle variant is exactly t bytes (t=1..3); bit 3: >= 4 bytes
     uint32_t sf_bloom_log2_words;
-    uint32_t sf_n_nodes, sf_pad;
+    uint32_t sf_n_nodes;
+    uint32_t ac_goto_log2_cap;  // AC goto hash: 1 << cap slots
     uint64_t off_bloom;         // u32[1 << sf_bloom_log2_words]
     uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}[1 << cap]; tier 4: hot fingerprint buckets u32x2[1 << cap] (2 slots each)
     uint32_t tier_log2_cap[4];
@@ -63,7 +64,9 @@ struct ImageHeader {
     uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
     uint64_t n_edges;
     uint64_t off_t4_cold;       // cold side of tier 4, 16 B per bucket: the 2 full keys, then the 2 depth-4 node ids (kNone: empty slot)
-    uint64_t reserved[3];
+    uint64_t checksum;          // of everything after the header (checked when an image comes from the host)
+    uint64_t off_goto;          // AC: u32x4{state, cp, next, used}[1 << ac_goto_log2_cap], open addressing: (state, cp) -> goto target
+    uint64_t off_fail;          // AC: u32[n_states] fallback state (the target of each state's wildcard entry)
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -75,6 +78,9 @@ struct AcView {
     const uint32_t* vlen;
     const int32_t* lower;
     uint32_t n_lower, max_needle_cps, chunk, root_vlen;
+    const struct u32x4* goto_tab;   // (state, cp) -> next, see ImageHeader::off_goto
+    const uint32_t* fail;
+    uint32_t goto_log2_cap;
 };
 
 struct alignas(8) u32x2 { uint32_t x, y; };
@@ -134,6 +140,7 @@ inline AcView make_ac_view(const void* base, const ImageHeader& h)
     v.vlen = (const uint32_t*)(b + h.off_vlen);
     v.lower = (const int32_t*)(b + h.off_lower);
     v.n_lower = h.n_lower; v.max_needle_cps = h.max_needle_cps; v.chunk = h.ac_chunk; v.root_vlen = h.root_vlen;
+    v.goto_tab = (const u32x4*)(b + h.off_goto); v.fail = (const uint32_t*)(b + h.off_fail); v.goto_log2_cap = h.ac_goto_log2_cap;
     return v;
 }
 
@@ -618,10 +625,21 @@ AM_HD uint32_t lower_cp(const AcView& a, uint32_t cp)
     return cp < a.n_lower ? (uint32_t)((int32_t)cp + a.lower[cp]) : cp;
 }
 
+// slot of (state, cp) in the AC goto hash (flattener and kernels must agree)
+AM_HD uint32_t ac_goto_slot(uint32_t state, uint32_t cp, uint32_t log2_cap)
+{
+    uint32_t h = state * 0x9E3779B1u ^ cp * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    return (h * 0x2C1B3C6Du) >> (32u - log2_cap);
+}
+
 // Automaton.hs:482-520 followCodePoint / lookupTransition / lookupRootAsciiTransition.
 // Returns true iff a goto edge was taken (then collectMatches applies to the new state).
+// The reference scans the state's edge list linearly (:489-510); the image answers the same question
+// "(state, cp) -> goto target or none" with one hash probe, and the wildcard entry's target is fail[state].
 AM_HD bool ac_step(const AcView& a, uint32_t& state, uint32_t cp)
 {
+    const uint32_t mask = (1u << a.goto_log2_cap) - 1u;
     for (;;) {
         if (state == 0 && cp < 128u) {
             const uint64_t t = a.root_ascii[cp];
@@ -629,17 +647,15 @@ AM_HD bool ac_step(const AcView& a, uint32_t& state, uint32_t cp)
             state = (uint32_t)(t >> 32);
             return true;
         }
-        uint32_t i = a.offsets[state];
+        uint32_t i = ac_goto_slot(state, cp, a.goto_log2_cap);
         for (;;) {
-            const uint64_t t = a.transitions[i];
-            if (t & kWildcard) {
-                if (state == 0) return false;
-                state = (uint32_t)(t >> 32);
-                break;
-            }
-            if ((uint32_t)(t & 0x1fffffu) == cp) { state = (uint32_t)(t >> 32); return true; }
-            i++;
+            const u32x4 e = load16(a.goto_tab + i);
+            if (e.w == 0u) break;                                       // empty slot: no such edge
+            if (e.x == state && e.y == cp) { state = e.z; return true; }
+            i = (i + 1u) & mask;
         }
+        if (state == 0) return false;                                   // wildcard at the root: next input (:496-497)
+        state = a.fail[state];
     }
 }
 
