@@ -96,7 +96,9 @@ constexpr int kSfStage = 1056;                   // per-wave copy of the current
 // LW: log2 of the filter size in words when it is the usual 128 KiB (15), so that the word address is a
 // constant shift + constant mask (VOP2 with immediates issues at almost twice the rate of anything that
 // reads an SGPR or needs the VOP3 encoding on gfx950, tools/microbench/valu_rates*.hip); 0 = any size
-template <bool IC, int MODE, int ILP, int LW, bool SHORT>
+// DBG: the timing / ablation experiments (AM_SF_ABLATE) live in their own instantiations, the production kernel
+// carries none of their code, registers or branches.
+template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG>
 __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
     __syncthreads();
 
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: unit / chunk arithmetic stays scalar
     uint8_t* stage = stage_all + wave * kSfStage;
     uint16_t* q1 = q1_all + wave * kSfQ1;
     uint16_t* q2 = q2_all + wave * kSfQ2;
@@ -125,7 +127,8 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     bool pool_ok = true;
 
     // optional phase timing (AM_SF_ABLATE>=8): s_memtime deltas per wavefront, summed into o.dbg
-    const bool timing = o.dbg != nullptr;
+    const bool timing = DBG && o.dbg != nullptr;
+    const uint32_t ablate = DBG ? o.ablate : 0u;
     uint64_t t_filter = 0, t_compact = 0, t_probe = 0, t_resolve = 0, t_probe_pre = 0, t_mark = 0;
     uint64_t t_r0 = 0, t_r1 = 0, t_r2 = 0, t_r3 = 0, n_batches = 0;
     auto tick = [&](uint64_t& acc) { if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc += now - t_mark; t_mark = now; } };
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
             uint4 next_v = make_uint4(0, 0, 0, 0); uint2 next_prev = make_uint2(0, 0);
-            if (o.ablate == 8) fetch(c, cur_v, cur_prev);          // timing experiment only: no prefetch, expose HBM latency in the filter phase
+            if (ablate == 8) fetch(c, cur_v, cur_prev);          // timing experiment only: no prefetch, expose HBM latency in the filter phase
             else fetch(ci + 1 < n_in_unit ? c + 1 : (u + n_waves) * UC, next_v, next_prev);
 
             const uint64_t c0 = c * kSfChunk;
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 }
             }
             if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
-            if (o.ablate == 1) cand = 0;               // timing experiment only
+            if (ablate == 1) cand = 0;               // timing experiment only
             if (timing) { asm volatile("" :: "v"(cand)); tick(t_filter); }
 
             for (;;) {
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                     }
                     if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
-                    sf_probe_n<W>(s, w, nb, avail, valid, defer, o.ablate);
+                    sf_probe_n<W>(s, w, nb, avail, valid, defer, ablate);
 #pragma unroll
                     for (int k = 0; k < W; k++) {
                         const uint64_t m = __ballot(defer[k]);
@@ -467,14 +470,14 @@ uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chu
 
 size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
 
-template <bool IC, int MODE, int ILP, int LW, bool SHORT>
+template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const size_t lds = sf_lds_bytes(s);
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
@@ -485,7 +488,7 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
+    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, o, n_chunks);
     return hipGetLastError();
 }
 
@@ -504,6 +507,8 @@ template <bool IC, int MODE>
 static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const bool lw15 = s.bloom_log2_words == 15;
+    if ((o.ablate || o.dbg) && MODE != kModeAny)                                            // experiments (AM_SF_ABLATE)
+        return lw15 && !(s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
     if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
         return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
