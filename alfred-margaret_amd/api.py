@@ -32,6 +32,7 @@ class Slice(C.Structure):          # am_slice
 
 
 MATCH_DTYPE = np.dtype([("end_pos", np.uint64), ("haystack", np.uint32), ("state", np.uint32)])   # am_match
+PRIO_MATCH_DTYPE = np.dtype([("start", np.uint64), ("len", np.uint64), ("haystack", np.uint32), ("payload", np.uint32)])   # am_prio_match
 
 _u8p, _u32p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
 _vp, _sz = C.c_void_p, C.c_size_t
@@ -64,6 +65,8 @@ ABI = {
     "am_replacer_destroy": (None, [_vp]),
     "am_replacer_run": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_uint64, C.POINTER(_vp)]),
     "am_replacer_run_batch": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "am_run_priority": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp, _vp, C.POINTER(_vp), C.POINTER(_sz)]),
+    "am_prio_matches_free": (None, [_vp]),
     "am_replaced_size": (C.c_uint64, [_vp]),
     "am_replaced_get": (C.c_int, [_vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]),
     "am_replaced_passes": (C.c_uint64, [_vp]),
@@ -425,6 +428,20 @@ class Replacer:
         h = _vp()
         _hcheck(libhost().amh_replacer_device(self._h, C.byref(h)))
         return h.value
+
+    def run_priority(self, texts, thresholds):
+        """One pass of the Replacer fold on the device (am_run_priority): (best priority per haystack, selected matches)."""
+        s = _Slices(texts)
+        thr = np.ascontiguousarray(thresholds, dtype=np.int64)
+        best = np.zeros(max(s.n, 1), np.int64)
+        p, n = _vp(), _sz(0)
+        check(libam().am_run_priority(self.device, s.arr, s.n, thr.ctypes.data, best.ctypes.data, C.byref(p), C.byref(n)))
+        try:
+            k = int(n.value)
+            ms = np.frombuffer((C.c_char * (k * PRIO_MATCH_DTYPE.itemsize)).from_address(p.value), dtype=PRIO_MATCH_DTYPE).copy() if k else np.zeros(0, PRIO_MATCH_DTYPE)
+        finally:
+            libam().am_prio_matches_free(p)
+        return best[:s.n], ms
 
     def last_stats(self):
         """(passes, haystack bytes scanned over all passes) of the last run_batch."""

@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -965,7 +966,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)s.records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
         { Prof pr("rp_pass", st);
           HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)s.records.p, (const uint64_t*)s.rec_first.p, cur_thr,
-                                 max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, st)); }
+                                 max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st)); }
         { Prof pr("rp_scans", st);
           HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_next, (uint64_t*)s.off_next.p, n1, st));
           HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_fin, (uint64_t*)s.off_fin.p, n1, st));
@@ -1037,6 +1038,59 @@ extern "C" int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t
     am_batch_destroy(b);
     return rc;
 }
+
+// One pass of the fold only (SURVEY 8b am_run_priority): prependMatch + makeMatch (Replacer.hs:252-274) on the device,
+// sort / removeOverlap / replace stay with the caller.
+static_assert(sizeof(am_prio_match) == sizeof(RpSelected) && offsetof(am_prio_match, haystack) == offsetof(RpSelected, haystack), "am_prio_match layout");
+
+extern "C" int am_run_priority(const am_replacer* r, const am_slice* hay, size_t n_hay, const int64_t* thresholds, int64_t* best_out,
+                               am_prio_match** matches_out, size_t* n_matches_out)
+{
+    if (!matches_out || !n_matches_out) return fail(AM_ERR_INVALID, "out pointers are null");
+    *matches_out = nullptr; *n_matches_out = 0;
+    if (!r) return fail(AM_ERR_INVALID, "null replacer");
+    if (n_hay && (!thresholds || !best_out)) return fail(AM_ERR_INVALID, "thresholds / best_out are null");
+    if (n_hay == 0) return AM_OK;
+    am_batch* b = nullptr;
+    AM_TRY(am_batch_upload(hay, n_hay, &b));
+    std::unique_ptr<am_batch, void (*)(am_batch*)> guard(b, am_batch_destroy);
+    hipStream_t st; AM_TRY(get_stream(&st));
+    const uint32_t n = (uint32_t)n_hay;
+    const uint64_t n1 = (uint64_t)n + 1;
+    DevBuf records, rec_first, kept, hs, nk, off, thr, best, out, tmp;
+    struct Release { std::initializer_list<DevBuf*> l; ~Release() { for (DevBuf* d : l) d->release(); } } rel{{&records, &rec_first, &kept, &hs, &nk, &off, &thr, &best, &out, &tmp}};
+    uint64_t n_rec = 0;
+    auto sink = [&](uint64_t k, Record** ptr) -> int { AM_TRY(records.ensure(k * sizeof(Record))); *ptr = (Record*)records.p; return AM_OK; };
+    AM_TRY(run_records(r->a, r->case_mode, b, sink, &n_rec));
+    AM_TRY(records.ensure(sizeof(Record)));
+    AM_TRY(rec_first.ensure(n1 * 8)); AM_TRY(kept.ensure((n_rec + 1) * sizeof(RpKept))); AM_TRY(hs.ensure(n1 * sizeof(RpHay)));
+    AM_TRY(nk.ensure(n1 * 4)); AM_TRY(off.ensure(n1 * 8)); AM_TRY(thr.ensure(n1 * 8)); AM_TRY(best.ensure(n1 * 8));
+    size_t tmp_bytes = 0;
+    if (scan_temp_bytes(n1, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    AM_TRY(tmp.ensure(tmp_bytes + 16));
+    HIP_TRY(hipMemcpyAsync(thr.p, thresholds, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync((uint32_t*)nk.p + n, 0, 4, st));
+    RpRoute route{nullptr, nullptr, (uint32_t*)nk.p, nullptr, nullptr};
+    HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)rec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, n, st));
+    HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, (const uint8_t*)b->d_text, b->d_offsets, (const Record*)records.p, (const uint64_t*)rec_first.p,
+                           (const int64_t*)thr.p, UINT64_MAX, (RpKept*)kept.p, (RpHay*)hs.p, route, n, 1u, st));
+    HIP_TRY(launch_scan(tmp.p, tmp_bytes, (const uint32_t*)nk.p, (uint64_t*)off.p, n1, st));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)off.p + n, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    AM_TRY(out.ensure((total + 1) * sizeof(RpSelected)));
+    HIP_TRY(launch_rp_gather((const RpHay*)hs.p, (const uint64_t*)rec_first.p, (const RpKept*)kept.p, (const uint64_t*)off.p, (RpSelected*)out.p, (int64_t*)best.p, n, st));
+    am_prio_match* host = (am_prio_match*)std::malloc((total ? total : 1) * sizeof(am_prio_match));
+    if (!host) return fail(AM_ERR_OOM, "malloc(matches) failed");
+    hipError_t e = hipMemcpyAsync(best_out, best.p, (size_t)n * 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && total) e = hipMemcpyAsync(host, out.p, total * sizeof(am_prio_match), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { std::free(host); return fail(AM_ERR_HIP, hipGetErrorString(e)); }
+    *matches_out = host; *n_matches_out = (size_t)total;
+    return AM_OK;
+}
+
+extern "C" void am_prio_matches_free(am_prio_match* m) { std::free(m); }
 
 extern "C" uint64_t am_replaced_size(const am_replaced* r) { return r ? r->text.size() : 0; }
 extern "C" uint64_t am_replaced_passes(const am_replaced* r) { return r ? r->passes : 0; }

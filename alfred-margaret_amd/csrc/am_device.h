@@ -67,7 +67,10 @@ constexpr uint64_t kRpTile = 16384;                      // bytes of new text pe
 hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, uint64_t* out5, hipStream_t st);
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
-                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, hipStream_t st);
+                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st);
+struct RpSelected { uint64_t start, len; uint32_t haystack, payload; };     // = am_prio_match in include/am.h
+hipError_t launch_rp_gather(const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const uint64_t* out_off, RpSelected* out, int64_t* best_out,
+                            uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_route(const RpHay* hs, const RpRouted& rt, const uint32_t* orig, uint32_t n_act, uint64_t* next_offsets, uint32_t* next_orig,
                            int64_t* next_thr, RpFin* fin, hipStream_t st);
 hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64_t* offsets, const uint64_t* rec_first, const RpKept* kept,

@@ -74,7 +74,7 @@ template <bool IC>
 __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets,
                                                  const Record* __restrict__ recs, const uint64_t* __restrict__ rec_first,
                                                  const int64_t* __restrict__ thr, uint64_t max_len, RpKept* __restrict__ kept,
-                                                 RpHay* __restrict__ hs, RpRoute route, uint32_t n_act)
+                                                 RpHay* __restrict__ hs, RpRoute route, uint32_t n_act, uint32_t keep_all)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
@@ -123,8 +123,8 @@ __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __re
             }
             delta_all += delta;
             // removeOverlap (:191-198): in position order keep a match iff it starts at or after the end of the last kept one
-            uint64_t pending = __ballot(sel);
-            bool keep = false;
+            uint64_t pending = keep_all ? 0ull : __ballot(sel);
+            bool keep = keep_all && sel;          // am_run_priority: the caller removes overlaps itself
             while (pending) {
                 const uint64_t ok = __ballot(sel && start >= last_end) & pending;
                 if (!ok) break;
@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __re
     if (lane == 0) {
         RpHay o; o.newlen = newlen; o.best = best; o.status = status; o.nkept = nkept; o.payload = payload; o.pad = 0;
         hs[h] = o;
+        if (keep_all) { route.tiles[h] = nkept; return; }
         route.len_next[h] = status == kRpActive ? newlen : 0;
         route.len_fin[h] = status == kRpFinished ? newlen : 0;
         route.tiles[h] = status == kRpNothing ? 0u : (uint32_t)((newlen + kRpTile - 1) / kRpTile);
@@ -257,11 +258,35 @@ hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, uint64_t* out5, 
 }
 
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
-                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, hipStream_t st)
+                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st)
 {
     const dim3 grid((n_act + 3) / 4), block(256);
-    if (ic) hipLaunchKernelGGL(k_rp_pass<true>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act);
-    else hipLaunchKernelGGL(k_rp_pass<false>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act);
+    if (ic) hipLaunchKernelGGL(k_rp_pass<true>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act, keep_all);
+    else hipLaunchKernelGGL(k_rp_pass<false>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act, keep_all);
+    return hipGetLastError();
+}
+
+// am_run_priority: the selected matches of every haystack, compacted in haystack order
+__global__ void __launch_bounds__(256) k_rp_gather(const RpHay* __restrict__ hs, const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
+                                                   const uint64_t* __restrict__ out_off, RpSelected* __restrict__ out, int64_t* __restrict__ best_out, uint32_t n_act)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_act) return;
+    const RpHay s = hs[h];
+    if (lane == 0) best_out[h] = s.best;
+    const RpKept* K = kept + rec_first[h];
+    for (uint32_t j = lane; j < s.nkept; j += kWave) {
+        RpSelected o; o.start = K[j].src_start; o.len = K[j].src_len; o.haystack = h; o.payload = s.payload;
+        out[out_off[h] + j] = o;
+    }
+}
+
+hipError_t launch_rp_gather(const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const uint64_t* out_off, RpSelected* out, int64_t* best_out,
+                            uint32_t n_act, hipStream_t st)
+{
+    if (n_act == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rp_gather, dim3((n_act + 3) / 4), dim3(256), 0, st, hs, rec_first, kept, out_off, out, best_out, n_act);
     return hipGetLastError();
 }
 

@@ -165,6 +165,20 @@ void am_replacer_destroy(am_replacer* r);
 /* max_length: runWithLimit's maxLength (:203); UINT64_MAX = `run` (:200-201, maxBound). */
 int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out);
 int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);   /* b is not modified */
+/* One pass only, for callers that keep sort / removeOverlap / replace (Replacer.hs:159-198) on their side: the fold
+ * `prependMatch` (:252-260) with seed (minBound, []) and the given threshold per haystack.  best_out[i] = the best
+ * priority below thresholds[i] among the matches of haystack i (INT64_MIN: none); *matches_out = every match that
+ * carries it, as makeMatch (:264-274) builds them (start and length in code units of the haystack), in
+ * (haystack, start) order = the order `sort` (:241) gives them.  Free with am_prio_matches_free. */
+typedef struct am_prio_match {
+    uint64_t start;
+    uint64_t len;
+    uint32_t haystack;
+    uint32_t payload;    /* index into the payload table given to am_replacer_create */
+} am_prio_match;
+int am_run_priority(const am_replacer* r, const am_slice* hay, size_t n_hay, const int64_t* thresholds,
+                    int64_t* best_out, am_prio_match** matches_out, size_t* n_matches_out);
+void am_prio_matches_free(am_prio_match* m);
 uint64_t am_replaced_size(const am_replaced* r);
 /* Returns 1 and the text for `Just`, 0 for `Nothing` (longer than max_length), < 0 on error.  *ptr is owned by r. */
 int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len);

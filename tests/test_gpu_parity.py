@@ -459,3 +459,42 @@ def test_soak_random_automata(seed):
         a.set_kernel(1)                                       # the general kernel must agree as well
         recs_ac = a.run_records(case, hays)
         assert np.array_equal(recs_ac, recs)
+
+
+def test_run_priority_single_pass():
+    """am_run_priority = prependMatch/makeMatch (Replacer.hs:252-274) for one pass, per-haystack thresholds."""
+    rng = random.Random(41)
+    for it in range(12):
+        case = it % 2
+        alphabet = "abAB" if it < 8 else "aikİKß"
+        pairs = [("".join(rng.choice(alphabet) for _ in range(rng.randint(1, 3))), "x" * rng.randint(0, 3)) for _ in range(rng.randint(1, 8))]
+        hays = ["".join(rng.choice(alphabet * 3 + "z") for _ in range(rng.choice((0, 5, 60, 700)))) for _ in range(10)]
+        thresholds = [rng.choice((1, 0, -1, -3, -100)) for _ in hays]
+        r = am.Replacer(case, pairs)
+        best, ms = r.run_priority(hays, thresholds)
+        needles = [oracle.lower_utf8(n).decode() if case else n for n, _ in pairs]
+        o = oracle.Machine(needles)
+        got = [(int(m["haystack"]), int(m["start"]), int(m["len"]), int(m["payload"])) for m in ms]
+        exp, exp_best = [], []
+        for i, h in enumerate(hays):
+            hb = h.encode("utf-8")
+            pos, val = o.run_list(case, h)
+            cands = [(int(p), int(v)) for p, v in zip(pos, val) if -int(v) < thresholds[i]]
+            if not cands:
+                exp_best.append(-2**63)
+                continue
+            b = max(-v for _, v in cands)
+            exp_best.append(b)
+            sel = []
+            for p, v in cands:
+                if -v != b:
+                    continue
+                orig = pairs[v][0]
+                if case == 0:
+                    ln = len(orig.encode("utf-8")); st = p - ln
+                else:
+                    st = oracle.skip_code_points_backwards(hb, p - 1, len(orig) - 1); ln = p - st
+                sel.append((i, st, ln, v))
+            exp += sorted(sel)
+        assert [int(x) for x in best] == exp_best, (case, pairs, thresholds)
+        assert got == exp, (case, pairs)
