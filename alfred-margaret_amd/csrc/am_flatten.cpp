@@ -488,20 +488,20 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             const TierEntry& e = ents[owner[sl]];
             const SfNode& nd = nodes[e.node];
             const uint32_t n_edges = nd.w & 0xFFFFu;
-            uint32_t word = t4_fingerprint(t4_hash_a(e.key), lb) | kT4Occupied;
-            if (nd.x) word |= kT4Terminal;
-            if (n_edges > 1) word |= kT4Multi;
-            if (n_edges == 1) {
-                word |= kT4Single | (((nd.w >> 16) & 0xFFu) << 16);
-                // second required byte: the first skip byte of the edge, or (no skip) the selector of the
-                // child's single edge provided no needle ends at the child
+            // bytes before the 4-byte suffix that every needle through this node fixes (0 when a needle ends here or the
+            // node branches): sel1 = the selector of the single edge; sel2 = the first skip byte of that edge, or (no
+            // skip) the selector of the child's single edge provided no needle ends at the child
+            uint32_t fixed = 0, sel1 = 0, sel2 = 0;
+            if (!nd.x && n_edges == 1) {
+                fixed = 1; sel1 = (nd.w >> 16) & 0xFFu;
                 const uint32_t skip = nd.w >> 24;
-                if (skip >= 1) word |= kT4Single2 | ((nd.label[3] >> 24) << 24);       // walk order byte 0 = last label byte in text order
+                if (skip >= 1) { fixed = 2; sel2 = nd.label[3] >> 24; }       // walk order byte 0 = last label byte in text order
                 else {
                     const SfNode& ch = nodes[nd.z];
-                    if (!ch.x && (ch.w & 0xFFFFu) == 1u) word |= kT4Single2 | (((ch.w >> 16) & 0xFFu) << 24);
+                    if (!ch.x && (ch.w & 0xFFFFu) == 1u) { fixed = 2; sel2 = (ch.w >> 16) & 0xFFu; }
                 }
             }
+            const uint32_t word = t4_slot_word(t4_fingerprint(t4_hash_a(e.key), lb), fixed, sel1, sel2);
             (&hot[sl >> 1].x)[sl & 1] = word;
             (&cold[sl >> 1].x)[sl & 1] = e.key;
             (&cold[sl >> 1].z)[sl & 1] = e.node;

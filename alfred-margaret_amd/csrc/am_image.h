@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 2;
+constexpr uint32_t kImageVersion = 3;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -320,24 +320,27 @@ AM_HD void load_node(const SfNode* p, SfNode& n)
 AM_HD uint32_t t4_hash_a(uint32_t key) { return key * 0x85EBCA6Bu; }
 AM_HD uint32_t t4_hash_b(uint32_t key) { return (key ^ (key >> 15)) * 0xC2B2AE35u; }
 AM_HD uint32_t t4_bucket(uint32_t h, uint32_t log2_buckets) { return h >> (32u - log2_buckets); }
-AM_HD uint32_t t4_fingerprint(uint32_t ha, uint32_t log2_buckets) { return (ha >> (log2_buckets < 21u ? 21u - log2_buckets : 0u)) & 0x7FFu; }
-// hot slot word: fingerprint (bits 0-10) | flags (11-15) | sel1 (16-23) | sel2 (24-31)
-constexpr uint32_t kT4Occupied = 1u << 11;    // slot in use
-constexpr uint32_t kT4Terminal = 1u << 12;    // a 4-byte needle (variant) ends at the depth-4 node
-constexpr uint32_t kT4Single = 1u << 13;      // the node has exactly one outgoing edge; sel1 = its selector byte
-constexpr uint32_t kT4Multi = 1u << 14;       // the node has several outgoing edges
-constexpr uint32_t kT4Single2 = 1u << 15;     // ... and after sel1 the trie is still a plain chain with no needle end: the next byte must be sel2
-
-// can this hot slot word belong to a needle ending at a position whose last 4 bytes hash to `fp` and
-// whose two preceding bytes are nb (nearest) and nb2?  more1 / more2: the haystack has at least 5 / 6
-// bytes up to the position.  Pure bit arithmetic on purpose: the probe must not branch.
-AM_HD uint32_t t4_slot_may_match(uint32_t slot, uint32_t fp, uint32_t nb, uint32_t nb2, uint32_t more1, uint32_t more2)
+AM_HD uint32_t t4_fingerprint(uint32_t ha, uint32_t log2_buckets) { return (ha >> (log2_buckets < 22u ? 22u - log2_buckets : 0u)) & 0x3FFu; }
+// Hot slot word, laid out so that the probe decides a slot with TWO instructions (v_lshl_or + v_bitop3, no compares,
+// no selects -- the VALU is the bottleneck of k_sf):
+//   bits 0-4   k8 = 8 x (number of bytes before the 4-byte suffix that are fixed): 0 when a needle (variant) ends at the
+//              depth-4 node or the node has several outgoing edges; 8 when it has exactly one (sel1 = its selector byte);
+//              16 when after sel1 the trie is still a plain chain without a needle end (the next byte must be sel2)
+//   bits 5-14  fingerprint, bit 15 occupied, bits 16-23 sel1, bits 24-31 sel2 (0 where not fixed)
+// A slot may belong to a needle ending at a position with fingerprint fp and preceding bytes nb (nearest), nb2 iff
+// t4_slot_diff(slot, t4_expect(fp, nb | nb2 << 8)) == 0: the shift by k8 (the hardware reads the low 5 bits of the
+// slot itself as the amount) blanks the selector fields that are not fixed.  Whether those bytes lie inside the
+// haystack is not checked here; phase 2 is exact, a candidate at the very start of a haystack is merely deferred.
+constexpr uint32_t kT4Occupied = 1u << 15;
+AM_HD uint32_t t4_slot_word(uint32_t fp, uint32_t fixed_bytes, uint32_t sel1, uint32_t sel2)
 {
-    const uint32_t fp_ok = (uint32_t)((slot & 0xFFFu) == (kT4Occupied | fp));
-    const uint32_t term = (slot >> 12) & 1u, single = (slot >> 13) & 1u, multi = (slot >> 14) & 1u, single2 = (slot >> 15) & 1u;
-    const uint32_t sel1_ok = (uint32_t)(((slot >> 16) & 0xFFu) == nb), sel2_ok = (uint32_t)((slot >> 24) == nb2);
-    const uint32_t chain = single & sel1_ok & ((single2 ^ 1u) | (more2 & sel2_ok));
-    return fp_ok & (term | (more1 & (multi | chain)));
+    return (8u * fixed_bytes) | (fp << 5) | kT4Occupied | (fixed_bytes >= 1 ? sel1 << 16 : 0u) | (fixed_bytes >= 2 ? sel2 << 24 : 0u);
+}
+AM_HD uint32_t t4_expect(uint32_t fp, uint32_t nbs) { return kT4Occupied | (fp << 5) | (nbs << 16); }
+AM_HD uint32_t t4_slot_diff(uint32_t slot, uint32_t expect)
+{
+    const uint32_t ignore = (0xFFFF0000u << (slot & 31u)) | 0x1Fu;
+    return (slot ^ expect) & ~ignore;
 }
 
 // Phase 1, N candidates per lane at once.  Inputs come straight from the filter stage's registers
@@ -386,11 +389,10 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
 #endif
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const uint32_t more1 = (uint32_t)(avail[k] > 4), more2 = (uint32_t)(avail[k] > 5);
-        const uint32_t nb = nbs[k] & 0xFFu, nb2 = (nbs[k] >> 8) & 0xFFu;
-        uint32_t hit = t4_slot_may_match(ba[k].x, fp[k], nb, nb2, more1, more2) | t4_slot_may_match(ba[k].y, fp[k], nb, nb2, more1, more2) |
-                       t4_slot_may_match(bb[k].x, fp[k], nb, nb2, more1, more2) | t4_slot_may_match(bb[k].y, fp[k], nb, nb2, more1, more2);
-        hit &= (uint32_t)probe[k];                               // empty buckets were substituted for non-probes anyway
+        const uint32_t e = t4_expect(fp[k], nbs[k] & 0xFFFFu);
+        const uint32_t za = t4_slot_diff(ba[k].x, e), zb = t4_slot_diff(ba[k].y, e), zc = t4_slot_diff(bb[k].x, e), zd = t4_slot_diff(bb[k].y, e);
+        const uint32_t za_b = za < zb ? za : zb, zc_d = zc < zd ? zc : zd;
+        uint32_t hit = (uint32_t)((za_b < zc_d ? za_b : zc_d) == 0u);   // some slot agrees (empty buckets were substituted for non-probes)
         hit |= (uint32_t)((s.tiers & 7u) != 0u);                 // 1..3-byte needles: always consult their tables
         if (ablate == 3) hit &= (uint32_t)(ba[k].x == 0x12345678u);   // timing experiment only
         defer[k] = valid[k] & (hit != 0u);
