@@ -410,10 +410,16 @@ AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
     n.x = a.x; n.y = a.y; n.z = a.z; n.w = a.w; n.label[0] = b.x; n.label[1] = b.y; n.label[2] = b.z; n.label[3] = b.w;
 }
 
-template <bool IC, int N>
-AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail)[N], const bool (&valid)[N],
+// SHORT = false promises that the automaton has no needle (variant) shorter than 4 bytes (s.tiers & 7 == 0): step 5 and the
+// three small tables drop out of the kernel.  Depths are 32-bit: a needle is far shorter than 4 GiB, and the bytes
+// available in the haystack only matter up to that.
+template <bool IC, int N, bool SHORT = true>
+AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail64)[N], const bool (&valid)[N],
                         bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N])
 {
+    uint32_t avail[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) avail[k] = avail64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)avail64[k];
     const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
     const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 2 x 16 B per edge
     uint32_t w[N], w2[N], node[N];
@@ -465,7 +471,7 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
     }
     // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
     uint32_t best_state[N], best_vlen[N], pre_node[N];
-    uint64_t depth[N];
+    uint32_t depth[N];
     bool go[N];
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -492,7 +498,7 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             if (!go[k]) continue;
             const uint32_t n_edges = rec[k].w & 0xFFFFu;
             uint32_t b;
-            if (depth[k] < 8) b = (w2[k] >> (8u * (7u - (uint32_t)depth[k]))) & 0xFFu;
+            if (depth[k] < 8) b = (w2[k] >> (8u * (7u - depth[k]))) & 0xFFu;
             else { b = text[gpos[k] - depth[k]]; if (IC) b = fold_byte(b); }
             if (n_edges == 1) {
                 if (((rec[k].w >> 16) & 0xFFu) == b) { next[k] = rec[k].z; skip[k] = rec[k].w >> 24; }
@@ -515,7 +521,7 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
                 next[k] = e0[k].y; skip[k] = e0[k].z;                       // SfEdge {byte, child, skip, pad, label[4]}
                 label[k][0] = e1[k].x; label[k][1] = e1[k].y; label[k][2] = e1[k].z; label[k][3] = e1[k].w;
             }
-            if (next[k] == kNone || depth[k] + 1 + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
+            if (next[k] == kNone || (uint64_t)depth[k] + 1u + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
         }
         // 4b: child record + the 16 bytes to compare with the label, for all N items together
         SfNode child[N];
@@ -553,7 +559,7 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
     // ---- step 5: needles of 1..3 bytes (only if nothing longer ends here)
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        if (valid[k] && !best_state[k] && (s.tiers & 7u)) {
+        if (SHORT && valid[k] && !best_state[k] && (s.tiers & 7u)) {
             uint32_t short_node = kNone;
             for (uint32_t t = 3; t >= 1; t--) {
                 if ((s.tiers & (1u << (t - 1))) && avail[k] >= t) {

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             end_pos[k] = valid[k] ? gpos[k] - b.offsets[hay[k]] + 1 : 0;
         }
         if (timing) { asm volatile("" :: "v"((uint32_t)end_pos[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r1 += now - t_mark; t_mark = now; }
-        sf_resolve_n<IC, RN>(s, b.text, gpos, end_pos, valid, found, state, vlen);
+        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, found, state, vlen);
         if (timing) { asm volatile("" :: "v"((uint32_t)found[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; n_batches++; }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
