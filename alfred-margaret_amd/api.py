@@ -71,6 +71,7 @@ ABI = {
     "am_replaced_get": (C.c_int, [_vp, _sz, C.POINTER(_vp), C.POINTER(_sz)]),
     "am_replaced_passes": (C.c_uint64, [_vp]),
     "am_replaced_scanned_bytes": (C.c_uint64, [_vp]),
+    "am_replaced_spliced_bytes": (C.c_uint64, [_vp]),
     "am_replaced_free": (None, [_vp]),
     "am_automaton_image_size": (C.c_int, [_vp, C.c_int, C.POINTER(_sz)]),
     "am_automaton_image_copy": (C.c_int, [_vp, C.c_int, _vp, _sz]),

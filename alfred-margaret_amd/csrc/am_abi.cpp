@@ -819,7 +819,7 @@ struct am_replaced {
     std::vector<Item> text;
     std::vector<uint8_t> just;
     std::vector<Slab> slabs;
-    uint64_t passes = 0, scanned = 0;
+    uint64_t passes = 0, scanned = 0, spliced = 0;
     ~am_replaced() { for (const Slab& s : slabs) g_slabs.give(s); }
     // room for n contiguous bytes in the current slab, or a new slab
     int room(size_t n, uint8_t** out)
@@ -892,15 +892,35 @@ namespace {
 
 struct RpSession {
     DevBuf text[2], offs[2], orig[2], thr[2];
-    DevBuf totals; uint64_t* tot_host = nullptr;       // the five per-pass totals, read back through pinned memory
-    DevBuf records, rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
+    DevBuf totals; uint64_t* tot_host = nullptr;       // the per-pass totals, read back through pinned memory
+    hipStream_t copy_stream = nullptr; hipEvent_t ev_spliced = nullptr;     // finished texts travel home next to the window scans
+    RpFin* fin_host = nullptr; size_t fin_host_cap = 0;                     // pinned
+    int pin_meta(size_t bytes)
+    {
+        if (bytes <= fin_host_cap) return AM_OK;
+        if (fin_host) (void)hipHostFree(fin_host);
+        fin_host = nullptr; fin_host_cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc((void**)&fin_host, want, hipHostMallocDefault) != hipSuccess) { fin_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+        fin_host_cap = want;
+        return AM_OK;
+    }
+    DevBuf recbuf[2];                    // sorted records of the current pass / of the next one (incremental re-scan)
+    DevBuf nwin, win_off, wins, wlen, woffs, wtext, wrec, wrec_first, mcount, moff;
+    am_batch ws2;                        // workspace of the window scans
+    DevBuf rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
     am_batch ws;                         // workspace holder for the scans; never owns its text
     ~RpSession()
     {
-        for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &records, &rec_first, &kept, &hs, &len_next, &len_fin,
+        for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &rec_first, &kept, &hs, &len_next, &len_fin,
+                          &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff,
                           &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta}) d->release();
         if (tot_host) (void)hipHostFree(tot_host);
-        for (DevBuf* d : {&ws.hidx, &ws.unit_counts, &ws.unit_offsets, &ws.scan_tmp, &ws.small, &ws.hay_counts, &ws.flags, &ws.unit_first, &ws.pool, &ws.block_next}) d->release();
+        if (fin_host) (void)hipHostFree(fin_host);
+        if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
+        if (ev_spliced) (void)hipEventDestroy(ev_spliced);
+        for (am_batch* w : {&ws, &ws2})
+            for (DevBuf* d : {&w->hidx, &w->unit_counts, &w->unit_offsets, &w->scan_tmp, &w->small, &w->hay_counts, &w->flags, &w->unit_first, &w->pool, &w->block_next}) d->release();
     }
 };
 
@@ -916,7 +936,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     hipStream_t st; AM_TRY(get_stream(&st));
     RpSession s;
     AM_TRY(s.totals.ensure(64));
-    if (hipHostMalloc((void**)&s.tot_host, 64, hipHostMallocDefault) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    if (hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocDefault) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
     // pass 0 reads the caller's batch in place; afterwards the text ping-pongs between s.text[0] and s.text[1]
     const uint8_t* cur_text = (const uint8_t*)in->d_text;
     const uint64_t* cur_offs = in->d_offsets;
@@ -934,7 +954,18 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     }
     const uint32_t* cur_orig = (const uint32_t*)first_orig.p;
     const int64_t* cur_thr = (const int64_t*)first_thr.p;
-    std::vector<RpFin> fin_host;
+    if (hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev_spliced, hipEventDisableTiming) != hipSuccess)
+        return fail(AM_ERR_HIP, "could not create the copy stream");
+    // Incremental re-scan (am_replace.hip): after the first pass only windows around the replacements are scanned and
+    // merged with the shifted records of the previous pass.  Needs the suffix-filter kernel's position-local semantics
+    // (automata with the empty needle re-scan everything); AM_RP_FULL_SCANS=1 turns it off (A/B, tests).
+    const Flavor* flavor = nullptr;
+    AM_TRY(prepare(r->a, r->case_mode, &flavor));
+    const uint32_t ov = 4u * (flavor->h.max_needle_cps ? flavor->h.max_needle_cps : 1u) + 4u;
+    const bool inc_enabled = flavor->h.sf_enabled && r->a->kernel_pref != 1 && std::getenv("AM_RP_FULL_SCANS") == nullptr;
+    bool have_inc = false;
+    uint64_t inc_n_rec = 0;
+    int cur_rec = 0;
     // AM_RP_TRACE=1: wall-clock split of the loop on stderr (development aid)
     const bool trace = std::getenv("AM_RP_TRACE") != nullptr;
     double t_scan = 0, t_fold = 0, t_splice = 0, t_home = 0;
@@ -943,14 +974,19 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
 
     while (n_act > 0) {
         double t0 = now();
-        res->passes++; res->scanned += total;
-        // ---- the scan (Replacer.hs:223-225)
-        s.ws.d_text = const_cast<uint8_t*>(cur_text); s.ws.d_offsets = const_cast<uint64_t*>(cur_offs); s.ws.owns = false;
-        s.ws.total = total; s.ws.n_hay = n_act;
-        AM_TRY(finish_batch(&s.ws));
+        res->passes++;
+        // ---- the scan (Replacer.hs:223-225): everything, unless the previous pass already derived this pass's records
         uint64_t n_rec = 0;
-        auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.records.ensure(n * sizeof(Record))); *ptr = (Record*)s.records.p; return AM_OK; };
-        AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &n_rec));
+        DevBuf& records = s.recbuf[cur_rec];
+        if (have_inc) { n_rec = inc_n_rec; have_inc = false; }
+        else {
+            res->scanned += total;
+            s.ws.d_text = const_cast<uint8_t*>(cur_text); s.ws.d_offsets = const_cast<uint64_t*>(cur_offs); s.ws.owns = false;
+            s.ws.total = total; s.ws.n_hay = n_act;
+            AM_TRY(finish_batch(&s.ws));
+            auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(records.ensure(n * sizeof(Record))); *ptr = (Record*)records.p; return AM_OK; };
+            AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &n_rec));
+        }
         t_scan += now() - t0; t0 = now();
         // ---- per-haystack fold of the records
         const uint64_t n1 = (uint64_t)n_act + 1;
@@ -961,11 +997,11 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
         const size_t tmp_bytes = t32 > t64 ? t32 : t64;
         AM_TRY(s.scan_tmp.ensure(tmp_bytes + 16));
-        AM_TRY(s.records.ensure(sizeof(Record)));          // a valid pointer even when nothing matched
+        AM_TRY(records.ensure(sizeof(Record)));            // a valid pointer even when nothing matched
         RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
-        { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)s.records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
+        { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
         { Prof pr("rp_pass", st);
-          HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)s.records.p, (const uint64_t*)s.rec_first.p, cur_thr,
+          HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, (const uint64_t*)s.rec_first.p, cur_thr,
                                  max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st)); }
         { Prof pr("rp_scans", st);
           HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_next, (uint64_t*)s.off_next.p, n1, st));
@@ -981,6 +1017,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         const uint64_t* tot = s.tot_host;
         const uint64_t total_next = tot[0], total_fin = tot[1], n_tiles = tot[2], n_next = tot[3], n_fin = tot[4];
         t_fold += now() - t0; t0 = now();
+        res->spliced += total_next + total_fin;
         if (n_tiles >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "replacement output too large for one launch; split the batch");
         // ---- replace (Replacer.hs:163-180) into the next batch / the finished buffer
         AM_TRY(s.text[nxt].ensure(padded_text(total_next))); AM_TRY(s.offs[nxt].ensure((n_next + 1) * 8));
@@ -992,23 +1029,87 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
           HIP_TRY(launch_rp_splice(r->t, cur_text, cur_offs, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, rt, n_act, n_tiles,
                                    (uint8_t*)s.text[nxt].p, (uint8_t*)s.fin_text.p, st)); }
         HIP_TRY(hipMemsetAsync((uint8_t*)s.text[nxt].p + total_next, 0, padded_text(total_next) - (size_t)total_next, st));
-        // ---- finished haystacks go home
+        // ---- finished haystacks go home: the copy runs on its own stream, next to the window scans below
         uint8_t* home = nullptr;
         if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
-        fin_host.resize(n_fin);
-        if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, st));
-        if (n_fin) HIP_TRY(hipMemcpyAsync(fin_host.data(), s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        AM_TRY(s.pin_meta((n_fin + 1) * sizeof(RpFin)));
+        HIP_TRY(hipEventRecord(s.ev_spliced, st));
+        HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0));
+        if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, s.copy_stream));
+        if (n_fin) HIP_TRY(hipMemcpyAsync(s.fin_host, s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, s.copy_stream));
+        auto finished_home = [&]() -> int {
+            HIP_TRY(hipStreamSynchronize(s.copy_stream));
+            for (uint64_t i = 0; i < n_fin; i++) {
+                const RpFin& f = s.fin_host[i];
+                if (f.orig >= n_hay || f.off + f.len > total_fin) return fail(AM_ERR_HIP, "replacer pass produced inconsistent metadata (internal error)");
+                if (f.status == kRpNothing) res->just[f.orig] = 0;
+                else res->text[f.orig] = am_replaced::Item{home + f.off, (size_t)f.len};
+            }
+            return AM_OK;
+        };
         t_splice += now() - t0; t0 = now();
-        for (const RpFin& f : fin_host) {
-            if (f.orig >= n_hay || f.off + f.len > total_fin) return fail(AM_ERR_HIP, "replacer pass produced inconsistent metadata (internal error)");
-            if (f.status == kRpNothing) res->just[f.orig] = 0;
-            else res->text[f.orig] = am_replaced::Item{home + f.off, (size_t)f.len};
+        t_home += now() - t0; t0 = now();
+        // ---- next pass's records without a full scan: windows around the replacements + the shifted old records
+        if (inc_enabled && n_next > 0 && n_rec > 0) {
+            const uint8_t* text_next = (const uint8_t*)s.text[nxt].p;
+            const uint64_t* offs_next = (const uint64_t*)s.offs[nxt].p;
+            AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8));
+            AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
+            size_t tw = 0;
+            if (scan_temp_bytes(n_rec + 1, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+            AM_TRY(s.scan_tmp.ensure(std::max(tw, tmp_bytes) + 16));
+            const size_t tmp2 = s.scan_tmp.cap - 16;
+            { Prof pr("rp_windows", st);
+              HIP_TRY(launch_rp_win_count((const RpHay*)s.hs.p, n_act, (uint32_t*)s.nwin.p, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.nwin.p, (uint64_t*)s.win_off.p, n1, st));
+              HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));           // at most one window per record; unused entries scan as zeros
+              HIP_TRY(launch_rp_win_meta(r->t, text_next, offs_next, rt, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p,
+                                         (const uint64_t*)s.win_off.p, ov, (RpWin*)s.wins.p, (uint32_t*)s.wlen.p, n_act, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st)); }
+            HIP_TRY(hipMemcpyAsync(&s.tot_host[5], (uint64_t*)s.win_off.p + n_act, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&s.tot_host[6], (uint64_t*)s.woffs.p + n_rec, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const uint64_t n_win = s.tot_host[5], total_w = s.tot_host[6];
+            if (n_win > 0 && n_win < 0xFFFFFFF0ull && total_w <= total_next / 2) {
+                AM_TRY(s.wtext.ensure(padded_text(total_w)));
+                { Prof pr("rp_windows", st);
+                  HIP_TRY(launch_rp_win_copy((const RpWin*)s.wins.p, (const uint64_t*)s.woffs.p, text_next, (uint8_t*)s.wtext.p, n_win, st));
+                  HIP_TRY(hipMemsetAsync((uint8_t*)s.wtext.p + total_w, 0, padded_text(total_w) - (size_t)total_w, st)); }
+                s.ws2.d_text = s.wtext.p; s.ws2.d_offsets = (uint64_t*)s.woffs.p; s.ws2.owns = false; s.ws2.total = total_w; s.ws2.n_hay = (uint32_t)n_win;
+                AM_TRY(finish_batch(&s.ws2));
+                uint64_t n_wrec = 0;
+                auto wsink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.wrec.ensure(n * sizeof(Record))); *ptr = (Record*)s.wrec.p; return AM_OK; };
+                AM_TRY(run_records(r->a, r->case_mode, &s.ws2, wsink, &n_wrec));
+                res->scanned += total_w;
+                AM_TRY(s.wrec.ensure(sizeof(Record)));
+                AM_TRY(s.wrec_first.ensure((n_win + 1) * 8)); AM_TRY(s.mcount.ensure((n_next + 1) * 4)); AM_TRY(s.moff.ensure((n_next + 1) * 8));
+                { Prof pr("rp_merge", st);
+                  HIP_TRY(launch_rp_ranges((const Record*)s.wrec.p, n_wrec, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
+                  HIP_TRY(hipMemsetAsync((uint32_t*)s.mcount.p + n_next, 0, 4, st));
+                  HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                                          (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
+                                          (uint32_t*)s.mcount.p, nullptr, nullptr, st));
+                  HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st)); }
+                HIP_TRY(hipMemcpyAsync(&s.tot_host[7], (uint64_t*)s.moff.p + n_next, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                inc_n_rec = s.tot_host[7];
+                DevBuf& next_records = s.recbuf[cur_rec ^ 1];
+                AM_TRY(next_records.ensure((inc_n_rec + 1) * sizeof(Record)));
+                { Prof pr("rp_merge", st);
+                  HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                                          (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
+                                          (uint32_t*)s.mcount.p, (const uint64_t*)s.moff.p, (Record*)next_records.p, st)); }
+                have_inc = true;
+            }
         }
+        t_scan += now() - t0; t0 = now();
+        AM_TRY(finished_home());
+        t_home += now() - t0; t0 = now();
+        cur_rec ^= 1;
         cur_text = (const uint8_t*)s.text[nxt].p; cur_offs = (const uint64_t*)s.offs[nxt].p;
         cur_orig = (const uint32_t*)s.orig[nxt].p; cur_thr = (const int64_t*)s.thr[nxt].p;
         total = total_next; n_act = (uint32_t)n_next; nxt ^= 1;
-        t_home += now() - t0;
+        t_scan += now() - t0;
     }
     return AM_OK;
 }
@@ -1095,6 +1196,7 @@ extern "C" void am_prio_matches_free(am_prio_match* m) { std::free(m); }
 extern "C" uint64_t am_replaced_size(const am_replaced* r) { return r ? r->text.size() : 0; }
 extern "C" uint64_t am_replaced_passes(const am_replaced* r) { return r ? r->passes : 0; }
 extern "C" uint64_t am_replaced_scanned_bytes(const am_replaced* r) { return r ? r->scanned : 0; }
+extern "C" uint64_t am_replaced_spliced_bytes(const am_replaced* r) { return r ? r->spliced : 0; }
 
 extern "C" int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len)
 {

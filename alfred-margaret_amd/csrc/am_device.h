@@ -78,6 +78,15 @@ hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64
 hipError_t launch_idset(const Record* recs, uint64_t r0, uint64_t r1, const uint64_t* vals_off, const uint32_t* vals, uint32_t n_needles,
                         uint32_t hay0, uint32_t words, uint32_t* bits, hipStream_t st);
 hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_needles, uint32_t n_hay, uint8_t* flags, hipStream_t st);
+// incremental re-scan between Replacer passes (am_replace.hip)
+struct RpWin { uint64_t src_abs; uint64_t ws; uint32_t len; uint32_t own_lo; };   // window: bytes src_abs.. of the next text; ws = its start inside the haystack; records with end > own_lo are its own
+hipError_t launch_rp_win_count(const RpHay* hs, uint32_t n_act, uint32_t* nwin, hipStream_t st);
+hipError_t launch_rp_win_meta(const RpTables& t, const uint8_t* text_next, const uint64_t* offs_next, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
+                              const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st);
+hipError_t launch_rp_win_copy(const RpWin* wins, const uint64_t* woffs, const uint8_t* text_next, uint8_t* wtext, uint64_t n_win, hipStream_t st);
+hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_first, const RpKept* kept, const RpHay* hs, const uint64_t* offsets, const RpRouted& rt,
+                           const uint64_t* win_off, const RpWin* wins, const Record* wrecs, const uint64_t* wrec_first, uint32_t ov, uint32_t n_act,
+                           uint32_t* mcount, const uint64_t* moff, Record* out, hipStream_t st);
 hipError_t scan64_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t st);
 

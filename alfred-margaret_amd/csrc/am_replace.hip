@@ -306,6 +306,148 @@ hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64
     return hipGetLastError();
 }
 
+// ---- incremental re-scan between Replacer passes -------------------------------------------------------------------------
+// The reference re-scans the whole rewritten haystack in every pass (Replacer.hs:223-225).  Whether a needle ends at a
+// position depends only on the `ov` bytes before it (ov >= the longest needle in haystack bytes), so after a pass the
+// records of the new text are: the old records outside the neighbourhood of the replacements, shifted; plus the
+// records of a scan of small windows around the replacements.  For kept match j of a haystack (new-text coordinates,
+// dst_j = start of its replacement, rl = replacement length):
+//   own range  (dst_j, min(dst_j + rl + ov, dst_{j+1}, newlen)]     end positions re-derived from window j
+//   window     [dst_j - ov (moved back to a code-point boundary), upper end of the own range)
+//   old records with end in (src_start_j, src_start_j + src_len_j + ov] are dropped, the others shift with the text.
+// k_rp_win_meta lays the windows out, k_rp_win_copy gathers their text into a small batch (scanned by k_sf like any
+// other batch), k_rp_merge<false/true> counts / writes the next pass's sorted record list.
+__global__ void __launch_bounds__(256) k_rp_win_count(const RpHay* __restrict__ hs, uint32_t n_act, uint32_t* __restrict__ nwin)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_act) return;
+    nwin[h] = (h < n_act && hs[h].status == kRpActive) ? hs[h].nkept : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_rp_win_meta(RpTables t, const uint8_t* __restrict__ text_next, const uint64_t* __restrict__ offs_next, RpRouted rt,
+                                                     const RpHay* __restrict__ hs, const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
+                                                     const uint64_t* __restrict__ win_off, uint32_t ov, RpWin* __restrict__ wins, uint32_t* __restrict__ wlen,
+                                                     uint32_t n_act)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h == n_act && lane == 0) wlen[win_off[n_act]] = 0;          // the scan's trailing element
+    if (h >= n_act) return;
+    const RpHay s = hs[h];
+    if (s.status != kRpActive) return;
+    const RpKept* K = kept + rec_first[h];
+    const uint64_t base = offs_next[rt.act_idx[h]], w0 = win_off[h];
+    const uint64_t rl = t.payloads[s.payload].repl_len;
+    for (uint32_t j = lane; j < s.nkept; j += kWave) {
+        const uint64_t dst = K[j].dst;
+        uint64_t hi = dst + rl + ov;
+        if (hi > s.newlen) hi = s.newlen;
+        if (j + 1 < s.nkept && K[j + 1].dst < hi) hi = K[j + 1].dst;
+        uint64_t ws = dst > ov ? dst - ov : 0;
+        while (ws > 0 && (text_next[base + ws] & 0xC0u) == 0x80u) ws--;
+        RpWin w; w.src_abs = base + ws; w.ws = ws;
+        w.len = hi > dst ? (uint32_t)(hi - ws) : 0u;                // empty own range: nothing to scan
+        w.own_lo = (uint32_t)(dst - ws);
+        wins[w0 + j] = w;
+        wlen[w0 + j] = w.len;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rp_win_copy(const RpWin* __restrict__ wins, const uint64_t* __restrict__ woffs, const uint8_t* __restrict__ text_next,
+                                                     uint8_t* __restrict__ wtext, uint64_t n_win)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wi = (uint64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (wi >= n_win) return;
+    const RpWin w = wins[wi];
+    const uint8_t* src = text_next + w.src_abs;
+    uint8_t* dst = wtext + woffs[wi];
+    for (uint32_t i = lane; i < w.len; i += kWave) dst[i] = src[i];
+}
+
+namespace {
+// first index in [lo, hi) whose end_pos is > x
+__device__ __forceinline__ uint64_t upper_bound_end(const Record* __restrict__ r, uint64_t lo, uint64_t hi, uint64_t x)
+{
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (r[mid].end_pos <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+}  // namespace
+
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_rp_merge(const Record* __restrict__ recs, const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
+                                                  const RpHay* __restrict__ hs, const uint64_t* __restrict__ offsets, RpRouted rt,
+                                                  const uint64_t* __restrict__ win_off, const RpWin* __restrict__ wins, const Record* __restrict__ wrecs,
+                                                  const uint64_t* __restrict__ wrec_first, uint32_t ov, uint32_t n_act,
+                                                  uint32_t* __restrict__ mcount, const uint64_t* __restrict__ moff, Record* __restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_act) return;
+    const RpHay s = hs[h];
+    if (s.status != kRpActive) return;
+    const uint32_t a = (uint32_t)rt.act_idx[h];                     // index of the haystack in the next pass
+    const uint64_t r0 = rec_first[h], r1 = rec_first[h + 1], w0 = win_off[h];
+    const RpKept* K = kept + r0;
+    const uint64_t curlen = offsets[h + 1] - offsets[h];
+    uint64_t cursor = WRITE ? moff[a] : 0, n = 0, at = r0;
+    for (uint32_t j = 0; j < s.nkept; j++) {
+        const RpKept k = K[j];
+        // old records that end at or before the replaced region: unchanged context, they move with the text
+        const uint64_t e = upper_bound_end(recs, at, r1, k.src_start);
+        if (WRITE) {
+            const int64_t shift = (int64_t)k.dst - (int64_t)k.src_start;
+            for (uint64_t i = at + lane; i < e; i += kWave) { Record r = recs[i]; r.end_pos = (uint64_t)((int64_t)r.end_pos + shift); r.haystack = a; out[cursor + (i - at)] = r; }
+        }
+        cursor += e - at; n += e - at;
+        // the window's own records
+        const RpWin w = wins[w0 + j];
+        const uint64_t q1 = wrec_first[w0 + j + 1];
+        const uint64_t q0 = upper_bound_end(wrecs, wrec_first[w0 + j], q1, w.own_lo);
+        if (WRITE) for (uint64_t i = q0 + lane; i < q1; i += kWave) { Record r = wrecs[i]; r.end_pos += w.ws; r.haystack = a; out[cursor + (i - q0)] = r; }
+        cursor += q1 - q0; n += q1 - q0;
+        // old records that touch the replaced bytes are gone
+        at = upper_bound_end(recs, e, r1, k.src_start + k.src_len + ov);
+    }
+    if (WRITE) {
+        const int64_t shift = (int64_t)s.newlen - (int64_t)curlen;
+        for (uint64_t i = at + lane; i < r1; i += kWave) { Record r = recs[i]; r.end_pos = (uint64_t)((int64_t)r.end_pos + shift); r.haystack = a; out[cursor + (i - at)] = r; }
+    }
+    n += r1 - at;
+    if (!WRITE && lane == 0) mcount[a] = (uint32_t)n;
+}
+
+hipError_t launch_rp_win_count(const RpHay* hs, uint32_t n_act, uint32_t* nwin, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rp_win_count, dim3((n_act + 1 + 255) / 256), dim3(256), 0, st, hs, n_act, nwin);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_win_meta(const RpTables& t, const uint8_t* text_next, const uint64_t* offs_next, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
+                              const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rp_win_meta, dim3((n_act + 1 + 3) / 4), dim3(256), 0, st, t, text_next, offs_next, rt, hs, rec_first, kept, win_off, ov, wins, wlen, n_act);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_win_copy(const RpWin* wins, const uint64_t* woffs, const uint8_t* text_next, uint8_t* wtext, uint64_t n_win, hipStream_t st)
+{
+    if (n_win == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rp_win_copy, dim3((uint32_t)((n_win + 3) / 4)), dim3(256), 0, st, wins, woffs, text_next, wtext, n_win);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_first, const RpKept* kept, const RpHay* hs, const uint64_t* offsets, const RpRouted& rt,
+                           const uint64_t* win_off, const RpWin* wins, const Record* wrecs, const uint64_t* wrec_first, uint32_t ov, uint32_t n_act,
+                           uint32_t* mcount, const uint64_t* moff, Record* out, hipStream_t st)
+{
+    if (n_act == 0) return hipSuccess;
+    const dim3 grid((n_act + 3) / 4), block(256);
+    if (write) hipLaunchKernelGGL(k_rp_merge<true>, grid, block, 0, st, recs, rec_first, kept, hs, offsets, rt, win_off, wins, wrecs, wrec_first, ov, n_act, mcount, moff, out);
+    else hipLaunchKernelGGL(k_rp_merge<false>, grid, block, 0, st, recs, rec_first, kept, hs, offsets, rt, win_off, wins, wrecs, wrec_first, ov, n_act, mcount, moff, out);
+    return hipGetLastError();
+}
+
 // ---- Searcher.containsAll (Searcher.hs:173-187) on the records: the IntSet of needle ids still missing, as one
 // bitmap of `words` 32-bit words per haystack.  k_idset sets the bit of every reported id, k_idset_all tests
 // whether all n_needles bits of a haystack are set (IS.null of the final accumulator).

@@ -183,7 +183,8 @@ uint64_t am_replaced_size(const am_replaced* r);
 /* Returns 1 and the text for `Just`, 0 for `Nothing` (longer than max_length), < 0 on error.  *ptr is owned by r. */
 int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len);
 uint64_t am_replaced_passes(const am_replaced* r);          /* scans that were needed (max over the batch) */
-uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes scanned over all passes */
+uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes scanned over all passes (after the first pass only windows around the replacements) */
+uint64_t am_replaced_spliced_bytes(const am_replaced* r);   /* bytes of rewritten text produced over all passes */
 void am_replaced_free(am_replaced* r);
 
 /* ---- multi-GPU: move the flattened automaton between devices -----------------------------------

@@ -277,7 +277,8 @@ def _replacer_three_ways(case, pairs, hays, max_len=-1):
     dev = r.run_batch(hays, max_len)
     dev_stats = r.last_stats()
     host = r.run_batch(hays, max_len, host_splice=True)
-    assert r.last_stats() == dev_stats                       # same number of passes, same bytes scanned
+    assert r.last_stats()[0] == dev_stats[0]                 # same number of passes
+    assert dev_stats[1] <= r.last_stats()[1]                 # the device re-scans only windows around the replacements
     o = oracle.Replacer(case, pairs)
     exp = [o.run(h, max_len) for h in hays]
     assert dev == exp, (case, pairs[:6], max_len)
@@ -327,6 +328,34 @@ def test_replacer_device_limit_and_empty_needle():
     with pytest.raises(am.AmError) as e:
         am.Replacer(1, [("", "-")]).run("ab")
     assert e.value.code == am.AM_ERR_UNSUPPORTED
+
+
+def test_replacer_incremental_rescan_equals_full_scans(monkeypatch):
+    """Windows + shifted records (am_replace.hip) give the same result, pass count and final text as re-scanning
+    everything in every pass (AM_RP_FULL_SCANS=1), on inputs with replacements close together, at haystack borders,
+    deletions, growth, and multi-byte text under IgnoreCase."""
+    rng = random.Random(77)
+    cases = []
+    cases.append((0, [("ab", "X"), ("Xc", "abab"), ("ba", ""), ("aX", "yy")], ["abcabcab" * 50, "ab", "bab", "", "cab" * 200]))
+    cases.append((0, [("aaa", "a"), ("a", "bb"), ("bbbb", "c")], ["a" * 1000, "a" * 7, "baab" * 100]))
+    cases.append((1, [("straße", "STR"), ("i", "İİ"), ("k", ""), ("å", "K")], ["Straße İstanbul KÅ" * 80, "strasse", "ẞ" * 50 + "straße"]))
+    for _ in range(8):
+        alpha = rng.choice(["abc ", "abİKß", "xyzXYZ"])
+        pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(1, 5))), "".join(rng.choice(alpha + "Q") for _ in range(rng.randint(0, 6)))) for _ in range(rng.randint(2, 25))]
+        hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 3, 50, 800, 5000)))) for _ in range(30)]
+        cases.append((rng.randint(0, 1), pairs, hays))
+    for case, pairs, hays in cases:
+        r = am.Replacer(case, pairs)
+        inc = r.run_batch(hays)
+        inc_stats = r.last_stats()
+        monkeypatch.setenv("AM_RP_FULL_SCANS", "1")
+        full = r.run_batch(hays)
+        full_stats = r.last_stats()
+        monkeypatch.delenv("AM_RP_FULL_SCANS")
+        assert inc == full, (case, pairs[:5])
+        assert inc_stats[0] == full_stats[0] and inc_stats[1] <= full_stats[1]
+        o = oracle.Replacer(case, pairs)
+        assert inc == [o.run(h) for h in hays]
 
 
 def test_replacer_device_many_haystacks_many_passes():

@@ -55,7 +55,7 @@ print("Replacer.run on device: %d pairs (build+flatten %.2f s), %d x %d KiB = %.
 print("  %.3f s -> %.3f GiB/s of input; %d passes, %.2f GiB scanned over all passes (%.1f GiB/s of scanned text)" %
       (dt, n_bytes / dt / 2**30, passes, scanned / 2**30, scanned / dt / 2**30))
 tot = 0.0
-for k in (b"hidx", b"sf", b"ac", b"scan", b"permute", b"rp_ranges", b"rp_pass", b"rp_scans", b"rp_route", b"rp_splice"):
+for k in (b"hidx", b"sf", b"ac", b"scan", b"permute", b"rp_ranges", b"rp_pass", b"rp_scans", b"rp_route", b"rp_splice", b"rp_windows", b"rp_merge"):
     ms, n = C.c_double(0), C.c_uint64(0)
     am.api.check(lib.am_profile_read(k, C.byref(ms), C.byref(n)))
     if n.value:
