@@ -906,14 +906,14 @@ struct RpSession {
         return AM_OK;
     }
     DevBuf recbuf[2];                    // sorted records of the current pass / of the next one (incremental re-scan)
-    DevBuf nwin, win_off, wins, wlen, woffs, wtext, wrec, wrec_first, mcount, moff;
+    DevBuf nwin, win_off, wins, wlen, woffs, wtext, wrec, wrec_first, mcount, moff, tile_hay;
     am_batch ws2;                        // workspace of the window scans
     DevBuf rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
     am_batch ws;                         // workspace holder for the scans; never owns its text
     ~RpSession()
     {
         for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &rec_first, &kept, &hs, &len_next, &len_fin,
-                          &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff,
+                          &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff, &tile_hay,
                           &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta}) d->release();
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
@@ -1022,12 +1022,12 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         // ---- replace (Replacer.hs:163-180) into the next batch / the finished buffer
         AM_TRY(s.text[nxt].ensure(padded_text(total_next))); AM_TRY(s.offs[nxt].ensure((n_next + 1) * 8));
         AM_TRY(s.orig[nxt].ensure((n_next + 1) * 4)); AM_TRY(s.thr[nxt].ensure((n_next + 1) * 8));
-        AM_TRY(s.fin_text.ensure(total_fin + 16)); AM_TRY(s.fin_meta.ensure((n_fin + 1) * sizeof(RpFin)));
+        AM_TRY(s.fin_text.ensure(total_fin + 16)); AM_TRY(s.fin_meta.ensure((n_fin + 1) * sizeof(RpFin))); AM_TRY(s.tile_hay.ensure((n_tiles + 1) * 4));
         { Prof pr("rp_route", st);
           HIP_TRY(launch_rp_route((const RpHay*)s.hs.p, rt, cur_orig, n_act, (uint64_t*)s.offs[nxt].p, (uint32_t*)s.orig[nxt].p, (int64_t*)s.thr[nxt].p, (RpFin*)s.fin_meta.p, st)); }
         { Prof pr("rp_splice", st);
           HIP_TRY(launch_rp_splice(r->t, cur_text, cur_offs, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, rt, n_act, n_tiles,
-                                   (uint8_t*)s.text[nxt].p, (uint8_t*)s.fin_text.p, st)); }
+                                   (uint32_t*)s.tile_hay.p, (uint8_t*)s.text[nxt].p, (uint8_t*)s.fin_text.p, st)); }
         HIP_TRY(hipMemsetAsync((uint8_t*)s.text[nxt].p + total_next, 0, padded_text(total_next) - (size_t)total_next, st));
         // ---- finished haystacks go home: the copy runs on its own stream, next to the window scans below
         uint8_t* home = nullptr;

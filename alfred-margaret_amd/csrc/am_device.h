@@ -74,7 +74,8 @@ hipError_t launch_rp_gather(const RpHay* hs, const uint64_t* rec_first, const Rp
 hipError_t launch_rp_route(const RpHay* hs, const RpRouted& rt, const uint32_t* orig, uint32_t n_act, uint64_t* next_offsets, uint32_t* next_orig,
                            int64_t* next_thr, RpFin* fin, hipStream_t st);
 hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64_t* offsets, const uint64_t* rec_first, const RpKept* kept,
-                            const RpHay* hs, const RpRouted& rt, uint32_t n_act, uint64_t n_tiles, uint8_t* text_next, uint8_t* text_fin, hipStream_t st);
+                            const RpHay* hs, const RpRouted& rt, uint32_t n_act, uint64_t n_tiles, uint32_t* tile_hay /* n_tiles entries, scratch */,
+                            uint8_t* text_next, uint8_t* text_fin, hipStream_t st);
 hipError_t launch_idset(const Record* recs, uint64_t r0, uint64_t r1, const uint64_t* vals_off, const uint32_t* vals, uint32_t n_needles,
                         uint32_t hay0, uint32_t words, uint32_t* bits, hipStream_t st);
 hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_needles, uint32_t n_hay, uint8_t* flags, hipStream_t st);

@@ -187,15 +187,12 @@ __global__ void __launch_bounds__(256) k_rp_route(const RpHay* __restrict__ hs, 
 
 __global__ void __launch_bounds__(256) k_rp_splice(RpTables t, const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets,
                                                    const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
-                                                   const RpHay* __restrict__ hs, RpRouted rt, uint32_t n_act,
+                                                   const RpHay* __restrict__ hs, RpRouted rt, const uint32_t* __restrict__ tile_hay,
                                                    uint8_t* __restrict__ text_next, uint8_t* __restrict__ text_fin)
 {
     typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
     const uint64_t tile = blockIdx.x;
-    // haystack of this tile: the last h with tile_off[h] <= tile (haystacks without tiles share their successor's offset)
-    uint32_t lo = 0, hi = n_act;                  // invariant: tile_off[lo] <= tile < tile_off[hi]
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (rt.tile_off[mid] <= tile) lo = mid; else hi = mid; }
-    const uint32_t h = lo;
+    const uint32_t h = tile_hay[tile];            // k_rp_tilemap: one load instead of a binary search per workgroup
     const RpHay s = hs[h];
     const uint8_t* src = text + offsets[h];
     uint8_t* dst = s.status == kRpActive ? text_next + rt.off_next[h] : text_fin + rt.off_fin[h];
@@ -206,16 +203,31 @@ __global__ void __launch_bounds__(256) k_rp_splice(RpTables t, const uint8_t* __
     const uint8_t* repl = t.repl + pp.repl_off;
     const uint64_t repl_len = nk ? pp.repl_len : 0;
     const uint64_t tbase = (tile - rt.tile_off[h]) * kRpTile;
+    // Most tiles lie inside ONE gap between replacements (a 64-KiB haystack has a few replacements per pass): then the
+    // tile is a plain copy from a constant source offset.  Everything here is uniform across the workgroup.
+    int64_t kb = -1;                                   // last kept match whose replacement starts at or before the tile
+    { int64_t a = 0, b = nk; while (a < b) { const int64_t mid = (a + b) >> 1; if (K[mid].dst <= tbase) a = mid + 1; else b = mid; } kb = a - 1; }
+    const uint64_t tend = tbase + kRpTile < newlen ? tbase + kRpTile : newlen;
+    uint64_t gap_lo = 0, gap_hi = newlen, gap_src = 0;  // new-text range of the gap after kb and where its first byte comes from
+    if (nk) {
+        if (kb >= 0) { const RpKept e = K[kb]; gap_lo = e.dst + repl_len; gap_src = e.src_start + e.src_len; }
+        if (kb + 1 < (int64_t)nk) gap_hi = K[kb + 1].dst;
+    }
+    if (tbase >= gap_lo && tend <= gap_hi) {
+        const uint8_t* from = src + gap_src - gap_lo;    // from[p] is the source of new-text byte p
+#pragma unroll
+        for (uint32_t it = 0; it < kRpTile / (256 * 16); it++) {
+            const uint64_t o = tbase + ((uint64_t)it * 256 + threadIdx.x) * 16;
+            if (o + 16 <= tend) *reinterpret_cast<u32x4_u*>(dst + o) = *reinterpret_cast<const u32x4_u*>(from + o);
+            else if (o < tend) for (uint64_t p = o; p < tend; p++) dst[p] = from[p];
+        }
+        return;
+    }
 #pragma unroll 1
     for (uint32_t it = 0; it < kRpTile / (256 * 16); it++) {
         const uint64_t o = tbase + ((uint64_t)it * 256 + threadIdx.x) * 16;
         if (o >= newlen) break;
         const uint64_t end = o + 16 < newlen ? o + 16 : newlen;
-        if (nk == 0) {
-            if (end - o == 16) *reinterpret_cast<u32x4_u*>(dst + o) = *reinterpret_cast<const u32x4_u*>(src + o);
-            else for (uint64_t p = o; p < end; p++) dst[p] = src[p];
-            continue;
-        }
         // last kept match whose replacement starts at or before o (-1: none)
         int64_t k = -1;
         { int64_t a = 0, b = nk; while (a < b) { const int64_t mid = (a + b) >> 1; if (K[mid].dst <= o) a = mid + 1; else b = mid; } k = a - 1; }
@@ -298,11 +310,22 @@ hipError_t launch_rp_route(const RpHay* hs, const RpRouted& rt, const uint32_t* 
     return hipGetLastError();
 }
 
+// tile -> haystack map of k_rp_splice: one wavefront per haystack writes its own index into its tiles' entries
+__global__ void __launch_bounds__(256) k_rp_tilemap(RpRouted rt, uint32_t n_act, uint32_t* __restrict__ tile_hay)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_act) return;
+    for (uint64_t t = rt.tile_off[h] + lane, e = rt.tile_off[h + 1]; t < e; t += kWave) tile_hay[t] = h;
+}
+
 hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64_t* offsets, const uint64_t* rec_first, const RpKept* kept,
-                            const RpHay* hs, const RpRouted& rt, uint32_t n_act, uint64_t n_tiles, uint8_t* text_next, uint8_t* text_fin, hipStream_t st)
+                            const RpHay* hs, const RpRouted& rt, uint32_t n_act, uint64_t n_tiles, uint32_t* tile_hay, uint8_t* text_next, uint8_t* text_fin,
+                            hipStream_t st)
 {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rp_splice, dim3((uint32_t)n_tiles), dim3(256), 0, st, t, text, offsets, rec_first, kept, hs, rt, n_act, text_next, text_fin);
+    hipLaunchKernelGGL(k_rp_tilemap, dim3((n_act + 3) / 4), dim3(256), 0, st, rt, n_act, tile_hay);
+    hipLaunchKernelGGL(k_rp_splice, dim3((uint32_t)n_tiles), dim3(256), 0, st, t, text, offsets, rec_first, kept, hs, rt, tile_hay, text_next, text_fin);
     return hipGetLastError();
 }
 
