@@ -1009,13 +1009,32 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
           HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.tiles, (uint64_t*)s.tile_off.p, n1, st));
           HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.act, (uint64_t*)s.act_idx.p, n1, st));
           HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.fin, (uint64_t*)s.fin_idx.p, n1, st)); }
-        // bytes of next text, bytes of finished text, tiles, haystacks still active, haystacks finished
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
-        HIP_TRY(launch_rp_totals(rt, n_act, (uint64_t*)s.totals.p, st));
-        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 40, hipMemcpyDeviceToHost, st));
+        // windows of the incremental re-scan (their geometry follows from the kept matches alone, the text is copied after the splice)
+        const bool try_inc = inc_enabled && n_rec > 0;
+        size_t tmp2 = tmp_bytes;
+        if (try_inc) {
+            AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8));
+            AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
+            size_t tw = 0;
+            if (scan_temp_bytes(n_rec + 1, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+            AM_TRY(s.scan_tmp.ensure(std::max(tw, tmp_bytes) + 16));
+            tmp2 = s.scan_tmp.cap - 16;
+            Prof pr("rp_windows", st);
+            HIP_TRY(launch_rp_win_count((const RpHay*)s.hs.p, n_act, (uint32_t*)s.nwin.p, st));
+            HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.nwin.p, (uint64_t*)s.win_off.p, n1, st));
+            HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));           // at most one window per record; unused entries scan as zeros
+            HIP_TRY(launch_rp_win_meta(r->t, rt, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p,
+                                       (const uint64_t*)s.win_off.p, ov, (RpWin*)s.wins.p, (uint32_t*)s.wlen.p, n_act, st));
+            HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st));
+        }
+        // bytes of next text, bytes of finished text, tiles, haystacks still active, haystacks finished, windows, window bytes
+        HIP_TRY(launch_rp_totals(rt, n_act, try_inc ? (const uint64_t*)s.win_off.p : nullptr, try_inc ? (const uint64_t*)s.woffs.p : nullptr, n_rec,
+                                 (uint64_t*)s.totals.p, st));
+        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 56, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint64_t* tot = s.tot_host;
-        const uint64_t total_next = tot[0], total_fin = tot[1], n_tiles = tot[2], n_next = tot[3], n_fin = tot[4];
+        const uint64_t total_next = tot[0], total_fin = tot[1], n_tiles = tot[2], n_next = tot[3], n_fin = tot[4], n_win = tot[5], total_w = tot[6];
         t_fold += now() - t0; t0 = now();
         res->spliced += total_next + total_fin;
         if (n_tiles >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "replacement output too large for one launch; split the batch");
@@ -1050,58 +1069,37 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         t_splice += now() - t0; t0 = now();
         t_home += now() - t0; t0 = now();
         // ---- next pass's records without a full scan: windows around the replacements + the shifted old records
-        if (inc_enabled && n_next > 0 && n_rec > 0) {
+        if (try_inc && n_next > 0 && n_win > 0 && n_win < 0xFFFFFFF0ull && total_w <= total_next / 2) {
             const uint8_t* text_next = (const uint8_t*)s.text[nxt].p;
-            const uint64_t* offs_next = (const uint64_t*)s.offs[nxt].p;
-            AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8));
-            AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
-            size_t tw = 0;
-            if (scan_temp_bytes(n_rec + 1, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
-            AM_TRY(s.scan_tmp.ensure(std::max(tw, tmp_bytes) + 16));
-            const size_t tmp2 = s.scan_tmp.cap - 16;
+            AM_TRY(s.wtext.ensure(padded_text(total_w)));
             { Prof pr("rp_windows", st);
-              HIP_TRY(launch_rp_win_count((const RpHay*)s.hs.p, n_act, (uint32_t*)s.nwin.p, st));
-              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.nwin.p, (uint64_t*)s.win_off.p, n1, st));
-              HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));           // at most one window per record; unused entries scan as zeros
-              HIP_TRY(launch_rp_win_meta(r->t, text_next, offs_next, rt, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p,
-                                         (const uint64_t*)s.win_off.p, ov, (RpWin*)s.wins.p, (uint32_t*)s.wlen.p, n_act, st));
-              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st)); }
-            HIP_TRY(hipMemcpyAsync(&s.tot_host[5], (uint64_t*)s.win_off.p + n_act, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&s.tot_host[6], (uint64_t*)s.woffs.p + n_rec, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            const uint64_t n_win = s.tot_host[5], total_w = s.tot_host[6];
-            if (n_win > 0 && n_win < 0xFFFFFFF0ull && total_w <= total_next / 2) {
-                AM_TRY(s.wtext.ensure(padded_text(total_w)));
-                { Prof pr("rp_windows", st);
-                  HIP_TRY(launch_rp_win_copy((const RpWin*)s.wins.p, (const uint64_t*)s.woffs.p, text_next, (uint8_t*)s.wtext.p, n_win, st));
-                  HIP_TRY(hipMemsetAsync((uint8_t*)s.wtext.p + total_w, 0, padded_text(total_w) - (size_t)total_w, st)); }
-                s.ws2.d_text = s.wtext.p; s.ws2.d_offsets = (uint64_t*)s.woffs.p; s.ws2.owns = false; s.ws2.total = total_w; s.ws2.n_hay = (uint32_t)n_win;
-                AM_TRY(finish_batch(&s.ws2));
-                uint64_t n_wrec = 0;
-                auto wsink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.wrec.ensure(n * sizeof(Record))); *ptr = (Record*)s.wrec.p; return AM_OK; };
-                AM_TRY(run_records(r->a, r->case_mode, &s.ws2, wsink, &n_wrec));
-                res->scanned += total_w;
-                AM_TRY(s.wrec.ensure(sizeof(Record)));
-                AM_TRY(s.wrec_first.ensure((n_win + 1) * 8)); AM_TRY(s.mcount.ensure((n_next + 1) * 4)); AM_TRY(s.moff.ensure((n_next + 1) * 8));
-                { Prof pr("rp_merge", st);
-                  HIP_TRY(launch_rp_ranges((const Record*)s.wrec.p, n_wrec, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
-                  HIP_TRY(hipMemsetAsync((uint32_t*)s.mcount.p + n_next, 0, 4, st));
-                  HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
-                                          (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
-                                          (uint32_t*)s.mcount.p, nullptr, nullptr, st));
-                  HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st)); }
-                HIP_TRY(hipMemcpyAsync(&s.tot_host[7], (uint64_t*)s.moff.p + n_next, 8, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                inc_n_rec = s.tot_host[7];
-                DevBuf& next_records = s.recbuf[cur_rec ^ 1];
-                AM_TRY(next_records.ensure((inc_n_rec + 1) * sizeof(Record)));
-                { Prof pr("rp_merge", st);
-                  HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
-                                          (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
-                                          (uint32_t*)s.mcount.p, (const uint64_t*)s.moff.p, (Record*)next_records.p, st)); }
-                have_inc = true;
-            }
+              HIP_TRY(launch_rp_win_copy((const RpWin*)s.wins.p, (const uint64_t*)s.woffs.p, text_next, (uint8_t*)s.wtext.p, n_win, st));
+              HIP_TRY(hipMemsetAsync((uint8_t*)s.wtext.p + total_w, 0, padded_text(total_w) - (size_t)total_w, st)); }
+            s.ws2.d_text = s.wtext.p; s.ws2.d_offsets = (uint64_t*)s.woffs.p; s.ws2.owns = false; s.ws2.total = total_w; s.ws2.n_hay = (uint32_t)n_win;
+            AM_TRY(finish_batch(&s.ws2));
+            uint64_t n_wrec = 0;
+            auto wsink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.wrec.ensure(n * sizeof(Record))); *ptr = (Record*)s.wrec.p; return AM_OK; };
+            AM_TRY(run_records(r->a, r->case_mode, &s.ws2, wsink, &n_wrec));
+            res->scanned += total_w;
+            AM_TRY(s.wrec.ensure(sizeof(Record)));
+            AM_TRY(s.wrec_first.ensure((n_win + 1) * 8)); AM_TRY(s.mcount.ensure((n_next + 1) * 4)); AM_TRY(s.moff.ensure((n_next + 1) * 8));
+            DevBuf& next_records = s.recbuf[cur_rec ^ 1];
+            AM_TRY(next_records.ensure((n_rec + n_wrec + 1) * sizeof(Record)));          // upper bound; the exact count arrives with the end-of-pass sync
+            Prof pr("rp_merge", st);
+            HIP_TRY(launch_rp_ranges((const Record*)s.wrec.p, n_wrec, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
+            HIP_TRY(hipMemsetAsync((uint32_t*)s.mcount.p + n_next, 0, 4, st));
+            HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                                    (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
+                                    (uint32_t*)s.mcount.p, nullptr, nullptr, st));
+            HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st));
+            HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                                    (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
+                                    (uint32_t*)s.mcount.p, (const uint64_t*)s.moff.p, (Record*)next_records.p, st));
+            HIP_TRY(hipMemcpyAsync(&s.tot_host[7], (uint64_t*)s.moff.p + n_next, 8, hipMemcpyDeviceToHost, st));
+            have_inc = true;
         }
+        HIP_TRY(hipStreamSynchronize(st));            // end of pass: the merged record count (if any) is on the host now
+        if (have_inc) inc_n_rec = s.tot_host[7];
         t_scan += now() - t0; t0 = now();
         AM_TRY(finished_home());
         t_home += now() - t0; t0 = now();

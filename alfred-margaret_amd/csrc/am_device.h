@@ -65,7 +65,7 @@ struct RpRouted { const uint64_t* off_next; const uint64_t* off_fin; const uint6
 constexpr uint64_t kRpTile = 16384;                      // bytes of new text per k_rp_splice workgroup
 
 hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
-hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, uint64_t* out5, hipStream_t st);
+hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out7, hipStream_t st);
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
                           const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st);
 struct RpSelected { uint64_t start, len; uint32_t haystack, payload; };     // = am_prio_match in include/am.h
@@ -82,7 +82,7 @@ hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_nee
 // incremental re-scan between Replacer passes (am_replace.hip)
 struct RpWin { uint64_t src_abs; uint64_t ws; uint32_t len; uint32_t own_lo; };   // window: bytes src_abs.. of the next text; ws = its start inside the haystack; records with end > own_lo are its own
 hipError_t launch_rp_win_count(const RpHay* hs, uint32_t n_act, uint32_t* nwin, hipStream_t st);
-hipError_t launch_rp_win_meta(const RpTables& t, const uint8_t* text_next, const uint64_t* offs_next, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
+hipError_t launch_rp_win_meta(const RpTables& t, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
                               const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_win_copy(const RpWin* wins, const uint64_t* woffs, const uint8_t* text_next, uint8_t* wtext, uint64_t n_win, hipStream_t st);
 hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_first, const RpKept* kept, const RpHay* hs, const uint64_t* offsets, const RpRouted& rt,

@@ -258,14 +258,16 @@ hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_fi
     return hipGetLastError();
 }
 
-__global__ void k_rp_totals(RpRouted rt, uint32_t n_act, uint64_t* __restrict__ out5)
+__global__ void k_rp_totals(RpRouted rt, uint32_t n_act, const uint64_t* __restrict__ win_off, const uint64_t* __restrict__ woffs, uint64_t woffs_last,
+                            uint64_t* __restrict__ out7)
 {
-    out5[0] = rt.off_next[n_act]; out5[1] = rt.off_fin[n_act]; out5[2] = rt.tile_off[n_act]; out5[3] = rt.act_idx[n_act]; out5[4] = rt.fin_idx[n_act];
+    out7[0] = rt.off_next[n_act]; out7[1] = rt.off_fin[n_act]; out7[2] = rt.tile_off[n_act]; out7[3] = rt.act_idx[n_act]; out7[4] = rt.fin_idx[n_act];
+    out7[5] = win_off ? win_off[n_act] : 0; out7[6] = woffs ? woffs[woffs_last] : 0;       // windows of the incremental re-scan and their bytes
 }
 
-hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, uint64_t* out5, hipStream_t st)
+hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out7, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, out5);
+    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, win_off, woffs, woffs_last, out7);
     return hipGetLastError();
 }
 
@@ -336,7 +338,7 @@ hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64
 // records of a scan of small windows around the replacements.  For kept match j of a haystack (new-text coordinates,
 // dst_j = start of its replacement, rl = replacement length):
 //   own range  (dst_j, min(dst_j + rl + ov, dst_{j+1}, newlen)]     end positions re-derived from window j
-//   window     [dst_j - ov (moved back to a code-point boundary), upper end of the own range)
+//   window     [dst_j - ov, upper end of the own range)
 //   old records with end in (src_start_j, src_start_j + src_len_j + ov] are dropped, the others shift with the text.
 // k_rp_win_meta lays the windows out, k_rp_win_copy gathers their text into a small batch (scanned by k_sf like any
 // other batch), k_rp_merge<false/true> counts / writes the next pass's sorted record list.
@@ -347,7 +349,7 @@ __global__ void __launch_bounds__(256) k_rp_win_count(const RpHay* __restrict__ 
     nwin[h] = (h < n_act && hs[h].status == kRpActive) ? hs[h].nkept : 0u;
 }
 
-__global__ void __launch_bounds__(256) k_rp_win_meta(RpTables t, const uint8_t* __restrict__ text_next, const uint64_t* __restrict__ offs_next, RpRouted rt,
+__global__ void __launch_bounds__(256) k_rp_win_meta(RpTables t, RpRouted rt,
                                                      const RpHay* __restrict__ hs, const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
                                                      const uint64_t* __restrict__ win_off, uint32_t ov, RpWin* __restrict__ wins, uint32_t* __restrict__ wlen,
                                                      uint32_t n_act)
@@ -359,15 +361,15 @@ __global__ void __launch_bounds__(256) k_rp_win_meta(RpTables t, const uint8_t* 
     const RpHay s = hs[h];
     if (s.status != kRpActive) return;
     const RpKept* K = kept + rec_first[h];
-    const uint64_t base = offs_next[rt.act_idx[h]], w0 = win_off[h];
+    const uint64_t base = rt.off_next[h], w0 = win_off[h];      // where the haystack will start in the next text
     const uint64_t rl = t.payloads[s.payload].repl_len;
     for (uint32_t j = lane; j < s.nkept; j += kWave) {
         const uint64_t dst = K[j].dst;
         uint64_t hi = dst + rl + ov;
         if (hi > s.newlen) hi = s.newlen;
         if (j + 1 < s.nkept && K[j + 1].dst < hi) hi = K[j + 1].dst;
-        uint64_t ws = dst > ov ? dst - ov : 0;
-        while (ws > 0 && (text_next[base + ws] & 0xC0u) == 0x80u) ws--;
+        // a window may start inside a code point: k_sf compares bytes, and no needle starts with a continuation byte
+        const uint64_t ws = dst > ov ? dst - ov : 0;
         RpWin w; w.src_abs = base + ws; w.ws = ws;
         w.len = hi > dst ? (uint32_t)(hi - ws) : 0u;                // empty own range: nothing to scan
         w.own_lo = (uint32_t)(dst - ws);
@@ -446,10 +448,10 @@ hipError_t launch_rp_win_count(const RpHay* hs, uint32_t n_act, uint32_t* nwin, 
     return hipGetLastError();
 }
 
-hipError_t launch_rp_win_meta(const RpTables& t, const uint8_t* text_next, const uint64_t* offs_next, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
+hipError_t launch_rp_win_meta(const RpTables& t, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
                               const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rp_win_meta, dim3((n_act + 1 + 3) / 4), dim3(256), 0, st, t, text_next, offs_next, rt, hs, rec_first, kept, win_off, ov, wins, wlen, n_act);
+    hipLaunchKernelGGL(k_rp_win_meta, dim3((n_act + 1 + 3) / 4), dim3(256), 0, st, t, rt, hs, rec_first, kept, win_off, ov, wins, wlen, n_act);
     return hipGetLastError();
 }
 
