@@ -225,10 +225,10 @@ def bench_replacer(args, w, rank, world, dev):
     last = {}
 
     def step():
+        if "res" in last:                                  # hand the previous result's pinned slabs back first, as a caller would
+            lib.am_replaced_free(last.pop("res"))
         res = C.c_void_p()
         am.api.check(lib.am_replacer_run_batch(rdev, batch, C.c_uint64(2**64 - 1), C.byref(res)))
-        if "res" in last:
-            lib.am_replaced_free(last["res"])
         last["res"] = res
         return int(lib.am_replaced_passes(res)), int(lib.am_replaced_scanned_bytes(res))
 
