@@ -6,6 +6,6 @@ for a in $1; do
 import sys, json
 for l in sys.stdin:
     d = json.loads(l); r = d['roofline']
-    print('ablate $a variant ${2:-10}: count-only %.1f GiB/s  k_sf %.3f ms/launch' % (d['count_only_gibps'], r['avg_launch_ms']))
+    print('ablate $a: count-only %.1f GiB/s  k_sf %.3f ms/launch' % (d['count_only_gibps'], r['avg_launch_ms']))
 "
 done
