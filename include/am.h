@@ -84,8 +84,9 @@ const char* am_last_error(void);
  *   offsets       machineOffsets, n_states + 1 entries (scanl, :170)
  *   root_ascii    machineRootAsciiTransitions, 128 entries
  *   values_len    length (machineValues ! s) for every state (the values themselves stay in Haskell)
- * and flattens them into the device image (column-major suffix tables, reversed-needle trie, LDS
- * filter).  The image for each case mode is built and uploaded on first use. */
+ * and flattens them into the device image (LDS filter, cuckoo fingerprint table and Patricia trie of
+ * the reversed needles, goto hash of the general path).  The image for each case mode
+ * is built and uploaded on first use. */
 int am_automaton_create(const uint64_t* transitions, size_t n_transitions,
                         const uint32_t* offsets, size_t n_states,
                         const uint64_t* root_ascii,
