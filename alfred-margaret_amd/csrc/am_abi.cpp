@@ -1157,7 +1157,7 @@ extern "C" int am_run_priority(const am_replacer* r, const am_slice* hay, size_t
     const uint32_t n = (uint32_t)n_hay;
     const uint64_t n1 = (uint64_t)n + 1;
     DevBuf records, rec_first, kept, hs, nk, off, thr, best, out, tmp;
-    struct Release { std::initializer_list<DevBuf*> l; ~Release() { for (DevBuf* d : l) d->release(); } } rel{{&records, &rec_first, &kept, &hs, &nk, &off, &thr, &best, &out, &tmp}};
+    struct Release { std::vector<DevBuf*> l; ~Release() { for (DevBuf* d : l) d->release(); } } rel{{&records, &rec_first, &kept, &hs, &nk, &off, &thr, &best, &out, &tmp}};
     uint64_t n_rec = 0;
     auto sink = [&](uint64_t k, Record** ptr) -> int { AM_TRY(records.ensure(k * sizeof(Record))); *ptr = (Record*)records.p; return AM_OK; };
     AM_TRY(run_records(r->a, r->case_mode, b, sink, &n_rec));

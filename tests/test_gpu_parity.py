@@ -527,3 +527,29 @@ def test_run_priority_single_pass():
             exp += sorted(sel)
         assert [int(x) for x in best] == exp_best, (case, pairs, thresholds)
         assert got == exp, (case, pairs)
+
+
+def test_shared_handles_from_several_threads():
+    """Handles are immutable after creation: several host threads may share one automaton / replacer (include/am.h)."""
+    from concurrent.futures import ThreadPoolExecutor
+    needles = synth.needles_for("cfg2_runText_10k_1GiB")[:3000]
+    a = am.Automaton(needles)
+    s = am.Searcher(1, [n.lower() if isinstance(n, str) else n for n in needles])
+    pairs = [(n, "<%d>" % i) for i, n in enumerate(needles[:200])]
+    r = am.Replacer(0, pairs)
+    texts = [bytes(synth.haystacks_host(needles, False, 64 * i, 64)) for i in range(6)]
+    exp_counts = [int(a.count_matches(0, [t])[0]) for t in texts]
+    exp_recs = [a.run_records(0, [t]) for t in texts]
+    exp_any = [bool(s.contains_any(t)) for t in texts]
+    exp_rep = [r.run(t[:8192]) for t in texts]
+
+    def work(i):
+        k = i % len(texts)
+        assert int(a.count_matches(0, [texts[k]])[0]) == exp_counts[k]
+        assert np.array_equal(a.run_records(0, [texts[k]]), exp_recs[k])
+        assert bool(s.contains_any(texts[k])) == exp_any[k]
+        assert r.run(texts[k][:8192]) == exp_rep[k]
+        return True
+
+    with ThreadPoolExecutor(6) as pool:
+        assert all(pool.map(work, range(48)))
