@@ -149,6 +149,7 @@ struct am_automaton {
 struct am_batch {
     void* d_text = nullptr; uint64_t* d_offsets = nullptr;
     bool owns = false;
+    bool hidx_ready = false;     // the per-KiB haystack index depends only on the offsets: built once per batch
     uint64_t total = 0; uint32_t n_hay = 0;
     std::mutex mu;              // guards the workspaces below (calls on one batch serialise)
     DevBuf text_buf, offs_buf;  // backing store of d_text / d_offsets when the batch owns them
@@ -156,9 +157,31 @@ struct am_batch {
 };
 
 struct am_matches {
-    Record* d_records = nullptr; uint64_t n = 0;
+    Record* d_records = nullptr; uint64_t n = 0; size_t cap_bytes = 0;
     std::vector<am_match> host; bool fetched = false;
 };
+
+// The record array of the last freed result is kept for the next call (one buffer, reused when it is large enough
+// and not more than twice what is needed): a caller that scans batch after batch does not pay hipMalloc/hipFree of
+// hundreds of megabytes per call.
+namespace {
+struct RecordCache {
+    std::mutex mu; void* p = nullptr; size_t cap = 0;
+    void* take(size_t need, size_t* cap_out)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (p && cap >= need && cap <= 2 * need + (1u << 20)) { void* r = p; *cap_out = cap; p = nullptr; cap = 0; return r; }
+        return nullptr;
+    }
+    void give(void* q, size_t c)
+    {
+        void* old = nullptr;
+        { std::lock_guard<std::mutex> lk(mu); old = p; p = q; cap = c; }
+        if (old) (void)hipFree(old);
+    }
+};
+RecordCache g_record_cache;
+}  // namespace
 
 // ------------------------------------------------------------------ automaton
 
@@ -300,6 +323,7 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
 
 static int finish_batch(am_batch* b)
 {
+    b->hidx_ready = false;
     if (b->total > 0) AM_TRY(b->hidx.ensure(((b->total >> kHidxShift) + 2) * sizeof(uint32_t)));
     return AM_OK;
 }
@@ -477,8 +501,10 @@ int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st
 
 int build_hidx(const Plan& p, am_batch* b, hipStream_t st)
 {
+    if (b->hidx_ready) return AM_OK;
     Prof pr("hidx", st);
     HIP_TRY(launch_hidx(p.bv, (uint32_t*)b->hidx.p, (b->total >> kHidxShift) + 2, st));
+    b->hidx_ready = true;
     return AM_OK;
 }
 
@@ -625,8 +651,13 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
     if (!cb) return fail(AM_ERR_INVALID, "null batch");
     am_matches* m = new am_matches();
     auto sink = [&](uint64_t total, Record** ptr) -> int {
-        hipError_t e = hipMalloc((void**)&m->d_records, total * sizeof(Record));
-        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e));
+        const size_t need = total * sizeof(Record);
+        m->d_records = (Record*)g_record_cache.take(need, &m->cap_bytes);
+        if (!m->d_records) {
+            m->cap_bytes = need + need / 16;
+            hipError_t e = hipMalloc((void**)&m->d_records, m->cap_bytes);
+            if (e != hipSuccess) { m->d_records = nullptr; return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e)); }
+        }
         *ptr = m->d_records;
         return AM_OK;
     };
@@ -692,7 +723,7 @@ extern "C" const void* am_matches_device_data(const am_matches* m) { return m ? 
 extern "C" void am_matches_free(am_matches* m)
 {
     if (!m) return;
-    if (m->d_records) (void)hipFree(m->d_records);
+    if (m->d_records) g_record_cache.give(m->d_records, m->cap_bytes);
     delete m;
 }
 

@@ -110,7 +110,8 @@ int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_h
 int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out);
 /* Borrow a batch that already lives in HBM: d_bytes = concatenated haystacks (16-byte aligned,
  * readable up to round_up(total, 16) bytes), d_offsets = n_hay + 1 ascending uint64 byte offsets
- * with d_offsets[0] == 0 and d_offsets[n_hay] == total_bytes. */
+ * with d_offsets[0] == 0 and d_offsets[n_hay] == total_bytes.  The offsets must not change while the batch
+ * exists (the text may). */
 int am_batch_from_device(const void* d_bytes, const void* d_offsets, size_t n_hay, uint64_t total_bytes, am_batch** out);
 void am_batch_destroy(am_batch* b);
 uint64_t am_batch_total_bytes(const am_batch* b);
