@@ -447,7 +447,17 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         // 4-byte suffixes: (2,2) cuckoo hashing -- 2 candidate buckets of 2 slots per key, ~75 % full.
         // HOT side: 4 bytes per slot = 8 B per bucket; for 100k needles that is 0.5 MiB, resident in
         // every XCD's L2 next to the streamed haystack.  COLD side: full keys + node ids, 16 B per bucket.
-        const std::vector<TierEntry>& ents = tier_entries[3];
+        // Entries: one per key first (`edge` = 0: the node as a whole).  A depth-4 node that branches (2-4 children, no
+        // needle end) is upgraded afterwards to one entry PER CHILD (`edge` = i + 1), each fixing that child's selector
+        // byte, wherever its four candidate slots have room: under IgnoreCase every needle letter with several encodings
+        // before the suffix (k/K/KELVIN SIGN, i/I/İ, any non-ASCII letter) makes such a node, and left as "always look
+        // closer" entries they are half of the candidates that reach phase 2.  The copies share key and node; the probe
+        // ORs over the four candidate slots anyway.
+        struct HotEntry { uint32_t key, node, edge; };
+        std::vector<HotEntry> ents;
+        ents.reserve(tier_entries[3].size() + tier_entries[3].size() / 4);
+        for (const TierEntry& e : tier_entries[3]) ents.push_back(HotEntry{e.key, e.node, 0});
+        const size_t n_base = ents.size();
         uint32_t lb = 2;
         while (((uint64_t)2 << lb) * 75 < (uint64_t)ents.size() * 100) lb++;
         std::vector<uint32_t> owner;          // slot -> entry index
@@ -456,7 +466,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             owner.assign((size_t)2 << lb, kNone);
             bool ok = true;
             uint32_t rng = 0x12345u;
-            for (uint32_t k = 0; k < ents.size() && ok; k++) {
+            for (uint32_t k = 0; k < n_base && ok; k++) {
                 uint32_t cur = k;
                 uint32_t bucket = t4_bucket(t4_hash_a(ents[cur].key), lb);
                 for (int kicks = 0;; kicks++) {
@@ -465,7 +475,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     for (uint32_t bsel : {ba, bb}) {
                         for (uint32_t j = 0; j < 2 && !placed; j++) {
                             uint32_t& o = owner[2u * bsel + j];
-                            if (o != kNone && ents[o].key == ents[cur].key) { err = "duplicate suffix key (internal error)"; return -1; }
+                            if (o != kNone && ents[o].key == ents[cur].key && ents[o].edge == ents[cur].edge) { err = "duplicate suffix key (internal error)"; return -1; }
                             if (o == kNone) { o = cur; placed = true; }
                         }
                         if (placed) break;
@@ -480,12 +490,46 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             }
             if (ok) break;
         }
+        // upgrade branching nodes: free slots among the key's four candidates, plus slots freed by moving a neighbour
+        // to a free slot of ITS other bucket (one step, no chains)
+        {
+            std::vector<uint32_t> where(n_base, kNone);
+            for (size_t sl = 0; sl < owner.size(); sl++) if (owner[sl] != kNone) where[owner[sl]] = (uint32_t)sl;
+            for (uint32_t k = 0; k < n_base; k++) {
+                const SfNode& nd = nodes[ents[k].node];
+                const uint32_t c = nd.w & 0xFFFFu;
+                if (nd.x || c < 2 || c > 4) continue;
+                const uint32_t ba = t4_bucket(t4_hash_a(ents[k].key), lb), bb = t4_bucket(t4_hash_b(ents[k].key), lb);
+                uint32_t cand[4] = {2u * ba, 2u * ba + 1u, 2u * bb, 2u * bb + 1u};
+                const uint32_t n_cand = ba == bb ? 2u : 4u;
+                std::vector<uint32_t> room;
+                for (uint32_t i = 0; i < n_cand; i++) if (owner[cand[i]] == kNone) room.push_back(cand[i]);
+                for (uint32_t i = 0; i < n_cand && room.size() + 1 < c; i++) {
+                    const uint32_t o = owner[cand[i]];
+                    if (o == kNone || o == k || ents[o].key == ents[k].key) continue;
+                    const uint32_t oa = t4_bucket(t4_hash_a(ents[o].key), lb), ob = t4_bucket(t4_hash_b(ents[o].key), lb);
+                    const uint32_t other = (cand[i] >> 1) == oa ? ob : oa;
+                    if (other == ba || other == bb) continue;
+                    for (uint32_t j = 0; j < 2; j++) {
+                        if (owner[2u * other + j] != kNone) continue;
+                        owner[2u * other + j] = o;
+                        if (o < n_base) where[o] = 2u * other + j;
+                        owner[cand[i]] = kNone;
+                        room.push_back(cand[i]);
+                        break;
+                    }
+                }
+                if (room.size() + 1 < c) continue;                         // no room: the node keeps its single entry
+                ents[k].edge = 1;
+                for (uint32_t i = 1; i < c; i++) { owner[room[i - 1]] = (uint32_t)ents.size(); ents.push_back(HotEntry{ents[k].key, ents[k].node, i + 1}); }
+            }
+        }
         h.tier_log2_cap[3] = lb;
         std::vector<u32x2> hot((size_t)1 << lb, u32x2{0, 0});
         std::vector<u32x4> cold((size_t)1 << lb, u32x4{0, 0, kNone, kNone});
         for (size_t sl = 0; sl < owner.size(); sl++) {
             if (owner[sl] == kNone) continue;
-            const TierEntry& e = ents[owner[sl]];
+            const HotEntry& e = ents[owner[sl]];
             const SfNode& nd = nodes[e.node];
             const uint32_t n_edges = nd.w & 0xFFFFu;
             // bytes before the 4-byte suffix that every needle through this node fixes (0 when a needle ends here or the
@@ -498,6 +542,15 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 if (skip >= 1) { fixed = 2; sel2 = nd.label[3] >> 24; }       // walk order byte 0 = last label byte in text order
                 else {
                     const SfNode& ch = nodes[nd.z];
+                    if (!ch.x && (ch.w & 0xFFFFu) == 1u) { fixed = 2; sel2 = (ch.w >> 16) & 0xFFu; }
+                }
+            }
+            if (e.edge) {                                                      // one child of a branching node
+                const SfEdge& ed = edges_out[nd.z + e.edge - 1];
+                fixed = 1; sel1 = ed.byte & 0xFFu;
+                if (ed.skip >= 1) { fixed = 2; sel2 = ed.label[3] >> 24; }
+                else {
+                    const SfNode& ch = nodes[ed.child];
                     if (!ch.x && (ch.w & 0xFFFFu) == 1u) { fixed = 2; sel2 = (ch.w >> 16) & 0xFFu; }
                 }
             }
