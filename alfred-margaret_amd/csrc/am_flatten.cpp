@@ -445,7 +445,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     }
     {
         // 4-byte suffixes: (2,2) cuckoo hashing -- 2 candidate buckets of 2 slots per key, ~75 % full.
-        // HOT side: 4 bytes per slot = 8 B per bucket; for 100k needles that is 0.5 MiB, resident in
+        // HOT side: 4 bytes per slot = 8 B per bucket; for 100k needles that is 1 MiB, resident in
         // every XCD's L2 next to the streamed haystack.  COLD side: full keys + node ids, 16 B per bucket.
         // Entries: one per key first (`edge` = 0: the node as a whole).  A depth-4 node that branches (2-4 children, no
         // needle end) is upgraded afterwards to one entry PER CHILD (`edge` = i + 1), each fixing that child's selector

@@ -108,7 +108,7 @@ struct SfView {
     const uint32_t* bloom;
     const u32x2* tier[3];    // exact tables for needles (variants) of exactly 1, 2, 3 bytes
     // 4-byte suffixes: (2,2) cuckoo table.  A key lives in one of the 2 slots of bucket_a(key) or
-    // bucket_b(key).  HOT side (what the probe reads, 8 B per bucket, ~0.5 MiB for 100k needles, so
+    // bucket_b(key).  HOT side (what the probe reads, 8 B per bucket, ~1 MiB for 100k needles, so
     // it stays in each XCD's L2): per slot an 11-bit fingerprint, flags, and the next TWO bytes the
     // trie requires after the 4-byte suffix when it is a plain chain there.  COLD side (read only
     // when a needle may really end at the position): the full keys and the node ids.
