@@ -1034,16 +1034,12 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         { Prof pr("rp_pass", st);
           HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, (const uint64_t*)s.rec_first.p, cur_thr,
                                  max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st)); }
-        { Prof pr("rp_scans", st);
-          HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_next, (uint64_t*)s.off_next.p, n1, st));
-          HIP_TRY(launch_scan64(s.scan_tmp.p, tmp_bytes, route.len_fin, (uint64_t*)s.off_fin.p, n1, st));
-          HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.tiles, (uint64_t*)s.tile_off.p, n1, st));
-          HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.act, (uint64_t*)s.act_idx.p, n1, st));
-          HIP_TRY(launch_scan(s.scan_tmp.p, tmp_bytes, route.fin, (uint64_t*)s.fin_idx.p, n1, st)); }
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
         // windows of the incremental re-scan (their geometry follows from the kept matches alone, the text is copied after the splice)
         const bool try_inc = inc_enabled && n_rec > 0;
+        const bool small = n1 <= (1u << 18);          // bookkeeping sums in one launch (k_scan_jobs) instead of a dozen hipcub launches
         size_t tmp2 = tmp_bytes;
+        uint64_t woffs_last = n_rec;
         if (try_inc) {
             AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8));
             AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
@@ -1051,16 +1047,42 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
             if (scan_temp_bytes(n_rec + 1, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
             AM_TRY(s.scan_tmp.ensure(std::max(tw, tmp_bytes) + 16));
             tmp2 = s.scan_tmp.cap - 16;
-            Prof pr("rp_windows", st);
             HIP_TRY(launch_rp_win_count((const RpHay*)s.hs.p, n_act, (uint32_t*)s.nwin.p, st));
-            HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.nwin.p, (uint64_t*)s.win_off.p, n1, st));
-            HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));           // at most one window per record; unused entries scan as zeros
+        }
+        { Prof pr("rp_scans", st);
+          if (small) {
+              ScanJobs jobs{};
+              jobs.j[0] = ScanJob{nullptr, route.len_next, (uint64_t*)s.off_next.p, n1, nullptr};
+              jobs.j[1] = ScanJob{nullptr, route.len_fin, (uint64_t*)s.off_fin.p, n1, nullptr};
+              jobs.j[2] = ScanJob{route.tiles, nullptr, (uint64_t*)s.tile_off.p, n1, nullptr};
+              jobs.j[3] = ScanJob{route.act, nullptr, (uint64_t*)s.act_idx.p, n1, nullptr};
+              jobs.j[4] = ScanJob{route.fin, nullptr, (uint64_t*)s.fin_idx.p, n1, nullptr};
+              jobs.n_jobs = 5;
+              if (try_inc) { jobs.j[5] = ScanJob{(const uint32_t*)s.nwin.p, nullptr, (uint64_t*)s.win_off.p, n1, nullptr}; jobs.n_jobs = 6; }
+              HIP_TRY(launch_scan_jobs(jobs, st));
+          } else {
+              HIP_TRY(launch_scan64(s.scan_tmp.p, tmp2, route.len_next, (uint64_t*)s.off_next.p, n1, st));
+              HIP_TRY(launch_scan64(s.scan_tmp.p, tmp2, route.len_fin, (uint64_t*)s.off_fin.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, route.tiles, (uint64_t*)s.tile_off.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, route.act, (uint64_t*)s.act_idx.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, route.fin, (uint64_t*)s.fin_idx.p, n1, st));
+              if (try_inc) HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.nwin.p, (uint64_t*)s.win_off.p, n1, st));
+          } }
+        if (try_inc) {
+            Prof pr("rp_windows", st);
+            if (!small) HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));     // at most one window per record; unused entries scan as zeros
             HIP_TRY(launch_rp_win_meta(r->t, rt, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p,
                                        (const uint64_t*)s.win_off.p, ov, (RpWin*)s.wins.p, (uint32_t*)s.wlen.p, n_act, st));
-            HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st));
+            if (small) {          // exactly n_win + 1 elements: the count is read on the device
+                ScanJobs jobs{};
+                jobs.j[0] = ScanJob{(const uint32_t*)s.wlen.p, nullptr, (uint64_t*)s.woffs.p, 1, (const uint64_t*)s.win_off.p + n_act};
+                jobs.n_jobs = 1;
+                HIP_TRY(launch_scan_jobs(jobs, st));
+                woffs_last = ~0ull;
+            } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st));
         }
         // bytes of next text, bytes of finished text, tiles, haystacks still active, haystacks finished, windows, window bytes
-        HIP_TRY(launch_rp_totals(rt, n_act, try_inc ? (const uint64_t*)s.win_off.p : nullptr, try_inc ? (const uint64_t*)s.woffs.p : nullptr, n_rec,
+        HIP_TRY(launch_rp_totals(rt, n_act, try_inc ? (const uint64_t*)s.win_off.p : nullptr, try_inc ? (const uint64_t*)s.woffs.p : nullptr, woffs_last,
                                  (uint64_t*)s.totals.p, st));
         HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 56, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -1122,7 +1144,12 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
             HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
                                     (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
                                     (uint32_t*)s.mcount.p, nullptr, nullptr, st));
-            HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st));
+            if (n_next + 1 <= (1u << 18)) {
+                ScanJobs jobs{};
+                jobs.j[0] = ScanJob{(const uint32_t*)s.mcount.p, nullptr, (uint64_t*)s.moff.p, n_next + 1, nullptr};
+                jobs.n_jobs = 1;
+                HIP_TRY(launch_scan_jobs(jobs, st));
+            } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st));
             HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
                                     (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
                                     (uint32_t*)s.mcount.p, (const uint64_t*)s.moff.p, (Record*)next_records.p, st));

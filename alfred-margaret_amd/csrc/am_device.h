@@ -88,6 +88,10 @@ hipError_t launch_rp_win_copy(const RpWin* wins, const uint64_t* woffs, const ui
 hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_first, const RpKept* kept, const RpHay* hs, const uint64_t* offsets, const RpRouted& rt,
                            const uint64_t* win_off, const RpWin* wins, const Record* wrecs, const uint64_t* wrec_first, uint32_t ov, uint32_t n_act,
                            uint32_t* mcount, const uint64_t* moff, Record* out, hipStream_t st);
+// several small exclusive sums in one launch: out[i] = sum of in[0..i), for i < n (+ *n_dev when given)
+struct ScanJob { const uint32_t* in32; const uint64_t* in64; uint64_t* out; uint64_t n; const uint64_t* n_dev; };
+struct ScanJobs { ScanJob j[6]; uint32_t n_jobs; };
+hipError_t launch_scan_jobs(const ScanJobs& jobs, hipStream_t st);
 hipError_t scan64_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t st);
 

@@ -262,7 +262,8 @@ __global__ void k_rp_totals(RpRouted rt, uint32_t n_act, const uint64_t* __restr
                             uint64_t* __restrict__ out7)
 {
     out7[0] = rt.off_next[n_act]; out7[1] = rt.off_fin[n_act]; out7[2] = rt.tile_off[n_act]; out7[3] = rt.act_idx[n_act]; out7[4] = rt.fin_idx[n_act];
-    out7[5] = win_off ? win_off[n_act] : 0; out7[6] = woffs ? woffs[woffs_last] : 0;       // windows of the incremental re-scan and their bytes
+    out7[5] = win_off ? win_off[n_act] : 0;                                                  // windows of the incremental re-scan and their bytes
+    out7[6] = woffs ? woffs[woffs_last == ~0ull ? win_off[n_act] : woffs_last] : 0;          // (~0: the scan stopped at the last window)
 }
 
 hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out7, hipStream_t st)
@@ -515,6 +516,48 @@ hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_nee
 {
     if (n_hay == 0) return hipSuccess;
     hipLaunchKernelGGL(k_idset_all, dim3((n_hay + 3) / 4), dim3(256), 0, st, bits, words, n_needles, n_hay, flags);
+    return hipGetLastError();
+}
+
+// ---- several small exclusive sums in ONE launch (the Replacer's per-pass bookkeeping: a dozen hipcub launches otherwise).
+// One 1024-thread workgroup per job walks its array in tiles of 4096 elements: 4 elements per thread, wave scan with
+// shuffles, wave totals through LDS, running carry.  Meant for arrays up to a few hundred thousand elements.
+__global__ void __launch_bounds__(1024) k_scan_jobs(ScanJobs jobs)
+{
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry_s;
+    const ScanJob j = jobs.j[blockIdx.x];
+    const uint64_t n = j.n_dev ? *j.n_dev + j.n : j.n;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 4096) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
+        uint64_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t i = i0 + k;
+            v[k] = i < n ? (j.in64 ? j.in64[i] : (uint64_t)j.in32[i]) : 0ull;
+        }
+        const uint64_t mine = v[0] + v[1] + v[2] + v[3];
+        int64_t incl = wave_inclusive_sum_i64((int64_t)mine, lane);
+        if (lane == kWave - 1) wave_tot[wave] = (uint64_t)incl;
+        __syncthreads();
+        uint64_t before = carry_s;
+        for (int w = 0; w < wave; w++) before += wave_tot[w];
+        uint64_t run = before + (uint64_t)incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const uint64_t i = i0 + k; if (i < n) j.out[i] = run; run += v[k]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;        // the last thread's running sum = everything so far
+        __syncthreads();
+    }
+}
+
+hipError_t launch_scan_jobs(const ScanJobs& jobs, hipStream_t st)
+{
+    if (jobs.n_jobs == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_jobs, dim3(jobs.n_jobs), dim3(1024), 0, st, jobs);
     return hipGetLastError();
 }
 
