@@ -553,3 +553,19 @@ def test_shared_handles_from_several_threads():
 
     with ThreadPoolExecutor(6) as pool:
         assert all(pool.map(work, range(48)))
+
+
+def test_replacer_many_tiny_haystacks_large_bookkeeping():
+    """More than 2^18 haystacks: the per-pass bookkeeping goes through the hipcub scans instead of the single-launch
+    k_scan_jobs; same answers."""
+    pairs = [("ab", "X"), ("Xc", "ba"), ("b", "yy"), ("zz", "")]
+    distinct = ["", "a", "ab", "abc", "cab", "abcab", "zzabzz", "bbbb", "Xc", "abab" * 3]
+    o = oracle.Replacer(0, pairs)
+    exp = {d: o.run(d) for d in distinct}
+    n = (1 << 18) + 1500
+    hays = [distinct[(i * 7 + i // 11) % len(distinct)] for i in range(n)]
+    r = am.Replacer(0, pairs)
+    got = r.run_batch(hays)
+    assert len(got) == n
+    bad = [i for i in range(n) if got[i] != exp[hays[i]]]
+    assert not bad, (bad[:5], [got[i] for i in bad[:5]])
