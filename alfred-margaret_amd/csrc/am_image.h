@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 3;
+constexpr uint32_t kImageVersion = 4;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -202,18 +202,28 @@ AM_HD uint32_t fold_dword(uint32_t x)
 constexpr uint32_t kBloomMul = 0x9E3779B1u;
 AM_HD uint32_t bloom_hash(uint32_t key, uint32_t tier) { return (key + (4u - tier) * 0x7F4A7C15u) * kBloomMul; }
 AM_HD uint32_t bloom_word(uint32_t h, uint32_t log2_words) { return h >> (32u - log2_words); }
-// three bits of one 32-bit word; the fields sit where the kernel can use them as shift amounts with the fewest
-// instructions (a variable shift reads only the low 5 bits of its amount, so `h` itself serves as the third field)
-AM_HD uint32_t bloom_mask(uint32_t h) { return (1u << ((h >> 12) & 31u)) | (1u << ((h >> 7) & 31u)) | (1u << (h & 31u)); }
-// 1 iff all three bits of h are set in the filter word v
-AM_HD uint32_t bloom_hit(uint32_t v, uint32_t h)
+// Bits per key in one 32-bit filter word: three for the full 128-KiB filter (many keys), two for the smaller filters of
+// small automata (they are sparse enough, and every bit costs two VALU instructions per haystack position).  The fields
+// sit where the kernel can use them as shift amounts with the fewest instructions (a variable shift reads only the low
+// 5 bits of its amount, so `h` itself serves as one field).
+AM_HD bool bloom_three_bits(uint32_t log2_words) { return log2_words >= 15u; }
+AM_HD uint32_t bloom_mask(uint32_t h, bool three)
+{
+    return (1u << ((h >> 12) & 31u)) | (1u << (h & 31u)) | (three ? 1u << ((h >> 7) & 31u) : 0u);
+}
+// 1 iff all bits of h are set in the filter word v
+template <bool THREE>
+AM_HD uint32_t bloom_hit_k(uint32_t v, uint32_t h)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_ubfe(v, h >> 12, 1u) & (v >> ((h >> 7) & 31u)) & (v >> (h & 31u));
+    const uint32_t two = __builtin_amdgcn_ubfe(v, h >> 12, 1u) & (v >> (h & 31u));
+    return THREE ? two & (v >> ((h >> 7) & 31u)) : two;
 #else
-    return ((v >> ((h >> 12) & 31u)) & (v >> ((h >> 7) & 31u)) & (v >> (h & 31u))) & 1u;
+    const uint32_t two = (v >> ((h >> 12) & 31u)) & (v >> (h & 31u));
+    return (THREE ? two & (v >> ((h >> 7) & 31u)) : two) & 1u;
 #endif
 }
+AM_HD uint32_t bloom_hit(uint32_t v, uint32_t h, bool three) { return three ? bloom_hit_k<true>(v, h) : bloom_hit_k<false>(v, h); }
 
 AM_HD uint32_t tier_slot(uint32_t key, uint32_t log2_cap) { return (key * 0x85EBCA6Bu) >> (32u - log2_cap); }
 
@@ -611,7 +621,7 @@ AM_HD bool sf_filter_short(const uint32_t* bloom, uint32_t log2_words, uint32_t 
     for (uint32_t t = 1; t <= 3; t++) {
         if (tiers & (1u << (t - 1))) {
             const uint32_t h = bloom_hash(w >> (8u * (4u - t)), t);
-            hit = hit || bloom_hit(bloom[bloom_word(h, log2_words)], h);
+            hit = hit || bloom_hit(bloom[bloom_word(h, log2_words)], h, bloom_three_bits(log2_words));
         }
     }
     return hit;
@@ -619,7 +629,7 @@ AM_HD bool sf_filter_short(const uint32_t* bloom, uint32_t log2_words, uint32_t 
 AM_HD bool sf_filter_window(const uint32_t* bloom, uint32_t log2_words, uint32_t tiers, uint32_t w)
 {
     const uint32_t h = bloom_hash(w, 4);
-    bool hit = (tiers & 8u) && bloom_hit(bloom[bloom_word(h, log2_words)], h);
+    bool hit = (tiers & 8u) && bloom_hit(bloom[bloom_word(h, log2_words)], h, bloom_three_bits(log2_words));
     if (tiers & 7u) hit = hit || sf_filter_short(bloom, log2_words, tiers, w);
     return hit;
 }

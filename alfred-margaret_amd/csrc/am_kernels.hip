@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     else v[k] = bloom[h[k] >> sh_word];
                 }
 #pragma unroll
-                for (int k = 15; k >= 0; k--) cand = (cand << 1) | bloom_hit(v[k], h[k]);      // bit k of cand = position k
+                for (int k = 15; k >= 0; k--) cand = (cand << 1) | bloom_hit_k<LW == 15>(v[k], h[k]);      // bit k of cand = position k (LW = 0 instances only run filters below 128 KiB: two bits per key)
             }
             if (SHORT) {                                   // automata with 1..3-byte needles: extra probes per position
 #pragma unroll
@@ -507,8 +507,10 @@ template <bool IC, int MODE>
 static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const bool lw15 = s.bloom_log2_words == 15;
-    if ((o.ablate || o.dbg) && MODE != kModeAny)                                            // experiments (AM_SF_ABLATE)
-        return lw15 && !(s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
+    if ((o.ablate || o.dbg) && MODE != kModeAny) {                                          // experiments (AM_SF_ABLATE)
+        if (!lw15) return launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
+        return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, true, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st);
+    }
     if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
         return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
