@@ -810,6 +810,11 @@ struct am_replacer {
     int case_mode = 0;
     DevBuf vals_off, vals, payloads, repl;
     RpTables t{};
+    // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
+    // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
+    mutable std::mutex session_mu;
+    mutable void* session = nullptr;
+    void (*session_delete)(void*) = nullptr;
 };
 
 // Finished texts are copied D2H straight into pinned slabs that the result object keeps (no second host
@@ -915,6 +920,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
 extern "C" void am_replacer_destroy(am_replacer* r)
 {
     if (!r) return;
+    if (r->session && r->session_delete) r->session_delete(r->session);
     for (DevBuf* d : {&r->vals_off, &r->vals, &r->payloads, &r->repl}) d->release();
     delete r;
 }
@@ -941,11 +947,18 @@ struct RpSession {
     am_batch ws2;                        // workspace of the window scans
     DevBuf rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
     am_batch ws;                         // workspace holder for the scans; never owns its text
+    DevBuf first_orig, first_thr;
+    size_t device_bytes() const
+    {
+        size_t n = 0;
+        for (const DevBuf* d : {&text[0], &text[1], &recbuf[0], &recbuf[1], &kept, &wins, &wtext, &wrec, &fin_text, &ws.pool, &ws2.pool, &ws.hidx, &ws2.hidx}) n += d->cap;
+        return n;
+    }
     ~RpSession()
     {
         for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &rec_first, &kept, &hs, &len_next, &len_fin,
                           &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff, &tile_hay,
-                          &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta}) d->release();
+                          &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr}) d->release();
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
@@ -965,17 +978,31 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     res->just.assign(n_hay, 1);
     if (n_hay == 0) return AM_OK;
     hipStream_t st; AM_TRY(get_stream(&st));
-    RpSession s;
+    // take the replacer's cached workspace (or make one); it goes back at the end unless it has grown large
+    RpSession* sp = nullptr;
+    { std::lock_guard<std::mutex> lk(r->session_mu); sp = static_cast<RpSession*>(r->session); r->session = nullptr; }
+    if (!sp) sp = new RpSession();
+    struct Return {
+        const am_replacer* r; RpSession* sp;
+        ~Return()
+        {
+            if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
+            if (sp->device_bytes() > (512ull << 20)) { delete sp; return; }
+            RpSession* old = nullptr;
+            { std::lock_guard<std::mutex> lk(r->session_mu); old = static_cast<RpSession*>(r->session); r->session = sp; const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); }; }
+            delete old;
+        }
+    } give_back{r, sp};
+    RpSession& s = *sp;
     AM_TRY(s.totals.ensure(64));
-    if (hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocDefault) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocDefault) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
     // pass 0 reads the caller's batch in place; afterwards the text ping-pongs between s.text[0] and s.text[1]
     const uint8_t* cur_text = (const uint8_t*)in->d_text;
     const uint64_t* cur_offs = in->d_offsets;
     uint64_t total = in->total;
     uint32_t n_act = n_hay;
     int nxt = 0;
-    DevBuf first_orig, first_thr;
-    struct Release { DevBuf &a, &b; ~Release() { a.release(); b.release(); } } rel{first_orig, first_thr};
+    DevBuf& first_orig = s.first_orig; DevBuf& first_thr = s.first_thr;
     {
         std::vector<uint32_t> o(n_hay); std::vector<int64_t> t(n_hay, 1);      // initialThreshold = 1 (Replacer.hs:211)
         for (uint32_t i = 0; i < n_hay; i++) o[i] = i;
@@ -985,7 +1012,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     }
     const uint32_t* cur_orig = (const uint32_t*)first_orig.p;
     const int64_t* cur_thr = (const int64_t*)first_thr.p;
-    if (hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev_spliced, hipEventDisableTiming) != hipSuccess)
+    if (!s.copy_stream && (hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev_spliced, hipEventDisableTiming) != hipSuccess))
         return fail(AM_ERR_HIP, "could not create the copy stream");
     // Incremental re-scan (am_replace.hip): after the first pass only windows around the replacements are scanned and
     // merged with the shifted records of the previous pass.  Needs the suffix-filter kernel's position-local semantics

@@ -38,3 +38,19 @@ for name, hay in (("1 MB", big), ("100 B", big[:100]), ("10 KB", big[:10_000])):
     assert int(counts[0]) == c
     print("%6s haystack: am_count %7.1f us  am_contains_any %7.1f us  am_run %7.1f us   CPU oracle count %9.1f us (%d matches)" %
           (name, t_count * 1e6, t_any * 1e6, t_run * 1e6, t_cpu * 1e6, c))
+
+# Replacer.run on one small document per call
+pairs = [("tshirt", "T-SHIRT"), ("shorts", "pants"), ("quick", "slow"), ("fox", "dog")]
+r = am.Replacer(0, pairs)
+orc = oracle.Replacer(0, pairs)
+for name, hay in (("100 B", big[:100]), ("10 KB", big[:10_000]), ("1 MB", big)):
+    for _ in range(3):
+        out = r.run(hay)
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        out = r.run(hay)
+    t_gpu = (time.perf_counter() - t0) / n
+    t0 = time.perf_counter(); exp = orc.run(hay); t_cpu = time.perf_counter() - t0
+    assert out == exp
+    print("%6s document: Replacer.run %8.1f us (%d passes)   CPU oracle %9.1f us" % (name, t_gpu * 1e6, r.last_stats()[0], t_cpu * 1e6))
