@@ -948,17 +948,19 @@ struct RpSession {
     DevBuf rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
     am_batch ws;                         // workspace holder for the scans; never owns its text
     DevBuf first_orig, first_thr;
+    DevBuf pf_best, pf_delta, pf_payload, pf_selflag, pf_sidx, pf_cand, pf_sel, pf_keep, pf_kflag, pf_kdelta, pf_kidx, pf_kdpre, pf_tmp;   // record-parallel fold
     size_t device_bytes() const
     {
         size_t n = 0;
-        for (const DevBuf* d : {&text[0], &text[1], &recbuf[0], &recbuf[1], &kept, &wins, &wtext, &wrec, &fin_text, &ws.pool, &ws2.pool, &ws.hidx, &ws2.hidx}) n += d->cap;
+        for (const DevBuf* d : {&text[0], &text[1], &recbuf[0], &recbuf[1], &kept, &wins, &wtext, &wrec, &fin_text, &ws.pool, &ws2.pool, &ws.hidx, &ws2.hidx, &pf_cand, &pf_sel, &pf_sidx}) n += d->cap;
         return n;
     }
     ~RpSession()
     {
         for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &rec_first, &kept, &hs, &len_next, &len_fin,
                           &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff, &tile_hay,
-                          &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr}) d->release();
+                          &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr,
+                          &pf_best, &pf_delta, &pf_payload, &pf_selflag, &pf_sidx, &pf_cand, &pf_sel, &pf_keep, &pf_kflag, &pf_kdelta, &pf_kidx, &pf_kdpre, &pf_tmp}) d->release();
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
@@ -1058,9 +1060,40 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         AM_TRY(records.ensure(sizeof(Record)));            // a valid pointer even when nothing matched
         RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
         { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
-        { Prof pr("rp_pass", st);
-          HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, (const uint64_t*)s.rec_first.p, cur_thr,
-                                 max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st)); }
+        // one wavefront per haystack, or -- few haystacks with very many matches each -- parallel over the records
+        bool par_fold = n_rec > 2048ull * n_act;
+        if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;        // tests force either path
+        if (!par_fold) {
+            Prof pr("rp_pass", st);
+            HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, (const uint64_t*)s.rec_first.p, cur_thr,
+                                   max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st));
+        } else {
+            Prof pr("rp_pass", st);
+            const uint64_t nb = n_rec + 2;
+            AM_TRY(s.pf_best.ensure(n1 * 8)); AM_TRY(s.pf_delta.ensure(n1 * 8)); AM_TRY(s.pf_payload.ensure(n1 * 4));
+            AM_TRY(s.pf_selflag.ensure(nb * 4)); AM_TRY(s.pf_sidx.ensure(nb * 8)); AM_TRY(s.pf_cand.ensure(nb * sizeof(RpSel))); AM_TRY(s.pf_sel.ensure(nb * sizeof(RpSel)));
+            AM_TRY(s.pf_keep.ensure(nb * 4)); AM_TRY(s.pf_kflag.ensure(nb * 4)); AM_TRY(s.pf_kdelta.ensure(nb * 8)); AM_TRY(s.pf_kidx.ensure(nb * 8)); AM_TRY(s.pf_kdpre.ensure(nb * 8));
+            size_t t32b = 0, t64b = 0;
+            if (scan_temp_bytes(nb, &t32b) != hipSuccess || scan64_temp_bytes(nb, &t64b) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+            AM_TRY(s.pf_tmp.ensure(std::max(t32b, t64b) + 16));
+            const size_t ptmp = s.pf_tmp.cap - 16;
+            HIP_TRY(hipMemsetAsync(s.pf_delta.p, 0, n1 * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_payload.p, 0, n1 * 4, st));
+            HIP_TRY(hipMemsetAsync(s.pf_kflag.p, 0, nb * 4, st)); HIP_TRY(hipMemsetAsync(s.pf_kdelta.p, 0, nb * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_keep.p, 0, nb * 4, st));
+            HIP_TRY(launch_rpp_best(r->t, (const Record*)records.p, n_rec, cur_thr, (int64_t*)s.pf_best.p, n_act, st));
+            HIP_TRY(launch_rpp_select(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, n_rec, (const int64_t*)s.pf_best.p,
+                                      (uint32_t*)s.pf_selflag.p, (RpSel*)s.pf_cand.p, (int64_t*)s.pf_delta.p, (uint32_t*)s.pf_payload.p, st));
+            HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_selflag.p, (uint64_t*)s.pf_sidx.p, n_rec + 1, st));
+            const uint64_t* n_sel_dev = (const uint64_t*)s.pf_sidx.p + n_rec;
+            HIP_TRY(launch_rpp_compact((const uint32_t*)s.pf_selflag.p, (const uint64_t*)s.pf_sidx.p, (const RpSel*)s.pf_cand.p, n_rec, (RpSel*)s.pf_sel.p, st));
+            HIP_TRY(launch_rpp_overlaps((const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (uint32_t*)s.pf_keep.p, st));
+            HIP_TRY(launch_rpp_kflags((const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_keep.p, r->t, (const uint32_t*)s.pf_payload.p,
+                                      (uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kdelta.p, st));
+            HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kidx.p, n_rec + 2, st));
+            HIP_TRY(launch_scan64(s.pf_tmp.p, ptmp, (const uint64_t*)s.pf_kdelta.p, (uint64_t*)s.pf_kdpre.p, n_rec + 2, st));
+            HIP_TRY(launch_rpp_finish(r->t, (const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_kflag.p, (const uint64_t*)s.pf_kidx.p,
+                                      (const uint64_t*)s.pf_kdpre.p, (const uint64_t*)s.pf_sidx.p, cur_offs, (const uint64_t*)s.rec_first.p, (const int64_t*)s.pf_best.p,
+                                      (const int64_t*)s.pf_delta.p, (const uint32_t*)s.pf_payload.p, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, st));
+        }
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
         // windows of the incremental re-scan (their geometry follows from the kept matches alone, the text is copied after the splice)
         const bool try_inc = inc_enabled && n_rec > 0;

@@ -88,6 +88,19 @@ hipError_t launch_rp_win_copy(const RpWin* wins, const uint64_t* woffs, const ui
 hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_first, const RpKept* kept, const RpHay* hs, const uint64_t* offsets, const RpRouted& rt,
                            const uint64_t* win_off, const RpWin* wins, const Record* wrecs, const uint64_t* wrec_first, uint32_t ov, uint32_t n_act,
                            uint32_t* mcount, const uint64_t* moff, Record* out, hipStream_t st);
+// the record-parallel variant of the fold (few haystacks with very many matches), same outputs as launch_rp_pass
+struct RpSel { uint64_t start, len; uint32_t haystack, pad; };
+hipError_t launch_rpp_best(const RpTables& t, const Record* recs, uint64_t n_rec, const int64_t* thr, int64_t* best /* n_act + 1 */, uint32_t n_act, hipStream_t st);
+hipError_t launch_rpp_select(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, uint64_t n_rec, const int64_t* best,
+                             uint32_t* selflag, RpSel* cand, int64_t* delta_all, uint32_t* payload_of, hipStream_t st);
+hipError_t launch_rpp_compact(const uint32_t* selflag, const uint64_t* sidx, const RpSel* cand, uint64_t n_rec, RpSel* sel, hipStream_t st);
+hipError_t launch_rpp_overlaps(const RpSel* sel, const uint64_t* n_sel_dev, uint64_t bound, uint32_t* keep, hipStream_t st);
+hipError_t launch_rpp_kflags(const RpSel* sel, const uint64_t* n_sel_dev, uint64_t bound, const uint32_t* keep, const RpTables& t, const uint32_t* payload_of,
+                             uint32_t* kflag, uint64_t* kdelta, hipStream_t st);
+hipError_t launch_rpp_finish(const RpTables& t, const RpSel* sel, const uint64_t* n_sel_dev, uint64_t bound, const uint32_t* kflag, const uint64_t* kidx,
+                             const uint64_t* kdpre, const uint64_t* sidx, const uint64_t* offsets, const uint64_t* rec_first, const int64_t* best,
+                             const int64_t* delta_all, const uint32_t* payload_of, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act,
+                             hipStream_t st);
 // several small exclusive sums in one launch: out[i] = sum of in[0..i), for i < n (+ *n_dev when given)
 struct ScanJob { const uint32_t* in32; const uint64_t* in64; uint64_t* out; uint64_t n; const uint64_t* n_dev; };
 struct ScanJobs { ScanJob j[6]; uint32_t n_jobs; };

@@ -168,6 +168,197 @@ __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __re
     }
 }
 
+// ---- the same fold, parallel over RECORDS instead of one wavefront per haystack (few haystacks with very many matches) ----
+// prependMatch: k_rpp_best (atomic max per haystack) and k_rpp_select (which records carry the best priority, makeMatch);
+// removeOverlap: selected matches are sorted by start and all have the same code-point length, so a match that does not
+// overlap its predecessor is kept whatever happened before it; only runs of consecutively overlapping matches need the
+// serial greedy (k_rpp_heads marks the run heads, k_rpp_greedy walks each run); k_rpp_kept / k_rpp_hay write exactly what
+// k_rp_pass writes (kept[], hs[], route), so everything after the fold is shared.
+__global__ void __launch_bounds__(256) k_rpp_best(RpTables t, const Record* __restrict__ recs, uint64_t n_rec, const int64_t* __restrict__ thr,
+                                                  int64_t* __restrict__ best)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t b = INT64_MIN; uint32_t hay = 0xFFFFFFFFu;
+    if (r < n_rec) {
+        const Record rec = recs[r];
+        hay = rec.haystack;
+        const int64_t threshold = thr[hay];
+        for (uint64_t k = t.vals_off[rec.state], ke = t.vals_off[rec.state + 1]; k < ke; k++) {
+            const int64_t p = t.payloads[t.vals[k]].priority;
+            if (p < threshold && p > b) b = p;
+        }
+    }
+    const uint32_t h0 = __shfl(hay, 0, kWave);
+    if (__ballot(hay != h0 && hay != 0xFFFFFFFFu) == 0) {          // the usual case: the whole wavefront inside one haystack
+        b = wave_max_i64(b);
+        if ((threadIdx.x & (kWave - 1)) == 0 && b != INT64_MIN && h0 != 0xFFFFFFFFu) atomicMax((long long*)(best + h0), (long long)b);
+    } else if (b != INT64_MIN) atomicMax((long long*)(best + hay), (long long)b);
+}
+
+template <bool IC>
+__global__ void __launch_bounds__(256) k_rpp_select(RpTables t, const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets,
+                                                    const Record* __restrict__ recs, uint64_t n_rec, const int64_t* __restrict__ best,
+                                                    uint32_t* __restrict__ selflag, RpSel* __restrict__ cand, int64_t* __restrict__ delta_all,
+                                                    uint32_t* __restrict__ payload_of)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_rec) return;
+    if (r == n_rec) { selflag[r] = 0; return; }                    // the scan's trailing element
+    const Record rec = recs[r];
+    const int64_t b = best[rec.haystack];
+    uint32_t flag = 0;
+    if (b != INT64_MIN) {
+        for (uint64_t k = t.vals_off[rec.state], ke = t.vals_off[rec.state + 1]; k < ke; k++) {
+            const uint32_t v = t.vals[k];
+            const RpPayload pp = t.payloads[v];
+            if (pp.priority != b) continue;
+            uint64_t start, len;
+            if (!IC) { len = pp.len_bytes; start = rec.end_pos - len; }
+            else {
+                start = pp.len_code_points == 0 ? rec.end_pos : skip_code_points_backwards(text + offsets[rec.haystack], rec.end_pos - 1, pp.len_code_points - 1);
+                len = rec.end_pos - start;
+            }
+            RpSel c; c.start = start; c.len = len; c.haystack = rec.haystack; c.pad = 0;
+            cand[r] = c;
+            payload_of[rec.haystack] = v;
+            atomicAdd((unsigned long long*)(delta_all + rec.haystack), (unsigned long long)((int64_t)pp.repl_len - (int64_t)len));
+            flag = 1;
+        }
+    }
+    selflag[r] = flag;
+}
+
+__global__ void __launch_bounds__(256) k_rpp_compact(const uint32_t* __restrict__ selflag, const uint64_t* __restrict__ sidx, const RpSel* __restrict__ cand,
+                                                     uint64_t n_rec, RpSel* __restrict__ sel)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_rec && selflag[r]) sel[sidx[r]] = cand[r];
+}
+
+__global__ void __launch_bounds__(256) k_rpp_heads(const RpSel* __restrict__ sel, const uint64_t* __restrict__ n_sel_dev, uint32_t* __restrict__ keep)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_sel = *n_sel_dev;
+    if (i > n_sel) return;
+    if (i == n_sel) { keep[i] = 0; return; }
+    const RpSel c = sel[i];
+    bool head = i == 0;
+    if (!head) { const RpSel p = sel[i - 1]; head = p.haystack != c.haystack || c.start >= p.start + p.len; }
+    keep[i] = head ? 3u : 0u;                                      // bit 0: kept, bit 1: head of a run
+}
+
+__global__ void __launch_bounds__(256) k_rpp_greedy(const RpSel* __restrict__ sel, const uint64_t* __restrict__ n_sel_dev, uint32_t* __restrict__ keep)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_sel = *n_sel_dev;
+    if (i >= n_sel || !(keep[i] & 2u)) return;
+    uint64_t last_end = sel[i].start + sel[i].len;
+    for (uint64_t j = i + 1; j < n_sel && !(keep[j] & 2u); j++) {   // the rest of the run: removeOverlap (Replacer.hs:191-198)
+        const RpSel c = sel[j];
+        if (c.start >= last_end) { keep[j] = 1u; last_end = c.start + c.len; }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rpp_kflags(const RpSel* __restrict__ sel, const uint64_t* __restrict__ n_sel_dev, const uint32_t* __restrict__ keep,
+                                                    RpTables t, const uint32_t* __restrict__ payload_of, uint32_t* __restrict__ kflag, uint64_t* __restrict__ kdelta)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_sel = *n_sel_dev;
+    if (i > n_sel) return;
+    const bool k = i < n_sel && (keep[i] & 1u);
+    kflag[i] = k ? 1u : 0u;
+    kdelta[i] = k ? (uint64_t)((int64_t)t.payloads[payload_of[sel[i].haystack]].repl_len - (int64_t)sel[i].len) : 0ull;
+}
+
+__global__ void __launch_bounds__(256) k_rpp_kept(const RpSel* __restrict__ sel, const uint64_t* __restrict__ n_sel_dev, const uint32_t* __restrict__ kflag,
+                                                  const uint64_t* __restrict__ kidx, const uint64_t* __restrict__ kdpre, const uint64_t* __restrict__ sidx,
+                                                  const uint64_t* __restrict__ rec_first, RpKept* __restrict__ kept)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_sel = *n_sel_dev;
+    if (i >= n_sel || !kflag[i]) return;
+    const RpSel c = sel[i];
+    const uint64_t r0 = rec_first[c.haystack], s0 = sidx[r0];      // first record / first selected match of the haystack
+    RpKept e; e.src_start = c.start; e.src_len = c.len; e.dst = (uint64_t)((int64_t)c.start + (int64_t)(kdpre[i] - kdpre[s0]));
+    kept[r0 + (kidx[i] - kidx[s0])] = e;
+}
+
+__global__ void __launch_bounds__(256) k_rpp_hay(RpTables t, const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ rec_first,
+                                                 const uint64_t* __restrict__ sidx, const uint64_t* __restrict__ kidx, const uint64_t* __restrict__ kdpre,
+                                                 const int64_t* __restrict__ best, const int64_t* __restrict__ delta_all, const uint32_t* __restrict__ payload_of,
+                                                 uint64_t max_len, RpHay* __restrict__ hs, RpRoute route, uint32_t n_act)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_act) return;
+    const uint64_t curlen = offsets[h + 1] - offsets[h];
+    const uint64_t s0 = sidx[rec_first[h]], s1 = sidx[rec_first[h + 1]];
+    const int64_t b = best[h];
+    uint32_t status = kRpFinished, nkept = 0; uint64_t newlen = curlen;
+    if (b != INT64_MIN) {
+        const int64_t newlen_all = (int64_t)curlen + delta_all[h];
+        if (newlen_all > 0 && (uint64_t)newlen_all > max_len) { status = kRpNothing; newlen = 0; }
+        else {
+            nkept = (uint32_t)(kidx[s1] - kidx[s0]);
+            newlen = (uint64_t)((int64_t)curlen + (int64_t)(kdpre[s1] - kdpre[s0]));
+            status = b == t.min_priority ? kRpFinished : kRpActive;
+        }
+    }
+    RpHay o; o.newlen = newlen; o.best = b; o.status = status; o.nkept = nkept; o.payload = b != INT64_MIN ? payload_of[h] : 0u; o.pad = 0;
+    hs[h] = o;
+    route.len_next[h] = status == kRpActive ? newlen : 0;
+    route.len_fin[h] = status == kRpFinished ? newlen : 0;
+    route.tiles[h] = status == kRpNothing ? 0u : (uint32_t)((newlen + kRpTile - 1) / kRpTile);
+    route.act[h] = status == kRpActive ? 1u : 0u;
+    route.fin[h] = status == kRpActive ? 0u : 1u;
+}
+
+__global__ void __launch_bounds__(256) k_fill_i64(int64_t* __restrict__ p, uint64_t n, int64_t v)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+hipError_t launch_rpp_best(const RpTables& t, const Record* recs, uint64_t n_rec, const int64_t* thr, int64_t* best, uint32_t n_act, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fill_i64, dim3((n_act + 256) / 256), dim3(256), 0, st, best, (uint64_t)n_act + 1, INT64_MIN);
+    if (n_rec == 0) return hipGetLastError();
+    hipLaunchKernelGGL(k_rpp_best, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, t, recs, n_rec, thr, best);
+    return hipGetLastError();
+}
+hipError_t launch_rpp_select(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, uint64_t n_rec, const int64_t* best,
+                             uint32_t* selflag, RpSel* cand, int64_t* delta_all, uint32_t* payload_of, hipStream_t st)
+{
+    const dim3 grid((uint32_t)((n_rec + 1 + 255) / 256)), block(256);
+    if (ic) hipLaunchKernelGGL(k_rpp_select<true>, grid, block, 0, st, t, text, offsets, recs, n_rec, best, selflag, cand, delta_all, payload_of);
+    else hipLaunchKernelGGL(k_rpp_select<false>, grid, block, 0, st, t, text, offsets, recs, n_rec, best, selflag, cand, delta_all, payload_of);
+    return hipGetLastError();
+}
+hipError_t launch_rpp_compact(const uint32_t* selflag, const uint64_t* sidx, const RpSel* cand, uint64_t n_rec, RpSel* sel, hipStream_t st)
+{
+    if (n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rpp_compact, dim3((uint32_t)((n_rec + 255) / 256)), dim3(256), 0, st, selflag, sidx, cand, n_rec, sel);
+    return hipGetLastError();
+}
+// the kernels over selected matches are launched for the upper bound n_rec + 1 threads; the real count is read on the device
+hipError_t launch_rpp_overlaps(const RpSel* sel, const uint64_t* n_sel_dev, uint64_t bound, uint32_t* keep, hipStream_t st)
+{
+    const dim3 grid((uint32_t)((bound + 1 + 255) / 256)), block(256);
+    hipLaunchKernelGGL(k_rpp_heads, grid, block, 0, st, sel, n_sel_dev, keep);
+    hipLaunchKernelGGL(k_rpp_greedy, grid, block, 0, st, sel, n_sel_dev, keep);
+    return hipGetLastError();
+}
+hipError_t launch_rpp_kflags(const RpSel* sel, const uint64_t* n_sel_dev, uint64_t bound, const uint32_t* keep, const RpTables& t, const uint32_t* payload_of,
+                             uint32_t* kflag, uint64_t* kdelta, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rpp_kflags, dim3((uint32_t)((bound + 1 + 255) / 256)), dim3(256), 0, st, sel, n_sel_dev, keep, t, payload_of, kflag, kdelta);
+    return hipGetLastError();
+}
+hipError_t launch_rpp_finish(const RpTables& t, const RpSel* sel, const uint64_t* n_sel_dev, uint64_t bound, const uint32_t* kflag, const uint64_t* kidx,
+                             const uint64_t* kdpre, const uint64_t* sidx, const uint64_t* offsets, const uint64_t* rec_first, const int64_t* best,
+                             const int64_t* delta_all, const uint32_t* payload_of, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act,
+                             hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rpp_kept, dim3((uint32_t)((bound + 255) / 256 + 1)), dim3(256), 0, st, sel, n_sel_dev, kflag, kidx, kdpre, sidx, rec_first, kept);
+    hipLaunchKernelGGL(k_rpp_hay, dim3((n_act + 255) / 256), dim3(256), 0, st, t, offsets, rec_first, sidx, kidx, kdpre, best, delta_all, payload_of, max_len, hs, route, n_act);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(256) k_rp_route(const RpHay* __restrict__ hs, RpRouted rt, const uint32_t* __restrict__ orig, uint32_t n_act,
                                                   uint64_t* __restrict__ next_offsets, uint32_t* __restrict__ next_orig, int64_t* __restrict__ next_thr,
                                                   RpFin* __restrict__ fin)

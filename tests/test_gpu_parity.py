@@ -569,3 +569,36 @@ def test_replacer_many_tiny_haystacks_large_bookkeeping():
     assert len(got) == n
     bad = [i for i in range(n) if got[i] != exp[hays[i]]]
     assert not bad, (bad[:5], [got[i] for i in bad[:5]])
+
+
+def test_replacer_record_parallel_fold(monkeypatch):
+    """The fold of a pass has two implementations: one wavefront per haystack (many documents) and parallel over the
+    records (few documents with very many matches, chosen when records/haystack > 2048).  Both are forced here on the
+    same inputs, incl. long runs of overlapping matches (the only serial part of the parallel one)."""
+    rng = random.Random(5)
+    cases = [
+        (0, [("aa", "b")], ["a" * n for n in (0, 1, 2, 3, 64, 65, 127, 128, 129, 1000, 4097)]),
+        (0, [("abab", "X"), ("ab", "yy")], ["ab" * 300, "abab" * 77 + "a", "b" + "ab" * 129]),
+        (0, [("aaa", ""), ("a", "bbbbb")], ["a" * 500, "a" * 7 + "c" + "a" * 200]),
+        (0, [("a", "b"), ("b", "c"), ("c", "dd"), ("dd", "")], ["abcabc" * 50, "", "dddd", "x"]),
+        (1, [("i", "<I>"), ("ß", "ss"), ("k", "K!"), ("å", "")], ["İxİİ", "ẞßẞ", "KkK", "ÅåÅ" * 30, "İẞKÅ" * 100, "aİ" * 70]),
+        (0, [("a", "bbbb"), ("c", "")], ["aa", "a", "", "acac", "cccc", "aaaa" * 10]),
+    ]
+    for _ in range(6):
+        alpha = rng.choice(["abc ", "abİKß", "xyzXYZ"])
+        pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(1, 4))), "".join(rng.choice(alpha + "Q") for _ in range(rng.randint(0, 5)))) for _ in range(rng.randint(2, 20))]
+        hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 3, 50, 800, 6000)))) for _ in range(20)]
+        cases.append((rng.randint(0, 1), pairs, hays))
+    for case, pairs, hays in cases:
+        o = oracle.Replacer(case, pairs)
+        for max_len in (-1, 40):
+            exp = [o.run(h, max_len) for h in hays]
+            r = am.Replacer(case, pairs)
+            for forced in ("1", "0"):
+                monkeypatch.setenv("AM_RP_PARALLEL_FOLD", forced)
+                assert r.run_batch(hays, max_len) == exp, (forced, case, pairs[:4], max_len)
+            monkeypatch.delenv("AM_RP_PARALLEL_FOLD")
+    # natural trigger: one document with > 2048 matches per pass
+    big = ("short tshirts and sweatshirts " * 4000)
+    pairs = [("tshirt", "T"), ("shirts", "S"), ("short", "long"), ("and", "&")]
+    assert am.Replacer(0, pairs).run(big) == oracle.Replacer(0, pairs).run(big)
