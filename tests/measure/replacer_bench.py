@@ -3,10 +3,10 @@
 pairs, every pass on the device (am_replacer_run_batch).  Prints wall time, passes, bytes scanned and the
 per-kernel HIP-event breakdown; checks a sample against the oracle.
 
-  python tools/replacer_bench.py [--n-hay 16384] [--pairs 50000] [--case 0] [--sample 4] [--host-splice-sample 64]
+  python tests/measure/replacer_bench.py [--n-hay 16384] [--pairs 50000] [--case 0] [--sample 4] [--host-splice-sample 64]
 """
 import argparse, ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

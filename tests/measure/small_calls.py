@@ -2,7 +2,7 @@
 """Latency of one-shot calls on small inputs (BASELINE configs[0]: 3 needles, one 1-MB ASCII haystack; and a 100-byte
 haystack): what a caller that scans one document per call pays.  Compared with the CPU oracle on the same input."""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import alfred_margaret_amd as am
