@@ -38,11 +38,12 @@ def test_no_cpu_fallback_without_gpu():
 
 def test_product_does_not_reference_the_oracle():
     bad = []
-    for base, _, files in os.walk(os.path.join(ROOT, "alfred-margaret_amd")):
-        if os.path.basename(base) == "lib":
+    for top in ("alfred-margaret_amd", "tools", "include"):
+      for base, _, files in os.walk(os.path.join(ROOT, top)):
+        if os.path.basename(base) in ("lib", "__pycache__"):
             continue
         for f in files:
-            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".sh")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 if re.search(r"(#include\s*[\"<][^\n]*oracle|import\s+oracle|from\s+oracle|liboracle|libam_oracle)", text):
                     bad.append(f)
