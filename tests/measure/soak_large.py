@@ -1,4 +1,4 @@
-"""Soak with the mid-sized adversarial automata of tests/test_gpu_parity.py::_soak_case (1500 long needles sharing stems, every UTF-8 length, near misses): records and Replacer output against the oracle for many seeds.  python tests/measure/soak_large.py"""
+"""Soak with the mid-sized adversarial automata of tests/test_gpu_parity.py::_soak_case (1500 long needles sharing stems, every UTF-8 length, near misses): records and Replacer output against the oracle for many seeds.  python tests/measure/soak_large.py [seconds] [first_seed]"""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -6,7 +6,7 @@ import alfred_margaret_amd as am
 from oracle import oracle
 from tests.helpers import expand_records, oracle_triples
 from tests.test_gpu_parity import _soak_case
-t_end = time.time() + 150; seed = 70000; n = 0
+t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 150.0); seed = int(sys.argv[2]) if len(sys.argv) > 2 else 70000; n = 0
 while time.time() < t_end:
     rng = random.Random(seed)
     needles, hays = _soak_case(rng)
