@@ -602,3 +602,29 @@ def test_replacer_record_parallel_fold(monkeypatch):
     big = ("short tshirts and sweatshirts " * 4000)
     pairs = [("tshirt", "T"), ("shirts", "S"), ("short", "long"), ("and", "&")]
     assert am.Replacer(0, pairs).run(big) == oracle.Replacer(0, pairs).run(big)
+
+
+def test_runtime_knobs_user_stream_and_profiling():
+    """am_set_stream: launches go to a caller-supplied HIP stream (here a torch stream); am_profile_*: per-kernel HIP-event
+    timing used by bench.py's roofline."""
+    import torch
+    lib = am.api.libam()
+    needles = synth.needles_for("cfg2_runText_10k_1GiB")[:2000]
+    a = am.Automaton(needles)
+    text = bytes(synth.haystacks_host(needles, False, 5, 256))
+    exp = a.run_records(0, [text])
+    stream = torch.cuda.Stream()
+    am.api.check(lib.am_set_stream(C.c_void_p(stream.cuda_stream)))
+    try:
+        am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+        got = a.run_records(0, [text])
+        am.api.check(lib.am_profile_enable(0))
+        assert np.array_equal(got, exp)
+        ms, n = C.c_double(0), C.c_uint64(0)
+        am.api.check(lib.am_profile_read(b"sf", C.byref(ms), C.byref(n)))
+        assert n.value == 1 and 0.0 < ms.value < 100.0
+        am.api.check(lib.am_profile_read(b"permute", C.byref(ms), C.byref(n)))
+        assert n.value == 1
+    finally:
+        am.api.check(lib.am_set_stream(None))
+    assert np.array_equal(a.run_records(0, [text]), exp)
