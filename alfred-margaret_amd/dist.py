@@ -72,3 +72,18 @@ def own_records(records, start, lo, hi):
     out = records[keep].copy()
     out["end_pos"] = end[keep]
     return out
+
+
+def gather_records(local_records, first_haystack, dst=0):
+    """match lists are not gathered on the device -- every rank copies its own records to the host and rank
+    `dst` concatenates them in haystack order.  local_records: numpy array of am_match records of this rank's block
+    (haystack ids relative to the block); first_haystack: global index of the block's first haystack.  Returns the global
+    record array on rank dst (None elsewhere); with contiguous blocks (shard_bounds) it is sorted by (haystack, end_pos)."""
+    import numpy as np
+    recs = local_records.copy()
+    recs["haystack"] = recs["haystack"] + np.uint32(first_haystack)
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return recs
+    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(recs, parts, dst=dst)
+    return np.concatenate(parts) if parts is not None else None

@@ -56,6 +56,19 @@ def _worker(rank, world, port, out_dir):
             assert total_values == sum(o.count_matches(am.IGNORE_CASE, h) for h in all_hays)
             assert total_values > n_hay * hay_cells // 2
         assert amdist.allreduce_max(float(rank), dev) == float(world - 1)
+        # match lists: gathered on the host in haystack order (rank 0 gets the global list)
+        local = np.zeros(max(n, 0), dtype=am.api.MATCH_DTYPE)
+        if n:
+            local["haystack"], local["state"], local["end_pos"] = recs[0], recs[1], recs[2]
+        everything = amdist.gather_records(local, lo, dst=0)
+        if rank == 0:
+            assert len(everything) == total_records
+            keys = list(zip(everything["haystack"].tolist(), everything["end_pos"].tolist()))
+            assert keys == sorted(keys) and everything["haystack"].max() == n_hay - 1
+            exp_all = [(i, int(p), int(v)) for i, h in enumerate(all_hays) for p, v in zip(*o.run_list(am.IGNORE_CASE, h))]
+            assert expand_records(o.values_off(), o.values(), everything["haystack"], everything["state"], everything["end_pos"]) == exp_all
+        else:
+            assert everything is None
         open(os.path.join(out_dir, "ok%d" % rank), "w").write("%d %d" % (total_values, total_records))
     finally:
         dist.destroy_process_group()
