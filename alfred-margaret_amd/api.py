@@ -109,6 +109,8 @@ _HOST = {
     "amh_searcher_contains_all_host_fold": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
     "amh_replacer_build": (C.c_int, [C.c_int, C.c_char_p, _vp, C.c_char_p, _vp, _sz, C.POINTER(_vp)]),
     "amh_replacer_free": (None, [_vp]),
+    "amh_replacer_with_replacements": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_vp)]),
+    "amh_replacer_set_case": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
     "amh_replacer_run_batch": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
     "amh_replacer_run_batch_host_splice": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
     "amh_replacer_last_stats": (None, [_vp, _vp, _vp]),
@@ -400,8 +402,30 @@ class Replacer:
         h = _vp()
         _hcheck(libhost().amh_replacer_build(case, nb, no.ctypes.data, rb, ro.ctypes.data, len(pairs), C.byref(h)))
         self._h = h
+        self.pairs = list(pairs)
 
     build = classmethod(lambda cls, case, pairs: cls(case, pairs))
+
+    @classmethod
+    def _wrap(cls, handle, pairs):
+        r = cls.__new__(cls)
+        r._h = handle
+        r.pairs = pairs
+        return r
+
+    def map_replacement(self, f):
+        """Replacer.mapReplacement (Replacer.hs:135-141): new replacements, same needles, no rebuild."""
+        fresh = [f(_as_bytes(rep)) for _, rep in self.pairs]
+        rb, ro = pack_texts(fresh)
+        h = _vp()
+        _hcheck(libhost().amh_replacer_with_replacements(self._h, rb, ro.ctypes.data, C.byref(h)))
+        return Replacer._wrap(h, [(n, rep) for (n, _), rep in zip(self.pairs, fresh)])
+
+    def set_case_sensitivity(self, case):
+        """Replacer.setCaseSensitivity (Replacer.hs:148-153): needles untouched."""
+        h = _vp()
+        _hcheck(libhost().amh_replacer_set_case(self._h, case, C.byref(h)))
+        return Replacer._wrap(h, self.pairs)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -117,6 +117,24 @@ int amh_replacer_build(int case_mode, const uint8_t* nbytes, const uint64_t* nof
     });
 }
 void amh_replacer_free(void* r) { delete static_cast<Replacer*>(r); }
+// mapReplacement with the new replacements given as a list (needle i gets rbytes[roffs[i] .. roffs[i+1]))
+int amh_replacer_with_replacements(void* r, const uint8_t* rbytes, const uint64_t* roffs, void** out)
+{
+    *out = nullptr;
+    return guarded([&] {
+        const Replacer* src = static_cast<Replacer*>(r);
+        size_t i = 0;
+        std::vector<std::string> fresh(src->searcher().numNeedles());
+        for (auto& f : fresh) { f.assign((const char*)rbytes + roffs[i], (size_t)(roffs[i + 1] - roffs[i])); i++; }
+        // mapReplacement sees the payloads in needle order for `needles`, and per state for the automaton: map by priority
+        *out = new Replacer(src->mapReplacementIndexed([&](size_t needle, const std::string&) { return fresh[needle]; }));
+    });
+}
+int amh_replacer_set_case(void* r, int case_mode, void** out)
+{
+    *out = nullptr;
+    return guarded([&] { *out = new Replacer(static_cast<Replacer*>(r)->setCaseSensitivity((CaseSensitivity)case_mode)); });
+}
 // Runs a batch; results are returned as one malloc'd blob + offsets (n+1); is_nothing[i] = 1 where the
 // reference returns Nothing.  max_len < 0 = maxBound.
 static int replacer_run_batch(void* r, bool host_splice, const am_slice* hay, size_t n_hay, long long max_len, uint8_t** blob_out, uint64_t* offs_out, uint8_t* is_nothing)

@@ -1,6 +1,7 @@
 // replacer.hpp -- host mirror of Data.Text.AhoCorasick.Replacer (reference:
 // src/Data/Text/AhoCorasick/Replacer.hs): sequential multi-needle replace with priorities.
-//   Payload :59-70, build :97-116, compose :120-133, run :200-201, runWithLimit :203-274,
+//   Payload :59-70, build :97-116, compose :120-133, mapReplacement :135-141, setCaseSensitivity :148-153,
+//   run :200-201, runWithLimit :203-274,
 //   removeOverlap :191-198, replace :163-180, replacementLength :183-187.
 // runBatchWithLimit hands the whole multi-pass loop to libam (am_replacer_*): scan, priority fold,
 // overlap removal and splice all run in HBM, only finished haystacks come back.
@@ -41,6 +42,24 @@ public:
         ns.insert(ns.end(), b.searcher_.needles().begin(), b.searcher_.needles().end());
         for (size_t i = 0; i < ns.size(); i++) ns[i].second.needlePriority = -(long long)i;
         return Replacer(Searcher<Payload>(a.caseSensitivity(), std::move(ns)));
+    }
+
+    // Replacer.hs:135-141 mapReplacement: new replacements, needles untouched
+    template <class F> Replacer mapReplacement(F f) const
+    {
+        return Replacer(searcher_.mapSearcher([&](const Payload& p) { Payload q = p; q.needleReplacement = f(p.needleReplacement); return q; }));
+    }
+    // the same with the needle's index (= -priority) handed to f
+    template <class F> Replacer mapReplacementIndexed(F f) const
+    {
+        return Replacer(searcher_.mapSearcher([&](const Payload& p) { Payload q = p; q.needleReplacement = f((size_t)(-p.needlePriority), p.needleReplacement); return q; }));
+    }
+    // Replacer.hs:148-153 setCaseSensitivity: flips the mode without touching the needles (the caller makes sure they are lower case for IgnoreCase)
+    Replacer setCaseSensitivity(CaseSensitivity cs) const
+    {
+        Searcher<Payload> s = searcher_.mapSearcher([](const Payload& p) { return p; });
+        s.setCaseSensitivity(cs);
+        return Replacer(std::move(s));
     }
 
     struct RunStats { uint64_t passes = 0, scannedBytes = 0; };

@@ -1,6 +1,6 @@
 // searcher.hpp -- host mirror of Data.Text.AhoCorasick.Searcher (reference:
 // src/Data/Text/AhoCorasick/Searcher.hs): needles + case mode + automaton.
-//   build / buildWithValues :110-118, containsAny :156-164, buildNeedleIdSearcher :167-169,
+//   build / buildWithValues :110-118, mapSearcher :121-125, containsAny :156-164, buildNeedleIdSearcher :167-169,
 //   containsAll :173-187, setCaseSensitivity :142-145.
 // containsAny dispatches to libam's flag kernel; containsAll to libam's needle-id bitmap fold
 // (am_contains_all); containsAllBatchHostFold is the same function folding the records on the host.
@@ -25,11 +25,29 @@ public:
     const std::vector<std::pair<std::string, V>>& needles() const { return needles_; }
     size_t numNeedles() const { return needles_.size(); }
     const AcMachine<V>& automaton() const { return automaton_; }
+    // Searcher.hs:121-125 mapSearcher: new values, same needles and transitions (the device automaton is shared, it never sees the values)
+    template <class F> auto mapSearcher(F f) const -> Searcher<decltype(f(std::declval<const V&>()))>
+    {
+        using B = decltype(f(std::declval<const V&>()));
+        Searcher<B> out;
+        out.case_ = case_;
+        out.needles_.reserve(needles_.size());
+        for (const auto& p : needles_) out.needles_.emplace_back(p.first, f(p.second));
+        out.automaton_.machineTransitions = automaton_.machineTransitions;
+        out.automaton_.machineOffsets = automaton_.machineOffsets;
+        out.automaton_.machineRootAsciiTransitions = automaton_.machineRootAsciiTransitions;
+        out.automaton_.device = automaton_.device;
+        out.automaton_.machineValues.reserve(automaton_.machineValues.size());
+        for (const auto& vs : automaton_.machineValues) { std::vector<B> bs; bs.reserve(vs.size()); for (const V& v : vs) bs.push_back(f(v)); out.automaton_.machineValues.push_back(std::move(bs)); }
+        return out;
+    }
     // per-searcher device-side extras (flattened machineValues), created on first use by the functions below
     std::shared_ptr<void>& deviceExtra() const { return extra_; }
     std::mutex& deviceExtraMutex() const { return *extraMu_; }
 
 private:
+    template <class U> friend class Searcher;
+    Searcher() = default;
     mutable std::shared_ptr<void> extra_;
     std::shared_ptr<std::mutex> extraMu_ = std::make_shared<std::mutex>();
     CaseSensitivity case_;

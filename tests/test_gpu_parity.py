@@ -628,3 +628,18 @@ def test_runtime_knobs_user_stream_and_profiling():
     finally:
         am.api.check(lib.am_set_stream(None))
     assert np.array_equal(a.run_records(0, [text]), exp)
+
+
+def test_replacer_map_replacement_and_set_case_sensitivity():
+    """Replacer.mapReplacement (Replacer.hs:135-141) and setCaseSensitivity (:148-153): derived replacers without a rebuild."""
+    pairs = [("tshirt", "top"), ("shorts", "pants"), ("ß", "ss"), ("k", "x")]
+    hays = ["Shorts and TSHIRT, shorts and tshirt K ẞ ß k", "", "tshirtshorts" * 20]
+    r = am.Replacer(0, pairs)
+    up = r.map_replacement(lambda rep: rep.upper() + b"!")
+    fresh = [(n, (rep.upper() + "!")) for n, rep in pairs]
+    assert up.run_batch(hays) == [oracle.Replacer(0, fresh).run(h) for h in hays]
+    assert r.run_batch(hays) == [oracle.Replacer(0, pairs).run(h) for h in hays]        # the original is untouched
+    ic = r.set_case_sensitivity(1)                                                      # needles are lower case already
+    assert ic.run_batch(hays) == [oracle.Replacer(1, pairs).run(h) for h in hays]
+    assert ic.map_replacement(lambda rep: b"").run_batch(hays) == [oracle.Replacer(1, [(n, "") for n, _ in pairs]).run(h) for h in hays]
+    assert ic.set_case_sensitivity(0).run_batch(hays) == r.run_batch(hays)
