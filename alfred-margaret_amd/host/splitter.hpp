@@ -4,12 +4,15 @@
 //   splitReverseIgnoreCase :112-121, Accum / stepAccum / finalizeAccum :128-170.
 // The match positions come from libam (GPU); the fold below is the reference's stepAccum.
 #pragma once
+#include <algorithm>
+
 #include "automaton.hpp"
 
 namespace alfred_margaret {
 
 class Splitter {
 public:
+    struct Unit0 {};
     explicit Splitter(std::string sep) : separator_(std::move(sep))
     {
         std::vector<std::pair<Text, Unit0>> nv{{Text(separator_), Unit0{}}};
@@ -61,9 +64,12 @@ public:
     }
     std::vector<std::string> split(const std::string& text) const { return splitBatch({text}, false)[0]; }
     std::vector<std::string> splitIgnoreCase(const std::string& text) const { return splitBatch({text}, true)[0]; }
+    // Splitter.hs:100-107 / :112-121: the fragments last-first (what the fold accumulates before `split` reverses it)
+    std::vector<std::string> splitReverse(const std::string& text) const { auto v = split(text); std::reverse(v.begin(), v.end()); return v; }
+    std::vector<std::string> splitReverseIgnoreCase(const std::string& text) const { auto v = splitIgnoreCase(text); std::reverse(v.begin(), v.end()); return v; }
+    const AcMachine<Unit0>& automaton() const { return automaton_; }       // Splitter.hs:71-72
 
 private:
-    struct Unit0 {};
     std::string separator_;
     AcMachine<Unit0> automaton_;
 };
