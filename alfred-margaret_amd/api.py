@@ -57,6 +57,7 @@ ABI = {
     "am_matches_data": (_vp, [_vp]),
     "am_matches_device_data": (_vp, [_vp]),
     "am_matches_free": (None, [_vp]),
+    "am_matches_fold_hash": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "am_needle_ids_create": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
     "am_needle_ids_destroy": (None, [_vp]),
     "am_contains_all": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
@@ -302,6 +303,37 @@ class Automaton:
             return matches_to_numpy(m)
         finally:
             libam().am_matches_free(m)
+
+
+class ValuesTable:
+    """machineValues of an Automaton in flat form on the device (am_needle_ids): what the fold-checksum and
+    containsAll kernels expand records with."""
+
+    def __init__(self, automaton, n_needles=None):
+        self._a = automaton                      # the am_automaton must outlive the table
+        self._off = np.ascontiguousarray(automaton.values_off(), dtype=np.uint64)
+        self._val = np.ascontiguousarray(automaton.values(), dtype=np.uint32)
+        if self._val.size == 0:
+            self._val = np.zeros(1, np.uint32)
+        h = _vp()
+        n = len(automaton.needles) if n_needles is None else n_needles
+        check(libam().am_needle_ids_create(automaton.device, self._off.ctypes.data, self._val.ctypes.data, n, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            libam().am_needle_ids_destroy(self._h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def fold_hash(self, matches, n_hay):
+        """am_matches_fold_hash: (hash[n_hay], count[n_hay]) of the fold sequences of an am_matches* result."""
+        hashes, counts = np.zeros(max(n_hay, 1), np.uint64), np.zeros(max(n_hay, 1), np.uint64)
+        check(libam().am_matches_fold_hash(matches, self._h, n_hay, hashes.ctypes.data, counts.ctypes.data))
+        return hashes[:n_hay], counts[:n_hay]
 
 
 class ImageAutomaton:

@@ -1337,11 +1337,17 @@ extern "C" int am_needle_ids_create(const am_automaton* a, const uint64_t* value
     *out = nullptr;
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
     AM_TRY(ensure_device());
-    if (!a->has_ref) return fail(AM_ERR_UNSUPPORTED, "needle ids need an automaton made by am_automaton_create");
-    const uint64_t n_states = a->offsets.size() - 1;
+    // a handle attached to a received image (multi-GPU ranks) has no reference arrays: the state count comes from the image
+    uint64_t n_states = 0;
+    if (a->has_ref) n_states = a->offsets.size() - 1;
+    else {
+        std::lock_guard<std::mutex> lk(const_cast<am_automaton*>(a)->mu);
+        for (const Flavor& f : a->fl) if (f.ready) n_states = f.h.n_states;
+        if (!n_states) return fail(AM_ERR_INVALID, "automaton handle has no image");
+    }
     if (!values_offsets || values_offsets[0] != 0) return fail(AM_ERR_INVALID, "values_offsets[0] must be 0");
     for (uint64_t s = 0; s < n_states; s++)
-        if (values_offsets[s + 1] < values_offsets[s] || values_offsets[s + 1] - values_offsets[s] != a->values_len[s])
+        if (values_offsets[s + 1] < values_offsets[s] || (a->has_ref && values_offsets[s + 1] - values_offsets[s] != a->values_len[s]))
             return fail(AM_ERR_INVALID, "values_offsets disagrees with the values_len given to am_automaton_create");
     const uint64_t n_values = values_offsets[n_states];
     if (n_values && !values) return fail(AM_ERR_INVALID, "values is null");
@@ -1401,6 +1407,30 @@ extern "C" int am_contains_all_batch(const am_needle_ids* ids, int case_mode, co
           HIP_TRY(launch_idset_all((const uint32_t*)bits.p, words, ids->n_needles, h1 - h0, (uint8_t*)flags.p + h0, st)); }
     }
     HIP_TRY(hipMemcpyAsync(flags_out, flags.p, n_hay, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return AM_OK;
+}
+
+extern "C" int am_matches_fold_hash(const am_matches* m, const am_needle_ids* ids, size_t n_hay, uint64_t* hash_out, uint64_t* count_out)
+{
+    if (!m || !ids) return fail(AM_ERR_INVALID, "null matches or values table");
+    if (n_hay && !hash_out) return fail(AM_ERR_INVALID, "hash_out is null");
+    if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
+    if (n_hay == 0) return AM_OK;
+    AM_TRY(ensure_device());
+    hipStream_t st; AM_TRY(get_stream(&st));
+    DevBuf rec_first, out, dummy;
+    struct Release { DevBuf &a, &b, &c; ~Release() { a.release(); b.release(); c.release(); } } rel{rec_first, out, dummy};
+    AM_TRY(rec_first.ensure((n_hay + 1) * 8));
+    AM_TRY(out.ensure(n_hay * 16));
+    AM_TRY(dummy.ensure(sizeof(Record)));
+    const Record* recs = m->n ? m->d_records : (const Record*)dummy.p;
+    HIP_TRY(launch_rp_ranges(recs, m->n, (uint64_t*)rec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_hay, st));
+    { Prof pr("fold_hash", st);
+      HIP_TRY(launch_fold_hash(recs, (const uint64_t*)rec_first.p, (const uint64_t*)ids->vals_off.p, (const uint32_t*)ids->vals.p, (uint32_t)n_hay,
+                               (uint64_t*)out.p, (uint64_t*)out.p + n_hay, st)); }
+    HIP_TRY(hipMemcpyAsync(hash_out, out.p, n_hay * 8, hipMemcpyDeviceToHost, st));
+    if (count_out) HIP_TRY(hipMemcpyAsync(count_out, (uint64_t*)out.p + n_hay, n_hay * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return AM_OK;
 }

@@ -78,6 +78,8 @@ hipError_t launch_rp_splice(const RpTables& t, const uint8_t* text, const uint64
                             uint8_t* text_next, uint8_t* text_fin, hipStream_t st);
 hipError_t launch_idset(const Record* recs, uint64_t r0, uint64_t r1, const uint64_t* vals_off, const uint32_t* vals, uint32_t n_needles,
                         uint32_t hay0, uint32_t words, uint32_t* bits, hipStream_t st);
+hipError_t launch_fold_hash(const Record* recs, const uint64_t* rec_first, const uint64_t* vals_off, const uint32_t* vals, uint32_t n_hay,
+                            uint64_t* hash_out, uint64_t* count_out, hipStream_t st);
 hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_needles, uint32_t n_hay, uint8_t* flags, hipStream_t st);
 // incremental re-scan between Replacer passes (am_replace.hip)
 struct RpWin { uint64_t src_abs; uint64_t ws; uint32_t len; uint32_t own_lo; };   // window: bytes src_abs.. of the next text; ws = its start inside the haystack; records with end > own_lo are its own

@@ -710,6 +710,56 @@ hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_nee
     return hipGetLastError();
 }
 
+// ---- checksum of the fold sequence (SURVEY 8d "parity check at scale"): per haystack, the left fold
+//   h' = h * P + mix(matchPos, value)      over every (record, value of machineValues ! record.state) in order
+// i.e. exactly what the reference's runWithCase would hand to a fold function, reduced to 64 bits.  One wavefront per
+// haystack: every lane folds a contiguous block of the haystack's records, the (hash, count) pairs are combined with
+// the associative rule (h1, c1) . (h2, c2) = (h1 * P^c2 + h2, c1 + c2).
+constexpr uint64_t kFoldP = 0x100000001B3ull;
+__device__ __forceinline__ uint64_t fold_mix(uint64_t pos, uint32_t v)
+{
+    uint64_t x = (pos * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)v + 0x632BE59BD9B4E019ull);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+    return x;
+}
+__device__ __forceinline__ uint64_t fold_pow(uint64_t e)
+{
+    uint64_t r = 1, b = kFoldP;
+    while (e) { if (e & 1) r *= b; b *= b; e >>= 1; }
+    return r;
+}
+__global__ void __launch_bounds__(256) k_fold_hash(const Record* __restrict__ recs, const uint64_t* __restrict__ rec_first, const uint64_t* __restrict__ vals_off,
+                                                   const uint32_t* __restrict__ vals, uint32_t n_hay, uint64_t* __restrict__ hash_out, uint64_t* __restrict__ count_out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_hay) return;
+    const uint64_t r0 = rec_first[h], r1 = rec_first[h + 1];
+    const uint64_t per = (r1 - r0 + kWave - 1) / kWave;
+    uint64_t a = r0 + per * lane, z = a + per;
+    if (a > r1) a = r1;
+    if (z > r1) z = r1;
+    uint64_t hh = 0, cnt = 0;
+    for (uint64_t r = a; r < z; r++) {
+        const Record rec = recs[r];
+        for (uint64_t k = vals_off[rec.state], ke = vals_off[rec.state + 1]; k < ke; k++) { hh = hh * kFoldP + fold_mix(rec.end_pos, vals[k]); cnt++; }
+    }
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {            // lanes whose index is a multiple of 2d absorb their right neighbour's block
+        const uint64_t oh = __shfl_down(hh, d, kWave), oc = __shfl_down(cnt, d, kWave);
+        hh = hh * fold_pow(oc) + oh; cnt += oc;
+    }
+    if (lane == 0) { hash_out[h] = hh; if (count_out) count_out[h] = cnt; }
+}
+
+hipError_t launch_fold_hash(const Record* recs, const uint64_t* rec_first, const uint64_t* vals_off, const uint32_t* vals, uint32_t n_hay,
+                            uint64_t* hash_out, uint64_t* count_out, hipStream_t st)
+{
+    if (n_hay == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fold_hash, dim3((n_hay + 3) / 4), dim3(256), 0, st, recs, rec_first, vals_off, vals, n_hay, hash_out, count_out);
+    return hipGetLastError();
+}
+
 // ---- several small exclusive sums in ONE launch (the Replacer's per-pass bookkeeping: a dozen hipcub launches otherwise).
 // One 1024-thread workgroup per job walks its array in tiles of 4096 elements: 4 elements per thread, wave scan with
 // shuffles, wave totals through LDS, running carry.  Meant for arrays up to a few hundred thousand elements.

@@ -46,11 +46,14 @@ def allreduce_max(value, device):
 
 def split_single_haystack(text, world, max_needle_code_points):
     """ONE haystack on `world` GPUs: rank r owns the end positions in (lo, hi] and scans
-    text[start:hi], where start = lo minus an overlap of one maximal match, moved back to a code-point
-    boundary.  Whether a needle ends at a position depends only on the max-needle-length bytes before
-    it, so a scan started `overlap` earlier reports exactly the reference's matches in (lo, hi].  The
-    overlap is 4 bytes per needle code point: under IgnoreCase a haystack code point may be longer than
-    the needle code point it lowers to (K, 3 bytes, lowers to k).  Returns [(start, lo, hi)] per rank."""
+    text[start:scan_hi], where start = lo minus an overlap of one maximal match, moved back to a code-point
+    boundary, and scan_hi = hi moved FORWARD to the next code-point boundary (at most 3 bytes): a slice that
+    ends inside a code point would hand the general kernel a truncated sequence, which its guarded decode
+    (am_image.h ac_scan_unit) reads as a different, bogus code point.  Whether a needle ends at a position
+    depends only on the max-needle-length bytes before it, so a scan started `overlap` earlier reports exactly
+    the reference's matches in (lo, hi].  The overlap is 4 bytes per needle code point: under IgnoreCase a
+    haystack code point may be longer than the needle code point it lowers to (K, 3 bytes, lowers to k).
+    Returns [(start, lo, hi, scan_hi)] per rank."""
     text = memoryview(text)
     n = len(text)
     overlap = 4 * max(int(max_needle_code_points), 1)
@@ -60,15 +63,18 @@ def split_single_haystack(text, world, max_needle_code_points):
         start = max(0, lo - overlap)
         while start > 0 and (text[start] & 0xC0) == 0x80:
             start -= 1
-        out.append((start, lo, hi))
+        scan_hi = hi
+        while scan_hi < n and (text[scan_hi] & 0xC0) == 0x80:
+            scan_hi += 1
+        out.append((start, lo, hi, scan_hi))
     return out
 
 
 def own_records(records, start, lo, hi):
-    """Filter + rebase the records of a scan of text[start:hi] to the rank's own range: keeps end
+    """Filter + rebase the records of a scan of text[start:scan_hi] to the rank's own range: keeps end
     positions in (lo, hi] and makes them relative to the whole haystack."""
     end = records["end_pos"] + start
-    keep = end > lo
+    keep = (end > lo) & (end <= hi)
     out = records[keep].copy()
     out["end_pos"] = end[keep]
     return out

@@ -23,7 +23,7 @@ WORKLOADS = {
     # name: (n_needles, case, haystack_bytes, n_haystacks, mixed_case)
     "cfg2_runText_10k_1GiB": dict(n_needles=10_000, case=api.CASE_SENSITIVE, hay_bytes=64 << 10, n_hay=16384, mixed=False),
     "cfg3_runLower_100k_10GiB": dict(n_needles=100_000, case=api.IGNORE_CASE, hay_bytes=1 << 20, n_hay=10240, mixed=True),
-    "cfg4_100k_1M_haystacks": dict(n_needles=100_000, case=api.IGNORE_CASE, hay_bytes=100 << 10, n_hay=1 << 20, mixed=True),
+    "cfg4_100k_1M_haystacks": dict(n_needles=100_000, case=api.IGNORE_CASE, hay_bytes=100 << 10, n_hay=1 << 20, mixed=True, sharded_total=True),
     "cfg5_replacer_50k_1GiB": dict(n_needles=50_000, case=api.CASE_SENSITIVE, hay_bytes=64 << 10, n_hay=16384, mixed=False),
 }
 

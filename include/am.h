@@ -137,6 +137,18 @@ void am_needle_ids_destroy(am_needle_ids* ids);
 int am_contains_all(const am_needle_ids* ids, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
 int am_contains_all_batch(const am_needle_ids* ids, int case_mode, const am_batch* b, uint8_t* flags_out);
 
+/* Checksum of the fold sequence of a result (harness aid; SURVEY 8d "parity check at scale",
+ * benchmark/benchmark.py:65-69 asserts count identity on every run).  For every haystack i < n_hay:
+ *   hash_out[i]  = foldl (\h (pos, v) -> h * 0x100000001B3 + mix pos v) 0  over the matches the reference's
+ *                  runWithCase would hand to its fold function for haystack i, in its order, where
+ *                  mix pos v = let x0 = (pos * 0x9E3779B97F4A7C15) xor (v + 0x632BE59BD9B4E019); x1 = x0 xor (x0 >> 32);
+ *                                  x2 = x1 * 0xD6E8FEB86659FD93 in x2 xor (x2 >> 32)          (all mod 2^64)
+ *   count_out[i] = the number of those matches (= countMatches, benchmark/haskell/app/Main.hs:67-76); nullable.
+ * `values` carries machineValues in flat form (am_needle_ids_create; any uint32 payload handles, n_needles unused).
+ * Computed on the device from the records in HBM; two runs agree on hash and count iff they fold the same
+ * (matchPos, value) sequences (up to 64-bit collisions). */
+int am_matches_fold_hash(const am_matches* m, const am_needle_ids* values, size_t n_hay, uint64_t* hash_out, uint64_t* count_out);
+
 /* ---- Replacer: all passes of Replacer.run on the device -----------------------------------------
  * Replaces the loop `runWithLimit.go` (src/Data/Text/AhoCorasick/Replacer.hs:219-242) for a batch of
  * haystacks: per pass one scan (:223-225), prependMatch/makeMatch (:252-274), the replacementLength

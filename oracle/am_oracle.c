@@ -384,6 +384,33 @@ uint64_t orc_run_list(const orc_machine* m, int ignore_case, const uint8_t* d, s
     return l.n;
 }
 
+/* Checksum of the whole fold sequence (SURVEY 8d "parity check at scale"): runWithCase with the fold
+ *   f (h, n) (Match pos v) = Step (h * P + mix pos v, n + 1)
+ * order-sensitive in (pos, v), so two runs agree iff they hand the same matches to the fold in the same order
+ * (up to 64-bit collisions).  libam computes the same fold over its records on the device (am_matches_fold_hash). */
+#define ORC_HASH_P 0x100000001B3ull
+static inline uint64_t orc_mix(uint64_t pos, uint32_t v)
+{
+    uint64_t x = (pos * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)v + 0x632BE59BD9B4E019ull);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+    return x;
+}
+typedef struct { uint64_t h, n; } hash_acc;
+static int fold_hash(void* a, uint64_t pos, uint32_t v)
+{
+    hash_acc* h = (hash_acc*)a;
+    h->h = h->h * ORC_HASH_P + orc_mix(pos, v);
+    h->n++;
+    return ORC_STEP;
+}
+uint64_t orc_fold_hash(const orc_machine* m, int ignore_case, const uint8_t* d, size_t off, size_t len, uint64_t* count_out)
+{
+    hash_acc h = { 0, 0 };
+    orc_run_with_case(ignore_case, &h, fold_hash, m, d, off, len);
+    if (count_out) *count_out = h.n;
+    return h.h;
+}
+
 /* src/Data/Text/AhoCorasick/Searcher.hs:156-164 containsAny */
 static int fold_any(void* acc, uint64_t pos, uint32_t v) { (void)pos; (void)v; *(int*)acc = 1; return ORC_DONE; }
 int orc_contains_any(const orc_machine* m, int ignore_case, const uint8_t* d, size_t off, size_t len)

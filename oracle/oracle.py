@@ -42,6 +42,8 @@ def _load():
     lib.orc_count_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
     lib.orc_run_list.restype = C.c_uint64
     lib.orc_run_list.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, u64p, u32p, C.c_uint64]
+    lib.orc_fold_hash.restype = C.c_uint64
+    lib.orc_fold_hash.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, u64p]
     lib.orc_contains_any.restype = C.c_int
     lib.orc_contains_any.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
     lib.orc_contains_all.restype = C.c_int
@@ -159,6 +161,13 @@ class Machine:
         lib().orc_run_list(self._h, case, p[0], off, length,
                            pos.ctypes.data_as(C.POINTER(C.c_uint64)), val.ctypes.data_as(C.POINTER(C.c_uint32)), n)
         return pos[:n], val[:n]
+
+    def fold_hash(self, case, text, off=0, length=None):
+        """(hash, count) of the fold sequence: h' = h * P + mix(matchPos, value), see am_oracle.c orc_fold_hash."""
+        p, off, length = self._args(text, off, length)
+        n = C.c_uint64(0)
+        h = lib().orc_fold_hash(self._h, case, p[0], off, length, C.byref(n))
+        return int(h), int(n.value)
 
     def contains_any(self, case, text, off=0, length=None):
         p, off, length = self._args(text, off, length)

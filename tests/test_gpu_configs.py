@@ -1,0 +1,157 @@
+"""BASELINE.json configs[3] / configs[4] and the at-scale parity gate, on the MI355X through the C ABI.
+
+  cfg4  100k needles, 100-KiB haystacks, the batch cut into contiguous blocks per rank (dist.shard_bounds)
+  cfg5  Replacer.run with the full 50k (needle, replacement) pair set
+  fold checksum  am_matches_fold_hash == the oracle's runWithCase folded with the same hash function
+"""
+import ctypes as C
+import functools
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import alfred_margaret_amd as am
+from alfred_margaret_amd import dist as amdist
+from alfred_margaret_amd import synth
+from oracle import oracle
+from tests.helpers import expand_records, fragment_case, oracle_triples
+
+pytestmark = pytest.mark.gpu
+
+
+@functools.lru_cache(maxsize=2)
+def _cfg3():
+    needles = synth.needles_for("cfg3_runLower_100k_10GiB")
+    return needles, am.Automaton(needles), oracle.Machine(needles)
+
+
+def _device_batch(needles, mixed, first_cell, n_hay, hay_bytes):
+    import torch
+    dev = torch.device("cuda:0")
+    text, n_bytes = synth.haystacks_device(needles, mixed, first_cell, n_hay * hay_bytes // synth.CELL, dev)
+    offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * hay_bytes
+    return text, offs, n_bytes
+
+
+def _run_device(a, case, text_ptr, offs_ptr, n_hay, n_bytes, table=None):
+    lib = am.api.libam()
+    b, m = C.c_void_p(), C.c_void_p()
+    am.api.check(lib.am_batch_from_device(text_ptr, offs_ptr, n_hay, n_bytes, C.byref(b)))
+    try:
+        am.api.check(lib.am_run_batch(a.device, case, b, C.byref(m)))
+        recs = am.api.matches_to_numpy(m)
+        hashes = table.fold_hash(m, n_hay) if table is not None else None
+        lib.am_matches_free(m)
+    finally:
+        lib.am_batch_destroy(b)
+    return recs, hashes
+
+
+def test_cfg4_shape_sharded_equals_unsharded_equals_oracle():
+    """BASELINE configs[3]: the cfg3 automaton (100k needles, IgnoreCase) over 2048 x 100-KiB haystacks; scanning the
+    contiguous per-rank blocks of dist.shard_bounds (world 2 and 8) and concatenating with dist.gather_records gives
+    the unsharded record array; a spread sample of haystacks is compared record by record with the oracle."""
+    import torch
+    w = synth.WORKLOADS["cfg4_100k_1M_haystacks"]
+    needles, a, o = _cfg3()
+    n_hay, hb = 2048, w["hay_bytes"]
+    text, offs, n_bytes = _device_batch(needles, w["mixed"], 0, n_hay, hb)
+    a.set_kernel(0)
+    whole, _ = _run_device(a, w["case"], text.data_ptr(), offs.data_ptr(), n_hay, n_bytes)
+    assert len(whole) > n_hay * 90                       # about one planted needle per KiB plus incidental ones
+    key = whole["haystack"].astype(np.uint64) * np.uint64(1 << 32) + whole["end_pos"]
+    assert np.all(key[1:] > key[:-1])
+    for world in (2, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = amdist.shard_bounds(n_hay, r, world)
+            o_local = torch.arange(hi - lo + 1, dtype=torch.int64, device=text.device) * hb
+            local, _ = _run_device(a, w["case"], text.data_ptr() + lo * hb, o_local.data_ptr(), hi - lo, (hi - lo) * hb)
+            parts.append(amdist.gather_records(local, lo))
+        got = np.concatenate(parts)
+        assert got.tobytes() == whole.tobytes(), world
+    # oracle on every 32nd haystack: full (matchPos, value) fold sequences
+    host = text[:n_bytes].cpu().numpy()
+    sample = list(range(0, n_hay, 32))
+    first = np.searchsorted(whole["haystack"], np.arange(n_hay + 1))
+    for h in sample:
+        pos, val = o.run_list(w["case"], host[h * hb:(h + 1) * hb])
+        rs = whole[first[h]:first[h + 1]]
+        got = expand_records(o.values_off(), o.values(), rs["haystack"], rs["state"], rs["end_pos"])
+        assert got == [(h, int(p), int(v)) for p, v in zip(pos, val)], h
+
+
+def test_cfg4_general_kernel_agrees_on_a_block():
+    """The independent algorithm (general AC walk) on one rank's block of the cfg4 shape."""
+    w = synth.WORKLOADS["cfg4_100k_1M_haystacks"]
+    needles, a, _ = _cfg3()
+    n_hay, hb = 256, w["hay_bytes"]
+    text, offs, n_bytes = _device_batch(needles, w["mixed"], 5 * 100, n_hay, hb)
+    out = {}
+    for k in (2, 1):
+        a.set_kernel(k)
+        out[k], _ = _run_device(a, w["case"], text.data_ptr(), offs.data_ptr(), n_hay, n_bytes)
+    a.set_kernel(0)
+    assert out[1].tobytes() == out[2].tobytes() and len(out[2]) > 10000
+
+
+@pytest.mark.parametrize("full_scans", [False, True])
+def test_cfg5_replacer_reduced(monkeypatch, full_scans):
+    """BASELINE configs[4]: Replacer.run with the full cfg5 pair set (50 000 pairs, ~160 passes) over 64 x 64 KiB of the
+    cfg5 haystack generator: device passes == the oracle's Replacer (Replacer.hs:203-242), with the incremental
+    re-scan and with a full scan in every pass (AM_RP_FULL_SCANS=1)."""
+    workload = "cfg5_replacer_50k_1GiB"
+    w = synth.WORKLOADS[workload]
+    pairs = synth.replacer_pairs(workload)
+    assert len(pairs) == 50_000
+    n_hay, hb = 64, w["hay_bytes"]
+    host = synth.haystacks_host([p[0] for p in pairs], w["mixed"], 0, n_hay * hb // synth.CELL)
+    hays = [bytes(host[i * hb:(i + 1) * hb]) for i in range(n_hay)] + [b"", bytes(host[:100])]
+    if full_scans:
+        monkeypatch.setenv("AM_RP_FULL_SCANS", "1")
+    r = am.Replacer(w["case"], pairs)
+    got = r.run_batch(hays)
+    passes, scanned = r.last_stats()
+    assert passes > 100
+    total = sum(len(h) for h in hays)
+    assert (scanned > total * 10) if full_scans else (scanned < total * 4)
+    orc = oracle.Replacer(w["case"], pairs)
+    with ThreadPoolExecutor(8) as pool:                   # ctypes releases the GIL
+        exp = list(pool.map(orc.run, hays))
+    assert got == exp
+    assert sum(g != h for g, h in zip(got, hays)) >= n_hay    # every 64-KiB haystack was rewritten
+
+
+def test_fold_hash_equals_oracle_fold():
+    """am_matches_fold_hash (device) == runWithCase folded with the same hash function in the oracle: random fragment
+    automata (both kernels, duplicates, empty needle, empty haystacks) and the cfg3 automaton on 48 x 128 KiB."""
+    rng = random.Random(99)
+    for _ in range(40):
+        needles, hays = fragment_case(rng, n_hay_max=6)
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+            o, a = oracle.Machine(ns), am.Automaton(ns)
+            table = am.ValuesTable(a)
+            exp = [o.fold_hash(case, h) for h in hays]
+            for k in (1, 2) if "" not in ns else (1,):
+                a.set_kernel(k)
+                s = am.api._Slices(hays)
+                m = C.c_void_p()
+                am.api.check(am.api.libam().am_run(a.device, case, s.arr, s.n, C.byref(m)))
+                hashes, counts = table.fold_hash(m, len(hays))
+                am.api.libam().am_matches_free(m)
+                assert [(int(h), int(c)) for h, c in zip(hashes, counts)] == exp, (ns, hays, case, k)
+    w = synth.WORKLOADS["cfg3_runLower_100k_10GiB"]
+    needles, a, o = _cfg3()
+    n_hay, hb = 48, 128 << 10
+    text, offs, n_bytes = _device_batch(needles, w["mixed"], 11, n_hay, hb)
+    host = text[:n_bytes].cpu().numpy()
+    table = am.ValuesTable(a)
+    exp = [o.fold_hash(w["case"], host[i * hb:(i + 1) * hb]) for i in range(n_hay)]
+    for k in (2, 1):
+        a.set_kernel(k)
+        _, (hashes, counts) = _run_device(a, w["case"], text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, table)
+        assert [(int(h), int(c)) for h, c in zip(hashes, counts)] == exp, k
+    a.set_kernel(0)

@@ -387,8 +387,8 @@ def test_single_haystack_split_like_multi_gpu():
         max_cps = max(len(n) if isinstance(n, str) else len(n.decode("utf-8")) for n in needles)
         for world in (2, 5, 8):
             parts = []
-            for start, lo, hi in amdist.split_single_haystack(text, world, max_cps):
-                parts.append(amdist.own_records(a.run_records(case, [text[start:hi]]), start, lo, hi))
+            for start, lo, hi, scan_hi in amdist.split_single_haystack(text, world, max_cps):
+                parts.append(amdist.own_records(a.run_records(case, [text[start:scan_hi]]), start, lo, hi))
             got = np.concatenate(parts)
             assert np.array_equal(got["end_pos"], whole["end_pos"]) and np.array_equal(got["state"], whole["state"])
 

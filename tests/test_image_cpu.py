@@ -109,17 +109,35 @@ def test_single_haystack_split_across_ranks(chk):
             p = am.Automaton(ns)
             img = chk.flatten(p, case)
             max_cps = max([len(n) for n in ns] + [1])
-            which = 0 if "" in ns else 1
-            n, whole = chk.scan(img, which, [b])
+            for which in ((0,) if "" in ns else (0, 1)):        # 0 = general AC walk, 1 = suffix filter
+                _split_equals_whole(chk, img, which, b, max_cps, (1, 2, 3, 7), (case, ns))
+
+
+def _split_equals_whole(chk, img, which, b, max_cps, worlds, ctx):
+    import numpy as np
+    from alfred_margaret_amd import dist as amdist
+    n, whole = chk.scan(img, which, [b])
+    assert n >= 0
+    exp = sorted(zip(whole[2].tolist(), whole[1].tolist()))
+    for world in worlds:
+        got = []
+        for start, lo, hi, scan_hi in amdist.split_single_haystack(b, world, max_cps):
+            n, part = chk.scan(img, which, [b[start:scan_hi]])
             assert n >= 0
-            exp = sorted(zip(whole[2].tolist(), whole[1].tolist()))
-            for world in (1, 2, 3, 7):
-                got = []
-                for start, lo, hi in amdist.split_single_haystack(b, world, max_cps):
-                    n, part = chk.scan(img, which, [b[start:hi]])
-                    assert n >= 0
-                    recs = np.zeros(len(part[0]), dtype=am.api.MATCH_DTYPE)
-                    recs["end_pos"], recs["state"] = part[2], part[1]
-                    own = amdist.own_records(recs, start, lo, hi)
-                    got += list(zip(own["end_pos"].tolist(), own["state"].tolist()))
-                assert got == exp, (world, case, ns, b)
+            recs = np.zeros(len(part[0]), dtype=am.api.MATCH_DTYPE)
+            recs["end_pos"], recs["state"] = part[2], part[1]
+            own = amdist.own_records(recs, start, lo, hi)
+            got += list(zip(own["end_pos"].tolist(), own["state"].tolist()))
+        assert got == exp, (world, which, ctx, b)
+
+
+def test_single_haystack_split_inside_code_points_general_kernel(chk):
+    """A rank's range may end inside a code point.  The general kernel must not see the truncated sequence (its
+    guarded decode would read it as another code point): needle U+00C0 / U+00E0 over U+00E9 x 10 used to report
+    matches that do not exist (round-1 advisor finding)."""
+    for case, needle in ((0, "\u00c0"), (1, "\u00e0"), (0, "\u00e9"), (1, "\u00e9")):
+        p = am.Automaton([needle])
+        img = chk.flatten(p, case)
+        for hay in ("\u00e9" * 10, "\u00c9\u00e9" * 7, "a\u20ac\U0001d11e\u00e9" * 5):
+            for which in (0, 1):
+                _split_equals_whole(chk, img, which, hay.encode("utf-8"), 1, (2, 3, 5, 7, 8), (case, needle))
