@@ -18,6 +18,7 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 LIB = os.path.join(PKG, "lib")
 ARCH = "gfx950"
+LINK_EXTRA = []        # extra link flags of libam.so (e.g. RCCL for the single-process multi-GPU entry points)
 
 
 def _hipcc():
@@ -44,13 +45,28 @@ def _glob_deps(*dirs):
 
 
 def build_libam(force=False):
+    """Every source is compiled to its own object (in parallel: am_kernels.hip alone takes ~40 s), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(LIB, exist_ok=True)
+    obj_dir = os.path.join(LIB, "obj")
+    os.makedirs(obj_dir, exist_ok=True)
     target = os.path.join(LIB, "libam.so")
-    srcs = [os.path.join(CSRC, f) for f in ("am_abi.cpp", "am_flatten.cpp", "am_kernels.hip", "am_replace.hip")]
-    deps = _glob_deps(CSRC) + [os.path.join(ROOT, "include", "am.h")]
-    if force or _stale(target, deps):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-x", "hip", *srcs, "-o", target + ".tmp"]
+    names = ("am_abi.cpp", "am_flatten.cpp", "am_kernels.hip", "am_replace.hip", "am_multi.cpp")
+    srcs = [os.path.join(CSRC, f) for f in names if os.path.exists(os.path.join(CSRC, f))]
+    headers = [d for d in _glob_deps(CSRC) if d.endswith((".h", ".hpp", ".inc"))] + [os.path.join(ROOT, "include", "am.h")]
+    objs = [os.path.join(obj_dir, os.path.basename(f) + ".o") for f in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if force or _stale(obj, [src] + headers):
+            subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src, "-o", obj + ".tmp"])
+            os.replace(obj + ".tmp", obj)
+        return obj
+
+    with ThreadPoolExecutor(len(srcs)) as pool:
+        list(pool.map(compile_one, zip(srcs, objs)))
+    if force or _stale(target, objs):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *objs, "-o", target + ".tmp"] + LINK_EXTRA
         subprocess.check_call(cmd)
         os.replace(target + ".tmp", target)
     return target

@@ -424,7 +424,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         h.sf_bloom_log2_words = lw;
         std::vector<uint32_t> bloom((size_t)1 << lw, 0);
         for (int t = 0; t < 4; t++)
-            for (const TierEntry& e : tier_entries[t]) { const uint32_t hh = bloom_hash(e.key, (uint32_t)t + 1); bloom[bloom_word(hh, lw)] |= bloom_mask(hh, bloom_three_bits(lw)); }
+            for (const TierEntry& e : tier_entries[t]) { const uint32_t hh = bloom_hash(e.key, (uint32_t)t + 1); bloom[bloom_word(hh, lw)] |= bloom_mask(hh); }
         h.off_bloom = blob.put(bloom);
     }
     for (int t = 0; t < 3; t++) {       // 1..3-byte needles: plain open addressing (rare)

@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 4;
+constexpr uint32_t kImageVersion = 5;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -191,39 +191,44 @@ AM_HD uint32_t fold_dword(uint32_t x)
     uint32_t hept = x & 0x7f7f7f7fu;
     uint32_t ge_a = hept + 0x3f3f3f3fu;      // bit 7 set iff heptet >= 0x41
     uint32_t gt_z = hept + 0x25252525u;      // bit 7 set iff heptet >  0x5A
-    uint32_t up = ge_a & ~gt_z & ~x & 0x80808080u;
-    return x | (up >> 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t up = __builtin_amdgcn_bitop3_b32(ge_a, gt_z, x, 0x10);      // ge_a & ~gt_z & ~x in one v_bitop3 (six VALU per dword in all)
+#else
+    const uint32_t up = ge_a & ~gt_z & ~x;
+#endif
+    return x | ((up >> 2) & 0x20202020u);
 }
 
-// Bloom filter over needle suffixes: one 32-bit word per key, three bits in it, all derived from ONE
-// 32-bit multiply (word = top bits of the product, bit positions = three 5-bit fields below them).
-// Measured on the 100k-needle workload (128 KiB filter): 2.5 % false positives, same as two
-// independent multiplies would give.  Tier 4 (the hot one) needs no salt.
+// Bloom filter over needle suffixes: one 32-bit word per key, FOUR bits in it.  Word and bits both come from ONE 32-bit
+// multiply: the word index is the top bits of the product, and the four bit positions are one of 512 precomputed masks,
+// selected by product bits 2..10.  In the kernel the mask table sits in LDS next to the filter, so a position is tested
+// with two LDS reads, one AND and one compare -- `(word & mask) == mask` -- instead of extracting and shifting three bit
+// fields (the VALU is the bottleneck of k_sf, the LDS pipe has room).  Measured on the 100k-needle workload (128 KiB
+// filter, 3.8 keys per word): 4.3 % false positives, the same as three independent bit fields gave; on the sparse
+// filters of small automata four bits beat three and two.  Tier 4 (the hot one) needs no salt.
 constexpr uint32_t kBloomMul = 0x9E3779B1u;
+constexpr uint32_t kBloomMaskLog2 = 9;                          // 512 masks = 2 KiB of LDS
+constexpr uint32_t kBloomMasks = 1u << kBloomMaskLog2;
 AM_HD uint32_t bloom_hash(uint32_t key, uint32_t tier) { return (key + (4u - tier) * 0x7F4A7C15u) * kBloomMul; }
 AM_HD uint32_t bloom_word(uint32_t h, uint32_t log2_words) { return h >> (32u - log2_words); }
-// Bits per key in one 32-bit filter word: three for the full 128-KiB filter (many keys), two for the smaller filters of
-// small automata (they are sparse enough, and every bit costs two VALU instructions per haystack position).  The fields
-// sit where the kernel can use them as shift amounts with the fewest instructions (a variable shift reads only the low
-// 5 bits of its amount, so `h` itself serves as one field).
-AM_HD bool bloom_three_bits(uint32_t log2_words) { return log2_words >= 15u; }
-AM_HD uint32_t bloom_mask(uint32_t h, bool three)
+AM_HD uint32_t bloom_mask_index(uint32_t h) { return (h >> 2) & (kBloomMasks - 1u); }
+// mask i of the table: four distinct bits chosen by a mix of i (the kernel fills its LDS copy with this at start-up)
+AM_HD uint32_t bloom_mask_entry(uint32_t i)
 {
-    return (1u << ((h >> 12) & 31u)) | (1u << (h & 31u)) | (three ? 1u << ((h >> 7) & 31u) : 0u);
+    uint32_t x = (i + 1u) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    uint32_t m = 0;
+    for (uint32_t k = 0; k < 4u; k++) {
+        uint32_t b = (x >> (5u * k)) & 31u;
+        while (m & (1u << b)) b = (b + 1u) & 31u;
+        m |= 1u << b;
+    }
+    return m;
 }
-// 1 iff all bits of h are set in the filter word v
-template <bool THREE>
-AM_HD uint32_t bloom_hit_k(uint32_t v, uint32_t h)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t two = __builtin_amdgcn_ubfe(v, h >> 12, 1u) & (v >> (h & 31u));
-    return THREE ? two & (v >> ((h >> 7) & 31u)) : two;
-#else
-    const uint32_t two = (v >> ((h >> 12) & 31u)) & (v >> (h & 31u));
-    return (THREE ? two & (v >> ((h >> 7) & 31u)) : two) & 1u;
-#endif
-}
-AM_HD uint32_t bloom_hit(uint32_t v, uint32_t h, bool three) { return three ? bloom_hit_k<true>(v, h) : bloom_hit_k<false>(v, h); }
+// mask of hash h; `tab` = the 512-entry table when the caller has one (the kernel's LDS copy), else null
+AM_HD uint32_t bloom_mask(uint32_t h, const uint32_t* tab = nullptr) { return tab ? tab[bloom_mask_index(h)] : bloom_mask_entry(bloom_mask_index(h)); }
+// true iff all mask bits of h are set in the filter word v
+AM_HD bool bloom_hit(uint32_t v, uint32_t h, const uint32_t* tab = nullptr) { const uint32_t m = bloom_mask(h, tab); return (v & m) == m; }
 
 AM_HD uint32_t tier_slot(uint32_t key, uint32_t log2_cap) { return (key * 0x85EBCA6Bu) >> (32u - log2_cap); }
 
@@ -612,16 +617,16 @@ AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64
 }
 
 // Bloom test of one window for every active tier; returns true if any tier may match.
-// `bloom` may point to LDS (device) or to the image (host checker).  The kernel's hot loop uses a
-// batched form of the tier-4 test (all 16 LDS reads of a lane in flight together) and calls this
-// only for automata that contain needles shorter than 4 bytes.
-AM_HD bool sf_filter_short(const uint32_t* bloom, uint32_t log2_words, uint32_t tiers, uint32_t w)
+// `bloom` may point to LDS (device) or to the image (host checker); `masks` = the kernel's LDS copy of the mask table or
+// null.  The kernel's hot loop uses a batched form of the tier-4 test (all LDS reads of a lane in flight together) and
+// calls sf_filter_short only for automata that contain needles shorter than 4 bytes.
+AM_HD bool sf_filter_short(const uint32_t* bloom, uint32_t log2_words, uint32_t tiers, uint32_t w, const uint32_t* masks = nullptr)
 {
     bool hit = false;
     for (uint32_t t = 1; t <= 3; t++) {
         if (tiers & (1u << (t - 1))) {
             const uint32_t h = bloom_hash(w >> (8u * (4u - t)), t);
-            hit = hit || bloom_hit(bloom[bloom_word(h, log2_words)], h, bloom_three_bits(log2_words));
+            hit = hit || bloom_hit(bloom[bloom_word(h, log2_words)], h, masks);
         }
     }
     return hit;
@@ -629,7 +634,7 @@ AM_HD bool sf_filter_short(const uint32_t* bloom, uint32_t log2_words, uint32_t 
 AM_HD bool sf_filter_window(const uint32_t* bloom, uint32_t log2_words, uint32_t tiers, uint32_t w)
 {
     const uint32_t h = bloom_hash(w, 4);
-    bool hit = (tiers & 8u) && bloom_hit(bloom[bloom_word(h, log2_words)], h, bloom_three_bits(log2_words));
+    bool hit = (tiers & 8u) && bloom_hit(bloom[bloom_word(h, log2_words)], h);
     if (tiers & 7u) hit = hit || sf_filter_short(bloom, log2_words, tiers, w);
     return hit;
 }

@@ -57,6 +57,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x, uint32_t /*la
     return x;
 }
 
+// a value that is the same in every lane, moved to scalar registers (the two v_readfirstlane also force any load that
+// produces it to be waited for right here)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x)
 {
 #pragma unroll
@@ -80,6 +88,13 @@ constexpr int kSfWaves = kSfThreads / 64;
 constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
 constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 10 | offset): candidates that need the exact lookup + trie walk
 constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
+constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table: first thing in LDS, the filter words follow
+
+// LDS by absolute byte address.  k_sf declares no static LDS, so its dynamic LDS starts at address 0; reading through an
+// address-space-3 pointer made from an integer lets the compiler put constant parts into the instruction's offset field
+// instead of adding the (relocatable, always zero) base of the extern array to every address (16 v_add per chunk).
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t byte_addr) { return *reinterpret_cast<const lds_u32_t*>((uintptr_t)byte_addr); }
 
 // ILP = candidates probed per lane per round (their loads are in flight together);
 // NT  = stream the haystack with non-temporal loads.
@@ -103,11 +118,13 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
-    uint32_t* bloom = lds;
-    uint8_t* stage_all = reinterpret_cast<uint8_t*>(lds + words);
+    uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
+    uint32_t* bloom = lds + kBloomMasks;                              // LDS bytes [kSfMaskBytes, kSfMaskBytes + 4 * words)
+    uint8_t* stage_all = reinterpret_cast<uint8_t*>(bloom + words);
     uint16_t* q1_all = reinterpret_cast<uint16_t*>(stage_all + kSfWaves * kSfStage);
     uint16_t* q2_all = q1_all + kSfWaves * kSfQ1;
 
+    for (uint32_t i = threadIdx.x; i < kBloomMasks; i += kSfThreads) masks[i] = bloom_mask_entry(i);
     for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
     __syncthreads();
 
@@ -212,24 +229,37 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         q2_head += nb;
     };
 
-    // software pipeline: the next chunk's 16 B per lane (+ the 4 bytes before them) are requested
-    // before the current chunk is filtered and probed, so HBM latency hides behind that work
-    auto fetch = [&](uint64_t cc, uint4& v, uint2& prev) {
+    // software pipeline: the next chunk's 16 B per lane are requested before the current chunk is filtered and probed,
+    // so HBM latency hides behind that work.  The bytes BEFORE a lane's 16 (its windows reach 3 bytes back, the probe
+    // 5) come from the lane below with one DPP move; lane 0 takes them from `carry` = the last 8 (folded) bytes of the
+    // chunk this wave processed just before, or -- at the start of a unit -- 8 bytes fetched from memory.
+    auto fetch = [&](uint64_t cc, uint4& v) {
         const uint64_t p = cc * kSfChunk + lane * 16u;
-        v = make_uint4(0, 0, 0, 0); prev = make_uint2(0, 0);
+        v = make_uint4(0, 0, 0, 0);
         if (cc < n_chunks && p < b.total) {
             typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
             const u32x4_native* src = reinterpret_cast<const u32x4_native*>(b.text + p);
             const u32x4_native t = *src;                                            // global_load_dwordx4
             v = make_uint4(t.x, t.y, t.z, t.w);
-            if (p >= 8) prev = *reinterpret_cast<const uint2*>(b.text + p - 8);     // the 8 bytes before the lane's 16
         }
+    };
+    auto fetch_before = [&](uint64_t cc, uint32_t& c3, uint32_t& c4) {          // uniform: one request for the wave
+        uint2 t = make_uint2(0, 0);
+        if (cc < n_chunks && cc > 0) {
+            t = *reinterpret_cast<const uint2*>(b.text + cc * kSfChunk - 8);
+            t.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x); t.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y);   // waited for here, not at the join
+        }
+        c3 = IC ? fold_dword(t.x) : t.x; c4 = IC ? fold_dword(t.y) : t.y;
     };
     if (timing) t_mark = __builtin_amdgcn_s_memtime();
     uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
-    uint32_t hay0 = 0; uint64_t hs0 = 1, he0 = 0;       // cached haystack bracket [hs0, he0): empty until the first lookup
-    uint4 cur_v; uint2 cur_prev;
-    fetch(u * UC, cur_v, cur_prev);
+    uint64_t hs0 = 1, he0 = 0;                          // cached haystack bracket [hs0, he0): empty until the first lookup
+    uint4 cur_v; uint32_t carry3, carry4;
+    fetch(u * UC, cur_v);
+    fetch_before(u * UC, carry3, carry4);
+    // the first chunk's data is waited for HERE: if it were still pending at the loop header, the compiler's (static) wait at
+    // the top of the loop body would also cover the prefetch of the next chunk that every iteration issues first
+    asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));
 
     for (; u < n_units; u += n_waves) {
         unit_base_chunk = u * UC;
@@ -237,29 +267,39 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
-            uint4 next_v = make_uint4(0, 0, 0, 0); uint2 next_prev = make_uint2(0, 0);
-            if (ablate == 8) fetch(c, cur_v, cur_prev);          // timing experiment only: no prefetch, expose HBM latency in the filter phase
-            else fetch(ci + 1 < n_in_unit ? c + 1 : (u + n_waves) * UC, next_v, next_prev);
+            uint4 next_v = make_uint4(0, 0, 0, 0);
+            uint32_t next_c3 = 0, next_c4 = 0;
+            const bool last_of_unit = ci + 1 >= n_in_unit;
+            fetch(!last_of_unit ? c + 1 : (u + n_waves) * UC, next_v);
+            if (last_of_unit) fetch_before((u + n_waves) * UC, next_c3, next_c4);
 
             const uint64_t c0 = c * kSfChunk;
             const uint64_t p0 = c0 + lane * 16u;
             // the haystack that contains the chunk's first byte is looked up only when the chunk leaves
             // the one found last time (same address in every lane: one request per load); almost every
-            // chunk lies inside one haystack, then no candidate needs its own lookup either
-            if (c0 >= he0 || c0 < hs0) { hay0 = find_haystack(b, c0); hs0 = b.offsets[hay0]; he0 = b.offsets[hay0 + 1]; }
+            // chunk lies inside one haystack, then no candidate needs its own lookup either.
+            // (The bracket goes through readfirstlane so that its loads are waited for INSIDE this rarely taken branch: a load
+            // left pending at the join would make the compiler wait with vmcnt(0) on every chunk -- and vmcnt counts in order,
+            // so that wait would also cover the prefetch issued just above and expose a full HBM latency per chunk.)
+            if (c0 >= he0 || c0 < hs0) { const uint32_t hay0 = find_haystack(b, c0); hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]); }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
-            (void)hay0;
 
-            uint32_t dm = cur_prev.x, d0 = cur_prev.y, d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
-            if (IC) { dm = fold_dword(dm); d0 = fold_dword(d0); d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+            uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+            if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+            // the 4 bytes before the lane's 16: the lane below's last dword (wave_shr:1; lane 0 keeps `old` = the carry)
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);
             const uint32_t d[5] = {d0, d1, d2, d3, d4};
             *reinterpret_cast<uint4*>(stage + 16u + lane * 16u) = make_uint4(d1, d2, d3, d4);
-            if (lane == 0) *reinterpret_cast<uint2*>(stage + 8u) = make_uint2(dm, d0);
+            if (lane == 0) *reinterpret_cast<uint2*>(stage + 8u) = make_uint2(carry3, carry4);
+            if (!last_of_unit) {                                  // the next chunk follows this one: its carry is this chunk's tail
+                next_c3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63);
+                next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
+            }
             uint32_t cand = 0;
             {
-                // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 16 LDS reads are all in
-                // flight before the first one is tested
-                uint32_t h[16], v[16];
+                // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 32 LDS reads (filter word + mask per
+                // position) are all in flight before the first one is tested
+                uint32_t h[16], v[16], m[16];
                 const uint32_t sh_word = 32u - log2_words;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -269,18 +309,19 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 }
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    if (LW) v[k] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(bloom) + ((h[k] >> (30 - LW)) & (((1u << LW) - 1u) << 2)));
-                    else v[k] = bloom[h[k] >> sh_word];
+                    if (LW) v[k] = lds_read_u32(kSfMaskBytes + ((h[k] >> (30 - LW)) & (((1u << LW) - 1u) << 2)));
+                    else v[k] = lds_read_u32(kSfMaskBytes + ((h[k] >> sh_word) << 2));
+                    m[k] = lds_read_u32(h[k] & ((kBloomMasks - 1u) << 2));
                 }
 #pragma unroll
-                for (int k = 15; k >= 0; k--) cand = (cand << 1) | bloom_hit_k<LW == 15>(v[k], h[k]);      // bit k of cand = position k (LW = 0 instances only run filters below 128 KiB: two bits per key)
+                for (int k = 15; k >= 0; k--) cand = (cand << 1) | (uint32_t)((v[k] & m[k]) == m[k]);      // bit k of cand = position k
             }
             if (SHORT) {                                   // automata with 1..3-byte needles: extra probes per position
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int j = k >> 2, sh = k & 3;
                     const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
-                    if (sf_filter_short(bloom, log2_words, tiers, w)) cand |= 1u << k;
+                    if (sf_filter_short(bloom, log2_words, tiers, w, masks)) cand |= 1u << k;
                 }
             }
             if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
@@ -309,6 +350,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 // The common case (<= 64 survivors left) takes the 1-wide instance: half the instructions.
                 auto probe_round = [&](uint32_t base, auto width_tag) {
                     constexpr int W = decltype(width_tag)::value;
+                    if (ablate == 5) return;                      // timing experiment only: filter + compaction, no probe
                     uint64_t avail[W];
                     uint32_t pos[W], w[W], nb[W];
                     bool valid[W], defer[W];
@@ -331,6 +373,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     }
                     if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
                     sf_probe_n<W>(s, w, nb, avail, valid, defer, ablate);
+                    if (ablate == 4) { for (int k = 0; k < W; k++) defer[k] = false; }      // timing experiment only: no resolve
 #pragma unroll
                     for (int k = 0; k < W; k++) {
                         const uint64_t m = __ballot(defer[k]);
@@ -349,7 +392,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 if (total <= (uint32_t)kSfQ1) break;
                 wave_lds_fence();
             }
-            cur_v = next_v; cur_prev = next_prev;
+            cur_v = next_v; carry3 = next_c3; carry4 = next_c4;
         }
         // end of unit: drain the ring so that every item of a batch belongs to one unit
         wave_lds_fence();
@@ -468,7 +511,7 @@ hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record
 }
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
-size_t sf_lds_bytes(const SfView& s) { return ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
+size_t sf_lds_bytes(const SfView& s) { return kSfMaskBytes + ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
 
 template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)

@@ -22,7 +22,7 @@ int main(){
   for(uint64_t p=8;p<n;p++){
     uint32_t w=0; for(int i=0;i<4;i++) w|=(uint32_t)(AM_REPLAY_CASE ? fold_byte(text[p-3+i]) : text[p-3+i])<<(8*i);
     const uint32_t hh=bloom_hash(w,4);
-    if(!bloom_hit(s.bloom[bloom_word(hh,s.bloom_log2_words)],hh,bloom_three_bits(s.bloom_log2_words))) continue;
+    if(!bloom_hit(s.bloom[bloom_word(hh,s.bloom_log2_words)],hh)) continue;
     cand++;
     { u32x4 ca=s.t4_cold[t4_bucket(t4_hash_a(w),lb)], cb=s.t4_cold[t4_bucket(t4_hash_b(w),lb)]; if((ca.x==w&&ca.z!=kNone)||(ca.y==w&&ca.w!=kNone)||(cb.x==w&&cb.z!=kNone)||(cb.y==w&&cb.w!=kNone)) keyhit++; }
     uint32_t nb=AM_REPLAY_CASE ? fold_byte(text[p-4]) : text[p-4], nb2=AM_REPLAY_CASE ? fold_byte(text[p-5]) : text[p-5];
