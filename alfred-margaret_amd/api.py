@@ -79,6 +79,18 @@ ABI = {
     "am_automaton_from_image": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "am_automaton_image_read": (C.c_int, [_vp, C.c_int, _vp, _sz]),
     "am_automaton_from_host_image": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "am_multi_unique_id": (C.c_int, [_vp]),
+    "am_multi_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "am_multi_create_rank": (C.c_int, [C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    "am_multi_destroy": (None, [_vp]),
+    "am_multi_local_devices": (C.c_int, [_vp]),
+    "am_multi_world_size": (C.c_int, [_vp]),
+    "am_multi_device": (C.c_int, [_vp, C.c_int]),
+    "am_multi_broadcast_automaton": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "am_multi_allreduce_sum": (C.c_int, [_vp, _vp, _sz]),
+    "am_multi_count": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(Slice), _sz, _vp, _u64p]),
+    "am_multi_run": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp), C.POINTER(_sz)]),
+    "am_multi_matches_free": (None, [_vp]),
     "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
     "am_unlower_code_point": (_sz, [C.c_uint32, _vp, _sz]),
     "am_set_stream": (C.c_int, [_vp]),

@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 LIB = os.path.join(PKG, "lib")
 ARCH = "gfx950"
-LINK_EXTRA = []        # extra link flags of libam.so (e.g. RCCL for the single-process multi-GPU entry points)
+LINK_EXTRA = ["-ldl"]        # RCCL (am_multi_*) is bound with dlopen at first use, not at link time
 
 
 def _hipcc():

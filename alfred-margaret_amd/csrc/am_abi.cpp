@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,7 @@ static_assert(offsetof(am_match, end_pos) == offsetof(Record, end_pos) && offset
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+namespace am { int abi_fail(int code, const std::string& msg) { return fail(code, msg); } }      // for am_multi.cpp (same thread-local message)
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -40,25 +42,28 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 namespace {
 
+// ---- per-device runtime.  libam serves every visible HIP device from one process: a handle (automaton, batch, result,
+// replacer) lives on the device that was current when it was made (or that its memory belongs to), every entry point makes
+// that device current for the calling thread while it runs, and launches go to a stream that belongs to the CALLING THREAD
+// (one library stream per thread and device, or the stream the thread gave with am_set_stream): calls from different
+// threads do not serialise on a shared stream or lock.
+constexpr int kMaxDev = 16;
+struct DeviceInfo { int n_cu = 0; size_t hbm = 0; std::string name; };
 struct Runtime {
     std::mutex mu;
     bool probed = false;
-    bool have_device = false;
-    int n_cu = 0;
-    size_t hbm = 0;
-    std::string name, why;
-    hipStream_t own_stream = nullptr;
-    hipStream_t user_stream = nullptr;
-    bool use_user = false;
-    // profiling
-    bool prof_on = false;
-    struct Pending { std::string k; hipEvent_t a, b; };
+    int n_dev = 0;
+    std::string why;
+    DeviceInfo dev[kMaxDev];
+    // profiling (process-wide totals per kernel name)
+    std::atomic<bool> prof_on{false};
+    struct Pending { std::string k; hipEvent_t a, b; int dev; };
     std::vector<Pending> pending;
     std::map<std::string, std::pair<double, uint64_t>> prof;
 };
 Runtime g_rt;
 
-int ensure_device()
+int ensure_runtime()
 {
     std::lock_guard<std::mutex> lk(g_rt.mu);
     if (!g_rt.probed) {
@@ -68,38 +73,88 @@ int ensure_device()
         if (e != hipSuccess || n <= 0) {
             g_rt.why = std::string("no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") + "); libam has no CPU path";
         } else {
-            int dev = 0;
-            hipDeviceProp_t p;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) {
-                g_rt.have_device = true;
-                g_rt.n_cu = p.multiProcessorCount;
-                g_rt.hbm = p.totalGlobalMem;
-                g_rt.name = p.gcnArchName;
-            } else {
-                g_rt.why = "hipGetDeviceProperties failed";
+            if (n > kMaxDev) n = kMaxDev;
+            for (int d = 0; d < n; d++) {
+                hipDeviceProp_t p;
+                if (hipGetDeviceProperties(&p, d) != hipSuccess) { g_rt.why = "hipGetDeviceProperties failed"; n = d; break; }
+                g_rt.dev[d].n_cu = p.multiProcessorCount; g_rt.dev[d].hbm = p.totalGlobalMem; g_rt.dev[d].name = p.gcnArchName;
             }
+            g_rt.n_dev = n;
         }
     }
-    if (!g_rt.have_device) return fail(AM_ERR_NO_DEVICE, g_rt.why);
+    if (g_rt.n_dev <= 0) return fail(AM_ERR_NO_DEVICE, g_rt.why);
     return AM_OK;
 }
 
-int get_stream(hipStream_t* st)
+// the device that is current for the calling thread
+int current_device(int* dev)
 {
-    std::lock_guard<std::mutex> lk(g_rt.mu);
-    if (g_rt.use_user) { *st = g_rt.user_stream; return AM_OK; }
-    if (!g_rt.own_stream) HIP_TRY(hipStreamCreateWithFlags(&g_rt.own_stream, hipStreamNonBlocking));
-    *st = g_rt.own_stream;
+    AM_TRY(ensure_runtime());
+    int d = 0;
+    HIP_TRY(hipGetDevice(&d));
+    if (d < 0 || d >= g_rt.n_dev) return fail(AM_ERR_UNSUPPORTED, "current HIP device is beyond the devices libam serves");
+    *dev = d;
+    return AM_OK;
+}
+int ensure_device() { int d; return current_device(&d); }
+
+// the device a device pointer belongs to (falls back to the current device for pointers HIP does not know)
+int device_of_pointer(const void* p, int* dev)
+{
+    AM_TRY(current_device(dev));
+    hipPointerAttribute_t at;
+    if (p && hipPointerGetAttributes(&at, p) == hipSuccess) { if (at.device >= 0 && at.device < g_rt.n_dev) *dev = at.device; }
+    else (void)hipGetLastError();
+    return AM_OK;
+}
+
+// RAII: makes `dev` current for the calling thread while an entry point runs
+struct OnDevice {
+    int prev = -1; bool switched = false; int rc = AM_OK;
+    explicit OnDevice(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { rc = fail(AM_ERR_HIP, "hipGetDevice failed"); return; }
+        if (prev != dev) {
+            hipError_t e = hipSetDevice(dev);
+            if (e != hipSuccess) { rc = fail(AM_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); return; }
+            switched = true;
+        }
+    }
+    ~OnDevice() { if (switched) (void)hipSetDevice(prev); }
+};
+#define ON_DEVICE(dev) OnDevice on_device_guard_(dev); AM_TRY(on_device_guard_.rc)
+
+struct am_batch_fwd;
+// per calling thread: its library streams (one per device, made on first use), its stream override, its one-shot batches
+struct ThreadState {
+    hipStream_t own[kMaxDev] = {};
+    hipStream_t user = nullptr; bool use_user = false;
+    am_batch* oneshot[kMaxDev] = {};
+    ~ThreadState();
+};
+thread_local ThreadState tl_state;
+hipStream_t adopt_stream(int dev);
+am_batch* adopt_batch(int dev);
+
+int get_stream(int dev, hipStream_t* st)
+{
+    if (tl_state.use_user) { *st = tl_state.user; return AM_OK; }
+    if (!tl_state.own[dev]) {
+        tl_state.own[dev] = adopt_stream(dev);                                                               // one left by a thread that ended
+        if (!tl_state.own[dev]) HIP_TRY(hipStreamCreateWithFlags(&tl_state.own[dev], hipStreamNonBlocking));     // the device is current (ON_DEVICE)
+    }
+    *st = tl_state.own[dev];
     return AM_OK;
 }
 
 // RAII HIP-event bracket around one kernel launch (only when profiling is enabled)
 struct Prof {
     bool on; hipStream_t st; Runtime::Pending p;
-    Prof(const char* k, hipStream_t s) : on(g_rt.prof_on), st(s)
+    Prof(const char* k, hipStream_t s) : on(g_rt.prof_on.load(std::memory_order_relaxed)), st(s)
     {
         if (!on) return;
-        p.k = k;
+        p.k = k; p.dev = 0;
+        (void)hipGetDevice(&p.dev);
         if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(p.a, st);
     }
@@ -137,6 +192,7 @@ struct Flavor {
 }  // namespace
 
 struct am_automaton {
+    int dev = 0;                 // the device its images live on
     std::vector<uint64_t> transitions, root_ascii;
     std::vector<uint32_t> offsets, values_len;
     bool has_ref = false;        // false for handles attached to a received image
@@ -147,6 +203,7 @@ struct am_automaton {
 };
 
 struct am_batch {
+    int dev = 0;
     void* d_text = nullptr; uint64_t* d_offsets = nullptr;
     bool owns = false;
     bool hidx_ready = false;     // the per-KiB haystack index depends only on the offsets: built once per batch
@@ -157,6 +214,7 @@ struct am_batch {
 };
 
 struct am_matches {
+    int dev = 0;
     Record* d_records = nullptr; uint64_t n = 0; size_t cap_bytes = 0;
     std::vector<am_match> host; bool fetched = false;
 };
@@ -180,7 +238,43 @@ struct RecordCache {
         if (old) (void)hipFree(old);
     }
 };
-RecordCache g_record_cache;
+RecordCache g_record_cache[kMaxDev];
+
+// Streams and one-shot batches of threads that have ended wait here for the next new thread: a thread-exit destructor must
+// not call into HIP (it may run while the runtime is being torn down at process exit), and a server that starts and ends
+// many threads must not leak a stream and a batch per thread.
+struct Orphans {
+    std::mutex mu;
+    std::vector<hipStream_t> streams[kMaxDev];
+    std::vector<am_batch*> batches[kMaxDev];
+};
+Orphans& orphans() { static Orphans* o = new Orphans(); return *o; }      // never destroyed: no static-destruction order to worry about
+hipStream_t adopt_stream(int dev)
+{
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (o.streams[dev].empty()) return nullptr;
+    hipStream_t s = o.streams[dev].back(); o.streams[dev].pop_back();
+    return s;
+}
+am_batch* adopt_batch(int dev)
+{
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (o.batches[dev].empty()) return nullptr;
+    am_batch* b = o.batches[dev].back(); o.batches[dev].pop_back();
+    return b;
+}
+
+ThreadState::~ThreadState()
+{
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    for (int d = 0; d < kMaxDev; d++) {
+        if (oneshot[d]) { o.batches[d].push_back(oneshot[d]); oneshot[d] = nullptr; }
+        if (own[d]) { o.streams[d].push_back(own[d]); own[d] = nullptr; }
+    }
+}
 }  // namespace
 
 // ------------------------------------------------------------------ automaton
@@ -194,7 +288,8 @@ static int prepare(const am_automaton* ca, int case_mode, const Flavor** out)
     Flavor& f = a->fl[case_mode];
     if (!f.ready) {
         if (!a->has_ref) return fail(AM_ERR_UNSUPPORTED, "this handle was attached to an image of the other case mode");
-        AM_TRY(ensure_device());
+        AM_TRY(ensure_runtime());
+        ON_DEVICE(a->dev);
         std::vector<uint8_t> img; std::string err;
         if (case_mode == AM_CASE_SENSITIVE && !a->cs_image.empty()) img.swap(a->cs_image);
         else {
@@ -235,6 +330,9 @@ extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transit
     a->root_ascii.assign(root_ascii, root_ascii + 128);
     a->values_len.assign(values_len, values_len + n_states);
     a->has_ref = true;
+    // the automaton belongs to the device that is current now (its images are uploaded there on first use); without a
+    // device the handle can still be made and inspected, every run entry point then fails with AM_ERR_NO_DEVICE
+    { int d = 0; if (current_device(&d) == AM_OK) a->dev = d; else g_err.clear(); }
     *out = a;
     return AM_OK;
 }
@@ -242,7 +340,7 @@ extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transit
 extern "C" void am_automaton_destroy(am_automaton* a)
 {
     if (!a) return;
-    for (Flavor& f : a->fl) if (f.d_image) (void)hipFree(f.d_image);
+    for (Flavor& f : a->fl) if (f.d_image) (void)hipFree(f.d_image);      // hipFree finds the owning device itself
     delete a;
 }
 
@@ -265,7 +363,8 @@ extern "C" int am_automaton_image_copy(const am_automaton* a, int case_mode, voi
 {
     const Flavor* f; AM_TRY(prepare(a, case_mode, &f));
     if (!d_dst || nbytes < f->bytes) return fail(AM_ERR_INVALID, "destination too small");
-    HIP_TRY(hipMemcpy(d_dst, f->d_image, f->bytes, hipMemcpyDeviceToDevice));
+    ON_DEVICE(a->dev);
+    HIP_TRY(hipMemcpy(d_dst, f->d_image, f->bytes, hipMemcpyDefault));       // d_dst may live on another device (peer copy)
     return AM_OK;
 }
 
@@ -273,8 +372,10 @@ extern "C" int am_automaton_from_image(const void* d_image, size_t nbytes, am_au
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
-    AM_TRY(ensure_device());
     if (!d_image || nbytes < sizeof(ImageHeader)) return fail(AM_ERR_INVALID, "image too small");
+    int dev = 0;
+    AM_TRY(device_of_pointer(d_image, &dev));             // the new handle lives where the received image lies
+    ON_DEVICE(dev);
     ImageHeader h;
     HIP_TRY(hipMemcpy(&h, d_image, sizeof(h), hipMemcpyDeviceToHost));
     if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image");
@@ -283,6 +384,7 @@ extern "C" int am_automaton_from_image(const void* d_image, size_t nbytes, am_au
     hipError_t e = hipMemcpy(d, d_image, h.total_bytes, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(AM_ERR_HIP, hipGetErrorString(e)); }
     am_automaton* a = new am_automaton();
+    a->dev = dev;
     Flavor& f = a->fl[h.case_mode];
     f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.ready = true;
     *out = a;
@@ -294,6 +396,7 @@ extern "C" int am_automaton_image_read(const am_automaton* a, int case_mode, voi
 {
     const Flavor* f; AM_TRY(prepare(a, case_mode, &f));
     if (!host_dst || nbytes < f->bytes) return fail(AM_ERR_INVALID, "destination too small");
+    ON_DEVICE(a->dev);
     HIP_TRY(hipMemcpy(host_dst, f->d_image, f->bytes, hipMemcpyDeviceToHost));
     return AM_OK;
 }
@@ -307,12 +410,14 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
     std::memcpy(&h, image, sizeof(h));
     if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image (magic, version or section bounds)");
     if (image_checksum((const uint8_t*)image + sizeof(h), (size_t)h.total_bytes - sizeof(h)) != h.checksum) return fail(AM_ERR_INVALID, "automaton image is corrupt (checksum)");
-    AM_TRY(ensure_device());
+    int dev = 0;
+    AM_TRY(current_device(&dev));
     void* d = nullptr;
     HIP_TRY(hipMalloc(&d, h.total_bytes));
     hipError_t e = hipMemcpy(d, image, h.total_bytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(d); return fail(AM_ERR_HIP, hipGetErrorString(e)); }
     am_automaton* a = new am_automaton();
+    a->dev = dev;
     Flavor& f = a->fl[h.case_mode];
     f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.ready = true;
     *out = a;
@@ -333,7 +438,8 @@ static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b)
 {
     if (n_hay && !hay) return fail(AM_ERR_INVALID, "hay is null");
     if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
-    AM_TRY(ensure_device());
+    AM_TRY(ensure_runtime());
+    ON_DEVICE(b->dev);
     std::vector<uint64_t> offs(n_hay + 1, 0);
     for (size_t i = 0; i < n_hay; i++) {
         if (hay[i].len && !hay[i].ptr) return fail(AM_ERR_INVALID, "slice with null ptr");
@@ -349,15 +455,27 @@ static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b)
     if (e == hipSuccess && total == 0) { e = hipMemset(b->d_text, 0, padded); if (e == hipSuccess) e = hipStreamSynchronize(nullptr); }
     // The slices are gathered piece by piece (several threads) into two pinned staging buffers that take turns:
     // while the DMA engine uploads one piece, the host fills the other.  The buffers stay for the next call.
-    if (e == hipSuccess && total > 0) {
-        static std::mutex stage_mu;
-        static uint8_t* stage[2] = {nullptr, nullptr};
-        static hipStream_t copy_stream = nullptr;
-        static hipEvent_t done[2] = {nullptr, nullptr};
+    // Small batches (the one-document-per-call pattern) are gathered into a buffer of the calling thread and copied
+    // directly: nothing shared, so calls from different threads do not meet.
+    constexpr uint64_t kSmallUpload = 4u << 20;
+    if (e == hipSuccess && total > 0 && total <= kSmallUpload) {
+        static thread_local std::vector<uint8_t> gather_buf;
+        gather_buf.resize(padded);
+        for (size_t i = 0; i < n_hay; i++) if (hay[i].len) std::memcpy(gather_buf.data() + offs[i], hay[i].ptr + hay[i].off, hay[i].len);
+        std::memset(gather_buf.data() + total, 0, padded - (size_t)total);
+        e = hipMemcpy(b->d_text, gather_buf.data(), padded, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess && total > kSmallUpload) {
+        struct UploadStage { std::mutex mu; uint8_t* stage[2] = {nullptr, nullptr}; hipStream_t copy_stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr}; };
+        static UploadStage per_device[kMaxDev];                  // pinned staging + copy stream of each device; big uploads to one device take turns (they share its PCIe link anyway)
+        UploadStage& us = per_device[b->dev];
+        uint8_t* (&stage)[2] = us.stage;
+        hipStream_t& copy_stream = us.copy_stream;
+        hipEvent_t (&done)[2] = us.done;
         constexpr size_t kPiece = 32u << 20;
-        std::lock_guard<std::mutex> stage_lk(stage_mu);
+        std::lock_guard<std::mutex> stage_lk(us.mu);
         if (!stage[0]) {
-            if (hipHostMalloc((void**)&stage[0], kPiece, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void**)&stage[1], kPiece, hipHostMallocDefault) != hipSuccess ||
+            if (hipHostMalloc((void**)&stage[0], kPiece, hipHostMallocPortable) != hipSuccess || hipHostMalloc((void**)&stage[1], kPiece, hipHostMallocPortable) != hipSuccess ||
                 hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&done[0]) != hipSuccess || hipEventCreate(&done[1]) != hipSuccess) {
                 if (stage[0]) (void)hipHostFree(stage[0]);
                 if (stage[1]) (void)hipHostFree(stage[1]);
@@ -411,35 +529,41 @@ extern "C" int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     am_batch* b = new am_batch();
-    const int rc = upload_slices(hay, n_hay, b);
+    int rc = current_device(&b->dev);
+    if (rc == AM_OK) rc = upload_slices(hay, n_hay, b);
     if (rc != AM_OK) { am_batch_destroy(b); return rc; }
     *out = b;
     return AM_OK;
 }
 
-// One-shot entry points keep one batch object (device text + workspaces) between calls, so that a caller that scans
-// one document per call does not pay a dozen hipMalloc/hipFree each time.  Anything larger than 256 MiB is let go.
+// One-shot entry points keep one batch object (device text + workspaces) per calling thread and device between calls, so
+// that a caller that scans one document per call does not pay a dozen hipMalloc/hipFree each time -- and calls from
+// different threads share nothing.  Anything larger than 256 MiB is let go.
 namespace {
-struct OneShot {
-    std::mutex mu;
-    am_batch* b = nullptr;
-    am_batch* get() { if (!b) b = new am_batch(); return b; }
-    void trim()
-    {
-        if (!b) return;
-        size_t held = b->text_buf.cap + b->pool.cap + b->hidx.cap + b->unit_offsets.cap + b->hay_counts.cap;
-        if (held > (256ull << 20)) { am_batch_destroy(b); b = nullptr; }
-    }
-};
-OneShot g_oneshot;
+am_batch* oneshot_get(int dev)
+{
+    am_batch*& b = tl_state.oneshot[dev];
+    if (!b) b = adopt_batch(dev);
+    if (!b) { b = new am_batch(); b->dev = dev; }
+    return b;
+}
+void oneshot_trim(int dev)
+{
+    am_batch*& b = tl_state.oneshot[dev];
+    if (!b) return;
+    const size_t held = b->text_buf.cap + b->pool.cap + b->hidx.cap + b->unit_offsets.cap + b->hay_counts.cap;
+    if (held > (256ull << 20)) { am_batch_destroy(b); b = nullptr; }
+}
 }  // namespace
 
 extern "C" int am_batch_from_device(const void* d_bytes, const void* d_offsets, size_t n_hay, uint64_t total_bytes, am_batch** out)
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
-    AM_TRY(ensure_device());
     if (!d_offsets || (total_bytes && !d_bytes)) return fail(AM_ERR_INVALID, "null device pointers");
+    int dev = 0;
+    AM_TRY(device_of_pointer(total_bytes ? d_bytes : d_offsets, &dev));      // the batch lives where its memory does
+    ON_DEVICE(dev);
     if (((uintptr_t)d_bytes & 15) != 0) return fail(AM_ERR_INVALID, "d_bytes must be 16-byte aligned");
     if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
     uint64_t first = 1, last = 0;
@@ -447,6 +571,7 @@ extern "C" int am_batch_from_device(const void* d_bytes, const void* d_offsets, 
     HIP_TRY(hipMemcpy(&last, (const uint64_t*)d_offsets + n_hay, 8, hipMemcpyDeviceToHost));
     if (first != 0 || last != total_bytes) return fail(AM_ERR_INVALID, "d_offsets[0] must be 0 and d_offsets[n_hay] must equal total_bytes");
     am_batch* b = new am_batch();
+    b->dev = dev;
     b->owns = false; b->d_text = const_cast<void*>(d_bytes); b->d_offsets = (uint64_t*)const_cast<void*>(d_offsets);
     b->total = total_bytes; b->n_hay = (uint32_t)n_hay;
     int rc = finish_batch(b);
@@ -469,13 +594,15 @@ extern "C" uint64_t am_batch_total_bytes(const am_batch* b) { return b ? b->tota
 namespace {
 
 struct Plan {
-    const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks;
+    const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
     AcView ac; SfView sf; BatchView bv;
 };
 
 int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
 {
     if (!b) return fail(AM_ERR_INVALID, "null batch");
+    if (!a) return fail(AM_ERR_INVALID, "null automaton");
+    if (a->dev != b->dev) return fail(AM_ERR_INVALID, "automaton and batch live on different devices");
     AM_TRY(prepare(a, case_mode, &p.f));
     p.ic = case_mode == AM_IGNORE_CASE;
     if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run automata that contain the empty needle");
@@ -486,7 +613,8 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     // no goto edge at all (no needles, or only empty needles): the reference never reports anything
     const bool no_edges = p.f->h.n_transitions == p.f->h.n_states;
     p.nothing = b->total == 0 || no_edges || (p.use_sf && p.f->h.sf_tiers == 0);
-    p.unit_chunks = p.use_sf ? sf_unit_chunks(p.bv, g_rt.n_cu) : 0;
+    p.unit_chunks = p.use_sf ? sf_unit_chunks(p.bv, g_rt.dev[b->dev].n_cu) : 0;
+    p.n_cu = g_rt.dev[b->dev].n_cu;
     p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
     if (p.n_units >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "batch too large for one launch; split it");
     return AM_OK;
@@ -494,7 +622,7 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
 
 int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st)
 {
-    if (p.use_sf) { Prof pr("sf", st); HIP_TRY(launch_sf(p.ic, mode, p.sf, p.bv, o, g_rt.n_cu, st)); }
+    if (p.use_sf) { Prof pr("sf", st); HIP_TRY(launch_sf(p.ic, mode, p.sf, p.bv, o, p.n_cu, st)); }
     else { Prof pr("ac", st); HIP_TRY(launch_ac(p.ic, mode, p.ac, p.bv, o, st)); }
     return AM_OK;
 }
@@ -518,7 +646,8 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
     if (counts_out && b->n_hay) std::memset(counts_out, 0, (size_t)b->n_hay * sizeof(uint64_t));
     if (p.nothing) return AM_OK;
     std::lock_guard<std::mutex> lk(b->mu);
-    hipStream_t st; AM_TRY(get_stream(&st));
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     AM_TRY(b->small.ensure(64));
     ScanOut o{};
     o.unit_chunks = p.unit_chunks;
@@ -548,7 +677,8 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     if (b->n_hay) std::memset(flags_out, 0, b->n_hay);
     if (p.nothing) return AM_OK;
     std::lock_guard<std::mutex> lk(b->mu);
-    hipStream_t st; AM_TRY(get_stream(&st));
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     AM_TRY(b->flags.ensure(b->n_hay));
     HIP_TRY(hipMemsetAsync(b->flags.p, 0, b->n_hay, st));
     ScanOut o{};
@@ -569,7 +699,8 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
     if (p.nothing) return AM_OK;
     std::lock_guard<std::mutex> lk(b->mu);
-    hipStream_t st; AM_TRY(get_stream(&st));
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     const uint64_t n = p.n_units + 1;           // trailing zero: offsets[n_units] = total
     AM_TRY(b->unit_counts.ensure(n * sizeof(uint32_t)));
     AM_TRY(b->unit_offsets.ensure(n * sizeof(uint64_t)));
@@ -650,9 +781,10 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
     *out = nullptr;
     if (!cb) return fail(AM_ERR_INVALID, "null batch");
     am_matches* m = new am_matches();
+    m->dev = cb->dev;
     auto sink = [&](uint64_t total, Record** ptr) -> int {
         const size_t need = total * sizeof(Record);
-        m->d_records = (Record*)g_record_cache.take(need, &m->cap_bytes);
+        m->d_records = (Record*)g_record_cache[m->dev].take(need, &m->cap_bytes);
         if (!m->d_records) {
             m->cap_bytes = need + need / 16;
             hipError_t e = hipMalloc((void**)&m->d_records, m->cap_bytes);
@@ -672,31 +804,31 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
 extern "C" int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out)
 {
     if (n_hay && !counts_out) return fail(AM_ERR_INVALID, "counts_out is null");
-    std::lock_guard<std::mutex> lk(g_oneshot.mu);
-    am_batch* b = g_oneshot.get();
+    if (!a) return fail(AM_ERR_INVALID, "null automaton");
+    am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
     int rc = upload_slices(hay, n_hay, b);
     if (rc == AM_OK) rc = am_count_batch(a, case_mode, b, counts_out, nullptr);
-    g_oneshot.trim();
+    oneshot_trim(a->dev);
     return rc;
 }
 
 extern "C" int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out)
 {
-    std::lock_guard<std::mutex> lk(g_oneshot.mu);
-    am_batch* b = g_oneshot.get();
+    if (!a) return fail(AM_ERR_INVALID, "null automaton");
+    am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
     int rc = upload_slices(hay, n_hay, b);
     if (rc == AM_OK) rc = am_contains_any_batch(a, case_mode, b, flags_out);
-    g_oneshot.trim();
+    oneshot_trim(a->dev);
     return rc;
 }
 
 extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out)
 {
-    std::lock_guard<std::mutex> lk(g_oneshot.mu);
-    am_batch* b = g_oneshot.get();
+    if (!a) return fail(AM_ERR_INVALID, "null automaton");
+    am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
     int rc = upload_slices(hay, n_hay, b);
     if (rc == AM_OK) rc = am_run_batch(a, case_mode, b, out);
-    g_oneshot.trim();
+    oneshot_trim(a->dev);
     return rc;
 }
 
@@ -710,6 +842,7 @@ extern "C" const am_match* am_matches_data(am_matches* m)
     if (!m->fetched) {
         m->host.resize(m->n);
         if (m->n) {
+            OnDevice od(m->dev);
             hipError_t e = hipMemcpy(m->host.data(), m->d_records, m->n * sizeof(Record), hipMemcpyDeviceToHost);
             if (e != hipSuccess) { fail(AM_ERR_HIP, std::string("hipMemcpy(records): ") + hipGetErrorString(e)); return nullptr; }
         }
@@ -723,7 +856,7 @@ extern "C" const void* am_matches_device_data(const am_matches* m) { return m ? 
 extern "C" void am_matches_free(am_matches* m)
 {
     if (!m) return;
-    if (m->d_records) g_record_cache.give(m->d_records, m->cap_bytes);
+    if (m->d_records) g_record_cache[m->dev].give(m->d_records, m->cap_bytes);
     delete m;
 }
 
@@ -743,18 +876,18 @@ extern "C" size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap)
 
 extern "C" int am_set_stream(void* hip_stream)
 {
-    std::lock_guard<std::mutex> lk(g_rt.mu);
-    g_rt.user_stream = (hipStream_t)hip_stream;
-    g_rt.use_user = hip_stream != nullptr;
+    tl_state.user = (hipStream_t)hip_stream;          // per calling thread
+    tl_state.use_user = hip_stream != nullptr;
     return AM_OK;
 }
 
 extern "C" int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap)
 {
-    AM_TRY(ensure_device());
-    if (n_cu) *n_cu = g_rt.n_cu;
-    if (hbm_bytes) *hbm_bytes = g_rt.hbm;
-    if (name && name_cap) { std::strncpy(name, g_rt.name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    int dev = 0;
+    AM_TRY(current_device(&dev));
+    if (n_cu) *n_cu = g_rt.dev[dev].n_cu;
+    if (hbm_bytes) *hbm_bytes = g_rt.dev[dev].hbm;
+    if (name && name_cap) { std::strncpy(name, g_rt.dev[dev].name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
     return AM_OK;
 }
 
@@ -766,7 +899,7 @@ extern "C" int am_debug_sf_phase_cycles(uint64_t* out5)
     return AM_OK;
 }
 
-extern "C" int am_profile_enable(int on) { std::lock_guard<std::mutex> lk(g_rt.mu); g_rt.prof_on = on != 0; return AM_OK; }
+extern "C" int am_profile_enable(int on) { g_rt.prof_on.store(on != 0); return AM_OK; }
 
 static void drain_profile_locked()
 {
@@ -834,7 +967,7 @@ struct SlabPool {
                 if (free_list[i].cap >= need) { *out = free_list[i]; out->used = 0; free_list.erase(free_list.begin() + i); return AM_OK; }
         }
         Slab s; s.cap = need > kSlab ? need : kSlab;
-        if (hipHostMalloc((void**)&s.p, s.cap, hipHostMallocDefault) != hipSuccess) return fail(AM_ERR_OOM, "hipHostMalloc(result slab) failed");
+        if (hipHostMalloc((void**)&s.p, s.cap, hipHostMallocPortable) != hipSuccess) return fail(AM_ERR_OOM, "hipHostMalloc(result slab) failed");
         *out = s;
         return AM_OK;
     }
@@ -876,6 +1009,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
     *out = nullptr;
     const Flavor* f = nullptr;
     AM_TRY(prepare(a, case_mode, &f));
+    ON_DEVICE(a->dev);
     const uint64_t n_states = f->h.n_states;
     if (!values_offsets || values_offsets[0] != 0) return fail(AM_ERR_INVALID, "values_offsets[0] must be 0");
     const uint64_t n_values = values_offsets[n_states];
@@ -938,7 +1072,7 @@ struct RpSession {
         if (fin_host) (void)hipHostFree(fin_host);
         fin_host = nullptr; fin_host_cap = 0;
         const size_t want = bytes + bytes / 2 + 4096;
-        if (hipHostMalloc((void**)&fin_host, want, hipHostMallocDefault) != hipSuccess) { fin_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+        if (hipHostMalloc((void**)&fin_host, want, hipHostMallocPortable) != hipSuccess) { fin_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
         fin_host_cap = want;
         return AM_OK;
     }
@@ -979,7 +1113,9 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     res->text.assign(n_hay, am_replaced::Item());
     res->just.assign(n_hay, 1);
     if (n_hay == 0) return AM_OK;
-    hipStream_t st; AM_TRY(get_stream(&st));
+    if (in->dev != r->a->dev) return fail(AM_ERR_INVALID, "replacer and batch live on different devices");
+    ON_DEVICE(in->dev);
+    hipStream_t st; AM_TRY(get_stream(in->dev, &st));
     // take the replacer's cached workspace (or make one); it goes back at the end unless it has grown large
     RpSession* sp = nullptr;
     { std::lock_guard<std::mutex> lk(r->session_mu); sp = static_cast<RpSession*>(r->session); r->session = nullptr; }
@@ -997,7 +1133,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     } give_back{r, sp};
     RpSession& s = *sp;
     AM_TRY(s.totals.ensure(64));
-    if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocDefault) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
     // pass 0 reads the caller's batch in place; afterwards the text ping-pongs between s.text[0] and s.text[1]
     const uint8_t* cur_text = (const uint8_t*)in->d_text;
     const uint64_t* cur_offs = in->d_offsets;
@@ -1041,6 +1177,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         if (have_inc) { n_rec = inc_n_rec; have_inc = false; }
         else {
             res->scanned += total;
+            s.ws.dev = in->dev;
             s.ws.d_text = const_cast<uint8_t*>(cur_text); s.ws.d_offsets = const_cast<uint64_t*>(cur_offs); s.ws.owns = false;
             s.ws.total = total; s.ws.n_hay = n_act;
             AM_TRY(finish_batch(&s.ws));
@@ -1188,6 +1325,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
             { Prof pr("rp_windows", st);
               HIP_TRY(launch_rp_win_copy((const RpWin*)s.wins.p, (const uint64_t*)s.woffs.p, text_next, (uint8_t*)s.wtext.p, n_win, st));
               HIP_TRY(hipMemsetAsync((uint8_t*)s.wtext.p + total_w, 0, padded_text(total_w) - (size_t)total_w, st)); }
+            s.ws2.dev = in->dev;
             s.ws2.d_text = s.wtext.p; s.ws2.d_offsets = (uint64_t*)s.woffs.p; s.ws2.owns = false; s.ws2.total = total_w; s.ws2.n_hay = (uint32_t)n_win;
             AM_TRY(finish_batch(&s.ws2));
             uint64_t n_wrec = 0;
@@ -1237,7 +1375,7 @@ extern "C" int am_replacer_run_batch(const am_replacer* r, const am_batch* b, ui
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!r || !b) return fail(AM_ERR_INVALID, "null replacer or batch");
-    AM_TRY(ensure_device());
+    AM_TRY(ensure_runtime());
     am_replaced* res = new am_replaced();
     const int rc = replacer_run(r, b, max_length, res);
     if (rc != AM_OK) { delete res; return rc; }
@@ -1249,6 +1387,8 @@ extern "C" int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
+    if (!r) return fail(AM_ERR_INVALID, "null replacer");
+    ON_DEVICE(r->a->dev);
     am_batch* b = nullptr;
     AM_TRY(am_batch_upload(hay, n_hay, &b));
     const int rc = am_replacer_run_batch(r, b, max_length, out);
@@ -1268,10 +1408,11 @@ extern "C" int am_run_priority(const am_replacer* r, const am_slice* hay, size_t
     if (!r) return fail(AM_ERR_INVALID, "null replacer");
     if (n_hay && (!thresholds || !best_out)) return fail(AM_ERR_INVALID, "thresholds / best_out are null");
     if (n_hay == 0) return AM_OK;
+    ON_DEVICE(r->a->dev);
     am_batch* b = nullptr;
     AM_TRY(am_batch_upload(hay, n_hay, &b));
     std::unique_ptr<am_batch, void (*)(am_batch*)> guard(b, am_batch_destroy);
-    hipStream_t st; AM_TRY(get_stream(&st));
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     const uint32_t n = (uint32_t)n_hay;
     const uint64_t n1 = (uint64_t)n + 1;
     DevBuf records, rec_first, kept, hs, nk, off, thr, best, out, tmp;
@@ -1336,7 +1477,8 @@ extern "C" int am_needle_ids_create(const am_automaton* a, const uint64_t* value
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
-    AM_TRY(ensure_device());
+    AM_TRY(ensure_runtime());
+    ON_DEVICE(a->dev);
     // a handle attached to a received image (multi-GPU ranks) has no reference arrays: the state count comes from the image
     uint64_t n_states = 0;
     if (a->has_ref) n_states = a->offsets.size() - 1;
@@ -1377,7 +1519,8 @@ extern "C" int am_contains_all_batch(const am_needle_ids* ids, int case_mode, co
     if (n_hay && !flags_out) return fail(AM_ERR_INVALID, "flags_out is null");
     if (ids->n_needles == 0) { if (n_hay) std::memset(flags_out, 1, n_hay); return AM_OK; }     // IS.null of the empty set (Searcher.hs:176,184)
     if (n_hay == 0) return AM_OK;
-    hipStream_t st; AM_TRY(get_stream(&st));
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     DevBuf records, rec_first, bits, flags;
     struct Release { DevBuf &a, &b, &c, &d; ~Release() { a.release(); b.release(); c.release(); d.release(); } } rel{records, rec_first, bits, flags};
     uint64_t n_rec = 0;
@@ -1417,8 +1560,10 @@ extern "C" int am_matches_fold_hash(const am_matches* m, const am_needle_ids* id
     if (n_hay && !hash_out) return fail(AM_ERR_INVALID, "hash_out is null");
     if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
     if (n_hay == 0) return AM_OK;
-    AM_TRY(ensure_device());
-    hipStream_t st; AM_TRY(get_stream(&st));
+    AM_TRY(ensure_runtime());
+    if (m->dev != ids->a->dev) return fail(AM_ERR_INVALID, "result and values table live on different devices");
+    ON_DEVICE(m->dev);
+    hipStream_t st; AM_TRY(get_stream(m->dev, &st));
     DevBuf rec_first, out, dummy;
     struct Release { DevBuf &a, &b, &c; ~Release() { a.release(); b.release(); c.release(); } } rel{rec_first, out, dummy};
     AM_TRY(rec_first.ensure((n_hay + 1) * 8));
@@ -1437,6 +1582,8 @@ extern "C" int am_matches_fold_hash(const am_matches* m, const am_needle_ids* id
 
 extern "C" int am_contains_all(const am_needle_ids* ids, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out)
 {
+    if (!ids) return fail(AM_ERR_INVALID, "null needle ids");
+    ON_DEVICE(ids->a->dev);
     am_batch* b = nullptr;
     AM_TRY(am_batch_upload(hay, n_hay, &b));
     const int rc = am_contains_all_batch(ids, case_mode, b, flags_out);

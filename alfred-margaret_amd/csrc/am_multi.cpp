@@ -1,0 +1,351 @@
+// am_multi.cpp -- several GPUs behind the C ABI (include/am.h "several GPUs").
+//
+// The path shards trivially: haystacks are independent and the automaton is read-only.  So the only traffic between
+// devices is (1) ONE broadcast of the flattened automaton image over xGMI (ncclBroadcast of the position-independent
+// blob) and (2) an all-reduce of match counts (ncclAllReduce, a handful of uint64).  Match lists never cross devices:
+// every device's records go to the host and are concatenated in haystack order.
+//
+// Two ways to span the devices, same entry points afterwards:
+//   am_multi_create       one process drives devices 0..n-1 (ncclCommInitAll; one host thread per device while scanning)
+//   am_multi_create_rank  one process per GPU (ncclCommInitRank with an id made by am_multi_unique_id on rank 0 and
+//                         handed round by the launcher -- bench.py uses torch.distributed only for those 128 bytes)
+// This file sits ABOVE the single-device ABI: it only calls what am.h declares.
+#include "../../include/am.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <mutex>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <dlfcn.h>
+
+namespace am { int abi_fail(int code, const std::string& msg); }
+using am::abi_fail;
+
+// RCCL is bound at first use (dlopen), not at link time: single-GPU callers never load it, and a process that already
+// holds an RCCL (PyTorch ships its own copy) keeps using that one instead of getting a second copy of the library.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&::ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&::ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&::ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&::ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&::ncclBroadcast) Broadcast = nullptr;
+    decltype(&::ncclAllReduce) AllReduce = nullptr;
+    decltype(&::ncclGroupStart) GroupStart = nullptr;
+    decltype(&::ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;
+    bool load()
+    {
+        if (lib) return true;
+        if (!why.empty()) return false;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }      // one that is already in the process
+        if (!lib) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) { why = std::string("RCCL not found: ") + dlerror(); return false; }
+        bool ok = true;
+        auto sym = [&](const char* n) { void* p = dlsym(lib, n); if (!p) { ok = false; why = std::string("RCCL symbol missing: ") + n; } return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { lib = nullptr; return false; }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+int need_rccl()
+{
+    std::call_once(g_rccl_once, [] { g_rccl.load(); });
+    if (!g_rccl.lib) return abi_fail(AM_ERR_UNSUPPORTED, g_rccl.why.empty() ? std::string("RCCL could not be loaded") : g_rccl.why);
+    return AM_OK;
+}
+}  // namespace
+#define ncclGetUniqueId g_rccl.GetUniqueId
+#define ncclCommInitAll g_rccl.CommInitAll
+#define ncclCommInitRank g_rccl.CommInitRank
+#define ncclCommDestroy g_rccl.CommDestroy
+#define ncclBroadcast g_rccl.Broadcast
+#define ncclAllReduce g_rccl.AllReduce
+#define ncclGroupStart g_rccl.GroupStart
+#define ncclGroupEnd g_rccl.GroupEnd
+#define ncclGetErrorString g_rccl.GetErrorString
+
+static_assert(AM_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "am_multi_unique_id hands out an ncclUniqueId");
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return abi_fail(AM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+#define NCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess) return abi_fail(AM_ERR_HIP, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+    } while (0)
+#define AM_TRY(expr) do { int rc_ = (expr); if (rc_ != AM_OK) return rc_; } while (0)
+
+struct am_multi {
+    int world = 0;                    // devices in all
+    int first_rank = 0;               // global rank of local device 0
+    std::vector<int> devs;            // HIP device ids this process drives
+    std::vector<ncclComm_t> comms;    // one communicator per local device
+    std::vector<hipStream_t> streams;
+    std::vector<uint64_t*> small;     // 4 KiB of device memory per local device (sizes, counters)
+};
+
+namespace {
+constexpr size_t kSmallBytes = 4096;
+
+struct DeviceGuard {
+    int prev = 0;
+    DeviceGuard() { (void)hipGetDevice(&prev); }
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
+int finish_create(am_multi* m)
+{
+    const size_t n = m->devs.size();
+    m->streams.assign(n, nullptr); m->small.assign(n, nullptr);
+    for (size_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(m->devs[i]));
+        HIP_TRY(hipStreamCreateWithFlags(&m->streams[i], hipStreamNonBlocking));
+        HIP_TRY(hipMalloc((void**)&m->small[i], kSmallBytes));
+        HIP_TRY(hipMemset(m->small[i], 0, kSmallBytes));
+    }
+    return AM_OK;
+}
+
+int sync_all(const am_multi* m)
+{
+    for (size_t i = 0; i < m->devs.size(); i++) { HIP_TRY(hipSetDevice(m->devs[i])); HIP_TRY(hipStreamSynchronize(m->streams[i])); }
+    return AM_OK;
+}
+}  // namespace
+
+extern "C" int am_multi_unique_id(uint8_t id_out[AM_UNIQUE_ID_BYTES])
+{
+    if (!id_out) return abi_fail(AM_ERR_INVALID, "id_out is null");
+    AM_TRY(need_rccl());
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    std::memcpy(id_out, &id, AM_UNIQUE_ID_BYTES);
+    return AM_OK;
+}
+
+extern "C" int am_multi_create(int n_devices, am_multi** out)
+{
+    if (!out) return abi_fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) return abi_fail(AM_ERR_NO_DEVICE, "no HIP device; libam has no CPU path");
+    if (n_devices == 0) n_devices = have;
+    if (n_devices < 0 || n_devices > have) return abi_fail(AM_ERR_INVALID, "n_devices exceeds the visible devices");
+    AM_TRY(need_rccl());
+    DeviceGuard guard;
+    am_multi* m = new am_multi();
+    m->world = n_devices; m->first_rank = 0;
+    for (int d = 0; d < n_devices; d++) m->devs.push_back(d);
+    m->comms.assign(n_devices, nullptr);
+    ncclResult_t r = ncclCommInitAll(m->comms.data(), n_devices, m->devs.data());
+    if (r != ncclSuccess) { m->comms.clear(); am_multi_destroy(m); return abi_fail(AM_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); }
+    const int rc = finish_create(m);
+    if (rc != AM_OK) { am_multi_destroy(m); return rc; }
+    *out = m;
+    return AM_OK;
+}
+
+extern "C" int am_multi_create_rank(int n_ranks, int rank, const uint8_t id[AM_UNIQUE_ID_BYTES], am_multi** out)
+{
+    if (!out) return abi_fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (!id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return abi_fail(AM_ERR_INVALID, "bad rank / id");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return abi_fail(AM_ERR_NO_DEVICE, "no HIP device; libam has no CPU path");
+    AM_TRY(need_rccl());
+    am_multi* m = new am_multi();
+    m->world = n_ranks; m->first_rank = rank;
+    m->devs.push_back(dev);
+    m->comms.assign(1, nullptr);
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, AM_UNIQUE_ID_BYTES);
+    ncclResult_t r = ncclCommInitRank(&m->comms[0], n_ranks, uid, rank);
+    if (r != ncclSuccess) { m->comms.clear(); am_multi_destroy(m); return abi_fail(AM_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    const int rc = finish_create(m);
+    if (rc != AM_OK) { am_multi_destroy(m); return rc; }
+    *out = m;
+    return AM_OK;
+}
+
+extern "C" void am_multi_destroy(am_multi* m)
+{
+    if (!m) return;
+    DeviceGuard guard;
+    for (size_t i = 0; i < m->devs.size(); i++) {
+        (void)hipSetDevice(m->devs[i]);
+        if (i < m->streams.size() && m->streams[i]) { (void)hipStreamSynchronize(m->streams[i]); (void)hipStreamDestroy(m->streams[i]); }
+        if (i < m->small.size() && m->small[i]) (void)hipFree(m->small[i]);
+        if (i < m->comms.size() && m->comms[i]) (void)ncclCommDestroy(m->comms[i]);
+    }
+    delete m;
+}
+
+extern "C" int am_multi_local_devices(const am_multi* m) { return m ? (int)m->devs.size() : 0; }
+extern "C" int am_multi_world_size(const am_multi* m) { return m ? m->world : 0; }
+extern "C" int am_multi_device(const am_multi* m, int i) { return (m && i >= 0 && i < (int)m->devs.size()) ? m->devs[i] : -1; }
+
+// The flattened automaton over xGMI: size first (8 bytes), then the blob, both with ncclBroadcast from `root`.
+extern "C" int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out)
+{
+    if (!m || !autos_out) return abi_fail(AM_ERR_INVALID, "null arguments");
+    if (root < 0 || root >= m->world) return abi_fail(AM_ERR_INVALID, "root out of range");
+    const int n = (int)m->devs.size();
+    for (int i = 0; i < n; i++) autos_out[i] = nullptr;
+    const int root_local = root - m->first_rank;                  // index of the root among this process's devices, if it is here
+    const bool have_root = root_local >= 0 && root_local < n;
+    if (have_root && !a) return abi_fail(AM_ERR_INVALID, "the root needs the automaton");
+    DeviceGuard guard;
+    uint64_t nbytes = 0;
+    if (have_root) {
+        size_t sz = 0;
+        HIP_TRY(hipSetDevice(m->devs[root_local]));
+        AM_TRY(am_automaton_image_size(a, case_mode, &sz));
+        nbytes = sz;
+        HIP_TRY(hipMemcpy(m->small[root_local], &nbytes, 8, hipMemcpyHostToDevice));
+    }
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; i++) NCCL_TRY(ncclBroadcast(m->small[i], m->small[i], 8, ncclUint8, root, m->comms[i], m->streams[i]));
+    NCCL_TRY(ncclGroupEnd());
+    AM_TRY(sync_all(m));
+    HIP_TRY(hipSetDevice(m->devs[0]));
+    HIP_TRY(hipMemcpy(&nbytes, m->small[0], 8, hipMemcpyDeviceToHost));
+    if (nbytes < 64 || nbytes > (1ull << 40)) return abi_fail(AM_ERR_HIP, "automaton broadcast: implausible image size received");
+    std::vector<void*> blob(n, nullptr);
+    auto release = [&]() { for (int i = 0; i < n; i++) if (blob[i]) { (void)hipSetDevice(m->devs[i]); (void)hipFree(blob[i]); } };
+    for (int i = 0; i < n; i++) {
+        hipError_t e = hipSetDevice(m->devs[i]);
+        if (e == hipSuccess) e = hipMalloc(&blob[i], nbytes);
+        if (e != hipSuccess) { release(); return abi_fail(AM_ERR_OOM, std::string("hipMalloc(image copy): ") + hipGetErrorString(e)); }
+    }
+    int rc = AM_OK;
+    if (have_root) { (void)hipSetDevice(m->devs[root_local]); rc = am_automaton_image_copy(a, case_mode, blob[root_local], nbytes); }
+    if (rc == AM_OK) {
+        ncclResult_t r = ncclGroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; i++) r = ncclBroadcast(blob[i], blob[i], nbytes, ncclUint8, root, m->comms[i], m->streams[i]);
+        if (r == ncclSuccess) r = ncclGroupEnd();
+        if (r != ncclSuccess) rc = abi_fail(AM_ERR_HIP, std::string("ncclBroadcast(image): ") + ncclGetErrorString(r));
+    }
+    if (rc == AM_OK) rc = sync_all(m);
+    for (int i = 0; i < n && rc == AM_OK; i++) {
+        (void)hipSetDevice(m->devs[i]);
+        rc = am_automaton_from_image(blob[i], nbytes, &autos_out[i]);        // copies the blob: the handle owns its image
+    }
+    release();
+    if (rc != AM_OK) for (int i = 0; i < n; i++) { am_automaton_destroy(autos_out[i]); autos_out[i] = nullptr; }
+    return rc;
+}
+
+extern "C" int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count)
+{
+    if (!m || (count && !values)) return abi_fail(AM_ERR_INVALID, "null arguments");
+    if (count * 8 > kSmallBytes) return abi_fail(AM_ERR_INVALID, "too many values for one all-reduce (512 at most)");
+    if (count == 0) return AM_OK;
+    const int n = (int)m->devs.size();
+    DeviceGuard guard;
+    for (int i = 0; i < n; i++) { HIP_TRY(hipSetDevice(m->devs[i])); HIP_TRY(hipMemcpyAsync(m->small[i], values + (size_t)i * count, count * 8, hipMemcpyHostToDevice, m->streams[i])); }
+    NCCL_TRY(ncclGroupStart());
+    for (int i = 0; i < n; i++) NCCL_TRY(ncclAllReduce(m->small[i], m->small[i], count, ncclUint64, ncclSum, m->comms[i], m->streams[i]));
+    NCCL_TRY(ncclGroupEnd());
+    for (int i = 0; i < n; i++) { HIP_TRY(hipSetDevice(m->devs[i])); HIP_TRY(hipMemcpyAsync(values + (size_t)i * count, m->small[i], count * 8, hipMemcpyDeviceToHost, m->streams[i])); }
+    return sync_all(m);
+}
+
+namespace {
+// contiguous block of haystacks of local device i: blocks differ by at most one haystack
+void block_of(size_t n_hay, int i, int n, size_t* lo, size_t* hi) { *lo = n_hay * (size_t)i / (size_t)n; *hi = n_hay * (size_t)(i + 1) / (size_t)n; }
+
+struct Job { int rc = AM_OK; std::string err; };
+
+// runs f(i) for every local device on its own host thread with that device current
+template <class F> int per_device(const am_multi* m, F f)
+{
+    const int n = (int)m->devs.size();
+    std::vector<Job> jobs(n);
+    auto body = [&](int i) {
+        if (hipSetDevice(m->devs[i]) != hipSuccess) { jobs[i].rc = AM_ERR_HIP; jobs[i].err = "hipSetDevice failed"; return; }
+        jobs[i].rc = f(i);
+        if (jobs[i].rc != AM_OK) jobs[i].err = am_last_error();           // thread-local: carry it to the caller's thread
+    };
+    if (n == 1) { DeviceGuard guard; body(0); }
+    else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < n; i++) pool.emplace_back(body, i);
+        for (auto& t : pool) t.join();
+    }
+    for (int i = 0; i < n; i++) if (jobs[i].rc != AM_OK) return abi_fail(jobs[i].rc, "device " + std::to_string(m->devs[i]) + ": " + jobs[i].err);
+    return AM_OK;
+}
+}  // namespace
+
+extern "C" int am_multi_count(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out, uint64_t* total_out)
+{
+    if (!m || !autos || (n_hay && !hay)) return abi_fail(AM_ERR_INVALID, "null arguments");
+    const int n = (int)m->devs.size();
+    std::vector<uint64_t> totals(n, 0);
+    AM_TRY(per_device(m, [&](int i) -> int {
+        size_t lo, hi; block_of(n_hay, i, n, &lo, &hi);
+        if (hi == lo) return AM_OK;
+        am_batch* b = nullptr;
+        AM_TRY(am_batch_upload(hay + lo, hi - lo, &b));
+        const int rc = am_count_batch(autos[i], case_mode, b, counts_out ? counts_out + lo : nullptr, &totals[i]);
+        am_batch_destroy(b);
+        return rc;
+    }));
+    AM_TRY(am_multi_allreduce_sum(m, totals.data(), 1));                  // final gather of match counts
+    if (total_out) *total_out = totals[0];
+    return AM_OK;
+}
+
+extern "C" int am_multi_run(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, am_match** matches_out, size_t* n_out)
+{
+    if (!m || !autos || !matches_out || !n_out || (n_hay && !hay)) return abi_fail(AM_ERR_INVALID, "null arguments");
+    *matches_out = nullptr; *n_out = 0;
+    const int n = (int)m->devs.size();
+    std::vector<am_matches*> res(n, nullptr);
+    struct Free { std::vector<am_matches*>& r; ~Free() { for (am_matches* x : r) am_matches_free(x); } } free_results{res};
+    AM_TRY(per_device(m, [&](int i) -> int {
+        size_t lo, hi; block_of(n_hay, i, n, &lo, &hi);
+        if (hi == lo) return AM_OK;
+        AM_TRY(am_run(autos[i], case_mode, hay + lo, hi - lo, &res[i]));
+        return am_matches_data(res[i]) || am_matches_size(res[i]) == 0 ? AM_OK : AM_ERR_HIP;      // D2H on the device's own thread
+    }));
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += (size_t)am_matches_size(res[i]);
+    am_match* all = (am_match*)std::malloc((total ? total : 1) * sizeof(am_match));
+    if (!all) return abi_fail(AM_ERR_OOM, "malloc(matches) failed");
+    size_t at = 0;
+    for (int i = 0; i < n; i++) {                                         // host concatenation in haystack order
+        const size_t k = (size_t)am_matches_size(res[i]);
+        if (!k) continue;
+        size_t lo, hi; block_of(n_hay, i, n, &lo, &hi);
+        const am_match* src = am_matches_data(res[i]);
+        for (size_t j = 0; j < k; j++) { all[at + j] = src[j]; all[at + j].haystack += (uint32_t)lo; }
+        at += k;
+    }
+    *matches_out = all; *n_out = total;
+    return AM_OK;
+}
+
+extern "C" void am_multi_matches_free(am_match* p) { std::free(p); }

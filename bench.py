@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fold-checksum parity gate (kernel vs kernel on every haystack, oracle on a sample)")
     ap.add_argument("--parity-oracle-mib", type=int, default=1024, help="haystack bytes of rank 0's shard the oracle re-scans for the parity gate")
+    ap.add_argument("--torch-collectives", action="store_true", help="N ranks: broadcast the automaton image and sum the counts with torch.distributed "
+                    "instead of libam's own RCCL entry points (am_multi_*): cross-check of the product path")
     args = ap.parse_args()
 
     import numpy as np
@@ -71,6 +73,8 @@ def main():
     w = synth.WORKLOADS[args.workload]
     if "replacer" in args.workload:
         return bench_replacer(args, w, rank, world, dev)
+    if world == 1 and (args.gpus > 1 or os.environ.get("AM_BENCH_SINGLE_PROCESS") == "1"):     # the env var: the same path on a 1-GPU box (tests)
+        return bench_single_process(args, w)          # one process drives all N GPUs through libam (am_multi_create)
     case = w["case"]
     # cfg4 (BASELINE configs[3]) is ONE batch of 1M haystacks block-sharded over the ranks (dist.shard_bounds): strong
     # scaling; every other workload gives each GPU its own n_hay haystacks: weak scaling
@@ -95,7 +99,26 @@ def main():
         nbytes = C.c_size_t(0)
         am.api.check(lib.am_automaton_image_size(handle, case, C.byref(nbytes)))
     build_s = time.time() - t0
-    if world > 1:
+    multi = None
+    if world > 1 and not args.torch_collectives:
+        # the product's own multi-GPU entry points (include/am.h am_multi_*): RCCL communicator over the ranks, automaton image
+        # broadcast over xGMI and the final all-reduce of counts inside libam; torch.distributed only carries the 128-byte id
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            am.api.check(lib.am_multi_unique_id(buf))
+            ident = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+        ident = ident.to(dev)
+        dist.broadcast(ident, 0)
+        ident_b = bytes(ident.cpu().numpy().tobytes())
+        multi = C.c_void_p()
+        with stdout_to_stderr():                       # RCCL prints a version banner on stdout
+            am.api.check(lib.am_multi_create_rank(world, rank, (C.c_uint8 * 128).from_buffer_copy(ident_b), C.byref(multi)))
+        autos = (C.c_void_p * 1)()
+        am.api.check(lib.am_multi_broadcast_automaton(multi, handle if rank == 0 else None, case, 0, autos))
+        handle = C.c_void_p(autos[0])
+        am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
+    elif world > 1:
         image = None
         if rank == 0:
             image = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
@@ -147,7 +170,12 @@ def main():
     t1 = time.perf_counter()
     am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total_values)))
     count_only_s = time.perf_counter() - t1
-    total_matches, total_records, amdist_total_bytes = amdist.allreduce_sum([int(total_values.value), n_records, n_bytes], dev)   # final gather of match counts
+    if multi is not None:                                    # final gather of match counts: ncclAllReduce inside libam
+        sums = np.array([int(total_values.value), n_records, n_bytes], dtype=np.uint64)
+        am.api.check(lib.am_multi_allreduce_sum(multi, sums.ctypes.data, 3))
+        total_matches, total_records, amdist_total_bytes = (int(x) for x in sums)
+    else:
+        total_matches, total_records, amdist_total_bytes = amdist.allreduce_sum([int(total_values.value), n_records, n_bytes], dev)
 
     parity = None
     if not args.no_parity:
@@ -192,7 +220,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "n_needles": len(needles), "case": "IgnoreCase" if case else "CaseSensitive",
                        "haystacks_per_gpu": n_hay, "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": n_bytes,
-                       "parallelism": "haystack-sharded x%d" % world, "kernel": kname.decode(),
+                       "parallelism": "haystack-sharded x%d%s" % (world, ", automaton broadcast + count all-reduce by libam (am_multi_*, RCCL)" if multi is not None else ""), "kernel": kname.decode(),
                        "automaton_image_bytes": image_bytes, "build_s": round(build_s, 2)},
             "matches_per_s": round(total_matches * args.steps / elapsed, 1),
             "matches_per_step": total_matches, "records_per_step": total_records,
@@ -208,9 +236,136 @@ def main():
         print(json.dumps(out), flush=True)
 
     lib.am_batch_destroy(batch)
+    if multi is not None:
+        lib.am_automaton_destroy(handle)
+        lib.am_multi_destroy(multi)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block (RCCL prints a version banner on stdout when a communicator is
+    made; rank 0's stdout must carry the one JSON line only)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        C.CDLL(None).fflush(None)                     # the banner sits in C stdio's buffer: flush it while fd 1 still points at stderr
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def bench_single_process(args, w):
+    """python bench.py --gpus N without torch.distributed.run: ONE process drives the N GPUs through the product's C ABI
+    (ncclCommInitAll inside am_multi_create, ncclBroadcast of the automaton image, a host thread per device
+    launching its block's scans concurrently, ncclAllReduce of the counts).  Same workload per GPU, same timing rule
+    (K steps, all devices inside each step) and the same JSON line as the one-process-per-GPU path."""
+    import numpy as np
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+
+    import alfred_margaret_amd as am
+    from alfred_margaret_amd import dist as amdist
+    from alfred_margaret_amd import synth
+    lib = am.api.libam()
+    N = args.gpus
+    if torch.cuda.device_count() < N:
+        raise SystemExit("bench.py --gpus %d: only %d devices visible" % (N, torch.cuda.device_count()))
+    case = w["case"]
+    strong = bool(w.get("sharded_total")) and not args.hay_count
+    hay_cells = w["hay_bytes"] // synth.CELL
+    needles = synth.needles_for(args.workload)
+    torch.cuda.set_device(0)
+    t0 = time.time()
+    machine = am.Automaton(needles)
+    build_s = time.time() - t0
+    multi = C.c_void_p()
+    with stdout_to_stderr():
+        am.api.check(lib.am_multi_create(N, C.byref(multi)))
+    autos = (C.c_void_p * N)()
+    am.api.check(lib.am_multi_broadcast_automaton(multi, machine.device, case, 0, autos))
+    nbytes = C.c_size_t(0)
+    am.api.check(lib.am_automaton_image_size(machine.device, case, C.byref(nbytes)))
+    texts, batches, sizes, hays = [], [], [], []
+    for i in range(N):
+        if strong:
+            lo, hi = amdist.shard_bounds(w["n_hay"], i, N)
+        else:
+            lo, hi = i * (args.hay_count or w["n_hay"]), (i + 1) * (args.hay_count or w["n_hay"])
+        dev = torch.device("cuda", i)
+        torch.cuda.set_device(i)
+        text, n_bytes = synth.haystacks_device(needles, w["mixed"], lo * hay_cells, (hi - lo) * hay_cells, dev)
+        offs = torch.arange(hi - lo + 1, dtype=torch.int64, device=dev) * w["hay_bytes"]
+        b = C.c_void_p()
+        am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), hi - lo, n_bytes, C.byref(b)))   # the batch lives where its memory does
+        am.api.check(lib.am_automaton_set_kernel(autos[i], args.kernel))
+        texts.append((text, offs)); batches.append(b); sizes.append(n_bytes); hays.append(hi - lo)
+    torch.cuda.set_device(0)
+    pool = ThreadPoolExecutor(N)
+
+    def one(i):
+        m = C.c_void_p()
+        am.api.check(lib.am_run_batch(autos[i], case, batches[i], C.byref(m)))       # makes device i current for this thread, own stream
+        n = int(lib.am_matches_size(m))
+        lib.am_matches_free(m)
+        return n
+
+    def step():
+        return list(pool.map(one, range(N)))
+
+    for _ in range(args.warmup):
+        recs = step()
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    for i in range(N):
+        torch.cuda.synchronize(i)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs = step()
+    for i in range(N):
+        torch.cuda.synchronize(i)
+    elapsed = time.perf_counter() - t0
+    am.api.check(lib.am_profile_enable(0))
+
+    def count(i):
+        t = C.c_uint64(0)
+        am.api.check(lib.am_count_batch(autos[i], case, batches[i], None, C.byref(t)))
+        return int(t.value)
+
+    sums = np.zeros((N, 3), dtype=np.uint64)
+    for i, c in enumerate(pool.map(count, range(N))):
+        sums[i] = (c, recs[i], sizes[i])
+    am.api.check(lib.am_multi_allreduce_sum(multi, sums.ctypes.data, 3))          # ncclAllReduce over the N devices
+    total_matches, total_records, total_bytes = (int(x) for x in sums[0])
+    kname = b"sf" if args.kernel != 1 else b"ac"
+    ms, launches = C.c_double(0), C.c_uint64(0)
+    am.api.check(lib.am_profile_read(kname, C.byref(ms), C.byref(launches)))
+    launches_n = max(int(launches.value), 1)
+    avg_ms = ms.value / launches_n                                                # average over every device's launches
+    per_dev_bytes = total_bytes / N
+    alg_bytes = per_dev_bytes + 16.0 * (total_records / N) + 16.0 * (sum(hays) / N)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    out = {
+        "metric": "GiB/s haystack bytes scanned (match-emitting runLower, 100k-needle automaton)" if "cfg3" in args.workload else "GiB/s haystack bytes scanned (match-emitting run)",
+        "value": round(total_bytes / float(1 << 30) * args.steps / elapsed, 3), "unit": "GiB/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": args.workload, "n_needles": len(needles), "case": "IgnoreCase" if case else "CaseSensitive", "haystacks_per_gpu": hays[0],
+                   "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": sizes[0], "parallelism": "haystack-sharded x%d, one process (am_multi_create: ncclCommInitAll, image broadcast, count all-reduce)" % N,
+                   "kernel": kname.decode(), "automaton_image_bytes": int(nbytes.value), "build_s": round(build_s, 2)},
+        "matches_per_s": round(total_matches * args.steps / elapsed, 1), "matches_per_step": total_matches, "records_per_step": total_records,
+        "roofline": {"bound": "hbm", "kernel": "k_" + kname.decode(), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value),
+                     "alg_bytes_per_launch": int(alg_bytes)},
+    }
+    print(json.dumps(out), flush=True)
+    for i in range(N):
+        lib.am_batch_destroy(batches[i])
+        lib.am_automaton_destroy(autos[i])
+    lib.am_multi_destroy(multi)
 
 
 def bench_replacer(args, w, rank, world, dev):

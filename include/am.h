@@ -27,9 +27,11 @@
  *
  * Conventions: every function returns AM_OK (0) or a negative AM_ERR_* code and never throws or
  * aborts; am_last_error() gives a thread-local message.  Inputs are borrowed for the duration of
- * the call only.  Handles are immutable after creation and may be shared between threads; calls
- * serialise on the library's HIP stream.  There is no CPU execution path: without a usable
- * MI355X every run entry point returns AM_ERR_NO_DEVICE.
+ * the call only.  Handles are immutable after creation and may be shared between threads; every
+ * calling thread launches on its own HIP stream (am_set_stream replaces it for that thread), so
+ * calls from different threads run concurrently; two calls on the SAME am_batch serialise on its
+ * workspaces.  There is no CPU execution path: without a usable MI355X every run entry point
+ * returns AM_ERR_NO_DEVICE.
  */
 #ifndef AM_H
 #define AM_H
@@ -201,6 +203,42 @@ uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes sc
 uint64_t am_replaced_spliced_bytes(const am_replaced* r);   /* bytes of rewritten text produced over all passes */
 void am_replaced_free(am_replaced* r);
 
+/* ---- several GPUs ---------------------------------------------------------------------
+ * Every handle lives on one device: an automaton / batch on the device that was current when it was made (or that its
+ * memory belongs to: am_batch_from_device, am_automaton_from_image), results and replacers with their automaton.
+ * Entry points make that device current for the calling thread while they run, so one process can drive all GPUs.
+ *
+ * am_multi spans the devices with RCCL.  The path shards trivially (independent haystacks, read-only automaton), so
+ * the only traffic between devices is one broadcast of the flattened automaton over xGMI and an all-reduce of match
+ * counts; match lists are concatenated on the host in haystack order.
+ *   am_multi_create        one process drives devices 0..n-1 (ncclCommInitAll); n_devices = 0: all visible devices
+ *   am_multi_create_rank   one process per GPU (ncclCommInitRank on the current device); the id comes from
+ *                          am_multi_unique_id on one rank and reaches the others through the launcher
+ * Reference shape of a foreign binding: benchmark/rust-ffi/app/Main.hs:28-45 (`foreign import ccall`, slices). */
+typedef struct am_multi am_multi;
+#define AM_UNIQUE_ID_BYTES 128
+int am_multi_unique_id(uint8_t id_out[AM_UNIQUE_ID_BYTES]);
+int am_multi_create(int n_devices, am_multi** out);
+int am_multi_create_rank(int n_ranks, int rank, const uint8_t id[AM_UNIQUE_ID_BYTES], am_multi** out);
+void am_multi_destroy(am_multi* m);
+int am_multi_local_devices(const am_multi* m);     /* devices this process drives */
+int am_multi_world_size(const am_multi* m);        /* devices in all */
+int am_multi_device(const am_multi* m, int i);     /* HIP device id of local device i */
+/* ncclBroadcast of the flattened image of `a` (held by global rank `root`; NULL in processes that do not hold the
+ * root) to every device; autos_out[i] = a handle on local device i attached to its copy (am_automaton_destroy each). */
+int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out);
+/* ncclAllReduce(sum) of `count` (<= 512) uint64 per device: values = local_devices x count, row i belongs to local
+ * device i; every row holds the sums afterwards. */
+int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count);
+/* This process's haystacks cut into contiguous blocks, one per local device (block i = haystacks [n*i/D, n*(i+1)/D)),
+ * scanned concurrently; counts_out (nullable) per haystack in order; *total_out = sum over ALL devices (all-reduce):
+ * countMatches (benchmark/haskell/app/Main.hs:67-76) of the whole job. */
+int am_multi_count(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out, uint64_t* total_out);
+/* runWithCase on every local device's block; the records of all blocks concatenated on the host in haystack order
+ * (haystack = index into `hay`).  Free with am_multi_matches_free. */
+int am_multi_run(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, am_match** matches_out, size_t* n_out);
+void am_multi_matches_free(am_match* p);
+
 /* ---- multi-GPU: move the flattened automaton between devices -----------------------------------
  * The image is one position-independent blob, so rank 0 flattens once and the blob is broadcast
  * over xGMI (RCCL broadcast of a byte tensor); every other rank attaches to its received copy. */
@@ -222,7 +260,7 @@ uint32_t am_lower_code_point(uint32_t cp);
 size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
 
 /* ---- runtime knobs ------------------------------------------------------------------------------ */
-int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches; NULL = library stream */
+int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches OF THE CALLING THREAD; NULL = the thread's library stream */
 int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 int am_profile_enable(int on);

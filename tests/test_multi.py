@@ -1,0 +1,203 @@
+"""Several GPUs behind the C ABI (include/am.h am_multi_*): automaton broadcast + block-sharded scan + count
+all-reduce inside libam, one process.  The driver's GPU box has ONE device, so the -m gpu tests run the degenerate
+1-device path (RCCL communicator of size 1, same code); tests/c/multi_driver.c takes every visible device and must print
+the same answer for any device count (its 2..8-device runs skip where the box has fewer).  Thread concurrency of the
+single-device ABI is tested here too: calls from different host threads go to different HIP streams."""
+import ctypes as C
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import alfred_margaret_amd as am
+from alfred_margaret_amd import synth
+from oracle import oracle
+from tests.conftest import ROOT
+from tests.helpers import expand_records, oracle_triples
+
+
+def _build_driver(tmp_path):
+    exe = str(tmp_path / "multi_driver")
+    lib = am.build.LIB
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "multi_driver.c"),
+                           "-L", lib, "-lam", "-Wl,-rpath," + lib, "-o", exe])
+    return exe
+
+
+def _dump(tmp_path, needles, text):
+    m = oracle.Machine(needles)
+    m.transitions().tofile(tmp_path / "tr"); m.offsets().tofile(tmp_path / "of"); m.root_ascii().tofile(tmp_path / "ra")
+    np.diff(m.values_off()).astype(np.uint32).tofile(tmp_path / "vl")
+    (tmp_path / "hay").write_bytes(bytes(text))
+    return m, [str(tmp_path / n) for n in ("tr", "of", "ra", "vl", "hay")]
+
+
+def test_multi_driver_links_without_a_gpu(tmp_path):
+    import torch
+    am.api.libam()
+    exe = _build_driver(tmp_path)
+    _, files = _dump(tmp_path, ["tshirt", "shirts", "shorts"], b"short tshirts!!!")
+    p = subprocess.run([exe] + files + ["2", "0"], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert p.returncode == 0, p.stderr
+    else:
+        assert p.returncode == 2 and "no HIP device" in p.stderr, (p.returncode, p.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_devices", [1, 2, 4, 8])
+def test_multi_driver_same_answer_for_any_device_count(tmp_path, n_devices):
+    """The plain-C consumer on 1 / 2 / 4 / 8 devices: total, per-haystack counts and the concatenated record list equal
+    the oracle's, whatever the device count.  Runs with more devices than the box has are skipped (exit code 3)."""
+    exe = _build_driver(tmp_path)
+    workload = "cfg3_runLower_100k_10GiB"
+    needles = synth.needles_for(workload)[:4000]
+    n_hay, hay_cells = 37, 8                                   # 37 does not divide by 2, 4 or 8: uneven blocks
+    text = synth.haystacks_host(needles, True, 3, n_hay * hay_cells)
+    m, files = _dump(tmp_path, needles, text)
+    p = subprocess.run([exe] + files + [str(n_hay), "1", str(n_devices)], capture_output=True, text=True)
+    if p.returncode == 3:
+        pytest.skip("box has fewer than %d devices" % n_devices)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.split("\n")
+    while lines and not lines[0].startswith("devices "):       # RCCL prints a version banner on stdout when a communicator is made
+        lines.pop(0)
+    assert lines[0] == "devices %d" % n_devices
+    hb = hay_cells * 1024
+    hays = [text[i * hb:(i + 1) * hb] for i in range(n_hay)]
+    exp_counts = [m.count_matches(1, h) for h in hays]
+    assert lines[1] == "total %d" % sum(exp_counts)
+    assert [int(x) for x in lines[2].split()[1:]] == exp_counts
+    k = int(lines[3].split()[1])
+    recs = np.array([[int(x) for x in l.split()] for l in lines[4:4 + k]], dtype=np.int64).reshape(k, 3)
+    got = expand_records(m.values_off(), m.values(), recs[:, 0], recs[:, 2], recs[:, 1])
+    assert got == oracle_triples(m, 1, hays) and k > 100
+
+
+@pytest.mark.gpu
+def test_multi_entry_points_one_device():
+    """am_multi_* from Python on the box's single device: am_multi_create(0) (all visible devices) and the rank flavour
+    (am_multi_unique_id + am_multi_create_rank with one rank): broadcast, count, run, all-reduce."""
+    lib = am.api.libam()
+    needles = synth.needles_for("cfg2_runText_10k_1GiB")[:3000]
+    a = am.Automaton(needles)
+    o = oracle.Machine(needles)
+    hays = [bytes(synth.haystacks_host(needles, False, 16 * i, 16)) for i in range(9)] + [b"", b"abc"]
+    exp = oracle_triples(o, 0, hays)
+    exp_counts = [o.count_matches(0, h) for h in hays]
+    ident = (C.c_uint8 * 128)()
+    am.api.check(lib.am_multi_unique_id(ident))
+    for flavour in ("all", "rank"):
+        m = C.c_void_p()
+        if flavour == "all":
+            am.api.check(lib.am_multi_create(0, C.byref(m)))
+        else:
+            am.api.check(lib.am_multi_create_rank(1, 0, ident, C.byref(m)))
+        try:
+            D = lib.am_multi_local_devices(m)
+            assert D >= 1 and lib.am_multi_world_size(m) == D and lib.am_multi_device(m, 0) == 0
+            autos = (C.c_void_p * D)()
+            am.api.check(lib.am_multi_broadcast_automaton(m, a.device, 0, 0, autos))
+            s = am.api._Slices(hays)
+            counts, total = np.zeros(len(hays), np.uint64), C.c_uint64(0)
+            am.api.check(lib.am_multi_count(m, autos, 0, s.arr, s.n, counts.ctypes.data, C.byref(total)))
+            assert [int(c) for c in counts] == exp_counts and int(total.value) == sum(exp_counts)
+            p, n = C.c_void_p(), C.c_size_t(0)
+            am.api.check(lib.am_multi_run(m, autos, 0, s.arr, s.n, C.byref(p), C.byref(n)))
+            recs = np.frombuffer((C.c_char * (n.value * am.api.MATCH_DTYPE.itemsize)).from_address(p.value), dtype=am.api.MATCH_DTYPE).copy() if n.value else np.zeros(0, am.api.MATCH_DTYPE)
+            lib.am_multi_matches_free(p)
+            assert expand_records(o.values_off(), o.values(), recs["haystack"], recs["state"], recs["end_pos"]) == exp
+            vals = np.arange(D * 3, dtype=np.uint64) + 5
+            before = vals.copy()
+            am.api.check(lib.am_multi_allreduce_sum(m, vals.ctypes.data, 3))
+            assert np.array_equal(vals.reshape(D, 3), np.tile(before.reshape(D, 3).sum(axis=0), (D, 1)))
+            for i in range(D):
+                lib.am_automaton_destroy(autos[i])
+        finally:
+            lib.am_multi_destroy(m)
+
+
+@pytest.mark.gpu
+def test_calls_from_two_threads_overlap():
+    """include/am.h: every calling thread launches on its own HIP stream and one-shot calls share no lock.  Thread A
+    scans 1 GiB with the general kernel (tens of milliseconds, many short workgroups); thread B starts a moment later
+    and makes 20 small am_count calls.  With a process-wide stream or lock B's first call could only complete after A's
+    kernel; on per-thread streams B's calls complete (with the right answers) while A is still running."""
+    import torch
+    lib = am.api.libam()
+    needles = synth.needles_for("cfg2_runText_10k_1GiB")[:2000]
+    big, small = am.Automaton(needles), am.Automaton(needles)
+    big.set_kernel(1)
+    o = oracle.Machine(needles)
+    text = bytes(synth.haystacks_host(needles, False, 0, 16))
+    exp = o.count_matches(0, text)
+    n_cells, hay_cells = 1 << 20, 1024                          # 1 GiB in 1-MiB haystacks
+    dev_text, n_bytes = synth.haystacks_device(needles, False, 0, n_cells, torch.device("cuda:0"))
+    offs = torch.arange(n_cells // hay_cells + 1, dtype=torch.int64, device="cuda:0") * (hay_cells * 1024)
+    batch = C.c_void_p()
+    am.api.check(lib.am_batch_from_device(dev_text.data_ptr(), offs.data_ptr(), n_cells // hay_cells, n_bytes, C.byref(batch)))
+    stamps = {}
+
+    def thread_a():
+        total = C.c_uint64(0)
+        stamps["a0"] = time.perf_counter()
+        am.api.check(lib.am_count_batch(big.device, 0, batch, None, C.byref(total)))
+        stamps["a1"] = time.perf_counter()
+        stamps["a_total"] = int(total.value)
+
+    def thread_b():
+        s = am.api._Slices([text])
+        c = np.zeros(1, np.uint64)
+        time.sleep(0.004)                                       # let A's kernel get going
+        done = []
+        for _ in range(20):
+            am.api.check(lib.am_count(small.device, 0, s.arr, 1, c.ctypes.data))
+            assert int(c[0]) == exp
+            done.append(time.perf_counter())
+        stamps["b_done"] = done
+
+    try:
+        thread_a(); thread_b()                                  # warm-up: images uploaded, workspaces and streams made
+        for attempt in range(3):
+            ts = [threading.Thread(target=thread_a), threading.Thread(target=thread_b)]
+            for t in ts: t.start()
+            for t in ts: t.join()
+            a_ms = (stamps["a1"] - stamps["a0"]) * 1e3
+            inside = sum(1 for t in stamps["b_done"] if stamps["a0"] < t < stamps["a1"])     # B's calls that completed while A's call was running
+            if inside >= 5:
+                break
+        assert stamps["a_total"] > n_cells * 0.9
+        assert inside >= 5, ("B's calls did not complete while A's call was running", inside, a_ms)
+    finally:
+        lib.am_batch_destroy(batch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("single_process", [False, True])
+def test_bench_line_reduced(single_process):
+    """bench.py end to end at a reduced size: the JSON line carries the metric, roofline, the parity gate (fold checksum:
+    suffix-filter kernel == general kernel on every haystack, == oracle on the sample) and cpu_baseline; with
+    AM_BENCH_SINGLE_PROCESS=1 the same workload goes through am_multi_create (one process driving the devices)."""
+    import json
+    import sys
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--hay-count", "96", "--steps", "2", "--warmup", "1"]
+    if single_process:
+        env["AM_BENCH_SINGLE_PROCESS"] = "1"
+    else:
+        cmd += ["--cpu-seconds", "2", "--parity-oracle-mib", "16"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, lines                                # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["unit"] == "GiB/s" and d["n_gpus"] == 1 and d["value"] > 60 and d["dtype"] == "u8"
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    if single_process:
+        assert "am_multi_create" in d["config"]["parallelism"]
+    else:
+        assert d["parity"]["hashed"] == 96 and d["parity"]["kernels_agree"] is True and d["parity"]["oracle_checked"] == 16
+        assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["run_s"]["min"] > 0
