@@ -153,6 +153,9 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     // ---- phase 2: resolve the oldest `nb` (<= 64 * RN) deferred items, RN per lane in lock step (all
     // belong to the current unit).  Item j of the batch sits in lane j % 64, slot j / 64, so ranks by
     // (slot, lane) reproduce the FIFO = position order.
+    // the unit being processed lies inside ONE haystack (the usual case: 64-KiB units, haystacks of many KiB): then a
+    // deferred position's haystack and offset need no lookup -- three dependent memory round trips less per batch
+    bool unit_single = false; uint32_t unit_hay = 0; uint64_t unit_hs = 0;
     uint32_t cnt_hay = kNone; uint64_t cnt_val = 0;          // count mode: running per-haystack sum of this wave
     auto flush_count = [&]() {
         if (cnt_hay != kNone && cnt_val && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + cnt_hay), (unsigned long long)cnt_val);
@@ -170,10 +173,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             const uint32_t item = valid[k] ? (uint32_t)q2[(q2_head + 64u * k + lane) % kSfQ2] : 0u;
             gpos[k] = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
             hlo[k] = 0; hhi[k] = 0;
-            if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
+            if (valid[k] && !unit_single) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
         }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
+            if (unit_single) { hay[k] = unit_hay; end_pos[k] = valid[k] ? gpos[k] - unit_hs + 1 : 0; continue; }
             hay[k] = hlo[k];
             if (valid[k] && hlo[k] != hhi[k]) hay[k] = find_haystack(b, gpos[k]);
             end_pos[k] = valid[k] ? gpos[k] - b.offsets[hay[k]] + 1 : 0;
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     };
     if (timing) t_mark = __builtin_amdgcn_s_memtime();
     uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
-    uint64_t hs0 = 1, he0 = 0;                          // cached haystack bracket [hs0, he0): empty until the first lookup
+    uint64_t hs0 = 1, he0 = 0; uint32_t hay0 = 0;       // cached haystack bracket [hs0, he0) of haystack hay0: empty until the first lookup
     uint4 cur_v; uint32_t carry3, carry4;
     fetch(u * UC, cur_v);
     fetch_before(u * UC, carry3, carry4);
@@ -281,8 +285,16 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             // (The bracket goes through readfirstlane so that its loads are waited for INSIDE this rarely taken branch: a load
             // left pending at the join would make the compiler wait with vmcnt(0) on every chunk -- and vmcnt counts in order,
             // so that wait would also cover the prefetch issued just above and expose a full HBM latency per chunk.)
-            if (c0 >= he0 || c0 < hs0) { const uint32_t hay0 = find_haystack(b, c0); hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]); }
+            if (c0 >= he0 || c0 < hs0) {
+                hay0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)find_haystack(b, c0));
+                hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]);
+            }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
+            if (ci == 0) {                                        // does the whole unit lie inside this haystack?
+                const uint64_t unit_end = (unit_base_chunk + n_in_unit) * kSfChunk;
+                unit_single = (unit_end < b.total ? unit_end : b.total) <= he0;
+                unit_hay = hay0; unit_hs = hs0;
+            }
 
             uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
             if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }

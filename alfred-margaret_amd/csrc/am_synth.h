@@ -23,7 +23,16 @@ struct Params {
     uint32_t cell_bytes;     // 1024
     uint32_t mode;           // 0: lower-case ASCII alphabet, 1: mixed case + special code points
     uint32_t n_needles;      // 0: plant nothing
-    uint32_t pad;
+    uint32_t plants;         // needles planted per cell: 0 and 1 = one (the BASELINE workloads), 2.. = that many, back to back with
+                             // random gaps (robustness sweep: match density)
+    // kind 1 ("natural text", robustness sweep): words drawn Zipf-like from a vocabulary through a quantile table, separated
+    // by spaces and some punctuation -- the needles of such a workload are vocabulary words and phrases, so suffixes are
+    // shared and matches are dense, the regime of the reference's real-world data set (README.md:14-25)
+    uint32_t kind;           // 0: random code points, 1: natural text
+    uint32_t n_quantile;     // entries of the quantile table (a power of two)
+    const uint8_t* vocab_bytes;
+    const uint64_t* vocab_offs;
+    const uint32_t* quantile;   // quantile[k] = word at quantile (k + 0.5) / n_quantile of the word distribution
 };
 
 struct Rng {
@@ -76,11 +85,62 @@ SYN_HD uint32_t random_cp(Rng& rng, uint32_t mode)
     return 0x1F300u + x % 0x300u;
 }
 
-// Fills out[0 .. cell_bytes) with cell `g`.
-SYN_HD void generate_cell(const Params& p, const uint8_t* needle_bytes, const uint64_t* needle_offs, uint64_t g, uint8_t* out)
+// kind 1: a cell of "natural text"
+SYN_HD void generate_cell_natural(const Params& p, uint64_t g, uint8_t* out)
 {
     Rng rng{p.seed ^ (g * 0xD1342543DE82EF95ull)};
     const uint32_t cell = p.cell_bytes;
+    uint32_t pos = 0;
+    bool capital = p.mode == 1;                       // mixed-case text: sentences start with a capital
+    for (;;) {
+        const uint64_t r = rng.next();
+        const uint32_t w = p.quantile[(uint32_t)r & (p.n_quantile - 1u)];
+        const uint64_t b = p.vocab_offs[w], e = p.vocab_offs[w + 1];
+        if (pos + (e - b) + 2 > cell) break;
+        const bool shout = p.mode == 1 && (uint32_t)((r >> 40) % 50u) == 0;           // an occasional WORD IN CAPITALS
+        for (uint64_t k = b; k < e; k++) {
+            uint32_t c = p.vocab_bytes[k];
+            if ((shout || (capital && k == b)) && c >= 'a' && c <= 'z') c -= 0x20;
+            out[pos++] = (uint8_t)c;
+        }
+        capital = false;
+        const uint32_t sep = (uint32_t)((r >> 32) % 100u);
+        if (sep < 6) { out[pos++] = ','; }
+        else if (sep < 11) { out[pos++] = '.'; capital = p.mode == 1; }
+        out[pos++] = ' ';
+    }
+    while (pos < cell) out[pos++] = ' ';
+}
+
+// Fills out[0 .. cell_bytes) with cell `g`.
+SYN_HD void generate_cell(const Params& p, const uint8_t* needle_bytes, const uint64_t* needle_offs, uint64_t g, uint8_t* out)
+{
+    if (p.kind == 1) { generate_cell_natural(p, g, out); return; }
+    Rng rng{p.seed ^ (g * 0xD1342543DE82EF95ull)};
+    const uint32_t cell = p.cell_bytes;
+    if (p.plants > 1 && p.n_needles) {
+        // many needles per cell: needle, gap of random code points, needle, ... with the mean spacing cell / plants
+        const uint32_t spacing = cell / p.plants;
+        uint32_t pos = 0;
+        while (pos + 4 <= cell) {
+            const uint64_t r = rng.next();
+            const uint32_t idx = (uint32_t)(r % p.n_needles);
+            const uint64_t b = needle_offs[idx], e = needle_offs[idx + 1];
+            if (pos + (e - b) + 4 > cell) break;
+            for (uint64_t k = b; k < e; k++) {
+                uint32_t c = needle_bytes[k];
+                if (p.mode == 1 && c >= 'a' && c <= 'z' && (uint32_t)(rng.next() % 10u) < 3) c -= 0x20;
+                out[pos++] = (uint8_t)c;
+            }
+            const uint32_t len = (uint32_t)(e - b);
+            const uint32_t mean_gap = spacing > len ? spacing - len : 0u;
+            uint32_t gap = mean_gap ? (uint32_t)((r >> 33) % (2u * mean_gap + 1u)) : 0u;
+            while (gap-- && pos + 4 <= cell) pos = put_cp(out, pos, random_cp(rng, p.mode));
+        }
+        while (pos + 4 <= cell) pos = put_cp(out, pos, random_cp(rng, p.mode));
+        while (pos < cell) out[pos++] = ' ';
+        return;
+    }
     const uint32_t plant_at = (uint32_t)(rng.next() % (uint64_t)(cell - 96u));
     bool planted = p.n_needles == 0;
     uint32_t pos = 0;

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fold-checksum parity gate (kernel vs kernel on every haystack, oracle on a sample)")
     ap.add_argument("--parity-oracle-mib", type=int, default=1024, help="haystack bytes of rank 0's shard the oracle re-scans for the parity gate")
+    ap.add_argument("--plants", type=int, default=1, help="needles planted per 1-KiB cell of the synthetic haystacks (robustness sweep: 0, 1, 8, 64; BASELINE = 1)")
     ap.add_argument("--torch-collectives", action="store_true", help="N ranks: broadcast the automaton image and sum the counts with torch.distributed "
                     "instead of libam's own RCCL entry points (am_multi_*): cross-check of the product path")
     args = ap.parse_args()
@@ -134,7 +135,7 @@ def main():
 
     # ---- this rank's shard of haystacks, generated in HBM (weak scaling: n_hay haystacks per GPU)
     n_cells = n_hay * hay_cells
-    text, n_bytes = synth.haystacks_device(needles, w["mixed"], first_hay * hay_cells, n_cells, dev)
+    text, n_bytes = synth.haystacks_device(needles, w["mixed"], first_hay * hay_cells, n_cells, dev, plants=args.plants, natural=bool(w.get("natural")))
     offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * w["hay_bytes"]
     batch = C.c_void_p()
     am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(batch)))
@@ -218,7 +219,7 @@ def main():
             "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": args.workload, "n_needles": len(needles), "case": "IgnoreCase" if case else "CaseSensitive",
+            "config": {"workload": args.workload + ("" if args.plants == 1 else " plants=%d" % args.plants), "n_needles": len(needles), "case": "IgnoreCase" if case else "CaseSensitive",
                        "haystacks_per_gpu": n_hay, "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": n_bytes,
                        "parallelism": "haystack-sharded x%d%s" % (world, ", automaton broadcast + count all-reduce by libam (am_multi_*, RCCL)" if multi is not None else ""), "kernel": kname.decode(),
                        "automaton_image_bytes": image_bytes, "build_s": round(build_s, 2)},
@@ -298,7 +299,7 @@ def bench_single_process(args, w):
             lo, hi = i * (args.hay_count or w["n_hay"]), (i + 1) * (args.hay_count or w["n_hay"])
         dev = torch.device("cuda", i)
         torch.cuda.set_device(i)
-        text, n_bytes = synth.haystacks_device(needles, w["mixed"], lo * hay_cells, (hi - lo) * hay_cells, dev)
+        text, n_bytes = synth.haystacks_device(needles, w["mixed"], lo * hay_cells, (hi - lo) * hay_cells, dev, plants=args.plants, natural=bool(w.get("natural")))
         offs = torch.arange(hi - lo + 1, dtype=torch.int64, device=dev) * w["hay_bytes"]
         b = C.c_void_p()
         am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), hi - lo, n_bytes, C.byref(b)))   # the batch lives where its memory does
@@ -651,10 +652,10 @@ def cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib):
     try:
         # calibration: one haystack (also warms the page cache of the tables)
         o, build0 = get_oracle(needles)
-        hay0 = synth.haystacks_host(needles, w["mixed"], 0, hay_cells)
+        hay0 = synth.haystacks_host(needles, w["mixed"], 0, hay_cells, plants=args.plants, natural=bool(w.get("natural")))
         t1 = time.perf_counter(); o.count_matches(case, hay0); per_hay = time.perf_counter() - t1
         k = int(max(1, min(n_hay, 64, (args.cpu_seconds / REPS) / max(per_hay, 1e-6))))
-        hays = [hay0] + [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells) for i in range(1, k)]
+        hays = [hay0] + [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells, plants=args.plants, natural=bool(w.get("natural"))) for i in range(1, k)]
         scanned = sum(h.size for h in hays)
         run_s, build_s, counts = [], [], None
         for _ in range(REPS):
@@ -690,7 +691,7 @@ def cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib):
         from concurrent.futures import ThreadPoolExecutor
         per_hay = float(run_s.mean()) / k
         n_tasks = min(n_hay, 1024, max(threads, int(threads * min(args.cpu_seconds, 10.0) / max(per_hay, 1e-6))))
-        hays = hays + [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells) for i in range(k, n_tasks)]
+        hays = hays + [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells, plants=args.plants, natural=bool(w.get("natural"))) for i in range(k, n_tasks)]
         hays = hays[:n_tasks]
         with ThreadPoolExecutor(threads) as pool:
             t1 = time.perf_counter()
