@@ -211,6 +211,7 @@ struct am_batch {
     std::mutex mu;              // guards the workspaces below (calls on one batch serialise)
     DevBuf text_buf, offs_buf;  // backing store of d_text / d_offsets when the batch owns them
     DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
+    DevBuf sparse, dense_counts, dense_offsets, dense_out;      // automata with the empty needle (dense pass)
 };
 
 struct am_matches {
@@ -583,7 +584,8 @@ extern "C" int am_batch_from_device(const void* d_bytes, const void* d_offsets, 
 extern "C" void am_batch_destroy(am_batch* b)
 {
     if (!b) return;
-    for (DevBuf* d : {&b->text_buf, &b->offs_buf, &b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next}) d->release();
+    for (DevBuf* d : {&b->text_buf, &b->offs_buf, &b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next,
+                      &b->sparse, &b->dense_counts, &b->dense_offsets, &b->dense_out}) d->release();
     delete b;
 }
 
@@ -595,6 +597,7 @@ namespace {
 
 struct Plan {
     const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
+    bool dense;          // automaton with the empty needle on the suffix-filter route: k_sf's records + the dense pass (am_dense.hip)
     AcView ac; SfView sf; BatchView bv;
 };
 
@@ -605,14 +608,15 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     if (a->dev != b->dev) return fail(AM_ERR_INVALID, "automaton and batch live on different devices");
     AM_TRY(prepare(a, case_mode, &p.f));
     p.ic = case_mode == AM_IGNORE_CASE;
-    if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run automata that contain the empty needle");
+    if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run this automaton (empty needle with too many prefix terminals)");
     p.use_sf = p.f->h.sf_enabled && a->kernel_pref != 1;
+    p.dense = p.use_sf && p.f->h.root_vlen > 0;
     p.ac = make_ac_view(p.f->d_image, p.f->h);
     p.sf = make_sf_view(p.f->d_image, p.f->h);
     p.bv = BatchView{(const uint8_t*)b->d_text, b->d_offsets, (const uint32_t*)b->hidx.p, b->total, b->n_hay, 0};
     // no goto edge at all (no needles, or only empty needles): the reference never reports anything
     const bool no_edges = p.f->h.n_transitions == p.f->h.n_states;
-    p.nothing = b->total == 0 || no_edges || (p.use_sf && p.f->h.sf_tiers == 0);
+    p.nothing = b->total == 0 || no_edges || (p.use_sf && p.f->h.sf_tiers == 0 && !p.dense);      // dense: first code points still report the root's values
     p.unit_chunks = p.use_sf ? sf_unit_chunks(p.bv, g_rt.dev[b->dev].n_cu) : 0;
     p.n_cu = g_rt.dev[b->dev].n_cu;
     p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
@@ -638,6 +642,37 @@ int build_hidx(const Plan& p, am_batch* b, hipStream_t st)
 
 }  // namespace
 
+static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out);
+
+// count / containsAny of an automaton with the empty needle on the suffix-filter route: a record at almost every position, so
+// the records are made (k_sf + dense pass) and reduced
+static int reduce_dense(const am_automaton* a, int case_mode, am_batch* b, uint64_t* counts_out, uint64_t* total_out, uint8_t* flags_out)
+{
+    uint64_t n_rec = 0;
+    auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(b->dense_out.ensure(n * sizeof(Record))); *ptr = (Record*)b->dense_out.p; return AM_OK; };
+    AM_TRY(run_records(a, case_mode, b, sink, &n_rec));
+    if (n_rec == 0) return AM_OK;
+    const Flavor* f = nullptr;
+    AM_TRY(prepare(a, case_mode, &f));
+    std::lock_guard<std::mutex> lk(b->mu);
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
+    AM_TRY(b->small.ensure(64));
+    HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
+    if (counts_out) { AM_TRY(b->hay_counts.ensure((size_t)b->n_hay * 8)); HIP_TRY(hipMemsetAsync(b->hay_counts.p, 0, (size_t)b->n_hay * 8, st)); }
+    if (flags_out) { AM_TRY(b->flags.ensure(b->n_hay)); HIP_TRY(hipMemsetAsync(b->flags.p, 0, b->n_hay, st)); }
+    const AcView ac = make_ac_view(f->d_image, f->h);
+    HIP_TRY(launch_records_reduce((const Record*)b->dense_out.p, n_rec, ac.vlen, counts_out ? (uint64_t*)b->hay_counts.p : nullptr, (uint64_t*)b->small.p,
+                                  flags_out ? (uint8_t*)b->flags.p : nullptr, st));
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, b->small.p, 8, hipMemcpyDeviceToHost, st));
+    if (counts_out) HIP_TRY(hipMemcpyAsync(counts_out, b->hay_counts.p, (size_t)b->n_hay * 8, hipMemcpyDeviceToHost, st));
+    if (flags_out) HIP_TRY(hipMemcpyAsync(flags_out, b->flags.p, b->n_hay, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (total_out) *total_out = total;
+    return AM_OK;
+}
+
 extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_batch* cb, uint64_t* counts_out, uint64_t* total_out)
 {
     am_batch* b = const_cast<am_batch*>(cb);
@@ -645,6 +680,7 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
     if (total_out) *total_out = 0;
     if (counts_out && b->n_hay) std::memset(counts_out, 0, (size_t)b->n_hay * sizeof(uint64_t));
     if (p.nothing) return AM_OK;
+    if (p.dense) return reduce_dense(a, case_mode, b, counts_out, total_out, nullptr);
     std::lock_guard<std::mutex> lk(b->mu);
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
@@ -676,6 +712,7 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     if (!flags_out && b->n_hay) return fail(AM_ERR_INVALID, "flags_out is null");
     if (b->n_hay) std::memset(flags_out, 0, b->n_hay);
     if (p.nothing) return AM_OK;
+    if (p.dense) return reduce_dense(a, case_mode, b, nullptr, nullptr, flags_out);
     std::lock_guard<std::mutex> lk(b->mu);
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
@@ -693,7 +730,7 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
 
 // The whole scan: leaves every record of the batch, sorted by (haystack, end_pos), in device memory
 // obtained from `sink(total, &ptr)` (called once, only when total > 0); *n_out = number of records.
-static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink, uint64_t* n_out)
+static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out)
 {
     *n_out = 0;
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
@@ -701,6 +738,11 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     std::lock_guard<std::mutex> lk(b->mu);
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
+    // automata with the empty needle: k_sf's (sparse) records go to a buffer of the batch, the dense pass writes the result
+    uint64_t n_sparse = 0;
+    auto sink_sparse = [&](uint64_t n, Record** ptr) -> int { AM_TRY(b->sparse.ensure(n * sizeof(Record))); *ptr = (Record*)b->sparse.p; return AM_OK; };
+    const std::function<int(uint64_t, Record**)>& sink = p.dense ? std::function<int(uint64_t, Record**)>(sink_sparse) : sink_final;
+    uint64_t* n_scan = p.dense ? &n_sparse : n_out;
     const uint64_t n = p.n_units + 1;           // trailing zero: offsets[n_units] = total
     AM_TRY(b->unit_counts.ensure(n * sizeof(uint32_t)));
     AM_TRY(b->unit_offsets.ensure(n * sizeof(uint64_t)));
@@ -722,7 +764,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
         uint64_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        *n_out = total;
+        *n_scan = total;
         if (total == 0) return AM_OK;
         AM_TRY(sink(total, &d_records));
         ScanOut w{};
@@ -763,7 +805,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
             HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64; continue; }    // pool too small: ctrl[0] = blocks actually needed
-            *n_out = total;
+            *n_scan = total;
             if (total == 0) return AM_OK;
             AM_TRY(sink(total, &d_records));
             { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, d_records, p.n_units, st)); }
@@ -772,7 +814,31 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
         }
         return fail(AM_ERR_HIP, "record pool overflowed repeatedly (internal error)");
     };
-    return p.use_sf ? body_sf() : body_ac();
+    if (!p.dense) return p.use_sf ? body_sf() : body_ac();
+    if (p.f->h.sf_tiers != 0) AM_TRY(body_sf());
+    else {                                                  // no needle end is reachable (e.g. upper-case needles under IgnoreCase): only the dense part
+        HIP_TRY(hipMemsetAsync(b->unit_offsets.p, 0, n * sizeof(uint64_t), st));
+        AM_TRY(build_hidx(p, b, st));
+    }
+    // dense pass: count per unit -> scan -> write (the unit boundaries and b->unit_offsets are those of the k_sf pass)
+    AM_TRY(b->sparse.ensure(sizeof(Record)));
+    AM_TRY(b->dense_counts.ensure(n * sizeof(uint32_t)));
+    AM_TRY(b->dense_offsets.ensure(n * sizeof(uint64_t)));
+    HIP_TRY(hipMemsetAsync((uint32_t*)b->dense_counts.p + p.n_units, 0, sizeof(uint32_t), st));
+    { Prof pr("dense", st);
+      HIP_TRY(launch_dense(p.ic, false, p.ac, p.bv, (const Record*)b->sparse.p, (const uint64_t*)b->unit_offsets.p, p.unit_chunks, p.n_units, (uint32_t*)b->dense_counts.p, nullptr, nullptr, st)); }
+    { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->dense_counts.p, (uint64_t*)b->dense_offsets.p, n, st)); }
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->dense_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *n_out = total;
+    if (total == 0) return AM_OK;
+    Record* d_out = nullptr;
+    AM_TRY(sink_final(total, &d_out));
+    { Prof pr("dense", st);
+      HIP_TRY(launch_dense(p.ic, true, p.ac, p.bv, (const Record*)b->sparse.p, (const uint64_t*)b->unit_offsets.p, p.unit_chunks, p.n_units, nullptr, (const uint64_t*)b->dense_offsets.p, d_out, st)); }
+    HIP_TRY(hipStreamSynchronize(st));
+    return AM_OK;
 }
 
 extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out)
@@ -1158,7 +1224,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     const Flavor* flavor = nullptr;
     AM_TRY(prepare(r->a, r->case_mode, &flavor));
     const uint32_t ov = 4u * (flavor->h.max_needle_cps ? flavor->h.max_needle_cps : 1u) + 4u;
-    const bool inc_enabled = flavor->h.sf_enabled && r->a->kernel_pref != 1 && std::getenv("AM_RP_FULL_SCANS") == nullptr;
+    const bool inc_enabled = flavor->h.sf_enabled && flavor->h.root_vlen == 0 && r->a->kernel_pref != 1 && std::getenv("AM_RP_FULL_SCANS") == nullptr;
     bool have_inc = false;
     uint64_t inc_n_rec = 0;
     int cur_rec = 0;

@@ -51,6 +51,11 @@ hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st);
 
 
+// ---- automata with the empty needle: dense pass over the suffix-filter kernel's records (am_dense.hip)
+hipError_t launch_dense(bool ic, bool write, const AcView& a, const BatchView& b, const Record* sparse, const uint64_t* sparse_offsets, uint32_t unit_chunks,
+                        uint64_t n_units, uint32_t* unit_totals, const uint64_t* out_offsets, Record* out, hipStream_t st);
+hipError_t launch_records_reduce(const Record* recs, uint64_t n, const uint32_t* vlen, uint64_t* hay_counts, uint64_t* total, uint8_t* flags, hipStream_t st);
+
 // ---- Replacer pass (am_replace.hip) ----------------------------------------------------------
 // same layout as am_payload in include/am.h (Replacer.hs:59-70 Payload, replacement text as a slice of one blob)
 struct RpPayload { int64_t priority; uint32_t len_bytes; uint32_t len_code_points; uint64_t repl_off; uint32_t repl_len; uint32_t reserved; };

@@ -212,11 +212,28 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         h.off_lower = blob.reserve_section(16);
     }
 
-    // ---- SF section.  The empty needle (values on the root, reported after every successful goto,
-    // Automaton.hs:373-376,502-503) needs the true AC state, so such automata use the AC kernel.
-    h.sf_enabled = vlen[0] == 0 ? 1u : 0u;
+    // ---- SF section.  The suffix filter answers "which is the deepest needle that ENDS at this position".  With the
+    // empty needle among the needles the root owns values, every state's list contains them (Automaton.hs:373-376), and the
+    // reference folds them wherever the automaton is not at the root after a code point (collectMatches runs after every
+    // successful goto, :502-503,519) -- i.e. wherever some needle PREFIX ends.  Position-parallel form of that rule:
+    //   * a prefix of one code point ends here  <=>  the (lowered) code point is the first of some needle: a per-position
+    //     test on the text alone (ends_first_code_point below), done by the dense pass of the ABI layer (k_dense_*);
+    //   * longer prefixes whose LAST code point starts no needle (the blank in "new york" when nothing starts with a
+    //     blank) become extra terminals of the reversed trie, reporting canon[s] -- the list the reference folds there.
+    // If those extra terminals would outnumber the real ones several times over, the automaton keeps the general kernel.
+    h.sf_enabled = 1u;
     std::vector<uint32_t> terminals;
     for (size_t s = 1; s < S; s++) if (owns[s]) terminals.push_back((uint32_t)s);
+    if (vlen[0] > 0) {
+        std::vector<uint32_t> first;
+        for (size_t s = 1; s < S; s++) if (parent[s] == 0) first.push_back(cp_in[s]);
+        std::sort(first.begin(), first.end());
+        std::vector<uint32_t> extra;
+        for (size_t s = 1; s < S; s++)
+            if (!owns[s] && depth[s] >= 2 && !std::binary_search(first.begin(), first.end(), cp_in[s])) extra.push_back((uint32_t)s);
+        if (extra.size() > 4 * terminals.size() + 4096) h.sf_enabled = 0u;
+        else terminals.insert(terminals.end(), extra.begin(), extra.end());
+    }
 
     std::vector<SfNode> nodes;
     std::vector<SfEdge> edges_out;
@@ -373,7 +390,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         for (uint32_t x = 0; x < n_byte_nodes; x++) {
             if (new_id[x] == kNone) continue;
             SfNode& rec = nodes[new_id[x]];
-            if (is_terminal(x)) { rec.x = term_state[x] + 1; rec.y = vlen[term_state[x]]; }
+            if (is_terminal(x)) { rec.x = canon[term_state[x]] + 1; rec.y = vlen[term_state[x]]; }      // canon[s] == s for needle ends; the prefix terminals of an empty-needle automaton report the deepest owner on their fallback chain
             const uint32_t n = c_first[x + 1] - c_first[x];
             if (n > 0xFFFF) { err = "node fan-out exceeds 65535"; return -1; }
             if (n == 1) {

@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 5;
+constexpr uint32_t kImageVersion = 6;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -679,6 +679,35 @@ AM_HD bool ac_step(const AcView& a, uint32_t& state, uint32_t cp)
         }
         if (state == 0) return false;                                   // wildcard at the root: next input (:496-497)
         state = a.fail[state];
+    }
+}
+
+// Automata with the empty needle, dense part (see am_flatten.cpp, SF section): is byte g (hs <= g < he, the bounds of its
+// haystack) the LAST byte of a code point whose lowered value is the first code point of some needle?  There the reference
+// is not at the root after the code point and folds at least the root's values.
+AM_HD bool ends_first_code_point(const AcView& a, bool ic, const uint8_t* text, uint64_t hs, uint64_t he, uint64_t g)
+{
+    const uint32_t b0 = text[g];
+    if (b0 < 0x80u) return !(a.root_ascii[ic ? fold_byte(b0) : b0] & kWildcard);
+    if ((b0 & 0xC0u) != 0x80u) return false;                                  // a lead byte ends nothing
+    if (g + 1 < he && (text[g + 1] & 0xC0u) == 0x80u) return false;         // the code point goes on
+    uint32_t k = 1;
+    while (k <= 3 && g >= hs + k && (text[g - k] & 0xC0u) == 0x80u) k++;
+    if (k > 3 || g < hs + k) return false;                                   // no lead byte inside the haystack
+    const uint32_t lead = text[g - k];
+    const uint32_t units = lead < 0xc0u ? 1u : lead < 0xe0u ? 2u : lead < 0xf0u ? 3u : 4u;
+    if (units != k + 1u) return false;
+    const uint32_t c1 = text[g - k + 1], c2 = units > 2 ? text[g - k + 2] : 0u, c3 = units > 3 ? text[g - k + 3] : 0u;
+    uint32_t cp = units == 2 ? ((lead & 0x1fu) << 6) | (c1 & 0x3fu)
+                : units == 3 ? ((lead & 0xfu) << 12) | ((c1 & 0x3fu) << 6) | (c2 & 0x3fu)
+                             : ((lead & 0x7u) << 18) | ((c1 & 0x3fu) << 12) | ((c2 & 0x3fu) << 6) | (c3 & 0x3fu);
+    if (ic) cp = lower_cp(a, cp);
+    if (cp < 128u) return !(a.root_ascii[cp] & kWildcard);                   // a non-ASCII code point may lower to ASCII (U+212A -> k)
+    const uint32_t mask = (1u << a.goto_log2_cap) - 1u;
+    for (uint32_t i = ac_goto_slot(0u, cp, a.goto_log2_cap);; i = (i + 1u) & mask) {
+        const u32x4 e = load16(a.goto_tab + i);
+        if (e.w == 0u) return false;
+        if (e.x == 0u && e.y == cp) return true;
     }
 }
 

@@ -114,6 +114,23 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
             }
         }
     }
+    if (which != 0 && h.root_vlen > 0 && total > 0) {
+        // automaton with the empty needle: the dense part (what k_dense_* does on the device) -- every position where a first
+        // code point ends and the suffix filter reported nothing folds the root's values (state 0)
+        std::vector<uint8_t> padded((size_t)((total + 15) & ~15ull) + 16, 0);
+        std::memcpy(padded.data(), text, (size_t)total);
+        AcView a = make_ac_view(image, h);
+        std::vector<Rec> merged;
+        size_t r = 0;
+        for (uint32_t hay = 0; hay < n_hay; hay++) {
+            for (uint64_t g = offsets[hay]; g < offsets[hay + 1]; g++) {
+                const uint64_t end_pos = g - offsets[hay] + 1;
+                if (r < recs.size() && recs[r].hay == hay && recs[r].end_pos == end_pos) { merged.push_back(recs[r++]); continue; }
+                if (ends_first_code_point(a, ic, padded.data(), offsets[hay], offsets[hay + 1], g)) merged.push_back({hay, 0u, end_pos, h.root_vlen});
+            }
+        }
+        recs.swap(merged);
+    }
     const size_t n = recs.size();
     for (size_t i = 0; i < n && i < cap; i++) {
         hay_out[i] = recs[i].hay; state_out[i] = recs[i].state; end_out[i] = recs[i].end_pos; vlen_out[i] = recs[i].vlen;

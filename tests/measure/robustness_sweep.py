@@ -6,6 +6,7 @@ synthetic point the headline is quoted on.
   natural     Zipf text over a 131k-word vocabulary, needles = 100k vocabulary words (>= 4 letters) and two-word phrases
   a/aa/aaa    needles a, aa, aaa over a...a: a record at EVERY position (16 output bytes per input byte), needles shorter
               than the 4-byte filter window, the record pool's overflow-and-retry path
+  empty       the cfg3 needles plus the empty needle: the reference folds the root's values after every successful goto
   concat      haystack = the cfg3 needles written one after the other (a match every ~10 bytes, every filter window hits)
 
 Every case is also a parity check: the fold checksum of the suffix-filter kernel's records equals the general kernel's on
@@ -111,6 +112,10 @@ def main():
     text = torch.full((small + 64,), ord("a"), dtype=torch.uint8, device=dev)
     text[small:] = 0
     measure("a, aa, aaa over a...a", ["a", "aa", "aaa"], 0, text, small, oracle_hays=2, note="a record at every position; %d MiB" % (small >> 20))
+    del text
+    text, n_bytes = synth.haystacks_device(cfg3, True, 0, small // 1024, dev)
+    measure("cfg3 needles + the empty needle, random text", cfg3 + [""], 1, text, n_bytes, oracle_hays=2,
+            note="the root's values at (almost) every position: k_sf + dense pass; %d MiB" % (small >> 20))
     del text
     blob = ("".join(cfg3)).encode("utf-8")                       # ~1 MB: one haystack = its first MiB (cut at a code-point boundary, padded), repeated
     one = np.frombuffer((blob * (HB // len(blob) + 1))[:HB], dtype=np.uint8).copy()

@@ -135,7 +135,7 @@ def test_fold_hash_equals_oracle_fold():
             o, a = oracle.Machine(ns), am.Automaton(ns)
             table = am.ValuesTable(a)
             exp = [o.fold_hash(case, h) for h in hays]
-            for k in (1, 2) if "" not in ns else (1,):
+            for k in (1, 2):
                 a.set_kernel(k)
                 s = am.api._Slices(hays)
                 m = C.c_void_p()

@@ -109,7 +109,7 @@ def test_single_haystack_split_across_ranks(chk):
             p = am.Automaton(ns)
             img = chk.flatten(p, case)
             max_cps = max([len(n) for n in ns] + [1])
-            for which in ((0,) if "" in ns else (0, 1)):        # 0 = general AC walk, 1 = suffix filter
+            for which in (0, 1):        # 0 = general AC walk, 1 = suffix filter (+ the dense part when the empty needle is there)
                 _split_equals_whole(chk, img, which, b, max_cps, (1, 2, 3, 7), (case, ns))
 
 
@@ -141,3 +141,27 @@ def test_single_haystack_split_inside_code_points_general_kernel(chk):
         for hay in ("\u00e9" * 10, "\u00c9\u00e9" * 7, "a\u20ac\U0001d11e\u00e9" * 5):
             for which in (0, 1):
                 _split_equals_whole(chk, img, which, hay.encode("utf-8"), 1, (2, 3, 5, 7, 8), (case, needle))
+
+
+def test_empty_needle_through_the_suffix_filter(chk):
+    """With the empty needle among the needles the reference folds the root's values wherever the automaton is not at
+    the root after a code point, i.e. wherever some needle PREFIX ends (Automaton.hs:373-376,502-503,519).  The suffix
+    filter gets there with extra terminals for prefixes whose last code point starts no needle (the blank of "new york")
+    plus a per-position test for first code points; the image must not fall back to the general kernel for these."""
+    cases = [
+        (["", "new york", "abc"], ["new york", "a new yor", "ab", "xnew  y", "", "abcabc new", "w york"]),
+        (["", "a b c d"], ["a b c d", "a b c", " b c d", "aa  b"]),
+        (["", "été fini", "k1"], ["ÉTÉ FINI", "été f", "K1 k", "é"]),
+        (["", "", "x"], ["xx", "y"]),
+        ([""], ["anything", ""]),
+    ]
+    for needles, hays in cases:
+        for case in (0, 1):
+            o = oracle.Machine(needles)
+            p = am.Automaton(needles)
+            img = chk.flatten(p, case)
+            exp = oracle_triples(o, case, hays)
+            for which in (1, 2, 0):
+                n, recs = chk.scan(img, which, hays)
+                assert n >= 0, (which, needles)
+                assert expand_records(o.values_off(), o.values(), recs[0], recs[1], recs[2]) == exp, (which, case, needles, hays)
