@@ -94,7 +94,16 @@ constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table
 // address-space-3 pointer made from an integer lets the compiler put constant parts into the instruction's offset field
 // instead of adding the (relocatable, always zero) base of the extern array to every address (16 v_add per chunk).
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
+typedef uint32_t u32x2_n __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32x2_n lds_u32x2_t;
+typedef __attribute__((address_space(3))) u32x4_n lds_u32x4_t;
 __device__ __forceinline__ uint32_t lds_read_u32(uint32_t byte_addr) { return *reinterpret_cast<const lds_u32_t*>((uintptr_t)byte_addr); }
+__device__ __forceinline__ uint32_t lds_read_u16(uint32_t byte_addr) { return *reinterpret_cast<const lds_u16_t*>((uintptr_t)byte_addr); }
+__device__ __forceinline__ void lds_write_u16(uint32_t byte_addr, uint32_t v) { *reinterpret_cast<lds_u16_t*>((uintptr_t)byte_addr) = (uint16_t)v; }
+__device__ __forceinline__ void lds_write_u32x2(uint32_t byte_addr, uint2 v) { u32x2_n t; t.x = v.x; t.y = v.y; *reinterpret_cast<lds_u32x2_t*>((uintptr_t)byte_addr) = t; }
+__device__ __forceinline__ void lds_write_u32x4(uint32_t byte_addr, uint4 v) { u32x4_n t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *reinterpret_cast<lds_u32x4_t*>((uintptr_t)byte_addr) = t; }
 
 // ILP = candidates probed per lane per round (their loads are in flight together);
 // NT  = stream the haystack with non-temporal loads.
@@ -129,9 +138,11 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: unit / chunk arithmetic stays scalar
-    uint8_t* stage = stage_all + wave * kSfStage;
-    uint16_t* q1 = q1_all + wave * kSfQ1;
-    uint16_t* q2 = q2_all + wave * kSfQ2;
+    // this wave's staging area and queues, as absolute LDS byte addresses (32-bit, uniform): no 64-bit pointer per structure
+    const uint32_t stage = kSfMaskBytes + 4u * words + wave * (uint32_t)kSfStage;
+    const uint32_t q1 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * kSfStage + wave * (uint32_t)(kSfQ1 * 2);
+    const uint32_t q2 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * (kSfStage + kSfQ1 * 2) + wave * (uint32_t)(kSfQ2 * 2);
+    (void)stage_all; (void)q1_all; (void)q2_all;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
     const uint32_t UC = o.unit_chunks;
@@ -153,9 +164,6 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     // ---- phase 2: resolve the oldest `nb` (<= 64 * RN) deferred items, RN per lane in lock step (all
     // belong to the current unit).  Item j of the batch sits in lane j % 64, slot j / 64, so ranks by
     // (slot, lane) reproduce the FIFO = position order.
-    // the unit being processed lies inside ONE haystack (the usual case: 64-KiB units, haystacks of many KiB): then a
-    // deferred position's haystack and offset need no lookup -- three dependent memory round trips less per batch
-    bool unit_single = false; uint32_t unit_hay = 0; uint64_t unit_hs = 0;
     uint32_t cnt_hay = kNone; uint64_t cnt_val = 0;          // count mode: running per-haystack sum of this wave
     auto flush_count = [&]() {
         if (cnt_hay != kNone && cnt_val && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + cnt_hay), (unsigned long long)cnt_val);
@@ -170,14 +178,13 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 #pragma unroll
         for (int k = 0; k < RN; k++) {
             valid[k] = 64u * k + lane < nb;
-            const uint32_t item = valid[k] ? (uint32_t)q2[(q2_head + 64u * k + lane) % kSfQ2] : 0u;
+            const uint32_t item = valid[k] ? lds_read_u16(q2 + 2u * ((q2_head + 64u * k + lane) % kSfQ2)) : 0u;
             gpos[k] = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
             hlo[k] = 0; hhi[k] = 0;
-            if (valid[k] && !unit_single) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
+            if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
         }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
-            if (unit_single) { hay[k] = unit_hay; end_pos[k] = valid[k] ? gpos[k] - unit_hs + 1 : 0; continue; }
             hay[k] = hlo[k];
             if (valid[k] && hlo[k] != hhi[k]) hay[k] = find_haystack(b, gpos[k]);
             end_pos[k] = valid[k] ? gpos[k] - b.offsets[hay[k]] + 1 : 0;
@@ -290,19 +297,14 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]);
             }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
-            if (ci == 0) {                                        // does the whole unit lie inside this haystack?
-                const uint64_t unit_end = (unit_base_chunk + n_in_unit) * kSfChunk;
-                unit_single = (unit_end < b.total ? unit_end : b.total) <= he0;
-                unit_hay = hay0; unit_hs = hs0;
-            }
 
             uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
             if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
             // the 4 bytes before the lane's 16: the lane below's last dword (wave_shr:1; lane 0 keeps `old` = the carry)
             const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);
             const uint32_t d[5] = {d0, d1, d2, d3, d4};
-            *reinterpret_cast<uint4*>(stage + 16u + lane * 16u) = make_uint4(d1, d2, d3, d4);
-            if (lane == 0) *reinterpret_cast<uint2*>(stage + 8u) = make_uint2(carry3, carry4);
+            lds_write_u32x4(stage + 16u + lane * 16u, make_uint4(d1, d2, d3, d4));
+            if (lane == 0) lds_write_u32x2(stage + 8u, make_uint2(carry3, carry4));
             if (!last_of_unit) {                                  // the next chunk follows this one: its carry is this chunk's tail
                 next_c3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63);
                 next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 while (cand && idx < (uint32_t)kSfQ1) {
                     const uint32_t k = __builtin_ctz(cand);
                     cand &= cand - 1u;
-                    q1[idx++] = (uint16_t)(lane * 16u + k);
+                    lds_write_u16(q1 + 2u * idx++, lane * 16u + k);
                 }
                 const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
                 wave_lds_fence();
@@ -370,12 +372,12 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     for (int k = 0; k < W; k++) {
                         const uint32_t e = base + 64u * k + lane;
                         valid[k] = e < n_q1;
-                        pos[k] = valid[k] ? (uint32_t)q1[e] : 0u;
+                        pos[k] = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
                         // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on
                         // top), nb = the two before it, nearest in bits 0-7
                         const uint32_t a = 11u + pos[k], sh = a & 3u;
-                        const uint32_t* sp = reinterpret_cast<const uint32_t*>(stage + (a & ~3u));
-                        const uint32_t x0 = sp[0], x1 = sp[1], x2 = sp[2];
+                        const uint32_t sp = stage + (a & ~3u);
+                        const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
                         const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
                         nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
                         w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
 #pragma unroll
                     for (int k = 0; k < W; k++) {
                         const uint64_t m = __ballot(defer[k]);
-                        if (defer[k]) q2[(q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2] = (uint16_t)((ci << 10) | pos[k]);
+                        if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (ci << 10) | pos[k]);
                         q2_tail += (uint32_t)__popcll(m);
                     }
                 };
