@@ -124,6 +124,7 @@ _HOST = {
     "amh_replacer_free": (None, [_vp]),
     "amh_replacer_with_replacements": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_vp)]),
     "amh_replacer_set_case": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
+    "amh_replacer_compose": (C.c_int, [_vp, _vp, C.POINTER(_vp)]),
     "amh_replacer_run_batch": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
     "amh_replacer_run_batch_host_splice": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_longlong, C.POINTER(_vp), _vp, _vp]),
     "amh_replacer_last_stats": (None, [_vp, _vp, _vp]),
@@ -464,6 +465,14 @@ class Replacer:
         h = _vp()
         _hcheck(libhost().amh_replacer_with_replacements(self._h, rb, ro.ctypes.data, C.byref(h)))
         return Replacer._wrap(h, [(n, rep) for (n, _), rep in zip(self.pairs, fresh)])
+
+    @staticmethod
+    def compose(first, second):
+        """Replacer.compose (Replacer.hs:120-133): `second` after `first` as ONE replacer (the second's priorities renumbered to
+        come after the first's); None when the case sensitivities differ."""
+        h = _vp()
+        _hcheck(libhost().amh_replacer_compose(first._h, second._h, C.byref(h)))
+        return Replacer._wrap(h, first.pairs + second.pairs) if h.value else None
 
     def set_case_sensitivity(self, case):
         """Replacer.setCaseSensitivity (Replacer.hs:148-153): needles untouched."""

@@ -411,6 +411,7 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
     std::memcpy(&h, image, sizeof(h));
     if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image (magic, version or section bounds)");
     if (image_checksum((const uint8_t*)image + sizeof(h), (size_t)h.total_bytes - sizeof(h)) != h.checksum) return fail(AM_ERR_INVALID, "automaton image is corrupt (checksum)");
+    { std::string why; if (!image_body_valid((const uint8_t*)image, h, why)) return fail(AM_ERR_INVALID, why); }       // the checksum is no proof of origin: check what the kernels will follow
     int dev = 0;
     AM_TRY(current_device(&dev));
     void* d = nullptr;

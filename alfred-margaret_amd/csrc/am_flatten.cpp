@@ -130,6 +130,11 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             cp_in[next] = (uint32_t)(t & 0x1fffffu);
         }
         edge_count[s] = (uint32_t)(i - edge_begin[s]);
+        // machineOffsets is a scanl over the per-state list lengths (Automaton.hs:170): every state owns its own run of
+        // entries, wildcard last.  Arrays that share entries between states would pass the checks above and then break the
+        // sizing of the tables below.
+        if (s + 1 < S && ref.offsets[s + 1] != i + 1) { err = "offsets do not partition the transition array"; return -1; }
+        if (s + 1 == S && i + 1 != ref.n_transitions) { err = "transition array has entries beyond the last state's list"; return -1; }
     }
     std::vector<uint32_t> bfs; bfs.reserve(S); bfs.push_back(0);
     for (size_t q = 0; q < bfs.size(); q++) {
@@ -181,7 +186,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     h.off_vlen = blob.put(vlen);
     {
         // goto hash + fallback array: what the kernel walks instead of the reference's per-state edge lists
-        uint64_t n_edges = ref.n_transitions >= S ? ref.n_transitions - S : 0;
+        const uint64_t n_edges = S - 1;                       // one goto edge per non-root state (checked above: the edges form a trie)
         uint32_t lc = 4;
         while ((1ull << lc) < 2 * n_edges + 8) lc++;
         if (lc > 31) { err = "automaton too large for the goto table"; return -1; }
@@ -597,6 +602,48 @@ uint64_t image_checksum(const uint8_t* p, size_t n)
     for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, p + i, 8); x = (x ^ w) * 0x100000001b3ull; }
     for (; i < n; i++) x = (x ^ p[i]) * 0x100000001b3ull;
     return x;
+}
+
+// One host pass over the body of an image that comes from outside (a file): every index the kernels follow must stay inside its
+// table, so that a stale or damaged image is refused instead of making k_ac / k_sf read out of bounds.
+bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err)
+{
+    const uint32_t S = h.n_states;
+    const uint32_t* offsets = (const uint32_t*)(img + h.off_offsets);
+    const uint64_t* tr = (const uint64_t*)(img + h.off_transitions);
+    const uint32_t* canon = (const uint32_t*)(img + h.off_canon);
+    const uint32_t* fail = (const uint32_t*)(img + h.off_fail);
+    for (uint32_t s = 0; s + 1 <= S; s++) {
+        if (offsets[s] > offsets[s + 1] || offsets[s + 1] > h.n_transitions) { err = "image: offsets out of range"; return false; }
+        if (canon[s] >= S || fail[s] >= S) { err = "image: canon/fail state out of range"; return false; }
+    }
+    for (uint64_t i = 0; i < h.n_transitions; i++) if ((uint32_t)(tr[i] >> 32) >= S) { err = "image: transition target out of range"; return false; }
+    const u32x4* go = (const u32x4*)(img + h.off_goto);
+    for (uint64_t i = 0; i < (1ull << h.ac_goto_log2_cap); i++) if (go[i].w && (go[i].x >= S || go[i].z >= S)) { err = "image: goto table entry out of range"; return false; }
+    if (!h.sf_enabled) return true;
+    const SfNode* nodes = (const SfNode*)(img + h.off_nodes);
+    const SfEdge* edges = (const SfEdge*)(img + h.off_edges);
+    for (uint32_t i = 0; i < h.sf_n_nodes; i++) {
+        const SfNode& n = nodes[i];
+        const uint32_t ne = n.w & 0xFFFFu;
+        if (n.x > S) { err = "image: node state out of range"; return false; }
+        if (ne == 1 && (n.z >= h.sf_n_nodes || (n.w >> 24) > kMaxSkip)) { err = "image: node child out of range"; return false; }
+        if (ne > 1 && ((uint64_t)n.z + ne > h.n_edges)) { err = "image: node edge range out of range"; return false; }
+    }
+    for (uint64_t i = 0; i < h.n_edges; i++) if (edges[i].child >= h.sf_n_nodes || edges[i].skip > kMaxSkip) { err = "image: edge out of range"; return false; }
+    for (int t = 0; t < 3; t++) {
+        if (!(h.sf_tiers & (1u << t))) continue;
+        const u32x2* tab = (const u32x2*)(img + h.off_tier[t]);
+        bool has_empty = false;
+        for (uint64_t i = 0; i < (1ull << h.tier_log2_cap[t]); i++) { if (tab[i].y == kNone) has_empty = true; else if (tab[i].y >= h.sf_n_nodes) { err = "image: suffix table node out of range"; return false; } }
+        if (!has_empty) { err = "image: suffix table without an empty slot"; return false; }      // the linear probe must terminate
+    }
+    if (h.sf_tiers & 8u) {
+        const u32x4* cold = (const u32x4*)(img + h.off_t4_cold);
+        for (uint64_t i = 0; i < (1ull << h.tier_log2_cap[3]); i++)
+            if ((cold[i].z != kNone && cold[i].z >= h.sf_n_nodes) || (cold[i].w != kNone && cold[i].w >= h.sf_n_nodes)) { err = "image: suffix bucket node out of range"; return false; }
+    }
+    return true;
 }
 
 bool image_sections_in_bounds(const ImageHeader& h)

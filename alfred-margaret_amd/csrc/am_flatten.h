@@ -25,6 +25,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 uint64_t image_checksum(const uint8_t* p, size_t n);
 // magic / version / every section inside total_bytes
 bool image_sections_in_bounds(const ImageHeader& h);
+// every index inside the body stays inside its table (images that come from a file)
+bool image_body_valid(const uint8_t* image, const ImageHeader& h, std::string& err);
 
 uint32_t simple_lower(uint32_t cp);
 void unlower(uint32_t cp, std::vector<uint32_t>& out);

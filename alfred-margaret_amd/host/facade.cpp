@@ -130,6 +130,15 @@ int amh_replacer_with_replacements(void* r, const uint8_t* rbytes, const uint64_
         *out = new Replacer(src->mapReplacementIndexed([&](size_t needle, const std::string&) { return fresh[needle]; }));
     });
 }
+// Replacer.compose (Replacer.hs:120-133): *out = null (and AM_OK) when the case sensitivities differ (the reference's Nothing)
+int amh_replacer_compose(void* r1, void* r2, void** out)
+{
+    *out = nullptr;
+    return guarded([&] {
+        std::optional<Replacer> c = Replacer::compose(*static_cast<Replacer*>(r1), *static_cast<Replacer*>(r2));
+        if (c) *out = new Replacer(std::move(*c));
+    });
+}
 int amh_replacer_set_case(void* r, int case_mode, void** out)
 {
     *out = nullptr;

@@ -62,8 +62,10 @@ public:
         return Replacer(std::move(s));
     }
 
+    // statistics of the last run THE CALLING THREAD made on this replacer (runs are const and may be made from several threads
+    // on one shared handle: the numbers live in thread-local storage, not in the object)
     struct RunStats { uint64_t passes = 0, scannedBytes = 0; };
-    RunStats lastStats() const { return stats_; }
+    RunStats lastStats() const { const auto& t = threadStats(); return t.first == this ? t.second : RunStats{}; }
 
     // Replacer.hs:203-274 runWithLimit on a batch; nullopt where the reference returns Nothing.
     std::vector<std::optional<std::string>> runBatchWithLimit(const std::vector<std::string>& inputs, size_t maxLength) const
@@ -73,6 +75,7 @@ public:
         am_replaced* raw = nullptr;
         amCheck(am_replacer_run(device(), slices.data(), slices.size(), maxLength == SIZE_MAX ? UINT64_MAX : (uint64_t)maxLength, &raw));
         std::unique_ptr<am_replaced, void (*)(am_replaced*)> res(raw, am_replaced_free);
+        RunStats& stats_ = statsOfThisThread();
         stats_ = RunStats{am_replaced_passes(raw), am_replaced_scanned_bytes(raw)};
         std::vector<std::optional<std::string>> out(inputs.size());
         for (size_t k = 0; k < inputs.size(); k++) {
@@ -123,6 +126,7 @@ public:
         std::vector<size_t> active(inputs.size());
         for (size_t i = 0; i < active.size(); i++) active[i] = i;
         struct Acc { long long pBest; std::vector<RMatch> matches; const std::string* hay; long long threshold; };
+        RunStats& stats_ = statsOfThisThread();
         stats_ = RunStats{};
         while (!active.empty()) {
             stats_.passes++;
@@ -211,7 +215,8 @@ private:
     Searcher<Payload> searcher_;
     std::shared_ptr<std::mutex> mu_ = std::make_shared<std::mutex>();
     mutable std::shared_ptr<am_replacer> device_;
-    mutable RunStats stats_;
+    static std::pair<const Replacer*, RunStats>& threadStats() { static thread_local std::pair<const Replacer*, RunStats> t{nullptr, RunStats{}}; return t; }
+    RunStats& statsOfThisThread() const { auto& t = threadStats(); t.first = this; return t.second; }
 };
 
 }  // namespace alfred_margaret

@@ -244,10 +244,11 @@ void am_multi_matches_free(am_match* p);
  * over xGMI (RCCL broadcast of a byte tensor); every other rank attaches to its received copy. */
 int am_automaton_image_size(const am_automaton* a, int case_mode, size_t* nbytes);
 int am_automaton_image_copy(const am_automaton* a, int case_mode, void* d_dst, size_t nbytes);   /* device -> device */
-int am_automaton_from_image(const void* d_image, size_t nbytes, am_automaton** out);            /* copies the blob */
+int am_automaton_from_image(const void* d_image, size_t nbytes, am_automaton** out);            /* copies the blob; TRUSTED input: a blob made by am_automaton_image_copy in this job (header checked only) */
 /* Serialised automaton: the same blob in host memory (write it to a file as is).  Loading checks the
- * header (magic, version, every section inside the blob) and a checksum of the body, so a truncated or
- * damaged file is refused; it skips build + flatten entirely (the reference's JSON instances store only
+ * header (magic, version, every section inside the blob), a checksum of the body and every index the kernels
+ * follow (states, node and edge ids, table slots), so a truncated, damaged or stale file is refused with
+ * AM_ERR_INVALID; it skips build + flatten entirely (the reference's JSON instances store only
  * the needles and rebuild, Searcher.hs:68-77).  A handle made from an image serves the image's case mode. */
 int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst, size_t nbytes);   /* device -> host */
 int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out);

@@ -636,3 +636,24 @@ def test_replacer_map_replacement_and_set_case_sensitivity():
     assert ic.run_batch(hays) == [oracle.Replacer(1, pairs).run(h) for h in hays]
     assert ic.map_replacement(lambda rep: b"").run_batch(hays) == [oracle.Replacer(1, [(n, "") for n, _ in pairs]).run(h) for h in hays]
     assert ic.set_case_sensitivity(0).run_batch(hays) == r.run_batch(hays)
+
+
+def test_replacer_compose_property():
+    """AhoCorasickSpec.hs:137-148: run (compose a b) == run b . run a, on the device; compose of replacers with different case
+    sensitivities is Nothing (Replacer.hs:122-123)."""
+    rng = random.Random(41)
+    for _ in range(25):
+        def pairs():
+            return [("".join(rng.choice("abAB\u0130k") for _ in range(rng.randint(1, 3))),
+                     "".join(rng.choice("abABxy\u212a") for _ in range(rng.randint(0, 4)))) for _ in range(rng.randint(0, 6))]
+        p1, p2 = pairs(), pairs()
+        hays = ["".join(rng.choice("abAB" * 6 + "\u0130kKz") for _ in range(rng.randint(0, 60))) for _ in range(8)]
+        for case in (0, 1):
+            r1, r2 = am.Replacer(case, p1), am.Replacer(case, p2)
+            r12 = am.Replacer.compose(r1, r2)
+            assert r12 is not None
+            step1 = r1.run_batch(hays)
+            assert r12.run_batch(hays) == r2.run_batch(step1), (case, p1, p2)
+            o12 = oracle.Replacer(case, p1 + p2)
+            assert r12.run_batch(hays) == [o12.run(h) for h in hays]
+        assert am.Replacer.compose(am.Replacer(0, p1), am.Replacer(1, p2)) is None

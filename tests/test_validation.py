@@ -1,0 +1,102 @@
+"""Malformed inputs at the C ABI are refused with AM_ERR_INVALID: they neither hang nor reach a kernel (round-1 advisor
+findings).  CPU only: the checks run before any device is touched."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+import alfred_margaret_amd as am
+from tests.helpers import ImgCheck
+
+WILDCARD = 0x200000
+
+
+def test_transition_lists_that_share_entries_are_refused():
+    """30 states, a root with 29 ASCII edges, every child's offset pointing at the root's wildcard entry (n_transitions = 30):
+    every index is in range and every list is wildcard-terminated, but the lists do not partition the array.  Used to make
+    am_automaton_create loop forever while filling the goto table."""
+    S = 30
+    tr = np.zeros(S, dtype=np.uint64)
+    for i in range(29):
+        tr[i] = (np.uint64(i + 1) << np.uint64(32)) | np.uint64(ord("a") + i if i < 26 else ord("0") + i - 26)
+    tr[29] = np.uint64(WILDCARD)                                     # the root's wildcard: fallback 0
+    offsets = np.full(S + 1, 29, dtype=np.uint32)
+    offsets[0] = 0
+    offsets[S] = 30
+    root = np.full(128, WILDCARD, dtype=np.uint64)
+    for i in range(29):
+        root[int(tr[i]) & 0x1FFFFF] = tr[i]
+    vlen = np.zeros(S, dtype=np.uint32)
+    h = C.c_void_p()
+    rc = am.api.libam().am_automaton_create(tr.ctypes.data, len(tr), offsets.ctypes.data, S, root.ctypes.data, vlen.ctypes.data, C.byref(h))
+    assert rc == am.AM_ERR_INVALID
+    assert b"partition" in am.api.libam().am_last_error()
+
+
+def test_stale_image_is_refused_even_with_a_valid_checksum():
+    """A serialised image whose header parses and whose checksum matches, but whose body points outside its tables (a node's
+    child id here), must not be attached."""
+    chk = ImgCheck()
+    a = am.Automaton(["tshirt", "shirts", "shorts", "a-needle-long-enough-for-the-trie"])
+    img = chk.flatten(a, 0).copy()
+    hdr = struct.Struct("<4IQ4I" + "7Q" + "2I" + "4I" + "Q" + "4Q" + "4I" + "6Q")
+    assert hdr.size <= 312
+    f = hdr.unpack_from(img.tobytes())
+    # locate sections by name through the checker's documented layout: off_nodes follows tier_log2_cap[4]
+    names = ["magic", "version", "case_mode", "flags", "total_bytes", "n_states", "max_needle_cps", "root_vlen", "ac_chunk",
+             "off_transitions", "n_transitions", "off_offsets", "off_root_ascii", "off_canon", "off_vlen", "off_lower",
+             "n_lower", "sf_enabled", "sf_tiers", "sf_bloom_log2_words", "sf_n_nodes", "ac_goto_log2_cap",
+             "off_bloom", "off_tier0", "off_tier1", "off_tier2", "off_tier3", "cap0", "cap1", "cap2", "cap3",
+             "off_nodes", "off_edges", "n_edges", "off_t4_cold", "checksum", "off_goto"]
+    h = dict(zip(names, f))
+    assert h["magic"] == 0x31474D41 and h["sf_n_nodes"] > 4
+    lib = am.api.libam()
+    good = bytes(img)
+    out = C.c_void_p()
+    rc = lib.am_automaton_from_host_image(good, len(good), C.byref(out))
+    assert rc in (am.AM_OK, am.AM_ERR_NO_DEVICE)                      # intact image: accepted (or no GPU in this container)
+    if rc == am.AM_OK:
+        lib.am_automaton_destroy(out)
+    # corrupt: node 1's child id (SfNode.z at byte 8 of the 32-byte record) -> far outside the node table
+    bad = bytearray(good)
+    node = h["off_nodes"] + 32 * 1
+    w = struct.unpack_from("<I", bad, node + 12)[0]
+    struct.pack_into("<I", bad, node + 12, (w & ~0xFFFF) | 1)       # exactly one edge ...
+    struct.pack_into("<I", bad, node + 8, 0x7FFFFFFF)                # ... to a node that does not exist
+    # recompute the checksum the way the library does (FNV-1a over 8-byte words, then the tail bytes), header excluded
+    body = bytes(bad[312:]) if False else None
+    hsize = _header_size(lib, good)
+    x = 0xcbf29ce484222325
+    data = bytes(bad[hsize:])
+    n8 = len(data) // 8
+    for wv in struct.unpack_from("<%dQ" % n8, data):
+        x = ((x ^ wv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    for bv in data[n8 * 8:]:
+        x = ((x ^ bv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    struct.pack_into("<Q", bad, _checksum_offset(good, h["checksum"]), x)
+    rc = lib.am_automaton_from_host_image(bytes(bad), len(bad), C.byref(out))
+    assert rc == am.AM_ERR_INVALID, (rc, lib.am_last_error())
+    assert b"image:" in lib.am_last_error()
+
+
+def _checksum_offset(good, value):
+    i = good.find(struct.pack("<Q", value))
+    assert 0 < i < 400
+    return i
+
+
+def _header_size(lib, good):
+    # the body starts right after the header; the first section is 256-byte aligned, so the header size is what the checksum
+    # routine skips: sizeof(ImageHeader).  Recover it by finding which prefix length reproduces the stored checksum.
+    for size in range(200, 400, 8):
+        x = 0xcbf29ce484222325
+        data = good[size:]
+        n8 = len(data) // 8
+        for wv in struct.unpack_from("<%dQ" % n8, data):
+            x = ((x ^ wv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        for bv in data[n8 * 8:]:
+            x = ((x ^ bv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        if good.find(struct.pack("<Q", x)) in range(0, size):
+            return size
+    raise AssertionError("header size not found")
