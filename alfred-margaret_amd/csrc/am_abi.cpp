@@ -1013,7 +1013,7 @@ struct am_replacer {
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
     // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
     mutable std::mutex session_mu;
-    mutable void* session = nullptr;
+    mutable std::vector<void*> sessions;              // workspaces of finished runs, kept for the next ones (several: concurrent groups / threads)
     void (*session_delete)(void*) = nullptr;
 };
 
@@ -1121,7 +1121,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
 extern "C" void am_replacer_destroy(am_replacer* r)
 {
     if (!r) return;
-    if (r->session && r->session_delete) r->session_delete(r->session);
+    if (r->session_delete) for (void* p : r->sessions) r->session_delete(p);
     for (DevBuf* d : {&r->vals_off, &r->vals, &r->payloads, &r->repl}) d->release();
     delete r;
 }
@@ -1149,6 +1149,7 @@ struct RpSession {
     DevBuf rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
     am_batch ws;                         // workspace holder for the scans; never owns its text
     DevBuf first_orig, first_thr;
+    DevBuf pt_pieces[2], pt_start[2], pt_cnt[2], pt_need, pt_need_off, pt_fin_start, pt_fin_cnt;      // piece-table path
     DevBuf pf_best, pf_delta, pf_payload, pf_selflag, pf_sidx, pf_cand, pf_sel, pf_keep, pf_kflag, pf_kdelta, pf_kidx, pf_kdpre, pf_tmp;   // record-parallel fold
     size_t device_bytes() const
     {
@@ -1161,7 +1162,8 @@ struct RpSession {
         for (DevBuf* d : {&text[0], &text[1], &offs[0], &offs[1], &orig[0], &orig[1], &thr[0], &thr[1], &rec_first, &kept, &hs, &len_next, &len_fin,
                           &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff, &tile_hay,
                           &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr,
-                          &pf_best, &pf_delta, &pf_payload, &pf_selflag, &pf_sidx, &pf_cand, &pf_sel, &pf_keep, &pf_kflag, &pf_kdelta, &pf_kidx, &pf_kdpre, &pf_tmp}) d->release();
+                          &pf_best, &pf_delta, &pf_payload, &pf_selflag, &pf_sidx, &pf_cand, &pf_sel, &pf_keep, &pf_kflag, &pf_kdelta, &pf_kidx, &pf_kdpre, &pf_tmp,
+                          &pt_pieces[0], &pt_pieces[1], &pt_start[0], &pt_start[1], &pt_cnt[0], &pt_cnt[1], &pt_need, &pt_need_off, &pt_fin_start, &pt_fin_cnt}) d->release();
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
@@ -1173,19 +1175,99 @@ struct RpSession {
 
 size_t padded_text(uint64_t total) { return (size_t)((total + 15) & ~15ull) + 16; }
 
-// Replacer.hs:203-242 runWithLimit for every haystack of `in`, all passes on the device.
-int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res)
+// The suffix-filter scan of a (small) batch WITHOUT a host round trip: the record pool is sized for the worst case -- a record at
+// every byte -- so the pass cannot overflow and needs no retry; the sorted records go to d_out (room for b->total records), their
+// number stays on the device (*n_dev points at it).  Used between Replacer passes, where a sync per scan would cost more than
+// the scan.
+static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, Record* d_out, const uint64_t** n_dev, hipStream_t st)
+{
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p));
+    if (!p.use_sf || p.dense) return fail(AM_ERR_UNSUPPORTED, "internal: asynchronous scan needs the plain suffix-filter route");
+    std::lock_guard<std::mutex> lk(b->mu);
+    const uint64_t n = p.n_units + 1;
+    AM_TRY(b->unit_counts.ensure(n * sizeof(uint32_t)));
+    AM_TRY(b->unit_offsets.ensure(n * sizeof(uint64_t)));
+    *n_dev = (const uint64_t*)b->unit_offsets.p + p.n_units;
+    if (p.nothing) { HIP_TRY(hipMemsetAsync(b->unit_offsets.p, 0, n * sizeof(uint64_t), st)); return AM_OK; }
+    AM_TRY(b->small.ensure(64));
+    AM_TRY(b->unit_first.ensure(p.n_units * sizeof(uint32_t)));
+    size_t tmp_bytes = 0;
+    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
+    const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8;          // ceil(records / 64) per unit, records <= bytes
+    if (want_blocks >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
+    AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
+    AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
+    ScanOut o{};
+    o.unit_chunks = p.unit_chunks;
+    o.unit_counts = (uint32_t*)b->unit_counts.p;
+    o.unit_first = (uint32_t*)b->unit_first.p;
+    o.pool = (Record*)b->pool.p;
+    o.block_next = (uint32_t*)b->block_next.p;
+    o.pool_ctrl = (uint32_t*)b->small.p + 4;
+    o.n_blocks = (uint32_t)want_blocks;
+    HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
+    HIP_TRY(hipMemsetAsync((uint32_t*)b->unit_counts.p + p.n_units, 0, sizeof(uint32_t), st));
+    AM_TRY(build_hidx(p, b, st));
+    AM_TRY(launch_scan_kernel(p, kModeEmit, o, st));
+    { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
+    { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, d_out, p.n_units, st)); }
+    return AM_OK;
+}
+
+// prependMatch + makeMatch + removeOverlap of one pass (Replacer.hs:252-274,191-198): one wavefront per haystack, or -- few
+// haystacks with very many matches each -- parallel over the records.  Writes kept[], hs[] and the route arrays.
+static int rp_fold(RpSession& s, const am_replacer* r, bool ic, const uint8_t* text, const uint64_t* offs, const Record* recs, uint64_t n_rec, const int64_t* thr,
+                   uint64_t max_length, const RpRoute& route, uint32_t n_act, hipStream_t st)
+{
+    const uint64_t n1 = (uint64_t)n_act + 1;
+    // one wavefront per haystack, or -- few haystacks with very many matches each -- parallel over the records
+        bool par_fold = n_rec > 2048ull * n_act;
+        if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;        // tests force either path
+        if (!par_fold) {
+            Prof pr("rp_pass", st);
+            HIP_TRY(launch_rp_pass(ic, r->t, text, offs, recs, (const uint64_t*)s.rec_first.p, thr,
+                                   max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st));
+        } else {
+            Prof pr("rp_pass", st);
+            const uint64_t nb = n_rec + 2;
+            AM_TRY(s.pf_best.ensure(n1 * 8)); AM_TRY(s.pf_delta.ensure(n1 * 8)); AM_TRY(s.pf_payload.ensure(n1 * 4));
+            AM_TRY(s.pf_selflag.ensure(nb * 4)); AM_TRY(s.pf_sidx.ensure(nb * 8)); AM_TRY(s.pf_cand.ensure(nb * sizeof(RpSel))); AM_TRY(s.pf_sel.ensure(nb * sizeof(RpSel)));
+            AM_TRY(s.pf_keep.ensure(nb * 4)); AM_TRY(s.pf_kflag.ensure(nb * 4)); AM_TRY(s.pf_kdelta.ensure(nb * 8)); AM_TRY(s.pf_kidx.ensure(nb * 8)); AM_TRY(s.pf_kdpre.ensure(nb * 8));
+            size_t t32b = 0, t64b = 0;
+            if (scan_temp_bytes(nb, &t32b) != hipSuccess || scan64_temp_bytes(nb, &t64b) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+            AM_TRY(s.pf_tmp.ensure(std::max(t32b, t64b) + 16));
+            const size_t ptmp = s.pf_tmp.cap - 16;
+            HIP_TRY(hipMemsetAsync(s.pf_delta.p, 0, n1 * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_payload.p, 0, n1 * 4, st));
+            HIP_TRY(hipMemsetAsync(s.pf_kflag.p, 0, nb * 4, st)); HIP_TRY(hipMemsetAsync(s.pf_kdelta.p, 0, nb * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_keep.p, 0, nb * 4, st));
+            HIP_TRY(launch_rpp_best(r->t, recs, n_rec, thr, (int64_t*)s.pf_best.p, n_act, st));
+            HIP_TRY(launch_rpp_select(ic, r->t, text, offs, recs, n_rec, (const int64_t*)s.pf_best.p,
+                                      (uint32_t*)s.pf_selflag.p, (RpSel*)s.pf_cand.p, (int64_t*)s.pf_delta.p, (uint32_t*)s.pf_payload.p, st));
+            HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_selflag.p, (uint64_t*)s.pf_sidx.p, n_rec + 1, st));
+            const uint64_t* n_sel_dev = (const uint64_t*)s.pf_sidx.p + n_rec;
+            HIP_TRY(launch_rpp_compact((const uint32_t*)s.pf_selflag.p, (const uint64_t*)s.pf_sidx.p, (const RpSel*)s.pf_cand.p, n_rec, (RpSel*)s.pf_sel.p, st));
+            HIP_TRY(launch_rpp_overlaps((const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (uint32_t*)s.pf_keep.p, st));
+            HIP_TRY(launch_rpp_kflags((const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_keep.p, r->t, (const uint32_t*)s.pf_payload.p,
+                                      (uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kdelta.p, st));
+            HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kidx.p, n_rec + 2, st));
+            HIP_TRY(launch_scan64(s.pf_tmp.p, ptmp, (const uint64_t*)s.pf_kdelta.p, (uint64_t*)s.pf_kdpre.p, n_rec + 2, st));
+            HIP_TRY(launch_rpp_finish(r->t, (const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_kflag.p, (const uint64_t*)s.pf_kidx.p,
+                                      (const uint64_t*)s.pf_kdpre.p, (const uint64_t*)s.pf_sidx.p, offs, (const uint64_t*)s.rec_first.p, (const int64_t*)s.pf_best.p,
+                                      (const int64_t*)s.pf_delta.p, (const uint32_t*)s.pf_payload.p, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, st));
+        }
+    return AM_OK;
+}
+
+// The same loop with the text of the active haystacks kept as PIECE TABLES (am_replace.hip): no pass rewrites a text; bytes
+// move into the re-scanned windows and, once per haystack, into the result.  CaseSensitive replacers on the suffix-filter
+// route (the incremental re-scan is part of the design: after the first pass only windows are scanned).
+int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res, const Flavor* flavor)
 {
     const uint32_t n_hay = in->n_hay;
-    res->text.assign(n_hay, am_replaced::Item());
-    res->just.assign(n_hay, 1);
-    if (n_hay == 0) return AM_OK;
-    if (in->dev != r->a->dev) return fail(AM_ERR_INVALID, "replacer and batch live on different devices");
     ON_DEVICE(in->dev);
     hipStream_t st; AM_TRY(get_stream(in->dev, &st));
-    // take the replacer's cached workspace (or make one); it goes back at the end unless it has grown large
     RpSession* sp = nullptr;
-    { std::lock_guard<std::mutex> lk(r->session_mu); sp = static_cast<RpSession*>(r->session); r->session = nullptr; }
+    { std::lock_guard<std::mutex> lk(r->session_mu); if (!r->sessions.empty()) { sp = static_cast<RpSession*>(r->sessions.back()); r->sessions.pop_back(); } }
     if (!sp) sp = new RpSession();
     struct Return {
         const am_replacer* r; RpSession* sp;
@@ -1194,7 +1276,277 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
             if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
             if (sp->device_bytes() > (512ull << 20)) { delete sp; return; }
             RpSession* old = nullptr;
-            { std::lock_guard<std::mutex> lk(r->session_mu); old = static_cast<RpSession*>(r->session); r->session = sp; const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); }; }
+            { std::lock_guard<std::mutex> lk(r->session_mu);
+              const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
+              if (r->sessions.size() >= 8) { old = static_cast<RpSession*>(r->sessions.front()); r->sessions.erase(r->sessions.begin()); }
+              r->sessions.push_back(sp); }
+            delete old;
+        }
+    } give_back{r, sp};
+    RpSession& s = *sp;
+    AM_TRY(s.totals.ensure(128));
+    if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    if (!s.copy_stream && (hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev_spliced, hipEventDisableTiming) != hipSuccess))
+        return fail(AM_ERR_HIP, "could not create the copy stream");
+    const uint8_t* base_text = (const uint8_t*)in->d_text;               // never modified: every text piece points into it
+    const uint64_t* cur_offs = in->d_offsets;                            // logical offsets of the active haystacks (lengths only after pass 0)
+    uint32_t n_act = n_hay;
+    int nxt = 0;
+    {
+        std::vector<uint32_t> o(n_hay); std::vector<int64_t> t(n_hay, 1);      // initialThreshold = 1 (Replacer.hs:211)
+        for (uint32_t i = 0; i < n_hay; i++) o[i] = i;
+        AM_TRY(s.first_orig.ensure(n_hay * sizeof(uint32_t))); AM_TRY(s.first_thr.ensure(n_hay * sizeof(int64_t)));
+        HIP_TRY(hipMemcpyAsync(s.first_orig.p, o.data(), n_hay * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s.first_thr.p, t.data(), n_hay * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    const uint32_t* cur_orig = (const uint32_t*)s.first_orig.p;
+    const int64_t* cur_thr = (const int64_t*)s.first_thr.p;
+    const uint32_t ov = 4u * (flavor->h.max_needle_cps ? flavor->h.max_needle_cps : 1u) + 4u;
+    // piece lists of pass 0: one piece per haystack
+    int cur_pt = 0;
+    AM_TRY(s.pt_pieces[0].ensure(((size_t)n_hay * 2 + 2) * sizeof(RpPiece)));
+    AM_TRY(s.pt_start[0].ensure(((size_t)n_hay + 1) * 8)); AM_TRY(s.pt_cnt[0].ensure(((size_t)n_hay + 1) * 4));
+    HIP_TRY(launch_pt_init(in->d_offsets, n_hay, (RpPiece*)s.pt_pieces[0].p, (uint64_t*)s.pt_start[0].p, (uint32_t*)s.pt_cnt[0].p, st));
+    // pass 0 scans the caller's batch; afterwards the records come from the window scans + the shifted old records
+    uint64_t n_rec = 0;                                   // records of the current pass: exact when n_rec_dev == nullptr, else an upper bound ...
+    const uint64_t* n_rec_dev = nullptr;                  // ... and the exact count is still on the device
+    int cur_rec = 0;
+    {
+        res->scanned += in->total;
+        s.ws.dev = in->dev; s.ws.d_text = in->d_text; s.ws.d_offsets = in->d_offsets; s.ws.owns = false; s.ws.total = in->total; s.ws.n_hay = n_hay;
+        AM_TRY(finish_batch(&s.ws));
+        auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.recbuf[0].ensure(n * sizeof(Record))); *ptr = (Record*)s.recbuf[0].p; return AM_OK; };
+        AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &n_rec));
+    }
+    const bool trace = std::getenv("AM_RP_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_a = 0, t_b = 0, t_c = 0;
+    // finished haystacks of the previous pass: their bytes are on their way home on the copy stream; the host looks at the list after
+    // the next pass's (only) synchronisation
+    uint64_t prev_n_fin = 0, prev_total_fin = 0; uint8_t* prev_home = nullptr;
+    hipEvent_t ev_copied = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev_copied, hipEventDisableTiming));
+    struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ev_guard{ev_copied};
+    bool copies_pending = false, ev_copied_used = false;
+    auto finished_home = [&]() -> int {
+        if (!copies_pending) return AM_OK;
+        HIP_TRY(hipStreamSynchronize(s.copy_stream));
+        copies_pending = false;
+        for (uint64_t i = 0; i < prev_n_fin; i++) {
+            const RpFin& f = s.fin_host[i];
+            if (f.orig >= n_hay || f.off + f.len > prev_total_fin) return fail(AM_ERR_HIP, "replacer pass produced inconsistent metadata (internal error)");
+            if (f.status == kRpNothing) res->just[f.orig] = 0;
+            else res->text[f.orig] = am_replaced::Item{prev_home + f.off, (size_t)f.len};
+        }
+        return AM_OK;
+    };
+
+    while (n_act > 0) {
+        double t0 = now();
+        res->passes++;
+        DevBuf& records = s.recbuf[cur_rec];
+        const uint64_t n1 = (uint64_t)n_act + 1;
+        // the record-parallel fold needs the exact count on the host: fetch it when that regime is possible
+        if (n_rec_dev && (n_rec > 2048ull * n_act || std::getenv("AM_RP_PARALLEL_FOLD"))) {
+            HIP_TRY(hipMemcpyAsync(&s.tot_host[9], n_rec_dev, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            n_rec = s.tot_host[9]; n_rec_dev = nullptr;
+        }
+        AM_TRY(s.rec_first.ensure(n1 * 8)); AM_TRY(s.kept.ensure((n_rec + 1) * sizeof(RpKept))); AM_TRY(s.hs.ensure(n1 * sizeof(RpHay)));
+        AM_TRY(s.len_next.ensure(n1 * 8)); AM_TRY(s.len_fin.ensure(n1 * 8)); AM_TRY(s.tiles.ensure(n1 * 4)); AM_TRY(s.act.ensure(n1 * 4)); AM_TRY(s.fin.ensure(n1 * 4));
+        AM_TRY(s.off_next.ensure(n1 * 8)); AM_TRY(s.off_fin.ensure(n1 * 8)); AM_TRY(s.tile_off.ensure(n1 * 8)); AM_TRY(s.act_idx.ensure(n1 * 8)); AM_TRY(s.fin_idx.ensure(n1 * 8));
+        AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8)); AM_TRY(s.pt_need.ensure(n1 * 4)); AM_TRY(s.pt_need_off.ensure(n1 * 8));
+        AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
+        size_t t32 = 0, t64 = 0, tw = 0;
+        if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess || scan_temp_bytes(n_rec + 2, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+        AM_TRY(s.scan_tmp.ensure(std::max(std::max(t32, t64), tw) + 16));
+        const size_t tmp2 = s.scan_tmp.cap - 16;
+        AM_TRY(records.ensure(sizeof(Record)));
+        RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
+        RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
+        { Prof pr("rp_ranges", st);
+          if (n_rec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)records.p, n_rec_dev, (uint64_t*)s.rec_first.p, route, n_act, st));
+          else HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
+        AM_TRY(rp_fold(s, r, false, base_text, cur_offs, (const Record*)records.p, n_rec_dev ? 0 : n_rec, cur_thr, max_length, route, n_act, st));
+        const bool small = n1 <= (1u << 18);
+        { Prof pr("rp_scans", st);
+          HIP_TRY(launch_pt_count((const RpHay*)s.hs.p, (const uint32_t*)s.pt_cnt[cur_pt].p, n_act, (uint32_t*)s.pt_need.p, (uint32_t*)s.nwin.p, st));
+          if (small) {
+              ScanJobs jobs{};
+              jobs.j[0] = ScanJob{nullptr, route.len_next, (uint64_t*)s.off_next.p, n1, nullptr};
+              jobs.j[1] = ScanJob{nullptr, route.len_fin, (uint64_t*)s.off_fin.p, n1, nullptr};
+              jobs.j[2] = ScanJob{(const uint32_t*)s.pt_need.p, nullptr, (uint64_t*)s.pt_need_off.p, n1, nullptr};
+              jobs.j[3] = ScanJob{route.act, nullptr, (uint64_t*)s.act_idx.p, n1, nullptr};
+              jobs.j[4] = ScanJob{route.fin, nullptr, (uint64_t*)s.fin_idx.p, n1, nullptr};
+              jobs.j[5] = ScanJob{(const uint32_t*)s.nwin.p, nullptr, (uint64_t*)s.win_off.p, n1, nullptr};
+              jobs.n_jobs = 6;
+              HIP_TRY(launch_scan_jobs(jobs, st));
+          } else {
+              HIP_TRY(launch_scan64(s.scan_tmp.p, tmp2, route.len_next, (uint64_t*)s.off_next.p, n1, st));
+              HIP_TRY(launch_scan64(s.scan_tmp.p, tmp2, route.len_fin, (uint64_t*)s.off_fin.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.pt_need.p, (uint64_t*)s.pt_need_off.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, route.act, (uint64_t*)s.act_idx.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, route.fin, (uint64_t*)s.fin_idx.p, n1, st));
+              HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.nwin.p, (uint64_t*)s.win_off.p, n1, st));
+          } }
+        uint64_t woffs_last = n_rec;
+        { Prof pr("rp_windows", st);
+          if (!small) HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));
+          HIP_TRY(launch_rp_win_meta(r->t, rt, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p,
+                                     (const uint64_t*)s.win_off.p, ov, (RpWin*)s.wins.p, (uint32_t*)s.wlen.p, n_act, st, true));
+          if (small) {
+              ScanJobs jobs{};
+              jobs.j[0] = ScanJob{(const uint32_t*)s.wlen.p, nullptr, (uint64_t*)s.woffs.p, 1, (const uint64_t*)s.win_off.p + n_act};
+              jobs.n_jobs = 1;
+              HIP_TRY(launch_scan_jobs(jobs, st));
+              woffs_last = ~0ull;
+          } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st)); }
+        // the pass's ONE synchronisation: bytes of next text, bytes of finished text, -, haystacks still active, haystacks finished,
+        // windows, window bytes, piece entries, and the exact record count of this pass when it was still on the device
+        HIP_TRY(launch_rp_totals(rt, n_act, (const uint64_t*)s.win_off.p, (const uint64_t*)s.woffs.p, woffs_last, (uint64_t*)s.totals.p, st));
+        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 56, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&s.tot_host[8], (uint64_t*)s.pt_need_off.p + n_act, 8, hipMemcpyDeviceToHost, st));
+        if (n_rec_dev) HIP_TRY(hipMemcpyAsync(&s.tot_host[9], n_rec_dev, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const uint64_t* tot = s.tot_host;
+        const uint64_t total_next = tot[0], total_fin = tot[1], n_next = tot[3], n_fin = tot[4], n_win = tot[5], total_w = tot[6], n_pieces = tot[8];
+        if (n_rec_dev) { n_rec = tot[9]; n_rec_dev = nullptr; }
+        AM_TRY(finished_home());                              // the previous pass's finished haystacks (their copies have had a whole pass)
+        t_a += now() - t0; t0 = now();
+        if (n_win >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many replacements in one pass; split the batch");
+        // ---- the next pass's piece lists; finished haystacks are materialised and go home
+        AM_TRY(s.offs[nxt].ensure((n_next + 1) * 8)); AM_TRY(s.orig[nxt].ensure((n_next + 1) * 4)); AM_TRY(s.thr[nxt].ensure((n_next + 1) * 8));
+        AM_TRY(s.fin_text.ensure(total_fin + 16)); AM_TRY(s.fin_meta.ensure((n_fin + 1) * sizeof(RpFin)));
+        AM_TRY(s.pt_pieces[cur_pt ^ 1].ensure((n_pieces + 2) * sizeof(RpPiece)));
+        AM_TRY(s.pt_start[cur_pt ^ 1].ensure((n_next + 1) * 8)); AM_TRY(s.pt_cnt[cur_pt ^ 1].ensure((n_next + 1) * 4));
+        AM_TRY(s.pt_fin_start.ensure((n_fin + 1) * 8)); AM_TRY(s.pt_fin_cnt.ensure((n_fin + 1) * 4));
+        { Prof pr("rp_route", st);
+          HIP_TRY(launch_rp_route((const RpHay*)s.hs.p, rt, cur_orig, n_act, (uint64_t*)s.offs[nxt].p, (uint32_t*)s.orig[nxt].p, (int64_t*)s.thr[nxt].p, (RpFin*)s.fin_meta.p, st)); }
+        { Prof pr("pt_build", st);
+          HIP_TRY(launch_pt_build(r->t, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpPiece*)s.pt_pieces[cur_pt].p,
+                                  (const uint64_t*)s.pt_start[cur_pt].p, (const uint32_t*)s.pt_cnt[cur_pt].p, (const uint64_t*)s.pt_need_off.p, rt, n_act,
+                                  (RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (uint64_t*)s.pt_start[cur_pt ^ 1].p, (uint32_t*)s.pt_cnt[cur_pt ^ 1].p,
+                                  (uint64_t*)s.pt_fin_start.p, (uint32_t*)s.pt_fin_cnt.p, st)); }
+        res->spliced += total_fin;
+        if (n_fin) {
+            uint8_t* home = nullptr;
+            if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
+            AM_TRY(s.pin_meta((n_fin + 1) * sizeof(RpFin)));
+            if (ev_copied_used) HIP_TRY(hipStreamWaitEvent(st, ev_copied, 0));      // the previous finished texts have left fin_text / fin_meta (a whole pass ago)
+            { Prof pr("pt_materialise", st);
+              HIP_TRY(launch_pt_materialise((const RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (const uint64_t*)s.pt_fin_start.p, (const uint32_t*)s.pt_fin_cnt.p, (const RpFin*)s.fin_meta.p,
+                                            (uint32_t)n_fin, base_text, r->t.repl, (uint8_t*)s.fin_text.p, st)); }
+            HIP_TRY(hipEventRecord(s.ev_spliced, st));
+            HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0));
+            if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, s.copy_stream));
+            HIP_TRY(hipMemcpyAsync(s.fin_host, s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, s.copy_stream));
+            HIP_TRY(hipEventRecord(ev_copied, s.copy_stream));
+            ev_copied_used = true;
+            prev_n_fin = n_fin; prev_total_fin = total_fin; prev_home = home; copies_pending = true;
+        }
+        t_b += now() - t0; t0 = now();
+        // ---- the next pass's records
+        uint64_t next_n_rec = 0; const uint64_t* next_n_rec_dev = nullptr;
+        if (n_next > 0) {
+            DevBuf& next_records = s.recbuf[cur_rec ^ 1];
+            if (total_w > total_next) {
+                // tiny texts: the windows would be larger than the texts themselves -- materialise the next texts and scan them whole
+                AM_TRY(s.text[0].ensure(padded_text(total_next)));
+                HIP_TRY(launch_pt_materialise_next((const RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (const uint64_t*)s.pt_start[cur_pt ^ 1].p, (const uint32_t*)s.pt_cnt[cur_pt ^ 1].p,
+                                                   (const uint64_t*)s.offs[nxt].p, (uint32_t)n_next, base_text, r->t.repl, (uint8_t*)s.text[0].p, st));
+                HIP_TRY(hipMemsetAsync((uint8_t*)s.text[0].p + total_next, 0, padded_text(total_next) - (size_t)total_next, st));
+                s.ws.dev = in->dev; s.ws.d_text = s.text[0].p; s.ws.d_offsets = (uint64_t*)s.offs[nxt].p; s.ws.owns = false; s.ws.total = total_next; s.ws.n_hay = (uint32_t)n_next;
+                AM_TRY(finish_batch(&s.ws));
+                auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(next_records.ensure(n * sizeof(Record))); *ptr = (Record*)next_records.p; return AM_OK; };
+                AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &next_n_rec));
+                res->scanned += total_next;
+            } else {
+                // windows around the replacements (gathered from the new piece lists) + the shifted old records; no host round trip when the
+                // worst-case record pool of the window scan stays small
+                const bool lean = total_w <= (64ull << 20);
+                uint64_t n_wrec = 0; const uint64_t* n_wrec_dev = nullptr;
+                AM_TRY(s.wtext.ensure(padded_text(total_w)));
+                AM_TRY(s.wrec.ensure(((lean ? total_w : 0) + 1) * sizeof(Record)));
+                if (n_win > 0 && total_w > 0) {
+                    { Prof pr("rp_windows", st);
+                      HIP_TRY(launch_pt_win_copy((const RpWin*)s.wins.p, (const uint64_t*)s.woffs.p, (const RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (const uint64_t*)s.pt_start[cur_pt ^ 1].p,
+                                                 (const uint32_t*)s.pt_cnt[cur_pt ^ 1].p, base_text, r->t.repl, (uint8_t*)s.wtext.p, n_win, total_w, padded_text(total_w), st)); }
+                    s.ws2.dev = in->dev; s.ws2.d_text = s.wtext.p; s.ws2.d_offsets = (uint64_t*)s.woffs.p; s.ws2.owns = false; s.ws2.total = total_w; s.ws2.n_hay = (uint32_t)n_win;
+                    AM_TRY(finish_batch(&s.ws2));
+                    if (lean) AM_TRY(run_records_async(r->a, r->case_mode, &s.ws2, (Record*)s.wrec.p, &n_wrec_dev, st));
+                    else {
+                        auto wsink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.wrec.ensure(n * sizeof(Record))); *ptr = (Record*)s.wrec.p; return AM_OK; };
+                        AM_TRY(run_records(r->a, r->case_mode, &s.ws2, wsink, &n_wrec));
+                    }
+                    res->scanned += total_w;
+                }
+                const uint64_t wrec_bound = n_wrec_dev ? total_w : n_wrec;
+                AM_TRY(s.wrec_first.ensure((n_win + 2) * 8)); AM_TRY(s.mcount.ensure((n_next + 1) * 4)); AM_TRY(s.moff.ensure((n_next + 1) * 8));
+                AM_TRY(next_records.ensure((n_rec + wrec_bound + 1) * sizeof(Record)));
+                Prof pr("rp_merge", st);
+                if (n_wrec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)s.wrec.p, n_wrec_dev, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
+                else HIP_TRY(launch_rp_ranges((const Record*)s.wrec.p, n_wrec, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
+                HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                                        (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
+                                        (uint32_t*)s.mcount.p, nullptr, nullptr, st));
+                if (n_next + 1 <= (1u << 18)) {
+                    ScanJobs jobs{};
+                    jobs.j[0] = ScanJob{(const uint32_t*)s.mcount.p, nullptr, (uint64_t*)s.moff.p, n_next + 1, nullptr};
+                    jobs.n_jobs = 1;
+                    HIP_TRY(launch_scan_jobs(jobs, st));
+                } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st));
+                HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                                        (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
+                                        (uint32_t*)s.mcount.p, (const uint64_t*)s.moff.p, (Record*)next_records.p, st));
+                next_n_rec = n_rec + wrec_bound;                 // an upper bound; the exact count is read with the next pass's totals
+                next_n_rec_dev = (const uint64_t*)s.moff.p + n_next;
+            }
+        }
+        t_c += now() - t0;
+        cur_rec ^= 1; cur_pt ^= 1; n_rec = next_n_rec; n_rec_dev = next_n_rec_dev;
+        cur_offs = (const uint64_t*)s.offs[nxt].p; cur_orig = (const uint32_t*)s.orig[nxt].p; cur_thr = (const int64_t*)s.thr[nxt].p;
+        n_act = (uint32_t)n_next; nxt ^= 1;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    AM_TRY(finished_home());
+    if (trace) std::fprintf(stderr, "[am_replacer pt] fold+scans %.1f ms, pieces+materialise %.1f ms, windows+merge %.1f ms\n", t_a * 1e3, t_b * 1e3, t_c * 1e3);
+    return AM_OK;
+}
+
+// Replacer.hs:203-242 runWithLimit for every haystack of `in`, all passes on the device.
+int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res)
+{
+    const uint32_t n_hay = in->n_hay;
+    res->text.assign(n_hay, am_replaced::Item());
+    res->just.assign(n_hay, 1);
+    if (n_hay == 0) return AM_OK;
+    if (in->dev != r->a->dev) return fail(AM_ERR_INVALID, "replacer and batch live on different devices");
+    {
+        // CaseSensitive replacers on the suffix-filter route keep the texts as piece tables (AM_RP_SPLICE=1: the splicing loop, for A/B and tests)
+        const Flavor* fl = nullptr;
+        AM_TRY(prepare(r->a, r->case_mode, &fl));
+        const bool pt = r->case_mode == AM_CASE_SENSITIVE && fl->h.sf_enabled && fl->h.root_vlen == 0 && r->a->kernel_pref != 1 &&
+                        std::getenv("AM_RP_FULL_SCANS") == nullptr && std::getenv("AM_RP_SPLICE") == nullptr;
+        if (pt) return replacer_run_pt(r, in, max_length, res, fl);
+    }
+    ON_DEVICE(in->dev);
+    hipStream_t st; AM_TRY(get_stream(in->dev, &st));
+    // take the replacer's cached workspace (or make one); it goes back at the end unless it has grown large
+    RpSession* sp = nullptr;
+    { std::lock_guard<std::mutex> lk(r->session_mu); if (!r->sessions.empty()) { sp = static_cast<RpSession*>(r->sessions.back()); r->sessions.pop_back(); } }
+    if (!sp) sp = new RpSession();
+    struct Return {
+        const am_replacer* r; RpSession* sp;
+        ~Return()
+        {
+            if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
+            if (sp->device_bytes() > (512ull << 20)) { delete sp; return; }
+            RpSession* old = nullptr;
+            { std::lock_guard<std::mutex> lk(r->session_mu);
+              const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
+              if (r->sessions.size() >= 8) { old = static_cast<RpSession*>(r->sessions.front()); r->sessions.erase(r->sessions.begin()); }
+              r->sessions.push_back(sp); }
             delete old;
         }
     } give_back{r, sp};
@@ -1264,40 +1616,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         AM_TRY(records.ensure(sizeof(Record)));            // a valid pointer even when nothing matched
         RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
         { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
-        // one wavefront per haystack, or -- few haystacks with very many matches each -- parallel over the records
-        bool par_fold = n_rec > 2048ull * n_act;
-        if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;        // tests force either path
-        if (!par_fold) {
-            Prof pr("rp_pass", st);
-            HIP_TRY(launch_rp_pass(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, (const uint64_t*)s.rec_first.p, cur_thr,
-                                   max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st));
-        } else {
-            Prof pr("rp_pass", st);
-            const uint64_t nb = n_rec + 2;
-            AM_TRY(s.pf_best.ensure(n1 * 8)); AM_TRY(s.pf_delta.ensure(n1 * 8)); AM_TRY(s.pf_payload.ensure(n1 * 4));
-            AM_TRY(s.pf_selflag.ensure(nb * 4)); AM_TRY(s.pf_sidx.ensure(nb * 8)); AM_TRY(s.pf_cand.ensure(nb * sizeof(RpSel))); AM_TRY(s.pf_sel.ensure(nb * sizeof(RpSel)));
-            AM_TRY(s.pf_keep.ensure(nb * 4)); AM_TRY(s.pf_kflag.ensure(nb * 4)); AM_TRY(s.pf_kdelta.ensure(nb * 8)); AM_TRY(s.pf_kidx.ensure(nb * 8)); AM_TRY(s.pf_kdpre.ensure(nb * 8));
-            size_t t32b = 0, t64b = 0;
-            if (scan_temp_bytes(nb, &t32b) != hipSuccess || scan64_temp_bytes(nb, &t64b) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
-            AM_TRY(s.pf_tmp.ensure(std::max(t32b, t64b) + 16));
-            const size_t ptmp = s.pf_tmp.cap - 16;
-            HIP_TRY(hipMemsetAsync(s.pf_delta.p, 0, n1 * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_payload.p, 0, n1 * 4, st));
-            HIP_TRY(hipMemsetAsync(s.pf_kflag.p, 0, nb * 4, st)); HIP_TRY(hipMemsetAsync(s.pf_kdelta.p, 0, nb * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_keep.p, 0, nb * 4, st));
-            HIP_TRY(launch_rpp_best(r->t, (const Record*)records.p, n_rec, cur_thr, (int64_t*)s.pf_best.p, n_act, st));
-            HIP_TRY(launch_rpp_select(r->case_mode == AM_IGNORE_CASE, r->t, cur_text, cur_offs, (const Record*)records.p, n_rec, (const int64_t*)s.pf_best.p,
-                                      (uint32_t*)s.pf_selflag.p, (RpSel*)s.pf_cand.p, (int64_t*)s.pf_delta.p, (uint32_t*)s.pf_payload.p, st));
-            HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_selflag.p, (uint64_t*)s.pf_sidx.p, n_rec + 1, st));
-            const uint64_t* n_sel_dev = (const uint64_t*)s.pf_sidx.p + n_rec;
-            HIP_TRY(launch_rpp_compact((const uint32_t*)s.pf_selflag.p, (const uint64_t*)s.pf_sidx.p, (const RpSel*)s.pf_cand.p, n_rec, (RpSel*)s.pf_sel.p, st));
-            HIP_TRY(launch_rpp_overlaps((const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (uint32_t*)s.pf_keep.p, st));
-            HIP_TRY(launch_rpp_kflags((const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_keep.p, r->t, (const uint32_t*)s.pf_payload.p,
-                                      (uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kdelta.p, st));
-            HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kidx.p, n_rec + 2, st));
-            HIP_TRY(launch_scan64(s.pf_tmp.p, ptmp, (const uint64_t*)s.pf_kdelta.p, (uint64_t*)s.pf_kdpre.p, n_rec + 2, st));
-            HIP_TRY(launch_rpp_finish(r->t, (const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_kflag.p, (const uint64_t*)s.pf_kidx.p,
-                                      (const uint64_t*)s.pf_kdpre.p, (const uint64_t*)s.pf_sidx.p, cur_offs, (const uint64_t*)s.rec_first.p, (const int64_t*)s.pf_best.p,
-                                      (const int64_t*)s.pf_delta.p, (const uint32_t*)s.pf_payload.p, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, st));
-        }
+        AM_TRY(rp_fold(s, r, r->case_mode == AM_IGNORE_CASE, cur_text, cur_offs, (const Record*)records.p, n_rec, cur_thr, max_length, route, n_act, st));
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
         // windows of the incremental re-scan (their geometry follows from the kept matches alone, the text is copied after the splice)
         const bool try_inc = inc_enabled && n_rec > 0;
@@ -1437,6 +1756,68 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
 
 }  // namespace
 
+// Large batches are cut into a few groups of haystacks that run the pass loop CONCURRENTLY, one host thread and HIP stream per
+// group: a pass is a chain of small kernels bound by launch and dependency latency, not by throughput, so the chains of
+// different groups overlap on the GPU.  The groups share nothing but the (read-only) batch text and the replacer tables.
+static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res)
+{
+    const uint32_t n_hay = in->n_hay;
+    uint32_t groups = n_hay / 2048u;
+    if (groups > 2) groups = 2;        // measured on config 5: 1 -> 82 ms, 2 -> 54 ms, 4 -> 77 ms, 8 -> 109 ms (the groups' kernels start to queue behind each other)
+    if (const char* env = std::getenv("AM_RP_GROUPS")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) groups = (uint32_t)v; }
+    if (groups < 2 || n_hay < groups) return replacer_run(r, in, max_length, res);
+    ON_DEVICE(in->dev);
+    std::vector<uint64_t> offs((size_t)n_hay + 1);
+    HIP_TRY(hipMemcpy(offs.data(), in->d_offsets, offs.size() * 8, hipMemcpyDeviceToHost));
+    // group boundaries at haystacks whose text starts 16-byte aligned (the scan kernels load aligned 16-byte groups)
+    std::vector<uint32_t> cut(1, 0);
+    for (uint32_t g = 1; g < groups; g++) {
+        uint32_t h = (uint32_t)((uint64_t)n_hay * g / groups);
+        while (h < n_hay && (offs[h] & 15u)) h++;
+        if (h > cut.back() && h < n_hay) cut.push_back(h);
+    }
+    cut.push_back(n_hay);
+    const size_t G = cut.size() - 1;
+    if (G < 2) return replacer_run(r, in, max_length, res);
+    struct Group { am_batch b; am_replaced part; int rc = AM_OK; std::string err; DevBuf offs; };
+    std::vector<std::unique_ptr<Group>> gs;
+    for (size_t g = 0; g < G; g++) {
+        auto gp = std::make_unique<Group>();
+        const uint32_t h0 = cut[g], h1 = cut[g + 1];
+        std::vector<uint64_t> sub(h1 - h0 + 1);
+        for (uint32_t i = 0; i <= h1 - h0; i++) sub[i] = offs[h0 + i] - offs[h0];
+        AM_TRY(gp->offs.ensure(sub.size() * 8));
+        HIP_TRY(hipMemcpy(gp->offs.p, sub.data(), sub.size() * 8, hipMemcpyHostToDevice));
+        gp->b.dev = in->dev; gp->b.owns = false; gp->b.d_text = (uint8_t*)in->d_text + offs[h0]; gp->b.d_offsets = (uint64_t*)gp->offs.p;
+        gp->b.total = sub.back(); gp->b.n_hay = h1 - h0;
+        gs.push_back(std::move(gp));
+    }
+    std::vector<std::thread> pool;
+    for (size_t g = 0; g < G; g++)
+        pool.emplace_back([&, g] {
+            Group& x = *gs[g];
+            x.rc = finish_batch(&x.b);
+            if (x.rc == AM_OK) x.rc = replacer_run(r, &x.b, max_length, &x.part);
+            if (x.rc != AM_OK) x.err = am_last_error();
+        });
+    for (auto& t : pool) t.join();
+    res->text.assign(n_hay, am_replaced::Item());
+    res->just.assign(n_hay, 1);
+    int rc = AM_OK;
+    for (size_t g = 0; g < G; g++) {
+        Group& x = *gs[g];
+        if (x.rc != AM_OK && rc == AM_OK) rc = fail(x.rc, x.err);
+        for (uint32_t i = 0; i < x.b.n_hay && i < x.part.text.size(); i++) { res->text[cut[g] + i] = x.part.text[i]; res->just[cut[g] + i] = x.part.just[i]; }
+        for (const Slab& sl : x.part.slabs) res->slabs.push_back(sl);      // the result keeps the group's pinned slabs (its texts point into them)
+        x.part.slabs.clear();
+        res->passes = std::max(res->passes, x.part.passes); res->scanned += x.part.scanned; res->spliced += x.part.spliced;
+        for (DevBuf* d : {&x.b.hidx, &x.b.unit_counts, &x.b.unit_offsets, &x.b.scan_tmp, &x.b.small, &x.b.hay_counts, &x.b.flags, &x.b.unit_first, &x.b.pool, &x.b.block_next,
+                          &x.b.sparse, &x.b.dense_counts, &x.b.dense_offsets, &x.b.dense_out}) d->release();
+        x.offs.release();
+    }
+    return rc;
+}
+
 extern "C" int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out)
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
@@ -1444,7 +1825,7 @@ extern "C" int am_replacer_run_batch(const am_replacer* r, const am_batch* b, ui
     if (!r || !b) return fail(AM_ERR_INVALID, "null replacer or batch");
     AM_TRY(ensure_runtime());
     am_replaced* res = new am_replaced();
-    const int rc = replacer_run(r, b, max_length, res);
+    const int rc = replacer_run_groups(r, b, max_length, res);
     if (rc != AM_OK) { delete res; return rc; }
     *out = res;
     return AM_OK;

@@ -70,6 +70,7 @@ struct RpRouted { const uint64_t* off_next; const uint64_t* off_fin; const uint6
 constexpr uint64_t kRpTile = 16384;                      // bytes of new text per k_rp_splice workgroup
 
 hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
+hipError_t launch_rp_ranges_dev(const Record* recs, const uint64_t* n_rec_dev, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out7, hipStream_t st);
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
                           const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st);
@@ -90,7 +91,20 @@ hipError_t launch_idset_all(const uint32_t* bits, uint32_t words, uint32_t n_nee
 struct RpWin { uint64_t src_abs; uint64_t ws; uint32_t len; uint32_t own_lo; };   // window: bytes src_abs.. of the next text; ws = its start inside the haystack; records with end > own_lo are its own
 hipError_t launch_rp_win_count(const RpHay* hs, uint32_t n_act, uint32_t* nwin, hipStream_t st);
 hipError_t launch_rp_win_meta(const RpTables& t, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
-                              const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st);
+                              const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st, bool pt = false);
+// piece table (am_replace.hip): the text of a haystack between passes as (source, logical start) pairs + a sentinel
+struct RpPiece { uint64_t src; uint64_t lstart; };
+hipError_t launch_pt_init(const uint64_t* offsets, uint32_t n_act, RpPiece* pieces, uint64_t* pc_start, uint32_t* pc_cnt, hipStream_t st);
+hipError_t launch_pt_count(const RpHay* hs, const uint32_t* pc_cnt, uint32_t n_act, uint32_t* need, uint32_t* nwin, hipStream_t st);
+hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const RpPiece* pieces, const uint64_t* pc_start,
+                           const uint32_t* pc_cnt, const uint64_t* need_off, const RpRouted& rt, uint32_t n_act, RpPiece* out, uint64_t* next_start, uint32_t* next_cnt,
+                           uint64_t* fin_start, uint32_t* fin_cnt, hipStream_t st);
+hipError_t launch_pt_materialise(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
+                                 const uint8_t* repl, uint8_t* text_fin, hipStream_t st);
+hipError_t launch_pt_materialise_next(const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint64_t* next_offsets, uint32_t n_next,
+                                      const uint8_t* text, const uint8_t* repl, uint8_t* out, hipStream_t st);
+hipError_t launch_pt_win_copy(const RpWin* wins, const uint64_t* woffs, const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint8_t* text,
+                              const uint8_t* repl, uint8_t* wtext, uint64_t n_win, uint64_t total_w, uint64_t padded, hipStream_t st);
 hipError_t launch_rp_win_copy(const RpWin* wins, const uint64_t* woffs, const uint8_t* text_next, uint8_t* wtext, uint64_t n_win, hipStream_t st);
 hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_first, const RpKept* kept, const RpHay* hs, const uint64_t* offsets, const RpRouted& rt,
                            const uint64_t* win_off, const RpWin* wins, const Record* wrecs, const uint64_t* wrec_first, uint32_t ov, uint32_t n_act,

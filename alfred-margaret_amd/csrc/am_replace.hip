@@ -60,10 +60,12 @@ __device__ __forceinline__ uint64_t skip_code_points_backwards(const uint8_t* ha
 
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_rp_ranges(const Record* __restrict__ recs, uint64_t n_rec, uint64_t* __restrict__ rec_first, RpRoute route, uint32_t n_act)
+__global__ void __launch_bounds__(256) k_rp_ranges(const Record* __restrict__ recs, uint64_t n_rec, const uint64_t* __restrict__ n_rec_dev, uint64_t* __restrict__ rec_first,
+                                                   RpRoute route, uint32_t n_act)
 {
     const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (h > n_act) return;
+    if (n_rec_dev) n_rec = *n_rec_dev;                 // the count is still on the device (no host round trip between passes)
     if (h == n_act && route.len_next) { route.len_next[h] = 0; route.len_fin[h] = 0; route.tiles[h] = 0; route.act[h] = 0; route.fin[h] = 0; }   // the scans' trailing element
     uint64_t lo = 0, hi = n_rec;                     // first record whose haystack >= h
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (recs[mid].haystack < h) lo = mid + 1; else hi = mid; }
@@ -445,7 +447,14 @@ __global__ void __launch_bounds__(256) k_rp_splice(RpTables t, const uint8_t* __
 hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st)
 {
     const uint32_t n = n_act + 1;
-    hipLaunchKernelGGL(k_rp_ranges, dim3((n + 255) / 256), dim3(256), 0, st, recs, n_rec, rec_first, route, n_act);
+    hipLaunchKernelGGL(k_rp_ranges, dim3((n + 255) / 256), dim3(256), 0, st, recs, n_rec, (const uint64_t*)nullptr, rec_first, route, n_act);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_ranges_dev(const Record* recs, const uint64_t* n_rec_dev, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st)
+{
+    const uint32_t n = n_act + 1;
+    hipLaunchKernelGGL(k_rp_ranges, dim3((n + 255) / 256), dim3(256), 0, st, recs, (uint64_t)0, n_rec_dev, rec_first, route, n_act);
     return hipGetLastError();
 }
 
@@ -544,7 +553,7 @@ __global__ void __launch_bounds__(256) k_rp_win_count(const RpHay* __restrict__ 
 __global__ void __launch_bounds__(256) k_rp_win_meta(RpTables t, RpRouted rt,
                                                      const RpHay* __restrict__ hs, const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
                                                      const uint64_t* __restrict__ win_off, uint32_t ov, RpWin* __restrict__ wins, uint32_t* __restrict__ wlen,
-                                                     uint32_t n_act)
+                                                     uint32_t n_act, bool pt)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
@@ -562,7 +571,7 @@ __global__ void __launch_bounds__(256) k_rp_win_meta(RpTables t, RpRouted rt,
         if (j + 1 < s.nkept && K[j + 1].dst < hi) hi = K[j + 1].dst;
         // a window may start inside a code point: k_sf compares bytes, and no needle starts with a continuation byte
         const uint64_t ws = dst > ov ? dst - ov : 0;
-        RpWin w; w.src_abs = base + ws; w.ws = ws;
+        RpWin w; w.src_abs = pt ? (rt.act_idx[h] << 40) | ws : base + ws; w.ws = ws;     // piece-table path: (index in the next pass, start) instead of an address
         w.len = hi > dst ? (uint32_t)(hi - ws) : 0u;                // empty own range: nothing to scan
         w.own_lo = (uint32_t)(dst - ws);
         wins[w0 + j] = w;
@@ -600,6 +609,7 @@ __global__ void __launch_bounds__(256) k_rp_merge(const Record* __restrict__ rec
 {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (!WRITE && h == 0 && lane == 0) mcount[rt.act_idx[n_act]] = 0;   // the scan's trailing element
     if (h >= n_act) return;
     const RpHay s = hs[h];
     if (s.status != kRpActive) return;
@@ -641,9 +651,9 @@ hipError_t launch_rp_win_count(const RpHay* hs, uint32_t n_act, uint32_t* nwin, 
 }
 
 hipError_t launch_rp_win_meta(const RpTables& t, const RpRouted& rt, const RpHay* hs, const uint64_t* rec_first,
-                              const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st)
+                              const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st, bool pt)
 {
-    hipLaunchKernelGGL(k_rp_win_meta, dim3((n_act + 1 + 3) / 4), dim3(256), 0, st, t, rt, hs, rec_first, kept, win_off, ov, wins, wlen, n_act);
+    hipLaunchKernelGGL(k_rp_win_meta, dim3((n_act + 1 + 3) / 4), dim3(256), 0, st, t, rt, hs, rec_first, kept, win_off, ov, wins, wlen, n_act, pt);
     return hipGetLastError();
 }
 
@@ -662,6 +672,219 @@ hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_f
     const dim3 grid((n_act + 3) / 4), block(256);
     if (write) hipLaunchKernelGGL(k_rp_merge<true>, grid, block, 0, st, recs, rec_first, kept, hs, offsets, rt, win_off, wins, wrecs, wrec_first, ov, n_act, mcount, moff, out);
     else hipLaunchKernelGGL(k_rp_merge<false>, grid, block, 0, st, recs, rec_first, kept, hs, offsets, rt, win_off, wins, wrecs, wrec_first, ov, n_act, mcount, moff, out);
+    return hipGetLastError();
+}
+
+// ---- piece table: the text of a haystack between Replacer passes without rewriting it ------------------------------------
+// `replace` (Replacer.hs:163-180) rebuilds the whole text in every pass; on BASELINE config 5 that is ~160 passes over 64-KiB
+// haystacks that each change a dozen bytes per pass: 129 GiB written for 1 GiB of input.  Here the current text of an active
+// haystack is a list of pieces -- (source, logical start) pairs pointing into the caller's batch (never modified) or into the
+// replacement blob, closed by a sentinel carrying the total length.  A pass turns the list into the next one (k_pt_build: old
+// pieces with the kept matches cut out and the replacement spliced in, one thread per haystack: a few hundred 16-byte entries);
+// bytes move only twice: into the small windows that are re-scanned (k_pt_win_copy) and, once per haystack, into the result when
+// the haystack is finished (k_pt_materialise).  CaseSensitive replacers only: makeMatch of an IgnoreCase replacer walks the
+// text backwards (skipCodePointsBackwards), those keep the splicing path.
+constexpr uint64_t kPieceRepl = 1ull << 63;             // Piece::src: offset into the replacement blob instead of the batch text
+
+__global__ void __launch_bounds__(256) k_pt_init(const uint64_t* __restrict__ offsets, uint32_t n_act, RpPiece* __restrict__ pieces, uint64_t* __restrict__ pc_start,
+                                                 uint32_t* __restrict__ pc_cnt)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_act) return;
+    pieces[2ull * h] = RpPiece{offsets[h], 0};
+    pieces[2ull * h + 1] = RpPiece{0, offsets[h + 1] - offsets[h]};          // sentinel: logical end
+    pc_start[h] = 2ull * h; pc_cnt[h] = 1;
+}
+
+// upper bound of the next list's entries per haystack (the scan's input): old pieces + 2 per kept match + sentinel
+// (and the windows of the incremental re-scan per haystack, what k_rp_win_count computes: one launch for both)
+__global__ void __launch_bounds__(256) k_pt_count(const RpHay* __restrict__ hs, const uint32_t* __restrict__ pc_cnt, uint32_t n_act, uint32_t* __restrict__ need,
+                                                  uint32_t* __restrict__ nwin)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_act) return;
+    need[h] = (h < n_act && hs[h].status != kRpNothing) ? pc_cnt[h] + 2u * hs[h].nkept + 1u : 0u;
+    nwin[h] = (h < n_act && hs[h].status == kRpActive) ? hs[h].nkept : 0u;
+}
+
+// One wavefront per haystack.  Old piece i = old text [ls, le).  The kept matches (sorted, disjoint) cut it into fragments; a
+// fragment that starts at old position x lies, in the new text, at x + (sum of the length changes of the matches before it)
+// = K[j].dst + repl_len + (x - end of K[j]) for the last match j before x.  The replacement of match j is emitted by the piece
+// that contains its first byte.  Two sweeps over the pieces (count, then write) with a wave prefix sum between them.
+__global__ void __launch_bounds__(256) k_pt_build(RpTables t, const RpHay* __restrict__ hs, const uint64_t* __restrict__ rec_first, const RpKept* __restrict__ kept,
+                                                  const RpPiece* __restrict__ pieces, const uint64_t* __restrict__ pc_start, const uint32_t* __restrict__ pc_cnt,
+                                                  const uint64_t* __restrict__ need_off, RpRouted rt, uint32_t n_act,
+                                                  RpPiece* __restrict__ out, uint64_t* __restrict__ next_start, uint32_t* __restrict__ next_cnt,
+                                                  uint64_t* __restrict__ fin_start, uint32_t* __restrict__ fin_cnt)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (h >= n_act) return;
+    const RpHay s = hs[h];
+    if (s.status == kRpNothing) { if (lane == 0) { fin_start[rt.fin_idx[h]] = 0; fin_cnt[rt.fin_idx[h]] = 0; } return; }
+    const RpPiece* P = pieces + pc_start[h];
+    const uint32_t n = pc_cnt[h];                        // P[n] is the sentinel
+    const RpKept* K = kept + rec_first[h];
+    const uint32_t nk = s.nkept;
+    const RpPayload pp = t.payloads[s.payload];
+    const uint64_t repl_len = nk ? pp.repl_len : 0;
+    RpPiece* Q = out + need_off[h];
+    // what piece i contributes: the matches j in [ja, jb) are those that end after its start and start before its end
+    auto span = [&](uint64_t ls, uint64_t le, uint32_t& ja, uint32_t& jb) {
+        uint32_t a = 0, b = nk;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (K[mid].src_start + K[mid].src_len <= ls) a = mid + 1; else b = mid; }
+        ja = a; jb = a;
+        while (jb < nk && K[jb].src_start < le) jb++;
+    };
+    // walks piece i: f(kind, src, new_pos) for every entry it emits, in order
+    auto emit = [&](uint32_t i, auto&& f) {
+        const uint64_t ls = P[i].lstart, le = P[i + 1].lstart;
+        if (le == ls) return;
+        uint32_t ja, jb; span(ls, le, ja, jb);
+        uint64_t x = ls;                                  // old position where the next fragment would start
+        // new position of old position x when it is not inside a match: after the last match that ends at or before x
+        auto new_pos = [&](uint64_t xx, uint32_t jprev_plus1) -> uint64_t {
+            if (jprev_plus1 == 0) return xx;
+            const RpKept k = K[jprev_plus1 - 1];
+            return k.dst + repl_len + (xx - (k.src_start + k.src_len));
+        };
+        uint32_t jp = ja;                                 // matches [0, jp) end at or before x
+        for (uint32_t j = ja; j < jb; j++) {
+            const RpKept k = K[j];
+            if (k.src_start > x) f(P[i].src + (x - ls), new_pos(x, jp));                          // fragment before the match
+            if (k.src_start >= ls && repl_len) f(kPieceRepl | pp.repl_off, k.dst);                  // the match starts in this piece: its replacement
+            x = k.src_start + k.src_len;
+            jp = j + 1;
+            if (x >= le) break;
+        }
+        if (x < le) f(P[i].src + (x - ls), new_pos(x, jp));
+    };
+    // 64 pieces per round, lane = piece within the round: count, prefix over the lanes, write -- rounds follow each other in order
+    uint32_t base = 0;
+    for (uint32_t r0 = 0; r0 < n; r0 += kWave) {
+        const uint32_t i = r0 + lane;
+        uint32_t c = 0;
+        if (i < n) emit(i, [&](uint64_t, uint64_t) { c++; });
+        const uint32_t incl = (uint32_t)wave_inclusive_sum_i64((int64_t)c, lane);
+        uint32_t at = base + incl - c;
+        if (i < n) emit(i, [&](uint64_t src, uint64_t pos) { Q[at++] = RpPiece{src, pos}; });
+        base += __shfl(incl, kWave - 1, kWave);
+    }
+    if (lane == 0) {
+        Q[base] = RpPiece{0, s.newlen};                   // sentinel
+        if (s.status == kRpActive) { const uint64_t a = rt.act_idx[h]; next_start[a] = need_off[h]; next_cnt[a] = base; }
+        else { const uint64_t f = rt.fin_idx[h]; fin_start[f] = need_off[h]; fin_cnt[f] = base; }
+    }
+}
+
+// bytes [lo, lo + len) of a piece list into dst, one wavefront
+__device__ __forceinline__ void pt_gather(const RpPiece* __restrict__ P, uint32_t n, const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl,
+                                          uint64_t lo, uint64_t len, uint8_t* __restrict__ dst, int lane)
+{
+    if (len == 0) return;
+    uint32_t a = 0, b = n;                               // last piece whose start is <= lo
+    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (P[mid].lstart <= lo) a = mid; else b = mid; }
+    uint64_t pos = lo;
+    const uint64_t end = lo + len;
+    for (uint32_t i = a; pos < end; i++) {
+        const uint64_t pe = P[i + 1].lstart < end ? P[i + 1].lstart : end;
+        const uint64_t s = P[i].src;
+        const uint8_t* from = ((s & kPieceRepl) ? repl + (s & ~kPieceRepl) : text + s) + (pos - P[i].lstart);
+        uint8_t* to = dst + (pos - lo);
+        for (uint64_t x = lane; x < pe - pos; x += kWave) to[x] = from[x];
+        pos = pe;
+    }
+}
+
+// finished haystacks: their text, once (one workgroup per haystack; 16-byte copies where source and destination allow)
+__global__ void __launch_bounds__(256) k_pt_materialise(const RpPiece* __restrict__ pieces, const uint64_t* __restrict__ fin_start, const uint32_t* __restrict__ fin_cnt,
+                                                        const RpFin* __restrict__ fin, const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl,
+                                                        uint8_t* __restrict__ text_fin)
+{
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+    const uint32_t f = blockIdx.x;
+    const RpFin m = fin[f];
+    if (m.status == kRpNothing || m.len == 0) return;
+    const RpPiece* P = pieces + fin_start[f];
+    const uint32_t n = fin_cnt[f];
+    uint8_t* dst = text_fin + m.off;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (uint32_t i = wave; i < n; i += 256 / kWave) {           // a piece is a few hundred bytes: one wavefront each, four at a time
+        const uint64_t ls = P[i].lstart, len = P[i + 1].lstart - ls, s = P[i].src;
+        const uint8_t* from = (s & kPieceRepl) ? repl + (s & ~kPieceRepl) : text + s;
+        uint8_t* to = dst + ls;
+        const uint64_t n16 = len / 16;
+        for (uint64_t x = lane; x < n16; x += kWave) *reinterpret_cast<u32x4_u*>(to + 16 * x) = *reinterpret_cast<const u32x4_u*>(from + 16 * x);
+        for (uint64_t x = n16 * 16 + lane; x < len; x += kWave) to[x] = from[x];
+    }
+}
+
+// the whole next text of every active haystack (only when the windows of a pass would be larger than the text itself: tiny inputs)
+__global__ void __launch_bounds__(256) k_pt_materialise_next(const RpPiece* __restrict__ pieces, const uint64_t* __restrict__ next_start, const uint32_t* __restrict__ next_cnt,
+                                                             const uint64_t* __restrict__ next_offsets, uint32_t n_next, const uint8_t* __restrict__ text,
+                                                             const uint8_t* __restrict__ repl, uint8_t* __restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t a = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (a >= n_next) return;
+    pt_gather(pieces + next_start[a], next_cnt[a], text, repl, 0, next_offsets[a + 1] - next_offsets[a], out + next_offsets[a], lane);
+}
+
+hipError_t launch_pt_materialise_next(const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint64_t* next_offsets, uint32_t n_next,
+                                      const uint8_t* text, const uint8_t* repl, uint8_t* out, hipStream_t st)
+{
+    if (n_next == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pt_materialise_next, dim3((n_next + 3) / 4), dim3(256), 0, st, pieces, next_start, next_cnt, next_offsets, n_next, text, repl, out);
+    return hipGetLastError();
+}
+
+// the windows of the incremental re-scan, gathered from the NEXT pass's piece lists (RpWin::src_abs = next index << 40 | start)
+__global__ void __launch_bounds__(256) k_pt_win_copy(const RpWin* __restrict__ wins, const uint64_t* __restrict__ woffs, const RpPiece* __restrict__ pieces,
+                                                     const uint64_t* __restrict__ next_start, const uint32_t* __restrict__ next_cnt,
+                                                     const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl, uint8_t* __restrict__ wtext, uint64_t n_win,
+                                                     uint64_t total_w, uint64_t padded)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint64_t wi = (uint64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+    if (wi == n_win) { for (uint64_t x = total_w + lane; x < padded; x += kWave) wtext[x] = 0; return; }      // the zero tail the scan kernels expect
+    if (wi > n_win) return;
+    const RpWin w = wins[wi];
+    const uint64_t a = w.src_abs >> 40, lo = w.src_abs & ((1ull << 40) - 1ull);
+    pt_gather(pieces + next_start[a], next_cnt[a], text, repl, lo, w.len, wtext + woffs[wi], lane);
+}
+
+hipError_t launch_pt_init(const uint64_t* offsets, uint32_t n_act, RpPiece* pieces, uint64_t* pc_start, uint32_t* pc_cnt, hipStream_t st)
+{
+    if (n_act == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pt_init, dim3((n_act + 255) / 256), dim3(256), 0, st, offsets, n_act, pieces, pc_start, pc_cnt);
+    return hipGetLastError();
+}
+hipError_t launch_pt_count(const RpHay* hs, const uint32_t* pc_cnt, uint32_t n_act, uint32_t* need, uint32_t* nwin, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pt_count, dim3((n_act + 1 + 255) / 256), dim3(256), 0, st, hs, pc_cnt, n_act, need, nwin);
+    return hipGetLastError();
+}
+hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const RpPiece* pieces, const uint64_t* pc_start,
+                           const uint32_t* pc_cnt, const uint64_t* need_off, const RpRouted& rt, uint32_t n_act, RpPiece* out, uint64_t* next_start, uint32_t* next_cnt,
+                           uint64_t* fin_start, uint32_t* fin_cnt, hipStream_t st)
+{
+    if (n_act == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pt_build, dim3((n_act + 3) / 4), dim3(256), 0, st, t, hs, rec_first, kept, pieces, pc_start, pc_cnt, need_off, rt, n_act, out, next_start, next_cnt,
+                       fin_start, fin_cnt);
+    return hipGetLastError();
+}
+hipError_t launch_pt_materialise(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
+                                 const uint8_t* repl, uint8_t* text_fin, hipStream_t st)
+{
+    if (n_fin == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pt_materialise, dim3(n_fin), dim3(256), 0, st, pieces, fin_start, fin_cnt, fin, text, repl, text_fin);
+    return hipGetLastError();
+}
+hipError_t launch_pt_win_copy(const RpWin* wins, const uint64_t* woffs, const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint8_t* text,
+                              const uint8_t* repl, uint8_t* wtext, uint64_t n_win, uint64_t total_w, uint64_t padded, hipStream_t st)
+{
+    if (n_win == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_pt_win_copy, dim3((uint32_t)((n_win + 1 + 3) / 4)), dim3(256), 0, st, wins, woffs, pieces, next_start, next_cnt, text, repl, wtext, n_win, total_w, padded);
     return hipGetLastError();
 }
 
