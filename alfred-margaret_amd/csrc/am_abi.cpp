@@ -600,6 +600,7 @@ struct Plan {
     const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
     bool dense;          // automaton with the empty needle on the suffix-filter route: k_sf's records + the dense pass (am_dense.hip)
     AcView ac; SfView sf; BatchView bv;
+    uint32_t* next_unit; // k_sf's unit counter (in the batch's `small` block: [0..1] total_values, [4] block counter, [5] overflow, [8] this)
 };
 
 int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
@@ -619,6 +620,8 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     const bool no_edges = p.f->h.n_transitions == p.f->h.n_states;
     p.nothing = b->total == 0 || no_edges || (p.use_sf && p.f->h.sf_tiers == 0 && !p.dense);      // dense: first code points still report the root's values
     p.unit_chunks = p.use_sf ? sf_unit_chunks(p.bv, g_rt.dev[b->dev].n_cu) : 0;
+    p.next_unit = nullptr;
+    if (p.use_sf) { ON_DEVICE(b->dev); AM_TRY(b->small.ensure(64)); p.next_unit = (uint32_t*)b->small.p + 8; }
     p.n_cu = g_rt.dev[b->dev].n_cu;
     p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
     if (p.n_units >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "batch too large for one launch; split it");
@@ -627,7 +630,12 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
 
 int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st)
 {
-    if (p.use_sf) { Prof pr("sf", st); HIP_TRY(launch_sf(p.ic, mode, p.sf, p.bv, o, p.n_cu, st)); }
+    if (p.use_sf) {
+        ScanOut os = o;
+        os.next_unit = p.next_unit;
+        Prof pr("sf", st);
+        HIP_TRY(launch_sf(p.ic, mode, p.sf, p.bv, os, p.n_cu, st));
+    }
     else { Prof pr("ac", st); HIP_TRY(launch_ac(p.ic, mode, p.ac, p.bv, o, st)); }
     return AM_OK;
 }
@@ -963,6 +971,13 @@ extern "C" int am_debug_sf_phase_cycles(uint64_t* out5)
 {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(read_sf_phase_cycles(out5));
+    return AM_OK;
+}
+
+extern "C" int am_debug_sf_wave_records(uint64_t* out, size_t n_waves)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(read_sf_wave_records(out, n_waves));
     return AM_OK;
 }
 

@@ -28,6 +28,7 @@ struct ScanOut {
     uint32_t* unit_first;         // first block of each unit (kNone: none)
     uint32_t n_blocks;
     uint32_t unit_chunks;         // 1-KiB chunks per unit
+    uint32_t* next_unit;          // zeroed before the launch: wavefronts draw their second and later units from it (null: fixed stride)
     // all kernels
     uint64_t* hay_counts;         // count mode, may be null
     uint64_t* total_values;       // count mode
@@ -47,6 +48,7 @@ size_t sf_lds_bytes(const SfView& s);
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
 hipError_t read_sf_phase_cycles(uint64_t* out5);
+hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);
 hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st);
 

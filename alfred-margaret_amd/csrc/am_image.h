@@ -428,32 +428,44 @@ AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
 // SHORT = false promises that the automaton has no needle (variant) shorter than 4 bytes (s.tiers & 7 == 0): step 5 and the
 // three small tables drop out of the kernel.  Depths are 32-bit: a needle is far shorter than 4 GiB, and the bytes
 // available in the haystack only matter up to that.
-template <bool IC, int N, bool SHORT = true>
+// `between` runs after the cold-bucket loads have been issued and before they are used: the kernel computes avail64 there
+// (haystack index -> offsets: two dependent loads of its own), so that chain overlaps with haystack bytes -> cold bucket
+// instead of preceding it.  avail64 is not read before that.
+struct SfNoHook { AM_HD void operator()() const {} };
+template <bool IC, int N, bool SHORT = true, class Between = SfNoHook>
 AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail64)[N], const bool (&valid)[N],
-                        bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N])
+                        bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N], Between between = Between(), uint64_t* dbg_iters = nullptr, uint32_t dbg_ablate = 0)
 {
     uint32_t avail[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) avail[k] = avail64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)avail64[k];
     const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
     const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 2 x 16 B per edge
     uint32_t w[N], w2[N], node[N];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[9] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
     // ---- step 1: last 8 haystack bytes
 #pragma unroll
     for (int k = 0; k < N; k++) { w[k] = 0; w2[k] = 0; if (valid[k]) load_suffix8(text, gpos[k], w[k], w2[k]); }
 #pragma unroll
     for (int k = 0; k < N; k++) if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[2] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
     // ---- step 2: exact lookup of the 4-byte suffix on the cold side of the cuckoo table
     {
         u32x4 ca[N], cb[N];
         const uint32_t lb = s.tier_log2_cap[3];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const bool look = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
+            const bool look = valid[k] && (s.tiers & 8u);
             const uint32_t ba = look ? t4_bucket(t4_hash_a(w[k]), lb) : 0u, bb = look ? t4_bucket(t4_hash_b(w[k]), lb) : 0u;
             ca[k] = s.t4_cold[ba]; cb[k] = s.t4_cold[bb];              // {key0, key1, node0, node1}
             if (!look) { ca[k].z = ca[k].w = cb[k].z = cb[k].w = kNone; }
         }
+        between();
+#pragma unroll
+        for (int k = 0; k < N; k++) avail[k] = avail64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)avail64[k];
 #pragma unroll
         for (int k = 0; k < N; k++) {
             node[k] = kNone;
@@ -461,8 +473,13 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             if (ca[k].y == w[k] && ca[k].w != kNone) node[k] = ca[k].w;
             if (cb[k].x == w[k] && cb[k].z != kNone) node[k] = cb[k].z;
             if (cb[k].y == w[k] && cb[k].w != kNone) node[k] = cb[k].w;
+            if (avail[k] < 4) node[k] = kNone;                         // the 4-byte suffix does not fit into the haystack
         }
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[3] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
     // ---- step 3: speculative loads -- the depth-4 node, the record after it (the DFS renumbering puts
     // a single child right after its parent) and the 16 haystack bytes the first edge label would be
     // compared with.  A typical needle (<= 21 bytes) then resolves without further loads.
@@ -484,6 +501,10 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             if (IC) { t16[k][0] = fold_dword(t16[k][0]); t16[k][1] = fold_dword(t16[k][1]); t16[k][2] = fold_dword(t16[k][2]); t16[k][3] = fold_dword(t16[k][3]); }
         }
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[4] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
     // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
     uint32_t best_state[N], best_vlen[N], pre_node[N];
     uint32_t depth[N];
@@ -500,7 +521,13 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
         bool any = false;
 #pragma unroll
         for (int k = 0; k < N; k++) any = any || go[k];
-        if (!any) break;
+        if (!any || dbg_ablate == 11) break;
+        if (dbg_iters) {
+            dbg_iters[0]++;
+#if defined(__HIP_DEVICE_COMPILE__)
+            dbg_iters[1] += (uint64_t)__popcll(__ballot(go[0]));
+#endif
+        }
         // 4a: which edge?  (selector bytes are inline for nodes with <= 4 edges; the edge record itself
         //     is only needed for multi-edge nodes and is loaded for all N items together)
         uint32_t which[N], next[N], skip[N], label[N][4];
@@ -538,6 +565,10 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             }
             if (next[k] == kNone || (uint64_t)depth[k] + 1u + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
         }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[5] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
         // 4b: child record + the 16 bytes to compare with the label, for all N items together
         SfNode child[N];
         uint32_t t[N][4];
@@ -560,6 +591,10 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
 #pragma unroll
             for (int k = 0; k < N; k++) { if (from_mem[k]) node_from_raw(c0[k], c1[k], child[k]); else child[k] = nxt[k]; }
         }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[6] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
         // 4c: compare the label, advance
 #pragma unroll
         for (int k = 0; k < N; k++) {
@@ -587,6 +622,9 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
         found[k] = valid[k] && best_state[k] != 0;
         state[k] = best_state[k] - 1u; vlen[k] = best_vlen[k];
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(state[0]), "v"(vlen[0]) : "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[8] += now - dbg_iters[7]; dbg_iters[7] = now; }
+#endif
 }
 
 template <bool IC>

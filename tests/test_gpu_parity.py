@@ -367,6 +367,25 @@ def test_replacer_device_many_haystacks_many_passes():
         assert got == r.run_batch(hays, host_splice=True)
 
 
+@pytest.mark.parametrize("groups", ["2", "3", "7"])
+def test_replacer_concurrent_haystack_groups(monkeypatch, groups):
+    """Large batches run the pass loop on several host threads / streams over groups of haystacks (am_abi.cpp
+    replacer_run_groups; from 4096 haystacks by default, forced here on a small ragged batch): same texts, same
+    Nothing entries under a length limit, as the oracle's Replacer one haystack at a time (Replacer.hs:203-242)."""
+    rng = random.Random(int(groups) * 31)
+    alpha = "abcd "
+    pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(2, 4))), "".join(rng.choice("AB" + alpha) for _ in range(rng.randint(0, 6))))
+             for _ in range(40)]
+    hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 1, 7, 15, 16, 17, 100, 900, 4000)))) for _ in range(157)]
+    monkeypatch.setenv("AM_RP_GROUPS", groups)
+    for case in (0, 1):
+        r, o = am.Replacer(case, pairs), oracle.Replacer(case, pairs)
+        assert r.run_batch(hays) == [o.run(h) for h in hays]
+        limited = r.run_batch(hays, max_len=1000)
+        assert limited == [o.run(h, 1000) for h in hays]
+        assert any(x is None for x in limited) and any(x is not None for x in limited)
+
+
 def test_single_haystack_split_like_multi_gpu():
     """one big haystack cut into per-rank ranges with a one-match overlap; the union of the ranks'
     own records is the whole-haystack result (here the 'ranks' run one after the other on one GPU)."""

@@ -18,18 +18,40 @@ offs = torch.arange(n_hay + 1, dtype=torch.int64, device="cuda:0") * w["hay_byte
 lib = am.api.libam()
 b = C.c_void_p()
 am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(b)))
-out = (C.c_uint64 * 11)()
+out = (C.c_uint64 * 16)()
 for mode in ("count", "emit"):
     for rep in range(2):
+        torch.cuda.synchronize(); import time; t0 = time.perf_counter()
         if mode == "count":
             tot = C.c_uint64(0); am.api.check(lib.am_count_batch(a.device, w["case"], b, None, C.byref(tot)))
         else:
             m = C.c_void_p(); am.api.check(lib.am_run_batch(a.device, w["case"], b, C.byref(m))); lib.am_matches_free(m)
+        torch.cuda.synchronize(); call_ms = (time.perf_counter() - t0) * 1e3
+        recs = (C.c_uint64 * (2 * 4096))(); lib.am_debug_sf_wave_records(recs, 4096)
         lib.am_debug_sf_phase_cycles(out)
+        steps = (C.c_uint64 * 16)(); lib.am_debug_sf_wave_records(steps, 0)
+    print("   resolve steps, cycles per batch: bytes %.0f, cold bucket + haystack %.0f, nodes %.0f, loop: edge choice %.0f, child + label bytes %.0f, rest of the function %.0f, before the function %.0f" % tuple(steps[i] / max(out[6], 1) for i in (2, 3, 4, 5, 6, 7, 8 - 0)))
+    print("   whole call (host clock) %.3f ms" % call_ms)
+    import numpy as np
+    r = np.frombuffer(recs, dtype=np.uint64).reshape(-1, 2)
+    dur = r[:, 0].astype(np.float64); xcc = (r[:, 1] >> np.uint64(32)).astype(np.int64) & 15; hw = (r[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    print("   wave durations: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (dur.min(), np.percentile(dur, 10), np.median(dur), np.percentile(dur, 90), dur.max()))
+    for x in sorted(set(xcc)):
+        d = dur[xcc == x]
+        print("     xcc %d: waves %d  mean %.0f  min %.0f  max %.0f" % (x, len(d), d.mean(), d.min(), d.max()))
+    wg = dur.reshape(-1, 16)
+    print("   per workgroup: spread inside a workgroup (max/min) mean %.2f; workgroup means min %.0f max %.0f" % ((wg.max(1) / wg.min(1)).mean(), wg.mean(1).min(), wg.mean(1).max()))
+    simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; se = (hw >> 13) & 7   # gfx9 HW_ID: wave_id 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13
+    for sd in range(4):
+        d = dur[simd == sd]
+        if len(d): print("     simd %d: waves %d mean %.0f" % (sd, len(d), d.mean()))
     waves = max(out[4], 1)
     chunks = n_bytes / 1024 / waves
     tot_c = sum(out[i] for i in range(4))
     nbat = max(out[6], 1)
-    print("   resolve batches/wave %.1f, cycles per batch: pre %.0f lookup %.0f preload %.0f walk %.0f" % (out[6] / waves, out[7] / nbat, out[8] / nbat, out[9] / nbat, out[10] / nbat))
-    print("%s %s: waves %d, chunks/wave %.0f, cycles/chunk: filter %.0f compact %.0f probe-setup %.0f probe-mem %.0f resolve %.0f  total %.0f" % (
-        wl, mode, waves, chunks, out[0] / waves / chunks, out[1] / waves / chunks, out[5] / waves / chunks, out[2] / waves / chunks, out[3] / waves / chunks, (tot_c + out[5]) / waves / chunks))
+    nch = n_bytes / 1024
+    print("   slowest wave: %.0f cycles = %.0f per chunk (the averages below are over all waves)" % (out[15], out[15] / (n_bytes / 1024 / max(out[4], 1))))
+    print("   per chunk: candidates %.2f, probe batches %.3f, deferred %.2f, resolve batches %.3f, found %.3f" % (out[11] / nch, out[12] / nch, out[13] / nch, out[6] / nch, out[14] / nch))
+    print("   resolve batches/wave %.1f, cycles per batch: pre %.0f walk %.0f; walk-loop iterations per batch %.2f, active lanes per iteration %.1f" % (out[6] / waves, out[7] / nbat, out[10] / nbat, out[8] / nbat, out[9] / max(out[8], 1)))
+    print("%s %s: waves %d, chunks/wave %.0f, cycles/chunk: filter %.0f compact %.0f probe-setup %.0f probe-mem %.0f resolve %.0f  load-wait %.0f total %.0f" % (
+        wl, mode, waves, chunks, out[0] / waves / chunks, out[1] / waves / chunks, out[5] / waves / chunks, out[2] / waves / chunks, out[3] / waves / chunks, out[9] / waves / chunks, (tot_c + out[5] + out[9]) / waves / chunks))
