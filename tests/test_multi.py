@@ -141,34 +141,60 @@ def test_calls_from_two_threads_overlap():
     am.api.check(lib.am_batch_from_device(dev_text.data_ptr(), offs.data_ptr(), n_cells // hay_cells, n_bytes, C.byref(batch)))
     stamps = {}
 
+    attempts, errors = 3, []
+
+    def judge():                                                    # once per attempt, when both threads have finished it
+        stamps["inside"] = sum(1 for t in stamps["b_done"] if stamps["a0"] < t < stamps["a1"])     # B's calls that completed while A's call was running
+        stamps["a_ms"] = (stamps["a1"] - stamps["a0"]) * 1e3
+
+    start, end = threading.Barrier(2), threading.Barrier(2, action=judge)
+
+    def guarded(body):
+        def run():
+            try:
+                body()
+            except BaseException as e:                              # noqa: BLE001 -- reported by the main thread
+                errors.append(e)
+                start.abort(); end.abort()
+        return run
+
     def thread_a():
         total = C.c_uint64(0)
-        stamps["a0"] = time.perf_counter()
-        am.api.check(lib.am_count_batch(big.device, 0, batch, None, C.byref(total)))
-        stamps["a1"] = time.perf_counter()
-        stamps["a_total"] = int(total.value)
+        am.api.check(lib.am_count_batch(big.device, 0, batch, None, C.byref(total)))     # warm-up ON THIS THREAD: its stream and workspaces exist afterwards
+        for _ in range(attempts):
+            start.wait(120)
+            stamps["a0"] = time.perf_counter()
+            am.api.check(lib.am_count_batch(big.device, 0, batch, None, C.byref(total)))
+            stamps["a1"] = time.perf_counter()
+            stamps["a_total"] = int(total.value)
+            end.wait(120)
+            if stamps["inside"] >= 5:
+                break
 
     def thread_b():
         s = am.api._Slices([text])
         c = np.zeros(1, np.uint64)
-        time.sleep(0.004)                                       # let A's kernel get going
-        done = []
-        for _ in range(20):
+        for _ in range(3):                                          # warm-up on this thread: a first call allocates, and hipMalloc may wait for running kernels
             am.api.check(lib.am_count(small.device, 0, s.arr, 1, c.ctypes.data))
-            assert int(c[0]) == exp
-            done.append(time.perf_counter())
-        stamps["b_done"] = done
+        for _ in range(attempts):
+            start.wait(120)
+            time.sleep(0.004)                                       # let A's kernel get going
+            done = []
+            for _ in range(20):
+                am.api.check(lib.am_count(small.device, 0, s.arr, 1, c.ctypes.data))
+                assert int(c[0]) == exp
+                done.append(time.perf_counter())
+            stamps["b_done"] = done
+            end.wait(120)
+            if stamps["inside"] >= 5:
+                break
 
     try:
-        thread_a(); thread_b()                                  # warm-up: images uploaded, workspaces and streams made
-        for attempt in range(3):
-            ts = [threading.Thread(target=thread_a), threading.Thread(target=thread_b)]
-            for t in ts: t.start()
-            for t in ts: t.join()
-            a_ms = (stamps["a1"] - stamps["a0"]) * 1e3
-            inside = sum(1 for t in stamps["b_done"] if stamps["a0"] < t < stamps["a1"])     # B's calls that completed while A's call was running
-            if inside >= 5:
-                break
+        ts = [threading.Thread(target=guarded(thread_a)), threading.Thread(target=guarded(thread_b))]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        assert not errors, errors
+        inside, a_ms = stamps["inside"], stamps["a_ms"]
         assert stamps["a_total"] > n_cells * 0.9
         assert inside >= 5, ("B's calls did not complete while A's call was running", inside, a_ms)
     finally:
