@@ -85,8 +85,9 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
-constexpr int kSfQ1 = 512;                       // per-wave ring of candidate positions (u16: chunk-in-unit << 10 | offset) that passed the filter
-constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (same encoding): candidates that need the exact lookup + trie walk
+constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
+constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 10 | offset): candidates that need the exact lookup + trie walk
+constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
 constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table: first thing in LDS, the filter words follow
 
 // LDS by absolute byte address.  k_sf declares no static LDS, so its dynamic LDS starts at address 0; reading through an
@@ -112,10 +113,8 @@ __device__ __forceinline__ void lds_write_u32x4(uint32_t byte_addr, uint4 v) { u
 // its units hit, its neighbours on the SIMD) finished 1.2x after the average one, and the launch lasts as long as the slowest.
 // Structure of one wavefront's loop (everything between two filter steps is wave-synchronous):
 //   filter   16 positions per lane against the LDS Bloom filter                      (LDS + VALU only)
-//   probe    surviving positions wait in a ring ACROSS chunks until 64 (*ILP) of them are there (a chunk of the
-//            benchmark text leaves ~20: probing per chunk ran the whole probe sequence, and its dependent-load chain,
-//            with a quarter of the lanes): last 8 haystack bytes (an L2 hit: the wave streamed them a moment ago) +
-//            both cuckoo slots; no data-dependent loop                                (phase 1)
+//   probe    surviving positions, 64*ILP at a time: last 8 haystack bytes + both cuckoo slots; no
+//            data-dependent loop, so every lane runs the same three loads            (phase 1)
 //   resolve  the few candidates that hit the suffix table AND continue in the trie (or end a needle)
 //            are parked in a ring and walked 64 at a time, across chunk boundaries   (phase 2)
 // Phase 2 is FIFO, so the records of a unit come out in position order: ballot + popcount rank them,
@@ -132,21 +131,25 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
     uint32_t* bloom = lds + kBloomMasks;                              // LDS bytes [kSfMaskBytes, kSfMaskBytes + 4 * words)
+    uint8_t* stage_all = reinterpret_cast<uint8_t*>(bloom + words);
+    uint16_t* q1_all = reinterpret_cast<uint16_t*>(stage_all + kSfWaves * kSfStage);
+    uint16_t* q2_all = q1_all + kSfWaves * kSfQ1;
 
     for (uint32_t i = threadIdx.x; i < kBloomMasks; i += kSfThreads) masks[i] = bloom_mask_entry(i);
     for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: unit / chunk arithmetic stays scalar
-    // this wave's queues, as absolute LDS byte addresses (32-bit, uniform): no 64-bit pointer per structure
-    const uint32_t q1 = kSfMaskBytes + 4u * words + wave * (uint32_t)(kSfQ1 * 2);
-    const uint32_t q2 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * (kSfQ1 * 2) + wave * (uint32_t)(kSfQ2 * 2);
+    // this wave's staging area and queues, as absolute LDS byte addresses (32-bit, uniform): no 64-bit pointer per structure
+    const uint32_t stage = kSfMaskBytes + 4u * words + wave * (uint32_t)kSfStage;
+    const uint32_t q1 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * kSfStage + wave * (uint32_t)(kSfQ1 * 2);
+    const uint32_t q2 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * (kSfStage + kSfQ1 * 2) + wave * (uint32_t)(kSfQ2 * 2);
+    (void)stage_all; (void)q1_all; (void)q2_all;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
     const uint32_t UC = o.unit_chunks;
     const uint64_t n_units = (n_chunks + UC - 1) / UC;
     uint64_t nval = 0;
-    uint32_t q1_head = 0, q1_tail = 0;                   // monotonic; slot = index % kSfQ1
     uint32_t q2_head = 0, q2_tail = 0;                   // monotonic; slot = index % kSfQ2
     // emit mode: state of the unit being written
     uint64_t unit_base_chunk = 0;
@@ -157,7 +160,6 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     const bool timing = DBG && o.dbg != nullptr;
     const uint32_t ablate = DBG ? o.ablate : 0u;
     uint64_t t_filter = 0, t_compact = 0, t_probe = 0, t_resolve = 0, t_probe_pre = 0, t_mark = 0;
-    uint64_t dbg_iters[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_r0 = 0, t_r1 = 0, t_r2 = 0, t_r3 = 0, n_batches = 0, n_cand = 0, n_probes = 0, n_defer = 0, n_found = 0;
     auto tick = [&](uint64_t& acc) { if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc += now - t_mark; t_mark = now; } };
 
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         uint64_t gpos[RN], end_pos[RN];
         uint32_t hay[RN], state[RN], vlen[RN], hlo[RN], hhi[RN];
         bool valid[RN], found[RN];
-        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; dbg_iters[7] = now; }
+        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
             valid[k] = 64u * k + lane < nb;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             }
         };
         for (int k = 0; k < RN; k++) end_pos[k] = 0;
-        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, found, state, vlen, locate, timing ? dbg_iters : nullptr, ablate);
+        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, found, state, vlen, locate);
         if (timing) { asm volatile("" :: "v"((uint32_t)found[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; n_batches++; }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
@@ -246,46 +248,6 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         q2_head += nb;
     };
 
-    // ---- phase 1: probe the oldest `nb` (<= 64 * W) candidates of the ring, W per lane with their loads in flight together.
-    // The window and the two bytes before it come from memory (the wave loaded that line a few chunks ago).  Whether the window
-    // lies inside one haystack is not looked at: phase 2 is exact, a candidate next to a haystack border is merely deferred.
-    auto probe_batch = [&](uint32_t nb, auto width_tag) {
-        constexpr int W = decltype(width_tag)::value;
-        if (ablate == 5) { q1_head += nb; return; }                      // timing experiment only: filter + compaction, no probe
-        uint64_t avail[W];
-        uint32_t item[W], w[W], nbs[W];
-        bool valid[W], defer[W];
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            valid[k] = 64u * k + lane < nb;
-            item[k] = valid[k] ? lds_read_u16(q1 + 2u * ((q1_head + 64u * k + lane) % kSfQ1)) : 0u;
-            w[k] = 0; nbs[k] = 0; avail[k] = 4;
-        }
-        uint32_t w2[W];
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            w2[k] = 0;
-            if (valid[k]) load_suffix8(b.text, (unit_base_chunk + (item[k] >> 10)) * kSfChunk + (item[k] & 1023u), w[k], w2[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
-            nbs[k] = (w2[k] >> 24) | ((w2[k] >> 8) & 0xFF00u);               // the two bytes before the window, nearest in bits 0-7
-        }
-        if (timing) { asm volatile("" :: "v"(w[0])); tick(t_probe_pre); }
-        sf_probe_n<W>(s, w, nbs, avail, valid, defer, ablate);
-        if (ablate == 4) { for (int k = 0; k < W; k++) defer[k] = false; }      // timing experiment only: no resolve
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            const uint64_t m = __ballot(defer[k]);
-            if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), item[k]);
-            q2_tail += (uint32_t)__popcll(m);
-            if (timing) n_defer += (uint32_t)__popcll(m);
-        }
-        if (timing) n_probes++;
-        q1_head += nb;
-    };
-
     // software pipeline: the next chunk's 16 B per lane are requested before the current chunk is filtered and probed,
     // so HBM latency hides behind that work.  The bytes BEFORE a lane's 16 (its windows reach 3 bytes back, the probe
     // 5) come from the lane below with one DPP move; lane 0 takes them from `carry` = the last 8 (folded) bytes of the
@@ -296,24 +258,25 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         if (cc < n_chunks && p < b.total) {
             typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
             const u32x4_native* src = reinterpret_cast<const u32x4_native*>(b.text + p);
-            const u32x4_native t = *src;                                            // global_load_dwordx4
+            const u32x4_native t = *src;                                            // global_load_dwordx4 (a non-temporal load changes neither the time nor the L2 miss count: measured)
             v = make_uint4(t.x, t.y, t.z, t.w);
         }
     };
-    auto fetch_before = [&](uint64_t cc, uint32_t& c4) {          // uniform: one request for the wave
-        uint32_t t = 0;
+    auto fetch_before = [&](uint64_t cc, uint32_t& c3, uint32_t& c4) {          // uniform: one request for the wave
+        uint2 t = make_uint2(0, 0);
         if (cc < n_chunks && cc > 0) {
-            t = *reinterpret_cast<const uint32_t*>(b.text + cc * kSfChunk - 4);
-            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);   // waited for here, not at the join
+            t = *reinterpret_cast<const uint2*>(b.text + cc * kSfChunk - 8);
+            t.x = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x); t.y = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y);   // waited for here, not at the join
         }
-        c4 = IC ? fold_dword(t) : t;
+        c3 = IC ? fold_dword(t.x) : t.x; c4 = IC ? fold_dword(t.y) : t.y;
     };
     const uint64_t t_begin = timing ? __builtin_amdgcn_s_memtime() : 0;
     if (timing) t_mark = t_begin;
     uint64_t u = (uint64_t)blockIdx.x * kSfWaves + wave;
-    uint4 cur_v; uint32_t carry4;
+    uint64_t hs0 = 1, he0 = 0; uint32_t hay0 = 0;       // cached haystack bracket [hs0, he0) of haystack hay0: empty until the first lookup
+    uint4 cur_v; uint32_t carry3, carry4;
     fetch(u * UC, cur_v);
-    fetch_before(u * UC, carry4);
+    fetch_before(u * UC, carry3, carry4);
     // the first chunk's data is waited for HERE: if it were still pending at the loop header, the compiler's (static) wait at
     // the top of the loop body would also cover the prefetch of the next chunk that every iteration issues first
     asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));
@@ -333,22 +296,36 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
             uint4 next_v = make_uint4(0, 0, 0, 0);
-            uint32_t next_c4 = 0;
+            uint32_t next_c3 = 0, next_c4 = 0;
             const bool last_of_unit = ci + 1 >= n_in_unit;
-            if (DBG && ablate == 10) {                     // timing experiment only: no prefetch, the chunk is loaded (and waited for) right here
-                fetch(c, cur_v);
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));
-                if (timing) tick(t_r2);
-            } else fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
-            if (last_of_unit) fetch_before(u_next * UC, next_c4);
+            fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
+            if (last_of_unit) fetch_before(u_next * UC, next_c3, next_c4);
 
-            const uint64_t p0 = c * kSfChunk + lane * 16u;
+            const uint64_t c0 = c * kSfChunk;
+            const uint64_t p0 = c0 + lane * 16u;
+            // the haystack that contains the chunk's first byte is looked up only when the chunk leaves
+            // the one found last time (same address in every lane: one request per load); almost every
+            // chunk lies inside one haystack, then no candidate needs its own lookup either.
+            // (The bracket goes through readfirstlane so that its loads are waited for INSIDE this rarely taken branch: a load
+            // left pending at the join would make the compiler wait with vmcnt(0) on every chunk -- and vmcnt counts in order,
+            // so that wait would also cover the prefetch issued just above and expose a full HBM latency per chunk.)
+            if (c0 >= he0 || c0 < hs0) {
+                hay0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)find_haystack(b, c0));
+                hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]);
+            }
+            const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
+
             uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
             if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
             // the 4 bytes before the lane's 16: the lane below's last dword (wave_shr:1; lane 0 keeps `old` = the carry)
             const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);
             const uint32_t d[5] = {d0, d1, d2, d3, d4};
-            if (!last_of_unit) next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);      // the next chunk follows this one: its carry is this chunk's tail
+            lds_write_u32x4(stage + 16u + lane * 16u, make_uint4(d1, d2, d3, d4));
+            if (lane == 0) lds_write_u32x2(stage + 8u, make_uint2(carry3, carry4));
+            if (!last_of_unit) {                                  // the next chunk follows this one: its carry is this chunk's tail
+                next_c3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63);
+                next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
+            }
             uint32_t cand = 0;
             {
                 // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 32 LDS reads (filter word + mask per
@@ -383,46 +360,77 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (timing) { asm volatile("" :: "v"(cand)); tick(t_filter); }
 
             for (;;) {
-                // append the candidate positions to the wave's ring, in position order (as many as fit)
+                // compact (up to kSfQ1) candidate positions into the wave's LDS queue, in position order
                 const uint32_t n = __popc(cand);
                 const uint32_t incl = wave_inclusive_sum(n, lane);
                 const uint32_t total = __shfl(incl, 63, 64);
                 if (total == 0) break;
-                const uint32_t room = (uint32_t)kSfQ1 - (q1_tail - q1_head);      // > kSfQ1 - 64 ILP: the ring is probed down below one batch after every append
                 uint32_t idx = incl - n;
                 // the loop runs as long as the busiest lane has candidates, so it only queues positions; the probe
-                // (dense, one candidate per lane) fetches the window and the two bytes before it
-                while (cand && idx < room) {
+                // (dense, one candidate per lane) picks the window and the two bytes before it out of the staged chunk
+                while (cand && idx < (uint32_t)kSfQ1) {
                     const uint32_t k = __builtin_ctz(cand);
                     cand &= cand - 1u;
-                    lds_write_u16(q1 + 2u * ((q1_tail + idx++) % kSfQ1), (ci << 10) | (lane * 16u + k));
+                    lds_write_u16(q1 + 2u * idx++, lane * 16u + k);
                 }
-                q1_tail += total < room ? total : room;
-                if (timing) n_cand += total < room ? total : room;
+                const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;
+                if (timing) n_cand += n_q1;
                 wave_lds_fence();
                 tick(t_compact);
-                while (q1_tail - q1_head >= 64u * ILP) {          // a full batch: ILP candidates per lane, their loads in flight together
-                    probe_batch(64u * ILP, std::integral_constant<int, ILP>());
+
+                // one probe round: up to 64 * W survivors, W per lane with their loads in flight together.
+                // The common case (<= 64 survivors left) takes the 1-wide instance: half the instructions.
+                auto probe_round = [&](uint32_t base, auto width_tag) {
+                    constexpr int W = decltype(width_tag)::value;
+                    if (ablate == 5) return;                      // timing experiment only: filter + compaction, no probe
+                    uint64_t avail[W];
+                    uint32_t pos[W], w[W], nb[W];
+                    bool valid[W], defer[W];
+#pragma unroll
+                    for (int k = 0; k < W; k++) {
+                        const uint32_t e = base + 64u * k + lane;
+                        valid[k] = e < n_q1;
+                        pos[k] = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
+                        // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on
+                        // top), nb = the two before it, nearest in bits 0-7
+                        const uint32_t a = 11u + pos[k], sh = a & 3u;
+                        const uint32_t sp = stage + (a & ~3u);
+                        const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
+                        const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
+                        nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
+                        w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
+                        const uint64_t gpos = c0 + pos[k];
+                        avail[k] = gpos - hs0 + 1;
+                        if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
+                    }
+                    if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
+                    sf_probe_n<W>(s, w, nb, avail, valid, defer, ablate);
+                    if (ablate == 4) { for (int k = 0; k < W; k++) defer[k] = false; }      // timing experiment only: no resolve
+#pragma unroll
+                    for (int k = 0; k < W; k++) {
+                        const uint64_t m = __ballot(defer[k]);
+                        if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (ci << 10) | pos[k]);
+                        q2_tail += (uint32_t)__popcll(m);
+                        if (timing) n_defer += (uint32_t)__popcll(m);
+                    }
+                    if (timing) n_probes++;
+                };
+                for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
+                    if (ILP == 1 || n_q1 - base <= 64u) probe_round(base, std::integral_constant<int, 1>());
+                    else probe_round(base, std::integral_constant<int, ILP>());
                     wave_lds_fence();
                     tick(t_probe);
                     while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }   // keeps room for the next round
                     tick(t_resolve);
                 }
-                if (total <= room) break;
+                if (total <= (uint32_t)kSfQ1) break;
+                wave_lds_fence();
             }
-            cur_v = next_v; carry4 = next_c4;
+            cur_v = next_v; carry3 = next_c3; carry4 = next_c4;
         }
         // end of unit: drain the ring so that every item of a batch belongs to one unit
         wave_lds_fence();
         tick(t_compact);
-        while (q1_tail != q1_head) {
-            const uint32_t nb = q1_tail - q1_head;
-            if (nb > 64u) probe_batch(nb < 64u * ILP ? nb : 64u * ILP, std::integral_constant<int, ILP>());
-            else probe_batch(nb, std::integral_constant<int, 1>());
-            wave_lds_fence();
-            while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }
-        }
-        tick(t_probe);
         while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u * RN ? nb : 64u * RN); }
         tick(t_resolve);
         if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; }
@@ -436,23 +444,22 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 5), (unsigned long long)t_probe_pre);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 6), (unsigned long long)n_batches);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 7), (unsigned long long)t_r0);
-        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 8), (unsigned long long)dbg_iters[0]);
-        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 9), (unsigned long long)(ablate == 10 ? t_r2 : dbg_iters[1]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 8), (unsigned long long)t_r1);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 9), (unsigned long long)t_r2);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 10), (unsigned long long)t_r3);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 11), (unsigned long long)n_cand);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 12), (unsigned long long)n_probes);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 13), (unsigned long long)n_defer);
+        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 14), (unsigned long long)n_found);
         atomicMax(reinterpret_cast<unsigned long long*>(o.dbg + 15), (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
         const uint64_t gw = (uint64_t)blockIdx.x * kSfWaves + wave;
-        if (gw < 8192) {
+        if (gw < 8192) {                                   // per wavefront: duration and where it ran
             uint32_t hw_id, xcc_id;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
             o.dbg[16 + 2 * gw] = __builtin_amdgcn_s_memtime() - t_begin;
             o.dbg[17 + 2 * gw] = ((uint64_t)xcc_id << 32) | hw_id;
         }
-        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 11), (unsigned long long)n_cand);
-        for (int i = 2; i < 10; i++) if (i != 7) atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 8192 * 2 + 16 + (i < 7 ? i : i - 1)), (unsigned long long)dbg_iters[i]);
-        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 12), (unsigned long long)n_probes);
-        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 13), (unsigned long long)n_defer);
-        atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 14), (unsigned long long)n_found);
     }
 
     if (MODE == kModeCount) {
@@ -551,7 +558,7 @@ hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record
 }
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
-size_t sf_lds_bytes(const SfView& s) { return kSfMaskBytes + ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
+size_t sf_lds_bytes(const SfView& s) { return kSfMaskBytes + ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
 
 template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
@@ -583,7 +590,6 @@ static uint64_t* g_sf_dbg = nullptr;
 hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves)
 {
     if (!g_sf_dbg) return hipErrorInvalidValue;
-    if (n_waves == 0) { hipError_t e = hipMemcpy(out, g_sf_dbg + 16 + 2 * 8192, 128, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemset(g_sf_dbg + 16 + 2 * 8192, 0, 128); return e; }
     return hipMemcpy(out, g_sf_dbg + 16, 16 * (n_waves < 8192 ? n_waves : 8192), hipMemcpyDeviceToHost);
 }
 
@@ -601,13 +607,13 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
 {
     const bool lw15 = s.bloom_log2_words == 15;
     if ((o.ablate || o.dbg) && MODE != kModeAny) {                                          // experiments (AM_SF_ABLATE)
-        if (!lw15) return launch_sf_v<IC, MODE, 3, 0, true, true>(s, b, o, n_cu, st);
-        return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 3, 15, true, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 3, 15, false, true>(s, b, o, n_cu, st);
+        if (!lw15) return launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
+        return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, true, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st);
     }
     if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
-        return lw15 ? launch_sf_v<IC, MODE, 3, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 3, 0, true>(s, b, o, n_cu, st);
+        return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
-    return lw15 ? launch_sf_v<IC, MODE, 3, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 3, 0, false>(s, b, o, n_cu, st);
+    return lw15 ? launch_sf_v<IC, MODE, 2, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
 }
 
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o_in, int n_cu, hipStream_t st)
@@ -617,7 +623,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     o.ablate = ablate;
     static uint64_t* dbg = nullptr;
     if (ablate >= 8) {
-        if (!dbg) { if (hipMalloc((void**)&dbg, 256 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 256 + 16 * 8192); }
+        if (!dbg) { if (hipMalloc((void**)&dbg, 128 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 128 + 16 * 8192); }
         o.dbg = dbg;
         g_sf_dbg = dbg;
     }

@@ -29,8 +29,6 @@ for mode in ("count", "emit"):
         torch.cuda.synchronize(); call_ms = (time.perf_counter() - t0) * 1e3
         recs = (C.c_uint64 * (2 * 4096))(); lib.am_debug_sf_wave_records(recs, 4096)
         lib.am_debug_sf_phase_cycles(out)
-        steps = (C.c_uint64 * 16)(); lib.am_debug_sf_wave_records(steps, 0)
-    print("   resolve steps, cycles per batch: bytes %.0f, cold bucket + haystack %.0f, nodes %.0f, loop: edge choice %.0f, child + label bytes %.0f, rest of the function %.0f, before the function %.0f" % tuple(steps[i] / max(out[6], 1) for i in (2, 3, 4, 5, 6, 7, 8 - 0)))
     print("   whole call (host clock) %.3f ms" % call_ms)
     import numpy as np
     r = np.frombuffer(recs, dtype=np.uint64).reshape(-1, 2)
@@ -52,6 +50,6 @@ for mode in ("count", "emit"):
     nch = n_bytes / 1024
     print("   slowest wave: %.0f cycles = %.0f per chunk (the averages below are over all waves)" % (out[15], out[15] / (n_bytes / 1024 / max(out[4], 1))))
     print("   per chunk: candidates %.2f, probe batches %.3f, deferred %.2f, resolve batches %.3f, found %.3f" % (out[11] / nch, out[12] / nch, out[13] / nch, out[6] / nch, out[14] / nch))
-    print("   resolve batches/wave %.1f, cycles per batch: pre %.0f walk %.0f; walk-loop iterations per batch %.2f, active lanes per iteration %.1f" % (out[6] / waves, out[7] / nbat, out[10] / nbat, out[8] / nbat, out[9] / max(out[8], 1)))
-    print("%s %s: waves %d, chunks/wave %.0f, cycles/chunk: filter %.0f compact %.0f probe-setup %.0f probe-mem %.0f resolve %.0f  load-wait %.0f total %.0f" % (
-        wl, mode, waves, chunks, out[0] / waves / chunks, out[1] / waves / chunks, out[5] / waves / chunks, out[2] / waves / chunks, out[3] / waves / chunks, out[9] / waves / chunks, (tot_c + out[5] + out[9]) / waves / chunks))
+    print("   resolve batches/wave %.1f, cycles per batch: before the lookup %.0f, lookup + walk %.0f" % (out[6] / waves, out[7] / nbat, (out[8] + out[10]) / nbat))
+    print("%s %s: waves %d, chunks/wave %.0f, cycles/chunk: filter %.0f compact %.0f probe-setup %.0f probe-mem %.0f resolve %.0f  total %.0f" % (
+        wl, mode, waves, chunks, out[0] / waves / chunks, out[1] / waves / chunks, out[5] / waves / chunks, out[2] / waves / chunks, (out[3] + out[7] + out[8] + out[10]) / waves / chunks, (tot_c + out[5] + out[7] + out[8] + out[10]) / waves / chunks))
