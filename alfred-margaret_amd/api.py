@@ -66,6 +66,9 @@ ABI = {
     "am_replacer_destroy": (None, [_vp]),
     "am_replacer_run": (C.c_int, [_vp, C.POINTER(Slice), _sz, C.c_uint64, C.POINTER(_vp)]),
     "am_replacer_run_batch": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "am_replacer_run_batch_device": (C.c_int, [_vp, _vp, C.c_uint64, C.POINTER(_vp)]),
+    "am_replaced_device": (C.c_int, [_vp]),
+    "am_replaced_read": (C.c_int, [_vp, _sz, _vp, _sz, C.POINTER(_sz)]),
     "am_run_priority": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp, _vp, C.POINTER(_vp), C.POINTER(_sz)]),
     "am_prio_matches_free": (None, [_vp]),
     "am_replaced_size": (C.c_uint64, [_vp]),
@@ -94,6 +97,7 @@ ABI = {
     "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
     "am_unlower_code_point": (_sz, [C.c_uint32, _vp, _sz]),
     "am_set_stream": (C.c_int, [_vp]),
+    "am_get_stream": (C.c_int, [C.POINTER(_vp)]),
     "am_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_sz), C.c_char_p, _sz]),
     "am_profile_enable": (C.c_int, [C.c_int]),
     "am_profile_reset": (C.c_int, []),

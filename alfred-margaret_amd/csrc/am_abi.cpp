@@ -956,6 +956,18 @@ extern "C" int am_set_stream(void* hip_stream)
     return AM_OK;
 }
 
+extern "C" int am_get_stream(void** hip_stream)
+{
+    if (!hip_stream) return fail(AM_ERR_INVALID, "hip_stream is null");
+    AM_TRY(ensure_runtime());
+    int dev = 0;
+    AM_TRY(current_device(&dev));
+    ON_DEVICE(dev);
+    hipStream_t st; AM_TRY(get_stream(dev, &st));
+    *hip_stream = (void*)st;
+    return AM_OK;
+}
+
 extern "C" int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap)
 {
     int dev = 0;
@@ -1040,6 +1052,7 @@ struct Slab { uint8_t* p = nullptr; size_t cap = 0, used = 0; };
 struct SlabPool {
     std::mutex mu;
     std::vector<Slab> free_list;
+    bool device = false;           // slabs in the current device's HBM (results that stay on the device) instead of pinned host memory
     static constexpr size_t kSlab = 256ull << 20, kKeep = 8;
     int take(size_t need, Slab* out)
     {
@@ -1049,7 +1062,8 @@ struct SlabPool {
                 if (free_list[i].cap >= need) { *out = free_list[i]; out->used = 0; free_list.erase(free_list.begin() + i); return AM_OK; }
         }
         Slab s; s.cap = need > kSlab ? need : kSlab;
-        if (hipHostMalloc((void**)&s.p, s.cap, hipHostMallocPortable) != hipSuccess) return fail(AM_ERR_OOM, "hipHostMalloc(result slab) failed");
+        if (device) { if (hipMalloc((void**)&s.p, s.cap) != hipSuccess) return fail(AM_ERR_OOM, "hipMalloc(result slab) failed"); }
+        else if (hipHostMalloc((void**)&s.p, s.cap, hipHostMallocPortable) != hipSuccess) return fail(AM_ERR_OOM, "hipHostMalloc(result slab) failed");
         *out = s;
         return AM_OK;
     }
@@ -1059,10 +1073,11 @@ struct SlabPool {
             std::lock_guard<std::mutex> lk(mu);
             if (free_list.size() < kKeep) { free_list.push_back(s); return; }
         }
-        (void)hipHostFree(s.p);
+        if (device) (void)hipFree(s.p); else (void)hipHostFree(s.p);
     }
 };
 SlabPool g_slabs;
+struct DevSlabPools { SlabPool p[kMaxDev]; DevSlabPools() { for (SlabPool& x : p) x.device = true; } } g_dev_slabs;
 }  // namespace
 
 struct am_replaced {
@@ -1071,11 +1086,13 @@ struct am_replaced {
     std::vector<uint8_t> just;
     std::vector<Slab> slabs;
     uint64_t passes = 0, scanned = 0, spliced = 0;
-    ~am_replaced() { for (const Slab& s : slabs) g_slabs.give(s); }
+    int dev = -1;                  // >= 0: the texts stay in that device's memory (am_replacer_run_batch_device)
+    SlabPool& pool() const { return dev >= 0 ? g_dev_slabs.p[dev] : g_slabs; }
+    ~am_replaced() { for (const Slab& s : slabs) pool().give(s); }
     // room for n contiguous bytes in the current slab, or a new slab
     int room(size_t n, uint8_t** out)
     {
-        if (slabs.empty() || slabs.back().cap - slabs.back().used < n) { Slab s; AM_TRY(g_slabs.take(n, &s)); slabs.push_back(s); }
+        if (slabs.empty() || slabs.back().cap - slabs.back().used < n) { Slab s; AM_TRY(pool().take(n, &s)); slabs.push_back(s); }
         *out = slabs.back().p + slabs.back().used;
         slabs.back().used += (n + 63) & ~(size_t)63;
         if (slabs.back().used > slabs.back().cap) slabs.back().used = slabs.back().cap;
@@ -1451,10 +1468,10 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             if (ev_copied_used) HIP_TRY(hipStreamWaitEvent(st, ev_copied, 0));      // the previous finished texts have left fin_text / fin_meta (a whole pass ago)
             { Prof pr("pt_materialise", st);
               HIP_TRY(launch_pt_materialise((const RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (const uint64_t*)s.pt_fin_start.p, (const uint32_t*)s.pt_fin_cnt.p, (const RpFin*)s.fin_meta.p,
-                                            (uint32_t)n_fin, base_text, r->t.repl, (uint8_t*)s.fin_text.p, st)); }
+                                            (uint32_t)n_fin, base_text, r->t.repl, res->dev >= 0 && total_fin ? home : (uint8_t*)s.fin_text.p, st)); }
             HIP_TRY(hipEventRecord(s.ev_spliced, st));
             HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0));
-            if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, s.copy_stream));
+            if (total_fin && res->dev < 0) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, s.copy_stream));
             HIP_TRY(hipMemcpyAsync(s.fin_host, s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, s.copy_stream));
             HIP_TRY(hipEventRecord(ev_copied, s.copy_stream));
             ev_copied_used = true;
@@ -1705,7 +1722,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         AM_TRY(s.pin_meta((n_fin + 1) * sizeof(RpFin)));
         HIP_TRY(hipEventRecord(s.ev_spliced, st));
         HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0));
-        if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, s.copy_stream));
+        if (total_fin) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDefault, s.copy_stream));      // the slab is pinned host memory, or device memory for results that stay there
         if (n_fin) HIP_TRY(hipMemcpyAsync(s.fin_host, s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, s.copy_stream));
         auto finished_home = [&]() -> int {
             HIP_TRY(hipStreamSynchronize(s.copy_stream));
@@ -1795,9 +1812,11 @@ static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_
     const size_t G = cut.size() - 1;
     if (G < 2) return replacer_run(r, in, max_length, res);
     struct Group { am_batch b; am_replaced part; int rc = AM_OK; std::string err; DevBuf offs; };
+    const int res_dev = res->dev;
     std::vector<std::unique_ptr<Group>> gs;
     for (size_t g = 0; g < G; g++) {
         auto gp = std::make_unique<Group>();
+        gp->part.dev = res_dev;
         const uint32_t h0 = cut[g], h1 = cut[g + 1];
         std::vector<uint64_t> sub(h1 - h0 + 1);
         for (uint32_t i = 0; i <= h1 - h0; i++) sub[i] = offs[h0 + i] - offs[h0];
@@ -1833,18 +1852,22 @@ static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_
     return rc;
 }
 
-extern "C" int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out)
+static int replacer_run_to(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out, bool on_device)
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!r || !b) return fail(AM_ERR_INVALID, "null replacer or batch");
     AM_TRY(ensure_runtime());
     am_replaced* res = new am_replaced();
+    if (on_device) res->dev = b->dev;
     const int rc = replacer_run_groups(r, b, max_length, res);
     if (rc != AM_OK) { delete res; return rc; }
     *out = res;
     return AM_OK;
 }
+
+extern "C" int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out) { return replacer_run_to(r, b, max_length, out, false); }
+extern "C" int am_replacer_run_batch_device(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out) { return replacer_run_to(r, b, max_length, out, true); }
 
 extern "C" int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out)
 {
@@ -1923,6 +1946,23 @@ extern "C" int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** p
     if (!r || i >= r->text.size() || !ptr || !len) return fail(AM_ERR_INVALID, "bad argument");
     *ptr = r->text[i].p ? r->text[i].p : (const uint8_t*)""; *len = r->text[i].len;
     return r->just[i] ? 1 : 0;
+}
+
+extern "C" int am_replaced_device(const am_replaced* r) { return r ? r->dev : -1; }
+
+// copies text i to host memory, wherever the result lives
+extern "C" int am_replaced_read(const am_replaced* r, size_t i, uint8_t* dst, size_t cap, size_t* len)
+{
+    if (!r || i >= r->text.size()) return fail(AM_ERR_INVALID, "index out of range");
+    if (len) *len = r->just[i] ? r->text[i].len : 0;
+    if (!r->just[i]) return 0;
+    const size_t n = r->text[i].len;
+    if (n > cap || (n && !dst)) return fail(AM_ERR_INVALID, "destination too small");
+    if (n == 0) return 1;
+    if (r->dev < 0) { std::memcpy(dst, r->text[i].p, n); return 1; }
+    ON_DEVICE(r->dev);
+    HIP_TRY(hipMemcpy(dst, r->text[i].p, n, hipMemcpyDeviceToHost));
+    return 1;
 }
 
 extern "C" void am_replaced_free(am_replaced* r) { delete r; }

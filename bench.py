@@ -371,8 +371,10 @@ def bench_single_process(args, w):
 
 def bench_replacer(args, w, rank, world, dev):
     """--workload cfg5_replacer_50k_1GiB (BASELINE.json configs[4]): one step = Replacer.run over the whole batch,
-    every pass on the device (am_replacer_run_batch), results on the host as the ABI returns them.  Every rank
-    builds the same Replacer (0.4 s) and rewrites its own shard of haystacks; no collective on the data path."""
+    every pass on the device.  Like the scan metric (records stay in HBM), `value` is measured with the rewritten texts
+    left in device memory (am_replacer_run_batch_device); `host_results` in the same JSON line is the rate of
+    am_replacer_run_batch, which also moves every result over PCIe into pinned host memory.  Every rank builds the same
+    Replacer (0.4 s) and rewrites its own shard of haystacks; no collective on the data path."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -397,11 +399,12 @@ def bench_replacer(args, w, rank, world, dev):
     am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(batch)))
     last = {}
 
-    def step():
-        if "res" in last:                                  # hand the previous result's pinned slabs back first, as a caller would
+    def step(on_device=True):
+        if "res" in last:                                  # hand the previous result's slabs back first, as a caller would
             lib.am_replaced_free(last.pop("res"))
         res = C.c_void_p()
-        am.api.check(lib.am_replacer_run_batch(rdev, batch, C.c_uint64(2**64 - 1), C.byref(res)))
+        run = lib.am_replacer_run_batch_device if on_device else lib.am_replacer_run_batch
+        am.api.check(run(rdev, batch, C.c_uint64(2**64 - 1), C.byref(res)))
         last["res"] = res
         return int(lib.am_replaced_passes(res)), int(lib.am_replaced_scanned_bytes(res))
 
@@ -419,6 +422,14 @@ def bench_replacer(args, w, rank, world, dev):
         passes, scanned = step()
     fence()
     elapsed = amdist.allreduce_max(time.perf_counter() - t0, dev)
+    # the same steps with the results brought to the host (PCIe-inclusive; reported next to `value`, never as `value`)
+    step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    fence()
+    elapsed_host = amdist.allreduce_max(time.perf_counter() - t0, dev)
     # the per-kernel breakdown comes from ONE extra step with the HIP-event brackets on: a pass is a few dozen launches of
     # microseconds each, and two event records per launch would be part of what is measured
     am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
@@ -447,6 +458,9 @@ def bench_replacer(args, w, rank, world, dev):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": args.workload, "n_pairs": len(pairs), "case": "IgnoreCase" if case else "CaseSensitive", "haystacks_per_gpu": n_hay,
                        "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": n_bytes, "parallelism": "haystack-sharded x%d" % world, "build_s": round(build_s, 2)},
+            "results": "device-resident (am_replacer_run_batch_device)",
+            "host_results": {"value": round(n_bytes * world / float(1 << 30) * args.steps / elapsed_host, 3), "unit": "GiB/s", "ms_per_step": round(elapsed_host / args.steps * 1e3, 3),
+                             "what": "am_replacer_run_batch: the same passes plus every rewritten text copied over PCIe into pinned host memory"},
             "passes": passes, "scanned_gib_per_step": round(total_scanned / float(1 << 30), 2), "spliced_gib_per_step": round(spliced / float(1 << 30), 2),
             "kernel_ms_per_step": {k: round(v[0] / prof_steps, 3) for k, v in prof.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -461,9 +475,9 @@ def bench_replacer(args, w, rank, world, dev):
             while spent < args.cpu_seconds and k < min(n_hay, 64):
                 hay = bytes(host[k * w["hay_bytes"]:(k + 1) * w["hay_bytes"]])
                 t1 = time.perf_counter(); exp = orc.run(hay); spent += time.perf_counter() - t1
-                p, n = C.c_void_p(), C.c_size_t(0)
-                just = lib.am_replaced_get(last["res"], k, C.byref(p), C.byref(n))
-                ok = ok and just == 1 and C.string_at(p, n.value) == exp
+                buf, n = C.create_string_buffer(len(exp) + 16), C.c_size_t(0)
+                just = lib.am_replaced_read(last["res"], k, buf, len(buf), C.byref(n))
+                ok = ok and just == 1 and buf.raw[:n.value] == exp
                 k += 1
             if not ok:
                 raise SystemExit("PARITY FAILURE: device Replacer output differs from the oracle on the CPU-baseline sample")

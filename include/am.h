@@ -181,6 +181,10 @@ void am_replacer_destroy(am_replacer* r);
 /* max_length: runWithLimit's maxLength (:203); UINT64_MAX = `run` (:200-201, maxBound). */
 int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out);
 int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);   /* b is not modified */
+/* The same, but the rewritten texts STAY IN DEVICE MEMORY (the batch's device), for callers that feed them to the next device
+   stage: am_replaced_get then returns device pointers, am_replaced_read copies one text to the host.  This is what a
+   device-resident pipeline measures; am_replacer_run_batch additionally moves every result over PCIe into pinned host memory. */
+int am_replacer_run_batch_device(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);
 /* One pass only, for callers that keep sort / removeOverlap / replace (Replacer.hs:159-198) on their side: the fold
  * `prependMatch` (:252-260) with seed (minBound, []) and the given threshold per haystack.  best_out[i] = the best
  * priority below thresholds[i] among the matches of haystack i (INT64_MIN: none); *matches_out = every match that
@@ -198,6 +202,9 @@ void am_prio_matches_free(am_prio_match* m);
 uint64_t am_replaced_size(const am_replaced* r);
 /* Returns 1 and the text for `Just`, 0 for `Nothing` (longer than max_length), < 0 on error.  *ptr is owned by r. */
 int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len);
+int am_replaced_device(const am_replaced* r);               /* -1: the texts are in host memory; otherwise the device that holds them */
+/* Copies text i into dst (host memory, cap bytes) wherever the result lives; *len = its length.  Returns like am_replaced_get. */
+int am_replaced_read(const am_replaced* r, size_t i, uint8_t* dst, size_t cap, size_t* len);
 uint64_t am_replaced_passes(const am_replaced* r);          /* scans that were needed (max over the batch) */
 uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes scanned over all passes (after the first pass only windows around the replacements) */
 uint64_t am_replaced_spliced_bytes(const am_replaced* r);   /* bytes of rewritten text produced over all passes */
@@ -262,6 +269,7 @@ size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
 
 /* ---- runtime knobs ------------------------------------------------------------------------------ */
 int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches OF THE CALLING THREAD; NULL = the thread's library stream */
+int am_get_stream(void** hip_stream);  /* the stream the calling thread's launches on the current device go to (to order other work after them) */
 int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 int am_profile_enable(int on);

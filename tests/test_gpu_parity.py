@@ -386,6 +386,54 @@ def test_replacer_concurrent_haystack_groups(monkeypatch, groups):
         assert any(x is None for x in limited) and any(x is not None for x in limited)
 
 
+def test_replacer_results_left_on_the_device():
+    """am_replacer_run_batch_device: same texts and Nothing entries as am_replacer_run_batch, read back one by one with
+    am_replaced_read; am_replaced_get hands out device pointers (hipPointerGetAttributes says so)."""
+    import torch
+    lib = am.api.libam()
+    rng = random.Random(5)
+    alpha = "abcd "
+    pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(2, 4))), "".join(rng.choice("AB" + alpha) for _ in range(rng.randint(0, 6)))) for _ in range(30)]
+    hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 1, 9, 100, 900, 5000)))) for _ in range(120)]
+    enc = [h.encode() for h in hays]
+    blob = b"".join(enc)
+    offs = np.cumsum([0] + [len(e) for e in enc]).astype(np.int64)
+    text = torch.frombuffer(bytearray(blob + b"\0" * 16), dtype=torch.uint8).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    for case in (0, 1):
+        r, o = am.Replacer(case, pairs), oracle.Replacer(case, pairs)
+        batch = C.c_void_p()
+        am.api.check(lib.am_batch_from_device(text.data_ptr(), d_offs.data_ptr(), len(hays), len(blob), C.byref(batch)))
+        try:
+            for limit in (2**64 - 1, 800):
+                exp = [o.run(h, -1 if limit > 2**60 else limit) for h in hays]
+                for fn, on_dev in ((lib.am_replacer_run_batch, False), (lib.am_replacer_run_batch_device, True)):
+                    res = C.c_void_p()
+                    am.api.check(fn(C.c_void_p(r.device), batch, C.c_uint64(limit), C.byref(res)))
+                    try:
+                        assert (lib.am_replaced_device(res) >= 0) == on_dev
+                        got = []
+                        for i in range(len(hays)):
+                            buf, n = C.create_string_buffer(1 << 16), C.c_size_t(0)
+                            just = lib.am_replaced_read(res, i, buf, len(buf), C.byref(n))
+                            assert just in (0, 1)
+                            got.append(buf.raw[:n.value] if just else None)
+                        assert got == exp
+                        if on_dev:
+                            i = max(range(len(hays)), key=lambda k: len(exp[k] or b""))
+                            p, n = C.c_void_p(), C.c_size_t(0)
+                            assert lib.am_replaced_get(res, i, C.byref(p), C.byref(n)) == 1
+                            assert n.value == len(exp[i]) and p.value
+                            hip = C.CDLL("libamdhip64.so")
+                            attr = C.create_string_buffer(256)          # hipPointerAttribute_t: int type first (2 = device memory)
+                            assert hip.hipPointerGetAttributes(attr, p) == 0
+                            assert int.from_bytes(attr.raw[:4], "little") == 2
+                    finally:
+                        lib.am_replaced_free(res)
+        finally:
+            lib.am_batch_destroy(batch)
+
+
 def test_single_haystack_split_like_multi_gpu():
     """one big haystack cut into per-rank ranges with a one-match overlap; the union of the ranks'
     own records is the whole-haystack result (here the 'ranks' run one after the other on one GPU)."""
