@@ -38,6 +38,7 @@ struct ScanOut {
 };
 
 constexpr uint32_t kPoolBlock = 64;   // records per pool block (1 KiB)
+constexpr uint32_t kPoolGrantSlack = 8u * 16u * 2u;   // per CU: blocks that may stay unused in the wavefronts' grants (8 per wavefront, <= 32 wavefronts)
 
 hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st);
 uint64_t sf_chunks(const BatchView& b);

@@ -548,7 +548,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         }
         h.tier_log2_cap[3] = lb;
         std::vector<u32x2> hot((size_t)1 << lb, u32x2{0, 0});
-        std::vector<u32x4> cold((size_t)1 << lb, u32x4{0, 0, kNone, kNone});
+        std::vector<SfSlot> slots((size_t)2 << lb, SfSlot{0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0, {0, 0, 0}});
         for (size_t sl = 0; sl < owner.size(); sl++) {
             if (owner[sl] == kNone) continue;
             const HotEntry& e = ents[owner[sl]];
@@ -578,11 +578,30 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             }
             const uint32_t word = t4_slot_word(t4_fingerprint(t4_hash_a(e.key), lb), fixed, sel1, sel2);
             (&hot[sl >> 1].x)[sl & 1] = word;
-            (&cold[sl >> 1].x)[sl & 1] = e.key;
-            (&cold[sl >> 1].z)[sl & 1] = e.node;
+            // the slot's line for phase 2: the depth-4 node, its single edge (or this copy's child edge) and that edge's child
+            SfSlot& so = slots[sl];
+            so.key = e.key; so.flags = kSlotOccupied | (e.edge ? kSlotChildCopy : 0u);
+            so.x = nd.x; so.y = nd.y;
+            const SfNode* ch = nullptr;
+            if (e.edge) {
+                const SfEdge& ed = edges_out[nd.z + e.edge - 1];
+                so.w = 1u | ((ed.byte & 0xFFu) << 16) | (ed.skip << 24);
+                so.z = ed.child;
+                for (int i = 0; i < 4; i++) so.label[i] = ed.label[i];
+                ch = &nodes[ed.child];
+            } else if (n_edges == 1) {
+                so.w = nd.w; so.z = nd.z;
+                for (int i = 0; i < 4; i++) so.label[i] = nd.label[i];
+                ch = &nodes[nd.z];
+            } else if (n_edges == 0) {
+                so.w = 0; so.z = 0;
+            } else {
+                so.w = n_edges; so.z = e.node;            // branching and not split: phase 2 continues at the node record
+            }
+            if (ch) { so.cx = ch->x; so.cy = ch->y; so.cw = ch->w; }
         }
         h.off_tier[3] = blob.put(hot);
-        h.off_t4_cold = blob.put(cold);
+        h.off_t4_slots = blob.put(slots);
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);
@@ -639,9 +658,12 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         if (!has_empty) { err = "image: suffix table without an empty slot"; return false; }      // the linear probe must terminate
     }
     if (h.sf_tiers & 8u) {
-        const u32x4* cold = (const u32x4*)(img + h.off_t4_cold);
-        for (uint64_t i = 0; i < (1ull << h.tier_log2_cap[3]); i++)
-            if ((cold[i].z != kNone && cold[i].z >= h.sf_n_nodes) || (cold[i].w != kNone && cold[i].w >= h.sf_n_nodes)) { err = "image: suffix bucket node out of range"; return false; }
+        const SfSlot* slots = (const SfSlot*)(img + h.off_t4_slots);
+        for (uint64_t i = 0; i < (2ull << h.tier_log2_cap[3]); i++) {
+            if (!(slots[i].flags & kSlotOccupied)) continue;
+            const uint32_t kind = slots[i].w & 0xFFFFu;
+            if ((kind != 0 && slots[i].z >= h.sf_n_nodes) || (kind == 1 && (slots[i].w >> 24) > kMaxSkip)) { err = "image: suffix slot out of range"; return false; }
+        }
     }
     return true;
 }
@@ -661,7 +683,7 @@ bool image_sections_in_bounds(const ImageHeader& h)
             if (!(h.sf_tiers & (1u << t))) continue;
             if (h.tier_log2_cap[t] > 30) return false;
             good = good && ok(h.off_tier[t], 1ull << h.tier_log2_cap[t], 8);
-            if (t == 3) good = good && ok(h.off_t4_cold, 1ull << h.tier_log2_cap[t], 16);
+            if (t == 3) good = good && ok(h.off_t4_slots, 2ull << h.tier_log2_cap[t], 64) && (h.off_t4_slots & 63u) == 0;
         }
     }
     return good;

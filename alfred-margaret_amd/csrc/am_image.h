@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 6;
+constexpr uint32_t kImageVersion = 7;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -63,7 +63,7 @@ struct ImageHeader {
     uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
     uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
     uint64_t n_edges;
-    uint64_t off_t4_cold;       // cold side of tier 4, 16 B per bucket: the 2 full keys, then the 2 depth-4 node ids (kNone: empty slot)
+    uint64_t off_t4_slots;      // cold side of tier 4: one 64-byte SfSlot per cuckoo slot (2 per bucket): full key + the depth-4 node, its single edge and that edge's child
     uint64_t checksum;          // of everything after the header (checked when an image comes from the host)
     uint64_t off_goto;          // AC: u32x4{state, cp, next, used}[1 << ac_goto_log2_cap], open addressing: (state, cp) -> goto target
     uint64_t off_fail;          // AC: u32[n_states] fallback state (the target of each state's wildcard entry)
@@ -104,6 +104,24 @@ struct alignas(32) SfEdge {
 };
 constexpr uint32_t kMaxSkip = 16;
 
+// Cold side of the 4-byte-suffix table: one 64-byte line per cuckoo slot, so that the position of a hot slot that matched IS the
+// address of everything the resolve needs for a typical needle: the full key, the depth-4 node (own needle end), its single edge
+// (selector, skip, label) and the child's needle end.  A needle of <= 4 + 1 + 16 bytes resolves with this one line; longer ones
+// and branching nodes continue in `nodes` / `edges`.  A branching depth-4 node that was split into one hot entry per child
+// (am_flatten.cpp) has one SfSlot per child too: w/label/z/c* describe that child's edge (kSlotChildCopy).
+struct alignas(64) SfSlot {
+    uint32_t key, flags;   // flags: kSlotOccupied, kSlotChildCopy
+    uint32_t x, y;         // needle end AT the depth-4 node: canonical state + 1 (0: none), vlen
+    uint32_t w;            // bits 0-15: 0 = leaf, 1 = the single (or this copy's) edge is described here, >= 2 = branching: continue at nodes[z]
+                           // bits 16-23 selector byte, 24-31 skip length of that edge
+    uint32_t z;            // w & 0xFFFF == 1: child node id; >= 2: the depth-4 node's own id
+    uint32_t cx, cy;       // needle end at the child (state + 1, vlen)
+    uint32_t label[4];     // skip bytes of the edge (text order, right-aligned)
+    uint32_t cw;           // the child's SfNode::w (its edge count decides whether the walk goes on)
+    uint32_t pad[3];
+};
+constexpr uint32_t kSlotOccupied = 1u, kSlotChildCopy = 2u;
+
 struct SfView {
     const uint32_t* bloom;
     const u32x2* tier[3];    // exact tables for needles (variants) of exactly 1, 2, 3 bytes
@@ -113,7 +131,7 @@ struct SfView {
     // trie requires after the 4-byte suffix when it is a plain chain there.  COLD side (read only
     // when a needle may really end at the position): the full keys and the node ids.
     const u32x2* t4_hot;
-    const u32x4* t4_cold;    // {key0, key1, node0, node1}
+    const SfSlot* t4_slots;  // 2 per bucket, same index as the hot slot
     const SfNode* nodes;
     const SfEdge* edges;
     uint32_t bloom_log2_words, tiers;
@@ -151,7 +169,7 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     v.bloom = (const uint32_t*)(b + h.off_bloom);
     for (int t = 0; t < 3; t++) v.tier[t] = (const u32x2*)(b + h.off_tier[t]);
     v.t4_hot = (const u32x2*)(b + h.off_tier[3]);
-    v.t4_cold = (const u32x4*)(b + h.off_t4_cold);
+    v.t4_slots = (const SfSlot*)(b + h.off_t4_slots);
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
     v.edges = (const SfEdge*)(b + h.off_edges);
@@ -365,7 +383,7 @@ AM_HD uint32_t t4_slot_diff(uint32_t slot, uint32_t expect)
 // defer[k] = true: a needle may end here, phase 2 must look (exactly).
 template <int N>
 AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N],
-                      const bool (&valid)[N], bool (&defer)[N], uint32_t ablate = 0)
+                      const bool (&valid)[N], bool (&defer)[N], uint32_t (&hint)[N], uint32_t ablate = 0)
 {
     u32x2 ba[N], bb[N];
     uint32_t fp[N];
@@ -373,7 +391,7 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
     const uint32_t lb = s.tier_log2_cap[3];
 #pragma unroll
     for (int k = 0; k < N; k++) probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
-    if (ablate == 2) { for (int k = 0; k < N; k++) defer[k] = valid[k] && w[k] == 0x12345678u && nbs[k] == 0x9au; return; }   // timing experiment only
+    if (ablate == 2) { for (int k = 0; k < N; k++) { defer[k] = valid[k] && w[k] == 0x12345678u && nbs[k] == 0x9au; hint[k] = 0; } return; }   // timing experiment only
 #if defined(__HIP_DEVICE_COMPILE__)
     {
         uint2 ra[N], rb[N];
@@ -411,6 +429,8 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
         hit |= (uint32_t)((s.tiers & 7u) != 0u);                 // 1..3-byte needles: always consult their tables
         if (ablate == 3) hit &= (uint32_t)(ba[k].x == 0x12345678u);   // timing experiment only
         defer[k] = valid[k] & (hit != 0u);
+        // which of the four candidate slots agreed (the first one; 3 also when none did): phase 2 reads exactly that slot's line
+        hint[k] = za_b == 0u ? (uint32_t)(za != 0u) : 2u + (uint32_t)(zc != 0u);
     }
 }
 
@@ -420,6 +440,16 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
 // so the N dependent-load chains (haystack bytes -> cold bucket -> trie node -> [edge -> child ...])
 // overlap instead of adding up.  Data-dependent loops live only here.
 
+// is the flag set in any lane of the wavefront?  (uniform: lets the whole wavefront skip a rarely needed block of loads)
+AM_HD bool wave_any(bool x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(x) != 0ull;
+#else
+    return x;
+#endif
+}
+
 AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
 {
     n.x = a.x; n.y = a.y; n.z = a.z; n.w = a.w; n.label[0] = b.x; n.label[1] = b.y; n.label[2] = b.z; n.label[3] = b.w;
@@ -428,95 +458,126 @@ AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
 // SHORT = false promises that the automaton has no needle (variant) shorter than 4 bytes (s.tiers & 7 == 0): step 5 and the
 // three small tables drop out of the kernel.  Depths are 32-bit: a needle is far shorter than 4 GiB, and the bytes
 // available in the haystack only matter up to that.
-// `between` runs after the cold-bucket loads have been issued and before they are used: the kernel computes avail64 there
-// (haystack index -> offsets: two dependent loads of its own), so that chain overlaps with haystack bytes -> cold bucket
+// `hint` = which of the four candidate slots the probe saw agree (sf_probe_n); any value is correct, the right one saves loads.
+// `between` runs after the slot-line loads have been issued and before they are used: the kernel computes avail64 there
+// (haystack index -> offsets: two dependent loads of its own), so that chain overlaps with haystack bytes -> slot line
 // instead of preceding it.  avail64 is not read before that.
 struct SfNoHook { AM_HD void operator()() const {} };
 template <bool IC, int N, bool SHORT = true, class Between = SfNoHook>
 AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail64)[N], const bool (&valid)[N],
-                        bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N], Between between = Between(), uint64_t* dbg_iters = nullptr, uint32_t dbg_ablate = 0)
+                        const uint32_t (&hint)[N], bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N], Between between = Between(),
+                        uint64_t* dbg_iters = nullptr, uint32_t dbg_ablate = 0)
 {
     uint32_t avail[N];
     const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
     const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 2 x 16 B per edge
     uint32_t w[N], w2[N], node[N];
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[9] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
-    // ---- step 1: last 8 haystack bytes
+    uint32_t t16[N][4];
+    // ---- step 1: the last 8 haystack bytes and the 16 before the 4-byte suffix (what the first edge label is compared with)
 #pragma unroll
-    for (int k = 0; k < N; k++) { w[k] = 0; w2[k] = 0; if (valid[k]) load_suffix8(text, gpos[k], w[k], w2[k]); }
+    for (int k = 0; k < N; k++) {
+        w[k] = 0; w2[k] = 0; t16[k][0] = t16[k][1] = t16[k][2] = t16[k][3] = 0;
+        if (valid[k]) { load_suffix8(text, gpos[k], w[k], w2[k]); if (gpos[k] >= 4) load_text16(text, gpos[k] - 4, t16[k]); }
+    }
 #pragma unroll
-    for (int k = 0; k < N; k++) if (IC) { w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]); }
-
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[2] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
-    // ---- step 2: exact lookup of the 4-byte suffix on the cold side of the cuckoo table
+    for (int k = 0; k < N; k++) if (IC) {
+        w[k] = fold_dword(w[k]); w2[k] = fold_dword(w2[k]);
+        t16[k][0] = fold_dword(t16[k][0]); t16[k][1] = fold_dword(t16[k][1]); t16[k][2] = fold_dword(t16[k][2]); t16[k][3] = fold_dword(t16[k][3]);
+    }
+    // ---- step 2: the slot the probe pointed at: ONE 64-byte line with the full key, the depth-4 node, its edge and the edge's child
+    SfSlot sl[N];
+    uint32_t slot_of[4][N];
+    bool look[N];
     {
-        u32x4 ca[N], cb[N];
+        const u32x4* slots16 = reinterpret_cast<const u32x4*>(s.t4_slots);
         const uint32_t lb = s.tier_log2_cap[3];
+        u32x4 q0[N], q1[N], q2[N], q3[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const bool look = valid[k] && (s.tiers & 8u);
-            const uint32_t ba = look ? t4_bucket(t4_hash_a(w[k]), lb) : 0u, bb = look ? t4_bucket(t4_hash_b(w[k]), lb) : 0u;
-            ca[k] = s.t4_cold[ba]; cb[k] = s.t4_cold[bb];              // {key0, key1, node0, node1}
-            if (!look) { ca[k].z = ca[k].w = cb[k].z = cb[k].w = kNone; }
+            look[k] = valid[k] && (s.tiers & 8u);
+            const uint32_t ba = look[k] ? t4_bucket(t4_hash_a(w[k]), lb) : 0u, bb = look[k] ? t4_bucket(t4_hash_b(w[k]), lb) : 0u;
+            slot_of[0][k] = 2u * ba; slot_of[1][k] = 2u * ba + 1u; slot_of[2][k] = 2u * bb; slot_of[3][k] = 2u * bb + 1u;
+            const uint32_t h = hint[k] & 3u;
+            const uint32_t idx = h == 0 ? slot_of[0][k] : h == 1 ? slot_of[1][k] : h == 2 ? slot_of[2][k] : slot_of[3][k];
+            q0[k] = slots16[4u * idx]; q1[k] = slots16[4u * idx + 1u]; q2[k] = slots16[4u * idx + 2u]; q3[k] = slots16[4u * idx + 3u];
         }
         between();
 #pragma unroll
         for (int k = 0; k < N; k++) avail[k] = avail64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)avail64[k];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            node[k] = kNone;
-            if (ca[k].x == w[k] && ca[k].z != kNone) node[k] = ca[k].z;
-            if (ca[k].y == w[k] && ca[k].w != kNone) node[k] = ca[k].w;
-            if (cb[k].x == w[k] && cb[k].z != kNone) node[k] = cb[k].z;
-            if (cb[k].y == w[k] && cb[k].w != kNone) node[k] = cb[k].w;
-            if (avail[k] < 4) node[k] = kNone;                         // the 4-byte suffix does not fit into the haystack
+            sl[k].key = q0[k].x; sl[k].flags = q0[k].y; sl[k].x = q0[k].z; sl[k].y = q0[k].w;
+            sl[k].w = q1[k].x; sl[k].z = q1[k].y; sl[k].cx = q1[k].z; sl[k].cy = q1[k].w;
+            sl[k].label[0] = q2[k].x; sl[k].label[1] = q2[k].y; sl[k].label[2] = q2[k].z; sl[k].label[3] = q2[k].w;
+            sl[k].cw = q3[k].x;
         }
-    }
-
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[3] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
-    // ---- step 3: speculative loads -- the depth-4 node, the record after it (the DFS renumbering puts
-    // a single child right after its parent) and the 16 haystack bytes the first edge label would be
-    // compared with.  A typical needle (<= 21 bytes) then resolves without further loads.
-    SfNode rec[N], nxt[N];
-    uint32_t t16[N][4];
-    {
-        u32x4 r0[N], r1[N], r2[N], r3[N];
+        // the slot is the right one if it holds this key -- and, for one child's copy of a branching node, this child's selector byte.
+        // Otherwise (a fingerprint collision, or a position deferred without any hot slot agreeing: automata with 1..3-byte needles,
+        // the host checker's verify-everything mode) look at the keys of all four candidate slots and fetch the right line.
+        bool miss[N], any_miss = false;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            const uint32_t id = node[k] != kNone ? node[k] : 0u;
-            const uint32_t id1 = id + 1u < s.n_nodes ? id + 1u : id;
-            r0[k] = nodes16[2u * id]; r1[k] = nodes16[2u * id + 1u]; r2[k] = nodes16[2u * id1]; r3[k] = nodes16[2u * id1 + 1u];
-            t16[k][0] = t16[k][1] = t16[k][2] = t16[k][3] = 0;
-            if (node[k] != kNone && gpos[k] >= 4) load_text16(text, gpos[k] - 4, t16[k]);
+            const uint32_t b4 = w2[k] >> 24;                 // the byte before the 4-byte suffix
+            const bool ok = (sl[k].flags & kSlotOccupied) && sl[k].key == w[k] && !((sl[k].flags & kSlotChildCopy) && ((sl[k].w >> 16) & 0xFFu) != b4);
+            miss[k] = look[k] && !ok;
+            if (!look[k] || !ok) sl[k].flags = 0;
+            any_miss = any_miss || miss[k];
         }
+        if (wave_any(any_miss)) {
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            node_from_raw(r0[k], r1[k], rec[k]); node_from_raw(r2[k], r3[k], nxt[k]);
-            if (IC) { t16[k][0] = fold_dword(t16[k][0]); t16[k][1] = fold_dword(t16[k][1]); t16[k][2] = fold_dword(t16[k][2]); t16[k][3] = fold_dword(t16[k][3]); }
+            for (int k = 0; k < N; k++) {
+                if (!miss[k]) continue;
+                const uint32_t b4 = w2[k] >> 24;
+                uint32_t found_idx = kNone;
+                for (int c = 0; c < 4; c++) {
+                    const u32x4 a0 = slots16[4u * slot_of[c][k]], a1 = slots16[4u * slot_of[c][k] + 1u];
+                    const bool ok = (a0.y & kSlotOccupied) && a0.x == w[k] && !((a0.y & kSlotChildCopy) && ((a1.x >> 16) & 0xFFu) != b4);
+                    if (ok && found_idx == kNone) found_idx = slot_of[c][k];
+                }
+                if (found_idx != kNone) {
+                    const u32x4 a0 = slots16[4u * found_idx], a1 = slots16[4u * found_idx + 1u], a2 = slots16[4u * found_idx + 2u], a3 = slots16[4u * found_idx + 3u];
+                    sl[k].key = a0.x; sl[k].flags = a0.y; sl[k].x = a0.z; sl[k].y = a0.w;
+                    sl[k].w = a1.x; sl[k].z = a1.y; sl[k].cx = a1.z; sl[k].cy = a1.w;
+                    sl[k].label[0] = a2.x; sl[k].label[1] = a2.y; sl[k].label[2] = a2.z; sl[k].label[3] = a2.w;
+                    sl[k].cw = a3.x;
+                }
+            }
         }
     }
-
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[4] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
-    // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
-    uint32_t best_state[N], best_vlen[N], pre_node[N];
+    // ---- step 3: what the slot line settles: the needle ending at the depth-4 node, the single edge and the needle ending at its
+    // child.  Only needles longer than that, and branching nodes, go on to the node records.
+    uint32_t best_state[N], best_vlen[N];
     uint32_t depth[N];
     bool go[N];
+    SfNode rec[N];
+    bool any_go = false;
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        best_state[k] = 0; best_vlen[k] = 0; depth[k] = 4; pre_node[k] = node[k]; go[k] = false;
-        if (node[k] != kNone) {
-            if (rec[k].x) { best_state[k] = rec[k].x; best_vlen[k] = rec[k].y; }
-            go[k] = depth[k] < avail[k] && (rec[k].w & 0xFFFFu) != 0;
-        }
+        best_state[k] = 0; best_vlen[k] = 0; depth[k] = 4; go[k] = false; node[k] = kNone;
+        rec[k] = SfNode{0, 0, 0, 0, {0, 0, 0, 0}};
+        if (!(sl[k].flags & kSlotOccupied) || avail[k] < 4) continue;       // the 4-byte suffix does not fit into the haystack
+        if (sl[k].x) { best_state[k] = sl[k].x; best_vlen[k] = sl[k].y; }
+        const uint32_t kind = sl[k].w & 0xFFFFu;
+        if (kind == 0 || avail[k] <= 4) continue;
+        if (kind == 1) {
+            const uint32_t skip = sl[k].w >> 24;
+            if (((sl[k].w >> 16) & 0xFFu) != (w2[k] >> 24)) continue;
+            if (5u + skip > avail[k]) continue;
+            if (skip && !label_match(t16[k], sl[k].label, skip)) continue;
+            depth[k] = 5u + skip;
+            if (sl[k].cx) { best_state[k] = sl[k].cx; best_vlen[k] = sl[k].cy; }
+            if ((sl[k].cw & 0xFFFFu) != 0 && depth[k] < avail[k]) { go[k] = true; node[k] = sl[k].z; }     // the walk continues at the child
+        } else { go[k] = true; node[k] = sl[k].z; }                                                       // branching: the depth-4 node itself
+        any_go = any_go || go[k];
     }
+    if (wave_any(any_go)) {
+        u32x4 r0[N], r1[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) { const uint32_t id = go[k] ? node[k] : 0u; r0[k] = nodes16[2u * id]; r1[k] = nodes16[2u * id + 1u]; }
+#pragma unroll
+        for (int k = 0; k < N; k++) if (go[k]) node_from_raw(r0[k], r1[k], rec[k]);
+    }
+    // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
     for (;;) {
         bool any = false;
 #pragma unroll
@@ -566,35 +627,26 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             if (next[k] == kNone || (uint64_t)depth[k] + 1u + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
         }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[5] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
         // 4b: child record + the 16 bytes to compare with the label, for all N items together
         SfNode child[N];
         uint32_t t[N][4];
         {
             u32x4 c0[N], c1[N];
-            bool from_mem[N];
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                from_mem[k] = false;
                 c0[k] = u32x4{0, 0, 0, 0}; c1[k] = c0[k];
                 t[k][0] = t16[k][0]; t[k][1] = t16[k][1]; t[k][2] = t16[k][2]; t[k][3] = t16[k][3];
                 if (!go[k]) continue;
-                const bool is_next = pre_node[k] != kNone && next[k] == pre_node[k] + 1u && pre_node[k] + 1u < s.n_nodes;
-                if (!is_next) { from_mem[k] = true; c0[k] = nodes16[2u * next[k]]; c1[k] = nodes16[2u * next[k] + 1u]; }
+                c0[k] = nodes16[2u * next[k]]; c1[k] = nodes16[2u * next[k] + 1u];
                 if (skip[k] && depth[k] != 4) {
                     load_text16(text, gpos[k] - depth[k], t[k]);       // the 16 bytes before the selector byte
                     if (IC) { t[k][0] = fold_dword(t[k][0]); t[k][1] = fold_dword(t[k][1]); t[k][2] = fold_dword(t[k][2]); t[k][3] = fold_dword(t[k][3]); }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < N; k++) { if (from_mem[k]) node_from_raw(c0[k], c1[k], child[k]); else child[k] = nxt[k]; }
+            for (int k = 0; k < N; k++) node_from_raw(c0[k], c1[k], child[k]);
         }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[6] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
         // 4c: compare the label, advance
 #pragma unroll
         for (int k = 0; k < N; k++) {
@@ -622,18 +674,16 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
         found[k] = valid[k] && best_state[k] != 0;
         state[k] = best_state[k] - 1u; vlen[k] = best_vlen[k];
     }
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" :: "v"(state[0]), "v"(vlen[0]) : "memory"); const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[8] += now - dbg_iters[7]; dbg_iters[7] = now; }
-#endif
 }
 
 template <bool IC>
-AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen)
+AM_HD bool sf_resolve(const SfView& s, const uint8_t* text, uint64_t gpos, uint64_t avail, uint32_t& state, uint32_t& vlen, uint32_t hint = 0)
 {
     const uint64_t g[1] = {gpos}, a[1] = {avail};
     const bool v[1] = {true};
     bool f[1]; uint32_t st[1], vl[1];
-    sf_resolve_n<IC, 1>(s, text, g, a, v, f, st, vl);
+    const uint32_t hi[1] = {hint};
+    sf_resolve_n<IC, 1>(s, text, g, a, v, hi, f, st, vl);
     state = st[0]; vlen = vl[0];
     return f[0];
 }
@@ -648,10 +698,10 @@ AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64
     const uint32_t wa[1] = {w}, nba[1] = {(w2 >> 24) | (((w2 >> 16) & 0xFFu) << 8)};
     const uint64_t a[1] = {avail};
     const bool v[1] = {true};
-    bool defer[1];
-    sf_probe_n<1>(s, wa, nba, a, v, defer);
+    bool defer[1]; uint32_t hint[1];
+    sf_probe_n<1>(s, wa, nba, a, v, defer, hint);
     if (!defer[0]) return false;
-    return sf_resolve<IC>(s, text, gpos, avail, state, vlen);
+    return sf_resolve<IC>(s, text, gpos, avail, state, vlen, hint[0]);
 }
 
 // Bloom test of one window for every active tier; returns true if any tier may match.

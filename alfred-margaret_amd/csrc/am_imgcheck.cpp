@@ -93,21 +93,25 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                     if (which == 1) {
                         // what the kernel does: w / nb from the (folded) haystack bytes, two candidates per probe call
                         uint32_t wv[2] = {0, 0}, nbv[2] = {0, 0};
-                        bool defer[2];
+                        bool defer[2]; uint32_t hint[2] = {0, 0};
                         for (int k = 0; k < 2; k++) if (valid[k]) {
                             for (uint32_t j = 0; j < 4; j++) { uint32_t byte = g[k] >= j ? padded[(size_t)(g[k] - j)] : 0u; wv[k] |= byte << (24u - 8u * j); }
                             uint32_t b1 = g[k] >= 4 ? padded[(size_t)(g[k] - 4)] : 0u, b2 = g[k] >= 5 ? padded[(size_t)(g[k] - 5)] : 0u;
                             if (ic) { wv[k] = fold_dword(wv[k]); b1 = fold_byte(b1); b2 = fold_byte(b2); }
                             nbv[k] = b1 | (b2 << 8);
                         }
-                        sf_probe_n<2>(s, wv, nbv, a, valid, defer);
+                        sf_probe_n<2>(s, wv, nbv, a, valid, defer, hint);
                         // phase 2, two items in lock step as in the kernel
                         bool todo[2] = {valid[0] && defer[0], valid[1] && defer[1]};
-                        if (ic) sf_resolve_n<true, 2>(s, padded.data(), g, a, todo, found, st, vl);
-                        else sf_resolve_n<false, 2>(s, padded.data(), g, a, todo, found, st, vl);
+                        if (ic) sf_resolve_n<true, 2>(s, padded.data(), g, a, todo, hint, found, st, vl);
+                        else sf_resolve_n<false, 2>(s, padded.data(), g, a, todo, hint, found, st, vl);
                     } else {
-                        for (int k = 0; k < 2; k++) if (valid[k])
-                            found[k] = ic ? sf_verify<true>(s, padded.data(), g[k], a[k], st[k], vl[k]) : sf_verify<false>(s, padded.data(), g[k], a[k], st[k], vl[k]);
+                        // every position through the exact phase 2, with a slot hint that is wrong three times out of four: the
+                        // probe only filters, so the answer must not depend on it (this is the path of a fingerprint collision)
+                        for (int k = 0; k < 2; k++) if (valid[k]) {
+                            const uint32_t hint = (uint32_t)(g[k] & 3u);
+                            found[k] = ic ? sf_resolve<true>(s, padded.data(), g[k], a[k], st[k], vl[k], hint) : sf_resolve<false>(s, padded.data(), g[k], a[k], st[k], vl[k], hint);
+                        }
                     }
                     for (int k = 0; k < 2; k++) if (valid[k] && found[k]) recs.push_back({hay[k], st[k], a[k], vl[k]});
                 }

@@ -86,7 +86,10 @@ __device__ __forceinline__ void wave_lds_fence()
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
 constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
-constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 10 | offset): candidates that need the exact lookup + trie walk
+constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 12 | agreeing slot << 10 | offset): candidates that need the exact look
+constexpr uint32_t kSfMaxUnitChunks = 64;
+constexpr uint32_t kSfBlockGrant = 8;            // pool blocks a wavefront takes per atomic (am_abi.cpp sizes the pool for the unused remainders)
+constexpr uint32_t kSfEpochChunks = 16;          // the ring is drained every 16 chunks, so that the chunk index fits the 4 bits an entry has for it
 constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
 constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table: first thing in LDS, the filter words follow
 
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     uint64_t nval = 0;
     uint32_t q2_head = 0, q2_tail = 0;                   // monotonic; slot = index % kSfQ2
     // emit mode: state of the unit being written
-    uint64_t unit_base_chunk = 0;
-    uint32_t unit_count = 0, cur_block = kNone, first_block = kNone;
+    uint64_t unit_base_chunk = 0, epoch_base_chunk = 0;
+    uint32_t unit_count = 0, cur_block = kNone, first_block = kNone, grant_next = 0, grant_left = 0;
     bool pool_ok = true;
 
     // optional phase timing (AM_SF_ABLATE>=8): s_memtime deltas per wavefront, summed into o.dbg
@@ -174,14 +177,15 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     constexpr int RN = 1;      // 2 halves the number of latency chains but spills registers (measured: 2x slower overall)
     auto resolve_batch = [&](uint32_t nb) {
         uint64_t gpos[RN], end_pos[RN];
-        uint32_t hay[RN], state[RN], vlen[RN], hlo[RN], hhi[RN];
+        uint32_t hay[RN], state[RN], vlen[RN], hlo[RN], hhi[RN], hint[RN];
         bool valid[RN], found[RN];
         if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
             valid[k] = 64u * k + lane < nb;
             const uint32_t item = valid[k] ? lds_read_u16(q2 + 2u * ((q2_head + 64u * k + lane) % kSfQ2)) : 0u;
-            gpos[k] = (unit_base_chunk + (item >> 10)) * kSfChunk + (item & 1023u);
+            gpos[k] = (epoch_base_chunk + (item >> 12)) * kSfChunk + (item & 1023u);
+            hint[k] = (item >> 10) & 3u;
             hlo[k] = 0; hhi[k] = 0;
             if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
         }
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             }
         };
         for (int k = 0; k < RN; k++) end_pos[k] = 0;
-        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, found, state, vlen, locate);
+        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, hint, found, state, vlen, locate, nullptr, ablate);
         if (timing) { asm volatile("" :: "v"((uint32_t)found[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; n_batches++; }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
@@ -222,9 +226,16 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     const bool need_new = r == 0u || r + F > kPoolBlock;
                     uint32_t new_block = kNone;
                     if (need_new) {
-                        uint32_t id = 0;
-                        if (lane == 0) id = atomicAdd(o.pool_ctrl, 1u);
-                        id = __builtin_amdgcn_readfirstlane(id);
+                        // blocks are drawn from the pool kSfBlockGrant at a time: one atomic on the (single, device-wide) counter
+                        // costs ~10 ns of serialised time, and match-dense text needs more than two blocks per KiB per wavefront
+                        if (grant_left == 0) {
+                            uint32_t g = 0;
+                            if (lane == 0) g = atomicAdd(o.pool_ctrl, kSfBlockGrant);
+                            grant_next = __builtin_amdgcn_readfirstlane(g);
+                            grant_left = kSfBlockGrant;
+                        }
+                        const uint32_t id = grant_next++;
+                        grant_left--;
                         if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }   // keep counting, host retries with a larger pool
                         else {
                             new_block = id;
@@ -295,6 +306,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
+            if ((ci & (kSfEpochChunks - 1u)) == 0) epoch_base_chunk = c;
             uint4 next_v = make_uint4(0, 0, 0, 0);
             uint32_t next_c3 = 0, next_c4 = 0;
             const bool last_of_unit = ci + 1 >= n_in_unit;
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                     constexpr int W = decltype(width_tag)::value;
                     if (ablate == 5) return;                      // timing experiment only: filter + compaction, no probe
                     uint64_t avail[W];
-                    uint32_t pos[W], w[W], nb[W];
+                    uint32_t pos[W], w[W], nb[W], hint[W];
                     bool valid[W], defer[W];
 #pragma unroll
                     for (int k = 0; k < W; k++) {
@@ -404,12 +416,12 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                     }
                     if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
-                    sf_probe_n<W>(s, w, nb, avail, valid, defer, ablate);
+                    sf_probe_n<W>(s, w, nb, avail, valid, defer, hint, ablate);
                     if (ablate == 4) { for (int k = 0; k < W; k++) defer[k] = false; }      // timing experiment only: no resolve
 #pragma unroll
                     for (int k = 0; k < W; k++) {
                         const uint64_t m = __ballot(defer[k]);
-                        if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (ci << 10) | pos[k]);
+                        if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), ((ci & (kSfEpochChunks - 1u)) << 12) | (hint[k] << 10) | pos[k]);
                         q2_tail += (uint32_t)__popcll(m);
                         if (timing) n_defer += (uint32_t)__popcll(m);
                     }
@@ -427,12 +439,14 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 wave_lds_fence();
             }
             cur_v = next_v; carry3 = next_c3; carry4 = next_c4;
+            // end of an epoch (and of the unit): drain the ring, so that every item of a batch belongs to one epoch of one unit
+            if ((ci & (kSfEpochChunks - 1u)) == kSfEpochChunks - 1u || last_of_unit) {
+                wave_lds_fence();
+                tick(t_compact);
+                while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u * RN ? nb : 64u * RN); }
+                tick(t_resolve);
+            }
         }
-        // end of unit: drain the ring so that every item of a batch belongs to one unit
-        wave_lds_fence();
-        tick(t_compact);
-        while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u * RN ? nb : 64u * RN); }
-        tick(t_resolve);
         if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; }
     }
     if (timing && lane == 0) {
@@ -545,7 +559,7 @@ uint32_t sf_unit_chunks(const BatchView& b, int n_cu)
     const uint64_t n_chunks = sf_chunks(b), waves = (uint64_t)n_cu * kSfWaves * 4;
     uint64_t uc = n_chunks / (waves ? waves : 1);
     if (uc < 1) uc = 1;
-    if (uc > 64) uc = 64;
+    if (uc > kSfMaxUnitChunks) uc = kSfMaxUnitChunks;
     return (uint32_t)uc;
 }
 
