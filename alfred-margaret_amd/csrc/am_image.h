@@ -376,62 +376,59 @@ AM_HD uint32_t t4_slot_diff(uint32_t slot, uint32_t expect)
     return (slot ^ expect) & ~ignore;
 }
 
-// Phase 1, N candidates per lane at once.  Inputs come straight from the filter stage's registers
-// (w = the 4 bytes ending at the position, nbs = the two bytes before them: nearest in bits 0-7, the
-// other in bits 8-15; all case-folded), so the only memory traffic is the two hot buckets, both in
-// flight together, no data-dependent loop.
-// defer[k] = true: a needle may end here, phase 2 must look (exactly).
+// Phase 1, N candidates per lane at once, in two halves so that the kernel can leave the loads in flight across other work:
+// sf_probe_issue requests the two hot buckets of every candidate (inputs straight from the filter stage: w = the 4 bytes ending at
+// the position, nbs = the two bytes before them, nearest in bits 0-7, the other in bits 8-15; all case-folded) and returns the raw
+// buckets + the word a matching slot must equal; sf_probe_decide looks at them: defer[k] = true: a needle may end here, phase 2
+// must look (exactly); hint[k] = which of the four candidate slots agreed.  No data-dependent loop, the only memory traffic is the
+// two 8-byte buckets.
 template <int N>
-AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N],
-                      const bool (&valid)[N], bool (&defer)[N], uint32_t (&hint)[N], uint32_t ablate = 0)
+AM_HD void sf_probe_issue(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N], const bool (&valid)[N],
+                          u32x2 (&ba)[N], u32x2 (&bb)[N], uint32_t (&expect)[N])
 {
-    u32x2 ba[N], bb[N];
-    uint32_t fp[N];
-    bool probe[N];
     const uint32_t lb = s.tier_log2_cap[3];
 #pragma unroll
-    for (int k = 0; k < N; k++) probe[k] = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
-    if (ablate == 2) { for (int k = 0; k < N; k++) { defer[k] = valid[k] && w[k] == 0x12345678u && nbs[k] == 0x9au; hint[k] = 0; } return; }   // timing experiment only
-#if defined(__HIP_DEVICE_COMPILE__)
-    {
-        uint2 ra[N], rb[N];
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            const uint32_t ha = t4_hash_a(w[k]), hb = t4_hash_b(w[k]);
-            fp[k] = t4_fingerprint(ha, lb);
-            ra[k] = make_uint2(0, 0); rb[k] = ra[k];
-            if (probe[k]) {
-                ra[k] = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(ha, lb));
-                rb[k] = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(hb, lb));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            asm volatile("" : "+v"(ra[k].x), "+v"(ra[k].y), "+v"(rb[k].x), "+v"(rb[k].y));     // all loads in flight before the first use
-            ba[k] = u32x2{ra[k].x, ra[k].y};
-            bb[k] = u32x2{rb[k].x, rb[k].y};
-        }
-    }
-#else
     for (int k = 0; k < N; k++) {
+        const bool probe = valid[k] && (s.tiers & 8u) && avail[k] >= 4;
         const uint32_t ha = t4_hash_a(w[k]), hb = t4_hash_b(w[k]);
-        fp[k] = t4_fingerprint(ha, lb);
-        ba[k] = probe[k] ? s.t4_hot[t4_bucket(ha, lb)] : u32x2{0, 0};
-        bb[k] = probe[k] ? s.t4_hot[t4_bucket(hb, lb)] : u32x2{0, 0};
-    }
+        expect[k] = t4_expect(t4_fingerprint(ha, lb), nbs[k] & 0xFFFFu);
+        ba[k] = u32x2{0, 0}; bb[k] = ba[k];                      // empty buckets for the lanes that do not probe
+        if (probe) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint2 ra = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(ha, lb)), rb = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(hb, lb));
+            ba[k] = u32x2{ra.x, ra.y}; bb[k] = u32x2{rb.x, rb.y};
+#else
+            ba[k] = s.t4_hot[t4_bucket(ha, lb)]; bb[k] = s.t4_hot[t4_bucket(hb, lb)];
 #endif
+        }
+    }
+}
+
+template <int N>
+AM_HD void sf_probe_decide(const SfView& s, const u32x2 (&ba)[N], const u32x2 (&bb)[N], const uint32_t (&expect)[N], const bool (&valid)[N],
+                           bool (&defer)[N], uint32_t (&hint)[N])
+{
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const uint32_t e = t4_expect(fp[k], nbs[k] & 0xFFFFu);
+        const uint32_t e = expect[k];
         const uint32_t za = t4_slot_diff(ba[k].x, e), zb = t4_slot_diff(ba[k].y, e), zc = t4_slot_diff(bb[k].x, e), zd = t4_slot_diff(bb[k].y, e);
         const uint32_t za_b = za < zb ? za : zb, zc_d = zc < zd ? zc : zd;
         uint32_t hit = (uint32_t)((za_b < zc_d ? za_b : zc_d) == 0u);   // some slot agrees (empty buckets were substituted for non-probes)
         hit |= (uint32_t)((s.tiers & 7u) != 0u);                 // 1..3-byte needles: always consult their tables
-        if (ablate == 3) hit &= (uint32_t)(ba[k].x == 0x12345678u);   // timing experiment only
         defer[k] = valid[k] & (hit != 0u);
         // which of the four candidate slots agreed (the first one; 3 also when none did): phase 2 reads exactly that slot's line
         hint[k] = za_b == 0u ? (uint32_t)(za != 0u) : 2u + (uint32_t)(zc != 0u);
     }
+}
+
+template <int N>
+AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N],
+                      const bool (&valid)[N], bool (&defer)[N], uint32_t (&hint)[N])
+{
+    u32x2 ba[N], bb[N];
+    uint32_t expect[N];
+    sf_probe_issue<N>(s, w, nbs, avail, valid, ba, bb, expect);
+    sf_probe_decide<N>(s, ba, bb, expect, valid, defer, hint);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -501,7 +498,14 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             const uint32_t idx = h == 0 ? slot_of[0][k] : h == 1 ? slot_of[1][k] : h == 2 ? slot_of[2][k] : slot_of[3][k];
             q0[k] = slots16[4u * idx]; q1[k] = slots16[4u * idx + 1u]; q2[k] = slots16[4u * idx + 2u]; q3[k] = slots16[4u * idx + 3u];
         }
+        #if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[2] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+#endif
         between();
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[3] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+#endif
 #pragma unroll
         for (int k = 0; k < N; k++) avail[k] = avail64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)avail64[k];
 #pragma unroll
@@ -570,6 +574,10 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
         } else { go[k] = true; node[k] = sl[k].z; }                                                       // branching: the depth-4 node itself
         any_go = any_go || go[k];
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[4] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+#endif
     if (wave_any(any_go)) {
         u32x4 r0[N], r1[N];
 #pragma unroll
@@ -658,6 +666,10 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             go[k] = depth[k] < avail[k] && (rec[k].w & 0xFFFFu) != 0;
         }
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[5] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+#endif
     // ---- step 5: needles of 1..3 bytes (only if nothing longer ends here)
 #pragma unroll
     for (int k = 0; k < N; k++) {

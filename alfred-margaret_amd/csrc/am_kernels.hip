@@ -163,6 +163,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
     const bool timing = DBG && o.dbg != nullptr;
     const uint32_t ablate = DBG ? o.ablate : 0u;
     uint64_t t_filter = 0, t_compact = 0, t_probe = 0, t_resolve = 0, t_probe_pre = 0, t_mark = 0;
+    uint64_t dbg_iters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t t_r0 = 0, t_r1 = 0, t_r2 = 0, t_r3 = 0, n_batches = 0, n_cand = 0, n_probes = 0, n_defer = 0, n_found = 0;
     auto tick = [&](uint64_t& acc) { if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); acc += now - t_mark; t_mark = now; } };
 
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             }
         };
         for (int k = 0; k < RN; k++) end_pos[k] = 0;
-        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, hint, found, state, vlen, locate, nullptr, ablate);
+        if (timing) dbg_iters[7] = __builtin_amdgcn_s_memtime();
+        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, hint, found, state, vlen, locate, timing ? dbg_iters : nullptr, ablate);
         if (timing) { asm volatile("" :: "v"((uint32_t)found[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; n_batches++; }
 #pragma unroll
         for (int k = 0; k < RN; k++) {
@@ -256,7 +258,31 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 if (found[k]) o.flags[hay[k]] = 1;
             }
         }
+        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[6] += now - dbg_iters[7]; dbg_iters[7] = now; }
         q2_head += nb;
+    };
+
+    // ---- phase 1, second half: look at the buckets requested by the last probe round, park the survivors in the ring
+    u32x2 p_a[2], p_b[2];                                  // the raw buckets (loads possibly still in flight)
+    uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};           // the word a matching slot equals; offset in the chunk | 0x8000 (0: no candidate)
+    uint32_t p_ci = 0;                                     // chunk (within its epoch) the round belongs to
+    bool pending = false;
+    p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
+    auto consume_round = [&]() {
+        bool valid[2], defer[2];
+        uint32_t hint[2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x8000u) != 0;
+        sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
+        if (ablate == 4) { defer[0] = false; defer[1] = false; }      // timing experiment only: no resolve
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint64_t m = __ballot(defer[k]);
+            if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | (hint[k] << 10) | (p_pos[k] & 1023u));
+            q2_tail += (uint32_t)__popcll(m);
+            if (timing) n_defer += (uint32_t)__popcll(m);
+        }
+        pending = false;
     };
 
     // software pipeline: the next chunk's 16 B per lane are requested before the current chunk is filtered and probed,
@@ -371,12 +397,15 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             if (ablate == 1) cand = 0;               // timing experiment only
             if (timing) { asm volatile("" :: "v"(cand)); tick(t_filter); }
 
-            for (;;) {
+            // Probe pipeline: the two hot buckets of a round's candidates are REQUESTED at the end of a chunk's iteration and LOOKED AT
+            // after the next chunk has been filtered and compacted, so the ~3k cycles of an L2 round trip pass under that work instead
+            // of stopping the wavefront (four in-order wavefronts per SIMD cannot hide them otherwise).
+            for (bool first = true;; first = false) {
                 // compact (up to kSfQ1) candidate positions into the wave's LDS queue, in position order
                 const uint32_t n = __popc(cand);
                 const uint32_t incl = wave_inclusive_sum(n, lane);
                 const uint32_t total = __shfl(incl, 63, 64);
-                if (total == 0) break;
+                if (total == 0 && !(first && pending)) break;
                 uint32_t idx = incl - n;
                 // the loop runs as long as the busiest lane has candidates, so it only queues positions; the probe
                 // (dense, one candidate per lane) picks the window and the two bytes before it out of the staged chunk
@@ -389,51 +418,41 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
                 if (timing) n_cand += n_q1;
                 wave_lds_fence();
                 tick(t_compact);
-
-                // one probe round: up to 64 * W survivors, W per lane with their loads in flight together.
-                // The common case (<= 64 survivors left) takes the 1-wide instance: half the instructions.
-                auto probe_round = [&](uint32_t base, auto width_tag) {
-                    constexpr int W = decltype(width_tag)::value;
-                    if (ablate == 5) return;                      // timing experiment only: filter + compaction, no probe
-                    uint64_t avail[W];
-                    uint32_t pos[W], w[W], nb[W], hint[W];
-                    bool valid[W], defer[W];
+                // the round requested before this one (the previous chunk's last, or this chunk's previous 128 candidates)
+                if (pending) {
+                    consume_round();
+                    wave_lds_fence();
+                    tick(t_probe);
+                    while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }   // keeps room for the next round
+                    tick(t_resolve);
+                }
+                // request this round: up to 128 survivors, two per lane
+                if (n_q1 && ablate != 5) {
+                    uint64_t avail[2];
+                    uint32_t w[2], nb[2];
+                    bool valid[2];
 #pragma unroll
-                    for (int k = 0; k < W; k++) {
-                        const uint32_t e = base + 64u * k + lane;
+                    for (int k = 0; k < 2; k++) {
+                        const uint32_t e = 64u * k + lane;
                         valid[k] = e < n_q1;
-                        pos[k] = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
+                        const uint32_t pos = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
                         // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on
                         // top), nb = the two before it, nearest in bits 0-7
-                        const uint32_t a = 11u + pos[k], sh = a & 3u;
+                        const uint32_t a = 11u + pos, sh = a & 3u;
                         const uint32_t sp = stage + (a & ~3u);
                         const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
                         const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
                         nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
                         w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
-                        const uint64_t gpos = c0 + pos[k];
+                        const uint64_t gpos = c0 + pos;
                         avail[k] = gpos - hs0 + 1;
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
+                        p_pos[k] = valid[k] ? (pos | 0x8000u) : 0u;
                     }
-                    if (timing) { asm volatile("" :: "v"(w[0]), "v"(avail[0])); tick(t_probe_pre); }
-                    sf_probe_n<W>(s, w, nb, avail, valid, defer, hint, ablate);
-                    if (ablate == 4) { for (int k = 0; k < W; k++) defer[k] = false; }      // timing experiment only: no resolve
-#pragma unroll
-                    for (int k = 0; k < W; k++) {
-                        const uint64_t m = __ballot(defer[k]);
-                        if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), ((ci & (kSfEpochChunks - 1u)) << 12) | (hint[k] << 10) | pos[k]);
-                        q2_tail += (uint32_t)__popcll(m);
-                        if (timing) n_defer += (uint32_t)__popcll(m);
-                    }
-                    if (timing) n_probes++;
-                };
-                for (uint32_t base = 0; base < n_q1; base += 64 * ILP) {
-                    if (ILP == 1 || n_q1 - base <= 64u) probe_round(base, std::integral_constant<int, 1>());
-                    else probe_round(base, std::integral_constant<int, ILP>());
-                    wave_lds_fence();
-                    tick(t_probe);
-                    while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }   // keeps room for the next round
-                    tick(t_resolve);
+                    sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
+                    p_ci = ci & (kSfEpochChunks - 1u);
+                    pending = true;
+                    if (timing) { n_probes++; tick(t_probe_pre); }
                 }
                 if (total <= (uint32_t)kSfQ1) break;
                 wave_lds_fence();
@@ -441,6 +460,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             cur_v = next_v; carry3 = next_c3; carry4 = next_c4;
             // end of an epoch (and of the unit): drain the ring, so that every item of a batch belongs to one epoch of one unit
             if ((ci & (kSfEpochChunks - 1u)) == kSfEpochChunks - 1u || last_of_unit) {
+                if (pending) consume_round();                 // not overlapped: once per 16 chunks
                 wave_lds_fence();
                 tick(t_compact);
                 while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u * RN ? nb : 64u * RN); }
@@ -461,6 +481,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 8), (unsigned long long)t_r1);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 9), (unsigned long long)t_r2);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 10), (unsigned long long)t_r3);
+        for (int i = 0; i < 7; i++) atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 16 + 2 * 8192 + i), (unsigned long long)dbg_iters[i]);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 11), (unsigned long long)n_cand);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 12), (unsigned long long)n_probes);
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 13), (unsigned long long)n_defer);
@@ -604,6 +625,7 @@ static uint64_t* g_sf_dbg = nullptr;
 hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves)
 {
     if (!g_sf_dbg) return hipErrorInvalidValue;
+    if (n_waves == 0) { hipError_t e = hipMemcpy(out, g_sf_dbg + 16 + 2 * 8192, 64, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemset(g_sf_dbg + 16 + 2 * 8192, 0, 64); return e; }
     return hipMemcpy(out, g_sf_dbg + 16, 16 * (n_waves < 8192 ? n_waves : 8192), hipMemcpyDeviceToHost);
 }
 
@@ -637,7 +659,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     o.ablate = ablate;
     static uint64_t* dbg = nullptr;
     if (ablate >= 8) {
-        if (!dbg) { if (hipMalloc((void**)&dbg, 128 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 128 + 16 * 8192); }
+        if (!dbg) { if (hipMalloc((void**)&dbg, 256 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 256 + 16 * 8192); }
         o.dbg = dbg;
         g_sf_dbg = dbg;
     }

@@ -29,6 +29,8 @@ for mode in ("count", "emit"):
         torch.cuda.synchronize(); call_ms = (time.perf_counter() - t0) * 1e3
         recs = (C.c_uint64 * (2 * 4096))(); lib.am_debug_sf_wave_records(recs, 4096)
         lib.am_debug_sf_phase_cycles(out)
+        steps = (C.c_uint64 * 8)(); lib.am_debug_sf_wave_records(steps, 0)
+    print("   inside a resolve batch (cycles, no forced waits): until the slot loads are issued %.0f, haystack lookup %.0f, slot line consumed %.0f, walk loop %.0f (%.2f iterations), epilogue (count / emit) %.0f" % (steps[2] / max(out[6], 1), steps[3] / max(out[6], 1), steps[4] / max(out[6], 1), steps[5] / max(out[6], 1), steps[0] / max(out[6], 1), steps[6] / max(out[6], 1)))
     print("   whole call (host clock) %.3f ms" % call_ms)
     import numpy as np
     r = np.frombuffer(recs, dtype=np.uint64).reshape(-1, 2)
