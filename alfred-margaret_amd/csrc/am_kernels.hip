@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOu
             // left pending at the join would make the compiler wait with vmcnt(0) on every chunk -- and vmcnt counts in order,
             // so that wait would also cover the prefetch issued just above and expose a full HBM latency per chunk.)
             if (c0 >= he0 || c0 < hs0) {
-                hay0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)find_haystack(b, c0));
+                hay0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.hidx[c0 >> kHidxShift]);      // c0 is a multiple of 1 KiB: the index names its haystack (one load instead of a binary search)
                 hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]);
             }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
@@ -577,7 +577,7 @@ uint64_t sf_chunks(const BatchView& b) { return (b.total + kSfChunk - 1) / kSfCh
 // chunks per work unit: 64 KiB units for big batches, smaller ones when that would leave wavefronts idle
 uint32_t sf_unit_chunks(const BatchView& b, int n_cu)
 {
-    const uint64_t n_chunks = sf_chunks(b), waves = (uint64_t)n_cu * kSfWaves * 4;
+    const uint64_t n_chunks = sf_chunks(b), waves = (uint64_t)n_cu * kSfWaves * 4;      // (8 units per wavefront: -2 %, 16: -10 %: the unit counter's atomics)
     uint64_t uc = n_chunks / (waves ? waves : 1);
     if (uc < 1) uc = 1;
     if (uc > kSfMaxUnitChunks) uc = kSfMaxUnitChunks;
