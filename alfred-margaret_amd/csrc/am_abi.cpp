@@ -1558,8 +1558,11 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         // CaseSensitive replacers on the suffix-filter route keep the texts as piece tables (AM_RP_SPLICE=1: the splicing loop, for A/B and tests)
         const Flavor* fl = nullptr;
         AM_TRY(prepare(r->a, r->case_mode, &fl));
+        // ... when the batch is made of many documents: the piece-table kernels give a haystack to ONE wavefront, the splicing loop
+        // cuts every text into 16-KiB tiles.  One 1-MB document with half a million replacements per pass: 472 ms vs 90 ms (measured).
+        const bool many_documents = n_hay >= 64 && in->total / n_hay <= (1ull << 20);
         const bool pt = r->case_mode == AM_CASE_SENSITIVE && fl->h.sf_enabled && fl->h.root_vlen == 0 && r->a->kernel_pref != 1 &&
-                        std::getenv("AM_RP_FULL_SCANS") == nullptr && std::getenv("AM_RP_SPLICE") == nullptr;
+                        std::getenv("AM_RP_FULL_SCANS") == nullptr && std::getenv("AM_RP_SPLICE") == nullptr && (many_documents || std::getenv("AM_RP_PIECES") != nullptr);
         if (pt) return replacer_run_pt(r, in, max_length, res, fl);
     }
     ON_DEVICE(in->dev);

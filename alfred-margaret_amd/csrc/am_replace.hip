@@ -248,14 +248,43 @@ __global__ void __launch_bounds__(256) k_rpp_heads(const RpSel* __restrict__ sel
     keep[i] = head ? 3u : 0u;                                      // bit 0: kept, bit 1: head of a run
 }
 
+// removeOverlap (Replacer.hs:191-198) inside the runs of consecutively overlapping matches.  One WAVEFRONT walks a run, 64 matches
+// at a time: which of them survive is a chain (the next kept match is the first one that starts at or after the end of the last
+// kept one), followed with ballot + ffs in registers -- ~20 cycles per kept match instead of a dependent global load.  A periodic
+// document (1 MB of "a", needle "aa") is ONE run of a million matches; a single thread took a second for it.  Every wavefront owns
+// the run heads among its 64 indices and does their runs one after the other.
 __global__ void __launch_bounds__(256) k_rpp_greedy(const RpSel* __restrict__ sel, const uint64_t* __restrict__ n_sel_dev, uint32_t* __restrict__ keep)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n_sel = *n_sel_dev;
-    if (i >= n_sel || !(keep[i] & 2u)) return;
-    uint64_t last_end = sel[i].start + sel[i].len;
-    for (uint64_t j = i + 1; j < n_sel && !(keep[j] & 2u); j++) {   // the rest of the run: removeOverlap (Replacer.hs:191-198)
-        const RpSel c = sel[j];
-        if (c.start >= last_end) { keep[j] = 1u; last_end = c.start + c.len; }
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane, n_sel = *n_sel_dev;
+    if (base >= n_sel) return;
+    const uint64_t i = base + lane;
+    uint64_t heads = __ballot(i < n_sel && (keep[i] & 2u));
+    while (heads) {
+        const uint32_t h = (uint32_t)__ffsll((unsigned long long)heads) - 1u;
+        heads &= heads - 1ull;
+        const RpSel head = sel[base + h];
+        uint64_t last_end = head.start + head.len;
+        for (uint64_t j0 = base + h + 1;; j0 += kWave) {
+            const uint64_t j = j0 + lane;
+            const bool in = j < n_sel;
+            const uint32_t k = in ? keep[j] : 2u;
+            const uint64_t stop = __ballot(!in || (k & 2u));                       // the run ends at the next head (or at the end of the list)
+            const uint32_t limit = stop ? (uint32_t)__ffsll((unsigned long long)stop) - 1u : (uint32_t)kWave;
+            RpSel c{0, 0, 0, 0};
+            if (lane < limit) c = sel[j];
+            uint32_t cur = 0;
+            for (;;) {
+                const uint64_t m = __ballot(lane >= cur && lane < limit && c.start >= last_end);
+                if (!m) break;
+                const uint32_t l = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+                if (lane == l) keep[j] = 1u;
+                const uint64_t e = c.start + c.len;
+                last_end = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(e >> 32), (int)l, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)e, (int)l, kWave);
+                cur = l + 1u;
+            }
+            if (limit < (uint32_t)kWave) break;
+        }
     }
 }
 

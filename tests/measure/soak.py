@@ -39,10 +39,12 @@ while time.time() < t_end:
             lim = rng.choice((-1, -1, 30, 200))
             expr = [oo.run(h, lim) for h in hays]
             for forced in (None, "1"):
-                if forced: os.environ["AM_RP_PARALLEL_FOLD"] = forced
-                got = r.run_batch(hays, lim)
-                os.environ.pop("AM_RP_PARALLEL_FOLD", None)
-                assert got == expr, ("replacer", seed, case, forced, pairs, hays, lim)
+                for pieces in (None, "1"):                  # small batches take the splicing loop by default: also the piece-table loop
+                    if forced: os.environ["AM_RP_PARALLEL_FOLD"] = forced
+                    if pieces: os.environ["AM_RP_PIECES"] = pieces
+                    got = r.run_batch(hays, lim)
+                    os.environ.pop("AM_RP_PARALLEL_FOLD", None); os.environ.pop("AM_RP_PIECES", None)
+                    assert got == expr, ("replacer", seed, case, forced, pieces, pairs, hays, lim)
             n_rep += 1
     seed += 1
 print("soak ok: %d automaton cases, %d replacer cases, seeds up to %d" % (n_cases, n_rep, seed))

@@ -347,6 +347,9 @@ def test_replacer_incremental_rescan_equals_full_scans(monkeypatch):
         monkeypatch.delenv("AM_RP_FULL_SCANS")
         assert inc == full, (case, pairs[:5])
         assert inc_stats[0] == full_stats[0] and inc_stats[1] <= full_stats[1]
+        monkeypatch.setenv("AM_RP_PIECES", "1")             # small batches take the splicing loop by default: the piece-table loop on the same inputs
+        assert r.run_batch(hays) == inc
+        monkeypatch.delenv("AM_RP_PIECES")
         o = oracle.Replacer(case, pairs)
         assert inc == [o.run(h) for h in hays]
 
@@ -657,11 +660,25 @@ def test_replacer_record_parallel_fold(monkeypatch):
             for forced in ("1", "0"):
                 monkeypatch.setenv("AM_RP_PARALLEL_FOLD", forced)
                 assert r.run_batch(hays, max_len) == exp, (forced, case, pairs[:4], max_len)
+                monkeypatch.setenv("AM_RP_PIECES", "1")     # and with the texts kept as piece tables (the default only for batches of >= 64 documents)
+                assert r.run_batch(hays, max_len) == exp, (forced, "pieces", case, pairs[:4], max_len)
+                monkeypatch.delenv("AM_RP_PIECES")
             monkeypatch.delenv("AM_RP_PARALLEL_FOLD")
     # natural trigger: one document with > 2048 matches per pass
     big = ("short tshirts and sweatshirts " * 4000)
     pairs = [("tshirt", "T"), ("shirts", "S"), ("short", "long"), ("and", "&")]
     assert am.Replacer(0, pairs).run(big) == oracle.Replacer(0, pairs).run(big)
+    # a periodic document is ONE run of overlapping matches: 1 MB of "a" against "aa" (a million matches, half of them kept);
+    # the run is walked by a wavefront, 64 matches per step -- a single thread took about a second for it
+    import time
+    periodic = "a" * (1 << 20) + "b" + "a" * 4097
+    r = am.Replacer(0, [("aa", "c")])
+    r.run("aaaa")                                   # warm-up: image upload, workspaces
+    t0 = time.perf_counter()
+    got = r.run(periodic)
+    dt = time.perf_counter() - t0
+    assert got == b"c" * (1 << 19) + b"b" + b"c" * 2048 + b"a"
+    assert dt < 0.3, dt
 
 
 def test_runtime_knobs_user_stream_and_profiling():
