@@ -4,11 +4,14 @@
 //         each wavefront streams 1 KiB of haystack per step with one coalesced 16 B load per lane,
 //         builds the 16 four-byte suffix windows per lane in registers (v_alignbyte), probes a Bloom
 //         filter of needle suffixes that lives in LDS (up to 128 KiB of the CU's 160 KiB), compacts
-//         the surviving positions into a per-wave LDS queue with a wave prefix sum, then verifies
-//         64 candidates at a time against the exact suffix tables + reversed-needle trie in HBM/L2.
-//         Match records are compacted with ballot + popcount into the unit's output slab.
+//         the surviving positions into a per-wave LDS queue with a wave prefix sum, probes them against
+//         an L2-resident fingerprint table (requested in one chunk's iteration, looked at in the next)
+//         and verifies the few survivors 64 at a time against one 64-byte table line each (+ the
+//         reversed-needle trie for long needles).  Match records are compacted with ballot + popcount
+//         into the unit's chain of pool blocks.
 //  k_ac   general path: the reference's own packed automaton walked by one lane per chunk with a
-//         warm-up overlap (needed for automata containing the empty needle; also the A/B baseline).
+//         warm-up overlap (the independent second algorithm of the parity gate; automata the suffix
+//         structure cannot take).
 //  k_hidx 1-KiB haystack index (position -> haystack id bracket).
 //
 // No MFMA anywhere: this is integer pointer chasing; the roofline is HBM bandwidth
@@ -108,20 +111,21 @@ __device__ __forceinline__ void lds_write_u16(uint32_t byte_addr, uint32_t v) { 
 __device__ __forceinline__ void lds_write_u32x2(uint32_t byte_addr, uint2 v) { u32x2_n t; t.x = v.x; t.y = v.y; *reinterpret_cast<lds_u32x2_t*>((uintptr_t)byte_addr) = t; }
 __device__ __forceinline__ void lds_write_u32x4(uint32_t byte_addr, uint4 v) { u32x4_n t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *reinterpret_cast<lds_u32x4_t*>((uintptr_t)byte_addr) = t; }
 
-// ILP = candidates probed per lane per round (their loads are in flight together);
-// NT  = stream the haystack with non-temporal loads.
+// ILP: unused since the probe always takes two candidates per lane (kept in the instantiation names).
 //
 // Work unit = `unit_chunks` consecutive 1-KiB chunks.  A wavefront starts with unit (workgroup, wave) and draws every further
 // one from a global counter: with a fixed stride the slowest wavefront (they differ by +-20 %: contents, the memory channels
 // its units hit, its neighbours on the SIMD) finished 1.2x after the average one, and the launch lasts as long as the slowest.
 // Structure of one wavefront's loop (everything between two filter steps is wave-synchronous):
 //   filter   16 positions per lane against the LDS Bloom filter                      (LDS + VALU only)
-//   probe    surviving positions, 64*ILP at a time: last 8 haystack bytes + both cuckoo slots; no
-//            data-dependent loop, so every lane runs the same three loads            (phase 1)
-//   resolve  the few candidates that hit the suffix table AND continue in the trie (or end a needle)
-//            are parked in a ring and walked 64 at a time, across chunk boundaries   (phase 2)
+//   compact  the survivors' offsets into the wave's queue (DPP prefix sum)
+//   look at  the buckets requested for the PREVIOUS chunk's survivors; park the few that agree in a ring
+//   request  both cuckoo buckets of this chunk's survivors, up to 128 at a time (window bytes from the
+//            chunk staged in LDS); no data-dependent loop                             (phase 1)
+//   resolve  when 64 are parked, and at the end of every 16-chunk epoch: one slot line per item, the
+//            trie walk for the rare long ones                                         (phase 2)
 // Phase 2 is FIFO, so the records of a unit come out in position order: ballot + popcount rank them,
-// and they are appended to the unit's chain of 64-record pool blocks (one atomic per block).
+// and they are appended to the unit's chain of 64-record pool blocks (blocks are taken 8 per atomic).
 // LW: log2 of the filter size in words when it is the usual 128 KiB (15), so that the word address is a
 // constant shift + constant mask (VOP2 with immediates issues at almost twice the rate of anything that
 // reads an SGPR or needs the VOP3 encoding on gfx950, tools/microbench/valu_rates*.hip); 0 = any size
