@@ -103,23 +103,35 @@ def main():
     multi = None
     if world > 1 and not args.torch_collectives:
         # the product's own multi-GPU entry points (include/am.h am_multi_*): RCCL communicator over the ranks, automaton image
-        # broadcast over xGMI and the final all-reduce of counts inside libam; torch.distributed only carries the 128-byte id
-        ident = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_uint8 * 128)()
-            am.api.check(lib.am_multi_unique_id(buf))
-            ident = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
-        ident = ident.to(dev)
-        dist.broadcast(ident, 0)
-        ident_b = bytes(ident.cpu().numpy().tobytes())
-        multi = C.c_void_p()
-        with stdout_to_stderr():                       # RCCL prints a version banner on stdout
-            am.api.check(lib.am_multi_create_rank(world, rank, (C.c_uint8 * 128).from_buffer_copy(ident_b), C.byref(multi)))
-        autos = (C.c_void_p * 1)()
-        am.api.check(lib.am_multi_broadcast_automaton(multi, handle if rank == 0 else None, case, 0, autos))
-        handle = C.c_void_p(autos[0])
-        am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
-    elif world > 1:
+        # broadcast over xGMI and the final all-reduce of counts inside libam; torch.distributed only carries the 128-byte id.
+        # If that fails on any rank (it cannot be exercised on the 1-GPU development box), every rank falls back to the
+        # torch.distributed path below and the JSON line says so.
+        ok, handle0 = 1, handle
+        try:
+            ident = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_uint8 * 128)()
+                am.api.check(lib.am_multi_unique_id(buf))
+                ident = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).clone()
+            ident = ident.to(dev)
+            dist.broadcast(ident, 0)
+            ident_b = bytes(ident.cpu().numpy().tobytes())
+            multi = C.c_void_p()
+            with stdout_to_stderr():                       # RCCL prints a version banner on stdout
+                am.api.check(lib.am_multi_create_rank(world, rank, (C.c_uint8 * 128).from_buffer_copy(ident_b), C.byref(multi)))
+            autos = (C.c_void_p * 1)()
+            am.api.check(lib.am_multi_broadcast_automaton(multi, handle if rank == 0 else None, case, 0, autos))
+            handle = C.c_void_p(autos[0])
+            am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
+        except Exception as e:                              # noqa: BLE001
+            ok = 0
+            print("rank %d: am_multi path failed (%s); falling back to torch.distributed collectives" % (rank, e), file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            multi, handle = None, handle0
+            args.torch_collectives = True
+    if world > 1 and multi is None:
         image = None
         if rank == 0:
             image = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
