@@ -789,7 +789,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     // repeated once with the exact number of blocks.
     auto body_sf = [&]() -> int {
         AM_TRY(b->unit_first.ensure(p.n_units * sizeof(uint32_t)));
-        uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + (uint64_t)p.n_cu * kPoolGrantSlack;
+        uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units);
         if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
         if (const char* env = std::getenv("AM_SF_POOL_BLOCKS")) { long v = std::atol(env); if (v > 0) want_blocks = (uint64_t)v; }   // tests: force the overflow/retry path
         for (int attempt = 0; attempt < 3; attempt++) {
@@ -813,7 +813,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
             HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64 + (uint64_t)p.n_cu * kPoolGrantSlack; continue; }    // pool too small: ctrl[0] = blocks actually needed
+            if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64 + pool_grant_slack(p.n_cu, p.n_units); continue; }    // pool too small: ctrl[0] = blocks actually needed
             *n_scan = total;
             if (total == 0) return AM_OK;
             AM_TRY(sink(total, &d_records));
@@ -1226,7 +1226,7 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
     size_t tmp_bytes = 0;
     if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
-    const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8 + (uint64_t)p.n_cu * kPoolGrantSlack;          // ceil(records / 64) per unit, records <= bytes; + the grants' unused remainders
+    const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8 + pool_grant_slack(p.n_cu, p.n_units);          // ceil(records / 64) per unit, records <= bytes; + the grants' unused remainders
     if (want_blocks >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
     AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
     AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));

@@ -38,7 +38,9 @@ struct ScanOut {
 };
 
 constexpr uint32_t kPoolBlock = 64;   // records per pool block (1 KiB)
-constexpr uint32_t kPoolGrantSlack = 8u * 16u * 2u;   // per CU: blocks that may stay unused in the wavefronts' grants (8 per wavefront, <= 32 wavefronts)
+constexpr uint32_t kSfBlockGrant = 32; // pool blocks a k_sf wavefront takes per atomic
+// blocks that may stay unused in the wavefronts' grants: one grant per wavefront that can be resident (<= 32 per CU), never more than units
+inline uint64_t pool_grant_slack(int n_cu, uint64_t n_units) { uint64_t w = (uint64_t)n_cu * 32u; if (w > n_units) w = n_units; return w * kSfBlockGrant; }
 
 hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st);
 uint64_t sf_chunks(const BatchView& b);

@@ -91,7 +91,6 @@ constexpr int kSfWaves = kSfThreads / 64;
 constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
 constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 12 | agreeing slot << 10 | offset): candidates that need the exact look
 constexpr uint32_t kSfMaxUnitChunks = 64;
-constexpr uint32_t kSfBlockGrant = 8;            // pool blocks a wavefront takes per atomic (am_abi.cpp sizes the pool for the unused remainders)
 constexpr uint32_t kSfEpochChunks = 16;          // the ring is drained every 16 chunks, so that the chunk index fits the 4 bits an entry has for it
 constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
 constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table: first thing in LDS, the filter words follow
@@ -125,7 +124,7 @@ __device__ __forceinline__ void lds_write_u32x4(uint32_t byte_addr, uint4 v) { u
 //   resolve  when 64 are parked, and at the end of every 16-chunk epoch: one slot line per item, the
 //            trie walk for the rare long ones                                         (phase 2)
 // Phase 2 is FIFO, so the records of a unit come out in position order: ballot + popcount rank them,
-// and they are appended to the unit's chain of 64-record pool blocks (blocks are taken 8 per atomic).
+// and they are appended to the unit's chain of 64-record pool blocks (blocks are taken 32 per atomic).
 // LW: log2 of the filter size in words when it is the usual 128 KiB (15), so that the word address is a
 // constant shift + constant mask (VOP2 with immediates issues at almost twice the rate of anything that
 // reads an SGPR or needs the VOP3 encoding on gfx950, tools/microbench/valu_rates*.hip); 0 = any size
