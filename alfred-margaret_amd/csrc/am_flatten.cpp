@@ -242,6 +242,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 
     std::vector<SfNode> nodes;
     std::vector<SfEdge> edges_out;
+    std::vector<SfEdgeMap> edge_maps;
     std::vector<TierEntry> tier_entries[4];
 
     if (h.sf_enabled && !terminals.empty()) {
@@ -407,14 +408,30 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 rec.z = (uint32_t)edges_out.size();
                 rec.w = n;
                 if (n <= 4) for (uint32_t i = 0; i < n; i++) rec.label[0] |= cedges[c_order[c_first[x] + i]].byte << (8u * i);   // inline selectors
+                else {
+                    // more children: a map of the selector bytes with running counts (the edges are sorted by selector byte)
+                    SfEdgeMap mp{{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+                    uint32_t prev = 0;
+                    for (uint32_t i = 0; i < n; i++) {
+                        const uint32_t b = cedges[c_order[c_first[x] + i]].byte & 0xFFu;
+                        if (i && b <= prev) { err = "edges of a node are not sorted by selector byte (internal error)"; return -1; }
+                        prev = b;
+                        mp.bits[b >> 5] |= 1u << (b & 31u);
+                    }
+                    uint32_t run = 0;
+                    for (uint32_t wv = 0; wv < 8; wv++) { mp.cum[wv] = (uint8_t)run; run += (uint32_t)__builtin_popcount(mp.bits[wv]); }
+                    rec.label[0] = (uint32_t)edge_maps.size();
+                    edge_maps.push_back(mp);
+                }
                 for (uint32_t e = c_first[x]; e < c_first[x + 1]; e++) {
                     const CEdge& ce = cedges[c_order[e]];
-                    SfEdge ed{ce.byte, new_id[ce.dst], (uint32_t)ce.skip.size(), 0, {0, 0, 0, 0}};
+                    SfEdge ed{ce.byte, new_id[ce.dst], (uint32_t)ce.skip.size(), 0, {0, 0, 0, 0}, SfNode{0, 0, 0, 0, {0, 0, 0, 0}}};
                     pack_label(ce.skip, ed.label);
                     edges_out.push_back(ed);
                 }
             }
         }
+        for (SfEdge& ed : edges_out) ed.to = nodes[ed.child];          // every edge's line carries its child's (now final) record
 
         // suffix tables: every byte path of length <= 4 from the root (never inside a compressed edge)
         struct Frame { uint32_t node, depth, key; };
@@ -435,6 +452,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 
     h.sf_n_nodes = (uint32_t)nodes.size();
     h.n_edges = edges_out.size();
+    h.n_edge_maps = edge_maps.size();
     h.sf_tiers = 0;
     size_t total_keys = 0;
     for (int t = 0; t < 4; t++) { if (!tier_entries[t].empty()) h.sf_tiers |= 1u << t; total_keys += tier_entries[t].size(); }
@@ -605,6 +623,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);
+    h.off_edge_maps = blob.put(edge_maps);
     blob.reserve_section(16);      // tail padding
     h.total_bytes = blob.bytes.size();
     h.checksum = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
@@ -649,7 +668,22 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         if (ne == 1 && (n.z >= h.sf_n_nodes || (n.w >> 24) > kMaxSkip)) { err = "image: node child out of range"; return false; }
         if (ne > 1 && ((uint64_t)n.z + ne > h.n_edges)) { err = "image: node edge range out of range"; return false; }
     }
-    for (uint64_t i = 0; i < h.n_edges; i++) if (edges[i].child >= h.sf_n_nodes || edges[i].skip > kMaxSkip) { err = "image: edge out of range"; return false; }
+    for (uint64_t i = 0; i < h.n_edges; i++) {
+        if (edges[i].child >= h.sf_n_nodes || edges[i].skip > kMaxSkip) { err = "image: edge out of range"; return false; }
+        if (std::memcmp(&edges[i].to, &nodes[edges[i].child], sizeof(SfNode)) != 0) { err = "image: an edge's copy of its child differs from the child"; return false; }
+    }
+    {
+        const SfEdgeMap* maps = (const SfEdgeMap*)(img + h.off_edge_maps);
+        for (uint32_t i = 0; i < h.sf_n_nodes; i++) {
+            const uint32_t ne = nodes[i].w & 0xFFFFu;
+            if (ne <= 4) continue;
+            if (nodes[i].label[0] >= h.n_edge_maps) { err = "image: selector map out of range"; return false; }
+            const SfEdgeMap& mp = maps[nodes[i].label[0]];
+            uint32_t run = 0;
+            for (uint32_t wv = 0; wv < 8; wv++) { if (mp.cum[wv] != (uint8_t)run) { err = "image: selector map counts are wrong"; return false; } run += (uint32_t)__builtin_popcount(mp.bits[wv]); }
+            if (run != ne) { err = "image: selector map does not match the edge count"; return false; }
+        }
+    }
     for (int t = 0; t < 3; t++) {
         if (!(h.sf_tiers & (1u << t))) continue;
         const u32x2* tab = (const u32x2*)(img + h.off_tier[t]);
@@ -678,7 +712,7 @@ bool image_sections_in_bounds(const ImageHeader& h)
                 h.ac_goto_log2_cap >= 4 && h.ac_goto_log2_cap <= 31 && ok(h.off_goto, 1ull << h.ac_goto_log2_cap, 16) && ok(h.off_fail, h.n_states, 4);
     if (h.sf_enabled) {
         if (h.sf_bloom_log2_words > 20) return false;
-        good = good && ok(h.off_bloom, 1ull << h.sf_bloom_log2_words, 4) && ok(h.off_nodes, h.sf_n_nodes, 32) && ok(h.off_edges, h.n_edges, 32);
+        good = good && ok(h.off_bloom, 1ull << h.sf_bloom_log2_words, 4) && ok(h.off_nodes, h.sf_n_nodes, 32) && ok(h.off_edges, h.n_edges, 64) && ok(h.off_edge_maps, h.n_edge_maps, 64);
         for (int t = 0; t < 4; t++) {
             if (!(h.sf_tiers & (1u << t))) continue;
             if (h.tier_log2_cap[t] > 30) return false;

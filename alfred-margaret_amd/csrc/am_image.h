@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 7;
+constexpr uint32_t kImageVersion = 8;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -61,8 +61,10 @@ struct ImageHeader {
     uint64_t off_tier[4];       // tiers 1-3: u32x2{key, node}[1 << cap]; tier 4: hot fingerprint buckets u32x2[1 << cap] (2 slots each)
     uint32_t tier_log2_cap[4];
     uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
-    uint64_t off_edges;         // SfEdge[n_edges]     (32 B: out-edges of nodes with more than one child)
+    uint64_t off_edges;         // SfEdge[n_edges]     (64 B: out-edges of nodes with more than one child, each with a copy of its child's record)
     uint64_t n_edges;
+    uint64_t off_edge_maps;     // SfEdgeMap[n_edge_maps] (64 B: which selector bytes a node with more than 4 children has, with running counts)
+    uint64_t n_edge_maps;
     uint64_t off_t4_slots;      // cold side of tier 4: one 64-byte SfSlot per cuckoo slot (2 per bucket): full key + the depth-4 node, its single edge and that edge's child
     uint64_t checksum;          // of everything after the header (checked when an image comes from the host)
     uint64_t off_goto;          // AC: u32x4{state, cp, next, used}[1 << ac_goto_log2_cap], open addressing: (state, cp) -> goto target
@@ -96,11 +98,22 @@ struct alignas(32) SfNode {
     uint32_t y;          // vlen = length machineValues[state]
     uint32_t z;          // n_edges == 1: child node; n_edges > 1: first SfEdge index
     uint32_t w;          // n_edges (bits 0-15) | selector byte of the single edge (16-23) | its skip length (24-31)
-    uint32_t label[4];   // n_edges == 1: skip bytes of the single edge; 2..4 edges: label[0] = their selector bytes (edge i in byte i)
+    uint32_t label[4];   // n_edges == 1: skip bytes of the single edge; 2..4 edges: label[0] = their selector bytes (edge i in byte i);
+                         // more: label[0] = index of the node's SfEdgeMap
 };
-struct alignas(32) SfEdge {
+// An out-edge of a branching node, one 64-byte line: the edge AND a copy of the child's record, so that one step of the walk
+// (choose the edge, compare its label, arrive at the child) is one dependent load.
+struct alignas(64) SfEdge {
     uint32_t byte, child, skip, pad;
     uint32_t label[4];
+    SfNode to;           // = nodes[child]
+};
+// Which selector bytes a node with more than 4 children has: edge of byte b = first edge + cum[b >> 5] + popcount(bits[b >> 5] below bit b & 31)
+// (the edges are sorted by selector byte).  One 64-byte line instead of a binary search over the edges (one dependent load per probe).
+struct alignas(64) SfEdgeMap {
+    uint32_t bits[8];
+    uint8_t cum[8];
+    uint32_t pad[6];
 };
 constexpr uint32_t kMaxSkip = 16;
 
@@ -134,6 +147,7 @@ struct SfView {
     const SfSlot* t4_slots;  // 2 per bucket, same index as the hot slot
     const SfNode* nodes;
     const SfEdge* edges;
+    const SfEdgeMap* edge_maps;
     uint32_t bloom_log2_words, tiers;
     uint32_t tier_log2_cap[4];
     uint32_t n_nodes;
@@ -173,6 +187,7 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
     v.edges = (const SfEdge*)(b + h.off_edges);
+    v.edge_maps = (const SfEdgeMap*)(b + h.off_edge_maps);
     v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers; v.n_nodes = h.sf_n_nodes;
     return v;
 }
@@ -467,7 +482,8 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
 {
     uint32_t avail[N];
     const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
-    const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 2 x 16 B per edge
+    const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 4 x 16 B per edge
+    const u32x4* maps16 = reinterpret_cast<const u32x4*>(s.edge_maps);   // 4 x 16 B per map
     uint32_t w[N], w2[N], node[N];
     uint32_t t16[N][4];
     // ---- step 1: the last 8 haystack bytes and the 16 before the 4-byte suffix (what the first edge label is compared with)
@@ -597,65 +613,73 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             dbg_iters[1] += (uint64_t)__popcll(__ballot(go[0]));
 #endif
         }
-        // 4a: which edge?  (selector bytes are inline for nodes with <= 4 edges; the edge record itself
-        //     is only needed for multi-edge nodes and is loaded for all N items together)
-        uint32_t which[N], next[N], skip[N], label[N][4];
-        u32x4 e0[N], e1[N];
+        // One step of the walk = ONE round of loads for all lanes: a single-edge node has its edge inline (selector, skip, label) and
+        // needs its child's record; a branching node needs the chosen edge's 64-byte line, which carries the child's record; the 16
+        // haystack bytes the label is compared with depend only on the depth.  Only a node with more than 4 children takes a round of
+        // its own first (its selector map).
+        uint32_t which[N], next[N], skip[N], label[N][4], bsel[N];
+        bool many[N], any_many = false;
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            which[k] = kNone; next[k] = kNone; skip[k] = 0;
+            which[k] = kNone; next[k] = kNone; skip[k] = 0; many[k] = false; bsel[k] = 0;
             label[k][0] = rec[k].label[0]; label[k][1] = rec[k].label[1]; label[k][2] = rec[k].label[2]; label[k][3] = rec[k].label[3];
-            e0[k] = u32x4{0, 0, 0, 0}; e1[k] = e0[k];
             if (!go[k]) continue;
             const uint32_t n_edges = rec[k].w & 0xFFFFu;
             uint32_t b;
             if (depth[k] < 8) b = (w2[k] >> (8u * (7u - depth[k]))) & 0xFFu;
             else { b = text[gpos[k] - depth[k]]; if (IC) b = fold_byte(b); }
+            bsel[k] = b;
             if (n_edges == 1) {
                 if (((rec[k].w >> 16) & 0xFFu) == b) { next[k] = rec[k].z; skip[k] = rec[k].w >> 24; }
             } else if (n_edges <= 4) {
                 for (uint32_t i = 0; i < n_edges; i++) if (((rec[k].label[0] >> (8u * i)) & 0xFFu) == b) which[k] = rec[k].z + i;
-            } else {
-                uint32_t lo = rec[k].z, hi = rec[k].z + n_edges;   // edges sorted by selector byte (rare: > 4 children below depth 4)
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const uint32_t eb = s.edges[mid].byte;
-                    if (eb == b) { which[k] = mid; break; }
-                    if (eb < b) lo = mid + 1; else hi = mid;
-                }
-            }
-            if (which[k] != kNone) { e0[k] = edges16[2u * which[k]]; e1[k] = edges16[2u * which[k] + 1u]; }
+            } else many[k] = true;
+            any_many = any_many || many[k];
         }
+        if (wave_any(any_many)) {
+            u32x4 m0[N], m1[N], m2[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) {
-            if (which[k] != kNone) {
-                next[k] = e0[k].y; skip[k] = e0[k].z;                       // SfEdge {byte, child, skip, pad, label[4]}
-                label[k][0] = e1[k].x; label[k][1] = e1[k].y; label[k][2] = e1[k].z; label[k][3] = e1[k].w;
+            for (int k = 0; k < N; k++) { const uint32_t mi = many[k] ? rec[k].label[0] : 0u; m0[k] = maps16[4u * mi]; m1[k] = maps16[4u * mi + 1u]; m2[k] = maps16[4u * mi + 2u]; }
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                if (!many[k]) continue;
+                const uint32_t b = bsel[k], wi = b >> 5;
+                const uint32_t bits[8] = {m0[k].x, m0[k].y, m0[k].z, m0[k].w, m1[k].x, m1[k].y, m1[k].z, m1[k].w};
+                uint32_t word = 0, cum = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) if (i == wi) { word = bits[i]; cum = ((i < 4 ? m2[k].x : m2[k].y) >> (8u * (i & 3u))) & 0xFFu; }
+                if ((word >> (b & 31u)) & 1u) which[k] = rec[k].z + cum + (uint32_t)__builtin_popcount(word & ((1u << (b & 31u)) - 1u));
             }
-            if (next[k] == kNone || (uint64_t)depth[k] + 1u + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
         }
-
-        // 4b: child record + the 16 bytes to compare with the label, for all N items together
         SfNode child[N];
         uint32_t t[N][4];
         {
-            u32x4 c0[N], c1[N];
+            u32x4 e0[N], e1[N], c0[N], c1[N];
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                c0[k] = u32x4{0, 0, 0, 0}; c1[k] = c0[k];
+                e0[k] = u32x4{0, 0, 0, 0}; e1[k] = e0[k]; c0[k] = e0[k]; c1[k] = e0[k];
                 t[k][0] = t16[k][0]; t[k][1] = t16[k][1]; t[k][2] = t16[k][2]; t[k][3] = t16[k][3];
                 if (!go[k]) continue;
-                c0[k] = nodes16[2u * next[k]]; c1[k] = nodes16[2u * next[k] + 1u];
-                if (skip[k] && depth[k] != 4) {
+                if (which[k] != kNone) {                                   // the edge's line: edge + the child's record
+                    e0[k] = edges16[4u * which[k]]; e1[k] = edges16[4u * which[k] + 1u]; c0[k] = edges16[4u * which[k] + 2u]; c1[k] = edges16[4u * which[k] + 3u];
+                } else if (next[k] != kNone) { c0[k] = nodes16[2u * next[k]]; c1[k] = nodes16[2u * next[k] + 1u]; }      // single edge: the child's record
+                else continue;
+                if (depth[k] != 4) {
                     load_text16(text, gpos[k] - depth[k], t[k]);       // the 16 bytes before the selector byte
                     if (IC) { t[k][0] = fold_dword(t[k][0]); t[k][1] = fold_dword(t[k][1]); t[k][2] = fold_dword(t[k][2]); t[k][3] = fold_dword(t[k][3]); }
                 }
             }
 #pragma unroll
-            for (int k = 0; k < N; k++) node_from_raw(c0[k], c1[k], child[k]);
+            for (int k = 0; k < N; k++) {
+                if (which[k] != kNone) {
+                    next[k] = e0[k].y; skip[k] = e0[k].z;                       // SfEdge {byte, child, skip, pad, label[4], to}
+                    label[k][0] = e1[k].x; label[k][1] = e1[k].y; label[k][2] = e1[k].z; label[k][3] = e1[k].w;
+                }
+                node_from_raw(c0[k], c1[k], child[k]);
+                if (next[k] == kNone || (uint64_t)depth[k] + 1u + skip[k] > avail[k]) { go[k] = false; next[k] = kNone; }
+            }
         }
-
-        // 4c: compare the label, advance
+        // compare the label, advance
 #pragma unroll
         for (int k = 0; k < N; k++) {
             if (!go[k]) continue;

@@ -165,3 +165,31 @@ def test_empty_needle_through_the_suffix_filter(chk):
                 n, recs = chk.scan(img, which, hays)
                 assert n >= 0, (which, needles)
                 assert expand_records(o.values_off(), o.values(), recs[0], recs[1], recs[2]) == exp, (which, case, needles, hays)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wide_fan_out_below_the_suffix(chk, seed):
+    """Reversed-needle trie nodes with 5..40 children deeper than the 4-byte suffix (needles that share a stem and differ in the
+    letter before it, two levels): the walk finds the child through the node's selector map (SfEdgeMap) and one 64-byte edge line
+    that carries the child's record.  Filter + probe + resolve and resolve-everything against the oracle, both case modes."""
+    rng = random.Random(300 + seed)
+    letters = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789"
+    for _ in range(5):
+        stem = "".join(rng.choice("xyz") for _ in range(rng.randint(4, 12)))
+        fan = rng.sample(letters, rng.randint(5, 40))
+        needles = [c + stem for c in fan]
+        for c in fan[:5]:
+            needles += [d + c + stem for d in rng.sample(letters, rng.randint(5, 20))]
+        needles += [stem, "q" + stem[1:]]
+        hays = ["".join(rng.choice(letters[:30]) for _ in range(5)) + n + "".join(rng.choice("xyz") for _ in range(3)) for n in rng.sample(needles, min(len(needles), 40))]
+        hays.append(" ".join(needles)[:5000])
+        for case in (0, 1):
+            ns = list(dict.fromkeys(oracle.lower_utf8(n).decode() for n in needles)) if case else needles
+            o, p = oracle.Machine(ns), am.Automaton(ns)
+            img = chk.flatten(p, case)
+            exp = oracle_triples(o, case, hays)
+            vo, vals = o.values_off(), o.values()
+            for which in (1, 2):
+                n, recs = chk.scan(img, which, hays)
+                assert n >= 0
+                assert expand_records(vo, vals, recs[0], recs[1], recs[2]) == exp, (case, which, needles[:6])

@@ -40,7 +40,7 @@ def test_stale_image_is_refused_even_with_a_valid_checksum():
     chk = ImgCheck()
     a = am.Automaton(["tshirt", "shirts", "shorts", "a-needle-long-enough-for-the-trie"])
     img = chk.flatten(a, 0).copy()
-    hdr = struct.Struct("<4IQ4I" + "7Q" + "2I" + "4I" + "Q" + "4Q" + "4I" + "6Q")
+    hdr = struct.Struct("<4IQ4I" + "7Q" + "2I" + "4I" + "Q" + "4Q" + "4I" + "8Q")
     assert hdr.size <= 312
     f = hdr.unpack_from(img.tobytes())
     # locate sections by name through the checker's documented layout: off_nodes follows tier_log2_cap[4]
@@ -48,7 +48,7 @@ def test_stale_image_is_refused_even_with_a_valid_checksum():
              "off_transitions", "n_transitions", "off_offsets", "off_root_ascii", "off_canon", "off_vlen", "off_lower",
              "n_lower", "sf_enabled", "sf_tiers", "sf_bloom_log2_words", "sf_n_nodes", "ac_goto_log2_cap",
              "off_bloom", "off_tier0", "off_tier1", "off_tier2", "off_tier3", "cap0", "cap1", "cap2", "cap3",
-             "off_nodes", "off_edges", "n_edges", "off_t4_slots", "checksum", "off_goto"]
+             "off_nodes", "off_edges", "n_edges", "off_edge_maps", "n_edge_maps", "off_t4_slots", "checksum", "off_goto"]
     h = dict(zip(names, f))
     assert h["magic"] == 0x31474D41 and h["sf_n_nodes"] > 4
     lib = am.api.libam()
