@@ -566,7 +566,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         }
         h.tier_log2_cap[3] = lb;
         std::vector<u32x2> hot((size_t)1 << lb, u32x2{0, 0});
-        std::vector<SfSlot> slots((size_t)2 << lb, SfSlot{0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0, {0, 0, 0}});
+        std::vector<SfSlot> slots((size_t)2 << lb, SfSlot{0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0, 0, 0, 0});
         for (size_t sl = 0; sl < owner.size(); sl++) {
             if (owner[sl] == kNone) continue;
             const HotEntry& e = ents[owner[sl]];
@@ -614,7 +614,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             } else if (n_edges == 0) {
                 so.w = 0; so.z = 0;
             } else {
-                so.w = n_edges; so.z = e.node;            // branching and not split: phase 2 continues at the node record
+                so.w = n_edges; so.z = e.node; so.ez = nd.z; so.el0 = nd.label[0];      // branching and not split: phase 2 starts its walk from this line
             }
             if (ch) { so.cx = ch->x; so.cy = ch->y; so.cw = ch->w; }
         }

@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 8;
+constexpr uint32_t kImageVersion = 9;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
 constexpr uint32_t kHidxShift = 10;             // haystack-index table granularity: 1 KiB
@@ -131,7 +131,9 @@ struct alignas(64) SfSlot {
     uint32_t cx, cy;       // needle end at the child (state + 1, vlen)
     uint32_t label[4];     // skip bytes of the edge (text order, right-aligned)
     uint32_t cw;           // the child's SfNode::w (its edge count decides whether the walk goes on)
-    uint32_t pad[3];
+    uint32_t ez, el0;      // branching node (w & 0xFFFF >= 2): its SfNode::z (first edge) and label[0] (inline selectors / selector map), so
+                           // that the walk starts from this line without loading the node's record
+    uint32_t pad;
 };
 constexpr uint32_t kSlotOccupied = 1u, kSlotChildCopy = 2u;
 
@@ -529,7 +531,7 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             sl[k].key = q0[k].x; sl[k].flags = q0[k].y; sl[k].x = q0[k].z; sl[k].y = q0[k].w;
             sl[k].w = q1[k].x; sl[k].z = q1[k].y; sl[k].cx = q1[k].z; sl[k].cy = q1[k].w;
             sl[k].label[0] = q2[k].x; sl[k].label[1] = q2[k].y; sl[k].label[2] = q2[k].z; sl[k].label[3] = q2[k].w;
-            sl[k].cw = q3[k].x;
+            sl[k].cw = q3[k].x; sl[k].ez = q3[k].y; sl[k].el0 = q3[k].z;
         }
         // the slot is the right one if it holds this key -- and, for one child's copy of a branching node, this child's selector byte.
         // Otherwise (a fingerprint collision, or a position deferred without any hot slot agreeing: automata with 1..3-byte needles,
@@ -559,7 +561,7 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
                     sl[k].key = a0.x; sl[k].flags = a0.y; sl[k].x = a0.z; sl[k].y = a0.w;
                     sl[k].w = a1.x; sl[k].z = a1.y; sl[k].cx = a1.z; sl[k].cy = a1.w;
                     sl[k].label[0] = a2.x; sl[k].label[1] = a2.y; sl[k].label[2] = a2.z; sl[k].label[3] = a2.w;
-                    sl[k].cw = a3.x;
+                    sl[k].cw = a3.x; sl[k].ez = a3.y; sl[k].el0 = a3.z;
                 }
             }
         }
@@ -570,11 +572,12 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
     uint32_t depth[N];
     bool go[N];
     SfNode rec[N];
-    bool any_go = false;
+    bool have_rec[N];
+    bool any_go = false, any_load = false;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         best_state[k] = 0; best_vlen[k] = 0; depth[k] = 4; go[k] = false; node[k] = kNone;
-        rec[k] = SfNode{0, 0, 0, 0, {0, 0, 0, 0}};
+        rec[k] = SfNode{0, 0, 0, 0, {0, 0, 0, 0}}; have_rec[k] = false;
         if (!(sl[k].flags & kSlotOccupied) || avail[k] < 4) continue;       // the 4-byte suffix does not fit into the haystack
         if (sl[k].x) { best_state[k] = sl[k].x; best_vlen[k] = sl[k].y; }
         const uint32_t kind = sl[k].w & 0xFFFFu;
@@ -587,19 +590,23 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             depth[k] = 5u + skip;
             if (sl[k].cx) { best_state[k] = sl[k].cx; best_vlen[k] = sl[k].cy; }
             if ((sl[k].cw & 0xFFFFu) != 0 && depth[k] < avail[k]) { go[k] = true; node[k] = sl[k].z; }     // the walk continues at the child
-        } else { go[k] = true; node[k] = sl[k].z; }                                                       // branching: the depth-4 node itself
+        } else {                                                                                           // branching: the walk starts at the depth-4 node itself
+            go[k] = true; node[k] = sl[k].z; have_rec[k] = true;
+            rec[k].x = sl[k].x; rec[k].y = sl[k].y; rec[k].z = sl[k].ez; rec[k].w = kind; rec[k].label[0] = sl[k].el0;
+        }
         any_go = any_go || go[k];
+        any_load = any_load || (go[k] && !have_rec[k]);
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
     if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[4] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
 #endif
-    if (wave_any(any_go)) {
+    if (wave_any(any_load)) {                        // walks that go on at the single edge's child need its record
         u32x4 r0[N], r1[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) { const uint32_t id = go[k] ? node[k] : 0u; r0[k] = nodes16[2u * id]; r1[k] = nodes16[2u * id + 1u]; }
+        for (int k = 0; k < N; k++) { const uint32_t id = go[k] && !have_rec[k] ? node[k] : 0u; r0[k] = nodes16[2u * id]; r1[k] = nodes16[2u * id + 1u]; }
 #pragma unroll
-        for (int k = 0; k < N; k++) if (go[k]) node_from_raw(r0[k], r1[k], rec[k]);
+        for (int k = 0; k < N; k++) if (go[k] && !have_rec[k]) node_from_raw(r0[k], r1[k], rec[k]);
     }
     // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
     for (;;) {
