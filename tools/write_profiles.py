@@ -89,20 +89,22 @@ tr = {"source": "profiles/%s_pmc_%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
 json.dump(tr, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 
 # Replacer (config 5)
-k5 = open(os.path.join(D, "kt5_summary.md")).read().split("| kernel | grid")[0].rstrip()
-r5 = line("bench_cfg5_replacer_50k_1GiB.log")
-open(os.path.join(P, "%s_replacer_trace_%s.md" % (RND, V)), "w").write('''# %s -- Replacer.run on config 5 (%s), rocprofv3 --kernel-trace --stats
+if os.path.exists(os.path.join(D, "bench_cfg5_replacer_50k_1GiB.log")) and os.path.getsize(os.path.join(D, "bench_cfg5_replacer_50k_1GiB.log")):
+    k5 = open(os.path.join(D, "kt5_summary.md")).read().split("| kernel | grid")[0].rstrip()
+    r5 = line("bench_cfg5_replacer_50k_1GiB.log")
+    open(os.path.join(P, "%s_replacer_trace_%s.md" % (RND, V)), "w").write('''# %s -- Replacer.run on config 5 (%s), rocprofv3 --kernel-trace --stats
 
-Command: `rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg5_replacer_50k_1GiB --steps 3 --warmup 1 --no-cpu-baseline`
-(16384 x 64 KiB, 50 000 pairs; every step runs ~160 passes in two concurrent haystack groups; the trace covers the device-resident steps, the
-host-result steps (am_replacer_run_batch: the `__amd_rocclr_copyBuffer` rows are their device-to-host copies) and one profiled step)
+    Command: `rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg5_replacer_50k_1GiB --steps 3 --warmup 1 --no-cpu-baseline`
+    (16384 x 64 KiB, 50 000 pairs; every step runs ~160 passes in two concurrent haystack groups; the trace covers the device-resident steps, the
+    host-result steps (am_replacer_run_batch: the `__amd_rocclr_copyBuffer` rows are their device-to-host copies) and one profiled step)
 
-%s
+    %s
 
-bench.py line without the profiler (profiles/history/%s_%s_bench_cfg5_replacer_50k_1GiB.log):
+    bench.py line without the profiler (profiles/history/%s_%s_bench_cfg5_replacer_50k_1GiB.log):
 
-```
-%s
-```
-''' % (RND, V, k5, RND, V, json.dumps(r5)))
+    ```
+    %s
+    ```
+    ''' % (RND, V, k5, RND, V, json.dumps(r5)))
+
 print("VALU/chunk %.0f SALU %.0f LDS %.1f traffic upper %.2fx split %.2fx" % (vals["SQ_INSTS_VALU"] / chunks, vals["SQ_INSTS_SALU"] / chunks, vals["SQ_INSTS_LDS"] / chunks, upper / scanned, split / scanned))
