@@ -678,7 +678,7 @@ def test_replacer_record_parallel_fold(monkeypatch):
     got = r.run(periodic)
     dt = time.perf_counter() - t0
     assert got == b"c" * (1 << 19) + b"b" + b"c" * 2048 + b"a"
-    assert dt < 0.3, dt
+    assert dt < 0.6, dt                              # one thread per run took > 1 s
 
 
 def test_runtime_knobs_user_stream_and_profiling():
