@@ -789,7 +789,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     // repeated once with the exact number of blocks.
     auto body_sf = [&]() -> int {
         AM_TRY(b->unit_first.ensure(p.n_units * sizeof(uint32_t)));
-        uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units);
+        uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);
         if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
         if (const char* env = std::getenv("AM_SF_POOL_BLOCKS")) { long v = std::atol(env); if (v > 0) want_blocks = (uint64_t)v; }   // tests: force the overflow/retry path
         for (int attempt = 0; attempt < 3; attempt++) {
@@ -813,7 +813,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
             HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64 + pool_grant_slack(p.n_cu, p.n_units); continue; }    // pool too small: ctrl[0] = blocks actually needed
+            if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024); continue; }    // pool too small: ctrl[0] = blocks actually needed
             *n_scan = total;
             if (total == 0) return AM_OK;
             AM_TRY(sink(total, &d_records));
@@ -1226,7 +1226,7 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
     size_t tmp_bytes = 0;
     if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
-    const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8 + pool_grant_slack(p.n_cu, p.n_units);          // ceil(records / 64) per unit, records <= bytes; + the grants' unused remainders
+    const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);          // ceil(records / 64) per unit, records <= bytes; + the grants' unused remainders
     if (want_blocks >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
     AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
     AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
@@ -1306,7 +1306,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         ~Return()
         {
             if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
-            if (sp->device_bytes() > (512ull << 20)) { delete sp; return; }
+            if (sp->device_bytes() > (2048ull << 20)) { delete sp; return; }      // keep workspaces of up to 2 GiB between calls
             RpSession* old = nullptr;
             { std::lock_guard<std::mutex> lk(r->session_mu);
               const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
@@ -1576,7 +1576,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         ~Return()
         {
             if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
-            if (sp->device_bytes() > (512ull << 20)) { delete sp; return; }
+            if (sp->device_bytes() > (2048ull << 20)) { delete sp; return; }      // keep workspaces of up to 2 GiB between calls
             RpSession* old = nullptr;
             { std::lock_guard<std::mutex> lk(r->session_mu);
               const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
@@ -1830,13 +1830,17 @@ static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_
         gs.push_back(std::move(gp));
     }
     std::vector<std::thread> pool;
-    for (size_t g = 0; g < G; g++)
-        pool.emplace_back([&, g] {
-            Group& x = *gs[g];
-            x.rc = finish_batch(&x.b);
-            if (x.rc == AM_OK) x.rc = replacer_run(r, &x.b, max_length, &x.part);
-            if (x.rc != AM_OK) x.err = am_last_error();
-        });
+    auto work = [&](size_t g) {
+        Group& x = *gs[g];
+        x.rc = finish_batch(&x.b);
+        if (x.rc == AM_OK) x.rc = replacer_run(r, &x.b, max_length, &x.part);
+        if (x.rc != AM_OK) x.err = am_last_error();
+    };
+    // every group on a thread of its own (letting the calling thread take one of them serialised the two: 73 ms instead of 38, measured)
+    for (size_t g = 0; g < G; g++) {
+        try { pool.emplace_back(work, g); }
+        catch (const std::exception&) { work(g); }          // no thread to be had: this group runs here (nothing may throw across the C ABI)
+    }
     for (auto& t : pool) t.join();
     res->text.assign(n_hay, am_replaced::Item());
     res->just.assign(n_hay, 1);

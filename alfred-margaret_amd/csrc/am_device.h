@@ -40,7 +40,14 @@ struct ScanOut {
 constexpr uint32_t kPoolBlock = 64;   // records per pool block (1 KiB)
 constexpr uint32_t kSfBlockGrant = 32; // pool blocks a k_sf wavefront takes per atomic
 // blocks that may stay unused in the wavefronts' grants: one grant per wavefront that can be resident (<= 32 per CU), never more than units
-inline uint64_t pool_grant_slack(int n_cu, uint64_t n_units) { uint64_t w = (uint64_t)n_cu * 32u; if (w > n_units) w = n_units; return w * kSfBlockGrant; }
+// (wavefronts launched = 16 per workgroup, one workgroup per CU -- two when the filter is small -- and never more workgroups than 16-unit groups)
+inline uint64_t pool_grant_slack(int n_cu, uint64_t n_units, bool two_per_cu)
+{
+    uint64_t w = (uint64_t)n_cu * (two_per_cu ? 32u : 16u);
+    const uint64_t need = (n_units + 15u) / 16u * 16u;
+    if (w > need) w = need;
+    return w * kSfBlockGrant;
+}
 
 hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st);
 uint64_t sf_chunks(const BatchView& b);
