@@ -938,6 +938,7 @@ extern "C" void am_matches_free(am_matches* m)
 // ------------------------------------------------------------------ UTF-8 helpers
 
 extern "C" uint32_t am_lower_code_point(uint32_t cp) { return cp < 128 ? fold_byte(cp) : simple_lower(cp); }
+extern "C" uint32_t am_unicode_version(void) { return kUnicodeLowerVersion; }
 
 extern "C" size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap)
 {

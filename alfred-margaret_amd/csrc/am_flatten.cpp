@@ -14,7 +14,7 @@
 
 namespace am {
 
-// ------------------------------------------------------------------ simple lowercase (Unicode 13.0)
+// ------------------------------------------------------------------ simple lowercase (Unicode 14.0)
 
 namespace {
 struct LowerPair { uint32_t from, to; };
@@ -34,7 +34,7 @@ const std::unordered_multimap<uint32_t, uint32_t>& inverse_lower()
 }
 }  // namespace
 
-// Utf8.hs:145-151 lowerCodePoint; non-ASCII = Data.Char.toLower (simple mapping, Unicode 13.0 here).
+// Utf8.hs:145-151 lowerCodePoint; non-ASCII = Data.Char.toLower (simple mapping, Unicode 14.0 here: kUnicodeLowerVersion).
 uint32_t simple_lower(uint32_t cp)
 {
     size_t lo = 0, hi = kNLower;
@@ -162,7 +162,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 
     ImageHeader h;
     std::memset(&h, 0, sizeof(h));
-    h.magic = kImageMagic; h.version = kImageVersion; h.case_mode = (uint32_t)case_mode;
+    h.magic = kImageMagic; h.version = kImageVersion; h.case_mode = (uint32_t)case_mode; h.flags = kUnicodeLowerVersion;
     h.n_states = (uint32_t)S; h.max_needle_cps = max_needle_cps; h.root_vlen = vlen[0];
     {
         const uint64_t warm = 4ull * (max_needle_cps ? max_needle_cps : 1) + 4;
@@ -707,6 +707,7 @@ bool image_sections_in_bounds(const ImageHeader& h)
     const uint64_t T = h.total_bytes;
     auto ok = [T](uint64_t off, uint64_t count, uint64_t elem) { return off <= T && count <= (T - off) / elem; };
     if (h.magic != kImageMagic || h.version != kImageVersion || h.case_mode > 1 || T < sizeof(ImageHeader)) return false;
+    if ((h.flags & 0xFFFFu) != kUnicodeLowerVersion) return false;      // lower-cased with another Unicode version's table: its IgnoreCase edges differ
     bool good = ok(h.off_transitions, h.n_transitions, 8) && ok(h.off_offsets, (uint64_t)h.n_states + 1, 4) && ok(h.off_root_ascii, 128, 8) &&
                 ok(h.off_canon, h.n_states, 4) && ok(h.off_vlen, h.n_states, 4) && ok(h.off_lower, h.n_lower, 4) &&
                 h.ac_goto_log2_cap >= 4 && h.ac_goto_log2_cap <= 31 && ok(h.off_goto, 1ull << h.ac_goto_log2_cap, 16) && ok(h.off_fail, h.n_states, 4);

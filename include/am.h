@@ -261,10 +261,13 @@ int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst
 int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out);
 
 /* ---- UTF-8 helpers on the path -------------------------------------------------------------------
- * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151), simple mapping, Unicode 13.0.
+ * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151), simple mapping of Unicode 14.0
+ * (am_unicode_version() = 0x0E00: major << 8 | minor; the flattened image records it, and an image made with another
+ * table is refused).  The reference uses GHC base's Data.Char.toLower, whose Unicode version follows the compiler.
  * am_unlower_code_point: Utf8.unlowerCodePoint (src/Data/Text/Utf8/Unlower.hs:26-28) as an ascending set;
  * returns the set size (may exceed cap). */
 uint32_t am_lower_code_point(uint32_t cp);
+uint32_t am_unicode_version(void);
 size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
 
 /* ---- runtime knobs ------------------------------------------------------------------------------ */

@@ -11,9 +11,11 @@
  * this restatement is pinned by the reference's own known-answer tests, committed as
  * data under tests/golden/ (tests/Data/Text/AhoCorasickSpec.hs, Utf8Spec.hs and
  * README.md of the reference; see tests/golden/README.md for the line numbers).
- * Simple lowercase mapping: Unicode 13.0 table (tools/gen_unicode_lower.py);
- * the reference defers to GHC base's Data.Char.toLower, whose Unicode version is
- * not fixed by the reference -> code points added after 13.0: parity unpinned.
+ * Simple lowercase mapping: Unicode 14.0 table written by tools/gen_unicode_lower_node.js from
+ * node/ICU data -- a different program and a different source than the product's table
+ * (tools/gen_unicode_lower.py, Python's unicodedata; tests/test_unicode_lower.py compares them).
+ * The reference defers to GHC base's Data.Char.toLower, whose Unicode version is not fixed by
+ * the reference -> code points added after 14.0 (Unicode 16's Garay etc.): parity unpinned.
  *
  * Every function cites the reference lines it follows, relative to /root/reference.
  * Values `v` of the reference's `AcMachine v` are restated as uint32 handles that

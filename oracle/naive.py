@@ -12,13 +12,21 @@ benchmark/naive.py (count occurrences per needle) and the `all isInfixOf` proper
 quirk, Automaton.hs:502-503/519 + :373-376, is pinned separately by the golden tests).
 
 Lower-casing uses Python's own str.lower() per code point (U+0130 -> U+0069 special-cased:
-simple mapping), i.e. it is also independent of the generated C table.
+simple mapping), i.e. it is also independent of the generated C table; the 40 case pairs Unicode 14.0
+added (this Python knows 13.0) come from the data file tests/golden/unicode14_lower_additions.json.
 """
+import json
+import os
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "unicode14_lower_additions.json")) as _f:
+    _ADDED = {chr(a): chr(b) for a, b in json.load(_f)["pairs"]}
 
 
 def _lower_cp(ch):
     if ch == "İ":
         return "i"
+    if ch in _ADDED:
+        return _ADDED[ch]
     low = ch.lower()
     return low if len(low) == 1 else ch
 

@@ -71,7 +71,8 @@ def test_lower_code_point_vs_unlower_table(golden):
 
 def test_lower_code_point_all_unicode_matches_python():
     # Utf8Spec.hs:45-48 "lowerCodePoint is equivalent to Char.toLower on all of Unicode",
-    # with python's Unicode 13 simple mapping standing in for Char.toLower.
+    # with python's Unicode 13 simple mapping + the 40 pairs Unicode 14 added (tests/golden/unicode14_lower_additions.json)
+    # standing in for Char.toLower.
     for cp in range(0x110000):
         if 0xD800 <= cp <= 0xDFFF:
             continue
