@@ -94,6 +94,9 @@ ABI = {
     "am_multi_count": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(Slice), _sz, _vp, _u64p]),
     "am_multi_run": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp), C.POINTER(_sz)]),
     "am_multi_matches_free": (None, [_vp]),
+    "am_multi_batch_upload": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp)]),
+    "am_multi_count_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u64p, _u64p]),
+    "am_multi_run_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u64p]),
     "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
     "am_unicode_version": (C.c_uint32, []),
     "am_unlower_code_point": (_sz, [C.c_uint32, _vp, _sz]),

@@ -410,6 +410,16 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
     ImageHeader h;
     std::memcpy(&h, image, sizeof(h));
     if (!image_sections_in_bounds(h) || h.total_bytes > nbytes) return fail(AM_ERR_INVALID, "not an automaton image (magic, version or section bounds)");
+    // the validation below reads the sections through their own types (16-byte vectors, 64-byte lines): a caller's buffer need not
+    // be aligned for that, so a misaligned one is copied first
+    std::vector<uint64_t> aligned_copy;
+    if (((uintptr_t)image & 63u) != 0) {
+        try { aligned_copy.resize(((size_t)h.total_bytes + 7) / 8 + 8); } catch (const std::exception&) { return fail(AM_ERR_OOM, "no memory for an aligned copy of the image"); }
+        uint8_t* base = (uint8_t*)aligned_copy.data();
+        base += (64 - ((uintptr_t)base & 63u)) & 63u;
+        std::memcpy(base, image, (size_t)h.total_bytes);
+        image = base;
+    }
     if (image_checksum((const uint8_t*)image + sizeof(h), (size_t)h.total_bytes - sizeof(h)) != h.checksum) return fail(AM_ERR_INVALID, "automaton image is corrupt (checksum)");
     { std::string why; if (!image_body_valid((const uint8_t*)image, h, why)) return fail(AM_ERR_INVALID, why); }       // the checksum is no proof of origin: check what the kernels will follow
     int dev = 0;
@@ -432,6 +442,9 @@ static int finish_batch(am_batch* b)
 {
     b->hidx_ready = false;
     if (b->total > 0) AM_TRY(b->hidx.ensure(((b->total >> kHidxShift) + 2) * sizeof(uint32_t)));
+    // the batch's block of counters is allocated HERE, once, before the batch is visible to other threads: make_plan reads its
+    // address without the batch lock, so it must never be re-allocated later (every later ensure(64) is a no-op)
+    AM_TRY(b->small.ensure(64));
     return AM_OK;
 }
 
@@ -621,7 +634,7 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     p.nothing = b->total == 0 || no_edges || (p.use_sf && p.f->h.sf_tiers == 0 && !p.dense);      // dense: first code points still report the root's values
     p.unit_chunks = p.use_sf ? sf_unit_chunks(p.bv, g_rt.dev[b->dev].n_cu) : 0;
     p.next_unit = nullptr;
-    if (p.use_sf) { ON_DEVICE(b->dev); AM_TRY(b->small.ensure(64)); p.next_unit = (uint32_t*)b->small.p + 8; }
+    if (p.use_sf) { if (!b->small.p) return fail(AM_ERR_INVALID, "batch without its counter block (not made by am_batch_upload / am_batch_from_device)"); p.next_unit = (uint32_t*)b->small.p + 8; }
     p.n_cu = g_rt.dev[b->dev].n_cu;
     p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
     if (p.n_units >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "batch too large for one launch; split it");
@@ -651,7 +664,7 @@ int build_hidx(const Plan& p, am_batch* b, hipStream_t st)
 
 }  // namespace
 
-static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out);
+static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock = false);
 
 // count / containsAny of an automaton with the empty needle on the suffix-filter route: a record at almost every position, so
 // the records are made (k_sf + dense pass) and reduced
@@ -659,11 +672,11 @@ static int reduce_dense(const am_automaton* a, int case_mode, am_batch* b, uint6
 {
     uint64_t n_rec = 0;
     auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(b->dense_out.ensure(n * sizeof(Record))); *ptr = (Record*)b->dense_out.p; return AM_OK; };
-    AM_TRY(run_records(a, case_mode, b, sink, &n_rec));
-    if (n_rec == 0) return AM_OK;
     const Flavor* f = nullptr;
     AM_TRY(prepare(a, case_mode, &f));
-    std::lock_guard<std::mutex> lk(b->mu);
+    std::lock_guard<std::mutex> lk(b->mu);          // ONE lock over the scan and the reduction: b->dense_out must not be refilled by another thread in between
+    AM_TRY(run_records(a, case_mode, b, sink, &n_rec, true));
+    if (n_rec == 0) return AM_OK;
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     AM_TRY(b->small.ensure(64));
@@ -739,12 +752,13 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
 
 // The whole scan: leaves every record of the batch, sorted by (haystack, end_pos), in device memory
 // obtained from `sink(total, &ptr)` (called once, only when total > 0); *n_out = number of records.
-static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out)
+static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock)
 {
     *n_out = 0;
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
     if (p.nothing) return AM_OK;
-    std::lock_guard<std::mutex> lk(b->mu);
+    std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
+    if (!have_lock) lk.lock();
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     // automata with the empty needle: k_sf's (sparse) records go to a buffer of the batch, the dense pass writes the result
@@ -1563,7 +1577,8 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         // cuts every text into 16-KiB tiles.  One 1-MB document with half a million replacements per pass: 472 ms vs 90 ms (measured).
         const bool many_documents = n_hay >= 64 && in->total / n_hay <= (1ull << 20);
         const bool pt = r->case_mode == AM_CASE_SENSITIVE && fl->h.sf_enabled && fl->h.root_vlen == 0 && r->a->kernel_pref != 1 &&
-                        std::getenv("AM_RP_FULL_SCANS") == nullptr && std::getenv("AM_RP_SPLICE") == nullptr && (many_documents || std::getenv("AM_RP_PIECES") != nullptr);
+                        std::getenv("AM_RP_FULL_SCANS") == nullptr && std::getenv("AM_RP_SPLICE") == nullptr && (many_documents || std::getenv("AM_RP_PIECES") != nullptr) &&
+                        n_hay < (1u << 24) && in->total < (1ull << 40);        // RpWin::src_abs packs (haystack index << 40 | start): beyond that the splicing loop runs
         if (pt) return replacer_run_pt(r, in, max_length, res, fl);
     }
     ON_DEVICE(in->dev);
@@ -1831,9 +1846,25 @@ static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_
         gs.push_back(std::move(gp));
     }
     std::vector<std::thread> pool;
+    // The group threads launch on their own streams.  Work the caller queued on ITS stream before this call (a producer still
+    // writing the text of an am_batch_from_device batch) must come first: an event on the caller's stream, waited for by every group stream.
+    hipEvent_t caller_done = nullptr;
+    {
+        hipStream_t caller_st; AM_TRY(get_stream(in->dev, &caller_st));
+        HIP_TRY(hipEventCreateWithFlags(&caller_done, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(caller_done, caller_st);
+        if (e != hipSuccess) { (void)hipEventDestroy(caller_done); return fail(AM_ERR_HIP, std::string("hipEventRecord: ") + hipGetErrorString(e)); }
+    }
     auto work = [&](size_t g) {
         Group& x = *gs[g];
-        x.rc = finish_batch(&x.b);
+        OnDevice od(in->dev);                                   // a fresh thread's current device is 0: the group's buffers and launches belong to the batch's device
+        x.rc = od.rc;
+        if (x.rc == AM_OK) x.rc = finish_batch(&x.b);
+        if (x.rc == AM_OK) {
+            hipStream_t st;
+            x.rc = get_stream(in->dev, &st);
+            if (x.rc == AM_OK && hipStreamWaitEvent(st, caller_done, 0) != hipSuccess) x.rc = fail(AM_ERR_HIP, "hipStreamWaitEvent failed");
+        }
         if (x.rc == AM_OK) x.rc = replacer_run(r, &x.b, max_length, &x.part);
         if (x.rc != AM_OK) x.err = am_last_error();
     };
@@ -1843,6 +1874,7 @@ static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_
         catch (const std::exception&) { work(g); }          // no thread to be had: this group runs here (nothing may throw across the C ABI)
     }
     for (auto& t : pool) t.join();
+    (void)hipEventDestroy(caller_done);
     res->text.assign(n_hay, am_replaced::Item());
     res->just.assign(n_hay, 1);
     int rc = AM_OK;

@@ -656,8 +656,31 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         if (canon[s] >= S || fail[s] >= S) { err = "image: canon/fail state out of range"; return false; }
     }
     for (uint64_t i = 0; i < h.n_transitions; i++) if ((uint32_t)(tr[i] >> 32) >= S) { err = "image: transition target out of range"; return false; }
+    {
+        // the 128 root entries k_ac and ends_first_code_point follow (am_image.h ac_step): a goto target or the wildcard
+        const uint64_t* root = (const uint64_t*)(img + h.off_root_ascii);
+        for (uint32_t c = 0; c < 128; c++) if (!(root[c] & kWildcard) && (uint32_t)(root[c] >> 32) >= S) { err = "image: root table target out of range"; return false; }
+        // every fallback chain must reach the root, or ac_step never returns: colour the states along each chain (0 = unseen, 1 = on
+        // the chain being followed, 2 = known to end at the root)
+        if (S && fail[0] != 0) { err = "image: the root's fallback is not the root"; return false; }
+        std::vector<uint8_t> colour(S, 0);
+        std::vector<uint32_t> chain;
+        if (S) colour[0] = 2;
+        for (uint32_t s0 = 1; s0 < S; s0++) {
+            chain.clear();
+            uint32_t s = s0;
+            while (colour[s] == 0) { colour[s] = 1; chain.push_back(s); s = fail[s]; }
+            if (colour[s] == 1) { err = "image: fallback chain does not end at the root"; return false; }
+            for (uint32_t c : chain) colour[c] = 2;
+        }
+    }
     const u32x4* go = (const u32x4*)(img + h.off_goto);
-    for (uint64_t i = 0; i < (1ull << h.ac_goto_log2_cap); i++) if (go[i].w && (go[i].x >= S || go[i].z >= S)) { err = "image: goto table entry out of range"; return false; }
+    bool goto_has_empty = false;
+    for (uint64_t i = 0; i < (1ull << h.ac_goto_log2_cap); i++) {
+        if (!go[i].w) goto_has_empty = true;
+        else if (go[i].x >= S || go[i].z >= S) { err = "image: goto table entry out of range"; return false; }
+    }
+    if (!goto_has_empty) { err = "image: goto table without an empty slot"; return false; }      // the open-addressing probe must terminate
     if (!h.sf_enabled) return true;
     const SfNode* nodes = (const SfNode*)(img + h.off_nodes);
     const SfEdge* edges = (const SfEdge*)(img + h.off_edges);

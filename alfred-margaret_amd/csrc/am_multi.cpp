@@ -206,53 +206,109 @@ extern "C" int am_multi_local_devices(const am_multi* m) { return m ? (int)m->de
 extern "C" int am_multi_world_size(const am_multi* m) { return m ? m->world : 0; }
 extern "C" int am_multi_device(const am_multi* m, int i) { return (m && i >= 0 && i < (int)m->devs.size()) ? m->devs[i] : -1; }
 
-// The flattened automaton over xGMI: size first (8 bytes), then the blob, both with ncclBroadcast from `root`.
+namespace {
+// Collectives must be entered by EVERY rank, whatever went wrong locally: a rank that returns before the matching
+// ncclBroadcast / ncclAllReduce leaves the others blocked for ever.  So local failures are carried INTO the
+// collective as a flag and the decision is taken afterwards, identically on every rank; and a group that was started
+// is always ended.
+template <class F> ncclResult_t in_group(int n, F f)
+{
+    ncclResult_t first = ncclGroupStart();
+    if (first != ncclSuccess) return first;
+    for (int i = 0; i < n; i++) { const ncclResult_t r = f(i); if (r != ncclSuccess && first == ncclSuccess) first = r; }
+    const ncclResult_t e = ncclGroupEnd();
+    return first != ncclSuccess ? first : e;
+}
+
+// values[i * count .. +count) of local device i are summed over all devices; word `count` of every row is the error flag:
+// local_rc != AM_OK contributes 1.  Returns local_rc if that failed, the collective's own error, or AM_ERR_HIP "a peer failed".
+int allreduce_flagged(am_multi* m, uint64_t* values, size_t count, int local_rc)
+{
+    const int n = (int)m->devs.size();
+    DeviceGuard guard;
+    const std::string local_msg = local_rc != AM_OK ? std::string(am_last_error()) : std::string();
+    std::vector<uint64_t> row(count + 1);
+    int rc = AM_OK;
+    for (int i = 0; i < n && rc == AM_OK; i++) {
+        for (size_t k = 0; k < count; k++) row[k] = local_rc == AM_OK ? values[(size_t)i * count + k] : 0;
+        row[count] = local_rc == AM_OK ? 0 : 1;
+        hipError_t e = hipSetDevice(m->devs[i]);
+        if (e == hipSuccess) e = hipMemcpy(m->small[i], row.data(), (count + 1) * 8, hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = abi_fail(AM_ERR_HIP, std::string("all-reduce staging: ") + hipGetErrorString(e));      // still enter the collective below
+    }
+    const ncclResult_t r = in_group(n, [&](int i) { return ncclAllReduce(m->small[i], m->small[i], count + 1, ncclUint64, ncclSum, m->comms[i], m->streams[i]); });
+    if (r != ncclSuccess && rc == AM_OK) rc = abi_fail(AM_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    if (r == ncclSuccess) { const int s = sync_all(m); if (rc == AM_OK) rc = s; }
+    uint64_t failed = 0;
+    for (int i = 0; i < n && rc == AM_OK; i++) {
+        hipError_t e = hipSetDevice(m->devs[i]);
+        if (e == hipSuccess) e = hipMemcpy(row.data(), m->small[i], (count + 1) * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { rc = abi_fail(AM_ERR_HIP, std::string("all-reduce result: ") + hipGetErrorString(e)); break; }
+        for (size_t k = 0; k < count; k++) values[(size_t)i * count + k] = row[k];
+        failed = row[count];
+    }
+    if (local_rc != AM_OK) return abi_fail(local_rc, local_msg);
+    if (rc != AM_OK) return rc;
+    if (failed) return abi_fail(AM_ERR_HIP, std::to_string(failed) + " device(s) of the job failed before the collective; see their own error messages");
+    return AM_OK;
+}
+}  // namespace
+
+// The flattened automaton over xGMI: size first (8 bytes; 0 = the root could not produce its image), then an all-reduced
+// "everybody has room" flag, then the blob, then an all-reduced "everybody attached" flag -- so every rank takes part in
+// every collective and all ranks return the same verdict.
 extern "C" int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out)
 {
     if (!m || !autos_out) return abi_fail(AM_ERR_INVALID, "null arguments");
-    if (root < 0 || root >= m->world) return abi_fail(AM_ERR_INVALID, "root out of range");
+    if (root < 0 || root >= m->world) return abi_fail(AM_ERR_INVALID, "root out of range");       // same arguments on every rank: all return here
     const int n = (int)m->devs.size();
     for (int i = 0; i < n; i++) autos_out[i] = nullptr;
     const int root_local = root - m->first_rank;                  // index of the root among this process's devices, if it is here
     const bool have_root = root_local >= 0 && root_local < n;
-    if (have_root && !a) return abi_fail(AM_ERR_INVALID, "the root needs the automaton");
     DeviceGuard guard;
+    int rc = AM_OK;
     uint64_t nbytes = 0;
     if (have_root) {
         size_t sz = 0;
-        HIP_TRY(hipSetDevice(m->devs[root_local]));
-        AM_TRY(am_automaton_image_size(a, case_mode, &sz));
-        nbytes = sz;
-        HIP_TRY(hipMemcpy(m->small[root_local], &nbytes, 8, hipMemcpyHostToDevice));
+        if (!a) rc = abi_fail(AM_ERR_INVALID, "the root needs the automaton");
+        else if (hipSetDevice(m->devs[root_local]) != hipSuccess) rc = abi_fail(AM_ERR_HIP, "hipSetDevice(root) failed");
+        else rc = am_automaton_image_size(a, case_mode, &sz);
+        nbytes = rc == AM_OK ? sz : 0;                             // 0 tells every rank that the root failed
+        if (hipSetDevice(m->devs[root_local]) != hipSuccess || hipMemcpy(m->small[root_local], &nbytes, 8, hipMemcpyHostToDevice) != hipSuccess) {
+            if (rc == AM_OK) rc = abi_fail(AM_ERR_HIP, "automaton broadcast: could not stage the image size");   // the peers then receive whatever small[] held: the flag round below catches it
+        }
     }
-    NCCL_TRY(ncclGroupStart());
-    for (int i = 0; i < n; i++) NCCL_TRY(ncclBroadcast(m->small[i], m->small[i], 8, ncclUint8, root, m->comms[i], m->streams[i]));
-    NCCL_TRY(ncclGroupEnd());
-    AM_TRY(sync_all(m));
-    HIP_TRY(hipSetDevice(m->devs[0]));
-    HIP_TRY(hipMemcpy(&nbytes, m->small[0], 8, hipMemcpyDeviceToHost));
-    if (nbytes < 64 || nbytes > (1ull << 40)) return abi_fail(AM_ERR_HIP, "automaton broadcast: implausible image size received");
+    {
+        const ncclResult_t r = in_group(n, [&](int i) { return ncclBroadcast(m->small[i], m->small[i], 8, ncclUint8, root, m->comms[i], m->streams[i]); });
+        if (r != ncclSuccess && rc == AM_OK) rc = abi_fail(AM_ERR_HIP, std::string("ncclBroadcast(size): ") + ncclGetErrorString(r));
+        if (r == ncclSuccess) { const int s = sync_all(m); if (rc == AM_OK) rc = s; }
+    }
+    if (rc == AM_OK && !have_root) {
+        if (hipSetDevice(m->devs[0]) != hipSuccess || hipMemcpy(&nbytes, m->small[0], 8, hipMemcpyDeviceToHost) != hipSuccess) rc = abi_fail(AM_ERR_HIP, "automaton broadcast: could not read the image size");
+    }
+    if (rc == AM_OK && nbytes == 0) rc = abi_fail(AM_ERR_HIP, "automaton broadcast: the root rank could not produce its image");
+    if (rc == AM_OK && (nbytes < 64 || nbytes > (1ull << 40))) rc = abi_fail(AM_ERR_HIP, "automaton broadcast: implausible image size received");
     std::vector<void*> blob(n, nullptr);
-    auto release = [&]() { for (int i = 0; i < n; i++) if (blob[i]) { (void)hipSetDevice(m->devs[i]); (void)hipFree(blob[i]); } };
-    for (int i = 0; i < n; i++) {
+    auto release = [&]() { for (int i = 0; i < n; i++) if (blob[i]) { (void)hipSetDevice(m->devs[i]); (void)hipFree(blob[i]); blob[i] = nullptr; } };
+    for (int i = 0; i < n && rc == AM_OK; i++) {
         hipError_t e = hipSetDevice(m->devs[i]);
         if (e == hipSuccess) e = hipMalloc(&blob[i], nbytes);
-        if (e != hipSuccess) { release(); return abi_fail(AM_ERR_OOM, std::string("hipMalloc(image copy): ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) rc = abi_fail(AM_ERR_OOM, std::string("hipMalloc(image copy): ") + hipGetErrorString(e));
     }
-    int rc = AM_OK;
-    if (have_root) { (void)hipSetDevice(m->devs[root_local]); rc = am_automaton_image_copy(a, case_mode, blob[root_local], nbytes); }
-    if (rc == AM_OK) {
-        ncclResult_t r = ncclGroupStart();
-        for (int i = 0; i < n && r == ncclSuccess; i++) r = ncclBroadcast(blob[i], blob[i], nbytes, ncclUint8, root, m->comms[i], m->streams[i]);
-        if (r == ncclSuccess) r = ncclGroupEnd();
+    if (rc == AM_OK && have_root) { (void)hipSetDevice(m->devs[root_local]); rc = am_automaton_image_copy(a, case_mode, blob[root_local], nbytes); }
+    rc = allreduce_flagged(m, nullptr, 0, rc);                     // does every rank have the size, the room and (the root) the image?
+    if (rc != AM_OK) { release(); return rc; }                     // the same decision on every rank: nobody waits in the blob broadcast
+    {
+        const ncclResult_t r = in_group(n, [&](int i) { return ncclBroadcast(blob[i], blob[i], nbytes, ncclUint8, root, m->comms[i], m->streams[i]); });
         if (r != ncclSuccess) rc = abi_fail(AM_ERR_HIP, std::string("ncclBroadcast(image): ") + ncclGetErrorString(r));
+        else rc = sync_all(m);
     }
-    if (rc == AM_OK) rc = sync_all(m);
     for (int i = 0; i < n && rc == AM_OK; i++) {
         (void)hipSetDevice(m->devs[i]);
         rc = am_automaton_from_image(blob[i], nbytes, &autos_out[i]);        // copies the blob: the handle owns its image
     }
     release();
+    rc = allreduce_flagged(m, nullptr, 0, rc);                     // all ranks agree on whether the job has its automata
     if (rc != AM_OK) for (int i = 0; i < n; i++) { am_automaton_destroy(autos_out[i]); autos_out[i] = nullptr; }
     return rc;
 }
@@ -260,16 +316,9 @@ extern "C" int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, 
 extern "C" int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count)
 {
     if (!m || (count && !values)) return abi_fail(AM_ERR_INVALID, "null arguments");
-    if (count * 8 > kSmallBytes) return abi_fail(AM_ERR_INVALID, "too many values for one all-reduce (512 at most)");
+    if ((count + 1) * 8 > kSmallBytes) return abi_fail(AM_ERR_INVALID, "too many values for one all-reduce (511 at most)");
     if (count == 0) return AM_OK;
-    const int n = (int)m->devs.size();
-    DeviceGuard guard;
-    for (int i = 0; i < n; i++) { HIP_TRY(hipSetDevice(m->devs[i])); HIP_TRY(hipMemcpyAsync(m->small[i], values + (size_t)i * count, count * 8, hipMemcpyHostToDevice, m->streams[i])); }
-    NCCL_TRY(ncclGroupStart());
-    for (int i = 0; i < n; i++) NCCL_TRY(ncclAllReduce(m->small[i], m->small[i], count, ncclUint64, ncclSum, m->comms[i], m->streams[i]));
-    NCCL_TRY(ncclGroupEnd());
-    for (int i = 0; i < n; i++) { HIP_TRY(hipSetDevice(m->devs[i])); HIP_TRY(hipMemcpyAsync(values + (size_t)i * count, m->small[i], count * 8, hipMemcpyDeviceToHost, m->streams[i])); }
-    return sync_all(m);
+    return allreduce_flagged(m, values, count, AM_OK);
 }
 
 namespace {
@@ -304,7 +353,7 @@ extern "C" int am_multi_count(am_multi* m, am_automaton* const* autos, int case_
     if (!m || !autos || (n_hay && !hay)) return abi_fail(AM_ERR_INVALID, "null arguments");
     const int n = (int)m->devs.size();
     std::vector<uint64_t> totals(n, 0);
-    AM_TRY(per_device(m, [&](int i) -> int {
+    const int local = per_device(m, [&](int i) -> int {
         size_t lo, hi; block_of(n_hay, i, n, &lo, &hi);
         if (hi == lo) return AM_OK;
         am_batch* b = nullptr;
@@ -312,9 +361,55 @@ extern "C" int am_multi_count(am_multi* m, am_automaton* const* autos, int case_
         const int rc = am_count_batch(autos[i], case_mode, b, counts_out ? counts_out + lo : nullptr, &totals[i]);
         am_batch_destroy(b);
         return rc;
-    }));
-    AM_TRY(am_multi_allreduce_sum(m, totals.data(), 1));                  // final gather of match counts
+    });
+    AM_TRY(allreduce_flagged(m, totals.data(), 1, local));                // final gather of match counts; entered even after a local failure
     if (total_out) *total_out = totals[0];
+    return AM_OK;
+}
+
+extern "C" int am_multi_batch_upload(const am_multi* m, int local_device, const am_slice* hay, size_t n_hay, am_batch** out)
+{
+    if (!m || !out) return abi_fail(AM_ERR_INVALID, "null arguments");
+    *out = nullptr;
+    if (local_device < 0 || local_device >= (int)m->devs.size()) return abi_fail(AM_ERR_INVALID, "local_device out of range");
+    DeviceGuard guard;
+    HIP_TRY(hipSetDevice(m->devs[local_device]));
+    return am_batch_upload(hay, n_hay, out);                 // a batch lives on the device that is current when it is made
+}
+
+// Device-resident variants: batches[i] already lives on local device i (am_batch_upload / am_batch_from_device made there),
+// one host thread and stream per device, nothing crosses PCIe but the counts.  This is BASELINE configs[3] from C: every
+// GPU holds its share of the haystacks in HBM.
+extern "C" int am_multi_count_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, uint64_t* const* counts_out,
+                                    uint64_t* local_totals_out, uint64_t* total_out)
+{
+    if (!m || !autos || !batches) return abi_fail(AM_ERR_INVALID, "null arguments");
+    const int n = (int)m->devs.size();
+    std::vector<uint64_t> totals(n, 0);
+    const int local = per_device(m, [&](int i) -> int {
+        if (!batches[i]) return AM_OK;                                     // a device without work still takes part in the all-reduce
+        return am_count_batch(autos[i], case_mode, batches[i], counts_out ? counts_out[i] : nullptr, &totals[i]);
+    });
+    if (local_totals_out && local == AM_OK) for (int i = 0; i < n; i++) local_totals_out[i] = totals[i];
+    AM_TRY(allreduce_flagged(m, totals.data(), 1, local));
+    if (total_out) *total_out = totals[0];
+    return AM_OK;
+}
+
+extern "C" int am_multi_run_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, am_matches** results_out, uint64_t* total_records_out)
+{
+    if (!m || !autos || !batches || !results_out) return abi_fail(AM_ERR_INVALID, "null arguments");
+    const int n = (int)m->devs.size();
+    for (int i = 0; i < n; i++) results_out[i] = nullptr;
+    const int local = per_device(m, [&](int i) -> int {
+        if (!batches[i]) return AM_OK;
+        return am_run_batch(autos[i], case_mode, batches[i], &results_out[i]);      // the records stay in that device's HBM
+    });
+    std::vector<uint64_t> sizes(n, 0);
+    if (local == AM_OK) for (int i = 0; i < n; i++) sizes[i] = results_out[i] ? am_matches_size(results_out[i]) : 0;
+    const int rc = allreduce_flagged(m, sizes.data(), 1, local);
+    if (rc != AM_OK) { for (int i = 0; i < n; i++) { am_matches_free(results_out[i]); results_out[i] = nullptr; } return rc; }
+    if (total_records_out) *total_records_out = sizes[0];
     return AM_OK;
 }
 

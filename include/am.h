@@ -234,8 +234,8 @@ int am_multi_device(const am_multi* m, int i);     /* HIP device id of local dev
 /* ncclBroadcast of the flattened image of `a` (held by global rank `root`; NULL in processes that do not hold the
  * root) to every device; autos_out[i] = a handle on local device i attached to its copy (am_automaton_destroy each). */
 int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out);
-/* ncclAllReduce(sum) of `count` (<= 512) uint64 per device: values = local_devices x count, row i belongs to local
- * device i; every row holds the sums afterwards. */
+/* ncclAllReduce(sum) of `count` (<= 511) uint64 per device: values = local_devices x count, row i belongs to local
+ * device i; every row holds the sums afterwards (511 values at most). */
 int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count);
 /* This process's haystacks cut into contiguous blocks, one per local device (block i = haystacks [n*i/D, n*(i+1)/D)),
  * scanned concurrently; counts_out (nullable) per haystack in order; *total_out = sum over ALL devices (all-reduce):
@@ -245,6 +245,20 @@ int am_multi_count(am_multi* m, am_automaton* const* autos, int case_mode, const
  * (haystack = index into `hay`).  Free with am_multi_matches_free. */
 int am_multi_run(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, am_match** matches_out, size_t* n_out);
 void am_multi_matches_free(am_match* p);
+/* The same on DEVICE-RESIDENT batches: batches[i] lives on local device i (made there by am_batch_upload or
+ * am_batch_from_device; NULL = no work for that device); one host thread and stream per device; nothing but the counts
+ * leaves the devices.  BASELINE configs[3] (100 GiB of haystacks spread over the HBM of 8 GPUs) from a C / Haskell host.
+ *   am_multi_count_batch  counts_out (nullable; then one nullable array of batch-i-many counts per local device);
+ *                         local_totals_out (nullable): one sum per local device; *total_out: all devices (all-reduce)
+ *   am_multi_run_batch    results_out[i] = the records of batch i, left in device i's HBM (am_matches_free each);
+ *                         *total_records_out = records on all devices (all-reduce)
+ * Error behaviour of every am_multi_* collective: a failure on one device is carried into the collective as a flag, so
+ * every rank returns (none blocks) and every rank returns an error. */
+/* am_batch_upload onto local device i of m (a host without HIP of its own has no other way to choose the device). */
+int am_multi_batch_upload(const am_multi* m, int local_device, const am_slice* hay, size_t n_hay, am_batch** out);
+int am_multi_count_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, uint64_t* const* counts_out,
+                         uint64_t* local_totals_out, uint64_t* total_out);
+int am_multi_run_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, am_matches** results_out, uint64_t* total_records_out);
 
 /* ---- multi-GPU: move the flattened automaton between devices -----------------------------------
  * The image is one position-independent blob, so rank 0 flattens once and the blob is broadcast

@@ -1,7 +1,9 @@
 /* multi_driver.c -- a plain C consumer of the several-GPU entry points of include/am.h (am_multi_*): ONE process drives
  * every visible device (ncclCommInitAll inside libam), the automaton is broadcast over xGMI, a batch of haystacks is
  * scanned in contiguous blocks per device, counts are all-reduced, records concatenated in haystack order.
- *     devices <D>\n total <n>\n counts <c0> <c1> ...\n records <k>\n <haystack> <end_pos> <state>\n ...
+ * Then the same job with the haystacks RESIDENT on the devices (am_multi_batch_upload + am_multi_count_batch / am_multi_run_batch:
+ * records stay in each device's HBM, only counts are all-reduced) must give the same totals, counts and records: "resident ok".
+ *     devices <D>\n total <n>\n counts <c0> <c1> ...\n records <k>\n <haystack> <end_pos> <state>\n ... resident ok\n
  * The same output must come out for every number of devices (tests/test_multi.py compares it with the oracle).
  * Usage: multi_driver <transitions.u64> <offsets.u32> <root_ascii.u64> <values_len.u32> <haystacks> <n_hay> <case_mode> [n_devices]
  *        (the haystack file holds n_hay haystacks of equal length)
@@ -74,6 +76,39 @@ int main(int argc, char** argv)
     printf("\nrecords %llu\n", (unsigned long long)k);
     for (size_t i = 0; i < k; i++) printf("%u %llu %u\n", recs[i].haystack, (unsigned long long)recs[i].end_pos, recs[i].state);
 
+    /* device-resident: block i of the haystacks lives on device i; nothing but counts crosses PCIe in the timed calls */
+    {
+        am_batch** batches = (am_batch**)calloc((size_t)D, sizeof(am_batch*));
+        am_matches** res = (am_matches**)calloc((size_t)D, sizeof(am_matches*));
+        uint64_t** dcounts = (uint64_t**)calloc((size_t)D, sizeof(uint64_t*));
+        uint64_t* local_totals = (uint64_t*)calloc((size_t)D, sizeof(uint64_t));
+        for (int i = 0; i < D; i++) {
+            const size_t lo = n_hay * (size_t)i / (size_t)D, hi = n_hay * (size_t)(i + 1) / (size_t)D;
+            dcounts[i] = (uint64_t*)calloc(hi - lo + 1, sizeof(uint64_t));
+            if (hi > lo) check(am_multi_batch_upload(m, i, slices + lo, hi - lo, &batches[i]), "am_multi_batch_upload");
+        }
+        uint64_t total2 = 0, nrec2 = 0;
+        check(am_multi_count_batch(m, autos, case_mode, batches, dcounts, local_totals, &total2), "am_multi_count_batch");
+        check(am_multi_run_batch(m, autos, case_mode, batches, res, &nrec2), "am_multi_run_batch");
+        int ok = total2 == total && nrec2 == (uint64_t)k;
+        uint64_t sum_local = 0;
+        size_t at = 0;
+        for (int i = 0; i < D && ok; i++) {
+            const size_t lo = n_hay * (size_t)i / (size_t)D, hi = n_hay * (size_t)(i + 1) / (size_t)D;
+            sum_local += local_totals[i];
+            for (size_t j = lo; j < hi; j++) ok = ok && dcounts[i][j - lo] == counts[j];
+            const size_t kk = res[i] ? (size_t)am_matches_size(res[i]) : 0;
+            const am_match* src = kk ? am_matches_data(res[i]) : NULL;
+            for (size_t j = 0; j < kk && ok; j++)
+                ok = at + j < k && src[j].haystack + (uint32_t)lo == recs[at + j].haystack && src[j].end_pos == recs[at + j].end_pos && src[j].state == recs[at + j].state;
+            at += kk;
+        }
+        ok = ok && at == k && sum_local == total;
+        printf("resident %s\n", ok ? "ok" : "MISMATCH");
+        for (int i = 0; i < D; i++) { am_matches_free(res[i]); am_batch_destroy(batches[i]); free(dcounts[i]); }
+        free(batches); free(res); free(dcounts); free(local_totals);
+        if (!ok) return 1;
+    }
     am_multi_matches_free(recs);
     for (int i = 0; i < D; i++) am_automaton_destroy(autos[i]);
     am_automaton_destroy(a);

@@ -75,6 +75,8 @@ def test_multi_driver_same_answer_for_any_device_count(tmp_path, n_devices):
     recs = np.array([[int(x) for x in l.split()] for l in lines[4:4 + k]], dtype=np.int64).reshape(k, 3)
     got = expand_records(m.values_off(), m.values(), recs[:, 0], recs[:, 2], recs[:, 1])
     assert got == oracle_triples(m, 1, hays) and k > 100
+    # the device-resident entry points (am_multi_batch_upload / am_multi_count_batch / am_multi_run_batch) gave the same job the same answer
+    assert lines[4 + k] == "resident ok", lines[4 + k:]
 
 
 @pytest.mark.gpu
