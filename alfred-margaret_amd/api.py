@@ -583,6 +583,14 @@ class Splitter:
         return self.split_batch([text], True)[0]
 
 
+def image_version():
+    """kImageVersion of the flattened automaton image this build produces (csrc/am_image.h); read from the source so that
+    tools and bench.py can refuse measurements taken with another layout."""
+    import re
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "am_image.h")) as f:
+        return int(re.search(r"kImageVersion\s*=\s*(\d+)", f.read()).group(1))
+
+
 def lower_code_point(cp):
     return int(libam().am_lower_code_point(cp))
 

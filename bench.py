@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample (rank 0, N=1)")
     ap.add_argument("--no-cpu-all-cores", action="store_true", help="skip the all-host-cores leg of the CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive leg (am_count / am_run on pinned host slices)")
+    ap.add_argument("--h2d-mib", type=int, default=2048, help="haystack bytes of the PCIe-inclusive leg")
     ap.add_argument("--no-parity", action="store_true", help="skip the fold-checksum parity gate (kernel vs kernel on every haystack, oracle on a sample)")
     ap.add_argument("--parity-oracle-mib", type=int, default=1024, help="haystack bytes of rank 0's shard the oracle re-scans for the parity gate")
     ap.add_argument("--plants", type=int, default=1, help="needles planted per 1-KiB cell of the synthetic haystacks (robustness sweep: 0, 1, 8, 64; BASELINE = 1)")
@@ -104,9 +106,8 @@ def main():
     if world > 1 and not args.torch_collectives:
         # the product's own multi-GPU entry points (include/am.h am_multi_*): RCCL communicator over the ranks, automaton image
         # broadcast over xGMI and the final all-reduce of counts inside libam; torch.distributed only carries the 128-byte id.
-        # If that fails on any rank (it cannot be exercised on the 1-GPU development box), every rank falls back to the
-        # torch.distributed path below and the JSON line says so.
-        ok, handle0 = 1, handle
+        # A failure here is an ERROR (round 2 fell back to torch.distributed silently: the driver could have timed the wrong path
+        # without noticing); --torch-collectives selects the torch path explicitly, and the JSON line names what ran ("collectives").
         try:
             ident = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -124,13 +125,8 @@ def main():
             handle = C.c_void_p(autos[0])
             am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
         except Exception as e:                              # noqa: BLE001
-            ok = 0
-            print("rank %d: am_multi path failed (%s); falling back to torch.distributed collectives" % (rank, e), file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            multi, handle = None, handle0
-            args.torch_collectives = True
+            raise SystemExit("rank %d: libam's multi-GPU path (am_multi_create_rank / am_multi_broadcast_automaton) failed: %s\n"
+                             "No fallback is taken silently; re-run with --torch-collectives to time the torch.distributed path instead." % (rank, e))
     if world > 1 and multi is None:
         image = None
         if rank == 0:
@@ -181,13 +177,19 @@ def main():
     # values folded (= reference's countMatches) via the count-only entry point, summed over ranks
     total_values = C.c_uint64(0)
     t1 = time.perf_counter()
-    am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total_values)))
-    count_only_s = time.perf_counter() - t1
-    if multi is not None:                                    # final gather of match counts: ncclAllReduce inside libam
-        sums = np.array([int(total_values.value), n_records, n_bytes], dtype=np.uint64)
-        am.api.check(lib.am_multi_allreduce_sum(multi, sums.ctypes.data, 3))
-        total_matches, total_records, amdist_total_bytes = (int(x) for x in sums)
+    if multi is not None:
+        # the device-resident multi-GPU entry point: count on this rank's resident batch, ncclAllReduce of the totals inside libam
+        autos1, batches1 = (C.c_void_p * 1)(handle), (C.c_void_p * 1)(batch)
+        local_total, job_total = C.c_uint64(0), C.c_uint64(0)
+        am.api.check(lib.am_multi_count_batch(multi, autos1, case, batches1, None, C.byref(local_total), C.byref(job_total)))
+        count_only_s = time.perf_counter() - t1
+        sums = np.array([n_records, n_bytes], dtype=np.uint64)
+        am.api.check(lib.am_multi_allreduce_sum(multi, sums.ctypes.data, 2))
+        total_matches = int(job_total.value)
+        total_records, amdist_total_bytes = (int(x) for x in sums)
     else:
+        am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total_values)))
+        count_only_s = time.perf_counter() - t1
         total_matches, total_records, amdist_total_bytes = amdist.allreduce_sum([int(total_values.value), n_records, n_bytes], dev)
 
     parity = None
@@ -217,14 +219,17 @@ def main():
         # HBM traffic per launch: not measurable from inside this process; taken from the committed PMC
         # profile of the same kernel + workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected as
         # MI355X_MICROARCH.md prescribes), scaled to this launch's bytes.  null if there is no such profile.
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
-            if pt.get("workload") == args.workload and pt.get("kernel") == "k_" + kname.decode():
+            # a profile of another workload, kernel or image layout says nothing about this run: refuse it
+            if pt.get("workload") == args.workload and pt.get("kernel") == "k_" + kname.decode() and int(pt.get("image_version", -1)) == am.api.image_version():
                 traffic = int(pt["hbm_bytes_per_scanned_byte"] * n_bytes)
-        except (OSError, ValueError, KeyError):
-            traffic = None
+                traffic_source = "profiles/pmc_traffic.json (%s; rocprofv3 --pmc on a %s launch, 2 x FETCH_SIZE + WRITE_SIZE, scaled to this launch's bytes; NOT read in this run)" % (
+                    pt.get("profile", "?"), pt.get("launch", "?"))
+        except (OSError, ValueError, KeyError, TypeError):
+            traffic, traffic_source = None, None
         out = {
             "metric": "GiB/s haystack bytes scanned (match-emitting runLower, 100k-needle automaton)" if "cfg3" in args.workload
                       else "GiB/s haystack bytes scanned (match-emitting run)",
@@ -239,11 +244,14 @@ def main():
             "matches_per_step": total_matches, "records_per_step": total_records,
             "count_only_gibps": round(n_bytes / float(1 << 30) / count_only_s, 3),
             "roofline": {"bound": "hbm", "kernel": "k_" + kname.decode(), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes)},
+            "collectives": "none (1 GPU)" if world == 1 else ("libam-rccl" if multi is not None else "torch"),
         }
         if parity is not None:
             out["parity"] = parity
+        if world == 1 and not args.no_h2d:
+            out["h2d_inclusive"] = h2d_inclusive(args, w, handle, case, text, n_hay, lib)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib)
         print(json.dumps(out), flush=True)
@@ -318,17 +326,20 @@ def bench_single_process(args, w):
         am.api.check(lib.am_automaton_set_kernel(autos[i], args.kernel))
         texts.append((text, offs)); batches.append(b); sizes.append(n_bytes); hays.append(hi - lo)
     torch.cuda.set_device(0)
-    pool = ThreadPoolExecutor(N)
-
-    def one(i):
-        m = C.c_void_p()
-        am.api.check(lib.am_run_batch(autos[i], case, batches[i], C.byref(m)))       # makes device i current for this thread, own stream
-        n = int(lib.am_matches_size(m))
-        lib.am_matches_free(m)
-        return n
+    # The step is ONE call of the product's device-resident multi-GPU entry point: am_multi_run_batch scans batches[i] on device i
+    # (a host thread and a stream per device inside libam), leaves the records in each device's HBM and all-reduces their number.
+    autos_arr = (C.c_void_p * N)(*[autos[i] for i in range(N)])
+    batches_arr = (C.c_void_p * N)(*[b.value for b in batches])
 
     def step():
-        return list(pool.map(one, range(N)))
+        res = (C.c_void_p * N)()
+        total = C.c_uint64(0)
+        am.api.check(lib.am_multi_run_batch(multi, autos_arr, case, batches_arr, res, C.byref(total)))
+        recs = [int(lib.am_matches_size(res[i])) if res[i] else 0 for i in range(N)]
+        for i in range(N):
+            lib.am_matches_free(res[i])
+        assert sum(recs) == int(total.value)
+        return recs
 
     for _ in range(args.warmup):
         recs = step()
@@ -343,16 +354,11 @@ def bench_single_process(args, w):
     elapsed = time.perf_counter() - t0
     am.api.check(lib.am_profile_enable(0))
 
-    def count(i):
-        t = C.c_uint64(0)
-        am.api.check(lib.am_count_batch(autos[i], case, batches[i], None, C.byref(t)))
-        return int(t.value)
-
-    sums = np.zeros((N, 3), dtype=np.uint64)
-    for i, c in enumerate(pool.map(count, range(N))):
-        sums[i] = (c, recs[i], sizes[i])
-    am.api.check(lib.am_multi_allreduce_sum(multi, sums.ctypes.data, 3))          # ncclAllReduce over the N devices
-    total_matches, total_records, total_bytes = (int(x) for x in sums[0])
+    local_totals = (C.c_uint64 * N)()
+    job_total = C.c_uint64(0)
+    am.api.check(lib.am_multi_count_batch(multi, autos_arr, case, batches_arr, None, local_totals, C.byref(job_total)))   # ncclAllReduce over the N devices
+    total_matches, total_records, total_bytes = int(job_total.value), sum(recs), sum(sizes)
+    assert total_matches == sum(int(x) for x in local_totals)
     kname = b"sf" if args.kernel != 1 else b"ac"
     ms, launches = C.c_double(0), C.c_uint64(0)
     am.api.check(lib.am_profile_read(kname, C.byref(ms), C.byref(launches)))
@@ -367,12 +373,13 @@ def bench_single_process(args, w):
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "u8", "data": "synthetic",
         "config": {"workload": args.workload, "n_needles": len(needles), "case": "IgnoreCase" if case else "CaseSensitive", "haystacks_per_gpu": hays[0],
-                   "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": sizes[0], "parallelism": "haystack-sharded x%d, one process (am_multi_create: ncclCommInitAll, image broadcast, count all-reduce)" % N,
+                   "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": sizes[0], "parallelism": "haystack-sharded x%d, one process (am_multi_create: ncclCommInitAll, image broadcast; am_multi_run_batch / am_multi_count_batch on device-resident batches)" % N,
                    "kernel": kname.decode(), "automaton_image_bytes": int(nbytes.value), "build_s": round(build_s, 2)},
         "matches_per_s": round(total_matches * args.steps / elapsed, 1), "matches_per_step": total_matches, "records_per_step": total_records,
         "roofline": {"bound": "hbm", "kernel": "k_" + kname.decode(), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value),
                      "alg_bytes_per_launch": int(alg_bytes)},
+        "collectives": "libam-rccl",
     }
     print(json.dumps(out), flush=True)
     for i in range(N):
@@ -501,6 +508,43 @@ def bench_replacer(args, w, rank, world, dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def h2d_inclusive(args, w, handle, case, text, n_hay, lib):
+    """What a Haskell `runText` caller gets through the shim of INTEGRATION.md (SURVEY 7.4 H4 / 8d "reported separately"): the one-shot
+    entry points am_count / am_run on HOST slices -- gather into pinned staging, DMA over PCIe, scan, results back -- timed on the first
+    --h2d-mib MiB of the benchmark batch, copied to pinned host memory first.  Never `value`."""
+    import numpy as np
+    import torch
+    import alfred_margaret_amd as am
+    hb = w["hay_bytes"]
+    k = max(1, min(n_hay, (args.h2d_mib << 20) // hb))
+    host = torch.empty(k * hb, dtype=torch.uint8).pin_memory()
+    host.copy_(text[:k * hb])
+    torch.cuda.synchronize()
+    slices = (am.api.Slice * k)()
+    base = host.data_ptr()
+    for i in range(k):
+        slices[i].ptr, slices[i].off, slices[i].len = base, i * hb, hb
+    counts = np.zeros(k, dtype=np.uint64)
+    out = {"sample": "first %d haystacks (%d MiB) of the batch as pinned host slices; one call each, after one warm-up call" % (k, k * hb >> 20)}
+    am.api.check(lib.am_count(handle, case, slices, k, counts.ctypes.data))          # warm-up: staging buffers, workspaces
+    t0 = time.perf_counter()
+    am.api.check(lib.am_count(handle, case, slices, k, counts.ctypes.data))
+    t_count = time.perf_counter() - t0
+    m = C.c_void_p()
+    am.api.check(lib.am_run(handle, case, slices, k, C.byref(m)))
+    lib.am_matches_data(m); lib.am_matches_free(m)
+    t0 = time.perf_counter()
+    am.api.check(lib.am_run(handle, case, slices, k, C.byref(m)))
+    n_rec = int(lib.am_matches_size(m))
+    lib.am_matches_data(m)                                                              # the records on the host: part of what the caller waits for
+    t_run = time.perf_counter() - t0
+    lib.am_matches_free(m)
+    gib = k * hb / float(1 << 30)
+    out.update({"count_gibps": round(gib / t_count, 2), "run_gibps": round(gib / t_run, 2), "count_ms": round(t_count * 1e3, 2), "run_ms": round(t_run * 1e3, 2),
+                "records": n_rec, "values": int(counts.sum())})
+    return out
 
 
 def host_cores():
