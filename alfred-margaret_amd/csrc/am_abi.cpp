@@ -130,6 +130,11 @@ struct ThreadState {
     hipStream_t own[kMaxDev] = {};
     hipStream_t user = nullptr; bool use_user = false;
     am_batch* oneshot[kMaxDev] = {};
+    // one-shot calls on small inputs: pinned host memory of the calling thread, so that offsets + text go up with ONE asynchronous copy on
+    // the thread's stream and the results come back the same way -- a call costs one stream synchronisation, not four blocking copies
+    uint8_t* pin = nullptr; size_t pin_cap = 0;          // upload staging (two halves that take turns for inputs above kPinPiece)
+    uint8_t* pin_res = nullptr; size_t pin_res_cap = 0;  // results
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     ~ThreadState();
 };
 thread_local ThreadState tl_state;
@@ -146,6 +151,46 @@ int get_stream(int dev, hipStream_t* st)
     *st = tl_state.own[dev];
     return AM_OK;
 }
+
+constexpr size_t kSmallUpload = 4u << 20;       // one-shot batches up to this size take the pinned single-copy path
+constexpr size_t kPinPiece = 256u << 10;        // above this the gather into pinned memory and the DMA of the previous piece overlap
+
+int pin_ensure(uint8_t*& p, size_t& cap, size_t need)
+{
+    if (need <= cap) return AM_OK;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = need + need / 4 + 4096;
+    if (hipHostMalloc((void**)&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(AM_ERR_OOM, "hipHostMalloc(pinned staging) failed"); }
+    cap = want;
+    return AM_OK;
+}
+
+// Results of a call, device -> caller: small ones travel through the thread's pinned result buffer (an asynchronous copy into pageable
+// memory is a blocking, staged copy inside the runtime), the caller's buffers are filled after the call's ONE stream synchronisation.
+struct ResultCopies {
+    struct Item { void* dst; size_t off, n; };
+    Item items[4]; int n_items = 0; size_t used = 0;
+    int add(void* dst, const void* d_src, size_t n, hipStream_t st)
+    {
+        if (n == 0) return AM_OK;
+        if (n > (64u << 10) || n_items == 4) { HIP_TRY(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, st)); return AM_OK; }
+        const size_t off = (used + 15) & ~(size_t)15;
+        if (off + n > tl_state.pin_res_cap) {
+            if (n_items) { HIP_TRY(hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, st)); return AM_OK; }      // the buffer is in use by this call: do not move it
+            AM_TRY(pin_ensure(tl_state.pin_res, tl_state.pin_res_cap, (size_t)256 << 10));
+        }
+        HIP_TRY(hipMemcpyAsync(tl_state.pin_res + off, d_src, n, hipMemcpyDeviceToHost, st));
+        items[n_items++] = Item{dst, off, n};
+        used = off + n;
+        return AM_OK;
+    }
+    int finish(hipStream_t st)
+    {
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int i = 0; i < n_items; i++) std::memcpy(items[i].dst, tl_state.pin_res + items[i].off, items[i].n);
+        return AM_OK;
+    }
+};
 
 // RAII HIP-event bracket around one kernel launch (only when profiling is enabled)
 struct Prof {
@@ -210,6 +255,7 @@ struct am_batch {
     uint64_t total = 0; uint32_t n_hay = 0;
     std::mutex mu;              // guards the workspaces below (calls on one batch serialise)
     DevBuf text_buf, offs_buf;  // backing store of d_text / d_offsets when the batch owns them
+    DevBuf combo;               // ... or ONE buffer [offsets | text] for small batches that went up with a single copy
     DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
     DevBuf sparse, dense_counts, dense_offsets, dense_out;      // automata with the empty needle (dense pass)
 };
@@ -275,6 +321,7 @@ ThreadState::~ThreadState()
         if (oneshot[d]) { o.batches[d].push_back(oneshot[d]); oneshot[d] = nullptr; }
         if (own[d]) { o.streams[d].push_back(own[d]); own[d] = nullptr; }
     }
+    // the pinned buffers and events of an ended thread are left to the process (a thread-exit destructor must not call into HIP)
 }
 }  // namespace
 
@@ -449,7 +496,7 @@ static int finish_batch(am_batch* b)
 }
 
 // Uploads the slices into `b` (re-using its device buffers when they are large enough).
-static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b)
+static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b, bool oneshot = false)
 {
     if (n_hay && !hay) return fail(AM_ERR_INVALID, "hay is null");
     if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
@@ -462,25 +509,63 @@ static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b)
     }
     const uint64_t total = offs[n_hay];
     const size_t padded = (size_t)((total + 15) & ~15ull) + 16;
+    b->owns = true; b->total = total; b->n_hay = (uint32_t)n_hay;
+    if (total <= kSmallUpload && n_hay <= (1u << 16)) {
+        // Small batches (the one-document-per-call pattern): [offsets | text] is put together in pinned memory of the calling thread and goes
+        // up with asynchronous copies on the thread's stream; the kernels of the call follow on the same stream, so nothing waits here.
+        // Above kPinPiece the text is cut into pieces: the DMA of one piece runs while the host gathers the next into the other half.
+        const size_t text_off = (offs.size() * sizeof(uint64_t) + 63) & ~(size_t)63;
+        const size_t bytes = text_off + padded;
+        hipStream_t st; AM_TRY(get_stream(b->dev, &st));
+        AM_TRY(b->combo.ensure(bytes));
+        b->d_offsets = (uint64_t*)b->combo.p; b->d_text = (uint8_t*)b->combo.p + text_off;
+        const bool pieces = padded > kPinPiece;
+        AM_TRY(pin_ensure(tl_state.pin, tl_state.pin_cap, pieces ? text_off + 2 * kPinPiece : bytes));
+        uint8_t* pin = tl_state.pin;
+        std::memcpy(pin, offs.data(), offs.size() * sizeof(uint64_t));
+        // copies bytes [lo, hi) of the concatenated (zero-padded) text into dst
+        auto gather = [&](uint64_t lo, uint64_t hi, uint8_t* dst) {
+            uint64_t at = lo;
+            if (at < total) {
+                size_t i = (size_t)(std::upper_bound(offs.begin(), offs.end(), at) - offs.begin()) - 1;
+                const uint64_t stop_all = std::min<uint64_t>(hi, total);
+                while (at < stop_all) {
+                    while (offs[i + 1] <= at) i++;
+                    const uint64_t stop = std::min<uint64_t>(stop_all, offs[i + 1]);
+                    std::memcpy(dst + (at - lo), hay[i].ptr + hay[i].off + (at - offs[i]), (size_t)(stop - at));
+                    at = stop;
+                }
+            }
+            if (at < hi) std::memset(dst + (at - lo), 0, (size_t)(hi - at));        // zero tail: kernels read whole 16-byte groups
+        };
+        if (!pieces) {
+            gather(0, padded, pin + text_off);
+            HIP_TRY(hipMemcpyAsync(b->combo.p, pin, bytes, hipMemcpyHostToDevice, st));
+        } else {
+            for (int k = 0; k < 2; k++) if (!tl_state.pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&tl_state.pin_ev[k], hipEventDisableTiming));
+            HIP_TRY(hipMemcpyAsync(b->combo.p, pin, text_off, hipMemcpyHostToDevice, st));
+            bool used[2] = {false, false};
+            int turn = 0;
+            for (uint64_t lo = 0; lo < padded; lo += kPinPiece, turn ^= 1) {
+                const uint64_t hi = std::min<uint64_t>(padded, lo + kPinPiece);
+                uint8_t* half = pin + text_off + (size_t)turn * kPinPiece;
+                if (used[turn]) HIP_TRY(hipEventSynchronize(tl_state.pin_ev[turn]));       // the copy out of this half has finished
+                gather(lo, hi, half);
+                HIP_TRY(hipMemcpyAsync((uint8_t*)b->d_text + lo, half, (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipEventRecord(tl_state.pin_ev[turn], st));
+                used[turn] = true;
+            }
+        }
+        if (!oneshot) HIP_TRY(hipStreamSynchronize(st));       // a batch object may be used from any thread and stream afterwards
+        return finish_batch(b);
+    }
     AM_TRY(b->text_buf.ensure(padded));
     AM_TRY(b->offs_buf.ensure(offs.size() * sizeof(uint64_t)));
-    b->owns = true; b->total = total; b->n_hay = (uint32_t)n_hay;
     b->d_text = b->text_buf.p; b->d_offsets = (uint64_t*)b->offs_buf.p;
     hipError_t e = hipMemcpy(b->d_offsets, offs.data(), offs.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && total == 0) { e = hipMemset(b->d_text, 0, padded); if (e == hipSuccess) e = hipStreamSynchronize(nullptr); }
     // The slices are gathered piece by piece (several threads) into two pinned staging buffers that take turns:
     // while the DMA engine uploads one piece, the host fills the other.  The buffers stay for the next call.
-    // Small batches (the one-document-per-call pattern) are gathered into a buffer of the calling thread and copied
-    // directly: nothing shared, so calls from different threads do not meet.
-    constexpr uint64_t kSmallUpload = 4u << 20;
-    if (e == hipSuccess && total > 0 && total <= kSmallUpload) {
-        static thread_local std::vector<uint8_t> gather_buf;
-        gather_buf.resize(padded);
-        for (size_t i = 0; i < n_hay; i++) if (hay[i].len) std::memcpy(gather_buf.data() + offs[i], hay[i].ptr + hay[i].off, hay[i].len);
-        std::memset(gather_buf.data() + total, 0, padded - (size_t)total);
-        e = hipMemcpy(b->d_text, gather_buf.data(), padded, hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess && total > kSmallUpload) {
+    {
         struct UploadStage { std::mutex mu; uint8_t* stage[2] = {nullptr, nullptr}; hipStream_t copy_stream = nullptr; hipEvent_t done[2] = {nullptr, nullptr}; };
         static UploadStage per_device[kMaxDev];                  // pinned staging + copy stream of each device; big uploads to one device take turns (they share its PCIe link anyway)
         UploadStage& us = per_device[b->dev];
@@ -598,7 +683,7 @@ extern "C" int am_batch_from_device(const void* d_bytes, const void* d_offsets, 
 extern "C" void am_batch_destroy(am_batch* b)
 {
     if (!b) return;
-    for (DevBuf* d : {&b->text_buf, &b->offs_buf, &b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next,
+    for (DevBuf* d : {&b->text_buf, &b->offs_buf, &b->combo, &b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next,
                       &b->sparse, &b->dense_counts, &b->dense_offsets, &b->dense_out}) d->release();
     delete b;
 }
@@ -662,6 +747,21 @@ int build_hidx(const Plan& p, am_batch* b, hipStream_t st)
     return AM_OK;
 }
 
+// the haystack index and the clearing of (up to two) arrays in ONE launch when the index has to be built anyway -- the one-document call;
+// with the index in place the arrays are cleared by memsets.  bytes0 / bytes1 are multiples of 4.
+int build_hidx_and_clear(const Plan& p, am_batch* b, hipStream_t st, void* z0, size_t bytes0, void* z1, size_t bytes1)
+{
+    if (b->hidx_ready) {
+        if (bytes0) HIP_TRY(hipMemsetAsync(z0, 0, bytes0, st));
+        if (bytes1) HIP_TRY(hipMemsetAsync(z1, 0, bytes1, st));
+        return AM_OK;
+    }
+    Prof pr("hidx", st);
+    HIP_TRY(launch_hidx(p.bv, (uint32_t*)b->hidx.p, (b->total >> kHidxShift) + 2, st, (uint32_t*)z0, bytes0 / 4, (uint32_t*)z1, bytes1 / 4));
+    b->hidx_ready = true;
+    return AM_OK;
+}
+
 }  // namespace
 
 static int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock = false);
@@ -711,18 +811,17 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
     o.unit_chunks = p.unit_chunks;
     if (!p.use_sf) { AM_TRY(b->unit_counts.ensure((p.n_units + 1) * sizeof(uint32_t))); o.unit_counts = (uint32_t*)b->unit_counts.p; }
     o.total_values = (uint64_t*)b->small.p;
-    HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
     if (counts_out) {
         AM_TRY(b->hay_counts.ensure((size_t)b->n_hay * sizeof(uint64_t)));
-        HIP_TRY(hipMemsetAsync(b->hay_counts.p, 0, (size_t)b->n_hay * sizeof(uint64_t), st));
         o.hay_counts = (uint64_t*)b->hay_counts.p;
     }
-    AM_TRY(build_hidx(p, b, st));
+    AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, counts_out ? b->hay_counts.p : nullptr, counts_out ? (size_t)b->n_hay * sizeof(uint64_t) : 0));
     AM_TRY(launch_scan_kernel(p, kModeCount, o, st));
     uint64_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, b->small.p, 8, hipMemcpyDeviceToHost, st));
-    if (counts_out) HIP_TRY(hipMemcpyAsync(counts_out, b->hay_counts.p, (size_t)b->n_hay * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    ResultCopies rc;
+    if (total_out) AM_TRY(rc.add(&total, b->small.p, 8, st));
+    if (counts_out) AM_TRY(rc.add(counts_out, b->hay_counts.p, (size_t)b->n_hay * sizeof(uint64_t), st));
+    AM_TRY(rc.finish(st));
     if (total_out) *total_out = total;
     return AM_OK;
 }
@@ -738,16 +837,15 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     std::lock_guard<std::mutex> lk(b->mu);
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
-    AM_TRY(b->flags.ensure(b->n_hay));
-    HIP_TRY(hipMemsetAsync(b->flags.p, 0, b->n_hay, st));
+    AM_TRY(b->flags.ensure(((size_t)b->n_hay + 3) & ~(size_t)3));
     ScanOut o{};
     o.unit_chunks = p.unit_chunks;
     o.flags = (uint8_t*)b->flags.p;
-    AM_TRY(build_hidx(p, b, st));
+    AM_TRY(build_hidx_and_clear(p, b, st, b->flags.p, ((size_t)b->n_hay + 3) & ~(size_t)3, nullptr, 0));
     AM_TRY(launch_scan_kernel(p, kModeAny, o, st));
-    HIP_TRY(hipMemcpyAsync(flags_out, b->flags.p, b->n_hay, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return AM_OK;
+    ResultCopies rc;
+    AM_TRY(rc.add(flags_out, b->flags.p, b->n_hay, st));
+    return rc.finish(st);
 }
 
 // The whole scan: leaves every record of the batch, sorted by (haystack, end_pos), in device memory
@@ -895,7 +993,7 @@ extern "C" int am_count(const am_automaton* a, int case_mode, const am_slice* ha
     if (n_hay && !counts_out) return fail(AM_ERR_INVALID, "counts_out is null");
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
     am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
-    int rc = upload_slices(hay, n_hay, b);
+    int rc = upload_slices(hay, n_hay, b, true);
     if (rc == AM_OK) rc = am_count_batch(a, case_mode, b, counts_out, nullptr);
     oneshot_trim(a->dev);
     return rc;
@@ -905,7 +1003,7 @@ extern "C" int am_contains_any(const am_automaton* a, int case_mode, const am_sl
 {
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
     am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
-    int rc = upload_slices(hay, n_hay, b);
+    int rc = upload_slices(hay, n_hay, b, true);
     if (rc == AM_OK) rc = am_contains_any_batch(a, case_mode, b, flags_out);
     oneshot_trim(a->dev);
     return rc;
@@ -915,7 +1013,7 @@ extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay,
 {
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
     am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
-    int rc = upload_slices(hay, n_hay, b);
+    int rc = upload_slices(hay, n_hay, b, true);
     if (rc == AM_OK) rc = am_run_batch(a, case_mode, b, out);
     oneshot_trim(a->dev);
     return rc;

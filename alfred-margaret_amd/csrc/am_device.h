@@ -49,7 +49,8 @@ inline uint64_t pool_grant_slack(int n_cu, uint64_t n_units, bool two_per_cu)
     return w * kSfBlockGrant;
 }
 
-hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st);
+// z0 / z1 (nullable): up to two arrays of n0 / n1 dwords that the same launch clears
+hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st, uint32_t* z0 = nullptr, uint64_t n0 = 0, uint32_t* z1 = nullptr, uint64_t n1 = 0);
 uint64_t sf_chunks(const BatchView& b);
 uint32_t sf_unit_chunks(const BatchView& b, int n_cu);
 hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record* out, uint64_t n_units, hipStream_t st);

@@ -225,7 +225,9 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     //     test on the text alone (ends_first_code_point below), done by the dense pass of the ABI layer (k_dense_*);
     //   * longer prefixes whose LAST code point starts no needle (the blank in "new york" when nothing starts with a
     //     blank) become extra terminals of the reversed trie, reporting canon[s] -- the list the reference folds there.
-    // If those extra terminals would outnumber the real ones several times over, the automaton keeps the general kernel.
+    // No automaton is refused (round 2 kept the general kernel when the extra terminals outnumbered the real ones several times over: that
+    // kernel is 50-100 x slower, so the suffix structure simply grows -- its tables are sized by the number of terminals either way, and
+    // such an automaton reports at almost every position, i.e. it is bound by its output, not by the tables).
     h.sf_enabled = 1u;
     std::vector<uint32_t> terminals;
     for (size_t s = 1; s < S; s++) if (owns[s]) terminals.push_back((uint32_t)s);
@@ -236,8 +238,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         std::vector<uint32_t> extra;
         for (size_t s = 1; s < S; s++)
             if (!owns[s] && depth[s] >= 2 && !std::binary_search(first.begin(), first.end(), cp_in[s])) extra.push_back((uint32_t)s);
-        if (extra.size() > 4 * terminals.size() + 4096) h.sf_enabled = 0u;
-        else terminals.insert(terminals.end(), extra.begin(), extra.end());
+        terminals.insert(terminals.end(), extra.begin(), extra.end());
     }
 
     std::vector<SfNode> nodes;

@@ -29,9 +29,14 @@ namespace dev {
 
 // ------------------------------------------------------------------ haystack index
 
-__global__ void k_hidx(const uint64_t* __restrict__ offsets, uint32_t n_hay, uint64_t total, uint32_t* __restrict__ hidx, uint64_t n_entries)
+// (also clears up to two result / counter arrays of the call that follows, so that a one-document call needs no memset launches of its own)
+__global__ void k_hidx(const uint64_t* __restrict__ offsets, uint32_t n_hay, uint64_t total, uint32_t* __restrict__ hidx, uint64_t n_entries,
+                       uint32_t* __restrict__ z0, uint64_t n0, uint32_t* __restrict__ z1, uint64_t n1)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = k; i < n0; i += stride) z0[i] = 0u;
+    for (uint64_t i = k; i < n1; i += stride) z1[i] = 0u;
     if (k >= n_entries) return;
     uint64_t p = k << kHidxShift;
     if (p > total - 1) p = total - 1;
@@ -568,10 +573,10 @@ __global__ __launch_bounds__(256) void k_ac(AcView a, BatchView b, ScanOut o, ui
 
 // ------------------------------------------------------------------ launchers
 
-hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st)
+hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st, uint32_t* z0, uint64_t n0, uint32_t* z1, uint64_t n1)
 {
-    const uint32_t blocks = (uint32_t)((n_entries + 255) / 256);
-    hipLaunchKernelGGL(k_hidx, dim3(blocks), dim3(256), 0, st, b.offsets, b.n_hay, b.total, hidx, n_entries);
+    const uint32_t blocks = (uint32_t)((n_entries + 255) / 256);      // >= 1: n_entries >= 2; the zero jobs are grid-stride loops
+    hipLaunchKernelGGL(k_hidx, dim3(blocks), dim3(256), 0, st, b.offsets, b.n_hay, b.total, hidx, n_entries, z0, n0, z1, n1);
     return hipGetLastError();
 }
 

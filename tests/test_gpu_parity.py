@@ -93,6 +93,20 @@ def test_empty_needle_quirk_and_duplicates():
     assert [int(c) for c in a.count_matches(0, ["abc"])] == [0]
 
 
+def test_empty_needle_with_many_prefix_terminals_stays_on_the_suffix_filter():
+    """Round 2 refused automata whose prefix terminals outnumbered 4 x needle ends + 4096 (they fell back to the 50-100 x slower
+    general kernel); now the suffix structure takes them.  300 needles of 60 code points that all start with 'a', plus the empty
+    needle: ~17 000 prefix states whose last code point starts no needle."""
+    rng = random.Random(5)
+    needles = [""] + ["a" + "".join(rng.choice("bcdefghij") for _ in range(59)) for _ in range(300)]
+    text = "".join(rng.choice(needles[1:])[: rng.randint(1, 60)] + rng.choice("xyz a") for _ in range(400))
+    a = am.Automaton(needles)
+    a.set_kernel(2)                                    # AM_ERR_UNSUPPORTED here would mean the automaton was refused
+    assert len(a.run_records(0, [text])) > 1000
+    check_all_paths(needles, [text, "", text[:100], "aab"], 0)
+    check_all_paths(needles, [text], 1)
+
+
 def test_edge_shapes():
     check_all_paths(["a", "aa", "aaa"], ["a" * 300, "", "aa", "b" * 100 + "a"], 0)          # dense output, ragged batch
     check_all_paths(["abc"], [], 0)                                                         # empty batch

@@ -13,7 +13,8 @@ needles = synth.needles_for(wl)
 a = am.Automaton(needles)
 n_hay = 2048 if w["hay_bytes"] >= (1 << 20) else 32768
 cells = w["hay_bytes"] // 1024
-text, n_bytes = synth.haystacks_device(needles, w["mixed"], 0, n_hay * cells, torch.device("cuda:0"))
+plants = int(os.environ.get("AM_PLANTS", "1"))
+text, n_bytes = synth.haystacks_device(needles, w["mixed"], 0, n_hay * cells, torch.device("cuda:0"), plants=plants, natural=bool(w.get("natural")))
 offs = torch.arange(n_hay + 1, dtype=torch.int64, device="cuda:0") * w["hay_bytes"]
 lib = am.api.libam()
 b = C.c_void_p()

@@ -17,7 +17,7 @@ a = am.Automaton(needles)
 with tempfile.TemporaryDirectory() as d:
     a.transitions().tofile(os.path.join(d, "tr.bin")); a.offsets().tofile(os.path.join(d, "of.bin")); a.root_ascii().tofile(os.path.join(d, "ra.bin"))
     np.diff(a.values_off()).astype(np.uint32).tofile(os.path.join(d, "vl.bin"))
-    synth.haystacks_host(needles, w["mixed"], 0, kib).tofile(os.path.join(d, "text.bin"))
+    synth.haystacks_host(needles, w["mixed"], 0, kib, natural=bool(w.get("natural"))).tofile(os.path.join(d, "text.bin"))
     exe = os.path.join(d, "replay")
     csrc = os.path.join(ROOT, "alfred-margaret_amd", "csrc")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-w", "-DAM_REPLAY_CASE=%d" % w["case"], "-I", csrc, os.path.join(ROOT, "tools", "replay_stats.cpp"),
