@@ -93,6 +93,11 @@ __device__ __forceinline__ void wave_lds_fence()
 
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
 constexpr int kSfWaves = kSfThreads / 64;
+// The LIGHT configuration for small batches (one document per call): workgroups of 4 wavefronts.  A 1024-thread workgroup needs 16 free
+// wavefront slots on ONE CU at the same moment; next to another stream's kernel that keeps every CU busy with short workgroups it can
+// wait for that kernel's grid to drain (seen in round 2: tests/test_multi.py), a 4-wavefront workgroup gets in like any of the others.
+constexpr int kSfLightThreads = 256;
+constexpr uint64_t kSfLightChunks = 256;         // batches of up to 256 KiB take the light configuration
 constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
 constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 12 | agreeing slot << 10 | offset): candidates that need the exact look
 constexpr uint32_t kSfMaxUnitChunks = 64;
@@ -135,9 +140,10 @@ __device__ __forceinline__ void lds_write_u32x4(uint32_t byte_addr, uint4 v) { u
 // reads an SGPR or needs the VOP3 encoding on gfx950, tools/microbench/valu_rates*.hip); 0 = any size
 // DBG: the timing / ablation experiments (AM_SF_ABLATE) live in their own instantiations, the production kernel
 // carries none of their code, registers or branches.
-template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG>
-__global__ __launch_bounds__(kSfThreads) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
+template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG, int NT = kSfThreads>
+__global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
+    constexpr int kSfThreads = NT, kSfWaves = NT / 64;      // (shadow the namespace constants: the body is written against these names)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
@@ -601,30 +607,32 @@ hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record
 }
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
-size_t sf_lds_bytes(const SfView& s) { return kSfMaskBytes + ((size_t)4 << s.bloom_log2_words) + (size_t)kSfWaves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
+static size_t sf_lds_bytes_w(const SfView& s, int waves) { return kSfMaskBytes + ((size_t)4 << s.bloom_log2_words) + (size_t)waves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
+size_t sf_lds_bytes(const SfView& s) { return sf_lds_bytes_w(s, kSfWaves); }
 
-template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false>
+template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false, int NT = kSfThreads>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
-    const size_t lds = sf_lds_bytes(s);
+    constexpr int waves_per_wg = NT / 64;
+    const size_t lds = sf_lds_bytes_w(s, waves_per_wg);
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT, DBG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
     const uint64_t n_chunks = sf_chunks(b);
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int per_cu = NT == kSfThreads ? (lds <= 80 * 1024 ? 2 : 1) : 8;          // light: up to 32 wavefronts per CU, like two full workgroups
     uint64_t blocks = (uint64_t)n_cu * per_cu;
     const uint64_t n_units = (n_chunks + o.unit_chunks - 1) / o.unit_chunks;
-    const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
+    const uint64_t need = (n_units + waves_per_wg - 1) / waves_per_wg;
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
     ScanOut oo = o;
-    if (n_units <= blocks * kSfWaves) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
+    if (n_units <= blocks * waves_per_wg) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
     else if (hipMemsetAsync(oo.next_unit, 0, sizeof(uint32_t), st) != hipSuccess) return hipGetLastError();
-    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, oo, n_chunks);
+    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), dim3((uint32_t)blocks), dim3(NT), lds, st, s, b, oo, n_chunks);
     return hipGetLastError();
 }
 
@@ -654,6 +662,8 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
         if (!lw15) return launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
         return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, true, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st);
     }
+    if (sf_chunks(b) <= kSfLightChunks)                                                     // one small document: the light configuration
+        return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true, false, kSfLightThreads>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false, false, kSfLightThreads>(s, b, o, n_cu, st);
     if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
         return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }

@@ -155,3 +155,25 @@ def test_fold_hash_equals_oracle_fold():
         _, (hashes, counts) = _run_device(a, w["case"], text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, table)
         assert [(int(h), int(c)) for h, c in zip(hashes, counts)] == exp, k
     a.set_kernel(0)
+
+
+def test_cfg1_contains_any_three_needles_one_megabyte():
+    """BASELINE.json configs[0]: Searcher.containsAny CaseSensitive, needles tshirt / shirts / shorts over 1 MB of synthetic ASCII
+    (Searcher.hs:156-164), through the one-shot entry points a Haskell caller binds: am_contains_any, am_count and am_run on a host
+    slice == the oracle, plus the haystack sizes around the light / full kernel configuration switch (256 KiB) and the pinned-upload
+    piece size."""
+    needles = ["tshirt", "shirts", "shorts"]
+    rng = np.random.default_rng(1)
+    words = ["short", "tshirts", "sweatshirts", "and", "shirtshirts", "the", "quick", "brown", "fox", "shorts"]
+    big = (" ".join(words[int(i)] for i in rng.integers(0, len(words), size=200000)))[:1_000_000].encode()
+    quiet = bytes(rng.integers(97, 123, size=1_000_000, dtype=np.uint8)).replace(b"sh", b"xx")       # 1 MB without any needle
+    a = am.Automaton(needles)
+    s = am.Searcher(0, needles)
+    o = oracle.Machine(needles)
+    for hay in (big, quiet, big[:262144], big[:262145], big[:300_001], big[:100], b""):
+        assert bool(s.contains_any(hay)) == o.contains_any(0, hay)
+        assert int(a.count_matches(0, [hay])[0]) == o.count_matches(0, hay)
+    hay_i, pos, val = a.run_batch_with_case(0, [big, quiet])
+    p_, v_ = o.run_list(0, big)
+    assert [(int(h), int(p), int(v)) for h, p, v in zip(hay_i, pos, val)] == [(0, int(p), int(v)) for p, v in zip(p_, v_)]
+    assert len(pos) > 100_000 and o.contains_any(0, quiet) is False
