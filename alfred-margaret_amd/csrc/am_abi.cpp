@@ -900,18 +900,19 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     // haystack bytes + one block per unit); if it overflows the kernel still counts, and the pass is
     // repeated once with the exact number of blocks.
     auto body_sf = [&]() -> int {
-        AM_TRY(b->unit_first.ensure(p.n_units * sizeof(uint32_t)));
+        AM_TRY(b->unit_first.ensure(2 * p.n_units * sizeof(uint32_t)));          // first block + slot count per unit
         uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);
         if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
         if (const char* env = std::getenv("AM_SF_POOL_BLOCKS")) { long v = std::atol(env); if (v > 0) want_blocks = (uint64_t)v; }   // tests: force the overflow/retry path
         for (int attempt = 0; attempt < 3; attempt++) {
-            if (want_blocks >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
+            if (want_blocks >= (1ull << 26)) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call (2^32 record slots); split the batch");      // k_sf addresses record slots with 32 bits
             AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
             AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
             ScanOut o{};
             o.unit_chunks = p.unit_chunks;
             o.unit_counts = (uint32_t*)b->unit_counts.p;
             o.unit_first = (uint32_t*)b->unit_first.p;
+            o.unit_slots = (uint32_t*)b->unit_first.p + p.n_units;
             o.pool = (Record*)b->pool.p;
             o.block_next = (uint32_t*)b->block_next.p;
             o.pool_ctrl = (uint32_t*)b->small.p + 4;            // small: [0..1] total_values, [4] block counter, [5] overflow
@@ -1335,18 +1336,19 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
     *n_dev = (const uint64_t*)b->unit_offsets.p + p.n_units;
     if (p.nothing) { HIP_TRY(hipMemsetAsync(b->unit_offsets.p, 0, n * sizeof(uint64_t), st)); return AM_OK; }
     AM_TRY(b->small.ensure(64));
-    AM_TRY(b->unit_first.ensure(p.n_units * sizeof(uint32_t)));
+    AM_TRY(b->unit_first.ensure(2 * p.n_units * sizeof(uint32_t)));
     size_t tmp_bytes = 0;
     if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
     const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);          // ceil(records / 64) per unit, records <= bytes; + the grants' unused remainders
-    if (want_blocks >= 0xFFFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
+    if (want_blocks >= (1ull << 26)) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call (2^32 record slots); split the batch");      // k_sf addresses record slots with 32 bits
     AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
     AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
     ScanOut o{};
     o.unit_chunks = p.unit_chunks;
     o.unit_counts = (uint32_t*)b->unit_counts.p;
     o.unit_first = (uint32_t*)b->unit_first.p;
+    o.unit_slots = (uint32_t*)b->unit_first.p + p.n_units;
     o.pool = (Record*)b->pool.p;
     o.block_next = (uint32_t*)b->block_next.p;
     o.pool_ctrl = (uint32_t*)b->small.p + 4;

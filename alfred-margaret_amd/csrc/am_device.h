@@ -26,6 +26,9 @@ struct ScanOut {
     uint32_t* block_next;
     uint32_t* pool_ctrl;          // [0] next free block (keeps counting past n_blocks = blocks needed), [1] overflow flag
     uint32_t* unit_first;         // first block of each unit (kNone: none)
+    uint32_t* unit_slots;         // record SLOTS in each unit's chain: its records (unit_counts) + the slots of parked walkers that found nothing
+                                  // (state == kNone; k_permute drops them)
+    uint32_t wq_cap;              // set by launch_sf: walker-queue entries per wavefront in LDS (0: the filter leaves no room)
     uint32_t n_blocks;
     uint32_t unit_chunks;         // 1-KiB chunks per unit
     uint32_t* next_unit;          // zeroed before the launch: wavefronts draw their second and later units from it (null: fixed stride)

@@ -478,17 +478,21 @@ AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
 // (haystack index -> offsets: two dependent loads of its own), so that chain overlaps with haystack bytes -> slot line
 // instead of preceding it.  avail64 is not read before that.
 struct SfNoHook { AM_HD void operator()() const {} };
-template <bool IC, int N, bool SHORT = true, class Between = SfNoHook>
-AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail64)[N], const bool (&valid)[N],
-                        const uint32_t (&hint)[N], bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N], Between between = Between(),
-                        uint64_t* dbg_iters = nullptr, uint32_t dbg_ablate = 0)
+
+// Phase 2 in three pieces (k_resolve runs them as separate stages: the head for every item, the walk only for the items that need
+// it, 64 of those at a time; the host checker and sf_resolve_n run them back to back):
+//   sf_resolve_head   steps 1-3: haystack bytes, the slot line, what the slot line settles
+//   sf_resolve_walk   step 4: the compressed trie, backwards along the haystack, to the deepest needle end
+//   sf_resolve_short  step 5: needles of 1..3 bytes (only if nothing longer ends at the position)
+// State handed from the head to the walk, per item: go (the walk has something to do), node (where it continues), have_rec (rec already
+// holds that node's record: a branching depth-4 node described by its slot line), depth, best_state (+1; 0: none yet), best_vlen,
+// avail (bytes of the haystack up to and including gpos, clamped to 32 bits), w2 (the four bytes before the 4-byte suffix, folded).
+template <bool IC, int N, class Between = SfNoHook>
+AM_HD void sf_resolve_head(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail64)[N], const bool (&valid)[N],
+                           const uint32_t (&hint)[N], Between between, uint32_t (&w)[N], uint32_t (&w2)[N], uint32_t (&avail)[N],
+                           uint32_t (&best_state)[N], uint32_t (&best_vlen)[N], uint32_t (&depth)[N], bool (&go)[N], uint32_t (&node)[N],
+                           SfNode (&rec)[N], bool (&have_rec)[N], uint32_t (&t16)[N][4], uint64_t* dbg_iters = nullptr)
 {
-    uint32_t avail[N];
-    const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
-    const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 4 x 16 B per edge
-    const u32x4* maps16 = reinterpret_cast<const u32x4*>(s.edge_maps);   // 4 x 16 B per map
-    uint32_t w[N], w2[N], node[N];
-    uint32_t t16[N][4];
     // ---- step 1: the last 8 haystack bytes and the 16 before the 4-byte suffix (what the first edge label is compared with)
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -517,13 +521,12 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             const uint32_t idx = h == 0 ? slot_of[0][k] : h == 1 ? slot_of[1][k] : h == 2 ? slot_of[2][k] : slot_of[3][k];
             q0[k] = slots16[4u * idx]; q1[k] = slots16[4u * idx + 1u]; q2[k] = slots16[4u * idx + 2u]; q3[k] = slots16[4u * idx + 3u];
         }
-        #if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[2] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[2] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
 #endif
         between();
-
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[3] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+        if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[3] += now - dbg_iters[7]; dbg_iters[7] = now; }
 #endif
 #pragma unroll
         for (int k = 0; k < N; k++) avail[k] = avail64[k] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)avail64[k];
@@ -569,12 +572,6 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
     }
     // ---- step 3: what the slot line settles: the needle ending at the depth-4 node, the single edge and the needle ending at its
     // child.  Only needles longer than that, and branching nodes, go on to the node records.
-    uint32_t best_state[N], best_vlen[N];
-    uint32_t depth[N];
-    bool go[N];
-    SfNode rec[N];
-    bool have_rec[N];
-    bool any_go = false, any_load = false;
 #pragma unroll
     for (int k = 0; k < N; k++) {
         best_state[k] = 0; best_vlen[k] = 0; depth[k] = 4; go[k] = false; node[k] = kNone;
@@ -595,13 +592,25 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             go[k] = true; node[k] = sl[k].z; have_rec[k] = true;
             rec[k].x = sl[k].x; rec[k].y = sl[k].y; rec[k].z = sl[k].ez; rec[k].w = kind; rec[k].label[0] = sl[k].el0;
         }
-        any_go = any_go || go[k];
-        any_load = any_load || (go[k] && !have_rec[k]);
     }
-
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[4] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[4] += now - dbg_iters[7]; dbg_iters[7] = now; }
 #endif
+}
+
+// ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
+template <bool IC, int N>
+AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint32_t (&avail)[N], const uint32_t (&w2)[N],
+                           bool (&go)[N], const uint32_t (&node)[N], SfNode (&rec)[N], const bool (&have_rec)[N], uint32_t (&depth)[N],
+                           uint32_t (&best_state)[N], uint32_t (&best_vlen)[N], uint64_t* dbg_iters = nullptr, uint32_t max_iters = 0xFFFFFFFFu,
+                           const uint32_t (*t16)[4] = nullptr)      // t16 (optional): the head's 16 folded bytes before the 4-byte suffix = what a step at depth 4 compares with
+{
+    const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
+    const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 4 x 16 B per edge
+    const u32x4* maps16 = reinterpret_cast<const u32x4*>(s.edge_maps);   // 4 x 16 B per map
+    bool any_load = false;
+#pragma unroll
+    for (int k = 0; k < N; k++) any_load = any_load || (go[k] && !have_rec[k]);
     if (wave_any(any_load)) {                        // walks that go on at the single edge's child need its record
         u32x4 r0[N], r1[N];
 #pragma unroll
@@ -609,12 +618,12 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
 #pragma unroll
         for (int k = 0; k < N; k++) if (go[k] && !have_rec[k]) node_from_raw(r0[k], r1[k], rec[k]);
     }
-    // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
-    for (;;) {
+    // max_iters: the caller takes the walk over again after that many steps (go[] still set, rec / depth / best_* as they stand)
+    for (uint32_t iter = 0; iter < max_iters; iter++) {
         bool any = false;
 #pragma unroll
         for (int k = 0; k < N; k++) any = any || go[k];
-        if (!any || dbg_ablate == 11) break;
+        if (!wave_any(any)) break;
         if (dbg_iters) {
             dbg_iters[0]++;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -666,13 +675,14 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 e0[k] = u32x4{0, 0, 0, 0}; e1[k] = e0[k]; c0[k] = e0[k]; c1[k] = e0[k];
-                t[k][0] = t16[k][0]; t[k][1] = t16[k][1]; t[k][2] = t16[k][2]; t[k][3] = t16[k][3];
+                t[k][0] = t[k][1] = t[k][2] = t[k][3] = 0;
                 if (!go[k]) continue;
                 if (which[k] != kNone) {                                   // the edge's line: edge + the child's record
                     e0[k] = edges16[4u * which[k]]; e1[k] = edges16[4u * which[k] + 1u]; c0[k] = edges16[4u * which[k] + 2u]; c1[k] = edges16[4u * which[k] + 3u];
                 } else if (next[k] != kNone) { c0[k] = nodes16[2u * next[k]]; c1[k] = nodes16[2u * next[k] + 1u]; }      // single edge: the child's record
                 else continue;
-                if (depth[k] != 4) {
+                if (t16 && depth[k] == 4) { t[k][0] = t16[k][0]; t[k][1] = t16[k][1]; t[k][2] = t16[k][2]; t[k][3] = t16[k][3]; }
+                else {
                     load_text16(text, gpos[k] - depth[k], t[k]);       // the 16 bytes before the selector byte
                     if (IC) { t[k][0] = fold_dword(t[k][0]); t[k][1] = fold_dword(t[k][1]); t[k][2] = fold_dword(t[k][2]); t[k][3] = fold_dword(t[k][3]); }
                 }
@@ -698,14 +708,18 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             go[k] = depth[k] < avail[k] && (rec[k].w & 0xFFFFu) != 0;
         }
     }
-
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[5] += now - dbg_iters[7]; dbg_iters[7] = now; }      // debug build: where a batch's cycles go
+    if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[5] += now - dbg_iters[7]; dbg_iters[7] = now; }
 #endif
-    // ---- step 5: needles of 1..3 bytes (only if nothing longer ends here)
+}
+
+// ---- step 5: needles of 1..3 bytes (only if nothing longer ends here)
+template <int N>
+AM_HD void sf_resolve_short(const SfView& s, const bool (&valid)[N], const uint32_t (&avail)[N], const uint32_t (&w)[N], uint32_t (&best_state)[N], uint32_t (&best_vlen)[N])
+{
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        if (SHORT && valid[k] && !best_state[k] && (s.tiers & 7u)) {
+        if (valid[k] && !best_state[k] && (s.tiers & 7u)) {
             uint32_t short_node = kNone;
             for (uint32_t t = 3; t >= 1; t--) {
                 if ((s.tiers & (1u << (t - 1))) && avail[k] >= t) {
@@ -715,6 +729,26 @@ AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&g
             }
             if (short_node != kNone) { best_state[k] = s.nodes[short_node].x; best_vlen[k] = s.nodes[short_node].y; }
         }
+    }
+}
+
+// SHORT = false promises that the automaton has no needle (variant) shorter than 4 bytes (s.tiers & 7 == 0).
+// `hint` = which of the four candidate slots the probe saw agree (sf_probe_n); any value is correct, the right one saves loads.
+// `between` runs after the slot-line loads have been issued and before they are used (the caller computes avail64 there: haystack
+// index -> offsets, two dependent loads of its own, overlapping haystack bytes -> slot line).  avail64 is not read before that.
+template <bool IC, int N, bool SHORT = true, class Between = SfNoHook>
+AM_HD void sf_resolve_n(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint64_t (&avail64)[N], const bool (&valid)[N],
+                        const uint32_t (&hint)[N], bool (&found)[N], uint32_t (&state)[N], uint32_t (&vlen)[N], Between between = Between(),
+                        uint64_t* dbg_iters = nullptr, uint32_t dbg_ablate = 0)
+{
+    uint32_t w[N], w2[N], avail[N], best_state[N], best_vlen[N], depth[N], node[N], t16[N][4];
+    bool go[N], have_rec[N];
+    SfNode rec[N];
+    sf_resolve_head<IC, N>(s, text, gpos, avail64, valid, hint, between, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16, dbg_iters);
+    if (dbg_ablate != 11) sf_resolve_walk<IC, N>(s, text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, dbg_iters, 0xFFFFFFFFu, t16);
+    if (SHORT) sf_resolve_short<N>(s, valid, avail, w, best_state, best_vlen);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
         found[k] = valid[k] && best_state[k] != 0;
         state[k] = best_state[k] - 1u; vlen[k] = best_vlen[k];
     }

@@ -161,6 +161,10 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     const uint32_t stage = kSfMaskBytes + 4u * words + wave * (uint32_t)kSfStage;
     const uint32_t q1 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * kSfStage + wave * (uint32_t)(kSfQ1 * 2);
     const uint32_t q2 = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * (kSfStage + kSfQ1 * 2) + wave * (uint32_t)(kSfQ2 * 2);
+    // walker queue (only when the filter leaves room, i.e. small automata -- the ones that see match-dense text): wq_cap entries of 16 dwords
+    const uint32_t wq_cap = o.wq_cap;
+    const uint32_t wq = kSfMaskBytes + 4u * words + (uint32_t)kSfWaves * (kSfStage + kSfQ1 * 2 + kSfQ2 * 2) + wave * (wq_cap * 64u);
+    uint32_t wq_n = 0;                                     // parked walkers (uniform)
     (void)stage_all; (void)q1_all; (void)q2_all;
     const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
     const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     uint32_t q2_head = 0, q2_tail = 0;                   // monotonic; slot = index % kSfQ2
     // emit mode: state of the unit being written
     uint64_t unit_base_chunk = 0, epoch_base_chunk = 0;
-    uint32_t unit_count = 0, cur_block = kNone, first_block = kNone, grant_next = 0, grant_left = 0;
+    uint32_t unit_count = 0, unit_slots = 0, cur_block = kNone, first_block = kNone, grant_next = 0, grant_left = 0;   // unit_slots: record slots taken (found + parked walkers); unit_count: records
     bool pool_ok = true;
 
     // optional phase timing (AM_SF_ABLATE>=8): s_memtime deltas per wavefront, summed into o.dbg
@@ -189,56 +193,96 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         if (cnt_hay != kNone && cnt_val && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + cnt_hay), (unsigned long long)cnt_val);
         cnt_val = 0;
     };
-    constexpr int RN = 1;      // 2 halves the number of latency chains but spills registers (measured: 2x slower overall)
-    auto resolve_batch = [&](uint32_t nb) {
-        uint64_t gpos[RN], end_pos[RN];
-        uint32_t hay[RN], state[RN], vlen[RN], hlo[RN], hhi[RN], hint[RN];
-        bool valid[RN], found[RN];
-        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; }
-#pragma unroll
-        for (int k = 0; k < RN; k++) {
-            valid[k] = 64u * k + lane < nb;
-            const uint32_t item = valid[k] ? lds_read_u16(q2 + 2u * ((q2_head + 64u * k + lane) % kSfQ2)) : 0u;
-            gpos[k] = (epoch_base_chunk + (item >> 12)) * kSfChunk + (item & 1023u);
-            hint[k] = (item >> 10) & 3u;
-            hlo[k] = 0; hhi[k] = 0;
-            if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
+    // per-haystack counts (count mode): the found lanes of a batch almost always lie inside one haystack, then the wave adds its sum to a
+    // running (haystack, count) pair that is flushed with ONE atomic when the haystack changes
+    auto add_counts = [&](bool found, uint32_t hay, uint32_t vlen) {
+        if (found) nval += vlen;
+        const uint64_t fm = __ballot(found);
+        if (!o.hay_counts || !fm) return;
+        const uint32_t h0 = __shfl(hay, __ffsll((unsigned long long)fm) - 1, 64);
+        if (__ballot(found && hay != h0) == 0) {
+            const uint64_t sum = wave_sum_u64(found ? (uint64_t)vlen : 0ull);
+            if (h0 != cnt_hay) { flush_count(); cnt_hay = h0; }
+            cnt_val += sum;
+        } else if (found) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
+    };
+    // ---- the parked walkers: the newest <= 64 of them, walked to the end in lock step (all lanes busy; see resolve_batch)
+    auto walk_parked = [&]() {
+        const uint32_t n = wq_n < 64u ? wq_n : 64u, base = wq_n - n;
+        wq_n = base;
+        const bool valid = lane < n;
+        const uint32_t e = wq + (base + (valid ? lane : 0u)) * 64u;
+        const u32x4_n a0 = *reinterpret_cast<const lds_u32x4_t*>((uintptr_t)e), a1 = *reinterpret_cast<const lds_u32x4_t*>((uintptr_t)(e + 16u)),
+                      a2 = *reinterpret_cast<const lds_u32x4_t*>((uintptr_t)(e + 32u)), a3 = *reinterpret_cast<const lds_u32x4_t*>((uintptr_t)(e + 48u));
+        uint64_t gpos[1] = {((uint64_t)a0.y << 32) | a0.x};
+        uint32_t avail[1] = {a0.z}, depth[1] = {a1.x}, best_state[1] = {a1.y}, best_vlen[1] = {a1.z}, w2[1] = {a1.w}, node[1] = {kNone};
+        const uint32_t slot = a0.w, hay = a3.z, prior = a1.y;
+        SfNode rec[1] = {SfNode{0, 0, a2.x, a2.y, {a2.z, a2.w, a3.x, a3.y}}};
+        bool go[1] = {valid}, have_rec[1] = {true};
+        wave_lds_fence();                                   // the entries are in registers before anything overwrites them
+        sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen);
+        if (SHORT) {
+            const bool vv[1] = {valid && !best_state[0]};
+            uint32_t w[1] = {0}, dummy = 0;
+            if (vv[0]) { load_suffix8(b.text, gpos[0], w[0], dummy); if (IC) w[0] = fold_dword(w[0]); }
+            sf_resolve_short<1>(s, vv, avail, w, best_state, best_vlen);
         }
-        // haystack index -> start offset: two dependent loads, made while sf_resolve_n's first two (haystack bytes -> cold
-        // bucket) are in flight: the index entries were requested above, the offsets go out right behind the cold buckets
-        auto locate = [&]() {
-#pragma unroll
-            for (int k = 0; k < RN; k++) {
-                hay[k] = hlo[k];
-                uint64_t start = valid[k] ? b.offsets[hlo[k]] : 0;
-                if (valid[k] && hlo[k] != hhi[k]) { hay[k] = find_haystack(b, gpos[k]); start = b.offsets[hay[k]]; }
-                end_pos[k] = valid[k] ? gpos[k] - start + 1 : 0;
-            }
-        };
-        for (int k = 0; k < RN; k++) end_pos[k] = 0;
-        if (timing) dbg_iters[7] = __builtin_amdgcn_s_memtime();
-        sf_resolve_n<IC, RN, SHORT>(s, b.text, gpos, end_pos, valid, hint, found, state, vlen, locate, timing ? dbg_iters : nullptr, ablate);
-        if (timing) { asm volatile("" :: "v"((uint32_t)found[0])); const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; n_batches++; }
-#pragma unroll
-        for (int k = 0; k < RN; k++) {
-            const uint64_t found_mask = __ballot(found[k]);
-            if (timing) n_found += (uint32_t)__popcll(found_mask);
-            if (MODE == kModeCount) {
-                if (found[k]) nval += vlen[k];
-                if (o.hay_counts && found_mask) {
-                    // per-haystack counts: a batch almost always lies inside one haystack, then the wave adds its sum to a
-                    // running (haystack, count) pair that is flushed with ONE atomic when the haystack changes
-                    const uint32_t h0 = __shfl(hay[k], __ffsll((unsigned long long)found_mask) - 1, 64);
-                    if (__ballot(found[k] && hay[k] != h0) == 0) {
-                        const uint64_t sum = wave_sum_u64(found[k] ? (uint64_t)vlen[k] : 0ull);
-                        if (h0 != cnt_hay) { flush_count(); cnt_hay = h0; }
-                        cnt_val += sum;
-                    } else if (found[k]) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)vlen[k]);
-                }
-            } else if (MODE == kModeEmit) {
-                const uint32_t F = (uint32_t)__popcll(found_mask);
+        const bool found = valid && best_state[0] != 0;
+        if (timing) n_found += (uint32_t)__popcll(__ballot(found && prior == 0u));
+        if (MODE == kModeCount) add_counts(found, hay, best_vlen[0]);
+        else if (MODE == kModeEmit) {
+            if (found && best_state[0] != prior && pool_ok) o.pool[slot].state = best_state[0] - 1u;      // the batch wrote end_pos and haystack into the walker's slot
+            unit_count += (uint32_t)__popcll(__ballot(found && prior == 0u));
+        } else if (found) o.flags[hay] = 1;
+    };
+
+    // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items in lock step (all belong to the current unit); item j of the batch
+    // sits in lane j, so ranks by lane reproduce the FIFO = position order.
+    //   head   haystack bytes + haystack index -> slot line + haystack start -> what the slot line settles (sf_resolve_head)
+    //   walk   the items that go on into the trie.  A walk lasts as long as its deepest lane.  With a walker queue (wq_cap > 0: small
+    //          filters, the automata that meet match-dense text) the batch only takes two steps; whoever is still walking then is parked
+    //          in LDS with 16 dwords of state and walked later, 64 at a time.  (Natural text: 97 % of the items walk, 44 % finish after one
+    //          step, 34 % after two, the deepest of 64 after six or seven: the batch used to wait for that one with 60 lanes idle.)
+    // Emit mode: a record SLOT of the unit's block chain for every item that has a record or is parked; a parked walker that finds
+    // nothing leaves state = kNone in its slot and k_permute drops it.  unit_slots counts slots, unit_count records.
+    constexpr int RN = 1;
+    // nb == 0 && drain: only walk what is parked (end of a unit).  walk_parked has ONE call site here (it contains a whole trie walk).
+    auto resolve_batch = [&](uint32_t nb, bool drain) {
+        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; n_batches++; }
+        uint64_t gpos[1] = {0};
+        uint32_t w2[1] = {0}, avail[1] = {0}, best_state[1] = {0}, best_vlen[1] = {0}, depth[1] = {0}, hay = 0, slot = 0;
+        SfNode rec[1] = {SfNode{0, 0, 0, 0, {0, 0, 0, 0}}};
+        bool parked = false;
+        uint64_t pm = 0;
+        if (nb) {
+            bool valid[1] = {lane < nb};
+            const uint32_t item = valid[0] ? lds_read_u16(q2 + 2u * ((q2_head + lane) % kSfQ2)) : 0u;
+            gpos[0] = (epoch_base_chunk + (item >> 12)) * kSfChunk + (item & 1023u);
+            const uint32_t hint[1] = {(item >> 10) & 3u};
+            uint32_t hlo = 0, hhi = 0;
+            if (valid[0]) { hlo = b.hidx[gpos[0] >> kHidxShift]; hhi = b.hidx[(gpos[0] >> kHidxShift) + 1]; }
+            uint64_t end_pos[1] = {0};
+            // haystack index -> start offset: two dependent loads, made while the head's first two (haystack bytes -> slot line) are in flight
+            auto locate = [&]() {
+                hay = hlo;
+                uint64_t start = valid[0] ? b.offsets[hlo] : 0;
+                if (valid[0] && hlo != hhi) { hay = find_haystack(b, gpos[0]); start = b.offsets[hay]; }
+                end_pos[0] = valid[0] ? gpos[0] - start + 1 : 0;
+            };
+            uint32_t w[1], node[1], t16[1][4];
+            bool go[1], have_rec[1];
+            sf_resolve_head<IC, 1>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16, timing ? dbg_iters : nullptr);
+            if (ablate != 11) sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? 2u : 0xFFFFFFFFu, t16);
+            parked = go[0] && valid[0];                      // still walking after two steps (only with a walker queue)
+            if (SHORT) { const bool vv[1] = {valid[0] && !parked}; sf_resolve_short<1>(s, vv, avail, w, best_state, best_vlen); }
+            const bool found = valid[0] && best_state[0] != 0;
+            if (timing) n_found += (uint32_t)__popcll(__ballot(found));
+            if (MODE == kModeCount) add_counts(found && !parked, hay, best_vlen[0]);      // a parked walker is counted when its walk is over
+            else if (MODE == kModeEmit) {
+                const uint64_t take_mask = __ballot(found || parked);
+                const uint32_t F = (uint32_t)__popcll(take_mask);
                 if (F) {
-                    const uint32_t r = unit_count & (kPoolBlock - 1u);      // fill of the current block
+                    const uint32_t r = unit_slots & (kPoolBlock - 1u);      // fill of the current block
                     const bool need_new = r == 0u || r + F > kPoolBlock;
                     uint32_t new_block = kNone;
                     if (need_new) {
@@ -259,20 +303,44 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                             if (first_block == kNone) first_block = id;
                         }
                     }
-                    if (found[k] && pool_ok) {
-                        const uint32_t p = r + (uint32_t)__popcll(found_mask & ((1ull << lane) - 1ull));
-                        const Record rec{end_pos[k], hay[k], state[k]};
-                        if (r != 0u && p < kPoolBlock) o.pool[(uint64_t)cur_block * kPoolBlock + p] = rec;
-                        else o.pool[(uint64_t)new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p)] = rec;
+                    if ((found || parked) && pool_ok) {
+                        const uint32_t p = r + (uint32_t)__popcll(take_mask & ((1ull << lane) - 1ull));
+                        slot = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
+                        o.pool[slot] = Record{end_pos[0], hay, found ? best_state[0] - 1u : kNone};
                     }
-                    if (need_new) cur_block = new_block;
-                    unit_count += F;
+                    if (need_new && pool_ok) cur_block = new_block;
+                    unit_slots += F;
+                    unit_count += (uint32_t)__popcll(__ballot(found));
                 }
             } else {
-                if (found[k]) o.flags[hay[k]] = 1;
+                if (found) o.flags[hay] = 1;
+            }
+            pm = __ballot(parked);
+        }
+        // park the walkers that are not done (rec = the record of the node they stand at); walk the queue when it could not take them, when
+        // it holds a full batch, and -- drain -- to the end
+        if (pm || (drain && wq_n)) {
+            const uint32_t n_park = (uint32_t)__popcll(pm);
+            bool pushed = pm == 0ull;
+            for (;;) {
+                if (!pushed && wq_n + n_park <= wq_cap) {            // (wq_cap >= 64 whenever a queue exists: after a walk there is room)
+                    if (parked) {
+                        const uint32_t e = wq + (wq_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))) * 64u;
+                        lds_write_u32x4(e, make_uint4((uint32_t)gpos[0], (uint32_t)(gpos[0] >> 32), avail[0], slot));
+                        lds_write_u32x4(e + 16u, make_uint4(depth[0], best_state[0], best_vlen[0], w2[0]));
+                        lds_write_u32x4(e + 32u, make_uint4(rec[0].z, rec[0].w, rec[0].label[0], rec[0].label[1]));
+                        lds_write_u32x4(e + 48u, make_uint4(rec[0].label[2], rec[0].label[3], hay, 0u));
+                    }
+                    wq_n += n_park;
+                    wave_lds_fence();
+                    pushed = true;
+                }
+                if (pushed && (drain ? wq_n == 0u : wq_n < 64u)) break;
+                walk_parked();
+                wave_lds_fence();
             }
         }
-        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[6] += now - dbg_iters[7]; dbg_iters[7] = now; }
+        if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r3 += now - t_mark; t_mark = now; }
         q2_head += nb;
     };
 
@@ -342,7 +410,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             u_next = n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
         }
         unit_base_chunk = u * UC;
-        unit_count = 0; cur_block = kNone; first_block = kNone;
+        unit_count = 0; unit_slots = 0; cur_block = kNone; first_block = kNone;
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
@@ -437,7 +505,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                     consume_round();
                     wave_lds_fence();
                     tick(t_probe);
-                    while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN); wave_lds_fence(); }   // keeps room for the next round
+                    while (q2_tail - q2_head >= 64u * RN) { resolve_batch(64u * RN, false); wave_lds_fence(); }   // keeps room for the next round
                     tick(t_resolve);
                 }
                 // request this round: up to 128 survivors, two per lane
@@ -477,11 +545,15 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 if (pending) consume_round();                 // not overlapped: once per 16 chunks
                 wave_lds_fence();
                 tick(t_compact);
-                while (q2_tail != q2_head) { const uint32_t nb = q2_tail - q2_head; resolve_batch(nb < 64u * RN ? nb : 64u * RN); }
+                // (at the end of a unit the last call also walks every parked walker to the end: they all belong to this unit)
+                while (q2_tail != q2_head || (last_of_unit && wq_n)) {
+                    const uint32_t left = q2_tail - q2_head, nb = left < 64u * RN ? left : 64u * RN;
+                    resolve_batch(nb, last_of_unit && left == nb);
+                }
                 tick(t_resolve);
             }
         }
-        if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; }
+        if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; o.unit_slots[u] = unit_slots; }
     }
     if (timing && lane == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(o.dbg + 0), (unsigned long long)t_filter);
@@ -518,17 +590,22 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     }
 }
 
-// copy every unit's chain of pool blocks to its final place (one wavefront per unit)
+// copy every unit's chain of pool blocks to its final place (one wavefront per unit), dropping the slots that hold no record
+// (state == kNone: a parked walker that found no needle end)
 __global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __restrict__ unit_offsets, Record* __restrict__ out, uint64_t n_units)
 {
     const uint64_t u = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     if (u >= n_units) return;
-    const uint32_t n = o.unit_counts[u];
-    const uint64_t base = unit_offsets[u];
+    const uint32_t n = o.unit_slots[u];
+    uint64_t at = unit_offsets[u];
     uint32_t blk = o.unit_first[u];
     for (uint32_t done = 0; done < n; done += kPoolBlock) {
-        if (done + lane < n) out[base + done + lane] = o.pool[(uint64_t)blk * kPoolBlock + lane];
+        Record r = Record{0, 0, kNone};
+        if (done + lane < n) r = o.pool[(uint64_t)blk * kPoolBlock + lane];
+        const uint64_t m = __ballot(r.state != kNone);
+        if (r.state != kNone) out[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        at += (uint32_t)__popcll(m);
         blk = o.block_next[blk];
     }
 }
@@ -608,13 +685,25 @@ hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record
 uint64_t ac_units(const AcView& a, const BatchView& b) { return (b.total + a.chunk - 1) / a.chunk; }
 
 static size_t sf_lds_bytes_w(const SfView& s, int waves) { return kSfMaskBytes + ((size_t)4 << s.bloom_log2_words) + (size_t)waves * (kSfStage + kSfQ1 * sizeof(uint16_t) + kSfQ2 * sizeof(uint16_t)); }
+// walker-queue entries per wavefront that fit next to the rest (0 when fewer than 64 would: the queue must take a whole batch)
+static uint32_t sf_wq_cap(const SfView& s, int waves)
+{
+    static const long forced = [] { const char* e = std::getenv("AM_SF_WQ"); return e ? std::atol(e) : -1L; }();      // A/B: 0 = no queue
+    const size_t base = sf_lds_bytes_w(s, waves), limit = 160 * 1024;
+    if (base >= limit) return 0;
+    size_t cap = (limit - base) / ((size_t)waves * 64);
+    if (cap > 128) cap = 128;
+    if (forced >= 0 && (size_t)forced < cap) cap = (size_t)forced;
+    return cap >= 64 ? (uint32_t)cap : 0u;
+}
 size_t sf_lds_bytes(const SfView& s) { return sf_lds_bytes_w(s, kSfWaves); }
 
 template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false, int NT = kSfThreads>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     constexpr int waves_per_wg = NT / 64;
-    const size_t lds = sf_lds_bytes_w(s, waves_per_wg);
+    const uint32_t wq_cap = MODE == kModeAny ? 0u : sf_wq_cap(s, waves_per_wg);
+    const size_t lds = sf_lds_bytes_w(s, waves_per_wg) + (size_t)waves_per_wg * wq_cap * 64;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
@@ -630,6 +719,7 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     if (blocks > need) blocks = need;
     if (blocks == 0) return hipSuccess;
     ScanOut oo = o;
+    oo.wq_cap = wq_cap;
     if (n_units <= blocks * waves_per_wg) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
     else if (hipMemsetAsync(oo.next_unit, 0, sizeof(uint32_t), st) != hipSuccess) return hipGetLastError();
     hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), dim3((uint32_t)blocks), dim3(NT), lds, st, s, b, oo, n_chunks);
