@@ -28,6 +28,7 @@ struct ScanOut {
     uint32_t* unit_first;         // first block of each unit (kNone: none)
     uint32_t* unit_slots;         // record SLOTS in each unit's chain: its records (unit_counts) + the slots of parked walkers that found nothing
                                   // (state == kNone; k_permute drops them)
+    uint32_t wq_iters;            // set by launch_sf: trie steps a resolve batch takes before it parks the walkers that are not done (2)
     uint32_t wq_cap;              // set by launch_sf: walker-queue entries per wavefront in LDS (0: the filter leaves no room)
     uint32_t n_blocks;
     uint32_t unit_chunks;         // 1-KiB chunks per unit

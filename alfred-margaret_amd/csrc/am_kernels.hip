@@ -272,7 +272,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             uint32_t w[1], node[1], t16[1][4];
             bool go[1], have_rec[1];
             sf_resolve_head<IC, 1>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16, timing ? dbg_iters : nullptr);
-            if (ablate != 11) sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? 2u : 0xFFFFFFFFu, t16);
+            if (ablate != 11) sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? o.wq_iters : 0xFFFFFFFFu, t16);
             parked = go[0] && valid[0];                      // still walking after two steps (only with a walker queue)
             if (SHORT) { const bool vv[1] = {valid[0] && !parked}; sf_resolve_short<1>(s, vv, avail, w, best_state, best_vlen); }
             const bool found = valid[0] && best_state[0] != 0;
@@ -720,6 +720,8 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     if (blocks == 0) return hipSuccess;
     ScanOut oo = o;
     oo.wq_cap = wq_cap;
+    static const uint32_t wq_iters = [] { const char* e = std::getenv("AM_SF_WQ_ITERS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 2u; }();   // A/B: steps a batch walks before it parks
+    oo.wq_iters = wq_iters;
     if (n_units <= blocks * waves_per_wg) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
     else if (hipMemsetAsync(oo.next_unit, 0, sizeof(uint32_t), st) != hipSuccess) return hipGetLastError();
     hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), dim3((uint32_t)blocks), dim3(NT), lds, st, s, b, oo, n_chunks);
