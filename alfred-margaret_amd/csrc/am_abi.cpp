@@ -1422,12 +1422,19 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         {
             if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
             if (sp->device_bytes() > (2048ull << 20)) { delete sp; return; }      // keep workspaces of up to 2 GiB between calls
-            RpSession* old = nullptr;
+            std::vector<RpSession*> doomed;
             { std::lock_guard<std::mutex> lk(r->session_mu);
               const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
-              if (r->sessions.size() >= 8) { old = static_cast<RpSession*>(r->sessions.front()); r->sessions.erase(r->sessions.begin()); }
-              r->sessions.push_back(sp); }
-            delete old;
+              r->sessions.push_back(sp);
+              // at most 8 cached workspaces and at most 4 GiB of device memory in all of them (each is below 2 GiB): the oldest go first
+              for (;;) {
+                  size_t held = 0;
+                  for (void* q : r->sessions) held += static_cast<RpSession*>(q)->device_bytes();
+                  if (r->sessions.size() <= 1 || (r->sessions.size() <= 8 && held <= (4096ull << 20))) break;
+                  doomed.push_back(static_cast<RpSession*>(r->sessions.front()));
+                  r->sessions.erase(r->sessions.begin());
+              } }
+            for (RpSession* q : doomed) delete q;
         }
     } give_back{r, sp};
     RpSession& s = *sp;
@@ -1693,12 +1700,19 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         {
             if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
             if (sp->device_bytes() > (2048ull << 20)) { delete sp; return; }      // keep workspaces of up to 2 GiB between calls
-            RpSession* old = nullptr;
+            std::vector<RpSession*> doomed;
             { std::lock_guard<std::mutex> lk(r->session_mu);
               const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
-              if (r->sessions.size() >= 8) { old = static_cast<RpSession*>(r->sessions.front()); r->sessions.erase(r->sessions.begin()); }
-              r->sessions.push_back(sp); }
-            delete old;
+              r->sessions.push_back(sp);
+              // at most 8 cached workspaces and at most 4 GiB of device memory in all of them (each is below 2 GiB): the oldest go first
+              for (;;) {
+                  size_t held = 0;
+                  for (void* q : r->sessions) held += static_cast<RpSession*>(q)->device_bytes();
+                  if (r->sessions.size() <= 1 || (r->sessions.size() <= 8 && held <= (4096ull << 20))) break;
+                  doomed.push_back(static_cast<RpSession*>(r->sessions.front()));
+                  r->sessions.erase(r->sessions.begin());
+              } }
+            for (RpSession* q : doomed) delete q;
         }
     } give_back{r, sp};
     RpSession& s = *sp;

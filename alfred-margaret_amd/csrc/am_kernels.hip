@@ -97,7 +97,9 @@ constexpr int kSfWaves = kSfThreads / 64;
 // wavefront slots on ONE CU at the same moment; next to another stream's kernel that keeps every CU busy with short workgroups it can
 // wait for that kernel's grid to drain (seen in round 2: tests/test_multi.py), a 4-wavefront workgroup gets in like any of the others.
 constexpr int kSfLightThreads = 256;
-constexpr uint64_t kSfLightChunks = 256;         // batches of up to 256 KiB take the light configuration
+constexpr uint64_t kSfLightChunks = 16;          // batches of up to 16 KiB take the light configuration (every workgroup copies the filter into its LDS:
+                                                 // four-wavefront workgroups on anything larger would copy it four times as often -- the Replacer's
+                                                 // window scans of 50-250 KiB ran 15 % slower with a 256-KiB limit)
 constexpr int kSfQ1 = 128;                       // per-wave queue of candidate positions (u16, offset in the chunk); more take several sub-passes
 constexpr int kSfQ2 = 256;                       // per-wave ring of deferred positions (u16: chunk-in-unit << 12 | agreeing slot << 10 | offset): candidates that need the exact look
 constexpr uint32_t kSfMaxUnitChunks = 64;
@@ -600,11 +602,15 @@ __global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __re
     const uint32_t n = o.unit_slots[u];
     uint64_t at = unit_offsets[u];
     uint32_t blk = o.unit_first[u];
+    // (records move as one 16-byte vector each -- {end_pos lo, end_pos hi, haystack, state} -- and never as a struct temporary: the
+    // compiler put a `Record` local into LDS, which made every launch read its dispatch packet from host memory: 6 -> 22 us per launch)
+    const uint4* pool4 = reinterpret_cast<const uint4*>(o.pool);
+    uint4* out4 = reinterpret_cast<uint4*>(out);
     for (uint32_t done = 0; done < n; done += kPoolBlock) {
-        Record r = Record{0, 0, kNone};
-        if (done + lane < n) r = o.pool[(uint64_t)blk * kPoolBlock + lane];
-        const uint64_t m = __ballot(r.state != kNone);
-        if (r.state != kNone) out[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
+        uint4 r = make_uint4(0u, 0u, 0u, kNone);
+        if (done + lane < n) r = pool4[(uint64_t)blk * kPoolBlock + lane];
+        const uint64_t m = __ballot(r.w != kNone);
+        if (r.w != kNone) out4[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = r;
         at += (uint32_t)__popcll(m);
         blk = o.block_next[blk];
     }

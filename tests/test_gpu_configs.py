@@ -160,8 +160,8 @@ def test_fold_hash_equals_oracle_fold():
 def test_cfg1_contains_any_three_needles_one_megabyte():
     """BASELINE.json configs[0]: Searcher.containsAny CaseSensitive, needles tshirt / shirts / shorts over 1 MB of synthetic ASCII
     (Searcher.hs:156-164), through the one-shot entry points a Haskell caller binds: am_contains_any, am_count and am_run on a host
-    slice == the oracle, plus the haystack sizes around the light / full kernel configuration switch (256 KiB) and the pinned-upload
-    piece size."""
+    slice == the oracle, plus haystack sizes around the light / full kernel configuration switch (16 KiB) and the pinned-upload
+    piece size (256 KiB)."""
     needles = ["tshirt", "shirts", "shorts"]
     rng = np.random.default_rng(1)
     words = ["short", "tshirts", "sweatshirts", "and", "shirtshirts", "the", "quick", "brown", "fox", "shorts"]
@@ -170,7 +170,7 @@ def test_cfg1_contains_any_three_needles_one_megabyte():
     a = am.Automaton(needles)
     s = am.Searcher(0, needles)
     o = oracle.Machine(needles)
-    for hay in (big, quiet, big[:262144], big[:262145], big[:300_001], big[:100], b""):
+    for hay in (big, quiet, big[:262144], big[:262145], big[:300_001], big[:16384], big[:16385], big[:100], b""):
         assert bool(s.contains_any(hay)) == o.contains_any(0, hay)
         assert int(a.count_matches(0, [hay])[0]) == o.count_matches(0, hay)
     hay_i, pos, val = a.run_batch_with_case(0, [big, quiet])

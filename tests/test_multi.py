@@ -112,6 +112,34 @@ def test_multi_entry_points_one_device():
             recs = np.frombuffer((C.c_char * (n.value * am.api.MATCH_DTYPE.itemsize)).from_address(p.value), dtype=am.api.MATCH_DTYPE).copy() if n.value else np.zeros(0, am.api.MATCH_DTYPE)
             lib.am_multi_matches_free(p)
             assert expand_records(o.values_off(), o.values(), recs["haystack"], recs["state"], recs["end_pos"]) == exp
+            # the device-resident forms: block i of the haystacks uploaded onto local device i, records left there, counts all-reduced
+            batches, results, dcounts = (C.c_void_p * D)(), (C.c_void_p * D)(), []
+            bounds = [(len(hays) * i // D, len(hays) * (i + 1) // D) for i in range(D)]
+            for i, (lo, hi) in enumerate(bounds):
+                part = am.api._Slices(hays[lo:hi])
+                bh = C.c_void_p()
+                am.api.check(lib.am_multi_batch_upload(m, i, part.arr, part.n, C.byref(bh)))
+                batches[i] = bh.value
+                dcounts.append(np.zeros(hi - lo + 1, np.uint64))
+            cptrs = (C.c_void_p * D)(*[c.ctypes.data for c in dcounts])
+            local_totals, job_total, n_recs = (C.c_uint64 * D)(), C.c_uint64(0), C.c_uint64(0)
+            am.api.check(lib.am_multi_count_batch(m, autos, 0, batches, cptrs, local_totals, C.byref(job_total)))
+            assert int(job_total.value) == sum(exp_counts) == sum(int(x) for x in local_totals)
+            assert [int(c) for i, (lo, hi) in enumerate(bounds) for c in dcounts[i][:hi - lo]] == exp_counts
+            am.api.check(lib.am_multi_run_batch(m, autos, 0, batches, results, C.byref(n_recs)))
+            got = []
+            for i, (lo, hi) in enumerate(bounds):
+                k = int(lib.am_matches_size(results[i]))
+                ptr = lib.am_matches_data(results[i])
+                r = np.frombuffer((C.c_char * (k * am.api.MATCH_DTYPE.itemsize)).from_address(ptr), dtype=am.api.MATCH_DTYPE).copy() if k else np.zeros(0, am.api.MATCH_DTYPE)
+                got += expand_records(o.values_off(), o.values(), r["haystack"] + lo, r["state"], r["end_pos"])
+                lib.am_matches_free(results[i]); lib.am_batch_destroy(batches[i])
+            assert got == exp and int(n_recs.value) == len(recs)
+            # a NULL batch is "no work for that device", and a bad argument comes back as an error from every entry point (no hang)
+            none = (C.c_void_p * D)()
+            am.api.check(lib.am_multi_count_batch(m, autos, 0, none, None, None, C.byref(job_total)))
+            assert int(job_total.value) == 0
+            assert lib.am_multi_batch_upload(m, D, s.arr, s.n, C.byref(C.c_void_p())) == am.AM_ERR_INVALID
             vals = np.arange(D * 3, dtype=np.uint64) + 5
             before = vals.copy()
             am.api.check(lib.am_multi_allreduce_sum(m, vals.ctypes.data, 3))

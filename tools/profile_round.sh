@@ -12,7 +12,7 @@ for w in $WL; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.log 2>$OUT/bench_$w.err; echo "bench $w rc=$?"
 done
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $R/bench.py --no-cpu-baseline > $OUT/kt.log 2>&1; echo "kernel trace rc=$?"
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-h2d > $OUT/kt.log 2>&1; echo "kernel trace rc=$?"
 python $R/tools/rocprof_summary.py $OUT/kt > $OUT/kt_summary.md 2>&1
 [ "${2:-all}" = "core" ] || timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt5 -o kt5 -- python $R/bench.py --workload cfg5_replacer_50k_1GiB --steps 3 --warmup 1 --no-cpu-baseline > $OUT/kt5.log 2>&1; echo "kernel trace cfg5 rc=$?"
 python $R/tools/rocprof_summary.py $OUT/kt5 > $OUT/kt5_summary.md 2>&1
