@@ -592,6 +592,338 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     }
 }
 
+// ------------------------------------------------------------------ the two-kernel pipeline for large batches (128-KiB filter)
+//
+// k_sf does everything in one wavefront: filter, compaction, probe, resolve.  Only the filter needs the 128-KiB LDS table that pins the
+// occupancy at four wavefronts per SIMD; the probe and the resolve are chains of dependent L2 / HBM trips that those four in-order
+// wavefronts cannot hide.  For large batches the work is therefore cut in two kernels that run AT THE SAME TIME on
+// two streams, slice by slice:
+//   k_filter   filter + compaction only; the candidate positions (u16 offsets in the work unit) go to per-unit chains of 256-entry
+//              blocks in HBM.  No staged chunk, no queues: 130 KiB of LDS, <= 64 VGPRs.
+//   k_consume  probe + resolve of the PREVIOUS slice's candidates: rounds of 128 candidates whatever the chunk boundaries (k_sf's rounds
+//              are per chunk and 65 % full), text bytes / buckets / candidate entries each requested one round ahead, the resolve as in
+//              k_sf.  No big LDS, <= 128 VGPRs: two of its wavefronts fit on every SIMD NEXT TO k_filter's four, so the CU's issue
+//              slots see six wavefronts, and the dependent trips of the one kind overlap with the arithmetic of the other.
+// A kernel boundary separates producer and consumer of a slice (no flags, no polling, no cross-XCD coherence games): slice i is consumed
+// while slice i + 1 is filtered.  Record output, ordering (per-unit chains, position order) and counts are exactly k_sf's.
+constexpr uint32_t kCandBlock = 256;             // candidate entries per block (512 B)
+constexpr uint32_t kCandGrant = 32;              // blocks a k_filter wavefront takes per atomic
+
+template <bool IC, int LW, bool SHORT>
+__global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, PipeView pv, uint32_t UC, uint64_t n_chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const uint32_t words = 1u << s.bloom_log2_words;
+    uint32_t* masks = lds;
+    uint32_t* bloom = lds + kBloomMasks;
+    for (uint32_t i = threadIdx.x; i < kBloomMasks; i += kSfThreads) masks[i] = bloom_mask_entry(i);
+    for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
+    const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
+    uint32_t grant_next = 0, grant_left = 0;
+    bool pool_ok = true;
+    auto fetch = [&](uint64_t cc, uint4& v) {
+        const uint64_t p = cc * kSfChunk + lane * 16u;
+        v = make_uint4(0, 0, 0, 0);
+        if (cc < n_chunks && p < b.total) {
+            typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
+            const u32x4_native t = *reinterpret_cast<const u32x4_native*>(b.text + p);
+            v = make_uint4(t.x, t.y, t.z, t.w);
+        }
+    };
+    auto fetch_before = [&](uint64_t cc, uint32_t& c4) {          // the 4 (folded) bytes before chunk cc; uniform: one request for the wave
+        uint32_t t = 0;
+        if (cc < n_chunks && cc > 0) t = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t*>(b.text + cc * kSfChunk - 4));
+        c4 = IC ? fold_dword(t) : t;
+    };
+    uint64_t u = pv.unit0 + (uint64_t)blockIdx.x * kSfWaves + wave;
+    uint4 cur_v; uint32_t carry4;
+    fetch(u < pv.unit1 ? u * UC : n_chunks, cur_v);
+    fetch_before(u < pv.unit1 ? u * UC : n_chunks, carry4);
+    asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));      // waited for here, not together with the loop's first prefetch
+    uint64_t u_next = u;
+    for (; u < pv.unit1; u = u_next) {
+        u_next = u + n_waves;
+        if (pv.unit_ticket) {
+            uint32_t ticket = 0;
+            if (lane == 0) ticket = atomicAdd(pv.unit_ticket, 1u);
+            u_next = pv.unit0 + n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+        }
+        const uint64_t next_first = u_next < pv.unit1 ? u_next * UC : n_chunks;        // (n_chunks: nothing to prefetch)
+        const uint64_t unit_base_chunk = u * UC;
+        uint32_t unit_cands = 0, cur_block = kNone, first_block = kNone;
+        const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
+        for (uint32_t ci = 0; ci < n_in_unit; ci++) {
+            const uint64_t c = unit_base_chunk + ci;
+            uint4 next_v;
+            uint32_t next_c4 = 0;
+            const bool last_of_unit = ci + 1 >= n_in_unit;
+            fetch(!last_of_unit ? c + 1 : next_first, next_v);
+            if (last_of_unit) fetch_before(next_first, next_c4);
+            const uint64_t p0 = c * kSfChunk + lane * 16u;
+            uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+            if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+            const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);      // the lane below's last dword (lane 0: the carry)
+            const uint32_t d[5] = {d0, d1, d2, d3, d4};
+            if (!last_of_unit) next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
+            uint32_t cand = 0;
+            {
+                uint32_t h[16], v[16], m[16];
+                const uint32_t sh_word = 32u - log2_words;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int j = k >> 2, sh = k & 3;
+                    const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
+                    h[k] = w * kBloomMul;
+                }
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (LW) v[k] = lds_read_u32(kSfMaskBytes + ((h[k] >> (30 - LW)) & (((1u << LW) - 1u) << 2)));
+                    else v[k] = lds_read_u32(kSfMaskBytes + ((h[k] >> sh_word) << 2));
+                    m[k] = lds_read_u32(h[k] & ((kBloomMasks - 1u) << 2));
+                }
+#pragma unroll
+                for (int k = 15; k >= 0; k--) cand = (cand << 1) | (uint32_t)((v[k] & m[k]) == m[k]);
+            }
+            if (SHORT) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int j = k >> 2, sh = k & 3;
+                    const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
+                    if (sf_filter_short(bloom, log2_words, tiers, w, masks)) cand |= 1u << k;
+                }
+            }
+            if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
+            // ---- the candidates of the chunk go to the unit's chain, in position order
+            const uint32_t n = __popc(cand);
+            const uint32_t incl = wave_inclusive_sum(n, lane);
+            const uint32_t total = __shfl(incl, 63, 64);
+            if (total) {
+                const uint32_t s0 = unit_cands, r = s0 & (kCandBlock - 1u);
+                const uint32_t n_new = ((s0 + total - 1u) / kCandBlock) - (s0 / kCandBlock) + (r ? 0u : 1u);      // <= 5: blocks with consecutive ids from ONE grant
+                const uint32_t old_block = cur_block;
+                uint32_t new_first = kNone;
+                if (n_new) {
+                    if (grant_left < n_new) {                    // what is left of the old grant is abandoned
+                        uint32_t g = 0;
+                        if (lane == 0) g = atomicAdd(pv.cctrl, kCandGrant);
+                        grant_next = __builtin_amdgcn_readfirstlane(g);
+                        grant_left = kCandGrant;
+                    }
+                    new_first = grant_next; grant_next += n_new; grant_left -= n_new;
+                    if (new_first + n_new > pv.n_cblocks) { pool_ok = false; if (lane == 0) pv.cctrl[1] = 1u; }     // keep counting; the host falls back to k_sf
+                    else {
+                        if (lane < n_new) pv.cblock_next[new_first + lane] = lane + 1u < n_new ? new_first + lane + 1u : kNone;
+                        if (lane == 0 && cur_block != kNone) pv.cblock_next[cur_block] = new_first;
+                        if (first_block == kNone) first_block = new_first;
+                        cur_block = new_first + n_new - 1u;
+                    }
+                }
+                if (pool_ok) {
+                    uint32_t slot = s0 + incl - n;
+                    const uint32_t pos_base = (ci << 10) | (lane * 16u);
+                    while (cand) {
+                        const uint32_t k = __builtin_ctz(cand);
+                        cand &= cand - 1u;
+                        const uint32_t bi = slot / kCandBlock - s0 / kCandBlock;
+                        const uint32_t blk = (r && bi == 0u) ? old_block : new_first + bi - (r ? 1u : 0u);
+                        pv.cands[(uint64_t)blk * kCandBlock + (slot & (kCandBlock - 1u))] = (uint16_t)(pos_base + k);
+                        slot++;
+                    }
+                }
+                unit_cands = s0 + total;
+            }
+            cur_v = next_v; carry4 = next_c4;
+        }
+        if (lane == 0) { pv.cand_first[u] = first_block; pv.cand_count[u] = unit_cands; }
+    }
+}
+
+// the consumer of one slice: wavefront w takes the units unit0 + w, unit0 + w + W, ...
+constexpr int kCsThreads = 256;
+constexpr uint32_t kCsRing = 256;               // per-wave ring of deferred candidates (u32: offset in the unit | agreeing slot << 16)
+template <bool IC, int MODE, bool SHORT>
+__global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, ScanOut o, PipeView pv)
+{
+    __shared__ uint32_t ring_all[(kCsThreads / 64) * kCsRing];
+    if (pv.cctrl[1]) return;                                 // the candidate pool overflowed: the host repeats the scan with k_sf
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t* ring = ring_all + wave * kCsRing;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kCsThreads / 64);
+    const uint64_t unit_bytes = (uint64_t)o.unit_chunks * kSfChunk;
+    uint64_t nval = 0;
+    uint32_t cnt_hay = kNone; uint64_t cnt_val = 0;          // count mode: running per-haystack sum of this wave
+    auto flush_count = [&]() {
+        if (cnt_hay != kNone && cnt_val && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + cnt_hay), (unsigned long long)cnt_val);
+        cnt_val = 0;
+    };
+    auto add_counts = [&](bool found, uint32_t hay, uint32_t vlen) {
+        if (found) nval += vlen;
+        const uint64_t fm = __ballot(found);
+        if (!o.hay_counts || !fm) return;
+        const uint32_t h0 = __shfl(hay, __ffsll((unsigned long long)fm) - 1, 64);
+        if (__ballot(found && hay != h0) == 0) {
+            const uint64_t sum = wave_sum_u64(found ? (uint64_t)vlen : 0ull);
+            if (h0 != cnt_hay) { flush_count(); cnt_hay = h0; }
+            cnt_val += sum;
+        } else if (found) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
+    };
+    uint32_t grant_next = 0, grant_left = 0;
+    bool pool_ok = true;
+
+    for (uint64_t u = pv.unit0 + (uint64_t)blockIdx.x * (kCsThreads / 64) + wave; u < pv.unit1; u += n_waves) {
+        const uint32_t n_cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_count[u]);
+        uint32_t unit_count = 0, unit_slots = 0, cur_block = kNone, first_block = kNone;
+        uint32_t rg_head = 0, rg_tail = 0;
+        const uint64_t unit_pos = u * unit_bytes;
+        // the haystack that holds the unit's first byte (uniform; one lookup per unit): a position below its end needs no lookup of its own
+        uint32_t hay_u = 0; uint64_t hs_u = 1, he_u = 0;
+        if (n_cand) {
+            hay_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.hidx[unit_pos >> kHidxShift]);
+            hs_u = uniform_u64(b.offsets[hay_u]); he_u = uniform_u64(b.offsets[hay_u + 1]);
+        }
+        // ---- phase 2 for the oldest nb (<= 64) deferred candidates of the ring, in lock step (as k_sf's resolve_batch, without a walker queue)
+        auto resolve_batch = [&](uint32_t nb) {
+            bool valid[1] = {lane < nb};
+            const uint32_t item = valid[0] ? ring[(rg_head + lane) % kCsRing] : 0u;
+            uint64_t gpos[1] = {unit_pos + (item & 0xFFFFu)};
+            const uint32_t hint[1] = {(item >> 16) & 3u};
+            const bool far = valid[0] && gpos[0] >= he_u;
+            uint32_t hlo = 0, hhi = 0;
+            if (far) { hlo = b.hidx[gpos[0] >> kHidxShift]; hhi = b.hidx[(gpos[0] >> kHidxShift) + 1]; }
+            uint64_t end_pos[1] = {0};
+            uint32_t hay = hay_u;
+            auto locate = [&]() {
+                uint64_t start = hs_u;
+                if (far) { hay = hlo; if (hlo != hhi) hay = find_haystack(b, gpos[0]); start = b.offsets[hay]; }
+                end_pos[0] = valid[0] ? gpos[0] - start + 1 : 0;
+            };
+            uint32_t w[1], w2[1], avail[1], best_state[1], best_vlen[1], depth[1], node[1], t16[1][4];
+            bool go[1], have_rec[1];
+            SfNode rec[1];
+            sf_resolve_head<IC, 1>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16);
+            sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, nullptr, 0xFFFFFFFFu, t16);
+            if (SHORT) sf_resolve_short<1>(s, valid, avail, w, best_state, best_vlen);
+            const bool found = valid[0] && best_state[0] != 0;
+            if (MODE == kModeCount) add_counts(found, hay, best_vlen[0]);
+            else if (MODE == kModeEmit) {
+                const uint64_t found_mask = __ballot(found);
+                const uint32_t F = (uint32_t)__popcll(found_mask);
+                if (F) {
+                    const uint32_t r = unit_slots & (kPoolBlock - 1u);
+                    const bool need_new = r == 0u || r + F > kPoolBlock;
+                    uint32_t new_block = kNone;
+                    if (need_new) {
+                        if (grant_left == 0) {
+                            uint32_t g = 0;
+                            if (lane == 0) g = atomicAdd(o.pool_ctrl, kSfBlockGrant);
+                            grant_next = __builtin_amdgcn_readfirstlane(g);
+                            grant_left = kSfBlockGrant;
+                        }
+                        const uint32_t id = grant_next++;
+                        grant_left--;
+                        if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }
+                        else {
+                            new_block = id;
+                            if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
+                            if (first_block == kNone) first_block = id;
+                        }
+                    }
+                    if (found && pool_ok) {
+                        const uint32_t p = r + (uint32_t)__popcll(found_mask & ((1ull << lane) - 1ull));
+                        const uint32_t slot = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
+                        uint4 rec4 = make_uint4((uint32_t)end_pos[0], (uint32_t)(end_pos[0] >> 32), hay, best_state[0] - 1u);
+                        reinterpret_cast<uint4*>(o.pool)[slot] = rec4;
+                    }
+                    if (need_new && pool_ok) cur_block = new_block;
+                    unit_slots += F; unit_count += F;
+                }
+            } else {
+                if (found) o.flags[hay] = 1;
+            }
+            rg_head += nb;
+        };
+
+        // ---- phase 1 over the unit's candidates, 128 per round (two per lane), three rounds in flight.  Pass i of the loop:
+        //   decides round i - 2, requests the two hot buckets of round i - 1, the haystack bytes of round i, the candidate entries of round i + 1
+        uint32_t blk_e = n_cand ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]) : kNone;      // block of the round whose entries are requested next
+        const uint32_t n_rounds = (n_cand + 127u) / 128u;
+        uint32_t e_pos[2] = {0, 0};                    // round i + 1 (after step 3 of the previous pass: entries requested)
+        uint32_t t_pos[2] = {0, 0}; uint64_t t_raw[2] = {0, 0}; bool t_valid[2] = {false, false};      // round i: text requested
+        u32x2 p_a[2], p_b[2]; uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0}; bool p_valid[2] = {false, false};      // round i - 1: buckets requested
+        p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
+        uint32_t blk_after = kNone;                    // the block after blk_e (requested when blk_e is entered, needed two rounds later)
+        auto request_entries = [&](uint32_t round) {             // round < n_rounds
+            if (!(round & 1u) && round + 2u < n_rounds) blk_after = pv.cblock_next[blk_e];                                          // two rounds per block
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t e = round * 128u + 64u * k + lane;
+                e_pos[k] = e < n_cand ? (uint32_t)pv.cands[(uint64_t)blk_e * kCandBlock + (e & (kCandBlock - 1u))] | 0x10000u : 0u;      // bit 16: valid
+            }
+            if ((round & 1u) && round + 1u < n_rounds) blk_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_after);
+        };
+        if (n_rounds) request_entries(0);
+        for (uint32_t i = 0; i < n_rounds + 2u; i++) {
+            // (1) decide round i - 2 (its buckets were requested in the previous pass)
+            if (i >= 2u) {
+                bool defer[2]; uint32_t hint[2];
+                sf_probe_decide<2>(s, p_a, p_b, p_e, p_valid, defer, hint);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint64_t m = __ballot(defer[k]);
+                    if (defer[k]) ring[(rg_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kCsRing] = (hint[k] << 16) | (p_pos[k] & 0xFFFFu);
+                    rg_tail += (uint32_t)__popcll(m);
+                }
+                wave_lds_fence();
+                while (rg_tail - rg_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }       // keeps room for the next round (<= 128 more)
+            }
+            // (2) round i - 1: its haystack bytes are here -> hashes -> request its two hot buckets
+            if (i >= 1u && i - 1u < n_rounds) {
+                uint64_t avail[2]; uint32_t w[2], nb[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint64_t gpos = unit_pos + (t_pos[k] & 0xFFFFu);
+                    uint64_t v = t_raw[k];
+                    const uint32_t drop = gpos >= 7 ? 0u : (uint32_t)(7 - gpos);
+                    v = drop ? (v << (8u * drop)) : v;                // byte gpos ends up on top; bytes before the buffer are zero
+                    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+                    if (IC) { lo = fold_dword(lo); hi = fold_dword(hi); }
+                    w[k] = hi;                                        // bytes gpos-3 .. gpos
+                    nb[k] = (lo >> 24) | (((lo >> 16) & 0xFFu) << 8);   // the two before them, nearest in bits 0-7
+                    avail[k] = gpos - hs_u + 1;
+                    if (t_valid[k] && gpos >= he_u) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
+                    p_pos[k] = t_pos[k]; p_valid[k] = t_valid[k];
+                }
+                sf_probe_issue<2>(s, w, nb, avail, p_valid, p_a, p_b, p_e);
+            } else { p_valid[0] = p_valid[1] = false; }
+            // (3) round i: its entries are here -> request its haystack bytes (the last 8 ending at the position: one unaligned 8-byte read)
+            if (i < n_rounds) {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    t_valid[k] = (e_pos[k] & 0x10000u) != 0u; t_pos[k] = e_pos[k];
+                    t_raw[k] = 0;
+                    if (t_valid[k]) {
+                        const uint64_t gpos = unit_pos + (e_pos[k] & 0xFFFFu);
+                        typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+                        t_raw[k] = *reinterpret_cast<const u64_unaligned*>(b.text + (gpos >= 7 ? gpos - 7 : 0));
+                    }
+                }
+            } else { t_valid[0] = t_valid[1] = false; }
+            // (4) request the entries of round i + 1
+            if (i + 1u < n_rounds) request_entries(i + 1u);
+        }
+        while (rg_tail != rg_head) { const uint32_t left = rg_tail - rg_head; resolve_batch(left < 64u ? left : 64u); }
+        if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; o.unit_slots[u] = unit_slots; }
+    }
+    if (MODE == kModeCount) {
+        if (o.hay_counts) flush_count();
+        nval = wave_sum_u64(nval);
+        if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+    }
+}
+
 // copy every unit's chain of pool blocks to its final place (one wavefront per unit), dropping the slots that hold no record
 // (state == kNone: a parked walker that found no needle end)
 __global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __restrict__ unit_offsets, Record* __restrict__ out, uint64_t n_units)
@@ -787,6 +1119,64 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     if (mode == kModeCount) return launch_sf_t<false, kModeCount>(s, b, o, n_cu, st);
     if (mode == kModeEmit) return launch_sf_t<false, kModeEmit>(s, b, o, n_cu, st);
     return launch_sf_t<false, kModeAny>(s, b, o, n_cu, st);
+}
+
+// ---- the two-kernel pipeline (k_filter / k_consume)
+template <bool IC, bool SHORT>
+static hipError_t launch_filter_t(const SfView& s, const BatchView& b, const PipeView& pv, uint32_t unit_chunks, int n_cu, hipStream_t st)
+{
+    const size_t lds = kSfMaskBytes + ((size_t)4 << s.bloom_log2_words);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter<IC, 15, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
+        attr_set = true;
+    }
+    const uint64_t n_units = pv.unit1 - pv.unit0;
+    uint64_t blocks = (uint64_t)n_cu;
+    const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
+    if (blocks > need) blocks = need;
+    if (blocks == 0) return hipSuccess;
+    PipeView p = pv;
+    if (n_units <= blocks * kSfWaves) p.unit_ticket = nullptr;          // one unit per wavefront at most: nothing to draw
+    hipLaunchKernelGGL((k_filter<IC, 15, SHORT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, p, unit_chunks, sf_chunks(b));
+    return hipGetLastError();
+}
+
+// k_filter over the units [pv.unit0, pv.unit1) (only for the 128-KiB filter: bloom_log2_words == 15); *pv.unit_ticket must be zero
+hipError_t launch_filter(bool ic, const SfView& s, const BatchView& b, const PipeView& pv, uint32_t unit_chunks, int n_cu, hipStream_t st)
+{
+    if (s.bloom_log2_words != 15) return hipErrorInvalidValue;
+    const bool sh = (s.tiers & 7u) != 0;
+    if (ic) return sh ? launch_filter_t<true, true>(s, b, pv, unit_chunks, n_cu, st) : launch_filter_t<true, false>(s, b, pv, unit_chunks, n_cu, st);
+    return sh ? launch_filter_t<false, true>(s, b, pv, unit_chunks, n_cu, st) : launch_filter_t<false, false>(s, b, pv, unit_chunks, n_cu, st);
+}
+
+constexpr int kCsWavesPerCu = 12;                // three per SIMD: what fits next to k_filter's four (56 VGPRs) with k_consume's <= 96
+
+template <bool IC, int MODE>
+static hipError_t launch_consume_t(const SfView& s, const BatchView& b, const ScanOut& o, const PipeView& pv, int n_cu, hipStream_t st)
+{
+    const uint64_t n_units = pv.unit1 - pv.unit0;
+    uint64_t waves = (uint64_t)n_cu * kCsWavesPerCu;
+    if (waves > n_units) waves = n_units;
+    const uint32_t blocks = (uint32_t)((waves + (kCsThreads / 64) - 1) / (kCsThreads / 64));
+    if (blocks == 0) return hipSuccess;
+    if (s.tiers & 7u) hipLaunchKernelGGL((k_consume<IC, MODE, true>), dim3(blocks), dim3(kCsThreads), 0, st, s, b, o, pv);
+    else hipLaunchKernelGGL((k_consume<IC, MODE, false>), dim3(blocks), dim3(kCsThreads), 0, st, s, b, o, pv);
+    return hipGetLastError();
+}
+
+// k_consume over the same units: probe + resolve of their candidates in `mode`
+hipError_t launch_consume(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, const PipeView& pv, int n_cu, hipStream_t st)
+{
+    if (ic) {
+        if (mode == kModeCount) return launch_consume_t<true, kModeCount>(s, b, o, pv, n_cu, st);
+        if (mode == kModeEmit) return launch_consume_t<true, kModeEmit>(s, b, o, pv, n_cu, st);
+        return launch_consume_t<true, kModeAny>(s, b, o, pv, n_cu, st);
+    }
+    if (mode == kModeCount) return launch_consume_t<false, kModeCount>(s, b, o, pv, n_cu, st);
+    if (mode == kModeEmit) return launch_consume_t<false, kModeEmit>(s, b, o, pv, n_cu, st);
+    return launch_consume_t<false, kModeAny>(s, b, o, pv, n_cu, st);
 }
 
 template <bool IC, int MODE>
