@@ -731,9 +731,10 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     p.n_cu = g_rt.dev[b->dev].n_cu;
     p.batch = b;
     {
-        // AM_SF_PIPE: 0 = never, 1 = whenever the filter allows it (tests), unset = batches of 256 MiB and more
-        static const int pipe_env = [] { const char* e = std::getenv("AM_SF_PIPE"); return e ? std::atoi(e) : -1; }();
-        p.pipe = p.use_sf && p.f->h.sf_bloom_log2_words == 15 && (p.f->h.sf_tiers & 8u) && pipe_env != 0 && (pipe_env == 1 || b->total >= (256ull << 20));
+        // AM_SF_PIPE=1: the two-kernel pipeline whenever the filter allows it (tests, A/B).  Off by default: measured slower than k_sf so far
+        // (DESIGN.md section 6).
+        static const int pipe_env = [] { const char* e = std::getenv("AM_SF_PIPE"); return e ? std::atoi(e) : 0; }();
+        p.pipe = p.use_sf && p.f->h.sf_bloom_log2_words == 15 && (p.f->h.sf_tiers & 8u) && pipe_env == 1;
         if (p.pipe) p.unit_chunks = 64;      // (a candidate's offset in its unit has 16 bits either way; the slices want whole 64-KiB units)
     }
     p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
@@ -796,13 +797,15 @@ int launch_scan_pipeline(const Plan& p, int mode, const ScanOut& o, hipStream_t 
     if (n_cblocks >= (1ull << 24)) return fail(AM_ERR_UNSUPPORTED, "too many candidate positions for one call; split the batch");
     AM_TRY(b->cands.ensure(n_cblocks * kCandBlockEntries * sizeof(uint16_t)));
     AM_TRY(b->cblock_next.ensure(n_cblocks * sizeof(uint32_t)));
-    AM_TRY(b->cand_meta.ensure(2 * p.n_units * sizeof(uint32_t)));
+    const uint64_t n_chunks_all = sf_chunks(p.bv);
+    AM_TRY(b->cand_meta.ensure(2 * p.n_units * sizeof(uint32_t) + (n_chunks_all + 2) * sizeof(uint16_t)));
     AM_TRY(b->pipe_tickets.ensure(n_slices * sizeof(uint32_t)));
     HIP_TRY(hipMemsetAsync(b->pipe_tickets.p, 0, n_slices * sizeof(uint32_t), st));
     PipeView pv{};
     pv.cands = (uint16_t*)b->cands.p; pv.cblock_next = (uint32_t*)b->cblock_next.p;
     pv.cctrl = (uint32_t*)b->small.p + 6;                   // cleared with the rest of the counter block by the caller
     pv.cand_first = (uint32_t*)b->cand_meta.p; pv.cand_count = (uint32_t*)b->cand_meta.p + p.n_units;
+    pv.chunk_count = (uint16_t*)((uint32_t*)b->cand_meta.p + 2 * p.n_units);
     pv.n_cblocks = (uint32_t)n_cblocks;
     // whatever the caller queued on its stream so far (clears, the haystack index) comes before the first consumer
     for (uint64_t i = 0; i < n_slices; i++) {

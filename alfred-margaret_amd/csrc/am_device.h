@@ -62,6 +62,7 @@ struct PipeView {
     uint32_t* cctrl;              // [0] next free block, [1] overflow flag
     uint32_t* cand_first;         // per unit: first block (kNone: none)
     uint32_t* cand_count;         // per unit: candidates
+    uint16_t* chunk_count;        // per 1-KiB chunk: candidates
     uint32_t* unit_ticket;        // per slice: k_filter's unit counter (zeroed by the host)
     uint32_t n_cblocks;
     uint64_t unit0, unit1;        // the slice: units [unit0, unit1)

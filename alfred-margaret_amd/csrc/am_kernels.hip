@@ -700,6 +700,7 @@ __global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, Pi
             const uint32_t n = __popc(cand);
             const uint32_t incl = wave_inclusive_sum(n, lane);
             const uint32_t total = __shfl(incl, 63, 64);
+            if (lane == 0) pv.chunk_count[c] = (uint16_t)total;          // (<= 1024)
             if (total) {
                 const uint32_t s0 = unit_cands, r = s0 & (kCandBlock - 1u);
                 const uint32_t n_new = ((s0 + total - 1u) / kCandBlock) - (s0 / kCandBlock) + (r ? 0u : 1u);      // <= 5: blocks with consecutive ids from ONE grant
@@ -748,6 +749,7 @@ template <bool IC, int MODE, bool SHORT>
 __global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, ScanOut o, PipeView pv)
 {
     __shared__ uint32_t ring_all[(kCsThreads / 64) * kCsRing];
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[(kCsThreads / 64) * (kSfStage / 4)];      // per wave: the current chunk, folded (k_sf's layout)
     if (pv.cctrl[1]) return;                                 // the candidate pool overflowed: the host repeats the scan with k_sf
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t* ring = ring_all + wave * kCsRing;
@@ -846,74 +848,140 @@ __global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, S
             rg_head += nb;
         };
 
-        // ---- phase 1 over the unit's candidates, 128 per round (two per lane), three rounds in flight.  Pass i of the loop:
-        //   decides round i - 2, requests the two hot buckets of round i - 1, the haystack bytes of round i, the candidate entries of round i + 1
-        uint32_t blk_e = n_cand ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]) : kNone;      // block of the round whose entries are requested next
-        const uint32_t n_rounds = (n_cand + 127u) / 128u;
-        uint32_t e_pos[2] = {0, 0};                    // round i + 1 (after step 3 of the previous pass: entries requested)
-        uint32_t t_pos[2] = {0, 0}; uint64_t t_raw[2] = {0, 0}; bool t_valid[2] = {false, false};      // round i: text requested
-        u32x2 p_a[2], p_b[2]; uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0}; bool p_valid[2] = {false, false};      // round i - 1: buckets requested
+        // ---- phase 1 over the unit's chunks, in k_sf's shape: the chunk is read with one coalesced 16-byte load per lane (sequential: the next
+        // chunk and its candidate entries are requested a chunk ahead), folded and staged in LDS; the candidates -- from k_filter's chain
+        // instead of a filter pass -- pick their window out of the staged chunk, two per lane, up to 128 per round; their two hot buckets
+        // are requested at the end of a chunk's pass and looked at in the next one.
+        const uint32_t UC = o.unit_chunks;
+        const uint64_t n_chunks_all = (b.total + kSfChunk - 1) / kSfChunk;
+        const uint64_t unit_base_chunk = u * UC;
+        const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks_all ? UC : n_chunks_all - unit_base_chunk);
+        auto fetch_chunk = [&](uint64_t cc, uint4& v) {
+            const uint64_t p = cc * kSfChunk + lane * 16u;
+            v = make_uint4(0, 0, 0, 0);
+            if (cc < n_chunks_all && p < b.total) {
+                typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
+                const u32x4_native t = *reinterpret_cast<const u32x4_native*>(b.text + p);
+                v = make_uint4(t.x, t.y, t.z, t.w);
+            }
+        };
+        u32x2 p_a[2], p_b[2]; uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};       // the round whose buckets are in flight (p_pos: offset in the unit | 0x10000)
         p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
-        uint32_t blk_after = kNone;                    // the block after blk_e (requested when blk_e is entered, needed two rounds later)
-        auto request_entries = [&](uint32_t round) {             // round < n_rounds
-            if (!(round & 1u) && round + 2u < n_rounds) blk_after = pv.cblock_next[blk_e];                                          // two rounds per block
+        bool pending = false;
+        auto consume_round = [&]() {
+            bool valid[2], defer[2]; uint32_t hint[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x10000u) != 0;
+            sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const uint32_t e = round * 128u + 64u * k + lane;
-                e_pos[k] = e < n_cand ? (uint32_t)pv.cands[(uint64_t)blk_e * kCandBlock + (e & (kCandBlock - 1u))] | 0x10000u : 0u;      // bit 16: valid
+                const uint64_t m = __ballot(defer[k]);
+                if (defer[k]) ring[(rg_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kCsRing] = (hint[k] << 16) | (p_pos[k] & 0xFFFFu);
+                rg_tail += (uint32_t)__popcll(m);
             }
-            if ((round & 1u) && round + 1u < n_rounds) blk_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_after);
+            pending = false;
+            wave_lds_fence();
+            while (rg_tail - rg_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }       // keeps room for the next round (<= 128 more)
         };
-        if (n_rounds) request_entries(0);
-        for (uint32_t i = 0; i < n_rounds + 2u; i++) {
-            // (1) decide round i - 2 (its buckets were requested in the previous pass)
-            if (i >= 2u) {
-                bool defer[2]; uint32_t hint[2];
-                sf_probe_decide<2>(s, p_a, p_b, p_e, p_valid, defer, hint);
+        // candidate entries of a chunk: entries [e0, e0 + n) of the unit's chain, two per lane per round; the chain block of entry e0
+        uint32_t blk_e = n_cand ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]) : kNone;      // block that holds entry e_next
+        uint32_t e_next = 0;                                     // first entry of the chunk whose entries are requested next
+        uint32_t ent[2] = {0, 0}; uint32_t ent_n_raw = 0;        // requested a chunk ahead: the first round of the next chunk's entries (pos | 0x10000, masked by the
+                                                                 // entries left in the unit) and that chunk's candidate count (the same value in every lane, not waited for)
+        uint32_t blk_after = kNone;                              // the block after blk_e (requested when blk_e is entered)
+        auto entries_of = [&](uint32_t e0, uint32_t n, uint32_t (&out)[2], uint32_t blk, uint32_t blk_nx) {      // first <= 128 of the n entries starting at e0 (in block blk)
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint64_t m = __ballot(defer[k]);
-                    if (defer[k]) ring[(rg_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kCsRing] = (hint[k] << 16) | (p_pos[k] & 0xFFFFu);
-                    rg_tail += (uint32_t)__popcll(m);
+            for (int k = 0; k < 2; k++) {
+                const uint32_t j = 64u * k + lane;
+                out[k] = 0;
+                if (j < n) {
+                    const uint32_t e = e0 + j;
+                    const uint32_t bk = (e / kCandBlock) != (e0 / kCandBlock) ? blk_nx : blk;      // a round spans <= 128 entries, a block holds 256: at most one step
+                    out[k] = (uint32_t)pv.cands[(uint64_t)bk * kCandBlock + (e & (kCandBlock - 1u))] | 0x10000u;
                 }
-                wave_lds_fence();
-                while (rg_tail - rg_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }       // keeps room for the next round (<= 128 more)
             }
-            // (2) round i - 1: its haystack bytes are here -> hashes -> request its two hot buckets
-            if (i >= 1u && i - 1u < n_rounds) {
-                uint64_t avail[2]; uint32_t w[2], nb[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint64_t gpos = unit_pos + (t_pos[k] & 0xFFFFu);
-                    uint64_t v = t_raw[k];
-                    const uint32_t drop = gpos >= 7 ? 0u : (uint32_t)(7 - gpos);
-                    v = drop ? (v << (8u * drop)) : v;                // byte gpos ends up on top; bytes before the buffer are zero
-                    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-                    if (IC) { lo = fold_dword(lo); hi = fold_dword(hi); }
-                    w[k] = hi;                                        // bytes gpos-3 .. gpos
-                    nb[k] = (lo >> 24) | (((lo >> 16) & 0xFFu) << 8);   // the two before them, nearest in bits 0-7
-                    avail[k] = gpos - hs_u + 1;
-                    if (t_valid[k] && gpos >= he_u) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
-                    p_pos[k] = t_pos[k]; p_valid[k] = t_valid[k];
-                }
-                sf_probe_issue<2>(s, w, nb, avail, p_valid, p_a, p_b, p_e);
-            } else { p_valid[0] = p_valid[1] = false; }
-            // (3) round i: its entries are here -> request its haystack bytes (the last 8 ending at the position: one unaligned 8-byte read)
-            if (i < n_rounds) {
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    t_valid[k] = (e_pos[k] & 0x10000u) != 0u; t_pos[k] = e_pos[k];
-                    t_raw[k] = 0;
-                    if (t_valid[k]) {
-                        const uint64_t gpos = unit_pos + (e_pos[k] & 0xFFFFu);
-                        typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
-                        t_raw[k] = *reinterpret_cast<const u64_unaligned*>(b.text + (gpos >= 7 ? gpos - 7 : 0));
-                    }
-                }
-            } else { t_valid[0] = t_valid[1] = false; }
-            // (4) request the entries of round i + 1
-            if (i + 1u < n_rounds) request_entries(i + 1u);
+        };
+        uint4 cur_v; uint32_t carry3 = 0, carry4 = 0;
+        if (n_cand) {
+            fetch_chunk(unit_base_chunk, cur_v);
+            if (unit_base_chunk > 0) {
+                const uint2 t = *reinterpret_cast<const uint2*>(b.text + unit_base_chunk * kSfChunk - 8);
+                carry3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x); carry4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y);
+                if (IC) { carry3 = fold_dword(carry3); carry4 = fold_dword(carry4); }
+            }
+            ent_n_raw = pv.chunk_count[unit_base_chunk];
+            const uint32_t nx = n_cand > kCandBlock ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[blk_e]) : kNone;      // once per unit: waited for
+            blk_after = nx;
+            entries_of(0, n_cand, ent, blk_e, nx);
         }
+        const uint32_t stage = 0;      // byte offset of this wave's staged chunk inside its LDS area (see stage_base)
+        (void)stage;
+        for (uint32_t ci = 0; ci < n_in_unit && n_cand; ci++) {
+            const uint64_t c = unit_base_chunk + ci;
+            const uint32_t n_here = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent_n_raw), e0 = e_next;      // requested a chunk ago
+            uint32_t my_ent[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) my_ent[k] = 64u * k + lane < n_here ? ent[k] : 0u;
+            // request the next chunk: its text, its candidate count and the first round of its entries
+            uint4 next_v = make_uint4(0, 0, 0, 0);
+            const bool last = ci + 1 >= n_in_unit;
+            if (!last) fetch_chunk(c + 1, next_v);
+            // stage this chunk (folded), 8 bytes before it at offset 8, the chunk at 16
+            uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+            if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+            uint32_t* stg = stage_all + wave * (kSfStage / 4);
+            stg[4u + lane * 4u] = d1; stg[5u + lane * 4u] = d2; stg[6u + lane * 4u] = d3; stg[7u + lane * 4u] = d4;
+            if (lane == 0) { stg[2] = carry3; stg[3] = carry4; }
+            const uint32_t nc3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63), nc4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
+            // advance the entry cursor past this chunk; prefetch the next chunk's count and first round
+            e_next = e0 + n_here;
+            {
+                uint32_t steps = e_next / kCandBlock - e0 / kCandBlock;                // whole blocks the cursor moves on (uniform; usually 0 or 1)
+                if (steps && e_next < n_cand) {
+                    blk_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_after);       // requested when the block before it was entered
+                    while (--steps) blk_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[blk_e]);      // a chunk with more than 256 candidates (rare)
+                    blk_after = (e_next / kCandBlock + 1u) * kCandBlock < n_cand ? pv.cblock_next[blk_e] : kNone;
+                }
+            }
+            if (!last) {
+                ent_n_raw = pv.chunk_count[c + 1];
+                entries_of(e_next, n_cand - e_next, ent, blk_e, blk_after);
+            }
+            wave_lds_fence();
+            // the rounds of this chunk
+            const uint32_t n_rounds = (n_here + 127u) / 128u;
+            for (uint32_t r = 0;; r++) {
+                if (pending) consume_round();                    // the round requested in the previous pass (the previous chunk's last, or this chunk's previous)
+                if (r >= n_rounds) break;
+                if (r > 0) {                                     // later rounds of a candidate-rich chunk: entries read on the spot (rare)
+                    uint32_t bk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]);
+                    for (uint32_t t = 0; t < (e0 + r * 128u) / kCandBlock; t++) bk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[bk]);
+                    const uint32_t bn = ((e0 + r * 128u) / kCandBlock + 1u) * kCandBlock < n_cand ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[bk]) : kNone;
+                    entries_of(e0 + r * 128u, n_here - r * 128u, my_ent, bk, bn);
+                }
+                uint64_t avail[2]; uint32_t w[2], nb[2]; bool valid[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    valid[k] = (my_ent[k] & 0x10000u) != 0u;
+                    const uint32_t pos = my_ent[k] & 1023u;      // offset in the chunk
+                    const uint32_t a = 11u + pos, sh = a & 3u;
+                    const uint32_t* sp = stg + (a >> 2);
+                    const uint32_t x0 = sp[0], x1 = sp[1], x2 = sp[2];
+                    const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
+                    nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
+                    w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
+                    const uint64_t gpos = c * kSfChunk + pos;
+                    avail[k] = gpos - hs_u + 1;
+                    if (valid[k] && gpos >= he_u) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
+                    p_pos[k] = valid[k] ? (0x10000u | (ci << 10) | pos) : 0u;
+                }
+                sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
+                pending = true;
+            }
+            wave_lds_fence();                                     // the stage is read completely before the next chunk overwrites it
+            cur_v = next_v; carry3 = nc3; carry4 = nc4;
+        }
+        if (pending) consume_round();
         while (rg_tail != rg_head) { const uint32_t left = rg_tail - rg_head; resolve_batch(left < 64u ? left : 64u); }
         if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; o.unit_slots[u] = unit_slots; }
     }
