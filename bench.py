@@ -543,20 +543,24 @@ def h2d_inclusive(args, w, handle, case, text, n_hay, lib):
     for i in range(k):
         slices[i].ptr, slices[i].off, slices[i].len = base, i * hb, hb
     counts = np.zeros(k, dtype=np.uint64)
-    out = {"sample": "first %d haystacks (%d MiB) of the batch as pinned host slices; one call each, after one warm-up call" % (k, k * hb >> 20)}
+    out = {"sample": "first %d haystacks (%d MiB) of the batch as pinned host slices; the better of two calls each, after one warm-up call" % (k, k * hb >> 20)}
     am.api.check(lib.am_count(handle, case, slices, k, counts.ctypes.data))          # warm-up: staging buffers, workspaces
-    t0 = time.perf_counter()
-    am.api.check(lib.am_count(handle, case, slices, k, counts.ctypes.data))
-    t_count = time.perf_counter() - t0
+    t_count = float("inf")
+    for _ in range(2):                                                                  # the better of two: the gather threads share the host with whatever else runs there
+        t0 = time.perf_counter()
+        am.api.check(lib.am_count(handle, case, slices, k, counts.ctypes.data))
+        t_count = min(t_count, time.perf_counter() - t0)
     m = C.c_void_p()
     am.api.check(lib.am_run(handle, case, slices, k, C.byref(m)))
     lib.am_matches_data(m); lib.am_matches_free(m)
-    t0 = time.perf_counter()
-    am.api.check(lib.am_run(handle, case, slices, k, C.byref(m)))
-    n_rec = int(lib.am_matches_size(m))
-    lib.am_matches_data(m)                                                              # the records on the host: part of what the caller waits for
-    t_run = time.perf_counter() - t0
-    lib.am_matches_free(m)
+    t_run = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        am.api.check(lib.am_run(handle, case, slices, k, C.byref(m)))
+        n_rec = int(lib.am_matches_size(m))
+        lib.am_matches_data(m)                                                          # the records on the host: part of what the caller waits for
+        t_run = min(t_run, time.perf_counter() - t0)
+        lib.am_matches_free(m)
     gib = k * hb / float(1 << 30)
     out.update({"count_gibps": round(gib / t_count, 2), "run_gibps": round(gib / t_run, 2), "count_ms": round(t_count * 1e3, 2), "run_ms": round(t_run * 1e3, 2),
                 "records": n_rec, "values": int(counts.sum())})
