@@ -792,7 +792,7 @@ int launch_scan_pipeline(const Plan& p, int mode, const ScanOut& o, hipStream_t 
     if (slice_env) slice_units = std::max<uint64_t>(1, (slice_env << 20) / unit_bytes);
     const uint64_t n_slices = (p.n_units + slice_units - 1) / slice_units;
     // candidate pool: a candidate per 8 haystack bytes (the benchmark text leaves one per 12) + a block per unit + what the grants strand
-    uint64_t n_cblocks = b->total / 8 / kCandBlockEntries + p.n_units + (uint64_t)p.n_cu * 16 * 32 + 1024;
+    uint64_t n_cblocks = b->total / 8 / kCandBlockEntries + p.n_units * 32 + (uint64_t)p.n_cu * 16 * 32 + 1024;      // (every unit starts a 32-block grant)
     if (b->cand_blocks_hint > n_cblocks) n_cblocks = b->cand_blocks_hint;
     if (n_cblocks >= (1ull << 24)) return fail(AM_ERR_UNSUPPORTED, "too many candidate positions for one call; split the batch");
     AM_TRY(b->cands.ensure(n_cblocks * kCandBlockEntries * sizeof(uint16_t)));

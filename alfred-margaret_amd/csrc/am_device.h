@@ -61,7 +61,7 @@ struct PipeView {
     uint32_t* cblock_next;        // chain links
     uint32_t* cctrl;              // [0] next free block, [1] overflow flag
     uint32_t* cand_first;         // per unit: first block (kNone: none)
-    uint32_t* cand_count;         // per unit: candidates
+    uint32_t* cand_count;         // per unit: candidates (bits 0-23) | blocks with consecutive ids from cand_first on (bits 24-31)
     uint16_t* chunk_count;        // per 1-KiB chunk: candidates
     uint32_t* unit_ticket;        // per slice: k_filter's unit counter (zeroed by the host)
     uint32_t n_cblocks;

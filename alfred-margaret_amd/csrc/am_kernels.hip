@@ -654,6 +654,8 @@ __global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, Pi
         const uint64_t next_first = u_next < pv.unit1 ? u_next * UC : n_chunks;        // (n_chunks: nothing to prefetch)
         const uint64_t unit_base_chunk = u * UC;
         uint32_t unit_cands = 0, cur_block = kNone, first_block = kNone;
+        uint32_t contig = 0;                                     // blocks of this unit's chain with the ids first_block, first_block + 1, ...
+        grant_left = 0;                                          // every unit starts a grant of its own: the consumer computes the first ids instead of following the chain
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
@@ -708,6 +710,7 @@ __global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, Pi
                 uint32_t new_first = kNone;
                 if (n_new) {
                     if (grant_left < n_new) {                    // what is left of the old grant is abandoned
+                        if (first_block != kNone) contig |= 0x80000000u;      // (the run of consecutive ids ends here)
                         uint32_t g = 0;
                         if (lane == 0) g = atomicAdd(pv.cctrl, kCandGrant);
                         grant_next = __builtin_amdgcn_readfirstlane(g);
@@ -719,6 +722,7 @@ __global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, Pi
                         if (lane < n_new) pv.cblock_next[new_first + lane] = lane + 1u < n_new ? new_first + lane + 1u : kNone;
                         if (lane == 0 && cur_block != kNone) pv.cblock_next[cur_block] = new_first;
                         if (first_block == kNone) first_block = new_first;
+                        if (!(contig & 0x80000000u)) contig += n_new;
                         cur_block = new_first + n_new - 1u;
                     }
                 }
@@ -738,7 +742,8 @@ __global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, Pi
             }
             cur_v = next_v; carry4 = next_c4;
         }
-        if (lane == 0) { pv.cand_first[u] = first_block; pv.cand_count[u] = unit_cands; }
+        contig &= 0x7FFFFFFFu;
+        if (lane == 0) { pv.cand_first[u] = first_block; pv.cand_count[u] = unit_cands | ((contig < 255u ? contig : 255u) << 24); }      // (unit_cands <= 65536)
     }
 }
 
@@ -749,7 +754,6 @@ template <bool IC, int MODE, bool SHORT>
 __global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, ScanOut o, PipeView pv)
 {
     __shared__ uint32_t ring_all[(kCsThreads / 64) * kCsRing];
-    __shared__ __attribute__((aligned(16))) uint32_t stage_all[(kCsThreads / 64) * (kSfStage / 4)];      // per wave: the current chunk, folded (k_sf's layout)
     if (pv.cctrl[1]) return;                                 // the candidate pool overflowed: the host repeats the scan with k_sf
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t* ring = ring_all + wave * kCsRing;
@@ -776,16 +780,19 @@ __global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, S
     bool pool_ok = true;
 
     for (uint64_t u = pv.unit0 + (uint64_t)blockIdx.x * (kCsThreads / 64) + wave; u < pv.unit1; u += n_waves) {
-        const uint32_t n_cand = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_count[u]);
+        const uint32_t cc_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_count[u]);
+        const uint32_t n_cand = cc_raw & 0xFFFFFFu, contig = cc_raw >> 24;       // candidates; blocks of the chain with consecutive ids from cand_first on
         uint32_t unit_count = 0, unit_slots = 0, cur_block = kNone, first_block = kNone;
         uint32_t rg_head = 0, rg_tail = 0;
         const uint64_t unit_pos = u * unit_bytes;
         // the haystack that holds the unit's first byte (uniform; one lookup per unit): a position below its end needs no lookup of its own
-        uint32_t hay_u = 0; uint64_t hs_u = 1, he_u = 0;
-        if (n_cand) {
-            hay_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.hidx[unit_pos >> kHidxShift]);
-            hs_u = uniform_u64(b.offsets[hay_u]); he_u = uniform_u64(b.offsets[hay_u + 1]);
+        if (!n_cand) {
+            if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = 0; o.unit_first[u] = kNone; o.unit_slots[u] = 0; }
+            continue;
         }
+        const uint32_t first_cblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]);
+        const uint32_t hay_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.hidx[unit_pos >> kHidxShift]);
+        const uint64_t hs_u = uniform_u64(b.offsets[hay_u]), he_u = uniform_u64(b.offsets[hay_u + 1]);
         // ---- phase 2 for the oldest nb (<= 64) deferred candidates of the ring, in lock step (as k_sf's resolve_batch, without a walker queue)
         auto resolve_batch = [&](uint32_t nb) {
             bool valid[1] = {lane < nb};
@@ -798,9 +805,12 @@ __global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, S
             uint64_t end_pos[1] = {0};
             uint32_t hay = hay_u;
             auto locate = [&]() {
-                uint64_t start = hs_u;
-                if (far) { hay = hlo; if (hlo != hhi) hay = find_haystack(b, gpos[0]); start = b.offsets[hay]; }
-                end_pos[0] = valid[0] ? gpos[0] - start + 1 : 0;
+                // (the far start is a value of its own, not a second source of `start`: with one load on either side the compiler turns the
+                // two into a load through a selected POINTER, and the uniform hs_u then lives in scratch memory -- every read of it in the
+                // pipeline below would wait for all loads in flight)
+                uint64_t far_start = 0;
+                if (far) { hay = hlo; if (hlo != hhi) hay = find_haystack(b, gpos[0]); far_start = b.offsets[hay]; }
+                end_pos[0] = valid[0] ? gpos[0] - (far ? far_start : hs_u) + 1 : 0;
             };
             uint32_t w[1], w2[1], avail[1], best_state[1], best_vlen[1], depth[1], node[1], t16[1][4];
             bool go[1], have_rec[1];
@@ -848,140 +858,105 @@ __global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, S
             rg_head += nb;
         };
 
-        // ---- phase 1 over the unit's chunks, in k_sf's shape: the chunk is read with one coalesced 16-byte load per lane (sequential: the next
-        // chunk and its candidate entries are requested a chunk ahead), folded and staged in LDS; the candidates -- from k_filter's chain
-        // instead of a filter pass -- pick their window out of the staged chunk, two per lane, up to 128 per round; their two hot buckets
-        // are requested at the end of a chunk's pass and looked at in the next one.
-        const uint32_t UC = o.unit_chunks;
-        const uint64_t n_chunks_all = (b.total + kSfChunk - 1) / kSfChunk;
-        const uint64_t unit_base_chunk = u * UC;
-        const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks_all ? UC : n_chunks_all - unit_base_chunk);
-        auto fetch_chunk = [&](uint64_t cc, uint4& v) {
-            const uint64_t p = cc * kSfChunk + lane * 16u;
-            v = make_uint4(0, 0, 0, 0);
-            if (cc < n_chunks_all && p < b.total) {
-                typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
-                const u32x4_native t = *reinterpret_cast<const u32x4_native*>(b.text + p);
-                v = make_uint4(t.x, t.y, t.z, t.w);
-            }
+        // ---- phase 1 over the unit's candidates, 128 per round (two per lane), whatever the chunk boundaries; eight rounds are in flight.
+        // Pass i of the loop
+        //   (1) decides round i - 7 (its two hot buckets were requested in pass i - 1),
+        //   (2) hashes round i - 6 (its haystack bytes were requested in pass i - 3) and requests its buckets,
+        //   (3) requests the haystack bytes of round i - 3 (its candidate entries were requested in pass i - 3),
+        //   (4) requests the candidate entries of round i.
+        // Loads retire in order, so waiting for what pass i - 3 requested leaves the requests of two whole passes in flight.  The stages'
+        // registers rotate by NAME (three copies of the pass, slot J = i mod 3): a register move of a pending load's target would wait for it.
+        const uint32_t n_rounds = (n_cand + 127u) / 128u;
+        uint32_t walk_j = contig ? contig - 1u : 0u, walk_id = first_cblock + walk_j;       // chain cursor for blocks beyond the contiguous run
+        auto block_of = [&](uint32_t j) -> uint32_t {
+            if (j < contig) return first_cblock + j;
+            while (walk_j < j) { walk_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[walk_id]); walk_j++; }      // (waited for: rare)
+            return walk_id;
         };
-        u32x2 p_a[2], p_b[2]; uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};       // the round whose buckets are in flight (p_pos: offset in the unit | 0x10000)
+        uint32_t E[3][2] = {{0, 0}, {0, 0}, {0, 0}};                         // candidate entries: offset in the unit | 0x10000 (valid)
+        uint32_t Tp[3][2] = {{0, 0}, {0, 0}, {0, 0}}; uint64_t Tr[3][2] = {{0, 0}, {0, 0}, {0, 0}};      // haystack bytes requested: the entry, the 8 bytes ending at it
+        u32x2 p_a[2], p_b[2]; uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};   // buckets requested
         p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
-        bool pending = false;
-        auto consume_round = [&]() {
-            bool valid[2], defer[2]; uint32_t hint[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x10000u) != 0;
-            sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint64_t m = __ballot(defer[k]);
-                if (defer[k]) ring[(rg_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kCsRing] = (hint[k] << 16) | (p_pos[k] & 0xFFFFu);
-                rg_tail += (uint32_t)__popcll(m);
-            }
-            pending = false;
-            wave_lds_fence();
-            while (rg_tail - rg_head >= 64u) { resolve_batch(64u); wave_lds_fence(); }       // keeps room for the next round (<= 128 more)
-        };
-        // candidate entries of a chunk: entries [e0, e0 + n) of the unit's chain, two per lane per round; the chain block of entry e0
-        uint32_t blk_e = n_cand ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]) : kNone;      // block that holds entry e_next
-        uint32_t e_next = 0;                                     // first entry of the chunk whose entries are requested next
-        uint32_t ent[2] = {0, 0}; uint32_t ent_n_raw = 0;        // requested a chunk ahead: the first round of the next chunk's entries (pos | 0x10000, masked by the
-                                                                 // entries left in the unit) and that chunk's candidate count (the same value in every lane, not waited for)
-        uint32_t blk_after = kNone;                              // the block after blk_e (requested when blk_e is entered)
-        auto entries_of = [&](uint32_t e0, uint32_t n, uint32_t (&out)[2], uint32_t blk, uint32_t blk_nx) {      // first <= 128 of the n entries starting at e0 (in block blk)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint32_t j = 64u * k + lane;
-                out[k] = 0;
-                if (j < n) {
-                    const uint32_t e = e0 + j;
-                    const uint32_t bk = (e / kCandBlock) != (e0 / kCandBlock) ? blk_nx : blk;      // a round spans <= 128 entries, a block holds 256: at most one step
-                    out[k] = (uint32_t)pv.cands[(uint64_t)bk * kCandBlock + (e & (kCandBlock - 1u))] | 0x10000u;
-                }
-            }
-        };
-        uint4 cur_v; uint32_t carry3 = 0, carry4 = 0;
-        if (n_cand) {
-            fetch_chunk(unit_base_chunk, cur_v);
-            if (unit_base_chunk > 0) {
-                const uint2 t = *reinterpret_cast<const uint2*>(b.text + unit_base_chunk * kSfChunk - 8);
-                carry3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.x); carry4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t.y);
-                if (IC) { carry3 = fold_dword(carry3); carry4 = fold_dword(carry4); }
-            }
-            ent_n_raw = pv.chunk_count[unit_base_chunk];
-            const uint32_t nx = n_cand > kCandBlock ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[blk_e]) : kNone;      // once per unit: waited for
-            blk_after = nx;
-            entries_of(0, n_cand, ent, blk_e, nx);
-        }
-        const uint32_t stage = 0;      // byte offset of this wave's staged chunk inside its LDS area (see stage_base)
-        (void)stage;
-        for (uint32_t ci = 0; ci < n_in_unit && n_cand; ci++) {
-            const uint64_t c = unit_base_chunk + ci;
-            const uint32_t n_here = (uint32_t)__builtin_amdgcn_readfirstlane((int)ent_n_raw), e0 = e_next;      // requested a chunk ago
-            uint32_t my_ent[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) my_ent[k] = 64u * k + lane < n_here ? ent[k] : 0u;
-            // request the next chunk: its text, its candidate count and the first round of its entries
-            uint4 next_v = make_uint4(0, 0, 0, 0);
-            const bool last = ci + 1 >= n_in_unit;
-            if (!last) fetch_chunk(c + 1, next_v);
-            // stage this chunk (folded), 8 bytes before it at offset 8, the chunk at 16
-            uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
-            if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
-            uint32_t* stg = stage_all + wave * (kSfStage / 4);
-            stg[4u + lane * 4u] = d1; stg[5u + lane * 4u] = d2; stg[6u + lane * 4u] = d3; stg[7u + lane * 4u] = d4;
-            if (lane == 0) { stg[2] = carry3; stg[3] = carry4; }
-            const uint32_t nc3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63), nc4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
-            // advance the entry cursor past this chunk; prefetch the next chunk's count and first round
-            e_next = e0 + n_here;
+        // Every pass issues the same loads whatever the round's state -- lanes without a candidate read a harmless address (the compiler
+        // counts the loads in flight only along straight code: one load behind a branch and every wait becomes "all of them").
+        const uint32_t lb_hot = s.tier_log2_cap[3];
+        auto pass = [&](auto slot_c, const uint32_t i) __attribute__((always_inline)) {
+            constexpr int J = decltype(slot_c)::value;
+            // (1)
             {
-                uint32_t steps = e_next / kCandBlock - e0 / kCandBlock;                // whole blocks the cursor moves on (uniform; usually 0 or 1)
-                if (steps && e_next < n_cand) {
-                    blk_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)blk_after);       // requested when the block before it was entered
-                    while (--steps) blk_e = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[blk_e]);      // a chunk with more than 256 candidates (rare)
-                    blk_after = (e_next / kCandBlock + 1u) * kCandBlock < n_cand ? pv.cblock_next[blk_e] : kNone;
-                }
-            }
-            if (!last) {
-                ent_n_raw = pv.chunk_count[c + 1];
-                entries_of(e_next, n_cand - e_next, ent, blk_e, blk_after);
-            }
-            wave_lds_fence();
-            // the rounds of this chunk
-            const uint32_t n_rounds = (n_here + 127u) / 128u;
-            for (uint32_t r = 0;; r++) {
-                if (pending) consume_round();                    // the round requested in the previous pass (the previous chunk's last, or this chunk's previous)
-                if (r >= n_rounds) break;
-                if (r > 0) {                                     // later rounds of a candidate-rich chunk: entries read on the spot (rare)
-                    uint32_t bk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]);
-                    for (uint32_t t = 0; t < (e0 + r * 128u) / kCandBlock; t++) bk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[bk]);
-                    const uint32_t bn = ((e0 + r * 128u) / kCandBlock + 1u) * kCandBlock < n_cand ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[bk]) : kNone;
-                    entries_of(e0 + r * 128u, n_here - r * 128u, my_ent, bk, bn);
-                }
-                uint64_t avail[2]; uint32_t w[2], nb[2]; bool valid[2];
+                bool valid[2], defer[2]; uint32_t hint[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
-                    valid[k] = (my_ent[k] & 0x10000u) != 0u;
-                    const uint32_t pos = my_ent[k] & 1023u;      // offset in the chunk
-                    const uint32_t a = 11u + pos, sh = a & 3u;
-                    const uint32_t* sp = stg + (a >> 2);
-                    const uint32_t x0 = sp[0], x1 = sp[1], x2 = sp[2];
-                    const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
-                    nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
-                    w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
-                    const uint64_t gpos = c * kSfChunk + pos;
-                    avail[k] = gpos - hs_u + 1;
-                    if (valid[k] && gpos >= he_u) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
-                    p_pos[k] = valid[k] ? (0x10000u | (ci << 10) | pos) : 0u;
+                    valid[k] = (p_pos[k] & 0x10000u) != 0;
+                    if (!(p_pos[k] & 0x20000u)) { p_a[k] = u32x2{0, 0}; p_b[k] = p_a[k]; }      // no probe: empty buckets
                 }
-                sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
-                pending = true;
+                sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint64_t m = __ballot(defer[k]);
+                    if (defer[k]) ring[(rg_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kCsRing] = (hint[k] << 16) | (p_pos[k] & 0xFFFFu);
+                    rg_tail += (uint32_t)__popcll(m);
+                }
+                wave_lds_fence();
+                while (rg_tail - rg_head >= 64u) {               // keeps room for the next round (<= 128 more)
+                    resolve_batch(64u); wave_lds_fence();
+                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing of the resolve is in flight where the paths join again --
+                }                                                // else the compiler waits for "all loads" on the path that did not resolve, too
             }
-            wave_lds_fence();                                     // the stage is read completely before the next chunk overwrites it
-            cur_v = next_v; carry3 = nc3; carry4 = nc4;
+            // (2)
+            {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const bool valid = (Tp[J][k] & 0x10000u) != 0;
+                    const uint64_t gpos = unit_pos + (Tp[J][k] & 0xFFFFu);
+                    uint64_t v = Tr[J][k];
+                    const uint32_t drop = gpos >= 7 ? 0u : (uint32_t)(7 - gpos);
+                    v = drop ? (v << (8u * drop)) : v;                // byte gpos ends up on top; bytes before the buffer are zero
+                    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+                    if (IC) { lo = fold_dword(lo); hi = fold_dword(hi); }
+                    const uint32_t w = hi;                            // bytes gpos-3 .. gpos
+                    const uint32_t nb = (lo >> 24) | (((lo >> 16) & 0xFFu) << 8);   // the two before them, nearest in bits 0-7
+                    uint64_t avail = gpos - hs_u + 1;
+                    if (valid && gpos >= he_u) {                      // (rare: the unit's later haystacks)
+                        uint64_t start = b.offsets[find_haystack(b, gpos)];
+                        asm volatile("" : "+v"(start));               // waited for HERE: a wait after the branch would hold up the lanes that never asked
+                        avail = gpos - start + 1;
+                    }
+                    const bool probe = valid && avail >= 4;           // (the pipeline runs only for automata with needles of 4+ bytes)
+                    const uint32_t ha = t4_hash_a(w), hb = t4_hash_b(w);
+                    p_e[k] = t4_expect(t4_fingerprint(ha, lb_hot), nb & 0xFFFFu);
+                    const uint2 ra = *reinterpret_cast<const uint2*>(s.t4_hot + (probe ? t4_bucket(ha, lb_hot) : 0u));
+                    const uint2 rb = *reinterpret_cast<const uint2*>(s.t4_hot + (probe ? t4_bucket(hb, lb_hot) : 0u));
+                    p_a[k] = u32x2{ra.x, ra.y}; p_b[k] = u32x2{rb.x, rb.y};
+                    p_pos[k] = (Tp[J][k] & 0x1FFFFu) | (probe ? 0x20000u : 0u);
+                }
+            }
+            // (3)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t e = (i - 3u) * 128u + 64u * k + lane;           // (i < 3: far beyond n_cand)
+                const bool valid = i >= 3u && e < n_cand;
+                const uint64_t gpos = unit_pos + (E[J][k] & 0xFFFFu);
+                Tp[J][k] = valid ? (E[J][k] & 0xFFFFu) | 0x10000u : 0u;
+                typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+                Tr[J][k] = *reinterpret_cast<const u64_unaligned*>(b.text + (valid && gpos >= 7 ? gpos - 7 : 0));
+            }
+            // (4)
+            {
+                const uint32_t r = i < n_rounds ? i : 0u;
+                const uint32_t blk = block_of(r >> 1);                // two rounds per block
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t e = r * 128u + 64u * k + lane;
+                    E[J][k] = (uint32_t)pv.cands[(uint64_t)blk * kCandBlock + ((e < n_cand ? e : 0u) & (kCandBlock - 1u))];
+                }
+            }
+        };
+        for (uint32_t i = 0; i < n_rounds + 7u; i += 3u) {
+            pass(std::integral_constant<int, 0>{}, i);
+            pass(std::integral_constant<int, 1>{}, i + 1u);
+            pass(std::integral_constant<int, 2>{}, i + 2u);
         }
-        if (pending) consume_round();
         while (rg_tail != rg_head) { const uint32_t left = rg_tail - rg_head; resolve_batch(left < 64u ? left : 64u); }
         if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; o.unit_slots[u] = unit_slots; }
     }
