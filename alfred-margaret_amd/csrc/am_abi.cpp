@@ -1447,9 +1447,7 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
     o.block_next = (uint32_t*)b->block_next.p;
     o.pool_ctrl = (uint32_t*)b->small.p + 4;
     o.n_blocks = (uint32_t)want_blocks;
-    HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
-    HIP_TRY(hipMemsetAsync((uint32_t*)b->unit_counts.p + p.n_units, 0, sizeof(uint32_t), st));
-    AM_TRY(build_hidx(p, b, st));
+    AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, (uint32_t*)b->unit_counts.p + p.n_units, sizeof(uint32_t)));      // (the Replacer's window batches are new every pass: one launch)
     AM_TRY(launch_scan_kernel(p, kModeEmit, o, st));
     { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
     { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, d_out, p.n_units, st)); }
@@ -1652,10 +1650,9 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
           } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st)); }
         // the pass's ONE synchronisation: bytes of next text, bytes of finished text, -, haystacks still active, haystacks finished,
         // windows, window bytes, piece entries, and the exact record count of this pass when it was still on the device
-        HIP_TRY(launch_rp_totals(rt, n_act, (const uint64_t*)s.win_off.p, (const uint64_t*)s.woffs.p, woffs_last, (uint64_t*)s.totals.p, st));
-        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 56, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&s.tot_host[8], (uint64_t*)s.pt_need_off.p + n_act, 8, hipMemcpyDeviceToHost, st));
-        if (n_rec_dev) HIP_TRY(hipMemcpyAsync(&s.tot_host[9], n_rec_dev, 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(launch_rp_totals(rt, n_act, (const uint64_t*)s.win_off.p, (const uint64_t*)s.woffs.p, woffs_last, (uint64_t*)s.totals.p, st,
+                                 (const uint64_t*)s.pt_need_off.p + n_act, n_rec_dev));
+        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 80, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         const uint64_t* tot = s.tot_host;
         const uint64_t total_next = tot[0], total_fin = tot[1], n_next = tot[3], n_fin = tot[4], n_win = tot[5], total_w = tot[6], n_pieces = tot[8];
@@ -1810,7 +1807,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         }
     } give_back{r, sp};
     RpSession& s = *sp;
-    AM_TRY(s.totals.ensure(64));
+    AM_TRY(s.totals.ensure(128));
     if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
     // pass 0 reads the caller's batch in place; afterwards the text ping-pongs between s.text[0] and s.text[1]
     const uint8_t* cur_text = (const uint8_t*)in->d_text;

@@ -105,7 +105,8 @@ constexpr uint64_t kRpTile = 16384;                      // bytes of new text pe
 
 hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_ranges_dev(const Record* recs, const uint64_t* n_rec_dev, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
-hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out7, hipStream_t st);
+hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out10, hipStream_t st,
+                            const uint64_t* extra8 = nullptr, const uint64_t* extra9 = nullptr);      // out10[8], out10[9] = *extra8, *extra9 (0 when null)
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
                           const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st);
 struct RpSelected { uint64_t start, len; uint32_t haystack, payload; };     // = am_prio_match in include/am.h

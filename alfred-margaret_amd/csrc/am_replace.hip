@@ -488,16 +488,20 @@ hipError_t launch_rp_ranges_dev(const Record* recs, const uint64_t* n_rec_dev, u
 }
 
 __global__ void k_rp_totals(RpRouted rt, uint32_t n_act, const uint64_t* __restrict__ win_off, const uint64_t* __restrict__ woffs, uint64_t woffs_last,
-                            uint64_t* __restrict__ out7)
+                            const uint64_t* __restrict__ extra8, const uint64_t* __restrict__ extra9, uint64_t* __restrict__ out10)
 {
-    out7[0] = rt.off_next[n_act]; out7[1] = rt.off_fin[n_act]; out7[2] = rt.tile_off[n_act]; out7[3] = rt.act_idx[n_act]; out7[4] = rt.fin_idx[n_act];
-    out7[5] = win_off ? win_off[n_act] : 0;                                                  // windows of the incremental re-scan and their bytes
-    out7[6] = woffs ? woffs[woffs_last == ~0ull ? win_off[n_act] : woffs_last] : 0;          // (~0: the scan stopped at the last window)
+    out10[0] = rt.off_next[n_act]; out10[1] = rt.off_fin[n_act]; out10[2] = rt.tile_off[n_act]; out10[3] = rt.act_idx[n_act]; out10[4] = rt.fin_idx[n_act];
+    out10[5] = win_off ? win_off[n_act] : 0;                                                  // windows of the incremental re-scan and their bytes
+    out10[6] = woffs ? woffs[woffs_last == ~0ull ? win_off[n_act] : woffs_last] : 0;          // (~0: the scan stopped at the last window)
+    out10[7] = 0;
+    out10[8] = extra8 ? *extra8 : 0;                                                          // two more scalars of the pass, so that ONE copy brings
+    out10[9] = extra9 ? *extra9 : 0;                                                          // everything to the host (each copy is a 16-us blit of its own)
 }
 
-hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out7, hipStream_t st)
+hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out10, hipStream_t st,
+                            const uint64_t* extra8, const uint64_t* extra9)
 {
-    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, win_off, woffs, woffs_last, out7);
+    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, win_off, woffs, woffs_last, extra8, extra9, out10);
     return hipGetLastError();
 }
 
