@@ -1052,6 +1052,80 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     return AM_OK;
 }
 
+// Small batches (the one-document call): the whole chain -- clears + haystack index, scan, unit offsets, k_permute into a record array of
+// the worst-case size (a record per byte) -- and the copies of the count and of the first records are enqueued at once, so the call has
+// ONE stream synchronisation.  (The general path needs the count on the host before it sizes the record array: two, and a third when the
+// caller reads the records.)  *done = false: not taken, or the record pool overflowed -- the general path runs.
+constexpr uint64_t kSmallRunBytes = 64u << 10;
+constexpr uint64_t kSmallRunEager = 256;                  // records that travel with the count (2048 of them: 10 us slower on a 10-KB document with 1 187 matches than a second copy)
+
+static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, am_matches* m, bool* done)
+{
+    *done = false;
+    if (b->total == 0 || b->total > kSmallRunBytes) return AM_OK;
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p));
+    if (p.nothing || p.dense || !p.use_sf || p.pipe) return AM_OK;
+    static const bool off = std::getenv("AM_NO_SMALL_RUN") != nullptr;       // A/B
+    if (off) return AM_OK;
+    std::lock_guard<std::mutex> lk(b->mu);
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
+    const uint64_t n = p.n_units + 1;
+    AM_TRY(b->unit_counts.ensure(n * sizeof(uint32_t)));
+    AM_TRY(b->unit_offsets.ensure(n * sizeof(uint64_t)));
+    AM_TRY(b->small.ensure(64));
+    AM_TRY(b->unit_first.ensure(2 * p.n_units * sizeof(uint32_t)));
+    size_t tmp_bytes = 0;
+    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
+    uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);
+    if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
+    if (std::getenv("AM_SF_POOL_BLOCKS")) return AM_OK;                      // (tests of the overflow / retry path: the general path has it)
+    AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
+    AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
+    const size_t need = (size_t)b->total * sizeof(Record);
+    size_t cap_bytes = 0;
+    Record* d_records = (Record*)g_record_cache[b->dev].take(need, &cap_bytes);
+    if (!d_records) {
+        cap_bytes = need + need / 16;
+        hipError_t e = hipMalloc((void**)&d_records, cap_bytes);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? AM_ERR_OOM : AM_ERR_HIP, std::string("hipMalloc(records): ") + hipGetErrorString(e));
+    }
+    auto body = [&]() -> int {
+        ScanOut o{};
+        o.unit_chunks = p.unit_chunks;
+        o.unit_counts = (uint32_t*)b->unit_counts.p;
+        o.unit_first = (uint32_t*)b->unit_first.p;
+        o.unit_slots = (uint32_t*)b->unit_first.p + p.n_units;
+        o.pool = (Record*)b->pool.p;
+        o.block_next = (uint32_t*)b->block_next.p;
+        o.pool_ctrl = (uint32_t*)b->small.p + 4;
+        o.n_blocks = (uint32_t)want_blocks;
+        AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, (uint32_t*)b->unit_counts.p + p.n_units, sizeof(uint32_t)));
+        AM_TRY(launch_scan_kernel(p, kModeEmit, o, st));
+        { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
+        { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, d_records, p.n_units, st)); }
+        uint64_t total = 0; uint32_t ctrl[2] = {0, 0};
+        const uint64_t eager = b->total < kSmallRunEager ? b->total : kSmallRunEager;
+        m->host.resize(eager);
+        ResultCopies rc;
+        AM_TRY(rc.add(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, st));
+        AM_TRY(rc.add(ctrl, o.pool_ctrl, 8, st));
+        AM_TRY(rc.add(m->host.data(), d_records, eager * sizeof(Record), st));
+        AM_TRY(rc.finish(st));
+        if (ctrl[1]) return AM_OK;                            // record pool too small (cannot happen with this guess on <= 64 KiB, but the general path knows what to do)
+        m->n = total;
+        if (total <= eager) { m->host.resize(total); m->fetched = true; }
+        else { m->host.clear(); m->fetched = false; }
+        *done = true;
+        return AM_OK;
+    };
+    const int rc = body();
+    if (rc == AM_OK && *done && m->n) { m->d_records = d_records; m->cap_bytes = cap_bytes; }
+    else g_record_cache[b->dev].give(d_records, cap_bytes);
+    return rc;
+}
+
 extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out)
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
@@ -1059,6 +1133,13 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
     if (!cb) return fail(AM_ERR_INVALID, "null batch");
     am_matches* m = new am_matches();
     m->dev = cb->dev;
+    {
+        bool done = false;
+        const int rc = run_records_small(a, case_mode, const_cast<am_batch*>(cb), m, &done);
+        if (rc != AM_OK) { am_matches_free(m); return rc; }
+        if (done) { *out = m; return AM_OK; }
+        m->host.clear(); m->fetched = false; m->n = 0;
+    }
     auto sink = [&](uint64_t total, Record** ptr) -> int {
         const size_t need = total * sizeof(Record);
         m->d_records = (Record*)g_record_cache[m->dev].take(need, &m->cap_bytes);

@@ -247,41 +247,68 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     //          step, 34 % after two, the deepest of 64 after six or seven: the batch used to wait for that one with 60 lanes idle.)
     // Emit mode: a record SLOT of the unit's block chain for every item that has a record or is parked; a parked walker that finds
     // nothing leaves state = kNone in its slot and k_permute drops it.  unit_slots counts slots, unit_count records.
+    // RN items per lane.  The code below is written for any RN; 2 was measured for the small filters (LW == 0) in round 3: twice the loads in
+    // flight per dependent step, half the batches -- but 128 VGPRs do not hold two items' slot lines next to the chunk loop's state (16
+    // dwords spilled to scratch, some of them in the chunk loop; 43 KB of code instead of 27): cfg2 994 -> 726 GiB/s, natural text 63.5 -> 56.4.
     constexpr int RN = 1;
     // nb == 0 && drain: only walk what is parked (end of a unit).  walk_parked has ONE call site here (it contains a whole trie walk).
     auto resolve_batch = [&](uint32_t nb, bool drain) {
         if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; n_batches++; }
-        uint64_t gpos[1] = {0};
-        uint32_t w2[1] = {0}, avail[1] = {0}, best_state[1] = {0}, best_vlen[1] = {0}, depth[1] = {0}, hay = 0, slot = 0;
-        SfNode rec[1] = {SfNode{0, 0, 0, 0, {0, 0, 0, 0}}};
-        bool parked = false;
-        uint64_t pm = 0;
+        uint64_t gpos[RN];
+        uint32_t w2[RN], avail[RN], best_state[RN], best_vlen[RN], depth[RN], hay[RN], slot[RN];
+        SfNode rec[RN];
+        bool parked[RN];
+        uint64_t pm[RN];
+#pragma unroll
+        for (int k = 0; k < RN; k++) {
+            gpos[k] = 0; w2[k] = avail[k] = best_state[k] = best_vlen[k] = depth[k] = hay[k] = slot[k] = 0;
+            rec[k] = SfNode{0, 0, 0, 0, {0, 0, 0, 0}}; parked[k] = false; pm[k] = 0;
+        }
         if (nb) {
-            bool valid[1] = {lane < nb};
-            const uint32_t item = valid[0] ? lds_read_u16(q2 + 2u * ((q2_head + lane) % kSfQ2)) : 0u;
-            gpos[0] = (epoch_base_chunk + (item >> 12)) * kSfChunk + (item & 1023u);
-            const uint32_t hint[1] = {(item >> 10) & 3u};
-            uint32_t hlo = 0, hhi = 0;
-            if (valid[0]) { hlo = b.hidx[gpos[0] >> kHidxShift]; hhi = b.hidx[(gpos[0] >> kHidxShift) + 1]; }
-            uint64_t end_pos[1] = {0};
+            bool valid[RN];
+            uint32_t hint[RN], hlo[RN], hhi[RN];
+            uint64_t end_pos[RN];
+#pragma unroll
+            for (int k = 0; k < RN; k++) {
+                valid[k] = 64u * k + lane < nb;
+                const uint32_t item = valid[k] ? lds_read_u16(q2 + 2u * ((q2_head + 64u * k + lane) % kSfQ2)) : 0u;
+                gpos[k] = (epoch_base_chunk + (item >> 12)) * kSfChunk + (item & 1023u);
+                hint[k] = (item >> 10) & 3u;
+                hlo[k] = hhi[k] = 0; end_pos[k] = 0;
+                if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
+            }
             // haystack index -> start offset: two dependent loads, made while the head's first two (haystack bytes -> slot line) are in flight
             auto locate = [&]() {
-                hay = hlo;
-                uint64_t start = valid[0] ? b.offsets[hlo] : 0;
-                if (valid[0] && hlo != hhi) { hay = find_haystack(b, gpos[0]); start = b.offsets[hay]; }
-                end_pos[0] = valid[0] ? gpos[0] - start + 1 : 0;
+#pragma unroll
+                for (int k = 0; k < RN; k++) {
+                    hay[k] = hlo[k];
+                    uint64_t start = valid[k] ? b.offsets[hlo[k]] : 0;
+                    if (valid[k] && hlo[k] != hhi[k]) { hay[k] = find_haystack(b, gpos[k]); start = b.offsets[hay[k]]; }
+                    end_pos[k] = valid[k] ? gpos[k] - start + 1 : 0;
+                }
             };
-            uint32_t w[1], node[1], t16[1][4];
-            bool go[1], have_rec[1];
-            sf_resolve_head<IC, 1>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16, timing ? dbg_iters : nullptr);
-            if (ablate != 11) sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? o.wq_iters : 0xFFFFFFFFu, t16);
-            parked = go[0] && valid[0];                      // still walking after two steps (only with a walker queue)
-            if (SHORT) { const bool vv[1] = {valid[0] && !parked}; sf_resolve_short<1>(s, vv, avail, w, best_state, best_vlen); }
-            const bool found = valid[0] && best_state[0] != 0;
-            if (timing) n_found += (uint32_t)__popcll(__ballot(found));
-            if (MODE == kModeCount) add_counts(found && !parked, hay, best_vlen[0]);      // a parked walker is counted when its walk is over
-            else if (MODE == kModeEmit) {
-                const uint64_t take_mask = __ballot(found || parked);
+            uint32_t w[RN], node[RN], t16[RN][4];
+            bool go[RN], have_rec[RN], found[RN];
+            sf_resolve_head<IC, RN>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16, timing ? dbg_iters : nullptr);
+            if (ablate != 11) sf_resolve_walk<IC, RN>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? o.wq_iters : 0xFFFFFFFFu, t16);
+#pragma unroll
+            for (int k = 0; k < RN; k++) parked[k] = go[k] && valid[k];      // still walking after two steps (only with a walker queue)
+            if (SHORT) {
+                bool vv[RN];
+#pragma unroll
+                for (int k = 0; k < RN; k++) vv[k] = valid[k] && !parked[k];
+                sf_resolve_short<RN>(s, vv, avail, w, best_state, best_vlen);
+            }
+#pragma unroll
+            for (int k = 0; k < RN; k++) {
+                found[k] = valid[k] && best_state[k] != 0;
+                if (timing) n_found += (uint32_t)__popcll(__ballot(found[k]));
+            }
+            if (MODE == kModeCount) {
+#pragma unroll
+                for (int k = 0; k < RN; k++) add_counts(found[k] && !parked[k], hay[k], best_vlen[k]);      // a parked walker is counted when its walk is over
+            } else if (MODE == kModeEmit && RN == 1) {
+                const uint64_t take_mask = __ballot(found[0] || parked[0]);
                 const uint32_t F = (uint32_t)__popcll(take_mask);
                 if (F) {
                     const uint32_t r = unit_slots & (kPoolBlock - 1u);      // fill of the current block
@@ -305,39 +332,98 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                             if (first_block == kNone) first_block = id;
                         }
                     }
-                    if ((found || parked) && pool_ok) {
+                    if ((found[0] || parked[0]) && pool_ok) {
                         const uint32_t p = r + (uint32_t)__popcll(take_mask & ((1ull << lane) - 1ull));
-                        slot = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
-                        o.pool[slot] = Record{end_pos[0], hay, found ? best_state[0] - 1u : kNone};
+                        slot[0] = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
+                        o.pool[slot[0]] = Record{end_pos[0], hay[0], found[0] ? best_state[0] - 1u : kNone};
                     }
                     if (need_new && pool_ok) cur_block = new_block;
                     unit_slots += F;
-                    unit_count += (uint32_t)__popcll(__ballot(found));
+                    unit_count += (uint32_t)__popcll(__ballot(found[0]));
+                }
+            } else if (MODE == kModeEmit) {
+                // RN items per lane: the slots of item 0 of all lanes, then those of item 1 (= position order); up to RN + 1 blocks join the chain
+                uint64_t take[RN]; uint32_t before[RN], F = 0, n_found_recs = 0;
+#pragma unroll
+                for (int k = 0; k < RN; k++) {
+                    take[k] = __ballot(found[k] || parked[k]); before[k] = F; F += (uint32_t)__popcll(take[k]);
+                    n_found_recs += (uint32_t)__popcll(__ballot(found[k]));
+                }
+                if (F) {
+                    const uint32_t s0 = unit_slots, have = (s0 + kPoolBlock - 1u) / kPoolBlock;      // blocks the chain has
+                    const uint32_t n_new = (s0 + F + kPoolBlock - 1u) / kPoolBlock - have;         // <= RN + 1
+                    const uint32_t prev_block = cur_block;          // takes the slots below `have` * 64 (when its last block is not full)
+                    uint32_t ids[RN + 1];
+#pragma unroll
+                    for (int t = 0; t < RN + 1; t++) {
+                        ids[t] = kNone;
+                        if ((uint32_t)t < n_new) {
+                            if (grant_left == 0) {
+                                uint32_t g = 0;
+                                if (lane == 0) g = atomicAdd(o.pool_ctrl, kSfBlockGrant);
+                                grant_next = __builtin_amdgcn_readfirstlane(g);
+                                grant_left = kSfBlockGrant;
+                            }
+                            const uint32_t id = grant_next++;
+                            grant_left--;
+                            if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }   // keep counting, host retries with a larger pool
+                            else if (pool_ok) {
+                                ids[t] = id;
+                                if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
+                                if (first_block == kNone) first_block = id;
+                                cur_block = id;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < RN; k++) {
+                        if ((found[k] || parked[k]) && pool_ok) {
+                            const uint32_t si = s0 + before[k] + (uint32_t)__popcll(take[k] & ((1ull << lane) - 1ull));
+                            const uint32_t q = si / kPoolBlock;
+                            uint32_t blk = prev_block;
+#pragma unroll
+                            for (int t = 0; t < RN + 1; t++) if (q == have + (uint32_t)t) blk = ids[t];
+                            slot[k] = blk * kPoolBlock + (si & (kPoolBlock - 1u));
+                            o.pool[slot[k]] = Record{end_pos[k], hay[k], found[k] ? best_state[k] - 1u : kNone};
+                        }
+                    }
+                    unit_slots += F;
+                    unit_count += n_found_recs;
                 }
             } else {
-                if (found) o.flags[hay] = 1;
+#pragma unroll
+                for (int k = 0; k < RN; k++) if (found[k]) o.flags[hay[k]] = 1;
             }
-            pm = __ballot(parked);
+#pragma unroll
+            for (int k = 0; k < RN; k++) pm[k] = __ballot(parked[k]);
         }
-        // park the walkers that are not done (rec = the record of the node they stand at); walk the queue when it could not take them, when
-        // it holds a full batch, and -- drain -- to the end
-        if (pm || (drain && wq_n)) {
-            const uint32_t n_park = (uint32_t)__popcll(pm);
-            bool pushed = pm == 0ull;
+        // park the walkers that are not done (rec = the record of the node they stand at), item 0's first; walk the queue when it cannot take
+        // the next lot, when it holds a full batch, and -- drain -- to the end
+        uint64_t pm_any = 0;
+#pragma unroll
+        for (int k = 0; k < RN; k++) pm_any |= pm[k];
+        if (pm_any || (drain && wq_n)) {
+            int next_k = 0;                                      // the item whose walkers are pushed next (RN: all pushed)
             for (;;) {
-                if (!pushed && wq_n + n_park <= wq_cap) {            // (wq_cap >= 64 whenever a queue exists: after a walk there is room)
-                    if (parked) {
-                        const uint32_t e = wq + (wq_n + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))) * 64u;
-                        lds_write_u32x4(e, make_uint4((uint32_t)gpos[0], (uint32_t)(gpos[0] >> 32), avail[0], slot));
-                        lds_write_u32x4(e + 16u, make_uint4(depth[0], best_state[0], best_vlen[0], w2[0]));
-                        lds_write_u32x4(e + 32u, make_uint4(rec[0].z, rec[0].w, rec[0].label[0], rec[0].label[1]));
-                        lds_write_u32x4(e + 48u, make_uint4(rec[0].label[2], rec[0].label[3], hay, 0u));
+#pragma unroll
+                for (int k = 0; k < RN; k++) {
+                    if (next_k == k) {
+                        const uint32_t n_park = (uint32_t)__popcll(pm[k]);
+                        if (wq_n + n_park <= wq_cap) {           // (wq_cap >= 64 whenever a queue exists: after a walk there is room)
+                            if (parked[k]) {
+                                const uint32_t e = wq + (wq_n + (uint32_t)__popcll(pm[k] & ((1ull << lane) - 1ull))) * 64u;
+                                lds_write_u32x4(e, make_uint4((uint32_t)gpos[k], (uint32_t)(gpos[k] >> 32), avail[k], slot[k]));
+                                lds_write_u32x4(e + 16u, make_uint4(depth[k], best_state[k], best_vlen[k], w2[k]));
+                                lds_write_u32x4(e + 32u, make_uint4(rec[k].z, rec[k].w, rec[k].label[0], rec[k].label[1]));
+                                lds_write_u32x4(e + 48u, make_uint4(rec[k].label[2], rec[k].label[3], hay[k], 0u));
+                            }
+                            wq_n += n_park;
+                            wave_lds_fence();
+                            next_k = k + 1;
+                        }
                     }
-                    wq_n += n_park;
-                    wave_lds_fence();
-                    pushed = true;
                 }
-                if (pushed && (drain ? wq_n == 0u : wq_n < 64u)) break;
+                if (next_k == RN && (drain ? wq_n == 0u : wq_n < 64u)) break;
                 walk_parked();
                 wave_lds_fence();
             }
