@@ -270,6 +270,7 @@ struct am_matches {
     int dev = 0;
     Record* d_records = nullptr; uint64_t n = 0; size_t cap_bytes = 0;
     std::vector<am_match> host; bool fetched = false;
+    am_match* big = nullptr; size_t big_cap = 0;         // large results: uninitialised host memory filled through pinned staging (am_matches_data)
 };
 
 // The record array of the last freed result is kept for the next call (one buffer, reused when it is large enough
@@ -1192,21 +1193,79 @@ extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay,
 
 // ------------------------------------------------------------------ results
 
+// one host block of a freed large result is kept for the next one (up to 1 GiB)
+struct HostCache {
+    std::mutex mu; void* p = nullptr; size_t cap = 0;
+    void* take(size_t need, size_t* cap_out)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (p && cap >= need && cap <= 2 * need + (1u << 20)) { void* r = p; *cap_out = cap; p = nullptr; cap = 0; return r; }
+        return nullptr;
+    }
+    void give(void* q, size_t c)
+    {
+        if (c > ((size_t)1 << 30)) { std::free(q); return; }
+        void* old = nullptr;
+        { std::lock_guard<std::mutex> lk(mu); old = p; p = q; cap = c; }
+        std::free(old);
+    }
+    ~HostCache() { std::free(p); }
+};
+static HostCache g_host_cache;
+
+constexpr size_t kRecordsDirect = 1u << 20;              // results up to this size: one plain copy
+constexpr size_t kFetchPiece = 8u << 20;
+
+// device -> pageable host memory through the calling thread's pinned staging area (two halves that take turns)
+static int fetch_through_pinned(void* dst, const void* d_src, size_t bytes, int dev)
+{
+    hipStream_t st; AM_TRY(get_stream(dev, &st));
+    AM_TRY(pin_ensure(tl_state.pin, tl_state.pin_cap, 2 * kFetchPiece));
+    for (int k = 0; k < 2; k++) if (!tl_state.pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&tl_state.pin_ev[k], hipEventDisableTiming));
+    const size_t n_pieces = (bytes + kFetchPiece - 1) / kFetchPiece;
+    auto issue = [&](size_t i) -> int {
+        const size_t lo = i * kFetchPiece, len = std::min(kFetchPiece, bytes - lo);
+        HIP_TRY(hipMemcpyAsync(tl_state.pin + (i & 1) * kFetchPiece, (const uint8_t*)d_src + lo, len, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(tl_state.pin_ev[i & 1], st));
+        return AM_OK;
+    };
+    auto take = [&](size_t i) -> int {
+        const size_t lo = i * kFetchPiece, len = std::min(kFetchPiece, bytes - lo);
+        HIP_TRY(hipEventSynchronize(tl_state.pin_ev[i & 1]));
+        std::memcpy((uint8_t*)dst + lo, tl_state.pin + (i & 1) * kFetchPiece, len);
+        return AM_OK;
+    };
+    AM_TRY(issue(0));
+    for (size_t i = 1; i < n_pieces; i++) { AM_TRY(issue(i)); AM_TRY(take(i - 1)); }
+    AM_TRY(take(n_pieces - 1));
+    return AM_OK;
+}
+
 extern "C" uint64_t am_matches_size(const am_matches* m) { return m ? m->n : 0; }
 
 extern "C" const am_match* am_matches_data(am_matches* m)
 {
     if (!m) return nullptr;
     if (!m->fetched) {
-        m->host.resize(m->n);
-        if (m->n) {
-            OnDevice od(m->dev);
-            hipError_t e = hipMemcpy(m->host.data(), m->d_records, m->n * sizeof(Record), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { fail(AM_ERR_HIP, std::string("hipMemcpy(records): ") + hipGetErrorString(e)); return nullptr; }
+        const size_t bytes = (size_t)m->n * sizeof(Record);
+        OnDevice od(m->dev);
+        if (bytes <= kRecordsDirect) {
+            m->host.resize(m->n);
+            if (m->n) {
+                hipError_t e = hipMemcpy(m->host.data(), m->d_records, bytes, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) { fail(AM_ERR_HIP, std::string("hipMemcpy(records): ") + hipGetErrorString(e)); return nullptr; }
+            }
+        } else {
+            // a large result: no zero-filled vector and no staged copy into pageable memory inside the runtime -- the records cross PCIe in
+            // pieces into the calling thread's pinned staging area, and piece i is copied out while piece i + 1 is on its way
+            m->big = (am_match*)g_host_cache.take(bytes, &m->big_cap);      // (a block used before has its pages: a fresh 100-MB block costs 10 ms of page faults)
+            if (!m->big) { m->big_cap = bytes + bytes / 16; m->big = (am_match*)std::malloc(m->big_cap); }
+            if (!m->big) { fail(AM_ERR_OOM, "out of host memory for the match records"); return nullptr; }
+            if (fetch_through_pinned(m->big, m->d_records, bytes, m->dev) != AM_OK) { std::free(m->big); m->big = nullptr; return nullptr; }
         }
         m->fetched = true;
     }
-    return m->host.data();
+    return m->big ? m->big : m->host.data();
 }
 
 extern "C" const void* am_matches_device_data(const am_matches* m) { return m ? m->d_records : nullptr; }
@@ -1215,6 +1274,7 @@ extern "C" void am_matches_free(am_matches* m)
 {
     if (!m) return;
     if (m->d_records) g_record_cache[m->dev].give(m->d_records, m->cap_bytes);
+    if (m->big) g_host_cache.give(m->big, m->big_cap);
     delete m;
 }
 
