@@ -116,6 +116,28 @@ def test_edge_shapes():
     check_all_paths(["é", "éé", "日本", "𝄞"], ["éééé日本語𝄞𝄞", "日", "𝄞"], 0)                  # 1-4 byte needles: all suffix tiers
 
 
+def test_large_result_reaches_the_host_in_pieces():
+    """A result of more than 8 MiB of records crosses PCIe through the pinned staging area piece by piece (am_matches_data); twice, so
+    that the second result lands in the host block kept from the first."""
+    n = 1_300_000                                       # 1.3 M records = 20.8 MB = three pieces
+    a = am.Automaton(["a"])
+    state = int(a.run_records(0, ["a"])[0]["state"])
+    for _ in range(2):
+        rec = a.run_records(0, ["a" * n, "b" * 10, "aa"])
+        assert len(rec) == n + 2
+        assert np.array_equal(rec["end_pos"][:n], np.arange(1, n + 1, dtype=np.uint64))
+        assert not rec["haystack"][:n].any() and (rec["state"] == state).all()
+        assert [int(x) for x in rec["haystack"][n:]] == [2, 2] and [int(x) for x in rec["end_pos"][n:]] == [1, 2]
+
+
+def test_one_document_run_has_the_records_with_the_count():
+    """Documents up to 64 KiB: count and first records come back in one copy (run_records_small); more than 256 records need the second one."""
+    for n in (1, 255, 256, 257, 5000):
+        check_all_paths(["a", "ab"], ["a" * n], 0)
+    check_all_paths(["abc"], ["x" * 65536], 0)           # the largest document of the short path, no match
+    check_all_paths(["abc"], ["x" * 65530 + "abcabc"], 0)
+
+
 def test_record_pool_overflow_retry(monkeypatch):
     # the single-pass emit guesses its record pool; force a 1-block pool so the retry path runs
     monkeypatch.setenv("AM_SF_POOL_BLOCKS", "1")
