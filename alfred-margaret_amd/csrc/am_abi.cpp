@@ -1890,6 +1890,9 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             }
         }
         t_c += now() - t0;
+        if (trace && std::getenv("AM_RP_TRACE")[0] == '2')
+            std::fprintf(stderr, "[am_replacer pt pass %u] active %u -> %llu, finished %llu, records <= %llu, windows %llu (%llu B), next text %llu B\n", (unsigned)res->passes, n_act,
+                         (unsigned long long)n_next, (unsigned long long)n_fin, (unsigned long long)n_rec, (unsigned long long)n_win, (unsigned long long)total_w, (unsigned long long)total_next);
         cur_rec ^= 1; cur_pt ^= 1; n_rec = next_n_rec; n_rec_dev = next_n_rec_dev;
         cur_offs = (const uint64_t*)s.offs[nxt].p; cur_orig = (const uint32_t*)s.orig[nxt].p; cur_thr = (const int64_t*)s.thr[nxt].p;
         n_act = (uint32_t)n_next; nxt ^= 1;
