@@ -1506,7 +1506,7 @@ namespace {
 
 struct RpSession {
     DevBuf text[2], offs[2], orig[2], thr[2];
-    DevBuf totals; uint64_t* tot_host = nullptr;       // the per-pass totals, read back through pinned memory
+    DevBuf totals; uint64_t* tot_host = nullptr; uint64_t tot_seq = 0;       // the per-pass totals, read back through pinned memory (tot_host[15]: sequence number of the last pass written)
     hipStream_t copy_stream = nullptr; hipEvent_t ev_spliced = nullptr;     // finished texts travel home next to the window scans
     RpFin* fin_host = nullptr; size_t fin_host_cap = 0;                     // pinned
     int pin_meta(size_t bytes)
@@ -1590,7 +1590,13 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
     o.n_blocks = (uint32_t)want_blocks;
     AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, (uint32_t*)b->unit_counts.p + p.n_units, sizeof(uint32_t)));      // (the Replacer's window batches are new every pass: one launch)
     AM_TRY(launch_scan_kernel(p, kModeEmit, o, st));
-    { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
+    { Prof pr("scan", st);
+      if (n <= (1u << 16)) {                                  // few units: the single-workgroup scan (one dispatch, no library sizing / configuration on the host)
+          ScanJobs jobs{};
+          jobs.j[0] = ScanJob{(const uint32_t*)b->unit_counts.p, nullptr, (uint64_t*)b->unit_offsets.p, n, nullptr};
+          jobs.n_jobs = 1;
+          HIP_TRY(launch_scan_jobs(jobs, st));
+      } else HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
     { Prof pr("permute", st); HIP_TRY(launch_permute(o, (const uint64_t*)b->unit_offsets.p, d_out, p.n_units, st)); }
     return AM_OK;
 }
@@ -1672,7 +1678,10 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
     } give_back{r, sp};
     RpSession& s = *sp;
     AM_TRY(s.totals.ensure(128));
-    if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    if (!s.tot_host) {
+        if (hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+        std::memset(s.tot_host, 0, 128);                  // (fine-grained: a device store is visible to the host while the kernel is still running)
+    }
     if (!s.copy_stream && (hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev_spliced, hipEventDisableTiming) != hipSuccess))
         return fail(AM_ERR_HIP, "could not create the copy stream");
     const uint8_t* base_text = (const uint8_t*)in->d_text;               // never modified: every text piece points into it
@@ -1708,7 +1717,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
     }
     const bool trace = std::getenv("AM_RP_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_a = 0, t_b = 0, t_c = 0;
+    double t_a = 0, t_b = 0, t_c = 0, t_sync = 0;
     // finished haystacks of the previous pass: their bytes are on their way home on the copy stream; the host looks at the list after
     // the next pass's (only) synchronisation
     uint64_t prev_n_fin = 0, prev_total_fin = 0; uint8_t* prev_home = nullptr;
@@ -1752,13 +1761,25 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         AM_TRY(records.ensure(sizeof(Record)));
         RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
-        { Prof pr("rp_ranges", st);
-          if (n_rec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)records.p, n_rec_dev, (uint64_t*)s.rec_first.p, route, n_act, st));
-          else HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
-        AM_TRY(rp_fold(s, r, false, base_text, cur_offs, (const Record*)records.p, n_rec_dev ? 0 : n_rec, cur_thr, max_length, route, n_act, st));
+        // the per-haystack fold also finds its record range and writes the piece / window counts (one dispatch instead of three in the pass's
+        // chain); the record-parallel fold keeps the separate launches
+        bool par_fold = (n_rec_dev ? 0 : n_rec) > 2048ull * n_act;
+        if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;
+        static const bool no_fuse = std::getenv("AM_RP_NO_FUSE") != nullptr;                      // A/B
+        const bool fused = !par_fold && !no_fuse;
+        if (fused) {
+            Prof pr("rp_pass", st);
+            const RpFused fu{(uint64_t*)s.rec_first.p, n_rec_dev ? 0 : n_rec, n_rec_dev, (const uint32_t*)s.pt_cnt[cur_pt].p, (uint32_t*)s.pt_need.p, (uint32_t*)s.nwin.p};
+            HIP_TRY(launch_rp_pass(false, r->t, base_text, cur_offs, (const Record*)records.p, nullptr, cur_thr, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st, &fu));
+        } else {
+            { Prof pr("rp_ranges", st);
+              if (n_rec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)records.p, n_rec_dev, (uint64_t*)s.rec_first.p, route, n_act, st));
+              else HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
+            AM_TRY(rp_fold(s, r, false, base_text, cur_offs, (const Record*)records.p, n_rec_dev ? 0 : n_rec, cur_thr, max_length, route, n_act, st));
+        }
         const bool small = n1 <= (1u << 18);
         { Prof pr("rp_scans", st);
-          HIP_TRY(launch_pt_count((const RpHay*)s.hs.p, (const uint32_t*)s.pt_cnt[cur_pt].p, n_act, (uint32_t*)s.pt_need.p, (uint32_t*)s.nwin.p, st));
+          if (!fused) HIP_TRY(launch_pt_count((const RpHay*)s.hs.p, (const uint32_t*)s.pt_cnt[cur_pt].p, n_act, (uint32_t*)s.pt_need.p, (uint32_t*)s.nwin.p, st));
           if (small) {
               ScanJobs jobs{};
               jobs.j[0] = ScanJob{nullptr, route.len_next, (uint64_t*)s.off_next.p, n1, nullptr};
@@ -1791,10 +1812,27 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
           } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.wlen.p, (uint64_t*)s.woffs.p, n_rec + 1, st)); }
         // the pass's ONE synchronisation: bytes of next text, bytes of finished text, -, haystacks still active, haystacks finished,
         // windows, window bytes, piece entries, and the exact record count of this pass when it was still on the device
-        HIP_TRY(launch_rp_totals(rt, n_act, (const uint64_t*)s.win_off.p, (const uint64_t*)s.woffs.p, woffs_last, (uint64_t*)s.totals.p, st,
-                                 (const uint64_t*)s.pt_need_off.p + n_act, n_rec_dev));
-        HIP_TRY(hipMemcpyAsync(s.tot_host, s.totals.p, 80, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // (k_rp_totals writes straight into the pinned host block -- 80 bytes of posted PCIe writes -- instead of into device memory that a
+        // 16-us copy dispatch would then move)
+        // ... and the host waits for the LAST word of that block (a sequence number the kernel stores after a system-scope fence) by spinning on
+        // it for a while before it falls back to hipStreamSynchronize: the blocking wait's wake-up cost 20-30 us of every pass's ~250
+        const uint64_t seq = ++s.tot_seq;
+        HIP_TRY(launch_rp_totals(rt, n_act, (const uint64_t*)s.win_off.p, (const uint64_t*)s.woffs.p, woffs_last, s.tot_host, st,
+                                 (const uint64_t*)s.pt_need_off.p + n_act, n_rec_dev, seq));
+        const double t_s0 = now();
+        {
+            static const bool no_spin = std::getenv("AM_RP_NO_SPIN") != nullptr;          // A/B
+            bool seen = false;
+            if (!no_spin) {
+                const double give_up = t_s0 + 2e-3;
+                for (uint32_t it = 0; !seen; it++) {
+                    seen = __atomic_load_n(&s.tot_host[15], __ATOMIC_ACQUIRE) == seq;
+                    if (!seen && (it & 1023u) == 1023u && now() > give_up) break;
+                }
+            }
+            if (!seen) HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (trace) t_sync += now() - t_s0;
         const uint64_t* tot = s.tot_host;
         const uint64_t total_next = tot[0], total_fin = tot[1], n_next = tot[3], n_fin = tot[4], n_win = tot[5], total_w = tot[6], n_pieces = tot[8];
         if (n_rec_dev) { n_rec = tot[9]; n_rec_dev = nullptr; }
@@ -1899,7 +1937,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
     }
     HIP_TRY(hipStreamSynchronize(st));
     AM_TRY(finished_home());
-    if (trace) std::fprintf(stderr, "[am_replacer pt] fold+scans %.1f ms, pieces+materialise %.1f ms, windows+merge %.1f ms\n", t_a * 1e3, t_b * 1e3, t_c * 1e3);
+    if (trace) std::fprintf(stderr, "[am_replacer pt] fold+scans %.1f ms (of which waiting for the device %.1f), pieces+materialise %.1f ms, windows+merge %.1f ms\n", t_a * 1e3, t_sync * 1e3, t_b * 1e3, t_c * 1e3);
     return AM_OK;
 }
 
@@ -1952,7 +1990,10 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     } give_back{r, sp};
     RpSession& s = *sp;
     AM_TRY(s.totals.ensure(128));
-    if (!s.tot_host && hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+    if (!s.tot_host) {
+        if (hipHostMalloc((void**)&s.tot_host, 128, hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) { s.tot_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+        std::memset(s.tot_host, 0, 128);                  // (fine-grained: a device store is visible to the host while the kernel is still running)
+    }
     // pass 0 reads the caller's batch in place; afterwards the text ping-pongs between s.text[0] and s.text[1]
     const uint8_t* cur_text = (const uint8_t*)in->d_text;
     const uint64_t* cur_offs = in->d_offsets;

@@ -106,9 +106,13 @@ constexpr uint64_t kRpTile = 16384;                      // bytes of new text pe
 hipError_t launch_rp_ranges(const Record* recs, uint64_t n_rec, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_ranges_dev(const Record* recs, const uint64_t* n_rec_dev, uint64_t* rec_first, const RpRoute& route, uint32_t n_act, hipStream_t st);
 hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out10, hipStream_t st,
-                            const uint64_t* extra8 = nullptr, const uint64_t* extra9 = nullptr);      // out10[8], out10[9] = *extra8, *extra9 (0 when null)
+                            const uint64_t* extra8 = nullptr, const uint64_t* extra9 = nullptr, uint64_t seq = 0);      // out10[8], out10[9] = *extra8, *extra9 (0 when null); seq != 0: out10 is pinned host memory, out10[15] = seq last
+// what k_rp_ranges (before the fold) and k_pt_count (after it) would write, done by k_rp_pass itself: one dispatch instead of three in the
+// chain of a Replacer pass.  rec_first_w == nullptr: not fused (rec_first is read).
+struct RpFused { uint64_t* rec_first_w; uint64_t n_rec; const uint64_t* n_rec_dev; const uint32_t* pc_cnt; uint32_t* need; uint32_t* nwin; };
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
-                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st);
+                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st,
+                          const RpFused* fused = nullptr);
 struct RpSelected { uint64_t start, len; uint32_t haystack, payload; };     // = am_prio_match in include/am.h
 hipError_t launch_rp_gather(const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const uint64_t* out_off, RpSelected* out, int64_t* best_out,
                             uint32_t n_act, hipStream_t st);

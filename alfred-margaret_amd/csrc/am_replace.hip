@@ -15,6 +15,7 @@
 // their start positions are ordered like their end positions and the derived-Ord sort (:159, :241) is the
 // identity on the record order.  am_replacer_create rejects payload tables with duplicate priorities.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <hipcub/hipcub.hpp>
 
 #include "am_device.h"
@@ -76,12 +77,31 @@ template <bool IC>
 __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __restrict__ text, const uint64_t* __restrict__ offsets,
                                                  const Record* __restrict__ recs, const uint64_t* __restrict__ rec_first,
                                                  const int64_t* __restrict__ thr, uint64_t max_len, RpKept* __restrict__ kept,
-                                                 RpHay* __restrict__ hs, RpRoute route, uint32_t n_act, uint32_t keep_all)
+                                                 RpHay* __restrict__ hs, RpRoute route, uint32_t n_act, uint32_t keep_all, RpFused fu)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t h = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
-    if (h >= n_act) return;
-    const uint64_t r0 = rec_first[h], r1 = rec_first[h + 1];
+    uint64_t r0, r1;
+    if (fu.rec_first_w) {
+        // fused: the record range of the haystack by two binary searches of its own (k_rp_ranges), the trailing elements of the scans' inputs by
+        // the wavefront after the last haystack
+        if (h > n_act) return;
+        const uint64_t n_rec = fu.n_rec_dev ? *fu.n_rec_dev : fu.n_rec;
+        auto first_of = [&](uint64_t hh) { uint64_t lo = 0, hi = n_rec; while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (recs[mid].haystack < hh) lo = mid + 1; else hi = mid; } return lo; };
+        r0 = first_of(h);
+        if (lane == 0) fu.rec_first_w[h] = r0;
+        if (h == n_act) {
+            if (lane == 0) {
+                route.len_next[h] = 0; route.len_fin[h] = 0; route.tiles[h] = 0; route.act[h] = 0; route.fin[h] = 0;
+                if (fu.need) { fu.need[h] = 0; fu.nwin[h] = 0; }
+            }
+            return;
+        }
+        r1 = first_of((uint64_t)h + 1);
+    } else {
+        if (h >= n_act) return;
+        r0 = rec_first[h]; r1 = rec_first[h + 1];
+    }
     const uint64_t hoff = offsets[h], curlen = offsets[h + 1] - hoff;
     const int64_t threshold = thr[h];
 
@@ -167,6 +187,10 @@ __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __re
         route.tiles[h] = status == kRpNothing ? 0u : (uint32_t)((newlen + kRpTile - 1) / kRpTile);
         route.act[h] = status == kRpActive ? 1u : 0u;
         route.fin[h] = status == kRpActive ? 0u : 1u;
+        if (fu.need) {                                   // (k_pt_count)
+            fu.need[h] = status != kRpNothing ? fu.pc_cnt[h] + 2u * nkept + 1u : 0u;
+            fu.nwin[h] = status == kRpActive ? nkept : 0u;
+        }
     }
 }
 
@@ -488,7 +512,7 @@ hipError_t launch_rp_ranges_dev(const Record* recs, const uint64_t* n_rec_dev, u
 }
 
 __global__ void k_rp_totals(RpRouted rt, uint32_t n_act, const uint64_t* __restrict__ win_off, const uint64_t* __restrict__ woffs, uint64_t woffs_last,
-                            const uint64_t* __restrict__ extra8, const uint64_t* __restrict__ extra9, uint64_t* __restrict__ out10)
+                            const uint64_t* __restrict__ extra8, const uint64_t* __restrict__ extra9, uint64_t* __restrict__ out10, uint64_t seq)
 {
     out10[0] = rt.off_next[n_act]; out10[1] = rt.off_fin[n_act]; out10[2] = rt.tile_off[n_act]; out10[3] = rt.act_idx[n_act]; out10[4] = rt.fin_idx[n_act];
     out10[5] = win_off ? win_off[n_act] : 0;                                                  // windows of the incremental re-scan and their bytes
@@ -496,21 +520,27 @@ __global__ void k_rp_totals(RpRouted rt, uint32_t n_act, const uint64_t* __restr
     out10[7] = 0;
     out10[8] = extra8 ? *extra8 : 0;                                                          // two more scalars of the pass, so that ONE copy brings
     out10[9] = extra9 ? *extra9 : 0;                                                          // everything to the host (each copy is a 16-us blit of its own)
+    if (seq) {                                            // out10 is pinned host memory and the host spins on this word: the values above first
+        __threadfence_system();
+        __hip_atomic_store(&out10[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t launch_rp_totals(const RpRouted& rt, uint32_t n_act, const uint64_t* win_off, const uint64_t* woffs, uint64_t woffs_last, uint64_t* out10, hipStream_t st,
-                            const uint64_t* extra8, const uint64_t* extra9)
+                            const uint64_t* extra8, const uint64_t* extra9, uint64_t seq)
 {
-    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, win_off, woffs, woffs_last, extra8, extra9, out10);
+    hipLaunchKernelGGL(k_rp_totals, dim3(1), dim3(1), 0, st, rt, n_act, win_off, woffs, woffs_last, extra8, extra9, out10, seq);
     return hipGetLastError();
 }
 
 hipError_t launch_rp_pass(bool ic, const RpTables& t, const uint8_t* text, const uint64_t* offsets, const Record* recs, const uint64_t* rec_first,
-                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st)
+                          const int64_t* thr, uint64_t max_len, RpKept* kept, RpHay* hs, const RpRoute& route, uint32_t n_act, uint32_t keep_all, hipStream_t st,
+                          const RpFused* fused)
 {
-    const dim3 grid((n_act + 3) / 4), block(256);
-    if (ic) hipLaunchKernelGGL(k_rp_pass<true>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act, keep_all);
-    else hipLaunchKernelGGL(k_rp_pass<false>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act, keep_all);
+    const RpFused fu = fused ? *fused : RpFused{nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+    const dim3 grid((n_act + (fused ? 1u : 0u) + 3) / 4), block(256);      // fused: one more wavefront for the trailing elements
+    if (ic) hipLaunchKernelGGL(k_rp_pass<true>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act, keep_all, fu);
+    else hipLaunchKernelGGL(k_rp_pass<false>, grid, block, 0, st, t, text, offsets, recs, rec_first, thr, max_len, kept, hs, route, n_act, keep_all, fu);
     return hipGetLastError();
 }
 
@@ -1060,8 +1090,15 @@ hipError_t launch_scan_jobs(const ScanJobs& jobs, hipStream_t st)
 
 hipError_t scan64_temp_bytes(uint64_t n, size_t* bytes)
 {
+    static std::atomic<size_t> memo[40];             // (as scan_temp_bytes: one answer per power of two)
+    int k = 10; while (k < 39 && (1ull << k) < n) k++;
+    const size_t have = memo[k].load(std::memory_order_relaxed);
+    if (have) { *bytes = have; return hipSuccess; }
     *bytes = 0;
-    return hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n, (hipStream_t)0);
+    const uint64_t n_up = (1ull << k) > 0x7FFFFFFFull ? 0x7FFFFFFFull : (1ull << k);
+    const hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(n > n_up ? n : n_up), (hipStream_t)0);
+    if (e == hipSuccess && n <= n_up) memo[k].store(*bytes ? *bytes : 1, std::memory_order_relaxed);
+    return e;
 }
 
 hipError_t launch_scan64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t st)
