@@ -1845,6 +1845,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         AM_TRY(s.pt_pieces[cur_pt ^ 1].ensure((n_pieces + 2) * sizeof(RpPiece)));
         AM_TRY(s.pt_start[cur_pt ^ 1].ensure((n_next + 1) * 8)); AM_TRY(s.pt_cnt[cur_pt ^ 1].ensure((n_next + 1) * 4));
         AM_TRY(s.pt_fin_start.ensure((n_fin + 1) * 8)); AM_TRY(s.pt_fin_cnt.ensure((n_fin + 1) * 4));
+        if (ev_copied_used) HIP_TRY(hipStreamWaitEvent(st, ev_copied, 0));      // the previous pass's finished texts are written and their metadata has left fin_meta
         { Prof pr("rp_route", st);
           HIP_TRY(launch_rp_route((const RpHay*)s.hs.p, rt, cur_orig, n_act, (uint64_t*)s.offs[nxt].p, (uint32_t*)s.orig[nxt].p, (int64_t*)s.thr[nxt].p, (RpFin*)s.fin_meta.p, st)); }
         { Prof pr("pt_build", st);
@@ -1857,12 +1858,16 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             uint8_t* home = nullptr;
             if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
             AM_TRY(s.pin_meta((n_fin + 1) * sizeof(RpFin)));
-            if (ev_copied_used) HIP_TRY(hipStreamWaitEvent(st, ev_copied, 0));      // the previous finished texts have left fin_text / fin_meta (a whole pass ago)
-            { Prof pr("pt_materialise", st);
+            // the finished texts are written out on the COPY stream (64 us of a 270-us pass that nothing of the next pass waits for): it starts when
+            // this pass's piece lists and metadata are complete; what it reads is not touched before the next pass's host-side look at the copy
+            // stream (finished_home, after the totals) -- and the next rp_route waits for the event as well
+            static const bool mat_main = std::getenv("AM_RP_MAT_MAIN") != nullptr;       // A/B: on the pass's own stream, as before
+            hipStream_t mst = mat_main ? st : s.copy_stream;
+            if (!mat_main) { HIP_TRY(hipEventRecord(s.ev_spliced, st)); HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0)); }
+            { Prof pr("pt_materialise", mst);
               HIP_TRY(launch_pt_materialise((const RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (const uint64_t*)s.pt_fin_start.p, (const uint32_t*)s.pt_fin_cnt.p, (const RpFin*)s.fin_meta.p,
-                                            (uint32_t)n_fin, base_text, r->t.repl, res->dev >= 0 && total_fin ? home : (uint8_t*)s.fin_text.p, st)); }
-            HIP_TRY(hipEventRecord(s.ev_spliced, st));
-            HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0));
+                                            (uint32_t)n_fin, base_text, r->t.repl, res->dev >= 0 && total_fin ? home : (uint8_t*)s.fin_text.p, mst)); }
+            if (mat_main) { HIP_TRY(hipEventRecord(s.ev_spliced, st)); HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0)); }
             if (total_fin && res->dev < 0) HIP_TRY(hipMemcpyAsync(home, s.fin_text.p, total_fin, hipMemcpyDeviceToHost, s.copy_stream));
             HIP_TRY(hipMemcpyAsync(s.fin_host, s.fin_meta.p, n_fin * sizeof(RpFin), hipMemcpyDeviceToHost, s.copy_stream));
             HIP_TRY(hipEventRecord(ev_copied, s.copy_stream));

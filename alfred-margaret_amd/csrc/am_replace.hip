@@ -16,6 +16,7 @@
 // identity on the record order.  am_replacer_create rejects payload tables with duplicate priorities.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdlib>
 #include <hipcub/hipcub.hpp>
 
 #include "am_device.h"
