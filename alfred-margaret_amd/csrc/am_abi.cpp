@@ -1522,7 +1522,7 @@ struct RpSession {
     DevBuf recbuf[2];                    // sorted records of the current pass / of the next one (incremental re-scan)
     DevBuf nwin, win_off, wins, wlen, woffs, wtext, wrec, wrec_first, mcount, moff, tile_hay;
     am_batch ws2;                        // workspace of the window scans
-    DevBuf rec_first, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;
+    DevBuf rec_first, rec_first2, kept, hs, len_next, len_fin, tiles, act, fin, off_next, off_fin, tile_off, act_idx, fin_idx, scan_tmp, fin_text, fin_meta;      // (rec_first2: the piece-table loop's second ranges buffer -- a pass's merge writes the next pass's ranges)
     am_batch ws;                         // workspace holder for the scans; never owns its text
     DevBuf first_orig, first_thr;
     DevBuf pt_pieces[2], pt_start[2], pt_cnt[2], pt_need, pt_need_off, pt_fin_start, pt_fin_cnt;      // piece-table path
@@ -1604,7 +1604,7 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
 // prependMatch + makeMatch + removeOverlap of one pass (Replacer.hs:252-274,191-198): one wavefront per haystack, or -- few
 // haystacks with very many matches each -- parallel over the records.  Writes kept[], hs[] and the route arrays.
 static int rp_fold(RpSession& s, const am_replacer* r, bool ic, const uint8_t* text, const uint64_t* offs, const Record* recs, uint64_t n_rec, const int64_t* thr,
-                   uint64_t max_length, const RpRoute& route, uint32_t n_act, hipStream_t st)
+                   uint64_t max_length, const RpRoute& route, uint32_t n_act, hipStream_t st, const uint64_t* rec_first)
 {
     const uint64_t n1 = (uint64_t)n_act + 1;
     // one wavefront per haystack, or -- few haystacks with very many matches each -- parallel over the records
@@ -1612,7 +1612,7 @@ static int rp_fold(RpSession& s, const am_replacer* r, bool ic, const uint8_t* t
         if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;        // tests force either path
         if (!par_fold) {
             Prof pr("rp_pass", st);
-            HIP_TRY(launch_rp_pass(ic, r->t, text, offs, recs, (const uint64_t*)s.rec_first.p, thr,
+            HIP_TRY(launch_rp_pass(ic, r->t, text, offs, recs, rec_first, thr,
                                    max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st));
         } else {
             Prof pr("rp_pass", st);
@@ -1638,7 +1638,7 @@ static int rp_fold(RpSession& s, const am_replacer* r, bool ic, const uint8_t* t
             HIP_TRY(launch_scan(s.pf_tmp.p, ptmp, (const uint32_t*)s.pf_kflag.p, (uint64_t*)s.pf_kidx.p, n_rec + 2, st));
             HIP_TRY(launch_scan64(s.pf_tmp.p, ptmp, (const uint64_t*)s.pf_kdelta.p, (uint64_t*)s.pf_kdpre.p, n_rec + 2, st));
             HIP_TRY(launch_rpp_finish(r->t, (const RpSel*)s.pf_sel.p, n_sel_dev, n_rec, (const uint32_t*)s.pf_kflag.p, (const uint64_t*)s.pf_kidx.p,
-                                      (const uint64_t*)s.pf_kdpre.p, (const uint64_t*)s.pf_sidx.p, offs, (const uint64_t*)s.rec_first.p, (const int64_t*)s.pf_best.p,
+                                      (const uint64_t*)s.pf_kdpre.p, (const uint64_t*)s.pf_sidx.p, offs, rec_first, (const int64_t*)s.pf_best.p,
                                       (const int64_t*)s.pf_delta.p, (const uint32_t*)s.pf_payload.p, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, st));
         }
     return AM_OK;
@@ -1738,6 +1738,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         return AM_OK;
     };
 
+    int cur_rf = 0; bool have_ranges = false;           // (see the ranges buffers below)
     while (n_act > 0) {
         double t0 = now();
         res->passes++;
@@ -1749,7 +1750,10 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             HIP_TRY(hipStreamSynchronize(st));
             n_rec = s.tot_host[9]; n_rec_dev = nullptr;
         }
-        AM_TRY(s.rec_first.ensure(n1 * 8)); AM_TRY(s.kept.ensure((n_rec + 1) * sizeof(RpKept))); AM_TRY(s.hs.ensure(n1 * sizeof(RpHay)));
+        // record ranges of the haystacks: two buffers that take turns -- the merge at the end of a pass leaves the offsets of the records it
+        // writes (per haystack of the next pass) in the other one, which ARE the next pass's ranges: no search then
+        DevBuf& rfb = cur_rf ? s.rec_first2 : s.rec_first; DevBuf& rfb_next = cur_rf ? s.rec_first : s.rec_first2;
+        AM_TRY(rfb.ensure(n1 * 8)); AM_TRY(s.kept.ensure((n_rec + 1) * sizeof(RpKept))); AM_TRY(s.hs.ensure(n1 * sizeof(RpHay)));
         AM_TRY(s.len_next.ensure(n1 * 8)); AM_TRY(s.len_fin.ensure(n1 * 8)); AM_TRY(s.tiles.ensure(n1 * 4)); AM_TRY(s.act.ensure(n1 * 4)); AM_TRY(s.fin.ensure(n1 * 4));
         AM_TRY(s.off_next.ensure(n1 * 8)); AM_TRY(s.off_fin.ensure(n1 * 8)); AM_TRY(s.tile_off.ensure(n1 * 8)); AM_TRY(s.act_idx.ensure(n1 * 8)); AM_TRY(s.fin_idx.ensure(n1 * 8));
         AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8)); AM_TRY(s.pt_need.ensure(n1 * 4)); AM_TRY(s.pt_need_off.ensure(n1 * 8));
@@ -1769,13 +1773,13 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         const bool fused = !par_fold && !no_fuse;
         if (fused) {
             Prof pr("rp_pass", st);
-            const RpFused fu{(uint64_t*)s.rec_first.p, n_rec_dev ? 0 : n_rec, n_rec_dev, (const uint32_t*)s.pt_cnt[cur_pt].p, (uint32_t*)s.pt_need.p, (uint32_t*)s.nwin.p};
-            HIP_TRY(launch_rp_pass(false, r->t, base_text, cur_offs, (const Record*)records.p, nullptr, cur_thr, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st, &fu));
+            const RpFused fu{have_ranges ? nullptr : (uint64_t*)rfb.p, n_rec_dev ? 0 : n_rec, n_rec_dev, (const uint32_t*)s.pt_cnt[cur_pt].p, (uint32_t*)s.pt_need.p, (uint32_t*)s.nwin.p};
+            HIP_TRY(launch_rp_pass(false, r->t, base_text, cur_offs, (const Record*)records.p, (const uint64_t*)rfb.p, cur_thr, max_length, (RpKept*)s.kept.p, (RpHay*)s.hs.p, route, n_act, 0u, st, &fu));
         } else {
             { Prof pr("rp_ranges", st);
-              if (n_rec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)records.p, n_rec_dev, (uint64_t*)s.rec_first.p, route, n_act, st));
-              else HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
-            AM_TRY(rp_fold(s, r, false, base_text, cur_offs, (const Record*)records.p, n_rec_dev ? 0 : n_rec, cur_thr, max_length, route, n_act, st));
+              if (n_rec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)records.p, n_rec_dev, (uint64_t*)rfb.p, route, n_act, st));
+              else HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)rfb.p, route, n_act, st)); }
+            AM_TRY(rp_fold(s, r, false, base_text, cur_offs, (const Record*)records.p, n_rec_dev ? 0 : n_rec, cur_thr, max_length, route, n_act, st, (const uint64_t*)rfb.p));
         }
         const bool small = n1 <= (1u << 18);
         { Prof pr("rp_scans", st);
@@ -1801,7 +1805,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         uint64_t woffs_last = n_rec;
         { Prof pr("rp_windows", st);
           if (!small) HIP_TRY(hipMemsetAsync(s.wlen.p, 0, (n_rec + 2) * 4, st));
-          HIP_TRY(launch_rp_win_meta(r->t, rt, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p,
+          HIP_TRY(launch_rp_win_meta(r->t, rt, (const RpHay*)s.hs.p, (const uint64_t*)rfb.p, (const RpKept*)s.kept.p,
                                      (const uint64_t*)s.win_off.p, ov, (RpWin*)s.wins.p, (uint32_t*)s.wlen.p, n_act, st, true));
           if (small) {
               ScanJobs jobs{};
@@ -1849,7 +1853,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         { Prof pr("rp_route", st);
           HIP_TRY(launch_rp_route((const RpHay*)s.hs.p, rt, cur_orig, n_act, (uint64_t*)s.offs[nxt].p, (uint32_t*)s.orig[nxt].p, (int64_t*)s.thr[nxt].p, (RpFin*)s.fin_meta.p, st)); }
         { Prof pr("pt_build", st);
-          HIP_TRY(launch_pt_build(r->t, (const RpHay*)s.hs.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpPiece*)s.pt_pieces[cur_pt].p,
+          HIP_TRY(launch_pt_build(r->t, (const RpHay*)s.hs.p, (const uint64_t*)rfb.p, (const RpKept*)s.kept.p, (const RpPiece*)s.pt_pieces[cur_pt].p,
                                   (const uint64_t*)s.pt_start[cur_pt].p, (const uint32_t*)s.pt_cnt[cur_pt].p, (const uint64_t*)s.pt_need_off.p, rt, n_act,
                                   (RpPiece*)s.pt_pieces[cur_pt ^ 1].p, (uint64_t*)s.pt_start[cur_pt ^ 1].p, (uint32_t*)s.pt_cnt[cur_pt ^ 1].p,
                                   (uint64_t*)s.pt_fin_start.p, (uint32_t*)s.pt_fin_cnt.p, st)); }
@@ -1876,7 +1880,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         }
         t_b += now() - t0; t0 = now();
         // ---- the next pass's records
-        uint64_t next_n_rec = 0; const uint64_t* next_n_rec_dev = nullptr;
+        uint64_t next_n_rec = 0; const uint64_t* next_n_rec_dev = nullptr; bool next_have_ranges = false;
         if (n_next > 0) {
             DevBuf& next_records = s.recbuf[cur_rec ^ 1];
             if (total_w > total_next) {
@@ -1911,25 +1915,26 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
                     res->scanned += total_w;
                 }
                 const uint64_t wrec_bound = n_wrec_dev ? total_w : n_wrec;
-                AM_TRY(s.wrec_first.ensure((n_win + 2) * 8)); AM_TRY(s.mcount.ensure((n_next + 1) * 4)); AM_TRY(s.moff.ensure((n_next + 1) * 8));
+                AM_TRY(s.wrec_first.ensure((n_win + 2) * 8)); AM_TRY(s.mcount.ensure((n_next + 1) * 4)); AM_TRY(rfb_next.ensure((n_next + 1) * 8));
                 AM_TRY(next_records.ensure((n_rec + wrec_bound + 1) * sizeof(Record)));
                 Prof pr("rp_merge", st);
                 if (n_wrec_dev) HIP_TRY(launch_rp_ranges_dev((const Record*)s.wrec.p, n_wrec_dev, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
                 else HIP_TRY(launch_rp_ranges((const Record*)s.wrec.p, n_wrec, (uint64_t*)s.wrec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_win, st));
-                HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                HIP_TRY(launch_rp_merge(false, (const Record*)records.p, (const uint64_t*)rfb.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
                                         (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
                                         (uint32_t*)s.mcount.p, nullptr, nullptr, st));
                 if (n_next + 1 <= (1u << 18)) {
                     ScanJobs jobs{};
-                    jobs.j[0] = ScanJob{(const uint32_t*)s.mcount.p, nullptr, (uint64_t*)s.moff.p, n_next + 1, nullptr};
+                    jobs.j[0] = ScanJob{(const uint32_t*)s.mcount.p, nullptr, (uint64_t*)rfb_next.p, n_next + 1, nullptr};
                     jobs.n_jobs = 1;
                     HIP_TRY(launch_scan_jobs(jobs, st));
-                } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)s.moff.p, n_next + 1, st));
-                HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)s.rec_first.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
+                } else HIP_TRY(launch_scan(s.scan_tmp.p, tmp2, (const uint32_t*)s.mcount.p, (uint64_t*)rfb_next.p, n_next + 1, st));
+                HIP_TRY(launch_rp_merge(true, (const Record*)records.p, (const uint64_t*)rfb.p, (const RpKept*)s.kept.p, (const RpHay*)s.hs.p, cur_offs, rt,
                                         (const uint64_t*)s.win_off.p, (const RpWin*)s.wins.p, (const Record*)s.wrec.p, (const uint64_t*)s.wrec_first.p, ov, n_act,
-                                        (uint32_t*)s.mcount.p, (const uint64_t*)s.moff.p, (Record*)next_records.p, st));
+                                        (uint32_t*)s.mcount.p, (const uint64_t*)rfb_next.p, (Record*)next_records.p, st));
                 next_n_rec = n_rec + wrec_bound;                 // an upper bound; the exact count is read with the next pass's totals
-                next_n_rec_dev = (const uint64_t*)s.moff.p + n_next;
+                next_n_rec_dev = (const uint64_t*)rfb_next.p + n_next;
+                next_have_ranges = true;
             }
         }
         t_c += now() - t0;
@@ -1937,6 +1942,8 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             std::fprintf(stderr, "[am_replacer pt pass %u] active %u -> %llu, finished %llu, records <= %llu, windows %llu (%llu B), next text %llu B\n", (unsigned)res->passes, n_act,
                          (unsigned long long)n_next, (unsigned long long)n_fin, (unsigned long long)n_rec, (unsigned long long)n_win, (unsigned long long)total_w, (unsigned long long)total_next);
         cur_rec ^= 1; cur_pt ^= 1; n_rec = next_n_rec; n_rec_dev = next_n_rec_dev;
+        static const bool no_reuse = std::getenv("AM_RP_NO_RANGE_REUSE") != nullptr;      // A/B
+        have_ranges = next_have_ranges && !no_reuse; cur_rf ^= 1;
         cur_offs = (const uint64_t*)s.offs[nxt].p; cur_orig = (const uint32_t*)s.orig[nxt].p; cur_thr = (const int64_t*)s.thr[nxt].p;
         n_act = (uint32_t)n_next; nxt ^= 1;
     }
@@ -2062,7 +2069,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         AM_TRY(records.ensure(sizeof(Record)));            // a valid pointer even when nothing matched
         RpRoute route{(uint64_t*)s.len_next.p, (uint64_t*)s.len_fin.p, (uint32_t*)s.tiles.p, (uint32_t*)s.act.p, (uint32_t*)s.fin.p};
         { Prof pr("rp_ranges", st); HIP_TRY(launch_rp_ranges((const Record*)records.p, n_rec, (uint64_t*)s.rec_first.p, route, n_act, st)); }
-        AM_TRY(rp_fold(s, r, r->case_mode == AM_IGNORE_CASE, cur_text, cur_offs, (const Record*)records.p, n_rec, cur_thr, max_length, route, n_act, st));
+        AM_TRY(rp_fold(s, r, r->case_mode == AM_IGNORE_CASE, cur_text, cur_offs, (const Record*)records.p, n_rec, cur_thr, max_length, route, n_act, st, (const uint64_t*)s.rec_first.p));
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
         // windows of the incremental re-scan (their geometry follows from the kept matches alone, the text is copied after the splice)
         const bool try_inc = inc_enabled && n_rec > 0;

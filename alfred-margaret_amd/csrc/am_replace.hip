@@ -100,6 +100,10 @@ __global__ void __launch_bounds__(256) k_rp_pass(RpTables t, const uint8_t* __re
         }
         r1 = first_of((uint64_t)h + 1);
     } else {
+        if (h == n_act && fu.need) {                     // ranges given (the previous pass's merge left them), counts fused: the trailing elements
+            if (lane == 0) { route.len_next[h] = 0; route.len_fin[h] = 0; route.tiles[h] = 0; route.act[h] = 0; route.fin[h] = 0; fu.need[h] = 0; fu.nwin[h] = 0; }
+            return;
+        }
         if (h >= n_act) return;
         r0 = rec_first[h]; r1 = rec_first[h + 1];
     }
