@@ -1056,33 +1056,51 @@ hipError_t launch_fold_hash(const Record* recs, const uint64_t* rec_first, const
 // shuffles, wave totals through LDS, running carry.  Meant for arrays up to a few hundred thousand elements.
 __global__ void __launch_bounds__(1024) k_scan_jobs(ScanJobs jobs)
 {
-    __shared__ uint64_t wave_tot[16];
-    __shared__ uint64_t carry_s;
+    // exclusive sums by ONE workgroup per job, 4 096 elements per sweep.  What a sweep costs is the latency of its loads (9.3 us for the five
+    // sweeps of 16 385 elements, whatever the barriers cost): the loads of FOUR sweeps are issued together (index clamped, value masked: no
+    // branch between them), then the four sweeps run.  Per sweep: a wavefront scan, the 16 wavefront totals through LDS (two buffers that take
+    // turns: one barrier per sweep) and a second wavefront scan over those 16 in every wavefront, which gives the wavefront's offset and the
+    // sweep's total -- the running carry stays in registers.
+    constexpr int kBatch = 4;
+    __shared__ uint64_t wave_tot[2][16];
     const ScanJob j = jobs.j[blockIdx.x];
     const uint64_t n = j.n_dev ? *j.n_dev + j.n : j.n;
+    if (n == 0) return;
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n; base += 4096) {
-        const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
-        uint64_t v[4];
+    uint64_t carry = 0;
+    int turn = 0;
+    for (uint64_t base0 = 0; base0 < n; base0 += 4096 * kBatch) {
+        uint64_t v[kBatch][4];
+        if (j.in64) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t i = i0 + k;
-            v[k] = i < n ? (j.in64 ? j.in64[i] : (uint64_t)j.in32[i]) : 0ull;
+            for (int bb = 0; bb < kBatch; bb++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const uint64_t i = base0 + 4096u * bb + (uint64_t)threadIdx.x * 4 + k; const uint64_t x = j.in64[i < n ? i : n - 1]; v[bb][k] = i < n ? x : 0ull; }
+        } else {
+#pragma unroll
+            for (int bb = 0; bb < kBatch; bb++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const uint64_t i = base0 + 4096u * bb + (uint64_t)threadIdx.x * 4 + k; const uint32_t x = j.in32[i < n ? i : n - 1]; v[bb][k] = i < n ? (uint64_t)x : 0ull; }
         }
-        const uint64_t mine = v[0] + v[1] + v[2] + v[3];
-        int64_t incl = wave_inclusive_sum_i64((int64_t)mine, lane);
-        if (lane == kWave - 1) wave_tot[wave] = (uint64_t)incl;
-        __syncthreads();
-        uint64_t before = carry_s;
-        for (int w = 0; w < wave; w++) before += wave_tot[w];
-        uint64_t run = before + (uint64_t)incl - mine;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const uint64_t i = i0 + k; if (i < n) j.out[i] = run; run += v[k]; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = run;        // the last thread's running sum = everything so far
-        __syncthreads();
+        for (int bb = 0; bb < kBatch; bb++) {
+            const uint64_t base = base0 + 4096u * bb;
+            if (base >= n) break;                         // (uniform)
+            const uint64_t i0 = base + (uint64_t)threadIdx.x * 4;
+            const uint64_t mine = v[bb][0] + v[bb][1] + v[bb][2] + v[bb][3];
+            const int64_t incl = wave_inclusive_sum_i64((int64_t)mine, lane);
+            if (lane == kWave - 1) wave_tot[turn][wave] = (uint64_t)incl;
+            __syncthreads();
+            const uint64_t wt = lane < 16 ? wave_tot[turn][lane] : 0ull;
+            const int64_t wincl = wave_inclusive_sum_i64((int64_t)wt, lane);               // lanes 0..15: totals of the wavefronts up to and including `lane`
+            const uint64_t before_waves = (uint64_t)__shfl(wincl, wave, kWave) - (uint64_t)__shfl((int64_t)wt, wave, kWave);
+            const uint64_t sweep_total = (uint64_t)__shfl(wincl, 15, kWave);
+            uint64_t run = carry + before_waves + (uint64_t)incl - mine;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint64_t i = i0 + k; if (i < n) j.out[i] = run; run += v[bb][k]; }
+            carry += sweep_total;
+            turn ^= 1;
+        }
     }
 }
 
