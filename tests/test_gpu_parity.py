@@ -390,6 +390,19 @@ def test_replacer_incremental_rescan_equals_full_scans(monkeypatch):
         assert inc == [o.run(h) for h in hays]
 
 
+@pytest.mark.parametrize("switch", ["", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN", "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE"])
+def test_replacer_piece_table_loop_under_its_switches(switch):
+    """The piece-table loop hands record ranges from pass to pass, writes finished texts on a second stream and reads its totals by spinning on
+    pinned memory; each of these has an A/B switch that is read once per process: the same mixed batches must equal the oracle either way."""
+    import os, subprocess, sys
+    from tests.conftest import ROOT
+    env = dict(os.environ)
+    if switch:
+        env[switch] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "measure", "replacer_toggles.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0 and "replacer toggles OK" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
+
+
 def test_replacer_device_many_haystacks_many_passes():
     rng = random.Random(23)
     alpha = "abcde "
