@@ -1191,7 +1191,8 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     static const uint32_t wq_iters = [] { const char* e = std::getenv("AM_SF_WQ_ITERS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 2u; }();   // A/B: steps a batch walks before it parks
     oo.wq_iters = wq_iters;
     if (n_units <= blocks * waves_per_wg) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
-    else if (hipMemsetAsync(oo.next_unit, 0, sizeof(uint32_t), st) != hipSuccess) return hipGetLastError();
+    // (else: *next_unit is zero -- it lives in the batch's 64-byte counter block, which every caller clears before the launch together with
+    // its other counters; a memset of its own here was one more dispatch in every call)
     hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), dim3((uint32_t)blocks), dim3(NT), lds, st, s, b, oo, n_chunks);
     return hipGetLastError();
 }
