@@ -1193,7 +1193,7 @@ extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay,
 
 // ------------------------------------------------------------------ results
 
-// one host block of a freed large result is kept for the next one (up to 1 GiB)
+// one host block of a freed large result is kept for the next one (up to 256 MiB; larger ones go back to the allocator)
 struct HostCache {
     std::mutex mu; void* p = nullptr; size_t cap = 0;
     void* take(size_t need, size_t* cap_out)
@@ -1204,7 +1204,7 @@ struct HostCache {
     }
     void give(void* q, size_t c)
     {
-        if (c > ((size_t)1 << 30)) { std::free(q); return; }
+        if (c > ((size_t)256 << 20)) { std::free(q); return; }
         void* old = nullptr;
         { std::lock_guard<std::mutex> lk(mu); old = p; p = q; cap = c; }
         std::free(old);
