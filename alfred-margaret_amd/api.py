@@ -41,6 +41,9 @@ _vp, _sz = C.c_void_p, C.c_size_t
 ABI = {
     "am_last_error": (C.c_char_p, []),
     "am_automaton_create": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp, C.POINTER(_vp)]),
+    "am_automaton_create_ex": (C.c_int, [_vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _sz, C.POINTER(_vp)]),
+    "am_automaton_lower_hash": (C.c_uint32, [_vp]),
+    "am_lower_table_hash": (C.c_uint32, [_vp, _vp, _sz]),
     "am_automaton_destroy": (None, [_vp]),
     "am_automaton_set_kernel": (C.c_int, [_vp, C.c_int]),
     "am_count": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
@@ -99,6 +102,7 @@ ABI = {
     "am_multi_run_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u64p]),
     "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
     "am_unicode_version": (C.c_uint32, []),
+    "am_image_version": (C.c_uint32, []),
     "am_unlower_code_point": (_sz, [C.c_uint32, _vp, _sz]),
     "am_set_stream": (C.c_int, [_vp]),
     "am_get_stream": (C.c_int, [C.POINTER(_vp)]),
@@ -111,6 +115,7 @@ ABI = {
 _HOST = {
     "amh_last_error": (C.c_char_p, []),
     "amh_build": (C.c_int, [C.c_char_p, _vp, _sz, _vp, C.POINTER(_vp)]),
+    "amh_build_ex": (C.c_int, [C.c_char_p, _vp, _sz, _vp, _vp, _vp, _sz, C.POINTER(_vp)]),
     "amh_free": (None, [_vp]),
     "amh_num_states": (_sz, [_vp]),
     "amh_num_transitions": (_sz, [_vp]),
@@ -129,6 +134,7 @@ _HOST = {
     "amh_searcher_contains_all": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
     "amh_searcher_contains_all_host_fold": (C.c_int, [_vp, C.POINTER(Slice), _sz, _vp]),
     "amh_replacer_build": (C.c_int, [C.c_int, C.c_char_p, _vp, C.c_char_p, _vp, _sz, C.POINTER(_vp)]),
+    "amh_replacer_build_ex": (C.c_int, [C.c_int, C.c_char_p, _vp, C.c_char_p, _vp, _sz, _vp, _vp, _sz, C.POINTER(_vp)]),
     "amh_replacer_free": (None, [_vp]),
     "amh_replacer_with_replacements": (C.c_int, [_vp, C.c_char_p, _vp, C.POINTER(_vp)]),
     "amh_replacer_set_case": (C.c_int, [_vp, C.c_int, C.POINTER(_vp)]),
@@ -225,10 +231,24 @@ class _Slices:
             self.arr[i] = Slice(ptr, off, size - off if ln is None else ln)
 
 
+def _lower_arrays(pairs):
+    if pairs is None:
+        return None, None, 0
+    f = np.ascontiguousarray([p[0] for p in pairs], dtype=np.uint32)
+    t = np.ascontiguousarray([p[1] for p in pairs], dtype=np.uint32)
+    return f, t, len(f)
+
+
+def lower_table_hash(pairs=None):
+    f, t, n = _lower_arrays(pairs)
+    return int(libam().am_lower_table_hash(f.ctypes.data if n else None, t.ctypes.data if n else None, n))
+
+
 class Automaton:
     """AcMachine v with v = uint32 handles (needle index by default)."""
 
-    def __init__(self, needles, values=None):
+    def __init__(self, needles, values=None, lower_pairs=None):
+        """lower_pairs: the caller's lower-casing as [(c, toLower c)] (am_automaton_create_ex); None = the built-in Unicode 14.0 table."""
         blob, offs = pack_texts(needles)
         self.needles = [_as_bytes(n) for n in needles]
         vptr = None
@@ -236,8 +256,13 @@ class Automaton:
             self._vals = np.ascontiguousarray(values, dtype=np.uint32)
             vptr = self._vals.ctypes.data
         h = _vp()
-        _hcheck(libhost().amh_build(blob, offs.ctypes.data, len(needles), vptr, C.byref(h)))
+        lf, lt, ln = _lower_arrays(lower_pairs)
+        _hcheck(libhost().amh_build_ex(blob, offs.ctypes.data, len(needles), vptr, lf.ctypes.data if ln else None, lt.ctypes.data if ln else None, ln, C.byref(h)))
         self._h = h
+
+    @property
+    def lower_hash(self):
+        return int(libam().am_automaton_lower_hash(self.device))
 
     @classmethod
     def build(cls, needles_with_values):
@@ -449,11 +474,13 @@ class Searcher:
 
 
 class Replacer:
-    def __init__(self, case, pairs):
+    def __init__(self, case, pairs, lower_pairs=None):
         nb, no = pack_texts([p[0] for p in pairs])
         rb, ro = pack_texts([p[1] for p in pairs])
         h = _vp()
-        _hcheck(libhost().amh_replacer_build(case, nb, no.ctypes.data, rb, ro.ctypes.data, len(pairs), C.byref(h)))
+        lf, lt, ln = _lower_arrays(lower_pairs)
+        _hcheck(libhost().amh_replacer_build_ex(case, nb, no.ctypes.data, rb, ro.ctypes.data, len(pairs), lf.ctypes.data if ln else None,
+                                               lt.ctypes.data if ln else None, ln, C.byref(h)))
         self._h = h
         self.pairs = list(pairs)
 
@@ -584,11 +611,9 @@ class Splitter:
 
 
 def image_version():
-    """kImageVersion of the flattened automaton image this build produces (csrc/am_image.h); read from the source so that
-    tools and bench.py can refuse measurements taken with another layout."""
-    import re
-    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "am_image.h")) as f:
-        return int(re.search(r"kImageVersion\s*=\s*(\d+)", f.read()).group(1))
+    """kImageVersion of the flattened automaton image this build produces (am_image_version()), so that tools and bench.py can
+    refuse measurements taken with another layout."""
+    return int(libam().am_image_version())
 
 
 def lower_code_point(cp):

@@ -245,6 +245,7 @@ struct am_automaton {
     std::vector<uint64_t> transitions, root_ascii;
     std::vector<uint32_t> offsets, values_len;
     bool has_ref = false;        // false for handles attached to a received image
+    std::shared_ptr<const LowerTable> lower;   // the caller's lower-case table (am_automaton_create_ex); null: the built-in one
     std::vector<uint8_t> cs_image;   // CaseSensitive image flattened (= validated) at creation, uploaded on first use
     int kernel_pref = 0;
     std::mutex mu;
@@ -349,7 +350,7 @@ static int prepare(const am_automaton* ca, int case_mode, const Flavor** out)
         if (case_mode == AM_CASE_SENSITIVE && !a->cs_image.empty()) img.swap(a->cs_image);
         else {
             RefArrays ref{a->transitions.data(), a->transitions.size(), a->offsets.data(), a->offsets.size() - 1, a->root_ascii.data(), a->values_len.data()};
-            if (flatten(ref, case_mode, img, err) != 0) return fail(AM_ERR_INVALID, err);
+            if (flatten(ref, case_mode, img, err, a->lower.get()) != 0) return fail(AM_ERR_INVALID, err);
         }
         void* d = nullptr;
         hipError_t e = hipMalloc(&d, img.size());
@@ -365,20 +366,33 @@ static int prepare(const am_automaton* ca, int case_mode, const Flavor** out)
 
 extern "C" const char* am_last_error(void) { return g_err.c_str(); }
 
-extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
-                                   const uint64_t* root_ascii, const uint32_t* values_len, am_automaton** out)
+// lower_from / lower_to (n_lower_pairs of them; null: the built-in Unicode 14.0 table): what `Data.Char.toLower` of the caller's GHC does,
+// as (c, toLower c) pairs -- Utf8.hs:145-151 lowerCodePoint, consumed by the IgnoreCase image (unlower sets baked into the suffix
+// structure's byte edges, the general kernel's delta table).
+extern "C" int am_automaton_create_ex(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
+                                      const uint64_t* root_ascii, const uint32_t* values_len,
+                                      const uint32_t* lower_from, const uint32_t* lower_to, size_t n_lower_pairs, am_automaton** out)
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!transitions || !offsets || !root_ascii || !values_len || n_states == 0) return fail(AM_ERR_INVALID, "null or empty automaton arrays");
+    std::shared_ptr<const LowerTable> lower;
+    if (lower_from || lower_to || n_lower_pairs) {
+        if (!lower_from || !lower_to) return fail(AM_ERR_INVALID, "lower_from and lower_to must both be given");
+        auto lt = std::make_shared<LowerTable>();
+        std::string err;
+        if (LowerTable::make(lower_from, lower_to, n_lower_pairs, *lt, err) != 0) return fail(AM_ERR_INVALID, err);
+        if (lt->hash != builtin_lower_table().hash) lower = lt;            // the built-in table handed back to us: nothing to keep
+    }
     // validate on the host right away (flatten checks every index); the image is uploaded on first use
     std::vector<uint8_t> img;
     {
         std::string err;
         RefArrays ref{transitions, n_transitions, offsets, n_states, root_ascii, values_len};
-        if (flatten(ref, AM_CASE_SENSITIVE, img, err) != 0) return fail(AM_ERR_INVALID, err);
+        if (flatten(ref, AM_CASE_SENSITIVE, img, err, lower.get()) != 0) return fail(AM_ERR_INVALID, err);
     }
     am_automaton* a = new am_automaton();
+    a->lower = lower;
     a->cs_image.swap(img);
     a->transitions.assign(transitions, transitions + n_transitions);
     a->offsets.assign(offsets, offsets + n_states + 1);
@@ -390,6 +404,28 @@ extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transit
     { int d = 0; if (current_device(&d) == AM_OK) a->dev = d; else g_err.clear(); }
     *out = a;
     return AM_OK;
+}
+
+extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
+                                   const uint64_t* root_ascii, const uint32_t* values_len, am_automaton** out)
+{
+    return am_automaton_create_ex(transitions, n_transitions, offsets, n_states, root_ascii, values_len, nullptr, nullptr, 0, out);
+}
+
+// identifies the lower-case table of the handle's IgnoreCase image (ImageHeader::flags); am_lower_table_hash of the same pairs agrees
+extern "C" uint32_t am_automaton_lower_hash(const am_automaton* a)
+{
+    if (!a) return 0;
+    for (const Flavor& f : a->fl) if (f.ready && !a->has_ref) return f.h.flags;      // attached to an image: what the image says
+    return a->lower ? a->lower->hash : builtin_lower_table().hash;
+}
+
+extern "C" uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs)
+{
+    if (!lower_from || !lower_to) return builtin_lower_table().hash;
+    LowerTable lt; std::string err;
+    if (LowerTable::make(lower_from, lower_to, n_pairs, lt, err) != 0) { g_err = err; return 0; }
+    return lt.hash;
 }
 
 extern "C" void am_automaton_destroy(am_automaton* a)
@@ -1289,6 +1325,7 @@ extern "C" void am_matches_free(am_matches* m)
 
 extern "C" uint32_t am_lower_code_point(uint32_t cp) { return cp < 128 ? fold_byte(cp) : simple_lower(cp); }
 extern "C" uint32_t am_unicode_version(void) { return kUnicodeLowerVersion; }
+extern "C" uint32_t am_image_version(void) { return kImageVersion; }
 
 extern "C" size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap)
 {

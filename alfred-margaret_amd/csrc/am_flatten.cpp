@@ -14,7 +14,11 @@
 
 namespace am {
 
-// ------------------------------------------------------------------ simple lowercase (Unicode 14.0)
+// ------------------------------------------------------------------ simple lowercase
+//
+// The reference lowers with GHC base's Data.Char.toLower (Utf8.hs:145-151), whose table follows the compiler's Unicode version.  So the
+// table is DATA: the caller of am_automaton_create_ex may hand over its own (from, to) pairs; without them the built-in Unicode 14.0
+// table (unicode_lower_tbl.inc) is used.  ASCII is never taken from the table: lowerCodePoint handles it itself (toLowerAscii, :131-135).
 
 namespace {
 struct LowerPair { uint32_t from, to; };
@@ -22,38 +26,69 @@ const LowerPair kLower[] = {
 #include "unicode_lower_tbl.inc"
 };
 constexpr size_t kNLower = sizeof(kLower) / sizeof(kLower[0]);
-
-const std::unordered_multimap<uint32_t, uint32_t>& inverse_lower()
-{
-    static const std::unordered_multimap<uint32_t, uint32_t> inv = [] {
-        std::unordered_multimap<uint32_t, uint32_t> m;
-        for (size_t i = 0; i < kNLower; i++) m.emplace(kLower[i].to, kLower[i].from);
-        return m;
-    }();
-    return inv;
-}
 }  // namespace
 
-// Utf8.hs:145-151 lowerCodePoint; non-ASCII = Data.Char.toLower (simple mapping, Unicode 14.0 here: kUnicodeLowerVersion).
-uint32_t simple_lower(uint32_t cp)
+int LowerTable::make(const uint32_t* from, const uint32_t* to, size_t n, LowerTable& out, std::string& err)
 {
-    size_t lo = 0, hi = kNLower;
-    while (lo < hi) {
-        size_t mid = (lo + hi) / 2;
-        if (kLower[mid].from < cp) lo = mid + 1; else hi = mid;
+    std::vector<std::pair<uint32_t, uint32_t>> v;
+    v.reserve(n + 26);
+    for (uint32_t c = 'A'; c <= 'Z'; c++) v.emplace_back(c, c + 0x20u);            // toLowerAscii
+    for (size_t i = 0; i < n; i++) {
+        if (from[i] > 0x10FFFFu || to[i] > 0x10FFFFu) { err = "lower-case pair beyond U+10FFFF"; return -1; }
+        if (from[i] < 128u) continue;                                               // ASCII: not the table's business
+        if (from[i] == to[i]) continue;                                             // identity pairs carry no information
+        v.emplace_back(from[i], to[i]);
     }
-    return (lo < kNLower && kLower[lo].from == cp) ? kLower[lo].to : cp;
+    std::sort(v.begin(), v.end());
+    for (size_t i = 1; i < v.size(); i++) {
+        if (v[i].first != v[i - 1].first) continue;
+        if (v[i].second != v[i - 1].second) { err = "lower-case table maps one code point to two different ones"; return -1; }
+    }
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    out.from.clear(); out.to.clear(); out.inverse.clear();
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (auto& p : v) {
+        out.from.push_back(p.first); out.to.push_back(p.second);
+        out.inverse.emplace(p.second, p.first);
+        for (uint32_t x : {p.first, p.second}) for (int b = 0; b < 4; b++) { h ^= (x >> (8 * b)) & 0xFFu; h *= 0x100000001B3ull; }
+    }
+    out.hash = (uint32_t)(h ^ (h >> 32));
+    if (out.hash == 0) out.hash = 1;
+    return 0;
 }
 
-// Utf8/Unlower.hs:26-40 unlowerCodePoint: every code point whose lowercase is `cp` (as a set).
-void unlower(uint32_t cp, std::vector<uint32_t>& out)
+uint32_t LowerTable::lower(uint32_t cp) const
+{
+    if (cp < 128u) return fold_byte(cp);
+    const auto it = std::lower_bound(from.begin(), from.end(), cp);
+    return (it != from.end() && *it == cp) ? to[(size_t)(it - from.begin())] : cp;
+}
+
+void LowerTable::unlower(uint32_t cp, std::vector<uint32_t>& out) const
 {
     out.clear();
-    if (simple_lower(cp) == cp) out.push_back(cp);
-    auto range = inverse_lower().equal_range(cp);
+    if (lower(cp) == cp) out.push_back(cp);
+    auto range = inverse.equal_range(cp);
     for (auto it = range.first; it != range.second; ++it) out.push_back(it->second);
     std::sort(out.begin(), out.end());
 }
+
+const LowerTable& builtin_lower_table()
+{
+    static const LowerTable* t = [] {
+        std::vector<uint32_t> f(kNLower), g(kNLower);
+        for (size_t i = 0; i < kNLower; i++) { f[i] = kLower[i].from; g[i] = kLower[i].to; }
+        LowerTable* lt = new LowerTable(); std::string err;
+        (void)LowerTable::make(f.data(), g.data(), kNLower, *lt, err);
+        return lt;
+    }();
+    return *t;
+}
+
+// Utf8.hs:145-151 lowerCodePoint with the built-in table (non-ASCII = Data.Char.toLower's simple mapping, Unicode 14.0: kUnicodeLowerVersion)
+uint32_t simple_lower(uint32_t cp) { return builtin_lower_table().lower(cp); }
+// Utf8/Unlower.hs:26-40 unlowerCodePoint: every code point whose lowercase is `cp` (as a set), built-in table
+void unlower(uint32_t cp, std::vector<uint32_t>& out) { builtin_lower_table().unlower(cp, out); }
 
 static void append_utf8(uint32_t c, std::string& out)   // Utf8.hs:154-160 unicode2utf8
 {
@@ -66,12 +101,12 @@ static void append_utf8(uint32_t c, std::string& out)   // Utf8.hs:154-160 unico
 // Byte strings (forward order) a haystack may contain where the lowered haystack has needle code
 // point `c`.  IgnoreCase: UTF-8 of every x with lower(x) == c, ASCII bytes folded to lower case
 // (the kernels fold haystack bytes the same way).  CaseSensitive: just UTF-8 of c.
-static void variants_of(uint32_t c, bool ignore_case, std::vector<std::string>& out)
+static void variants_of(const LowerTable& lt, uint32_t c, bool ignore_case, std::vector<std::string>& out)
 {
     out.clear();
     if (!ignore_case) { std::string s; append_utf8(c, s); out.push_back(s); return; }
     std::vector<uint32_t> xs;
-    unlower(c, xs);
+    lt.unlower(c, xs);
     for (uint32_t x : xs) {
         std::string s;
         append_utf8(x < 128 ? fold_byte(x) : x, s);
@@ -105,8 +140,9 @@ struct TierEntry { uint32_t key, node; };
 
 }  // namespace
 
-int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err)
+int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err, const LowerTable* lower_table)
 {
+    const LowerTable& lt = lower_table ? *lower_table : builtin_lower_table();
     const size_t S = ref.n_states;
     const bool ic = case_mode == 1;
     if (case_mode != 0 && case_mode != 1) { err = "case_mode must be 0 (CaseSensitive) or 1 (IgnoreCase)"; return -1; }
@@ -162,7 +198,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 
     ImageHeader h;
     std::memset(&h, 0, sizeof(h));
-    h.magic = kImageMagic; h.version = kImageVersion; h.case_mode = (uint32_t)case_mode; h.flags = kUnicodeLowerVersion;
+    h.magic = kImageMagic; h.version = kImageVersion; h.case_mode = (uint32_t)case_mode; h.flags = lt.hash;
     h.n_states = (uint32_t)S; h.max_needle_cps = max_needle_cps; h.root_vlen = vlen[0];
     {
         const uint64_t warm = 4ull * (max_needle_cps ? max_needle_cps : 1) + 4;
@@ -207,9 +243,9 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         h.off_fail = blob.put(fail);
     }
     if (ic) {
-        const uint32_t n_lower = (kLower[kNLower - 1].from + 256u) & ~255u;
+        const uint32_t n_lower = (lt.from.back() + 256u) & ~255u;                 // (never empty: the ASCII pairs are always there)
         std::vector<int32_t> delta(n_lower, 0);
-        for (size_t i = 0; i < kNLower; i++) delta[kLower[i].from] = (int32_t)kLower[i].to - (int32_t)kLower[i].from;
+        for (size_t i = 0; i < lt.from.size(); i++) delta[lt.from[i]] = (int32_t)lt.to[i] - (int32_t)lt.from[i];
         h.n_lower = n_lower;
         h.off_lower = blob.put(delta);
     } else {
@@ -301,7 +337,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             for (uint32_t e = cp_first[u]; e < cp_first[u + 1]; e++) {
                 const uint32_t c = cp_sorted[e].cp, v = cp_sorted[e].dst;
                 auto it = variant_cache.find(c);
-                if (it == variant_cache.end()) { std::vector<std::string> vs; variants_of(c, ic, vs); it = variant_cache.emplace(c, std::move(vs)).first; }
+                if (it == variant_cache.end()) { std::vector<std::string> vs; variants_of(lt, c, ic, vs); it = variant_cache.emplace(c, std::move(vs)).first; }
                 for (const std::string& var : it->second) {
                     uint32_t cur = (uint32_t)u;
                     for (size_t j = var.size(); j-- > 1;) {            // last byte first; all but the lead byte
@@ -657,6 +693,20 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         if (canon[s] >= S || fail[s] >= S) { err = "image: canon/fail state out of range"; return false; }
     }
     for (uint64_t i = 0; i < h.n_transitions; i++) if ((uint32_t)(tr[i] >> 32) >= S) { err = "image: transition target out of range"; return false; }
+    if (h.case_mode == 1) {
+        // the lower-case table the general kernel reads must be the one the header names (ImageHeader::flags = LowerTable::hash)
+        const int32_t* delta = (const int32_t*)(img + h.off_lower);
+        uint64_t hh = 0xCBF29CE484222325ull;
+        for (uint32_t cp = 0; cp < h.n_lower; cp++) {
+            if (!delta[cp]) continue;
+            const int64_t to = (int64_t)cp + delta[cp];
+            if (to < 0 || to > 0x10FFFF) { err = "image: lower-case table leaves the code point range"; return false; }
+            for (uint32_t x : {cp, (uint32_t)to}) for (int b = 0; b < 4; b++) { hh ^= (x >> (8 * b)) & 0xFFu; hh *= 0x100000001B3ull; }
+        }
+        uint32_t h32 = (uint32_t)(hh ^ (hh >> 32));
+        if (h32 == 0) h32 = 1;
+        if (h32 != h.flags) { err = "image: lower-case table does not match the header"; return false; }
+    }
     {
         // the 128 root entries k_ac and ends_first_code_point follow (am_image.h ac_step): a goto target or the wildcard
         const uint64_t* root = (const uint64_t*)(img + h.off_root_ascii);
@@ -731,7 +781,6 @@ bool image_sections_in_bounds(const ImageHeader& h)
     const uint64_t T = h.total_bytes;
     auto ok = [T](uint64_t off, uint64_t count, uint64_t elem) { return off <= T && count <= (T - off) / elem; };
     if (h.magic != kImageMagic || h.version != kImageVersion || h.case_mode > 1 || T < sizeof(ImageHeader)) return false;
-    if ((h.flags & 0xFFFFu) != kUnicodeLowerVersion) return false;      // lower-cased with another Unicode version's table: its IgnoreCase edges differ
     bool good = ok(h.off_transitions, h.n_transitions, 8) && ok(h.off_offsets, (uint64_t)h.n_states + 1, 4) && ok(h.off_root_ascii, 128, 8) &&
                 ok(h.off_canon, h.n_states, 4) && ok(h.off_vlen, h.n_states, 4) && ok(h.off_lower, h.n_lower, 4) &&
                 h.ac_goto_log2_cap >= 4 && h.ac_goto_log2_cap <= 31 && ok(h.off_goto, 1ull << h.ac_goto_log2_cap, 16) && ok(h.off_fail, h.n_states, 4);

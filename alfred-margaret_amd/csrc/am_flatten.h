@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "am_image.h"
@@ -19,7 +20,20 @@ struct RefArrays {
     const uint32_t* values_len;                          // length (machineValues ! s)
 };
 
-int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err);
+// Simple lower-casing as data (Utf8.hs:145-151 lowerCodePoint / Utf8/Unlower.hs:26-40 unlowerCodePoint): the reference's table is whatever
+// Data.Char.toLower of the GHC that built it says, so a caller may supply its own pairs (am_automaton_create_ex); ASCII is A-Z -> a-z always.
+struct LowerTable {
+    std::vector<uint32_t> from, to;                          // sorted by `from`; the 26 ASCII pairs + the non-ASCII pairs given
+    std::unordered_multimap<uint32_t, uint32_t> inverse;     // to -> from
+    uint32_t hash = 0;                                       // of the pairs: recorded in ImageHeader::flags (never 0)
+    static int make(const uint32_t* from, const uint32_t* to, size_t n, LowerTable& out, std::string& err);
+    uint32_t lower(uint32_t cp) const;
+    void unlower(uint32_t cp, std::vector<uint32_t>& out) const;
+};
+const LowerTable& builtin_lower_table();                     // Unicode 14.0 (unicode_lower_tbl.inc)
+
+// lower_table == nullptr: the built-in table
+int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err, const LowerTable* lower_table = nullptr);
 
 // ImageHeader::checksum: of everything after the header (checked when an image comes from the host)
 uint64_t image_checksum(const uint8_t* p, size_t n);

@@ -24,18 +24,29 @@ struct Collect {
 extern "C" {
 
 // Flatten only: returns image size (or -1) -- lets tests inspect the header.
-long long amchk_flatten(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
-                        const uint64_t* root_ascii, const uint32_t* values_len, int case_mode,
-                        uint8_t* image_out, size_t image_cap, char* err_out, size_t err_cap)
+// (lower_from / lower_to / n_pairs: the caller's lower-case table as am_automaton_create_ex takes it; null = built-in)
+long long amchk_flatten_ex(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
+                           const uint64_t* root_ascii, const uint32_t* values_len, int case_mode,
+                           const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs,
+                           uint8_t* image_out, size_t image_cap, char* err_out, size_t err_cap)
 {
     std::vector<uint8_t> img; std::string err;
     RefArrays ref{transitions, n_transitions, offsets, n_states, root_ascii, values_len};
-    if (flatten(ref, case_mode, img, err) != 0) {
+    LowerTable lt;
+    const bool custom = lower_from && lower_to;
+    if ((custom && LowerTable::make(lower_from, lower_to, n_pairs, lt, err) != 0) || flatten(ref, case_mode, img, err, custom ? &lt : nullptr) != 0) {
         if (err_out && err_cap) { std::strncpy(err_out, err.c_str(), err_cap - 1); err_out[err_cap - 1] = 0; }
         return -1;
     }
     if (image_out && image_cap >= img.size()) std::memcpy(image_out, img.data(), img.size());
     return (long long)img.size();
+}
+
+long long amchk_flatten(const uint64_t* transitions, size_t n_transitions, const uint32_t* offsets, size_t n_states,
+                        const uint64_t* root_ascii, const uint32_t* values_len, int case_mode,
+                        uint8_t* image_out, size_t image_cap, char* err_out, size_t err_cap)
+{
+    return amchk_flatten_ex(transitions, n_transitions, offsets, n_states, root_ascii, values_len, case_mode, nullptr, nullptr, 0, image_out, image_cap, err_out, err_cap);
 }
 
 // Interpret an image over a batch.  which: 0 = AC walk (general kernel's logic), 1 = SF (filter +

@@ -143,7 +143,8 @@ template <class V> struct AcMachine {
 };
 
 // Automaton.hs:176  build :: [(Text, v)] -> AcMachine v
-template <class V> AcMachine<V> build(const std::vector<std::pair<Text, V>>& needlesWithValues)
+// lower (optional): the caller's lower-casing for IgnoreCase runs (am_automaton_create_ex); null = libam's built-in table
+template <class V> AcMachine<V> build(const std::vector<std::pair<Text, V>>& needlesWithValues, const utf8::LowerTable* lower = nullptr)
 {
     std::vector<Text> needles; needles.reserve(needlesWithValues.size());
     for (auto& nv : needlesWithValues) needles.push_back(nv.first);
@@ -160,8 +161,9 @@ template <class V> AcMachine<V> build(const std::vector<std::pair<Text, V>>& nee
     m.machineOffsets = std::move(p.offsets);
     m.machineRootAsciiTransitions = std::move(p.rootAscii);
     am_automaton* a = nullptr;
-    amCheck(am_automaton_create(m.machineTransitions.data(), m.machineTransitions.size(), m.machineOffsets.data(), m.numStates(),
-                                m.machineRootAsciiTransitions.data(), valuesLen.data(), &a));
+    amCheck(am_automaton_create_ex(m.machineTransitions.data(), m.machineTransitions.size(), m.machineOffsets.data(), m.numStates(),
+                                   m.machineRootAsciiTransitions.data(), valuesLen.data(), lower ? lower->from.data() : nullptr,
+                                   lower ? lower->to.data() : nullptr, lower ? lower->from.size() : 0, &a));
     m.device.reset(a, detail::AutomatonDeleter());
     return m;
 }

@@ -1,6 +1,7 @@
 // facade.cpp -- flat C entry points over the C++ host mirror (automaton.hpp / searcher.hpp /
 // replacer.hpp) so that Python (ctypes) tests and bench.py can drive it.  Values are uint32 handles.
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "replacer.hpp"
@@ -33,17 +34,25 @@ extern "C" {
 const char* amh_last_error(void) { return g_err.c_str(); }
 
 // Automaton.build; values[i] (or i when values == NULL) is the payload handle of needle i
-int amh_build(const uint8_t* bytes, const uint64_t* offs, size_t n, const uint32_t* values, void** out)
+// (lower_from / lower_to / n_pairs: the caller's lower-case table, am_automaton_create_ex; null = built-in)
+int amh_build_ex(const uint8_t* bytes, const uint64_t* offs, size_t n, const uint32_t* values, const uint32_t* lower_from, const uint32_t* lower_to,
+                 size_t n_pairs, void** out)
 {
     *out = nullptr;
     return guarded([&] {
         std::vector<std::pair<Text, uint32_t>> nv(n);
         for (size_t i = 0; i < n; i++) nv[i] = {Text(bytes, (size_t)offs[i], (size_t)(offs[i + 1] - offs[i])), values ? values[i] : (uint32_t)i};
-        auto* box = new MachineBox{build(nv), {}, {}};
+        std::unique_ptr<utf8::LowerTable> lt;
+        if (lower_from && lower_to) lt.reset(new utf8::LowerTable(lower_from, lower_to, n_pairs));
+        auto* box = new MachineBox{build(nv, lt.get()), {}, {}};
         box->valuesOff.assign(1, 0);
         for (auto& vs : box->m.machineValues) { box->valuesFlat.insert(box->valuesFlat.end(), vs.begin(), vs.end()); box->valuesOff.push_back(box->valuesFlat.size()); }
         *out = box;
     });
+}
+int amh_build(const uint8_t* bytes, const uint64_t* offs, size_t n, const uint32_t* values, void** out)
+{
+    return amh_build_ex(bytes, offs, n, values, nullptr, nullptr, 0, out);
 }
 void amh_free(void* h) { delete static_cast<MachineBox*>(h); }
 size_t amh_num_states(void* h) { return static_cast<MachineBox*>(h)->m.numStates(); }
@@ -104,17 +113,24 @@ int amh_searcher_contains_all_host_fold(void* s, const am_slice* hay, size_t n_h
 }
 
 // ---- Replacer
-int amh_replacer_build(int case_mode, const uint8_t* nbytes, const uint64_t* noffs, const uint8_t* rbytes, const uint64_t* roffs, size_t n, void** out)
+int amh_replacer_build_ex(int case_mode, const uint8_t* nbytes, const uint64_t* noffs, const uint8_t* rbytes, const uint64_t* roffs, size_t n,
+                          const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs, void** out)
 {
     *out = nullptr;
     return guarded([&] {
+        std::unique_ptr<utf8::LowerTable> lt;
+        if (lower_from && lower_to) lt.reset(new utf8::LowerTable(lower_from, lower_to, n_pairs));
         std::vector<std::pair<std::string, std::string>> pairs(n);
         for (size_t i = 0; i < n; i++) {
             pairs[i].first.assign((const char*)nbytes + noffs[i], (size_t)(noffs[i + 1] - noffs[i]));
             pairs[i].second.assign((const char*)rbytes + roffs[i], (size_t)(roffs[i + 1] - roffs[i]));
         }
-        *out = new Replacer((CaseSensitivity)case_mode, pairs);
+        *out = new Replacer((CaseSensitivity)case_mode, pairs, lt.get());
     });
+}
+int amh_replacer_build(int case_mode, const uint8_t* nbytes, const uint64_t* noffs, const uint8_t* rbytes, const uint64_t* roffs, size_t n, void** out)
+{
+    return amh_replacer_build_ex(case_mode, nbytes, noffs, rbytes, roffs, n, nullptr, nullptr, 0, out);
 }
 void amh_replacer_free(void* r) { delete static_cast<Replacer*>(r); }
 // mapReplacement with the new replacements given as a list (needle i gets rbytes[roffs[i] .. roffs[i+1]))

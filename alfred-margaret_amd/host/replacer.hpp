@@ -28,8 +28,9 @@ class Replacer {
 public:
     // Replacer.hs:97-116 build: needle i has priority -i; IgnoreCase lower-cases the needle, the
     // payload lengths are those of the ORIGINAL needle.
-    Replacer(CaseSensitivity cs, const std::vector<std::pair<std::string, std::string>>& replaces)
-        : searcher_(cs, mapNeedles(cs, replaces)) {}
+    // lower (optional): the caller's Data.Char.toLower as data, used for the needles here (:105-107) and by the device for the haystacks
+    Replacer(CaseSensitivity cs, const std::vector<std::pair<std::string, std::string>>& replaces, const utf8::LowerTable* lower = nullptr)
+        : searcher_(cs, mapNeedles(cs, replaces, lower), lower) {}
 
     CaseSensitivity caseSensitivity() const { return searcher_.caseSensitivity(); }
     const Searcher<Payload>& searcher() const { return searcher_; }
@@ -202,13 +203,14 @@ public:
 
 private:
     explicit Replacer(Searcher<Payload> s) : searcher_(std::move(s)) {}
-    static std::vector<std::pair<std::string, Payload>> mapNeedles(CaseSensitivity cs, const std::vector<std::pair<std::string, std::string>>& replaces)
+    static std::vector<std::pair<std::string, Payload>> mapNeedles(CaseSensitivity cs, const std::vector<std::pair<std::string, std::string>>& replaces,
+                                                                   const utf8::LowerTable* lower)
     {
         std::vector<std::pair<std::string, Payload>> out; out.reserve(replaces.size());
         for (size_t i = 0; i < replaces.size(); i++) {
             const std::string& needle = replaces[i].first;
             Payload p{-(long long)i, needle.size(), utf8::lengthCodePoints(Text(needle)), replaces[i].second};
-            out.emplace_back(cs == CaseSensitivity::IgnoreCase ? utf8::lowerUtf8(Text(needle)) : needle, std::move(p));
+            out.emplace_back(cs == CaseSensitivity::IgnoreCase ? utf8::lowerUtf8(Text(needle), lower) : needle, std::move(p));
         }
         return out;
     }

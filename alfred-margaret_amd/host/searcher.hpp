@@ -13,12 +13,12 @@ namespace alfred_margaret {
 
 template <class V> class Searcher {
 public:
-    Searcher(CaseSensitivity cs, std::vector<std::pair<std::string, V>> needlesWithValues)
+    Searcher(CaseSensitivity cs, std::vector<std::pair<std::string, V>> needlesWithValues, const utf8::LowerTable* lower = nullptr)
         : case_(cs), needles_(std::move(needlesWithValues))
     {
         std::vector<std::pair<Text, V>> nv; nv.reserve(needles_.size());
         for (auto& p : needles_) nv.emplace_back(Text(p.first), p.second);
-        automaton_ = alfred_margaret::build(nv);                  // Searcher.hs:118  Aho.build ns
+        automaton_ = alfred_margaret::build(nv, lower);           // Searcher.hs:118  Aho.build ns
     }
     CaseSensitivity caseSensitivity() const { return case_; }
     void setCaseSensitivity(CaseSensitivity cs) { case_ = cs; }   // Searcher.hs:142-145: needles untouched
@@ -66,11 +66,11 @@ inline Searcher<Unit> buildSearcher(CaseSensitivity cs, const std::vector<std::s
 }
 
 // Searcher.hs:167-169 buildNeedleIdSearcher
-inline Searcher<int> buildNeedleIdSearcher(CaseSensitivity cs, const std::vector<std::string>& needles)
+inline Searcher<int> buildNeedleIdSearcher(CaseSensitivity cs, const std::vector<std::string>& needles, const utf8::LowerTable* lower = nullptr)
 {
     std::vector<std::pair<std::string, int>> nv; nv.reserve(needles.size());
     for (size_t i = 0; i < needles.size(); i++) nv.emplace_back(needles[i], (int)i);
-    return Searcher<int>(cs, std::move(nv));
+    return Searcher<int>(cs, std::move(nv), lower);
 }
 
 // Searcher.hs:156-164 containsAny, for a batch of haystacks (one Bool each)

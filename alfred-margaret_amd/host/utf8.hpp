@@ -3,8 +3,11 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "am.h"
 
@@ -43,16 +46,35 @@ inline void encode(uint32_t c, std::string& out)
     else { out.push_back((char)(0xf0 | (c >> 18))); out.push_back((char)(0x80 | ((c >> 12) & 0x3f))); out.push_back((char)(0x80 | ((c >> 6) & 0x3f))); out.push_back((char)(0x80 | (c & 0x3f))); }
 }
 
+// The lower-casing of the host language as data: what Data.Char.toLower of the caller's GHC does (Utf8.hs:151), as the (c, toLower c) pairs
+// with toLower c /= c.  Handed to am_automaton_create_ex by build(); null everywhere = libam's built-in Unicode 14.0 table.
+struct LowerTable {
+    std::vector<uint32_t> from, to;      // sorted by from
+    LowerTable(const uint32_t* f, const uint32_t* t, size_t n)
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> v(n);
+        for (size_t i = 0; i < n; i++) v[i] = {f[i], t[i]};
+        std::sort(v.begin(), v.end());
+        for (auto& p : v) { from.push_back(p.first); to.push_back(p.second); }
+    }
+    uint32_t lower(uint32_t cp) const
+    {
+        if (cp < 128) return cp - 0x41u < 26u ? cp + 0x20u : cp;         // toLowerAscii (Utf8.hs:131-135)
+        const auto it = std::lower_bound(from.begin(), from.end(), cp);
+        return it != from.end() && *it == cp ? to[(size_t)(it - from.begin())] : cp;
+    }
+};
+
 // Utf8.hs:145-151 lowerCodePoint
-inline uint32_t lowerCodePoint(uint32_t cp) { return am_lower_code_point(cp); }
+inline uint32_t lowerCodePoint(uint32_t cp, const LowerTable* lt = nullptr) { return lt ? lt->lower(cp) : am_lower_code_point(cp); }
 
 // Utf8.hs:138-140 lowerUtf8
-inline std::string lowerUtf8(const Text& t)
+inline std::string lowerUtf8(const Text& t, const LowerTable* lt = nullptr)
 {
     std::string out;
     out.reserve(t.len);
     const uint8_t* d = t.begin();
-    for (size_t i = 0; i < t.len;) { size_t u; uint32_t cp = decodeAt(d, i, t.len, u); encode(lowerCodePoint(cp), out); i += u; }
+    for (size_t i = 0; i < t.len;) { size_t u; uint32_t cp = decodeAt(d, i, t.len, u); encode(lowerCodePoint(cp, lt), out); i += u; }
     return out;
 }
 

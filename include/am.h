@@ -94,6 +94,23 @@ int am_automaton_create(const uint64_t* transitions, size_t n_transitions,
                         const uint64_t* root_ascii,
                         const uint32_t* values_len,
                         am_automaton** out);
+/* The same with the caller's lower-casing.  The reference lowers non-ASCII code points with GHC base's Data.Char.toLower
+ * (src/Data/Text/Utf8.hs:145-151 lowerCodePoint, :138-140 lowerUtf8; inverse src/Data/Text/Utf8/Unlower.hs:26-40), whose table
+ * follows the Unicode version of the compiler that builds it (alfred-margaret.cabal:69 `base >= 4.7 && < 5`; 9.6-9.10 = Unicode 15,
+ * 9.12+ = 16).  So that IgnoreCase is bit-exact against ANY such build, the table crosses the boundary as data:
+ *   lower_from[i] -> lower_to[i], n_lower_pairs pairs = [(c, toLower c) | c <- [minBound ..], toLower c /= c]
+ * in any order (pairs with lower_from < 128 are ignored: ASCII is toLowerAscii, :131-135; identity pairs are ignored; one code point
+ * with two different images is AM_ERR_INVALID).  NULL, NULL, 0 = the built-in Unicode 14.0 table (am_unicode_version()).
+ * The IgnoreCase image bakes the table in (byte edges of every x with toLower x == c; the general kernel's delta table) and
+ * records a hash of it: am_automaton_lower_hash(a) == am_lower_table_hash(pairs). */
+int am_automaton_create_ex(const uint64_t* transitions, size_t n_transitions,
+                           const uint32_t* offsets, size_t n_states,
+                           const uint64_t* root_ascii,
+                           const uint32_t* values_len,
+                           const uint32_t* lower_from, const uint32_t* lower_to, size_t n_lower_pairs,
+                           am_automaton** out);
+uint32_t am_automaton_lower_hash(const am_automaton* a);
+uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs);   /* NULL: the built-in table's; 0 on error */
 void am_automaton_destroy(am_automaton* a);
 /* Route k: 0 = automatic, 1 = force the general AC kernel, 2 = force the suffix-filter kernel
  * (fails with AM_ERR_UNSUPPORTED at run time for automata that contain the empty needle). */
@@ -275,13 +292,16 @@ int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst
 int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out);
 
 /* ---- UTF-8 helpers on the path -------------------------------------------------------------------
- * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151), simple mapping of Unicode 14.0
- * (am_unicode_version() = 0x0E00: major << 8 | minor; the flattened image records it, and an image made with another
- * table is refused).  The reference uses GHC base's Data.Char.toLower, whose Unicode version follows the compiler.
- * am_unlower_code_point: Utf8.unlowerCodePoint (src/Data/Text/Utf8/Unlower.hs:26-28) as an ascending set;
- * returns the set size (may exceed cap). */
+ * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151) with the BUILT-IN table: simple mapping of
+ * Unicode 14.0 (am_unicode_version() = 0x0E00: major << 8 | minor).  The reference uses GHC base's Data.Char.toLower, whose
+ * Unicode version follows the compiler: a caller that needs exactly its own hands its table to am_automaton_create_ex; a
+ * flattened image carries the table it was baked with and a hash of it (am_automaton_lower_hash).
+ * am_unlower_code_point: Utf8.unlowerCodePoint (src/Data/Text/Utf8/Unlower.hs:26-28) as an ascending set, built-in table;
+ * returns the set size (may exceed cap).
+ * am_image_version: layout version of the flattened image (am_automaton_image_*); images of another version are refused. */
 uint32_t am_lower_code_point(uint32_t cp);
 uint32_t am_unicode_version(void);
+uint32_t am_image_version(void);
 size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
 
 /* ---- runtime knobs ------------------------------------------------------------------------------ */

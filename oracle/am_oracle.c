@@ -35,9 +35,33 @@ static const lower_pair k_lower[] = {
 
 /* src/Data/Text/Utf8.hs:131-135 toLowerAscii, :145-151 lowerCodePoint
  * (non-ASCII: Data.Char.toLower of GHC base = simple lowercase mapping). */
+/* The table Data.Char.toLower uses follows the GHC that builds the reference (alfred-margaret.cabal:69, .semaphore/semaphore.yml:92),
+ * so tests may give the oracle the caller's pairs -- the same data libam's am_automaton_create_ex takes: orc_set_lower_table(from, to, n)
+ * replaces the built-in Unicode 14.0 table process-wide until orc_set_lower_table(NULL, NULL, 0).  `from` must be sorted ascending. */
+static const uint32_t* g_lower_from = NULL;
+static const uint32_t* g_lower_to = NULL;
+static size_t g_lower_n = 0;
+void orc_set_lower_table(const uint32_t* from, const uint32_t* to, size_t n)
+{
+    free((void*)g_lower_from); free((void*)g_lower_to);
+    g_lower_from = g_lower_to = NULL; g_lower_n = 0;
+    if (!from || !to || !n) return;
+    uint32_t* f = (uint32_t*)malloc(n * sizeof(uint32_t)); uint32_t* t = (uint32_t*)malloc(n * sizeof(uint32_t));
+    memcpy(f, from, n * sizeof(uint32_t)); memcpy(t, to, n * sizeof(uint32_t));
+    g_lower_from = f; g_lower_to = t; g_lower_n = n;
+}
+
 uint32_t orc_lower_code_point(uint32_t cp)
 {
     if (cp < 128) return (cp >= 'A' && cp <= 'Z') ? cp + 0x20 : cp;
+    if (g_lower_n) {
+        size_t lo = 0, hi = g_lower_n;
+        while (lo < hi) {
+            size_t mid = (lo + hi) / 2;
+            if (g_lower_from[mid] < cp) lo = mid + 1; else hi = mid;
+        }
+        return (lo < g_lower_n && g_lower_from[lo] == cp) ? g_lower_to[lo] : cp;
+    }
     size_t lo = 0, hi = N_LOWER;
     while (lo < hi) {
         size_t mid = (lo + hi) / 2;

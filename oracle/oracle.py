@@ -48,6 +48,8 @@ def _load():
     lib.orc_contains_any.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t]
     lib.orc_contains_all.restype = C.c_int
     lib.orc_contains_all.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t]
+    lib.orc_set_lower_table.restype = None
+    lib.orc_set_lower_table.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.orc_lower_code_point.restype = C.c_uint32
     lib.orc_lower_code_point.argtypes = [C.c_uint32]
     lib.orc_skip_code_points_backwards.restype = C.c_int64
@@ -176,6 +178,28 @@ class Machine:
     def contains_all(self, case, text, off=0, length=None):
         p, off, length = self._args(text, off, length)
         return bool(lib().orc_contains_all(self._h, case, self.n_needles, p[0], off, length))
+
+
+def set_lower_table(pairs=None):
+    """Give the oracle the caller's Data.Char.toLower as [(c, toLower c)] (what am_automaton_create_ex takes); None = back to the
+    built-in Unicode 14.0 table.  Process-wide: tests reset it in a finally block."""
+    if not pairs:
+        lib().orc_set_lower_table(None, None, 0)
+        return
+    ps = sorted((int(a), int(b)) for a, b in pairs if int(a) >= 128 and int(a) != int(b))
+    f = np.ascontiguousarray([a for a, _ in ps], dtype=np.uint32)
+    t = np.ascontiguousarray([b for _, b in ps], dtype=np.uint32)
+    lib().orc_set_lower_table(f.ctypes.data, t.ctypes.data, len(ps))
+
+
+def builtin_lower_pairs():
+    """The built-in table as data: [(c, lower c)] over all of Unicode (with whatever table is active)."""
+    out = []
+    for cp in range(128, 0x110000):
+        lo = int(lib().orc_lower_code_point(cp))
+        if lo != cp:
+            out.append((cp, lo))
+    return out
 
 
 def lower_code_point(cp):

@@ -47,20 +47,28 @@ class ImgCheck:
         from alfred_margaret_amd import build
         self.lib = C.CDLL(build.build_imgcheck())
         self.lib.amchk_flatten.restype = C.c_longlong
+        self.lib.amchk_flatten_ex.restype = C.c_longlong
         self.lib.amchk_scan.restype = C.c_longlong
 
-    def flatten(self, m, case):
-        """m: anything with transitions()/offsets()/root_ascii()/values_off()/n_states (oracle or product machine)."""
+    def flatten(self, m, case, lower_pairs=None):
+        """m: anything with transitions()/offsets()/root_ascii()/values_off()/n_states (oracle or product machine).
+        lower_pairs: the caller's lower-case table [(c, toLower c)] (am_automaton_create_ex); None = built-in."""
         tr, of, ra = m.transitions(), m.offsets(), m.root_ascii()
         vl = np.diff(m.values_off()).astype(np.uint32)
         err = C.create_string_buffer(256)
         P = lambda a: a.ctypes.data_as(C.c_void_p)
-        args = (P(tr), C.c_size_t(len(tr)), P(of), C.c_size_t(m.n_states), P(ra), P(vl), case)
-        n = self.lib.amchk_flatten(*args, None, C.c_size_t(0), err, C.c_size_t(256))
+        if lower_pairs is None:
+            low = (None, None, C.c_size_t(0))
+        else:
+            lf = np.ascontiguousarray([a for a, _ in lower_pairs], dtype=np.uint32)
+            lt = np.ascontiguousarray([b for _, b in lower_pairs], dtype=np.uint32)
+            low = (P(lf), P(lt), C.c_size_t(len(lf)))
+        args = (P(tr), C.c_size_t(len(tr)), P(of), C.c_size_t(m.n_states), P(ra), P(vl), case) + low
+        n = self.lib.amchk_flatten_ex(*args, None, C.c_size_t(0), err, C.c_size_t(256))
         if n < 0:
             raise ValueError(err.value.decode())
         img = np.zeros(n, dtype=np.uint8)
-        assert self.lib.amchk_flatten(*args, P(img), C.c_size_t(n), err, C.c_size_t(256)) == n
+        assert self.lib.amchk_flatten_ex(*args, P(img), C.c_size_t(n), err, C.c_size_t(256)) == n
         return img
 
     def scan(self, img, which, hays):
