@@ -135,10 +135,6 @@ struct ThreadState {
     uint8_t* pin = nullptr; size_t pin_cap = 0;          // upload staging (two halves that take turns for inputs above kPinPiece)
     uint8_t* pin_res = nullptr; size_t pin_res_cap = 0;  // results
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
-    // the two-kernel pipeline of large scans: k_consume runs on a second, high-priority stream of the calling thread (streams of different
-    // priorities never share a hardware queue, so the two kernels really run side by side), events order the slices
-    hipStream_t side[kMaxDev] = {};
-    hipEvent_t pipe_ev[kMaxDev][4] = {};
     ~ThreadState();
 };
 thread_local ThreadState tl_state;
@@ -263,8 +259,6 @@ struct am_batch {
     DevBuf combo;               // ... or ONE buffer [offsets | text] for small batches that went up with a single copy
     DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
     DevBuf sparse, dense_counts, dense_offsets, dense_out;      // automata with the empty needle (dense pass)
-    DevBuf cands, cblock_next, cand_meta, pipe_tickets;         // the two-kernel pipeline: candidate chains of k_filter
-    uint64_t cand_blocks_hint = 0;                              // blocks the last scan of this batch needed (a pool that overflowed is not guessed again)
 };
 
 struct am_matches {
@@ -727,7 +721,7 @@ extern "C" void am_batch_destroy(am_batch* b)
 {
     if (!b) return;
     for (DevBuf* d : {&b->text_buf, &b->offs_buf, &b->combo, &b->hidx, &b->unit_counts, &b->unit_offsets, &b->scan_tmp, &b->small, &b->hay_counts, &b->flags, &b->unit_first, &b->pool, &b->block_next,
-                      &b->sparse, &b->dense_counts, &b->dense_offsets, &b->dense_out, &b->cands, &b->cblock_next, &b->cand_meta, &b->pipe_tickets}) d->release();
+                      &b->sparse, &b->dense_counts, &b->dense_offsets, &b->dense_out}) d->release();
     delete b;
 }
 
@@ -741,7 +735,6 @@ struct Plan {
     const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
     bool dense;          // automaton with the empty needle on the suffix-filter route: k_sf's records + the dense pass (am_dense.hip)
     AcView ac; SfView sf; BatchView bv;
-    bool pipe;           // large batch + 128-KiB filter: the two-kernel pipeline (k_filter / k_consume) instead of k_sf
     am_batch* batch;
     uint32_t* next_unit; // k_sf's unit counter (in the batch's `small` block: [0..1] total_values, [4] block counter, [5] overflow, [8] this)
 };
@@ -767,23 +760,13 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     if (p.use_sf) { if (!b->small.p) return fail(AM_ERR_INVALID, "batch without its counter block (not made by am_batch_upload / am_batch_from_device)"); p.next_unit = (uint32_t*)b->small.p + 8; }
     p.n_cu = g_rt.dev[b->dev].n_cu;
     p.batch = b;
-    {
-        // AM_SF_PIPE=1: the two-kernel pipeline whenever the filter allows it (tests, A/B).  Off by default: measured slower than k_sf so far
-        // (DESIGN.md section 6).
-        static const int pipe_env = [] { const char* e = std::getenv("AM_SF_PIPE"); return e ? std::atoi(e) : 0; }();
-        p.pipe = p.use_sf && p.f->h.sf_bloom_log2_words == 15 && (p.f->h.sf_tiers & 8u) && pipe_env == 1;
-        if (p.pipe) p.unit_chunks = 64;      // (a candidate's offset in its unit has 16 bits either way; the slices want whole 64-KiB units)
-    }
     p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
     if (p.n_units >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "batch too large for one launch; split it");
     return AM_OK;
 }
 
-int launch_scan_pipeline(const Plan& p, int mode, const ScanOut& o, hipStream_t st);
-
 int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st)
 {
-    if (p.pipe) return launch_scan_pipeline(p, mode, o, st);
     if (p.use_sf) {
         ScanOut os = o;
         os.next_unit = p.next_unit;
@@ -800,62 +783,6 @@ int build_hidx(const Plan& p, am_batch* b, hipStream_t st)
     Prof pr("hidx", st);
     HIP_TRY(launch_hidx(p.bv, (uint32_t*)b->hidx.p, (b->total >> kHidxShift) + 2, st));
     b->hidx_ready = true;
-    return AM_OK;
-}
-
-// The two-kernel pipeline (am_kernels.hip): the batch is cut into slices of whole work units; k_filter(slice i) runs on the caller's stream,
-// k_consume(slice i) on the thread's high-priority side stream as soon as that filter is done -- i.e. at the same time as k_filter(slice
-// i + 1).  The caller's stream waits for the last consumer.  Candidate-pool overflow is reported in the batch's counter block next to the
-// record pool's ([6] blocks drawn, [7] overflow), the callers repeat the scan with the exact size.
-int launch_scan_pipeline(const Plan& p, int mode, const ScanOut& o, hipStream_t st)
-{
-    am_batch* b = p.batch;
-    const int dev = b->dev;
-    if (!tl_state.side[dev]) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);                       // hi = the numerically smallest = the most urgent
-        HIP_TRY(hipStreamCreateWithPriority(&tl_state.side[dev], hipStreamNonBlocking, hi));
-        for (int k = 0; k < 4; k++) HIP_TRY(hipEventCreateWithFlags(&tl_state.pipe_ev[dev][k], hipEventDisableTiming));
-    }
-    static const bool sequential = [] { const char* e = std::getenv("AM_SF_PIPE_SEQ"); return e && std::atoi(e) != 0; }();      // timing experiment: both kernels on ONE stream
-    hipStream_t side = sequential ? st : tl_state.side[dev];
-    hipEvent_t* ev = tl_state.pipe_ev[dev];
-    const uint64_t unit_bytes = (uint64_t)p.unit_chunks * kSfChunk;
-    // slices of 512 MiB, at least 4 units per k_filter wavefront
-    uint64_t slice_units = (512ull << 20) / unit_bytes;
-    const uint64_t min_units = (uint64_t)p.n_cu * 16 * 4;
-    if (slice_units < min_units) slice_units = min_units;
-    static const uint64_t slice_env = [] { const char* e = std::getenv("AM_SF_PIPE_SLICE_MIB"); return e ? (uint64_t)std::atoll(e) : 0ull; }();      // A/B
-    if (slice_env) slice_units = std::max<uint64_t>(1, (slice_env << 20) / unit_bytes);
-    const uint64_t n_slices = (p.n_units + slice_units - 1) / slice_units;
-    // candidate pool: a candidate per 8 haystack bytes (the benchmark text leaves one per 12) + a block per unit + what the grants strand
-    uint64_t n_cblocks = b->total / 8 / kCandBlockEntries + p.n_units * 32 + (uint64_t)p.n_cu * 16 * 32 + 1024;      // (every unit starts a 32-block grant)
-    if (b->cand_blocks_hint > n_cblocks) n_cblocks = b->cand_blocks_hint;
-    if (n_cblocks >= (1ull << 24)) return fail(AM_ERR_UNSUPPORTED, "too many candidate positions for one call; split the batch");
-    AM_TRY(b->cands.ensure(n_cblocks * kCandBlockEntries * sizeof(uint16_t)));
-    AM_TRY(b->cblock_next.ensure(n_cblocks * sizeof(uint32_t)));
-    const uint64_t n_chunks_all = sf_chunks(p.bv);
-    AM_TRY(b->cand_meta.ensure(2 * p.n_units * sizeof(uint32_t) + (n_chunks_all + 2) * sizeof(uint16_t)));
-    AM_TRY(b->pipe_tickets.ensure(n_slices * sizeof(uint32_t)));
-    HIP_TRY(hipMemsetAsync(b->pipe_tickets.p, 0, n_slices * sizeof(uint32_t), st));
-    PipeView pv{};
-    pv.cands = (uint16_t*)b->cands.p; pv.cblock_next = (uint32_t*)b->cblock_next.p;
-    pv.cctrl = (uint32_t*)b->small.p + 6;                   // cleared with the rest of the counter block by the caller
-    pv.cand_first = (uint32_t*)b->cand_meta.p; pv.cand_count = (uint32_t*)b->cand_meta.p + p.n_units;
-    pv.chunk_count = (uint16_t*)((uint32_t*)b->cand_meta.p + 2 * p.n_units);
-    pv.n_cblocks = (uint32_t)n_cblocks;
-    // whatever the caller queued on its stream so far (clears, the haystack index) comes before the first consumer
-    for (uint64_t i = 0; i < n_slices; i++) {
-        pv.unit0 = i * slice_units; pv.unit1 = std::min<uint64_t>(p.n_units, pv.unit0 + slice_units);
-        pv.unit_ticket = (uint32_t*)b->pipe_tickets.p + i;
-        { Prof pr("sf", st); HIP_TRY(launch_filter(p.ic, p.sf, p.bv, pv, p.unit_chunks, p.n_cu, st)); }
-        hipEvent_t e = ev[i & 1];
-        HIP_TRY(hipEventRecord(e, st));
-        HIP_TRY(hipStreamWaitEvent(side, e, 0));
-        { Prof pr("consume", side); HIP_TRY(launch_consume(p.ic, mode, p.sf, p.bv, o, pv, p.n_cu, side)); }
-    }
-    HIP_TRY(hipEventRecord(ev[2], side));
-    HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));
     return AM_OK;
 }
 
@@ -919,28 +846,23 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     AM_TRY(b->small.ensure(64));
-    for (int attempt = 0; attempt < 3; attempt++) {
-        ScanOut o{};
-        o.unit_chunks = p.unit_chunks;
-        if (!p.use_sf) { AM_TRY(b->unit_counts.ensure((p.n_units + 1) * sizeof(uint32_t))); o.unit_counts = (uint32_t*)b->unit_counts.p; }
-        o.total_values = (uint64_t*)b->small.p;
-        if (counts_out) {
-            AM_TRY(b->hay_counts.ensure((size_t)b->n_hay * sizeof(uint64_t)));
-            o.hay_counts = (uint64_t*)b->hay_counts.p;
-        }
-        AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, counts_out ? b->hay_counts.p : nullptr, counts_out ? (size_t)b->n_hay * sizeof(uint64_t) : 0));
-        AM_TRY(launch_scan_kernel(p, kModeCount, o, st));
-        uint64_t total = 0; uint32_t cctrl[2] = {0, 0};
-        ResultCopies rc;
-        if (total_out) AM_TRY(rc.add(&total, b->small.p, 8, st));
-        if (p.pipe) AM_TRY(rc.add(cctrl, (uint32_t*)b->small.p + 6, 8, st));
-        if (counts_out) AM_TRY(rc.add(counts_out, b->hay_counts.p, (size_t)b->n_hay * sizeof(uint64_t), st));
-        AM_TRY(rc.finish(st));
-        if (p.pipe && cctrl[1]) { b->cand_blocks_hint = (uint64_t)cctrl[0] + (uint64_t)p.n_cu * 16 * 32 + 64; continue; }      // candidate pool too small: once more with what was needed
-        if (total_out) *total_out = total;
-        return AM_OK;
+    ScanOut o{};
+    o.unit_chunks = p.unit_chunks;
+    if (!p.use_sf) { AM_TRY(b->unit_counts.ensure((p.n_units + 1) * sizeof(uint32_t))); o.unit_counts = (uint32_t*)b->unit_counts.p; }
+    o.total_values = (uint64_t*)b->small.p;
+    if (counts_out) {
+        AM_TRY(b->hay_counts.ensure((size_t)b->n_hay * sizeof(uint64_t)));
+        o.hay_counts = (uint64_t*)b->hay_counts.p;
     }
-    return fail(AM_ERR_HIP, "candidate pool overflowed repeatedly (internal error)");
+    AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, counts_out ? b->hay_counts.p : nullptr, counts_out ? (size_t)b->n_hay * sizeof(uint64_t) : 0));
+    AM_TRY(launch_scan_kernel(p, kModeCount, o, st));
+    uint64_t total = 0;
+    ResultCopies rc;
+    if (total_out) AM_TRY(rc.add(&total, b->small.p, 8, st));
+    if (counts_out) AM_TRY(rc.add(counts_out, b->hay_counts.p, (size_t)b->n_hay * sizeof(uint64_t), st));
+    AM_TRY(rc.finish(st));
+    if (total_out) *total_out = total;
+    return AM_OK;
 }
 
 extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const am_batch* cb, uint8_t* flags_out)
@@ -956,21 +878,15 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     AM_TRY(b->flags.ensure(((size_t)b->n_hay + 3) & ~(size_t)3));
     AM_TRY(b->small.ensure(64));
-    for (int attempt = 0; attempt < 3; attempt++) {
-        ScanOut o{};
-        o.unit_chunks = p.unit_chunks;
-        o.flags = (uint8_t*)b->flags.p;
-        AM_TRY(build_hidx_and_clear(p, b, st, b->flags.p, ((size_t)b->n_hay + 3) & ~(size_t)3, b->small.p, 64));      // (the counter block: k_sf's unit ticket, the pipeline's pool control)
-        AM_TRY(launch_scan_kernel(p, kModeAny, o, st));
-        uint32_t cctrl[2] = {0, 0};
-        ResultCopies rc;
-        if (p.pipe) AM_TRY(rc.add(cctrl, (uint32_t*)b->small.p + 6, 8, st));
-        AM_TRY(rc.add(flags_out, b->flags.p, b->n_hay, st));
-        AM_TRY(rc.finish(st));
-        if (p.pipe && cctrl[1]) { b->cand_blocks_hint = (uint64_t)cctrl[0] + (uint64_t)p.n_cu * 16 * 32 + 64; continue; }
-        return AM_OK;
-    }
-    return fail(AM_ERR_HIP, "candidate pool overflowed repeatedly (internal error)");
+    ScanOut o{};
+    o.unit_chunks = p.unit_chunks;
+    o.flags = (uint8_t*)b->flags.p;
+    AM_TRY(build_hidx_and_clear(p, b, st, b->flags.p, ((size_t)b->n_hay + 3) & ~(size_t)3, b->small.p, 64));      // (the counter block: k_sf's unit ticket)
+    AM_TRY(launch_scan_kernel(p, kModeAny, o, st));
+    ResultCopies rc;
+    AM_TRY(rc.add(flags_out, b->flags.p, b->n_hay, st));
+    AM_TRY(rc.finish(st));
+    return AM_OK;
 }
 
 // The whole scan: leaves every record of the batch, sorted by (haystack, end_pos), in device memory
@@ -1049,9 +965,9 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
             { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
             uint64_t total = 0; uint32_t ctrl[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 16, hipMemcpyDeviceToHost, st));      // [0..1] record pool, [2..3] candidate pool of the pipeline
+            HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 16, hipMemcpyDeviceToHost, st));      // [0] blocks drawn, [1] overflow, [2] kernel watchdog
             HIP_TRY(hipStreamSynchronize(st));
-            if (p.pipe && ctrl[3]) { b->cand_blocks_hint = (uint64_t)ctrl[2] + (uint64_t)p.n_cu * 16 * 32 + 64; continue; }
+            if (ctrl[2]) return fail(AM_ERR_HIP, "suffix-filter kernel: internal hand-over between its wavefronts timed out (watchdog)");
             if (ctrl[1]) { want_blocks = (uint64_t)ctrl[0] + 64 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024); continue; }    // pool too small: ctrl[0] = blocks actually needed
             *n_scan = total;
             if (total == 0) return AM_OK;
@@ -1101,7 +1017,7 @@ static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, 
     *done = false;
     if (b->total == 0 || b->total > kSmallRunBytes) return AM_OK;
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
-    if (p.nothing || p.dense || !p.use_sf || p.pipe) return AM_OK;
+    if (p.nothing || p.dense || !p.use_sf) return AM_OK;
     static const bool off = std::getenv("AM_NO_SMALL_RUN") != nullptr;       // A/B
     if (off) return AM_OK;
     std::lock_guard<std::mutex> lk(b->mu);
@@ -1603,11 +1519,6 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
 {
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
     if (!p.use_sf || p.dense) return fail(AM_ERR_UNSUPPORTED, "internal: asynchronous scan needs the plain suffix-filter route");
-    if (p.pipe) {                                             // (only when AM_SF_PIPE=1 forces it: the window scans are small) the pipeline's pools need a host look
-        p.pipe = false;
-        p.unit_chunks = sf_unit_chunks(p.bv, p.n_cu);
-        p.n_units = (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks;
-    }
     std::lock_guard<std::mutex> lk(b->mu);
     const uint64_t n = p.n_units + 1;
     AM_TRY(b->unit_counts.ensure(n * sizeof(uint32_t)));

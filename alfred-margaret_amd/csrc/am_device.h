@@ -54,23 +54,6 @@ inline uint64_t pool_grant_slack(int n_cu, uint64_t n_units, bool two_per_cu)
 }
 
 // z0 / z1 (nullable): up to two arrays of n0 / n1 dwords that the same launch clears
-// ---- the two-kernel pipeline for large batches with the 128-KiB filter (am_kernels.hip: k_filter / k_consume)
-constexpr uint32_t kCandBlockEntries = 256;      // candidate entries (u16) per block
-struct PipeView {
-    uint16_t* cands;              // u16[kCandBlock * n_cblocks]: offset of the candidate position in its unit
-    uint32_t* cblock_next;        // chain links
-    uint32_t* cctrl;              // [0] next free block, [1] overflow flag
-    uint32_t* cand_first;         // per unit: first block (kNone: none)
-    uint32_t* cand_count;         // per unit: candidates (bits 0-23) | blocks with consecutive ids from cand_first on (bits 24-31)
-    uint16_t* chunk_count;        // per 1-KiB chunk: candidates
-    uint32_t* unit_ticket;        // per slice: k_filter's unit counter (zeroed by the host)
-    uint32_t n_cblocks;
-    uint64_t unit0, unit1;        // the slice: units [unit0, unit1)
-};
-
-hipError_t launch_filter(bool ic, const SfView& s, const BatchView& b, const PipeView& pv, uint32_t unit_chunks, int n_cu, hipStream_t st);
-hipError_t launch_consume(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, const PipeView& pv, int n_cu, hipStream_t st);
-
 hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st, uint32_t* z0 = nullptr, uint64_t n0 = 0, uint32_t* z1 = nullptr, uint64_t n1 = 0);
 uint64_t sf_chunks(const BatchView& b);
 uint32_t sf_unit_chunks(const BatchView& b, int n_cu);

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "am_device.h"
+#include "am_wave.h"
 
 namespace am {
 namespace dev {
@@ -49,47 +50,6 @@ __global__ void k_hidx(const uint64_t* __restrict__ offsets, uint32_t n_hay, uin
     hidx[k] = lo;
 }
 
-// ------------------------------------------------------------------ wave helpers (wave64)
-
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-
-// inclusive prefix sum over the 64 lanes with DPP adds (no LDS round trips): Kogge-Stone inside each
-// 16-lane row (row_shr 1,2,4,8), then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x, uint32_t /*lane*/)
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
-    return x;
-}
-
-// a value that is the same in every lane, moved to scalar registers (the two v_readfirstlane also force any load that
-// produces it to be waited for right here)
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t x)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_down(x, d, 64);
-    return x;   // valid in lane 0
-}
-
-// order LDS traffic between lanes of one wavefront (DS ops of a wave execute in issue order;
-// this only stops the compiler from moving them)
-__device__ __forceinline__ void wave_lds_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 // ------------------------------------------------------------------ SF kernel
 
 constexpr int kSfThreads = 1024;                 // 16 waves: with a 128 KiB filter one workgroup owns the CU
@@ -107,21 +67,6 @@ constexpr uint32_t kSfMaxUnitChunks = 64;
 constexpr uint32_t kSfEpochChunks = 16;          // the ring is drained every 16 chunks, so that the chunk index fits the 4 bits an entry has for it
 constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
 constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table: first thing in LDS, the filter words follow
-
-// LDS by absolute byte address.  k_sf declares no static LDS, so its dynamic LDS starts at address 0; reading through an
-// address-space-3 pointer made from an integer lets the compiler put constant parts into the instruction's offset field
-// instead of adding the (relocatable, always zero) base of the extern array to every address (16 v_add per chunk).
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-typedef __attribute__((address_space(3))) uint16_t lds_u16_t;
-typedef uint32_t u32x2_n __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_n __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) u32x2_n lds_u32x2_t;
-typedef __attribute__((address_space(3))) u32x4_n lds_u32x4_t;
-__device__ __forceinline__ uint32_t lds_read_u32(uint32_t byte_addr) { return *reinterpret_cast<const lds_u32_t*>((uintptr_t)byte_addr); }
-__device__ __forceinline__ uint32_t lds_read_u16(uint32_t byte_addr) { return *reinterpret_cast<const lds_u16_t*>((uintptr_t)byte_addr); }
-__device__ __forceinline__ void lds_write_u16(uint32_t byte_addr, uint32_t v) { *reinterpret_cast<lds_u16_t*>((uintptr_t)byte_addr) = (uint16_t)v; }
-__device__ __forceinline__ void lds_write_u32x2(uint32_t byte_addr, uint2 v) { u32x2_n t; t.x = v.x; t.y = v.y; *reinterpret_cast<lds_u32x2_t*>((uintptr_t)byte_addr) = t; }
-__device__ __forceinline__ void lds_write_u32x4(uint32_t byte_addr, uint4 v) { u32x4_n t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *reinterpret_cast<lds_u32x4_t*>((uintptr_t)byte_addr) = t; }
 
 // ILP: unused since the probe always takes two candidates per lane (kept in the instantiation names).
 //
@@ -687,381 +632,6 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     }
 }
 
-// ------------------------------------------------------------------ the two-kernel pipeline for large batches (128-KiB filter)
-//
-// k_sf does everything in one wavefront: filter, compaction, probe, resolve.  Only the filter needs the 128-KiB LDS table that pins the
-// occupancy at four wavefronts per SIMD; the probe and the resolve are chains of dependent L2 / HBM trips that those four in-order
-// wavefronts cannot hide.  For large batches the work is therefore cut in two kernels that run AT THE SAME TIME on
-// two streams, slice by slice:
-//   k_filter   filter + compaction only; the candidate positions (u16 offsets in the work unit) go to per-unit chains of 256-entry
-//              blocks in HBM.  No staged chunk, no queues: 130 KiB of LDS, <= 64 VGPRs.
-//   k_consume  probe + resolve of the PREVIOUS slice's candidates: rounds of 128 candidates whatever the chunk boundaries (k_sf's rounds
-//              are per chunk and 65 % full), text bytes / buckets / candidate entries each requested one round ahead, the resolve as in
-//              k_sf.  No big LDS, <= 128 VGPRs: two of its wavefronts fit on every SIMD NEXT TO k_filter's four, so the CU's issue
-//              slots see six wavefronts, and the dependent trips of the one kind overlap with the arithmetic of the other.
-// A kernel boundary separates producer and consumer of a slice (no flags, no polling, no cross-XCD coherence games): slice i is consumed
-// while slice i + 1 is filtered.  Record output, ordering (per-unit chains, position order) and counts are exactly k_sf's.
-constexpr uint32_t kCandBlock = 256;             // candidate entries per block (512 B)
-constexpr uint32_t kCandGrant = 32;              // blocks a k_filter wavefront takes per atomic
-
-template <bool IC, int LW, bool SHORT>
-__global__ __launch_bounds__(kSfThreads) void k_filter(SfView s, BatchView b, PipeView pv, uint32_t UC, uint64_t n_chunks)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const uint32_t words = 1u << s.bloom_log2_words;
-    uint32_t* masks = lds;
-    uint32_t* bloom = lds + kBloomMasks;
-    for (uint32_t i = threadIdx.x; i < kBloomMasks; i += kSfThreads) masks[i] = bloom_mask_entry(i);
-    for (uint32_t i = threadIdx.x; i < words; i += kSfThreads) bloom[i] = s.bloom[i];
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t n_waves = (uint64_t)gridDim.x * kSfWaves;
-    const uint32_t log2_words = s.bloom_log2_words, tiers = s.tiers;
-    uint32_t grant_next = 0, grant_left = 0;
-    bool pool_ok = true;
-    auto fetch = [&](uint64_t cc, uint4& v) {
-        const uint64_t p = cc * kSfChunk + lane * 16u;
-        v = make_uint4(0, 0, 0, 0);
-        if (cc < n_chunks && p < b.total) {
-            typedef uint32_t u32x4_native __attribute__((ext_vector_type(4)));
-            const u32x4_native t = *reinterpret_cast<const u32x4_native*>(b.text + p);
-            v = make_uint4(t.x, t.y, t.z, t.w);
-        }
-    };
-    auto fetch_before = [&](uint64_t cc, uint32_t& c4) {          // the 4 (folded) bytes before chunk cc; uniform: one request for the wave
-        uint32_t t = 0;
-        if (cc < n_chunks && cc > 0) t = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t*>(b.text + cc * kSfChunk - 4));
-        c4 = IC ? fold_dword(t) : t;
-    };
-    uint64_t u = pv.unit0 + (uint64_t)blockIdx.x * kSfWaves + wave;
-    uint4 cur_v; uint32_t carry4;
-    fetch(u < pv.unit1 ? u * UC : n_chunks, cur_v);
-    fetch_before(u < pv.unit1 ? u * UC : n_chunks, carry4);
-    asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));      // waited for here, not together with the loop's first prefetch
-    uint64_t u_next = u;
-    for (; u < pv.unit1; u = u_next) {
-        u_next = u + n_waves;
-        if (pv.unit_ticket) {
-            uint32_t ticket = 0;
-            if (lane == 0) ticket = atomicAdd(pv.unit_ticket, 1u);
-            u_next = pv.unit0 + n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-        }
-        const uint64_t next_first = u_next < pv.unit1 ? u_next * UC : n_chunks;        // (n_chunks: nothing to prefetch)
-        const uint64_t unit_base_chunk = u * UC;
-        uint32_t unit_cands = 0, cur_block = kNone, first_block = kNone;
-        uint32_t contig = 0;                                     // blocks of this unit's chain with the ids first_block, first_block + 1, ...
-        grant_left = 0;                                          // every unit starts a grant of its own: the consumer computes the first ids instead of following the chain
-        const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
-        for (uint32_t ci = 0; ci < n_in_unit; ci++) {
-            const uint64_t c = unit_base_chunk + ci;
-            uint4 next_v;
-            uint32_t next_c4 = 0;
-            const bool last_of_unit = ci + 1 >= n_in_unit;
-            fetch(!last_of_unit ? c + 1 : next_first, next_v);
-            if (last_of_unit) fetch_before(next_first, next_c4);
-            const uint64_t p0 = c * kSfChunk + lane * 16u;
-            uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
-            if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
-            const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);      // the lane below's last dword (lane 0: the carry)
-            const uint32_t d[5] = {d0, d1, d2, d3, d4};
-            if (!last_of_unit) next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
-            uint32_t cand = 0;
-            {
-                uint32_t h[16], v[16], m[16];
-                const uint32_t sh_word = 32u - log2_words;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int j = k >> 2, sh = k & 3;
-                    const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
-                    h[k] = w * kBloomMul;
-                }
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    if (LW) v[k] = lds_read_u32(kSfMaskBytes + ((h[k] >> (30 - LW)) & (((1u << LW) - 1u) << 2)));
-                    else v[k] = lds_read_u32(kSfMaskBytes + ((h[k] >> sh_word) << 2));
-                    m[k] = lds_read_u32(h[k] & ((kBloomMasks - 1u) << 2));
-                }
-#pragma unroll
-                for (int k = 15; k >= 0; k--) cand = (cand << 1) | (uint32_t)((v[k] & m[k]) == m[k]);
-            }
-            if (SHORT) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int j = k >> 2, sh = k & 3;
-                    const uint32_t w = sh == 3 ? d[j + 1] : __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh + 1);
-                    if (sf_filter_short(bloom, log2_words, tiers, w, masks)) cand |= 1u << k;
-                }
-            }
-            if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
-            // ---- the candidates of the chunk go to the unit's chain, in position order
-            const uint32_t n = __popc(cand);
-            const uint32_t incl = wave_inclusive_sum(n, lane);
-            const uint32_t total = __shfl(incl, 63, 64);
-            if (lane == 0) pv.chunk_count[c] = (uint16_t)total;          // (<= 1024)
-            if (total) {
-                const uint32_t s0 = unit_cands, r = s0 & (kCandBlock - 1u);
-                const uint32_t n_new = ((s0 + total - 1u) / kCandBlock) - (s0 / kCandBlock) + (r ? 0u : 1u);      // <= 5: blocks with consecutive ids from ONE grant
-                const uint32_t old_block = cur_block;
-                uint32_t new_first = kNone;
-                if (n_new) {
-                    if (grant_left < n_new) {                    // what is left of the old grant is abandoned
-                        if (first_block != kNone) contig |= 0x80000000u;      // (the run of consecutive ids ends here)
-                        uint32_t g = 0;
-                        if (lane == 0) g = atomicAdd(pv.cctrl, kCandGrant);
-                        grant_next = __builtin_amdgcn_readfirstlane(g);
-                        grant_left = kCandGrant;
-                    }
-                    new_first = grant_next; grant_next += n_new; grant_left -= n_new;
-                    if (new_first + n_new > pv.n_cblocks) { pool_ok = false; if (lane == 0) pv.cctrl[1] = 1u; }     // keep counting; the host falls back to k_sf
-                    else {
-                        if (lane < n_new) pv.cblock_next[new_first + lane] = lane + 1u < n_new ? new_first + lane + 1u : kNone;
-                        if (lane == 0 && cur_block != kNone) pv.cblock_next[cur_block] = new_first;
-                        if (first_block == kNone) first_block = new_first;
-                        if (!(contig & 0x80000000u)) contig += n_new;
-                        cur_block = new_first + n_new - 1u;
-                    }
-                }
-                if (pool_ok) {
-                    uint32_t slot = s0 + incl - n;
-                    const uint32_t pos_base = (ci << 10) | (lane * 16u);
-                    while (cand) {
-                        const uint32_t k = __builtin_ctz(cand);
-                        cand &= cand - 1u;
-                        const uint32_t bi = slot / kCandBlock - s0 / kCandBlock;
-                        const uint32_t blk = (r && bi == 0u) ? old_block : new_first + bi - (r ? 1u : 0u);
-                        pv.cands[(uint64_t)blk * kCandBlock + (slot & (kCandBlock - 1u))] = (uint16_t)(pos_base + k);
-                        slot++;
-                    }
-                }
-                unit_cands = s0 + total;
-            }
-            cur_v = next_v; carry4 = next_c4;
-        }
-        contig &= 0x7FFFFFFFu;
-        if (lane == 0) { pv.cand_first[u] = first_block; pv.cand_count[u] = unit_cands | ((contig < 255u ? contig : 255u) << 24); }      // (unit_cands <= 65536)
-    }
-}
-
-// the consumer of one slice: wavefront w takes the units unit0 + w, unit0 + w + W, ...
-constexpr int kCsThreads = 256;
-constexpr uint32_t kCsRing = 256;               // per-wave ring of deferred candidates (u32: offset in the unit | agreeing slot << 16)
-template <bool IC, int MODE, bool SHORT>
-__global__ __launch_bounds__(kCsThreads) void k_consume(SfView s, BatchView b, ScanOut o, PipeView pv)
-{
-    __shared__ uint32_t ring_all[(kCsThreads / 64) * kCsRing];
-    if (pv.cctrl[1]) return;                                 // the candidate pool overflowed: the host repeats the scan with k_sf
-    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t* ring = ring_all + wave * kCsRing;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (kCsThreads / 64);
-    const uint64_t unit_bytes = (uint64_t)o.unit_chunks * kSfChunk;
-    uint64_t nval = 0;
-    uint32_t cnt_hay = kNone; uint64_t cnt_val = 0;          // count mode: running per-haystack sum of this wave
-    auto flush_count = [&]() {
-        if (cnt_hay != kNone && cnt_val && lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + cnt_hay), (unsigned long long)cnt_val);
-        cnt_val = 0;
-    };
-    auto add_counts = [&](bool found, uint32_t hay, uint32_t vlen) {
-        if (found) nval += vlen;
-        const uint64_t fm = __ballot(found);
-        if (!o.hay_counts || !fm) return;
-        const uint32_t h0 = __shfl(hay, __ffsll((unsigned long long)fm) - 1, 64);
-        if (__ballot(found && hay != h0) == 0) {
-            const uint64_t sum = wave_sum_u64(found ? (uint64_t)vlen : 0ull);
-            if (h0 != cnt_hay) { flush_count(); cnt_hay = h0; }
-            cnt_val += sum;
-        } else if (found) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)vlen);
-    };
-    uint32_t grant_next = 0, grant_left = 0;
-    bool pool_ok = true;
-
-    for (uint64_t u = pv.unit0 + (uint64_t)blockIdx.x * (kCsThreads / 64) + wave; u < pv.unit1; u += n_waves) {
-        const uint32_t cc_raw = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_count[u]);
-        const uint32_t n_cand = cc_raw & 0xFFFFFFu, contig = cc_raw >> 24;       // candidates; blocks of the chain with consecutive ids from cand_first on
-        uint32_t unit_count = 0, unit_slots = 0, cur_block = kNone, first_block = kNone;
-        uint32_t rg_head = 0, rg_tail = 0;
-        const uint64_t unit_pos = u * unit_bytes;
-        // the haystack that holds the unit's first byte (uniform; one lookup per unit): a position below its end needs no lookup of its own
-        if (!n_cand) {
-            if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = 0; o.unit_first[u] = kNone; o.unit_slots[u] = 0; }
-            continue;
-        }
-        const uint32_t first_cblock = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cand_first[u]);
-        const uint32_t hay_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)b.hidx[unit_pos >> kHidxShift]);
-        const uint64_t hs_u = uniform_u64(b.offsets[hay_u]), he_u = uniform_u64(b.offsets[hay_u + 1]);
-        // ---- phase 2 for the oldest nb (<= 64) deferred candidates of the ring, in lock step (as k_sf's resolve_batch, without a walker queue)
-        auto resolve_batch = [&](uint32_t nb) {
-            bool valid[1] = {lane < nb};
-            const uint32_t item = valid[0] ? ring[(rg_head + lane) % kCsRing] : 0u;
-            uint64_t gpos[1] = {unit_pos + (item & 0xFFFFu)};
-            const uint32_t hint[1] = {(item >> 16) & 3u};
-            const bool far = valid[0] && gpos[0] >= he_u;
-            uint32_t hlo = 0, hhi = 0;
-            if (far) { hlo = b.hidx[gpos[0] >> kHidxShift]; hhi = b.hidx[(gpos[0] >> kHidxShift) + 1]; }
-            uint64_t end_pos[1] = {0};
-            uint32_t hay = hay_u;
-            auto locate = [&]() {
-                // (the far start is a value of its own, not a second source of `start`: with one load on either side the compiler turns the
-                // two into a load through a selected POINTER, and the uniform hs_u then lives in scratch memory -- every read of it in the
-                // pipeline below would wait for all loads in flight)
-                uint64_t far_start = 0;
-                if (far) { hay = hlo; if (hlo != hhi) hay = find_haystack(b, gpos[0]); far_start = b.offsets[hay]; }
-                end_pos[0] = valid[0] ? gpos[0] - (far ? far_start : hs_u) + 1 : 0;
-            };
-            uint32_t w[1], w2[1], avail[1], best_state[1], best_vlen[1], depth[1], node[1], t16[1][4];
-            bool go[1], have_rec[1];
-            SfNode rec[1];
-            sf_resolve_head<IC, 1>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16);
-            sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, nullptr, 0xFFFFFFFFu, t16);
-            if (SHORT) sf_resolve_short<1>(s, valid, avail, w, best_state, best_vlen);
-            const bool found = valid[0] && best_state[0] != 0;
-            if (MODE == kModeCount) add_counts(found, hay, best_vlen[0]);
-            else if (MODE == kModeEmit) {
-                const uint64_t found_mask = __ballot(found);
-                const uint32_t F = (uint32_t)__popcll(found_mask);
-                if (F) {
-                    const uint32_t r = unit_slots & (kPoolBlock - 1u);
-                    const bool need_new = r == 0u || r + F > kPoolBlock;
-                    uint32_t new_block = kNone;
-                    if (need_new) {
-                        if (grant_left == 0) {
-                            uint32_t g = 0;
-                            if (lane == 0) g = atomicAdd(o.pool_ctrl, kSfBlockGrant);
-                            grant_next = __builtin_amdgcn_readfirstlane(g);
-                            grant_left = kSfBlockGrant;
-                        }
-                        const uint32_t id = grant_next++;
-                        grant_left--;
-                        if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }
-                        else {
-                            new_block = id;
-                            if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
-                            if (first_block == kNone) first_block = id;
-                        }
-                    }
-                    if (found && pool_ok) {
-                        const uint32_t p = r + (uint32_t)__popcll(found_mask & ((1ull << lane) - 1ull));
-                        const uint32_t slot = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
-                        uint4 rec4 = make_uint4((uint32_t)end_pos[0], (uint32_t)(end_pos[0] >> 32), hay, best_state[0] - 1u);
-                        reinterpret_cast<uint4*>(o.pool)[slot] = rec4;
-                    }
-                    if (need_new && pool_ok) cur_block = new_block;
-                    unit_slots += F; unit_count += F;
-                }
-            } else {
-                if (found) o.flags[hay] = 1;
-            }
-            rg_head += nb;
-        };
-
-        // ---- phase 1 over the unit's candidates, 128 per round (two per lane), whatever the chunk boundaries; eight rounds are in flight.
-        // Pass i of the loop
-        //   (1) decides round i - 7 (its two hot buckets were requested in pass i - 1),
-        //   (2) hashes round i - 6 (its haystack bytes were requested in pass i - 3) and requests its buckets,
-        //   (3) requests the haystack bytes of round i - 3 (its candidate entries were requested in pass i - 3),
-        //   (4) requests the candidate entries of round i.
-        // Loads retire in order, so waiting for what pass i - 3 requested leaves the requests of two whole passes in flight.  The stages'
-        // registers rotate by NAME (three copies of the pass, slot J = i mod 3): a register move of a pending load's target would wait for it.
-        const uint32_t n_rounds = (n_cand + 127u) / 128u;
-        uint32_t walk_j = contig ? contig - 1u : 0u, walk_id = first_cblock + walk_j;       // chain cursor for blocks beyond the contiguous run
-        auto block_of = [&](uint32_t j) -> uint32_t {
-            if (j < contig) return first_cblock + j;
-            while (walk_j < j) { walk_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)pv.cblock_next[walk_id]); walk_j++; }      // (waited for: rare)
-            return walk_id;
-        };
-        uint32_t E[3][2] = {{0, 0}, {0, 0}, {0, 0}};                         // candidate entries: offset in the unit | 0x10000 (valid)
-        uint32_t Tp[3][2] = {{0, 0}, {0, 0}, {0, 0}}; uint64_t Tr[3][2] = {{0, 0}, {0, 0}, {0, 0}};      // haystack bytes requested: the entry, the 8 bytes ending at it
-        u32x2 p_a[2], p_b[2]; uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};   // buckets requested
-        p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
-        // Every pass issues the same loads whatever the round's state -- lanes without a candidate read a harmless address (the compiler
-        // counts the loads in flight only along straight code: one load behind a branch and every wait becomes "all of them").
-        const uint32_t lb_hot = s.tier_log2_cap[3];
-        auto pass = [&](auto slot_c, const uint32_t i) __attribute__((always_inline)) {
-            constexpr int J = decltype(slot_c)::value;
-            // (1)
-            {
-                bool valid[2], defer[2]; uint32_t hint[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    valid[k] = (p_pos[k] & 0x10000u) != 0;
-                    if (!(p_pos[k] & 0x20000u)) { p_a[k] = u32x2{0, 0}; p_b[k] = p_a[k]; }      // no probe: empty buckets
-                }
-                sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint64_t m = __ballot(defer[k]);
-                    if (defer[k]) ring[(rg_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kCsRing] = (hint[k] << 16) | (p_pos[k] & 0xFFFFu);
-                    rg_tail += (uint32_t)__popcll(m);
-                }
-                wave_lds_fence();
-                while (rg_tail - rg_head >= 64u) {               // keeps room for the next round (<= 128 more)
-                    resolve_batch(64u); wave_lds_fence();
-                    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing of the resolve is in flight where the paths join again --
-                }                                                // else the compiler waits for "all loads" on the path that did not resolve, too
-            }
-            // (2)
-            {
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const bool valid = (Tp[J][k] & 0x10000u) != 0;
-                    const uint64_t gpos = unit_pos + (Tp[J][k] & 0xFFFFu);
-                    uint64_t v = Tr[J][k];
-                    const uint32_t drop = gpos >= 7 ? 0u : (uint32_t)(7 - gpos);
-                    v = drop ? (v << (8u * drop)) : v;                // byte gpos ends up on top; bytes before the buffer are zero
-                    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-                    if (IC) { lo = fold_dword(lo); hi = fold_dword(hi); }
-                    const uint32_t w = hi;                            // bytes gpos-3 .. gpos
-                    const uint32_t nb = (lo >> 24) | (((lo >> 16) & 0xFFu) << 8);   // the two before them, nearest in bits 0-7
-                    uint64_t avail = gpos - hs_u + 1;
-                    if (valid && gpos >= he_u) {                      // (rare: the unit's later haystacks)
-                        uint64_t start = b.offsets[find_haystack(b, gpos)];
-                        asm volatile("" : "+v"(start));               // waited for HERE: a wait after the branch would hold up the lanes that never asked
-                        avail = gpos - start + 1;
-                    }
-                    const bool probe = valid && avail >= 4;           // (the pipeline runs only for automata with needles of 4+ bytes)
-                    const uint32_t ha = t4_hash_a(w), hb = t4_hash_b(w);
-                    p_e[k] = t4_expect(t4_fingerprint(ha, lb_hot), nb & 0xFFFFu);
-                    const uint2 ra = *reinterpret_cast<const uint2*>(s.t4_hot + (probe ? t4_bucket(ha, lb_hot) : 0u));
-                    const uint2 rb = *reinterpret_cast<const uint2*>(s.t4_hot + (probe ? t4_bucket(hb, lb_hot) : 0u));
-                    p_a[k] = u32x2{ra.x, ra.y}; p_b[k] = u32x2{rb.x, rb.y};
-                    p_pos[k] = (Tp[J][k] & 0x1FFFFu) | (probe ? 0x20000u : 0u);
-                }
-            }
-            // (3)
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const uint32_t e = (i - 3u) * 128u + 64u * k + lane;           // (i < 3: far beyond n_cand)
-                const bool valid = i >= 3u && e < n_cand;
-                const uint64_t gpos = unit_pos + (E[J][k] & 0xFFFFu);
-                Tp[J][k] = valid ? (E[J][k] & 0xFFFFu) | 0x10000u : 0u;
-                typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
-                Tr[J][k] = *reinterpret_cast<const u64_unaligned*>(b.text + (valid && gpos >= 7 ? gpos - 7 : 0));
-            }
-            // (4)
-            {
-                const uint32_t r = i < n_rounds ? i : 0u;
-                const uint32_t blk = block_of(r >> 1);                // two rounds per block
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint32_t e = r * 128u + 64u * k + lane;
-                    E[J][k] = (uint32_t)pv.cands[(uint64_t)blk * kCandBlock + ((e < n_cand ? e : 0u) & (kCandBlock - 1u))];
-                }
-            }
-        };
-        for (uint32_t i = 0; i < n_rounds + 7u; i += 3u) {
-            pass(std::integral_constant<int, 0>{}, i);
-            pass(std::integral_constant<int, 1>{}, i + 1u);
-            pass(std::integral_constant<int, 2>{}, i + 2u);
-        }
-        while (rg_tail != rg_head) { const uint32_t left = rg_tail - rg_head; resolve_batch(left < 64u ? left : 64u); }
-        if (MODE == kModeEmit && lane == 0) { o.unit_counts[u] = unit_count; o.unit_first[u] = first_block; o.unit_slots[u] = unit_slots; }
-    }
-    if (MODE == kModeCount) {
-        if (o.hay_counts) flush_count();
-        nval = wave_sum_u64(nval);
-        if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
-    }
-}
-
 // copy every unit's chain of pool blocks to its final place (one wavefront per unit), dropping the slots that hold no record
 // (state == kNone: a parked walker that found no needle end)
 __global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __restrict__ unit_offsets, Record* __restrict__ out, uint64_t n_units)
@@ -1258,64 +828,6 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     if (mode == kModeCount) return launch_sf_t<false, kModeCount>(s, b, o, n_cu, st);
     if (mode == kModeEmit) return launch_sf_t<false, kModeEmit>(s, b, o, n_cu, st);
     return launch_sf_t<false, kModeAny>(s, b, o, n_cu, st);
-}
-
-// ---- the two-kernel pipeline (k_filter / k_consume)
-template <bool IC, bool SHORT>
-static hipError_t launch_filter_t(const SfView& s, const BatchView& b, const PipeView& pv, uint32_t unit_chunks, int n_cu, hipStream_t st)
-{
-    const size_t lds = kSfMaskBytes + ((size_t)4 << s.bloom_log2_words);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_filter<IC, 15, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) (void)hipGetLastError();
-        attr_set = true;
-    }
-    const uint64_t n_units = pv.unit1 - pv.unit0;
-    uint64_t blocks = (uint64_t)n_cu;
-    const uint64_t need = (n_units + kSfWaves - 1) / kSfWaves;
-    if (blocks > need) blocks = need;
-    if (blocks == 0) return hipSuccess;
-    PipeView p = pv;
-    if (n_units <= blocks * kSfWaves) p.unit_ticket = nullptr;          // one unit per wavefront at most: nothing to draw
-    hipLaunchKernelGGL((k_filter<IC, 15, SHORT>), dim3((uint32_t)blocks), dim3(kSfThreads), lds, st, s, b, p, unit_chunks, sf_chunks(b));
-    return hipGetLastError();
-}
-
-// k_filter over the units [pv.unit0, pv.unit1) (only for the 128-KiB filter: bloom_log2_words == 15); *pv.unit_ticket must be zero
-hipError_t launch_filter(bool ic, const SfView& s, const BatchView& b, const PipeView& pv, uint32_t unit_chunks, int n_cu, hipStream_t st)
-{
-    if (s.bloom_log2_words != 15) return hipErrorInvalidValue;
-    const bool sh = (s.tiers & 7u) != 0;
-    if (ic) return sh ? launch_filter_t<true, true>(s, b, pv, unit_chunks, n_cu, st) : launch_filter_t<true, false>(s, b, pv, unit_chunks, n_cu, st);
-    return sh ? launch_filter_t<false, true>(s, b, pv, unit_chunks, n_cu, st) : launch_filter_t<false, false>(s, b, pv, unit_chunks, n_cu, st);
-}
-
-constexpr int kCsWavesPerCu = 12;                // three per SIMD: what fits next to k_filter's four (56 VGPRs) with k_consume's <= 96
-
-template <bool IC, int MODE>
-static hipError_t launch_consume_t(const SfView& s, const BatchView& b, const ScanOut& o, const PipeView& pv, int n_cu, hipStream_t st)
-{
-    const uint64_t n_units = pv.unit1 - pv.unit0;
-    uint64_t waves = (uint64_t)n_cu * kCsWavesPerCu;
-    if (waves > n_units) waves = n_units;
-    const uint32_t blocks = (uint32_t)((waves + (kCsThreads / 64) - 1) / (kCsThreads / 64));
-    if (blocks == 0) return hipSuccess;
-    if (s.tiers & 7u) hipLaunchKernelGGL((k_consume<IC, MODE, true>), dim3(blocks), dim3(kCsThreads), 0, st, s, b, o, pv);
-    else hipLaunchKernelGGL((k_consume<IC, MODE, false>), dim3(blocks), dim3(kCsThreads), 0, st, s, b, o, pv);
-    return hipGetLastError();
-}
-
-// k_consume over the same units: probe + resolve of their candidates in `mode`
-hipError_t launch_consume(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, const PipeView& pv, int n_cu, hipStream_t st)
-{
-    if (ic) {
-        if (mode == kModeCount) return launch_consume_t<true, kModeCount>(s, b, o, pv, n_cu, st);
-        if (mode == kModeEmit) return launch_consume_t<true, kModeEmit>(s, b, o, pv, n_cu, st);
-        return launch_consume_t<true, kModeAny>(s, b, o, pv, n_cu, st);
-    }
-    if (mode == kModeCount) return launch_consume_t<false, kModeCount>(s, b, o, pv, n_cu, st);
-    if (mode == kModeEmit) return launch_consume_t<false, kModeEmit>(s, b, o, pv, n_cu, st);
-    return launch_consume_t<false, kModeAny>(s, b, o, pv, n_cu, st);
 }
 
 template <bool IC, int MODE>

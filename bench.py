@@ -213,19 +213,10 @@ def main():
         # (The general AC kernel runs a count launch and an emit launch per step: 8 B per record on average.)
         launches_n = max(int(launches.value), 1)
         per_step = launches_n / float(args.steps)
-        pipeline = None
         if kname == b"sf":
-            # the suffix-filter route: one k_sf launch per step -- or, for large batches with the 128-KiB filter, the two-kernel pipeline:
-            # per step one k_filter launch per 512-MiB slice ("sf") with k_consume (probe + resolve of the previous slice) running beside it on
-            # a second stream.  The dominant kernel's time per step = the sum of its launches; algorithmic bytes per step as before.
-            avg_ms = ms.value / float(args.steps)
+            # the suffix-filter route: one k_sf launch per step; algorithmic bytes per launch as above
+            avg_ms = ms.value / launches_n
             alg_bytes = n_bytes + 16.0 * n_records + 16.0 * n_hay
-            cms, cl = C.c_double(0), C.c_uint64(0)
-            am.api.check(lib.am_profile_read(b"consume", C.byref(cms), C.byref(cl)))
-            if cl.value:
-                pipeline = {"k_filter_launches_per_step": per_step, "k_filter_ms_per_step": round(avg_ms, 4), "k_consume_ms_per_step": round(cms.value / args.steps, 4),
-                            "what": "k_filter (filter + compaction -> candidate chains) on the caller's stream, k_consume (probe + resolve) of the previous slice on a "
-                                    "high-priority side stream at the same time; the two sums overlap, ms_per_step is the wall clock"}
         else:
             avg_ms = ms.value / launches_n
             alg_bytes = n_bytes + (16.0 / per_step) * n_records + 16.0 * n_hay
@@ -257,13 +248,11 @@ def main():
             "matches_per_s": round(total_matches * args.steps / elapsed, 1),
             "matches_per_step": total_matches, "records_per_step": total_records,
             "count_only_gibps": round(n_bytes / float(1 << 30) / count_only_s, 3),
-            "roofline": {"bound": "hbm", "kernel": ("k_filter" if pipeline else "k_" + kname.decode()), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_" + kname.decode(), "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes)},
             "collectives": "none (1 GPU)" if world == 1 else ("libam-rccl" if multi is not None else "torch"),
         }
-        if pipeline is not None:
-            out["pipeline"] = pipeline
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_h2d:
