@@ -610,6 +610,23 @@ class Splitter:
         return self.split_batch([text], True)[0]
 
 
+DEBUG_SWITCHES = ("AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SFX", "AM_NO_SMALL_RUN",
+                  "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
+                  "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE")
+
+
+def debug_set(name, value):
+    """A test / measurement switch of libam (csrc/am_config.h) by the name of its environment variable; -1 = unset.  No switch changes a result."""
+    fn = libam().am_debug_set
+    fn.restype, fn.argtypes = C.c_int, [C.c_char_p, C.c_long]
+    check(fn(name.encode(), int(value)))
+
+
+def debug_reset():
+    for name in DEBUG_SWITCHES:
+        debug_set(name, -1)
+
+
 def image_version():
     """kImageVersion of the flattened automaton image this build produces (am_image_version()), so that tools and bench.py can
     refuse measurements taken with another layout."""

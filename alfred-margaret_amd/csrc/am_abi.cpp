@@ -18,6 +18,7 @@
 #include <thread>
 #include <vector>
 
+#include "am_config.h"
 #include "am_device.h"
 #include "am_flatten.h"
 
@@ -855,13 +856,15 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
         o.hay_counts = (uint64_t*)b->hay_counts.p;
     }
     AM_TRY(build_hidx_and_clear(p, b, st, b->small.p, 64, counts_out ? b->hay_counts.p : nullptr, counts_out ? (size_t)b->n_hay * sizeof(uint64_t) : 0));
+    if (p.use_sf) o.pool_ctrl = (uint32_t*)b->small.p + 4;          // ([2]: the role-specialised kernel's watchdog reports here)
     AM_TRY(launch_scan_kernel(p, kModeCount, o, st));
-    uint64_t total = 0;
+    uint64_t head[4] = {0, 0, 0, 0};                                // total_values, -, {pool counter, overflow}, {watchdog, -}
     ResultCopies rc;
-    if (total_out) AM_TRY(rc.add(&total, b->small.p, 8, st));
+    AM_TRY(rc.add(head, b->small.p, 32, st));
     if (counts_out) AM_TRY(rc.add(counts_out, b->hay_counts.p, (size_t)b->n_hay * sizeof(uint64_t), st));
     AM_TRY(rc.finish(st));
-    if (total_out) *total_out = total;
+    if ((uint32_t)head[3] != 0) return fail(AM_ERR_HIP, "suffix-filter kernel: internal hand-over between its wavefronts timed out (watchdog)");
+    if (total_out) *total_out = head[0];
     return AM_OK;
 }
 
@@ -944,7 +947,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
         AM_TRY(b->unit_first.ensure(2 * p.n_units * sizeof(uint32_t)));          // first block + slot count per unit
         uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);
         if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
-        if (const char* env = std::getenv("AM_SF_POOL_BLOCKS")) { long v = std::atol(env); if (v > 0) want_blocks = (uint64_t)v; }   // tests: force the overflow/retry path
+        if (cfg::get(cfg::kSfPoolBlocks) > 0) want_blocks = (uint64_t)cfg::get(cfg::kSfPoolBlocks);   // tests: force the overflow/retry path
         for (int attempt = 0; attempt < 4; attempt++) {
             if (want_blocks >= (1ull << 26)) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call (2^32 record slots); split the batch");      // k_sf addresses record slots with 32 bits
             AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
@@ -1018,8 +1021,7 @@ static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, 
     if (b->total == 0 || b->total > kSmallRunBytes) return AM_OK;
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
     if (p.nothing || p.dense || !p.use_sf) return AM_OK;
-    static const bool off = std::getenv("AM_NO_SMALL_RUN") != nullptr;       // A/B
-    if (off) return AM_OK;
+    if (cfg::on(cfg::kNoSmallRun)) return AM_OK;                             // A/B
     std::lock_guard<std::mutex> lk(b->mu);
     ON_DEVICE(b->dev);
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
@@ -1033,7 +1035,7 @@ static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, 
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
     uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);
     if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
-    if (std::getenv("AM_SF_POOL_BLOCKS")) return AM_OK;                      // (tests of the overflow / retry path: the general path has it)
+    if (cfg::get(cfg::kSfPoolBlocks) > 0) return AM_OK;                      // (tests of the overflow / retry path: the general path has it)
     AM_TRY(b->pool.ensure(want_blocks * kPoolBlock * sizeof(Record)));
     AM_TRY(b->block_next.ensure(want_blocks * sizeof(uint32_t)));
     const size_t need = (size_t)b->total * sizeof(Record);
@@ -1287,6 +1289,20 @@ extern "C" int am_debug_sf_phase_cycles(uint64_t* out5)
 {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(read_sf_phase_cycles(out5));
+    return AM_OK;
+}
+
+// debug only: a test / measurement switch of am_config.h by the name of its environment variable ("AM_RP_FULL_SCANS", ...); value -1 = unset
+extern "C" int am_debug_set(const char* name, long value)
+{
+    if (!name || !cfg::set(name, value)) return fail(AM_ERR_INVALID, "no such switch");
+    return AM_OK;
+}
+
+extern "C" int am_debug_sfx_roles(uint64_t* out24)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(read_sfx_roles(out24));
     return AM_OK;
 }
 
@@ -1564,7 +1580,7 @@ static int rp_fold(RpSession& s, const am_replacer* r, bool ic, const uint8_t* t
     const uint64_t n1 = (uint64_t)n_act + 1;
     // one wavefront per haystack, or -- few haystacks with very many matches each -- parallel over the records
         bool par_fold = n_rec > 2048ull * n_act;
-        if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;        // tests force either path
+        if (cfg::get(cfg::kRpParallelFold) != cfg::kUnset) par_fold = cfg::get(cfg::kRpParallelFold) != 0;        // tests force either path
         if (!par_fold) {
             Prof pr("rp_pass", st);
             HIP_TRY(launch_rp_pass(ic, r->t, text, offs, recs, rec_first, thr,
@@ -1670,7 +1686,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.recbuf[0].ensure(n * sizeof(Record))); *ptr = (Record*)s.recbuf[0].p; return AM_OK; };
         AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &n_rec));
     }
-    const bool trace = std::getenv("AM_RP_TRACE") != nullptr;
+    const bool trace = cfg::on(cfg::kRpTrace);
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_a = 0, t_b = 0, t_c = 0, t_sync = 0;
     // finished haystacks of the previous pass: their bytes are on their way home on the copy stream; the host looks at the list after
@@ -1700,7 +1716,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         DevBuf& records = s.recbuf[cur_rec];
         const uint64_t n1 = (uint64_t)n_act + 1;
         // the record-parallel fold needs the exact count on the host: fetch it when that regime is possible
-        if (n_rec_dev && (n_rec > 2048ull * n_act || std::getenv("AM_RP_PARALLEL_FOLD"))) {
+        if (n_rec_dev && (n_rec > 2048ull * n_act || cfg::get(cfg::kRpParallelFold) != cfg::kUnset)) {
             HIP_TRY(hipMemcpyAsync(&s.tot_host[9], n_rec_dev, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             n_rec = s.tot_host[9]; n_rec_dev = nullptr;
@@ -1723,8 +1739,8 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         // the per-haystack fold also finds its record range and writes the piece / window counts (one dispatch instead of three in the pass's
         // chain); the record-parallel fold keeps the separate launches
         bool par_fold = (n_rec_dev ? 0 : n_rec) > 2048ull * n_act;
-        if (const char* env = std::getenv("AM_RP_PARALLEL_FOLD")) par_fold = std::atoi(env) != 0;
-        static const bool no_fuse = std::getenv("AM_RP_NO_FUSE") != nullptr;                      // A/B
+        if (cfg::get(cfg::kRpParallelFold) != cfg::kUnset) par_fold = cfg::get(cfg::kRpParallelFold) != 0;
+        const bool no_fuse = cfg::on(cfg::kRpNoFuse);                                             // A/B
         const bool fused = !par_fold && !no_fuse;
         if (fused) {
             Prof pr("rp_pass", st);
@@ -1780,7 +1796,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
                                  (const uint64_t*)s.pt_need_off.p + n_act, n_rec_dev, seq));
         const double t_s0 = now();
         {
-            static const bool no_spin = std::getenv("AM_RP_NO_SPIN") != nullptr;          // A/B
+            const bool no_spin = cfg::on(cfg::kRpNoSpin);                                 // A/B
             bool seen = false;
             if (!no_spin) {
                 const double give_up = t_s0 + 2e-3;
@@ -1820,7 +1836,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             // the finished texts are written out on the COPY stream (64 us of a 270-us pass that nothing of the next pass waits for): it starts when
             // this pass's piece lists and metadata are complete; what it reads is not touched before the next pass's host-side look at the copy
             // stream (finished_home, after the totals) -- and the next rp_route waits for the event as well
-            static const bool mat_main = std::getenv("AM_RP_MAT_MAIN") != nullptr;       // A/B: on the pass's own stream, as before
+            const bool mat_main = cfg::on(cfg::kRpMatMain);                              // A/B: on the pass's own stream, as before
             hipStream_t mst = mat_main ? st : s.copy_stream;
             if (!mat_main) { HIP_TRY(hipEventRecord(s.ev_spliced, st)); HIP_TRY(hipStreamWaitEvent(s.copy_stream, s.ev_spliced, 0)); }
             { Prof pr("pt_materialise", mst);
@@ -1893,11 +1909,11 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
             }
         }
         t_c += now() - t0;
-        if (trace && std::getenv("AM_RP_TRACE")[0] == '2')
+        if (trace && cfg::get(cfg::kRpTrace) == 2)
             std::fprintf(stderr, "[am_replacer pt pass %u] active %u -> %llu, finished %llu, records <= %llu, windows %llu (%llu B), next text %llu B\n", (unsigned)res->passes, n_act,
                          (unsigned long long)n_next, (unsigned long long)n_fin, (unsigned long long)n_rec, (unsigned long long)n_win, (unsigned long long)total_w, (unsigned long long)total_next);
         cur_rec ^= 1; cur_pt ^= 1; n_rec = next_n_rec; n_rec_dev = next_n_rec_dev;
-        static const bool no_reuse = std::getenv("AM_RP_NO_RANGE_REUSE") != nullptr;      // A/B
+        const bool no_reuse = cfg::on(cfg::kRpNoRangeReuse);                              // A/B
         have_ranges = next_have_ranges && !no_reuse; cur_rf ^= 1;
         cur_offs = (const uint64_t*)s.offs[nxt].p; cur_orig = (const uint32_t*)s.orig[nxt].p; cur_thr = (const int64_t*)s.thr[nxt].p;
         n_act = (uint32_t)n_next; nxt ^= 1;
@@ -1924,7 +1940,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         // cuts every text into 16-KiB tiles.  One 1-MB document with half a million replacements per pass: 472 ms vs 90 ms (measured).
         const bool many_documents = n_hay >= 64 && in->total / n_hay <= (1ull << 20);
         const bool pt = r->case_mode == AM_CASE_SENSITIVE && fl->h.sf_enabled && fl->h.root_vlen == 0 && r->a->kernel_pref != 1 &&
-                        std::getenv("AM_RP_FULL_SCANS") == nullptr && std::getenv("AM_RP_SPLICE") == nullptr && (many_documents || std::getenv("AM_RP_PIECES") != nullptr) &&
+                        !cfg::on(cfg::kRpFullScans) && !cfg::on(cfg::kRpSplice) && (many_documents || cfg::on(cfg::kRpPieces)) &&
                         n_hay < (1u << 24) && in->total < (1ull << 40);        // RpWin::src_abs packs (haystack index << 40 | start): beyond that the splicing loop runs
         if (pt) return replacer_run_pt(r, in, max_length, res, fl);
     }
@@ -1985,12 +2001,12 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
     const Flavor* flavor = nullptr;
     AM_TRY(prepare(r->a, r->case_mode, &flavor));
     const uint32_t ov = 4u * (flavor->h.max_needle_cps ? flavor->h.max_needle_cps : 1u) + 4u;
-    const bool inc_enabled = flavor->h.sf_enabled && flavor->h.root_vlen == 0 && r->a->kernel_pref != 1 && std::getenv("AM_RP_FULL_SCANS") == nullptr;
+    const bool inc_enabled = flavor->h.sf_enabled && flavor->h.root_vlen == 0 && r->a->kernel_pref != 1 && !cfg::on(cfg::kRpFullScans);
     bool have_inc = false;
     uint64_t inc_n_rec = 0;
     int cur_rec = 0;
     // AM_RP_TRACE=1: wall-clock split of the loop on stderr (development aid)
-    const bool trace = std::getenv("AM_RP_TRACE") != nullptr;
+    const bool trace = cfg::on(cfg::kRpTrace);
     double t_scan = 0, t_fold = 0, t_splice = 0, t_home = 0;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     struct Report { bool on; double &a, &b, &c, &d; ~Report() { if (on) std::fprintf(stderr, "[am_replacer] scan %.1f ms, fold+scans %.1f ms, splice+D2H %.1f ms, scatter %.1f ms\n", a * 1e3, b * 1e3, c * 1e3, d * 1e3); } } report{trace, t_scan, t_fold, t_splice, t_home};
@@ -2172,7 +2188,7 @@ static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_
     const uint32_t n_hay = in->n_hay;
     uint32_t groups = n_hay / 2048u;
     if (groups > 2) groups = 2;        // measured on config 5: 1 -> 82 ms, 2 -> 54 ms, 4 -> 77 ms, 8 -> 109 ms (the groups' kernels start to queue behind each other)
-    if (const char* env = std::getenv("AM_RP_GROUPS")) { const int v = std::atoi(env); if (v >= 1 && v <= 16) groups = (uint32_t)v; }
+    { const long v = cfg::get(cfg::kRpGroups); if (v >= 1 && v <= 16) groups = (uint32_t)v; }
     if (groups < 2 || n_hay < groups) return replacer_run(r, in, max_length, res);
     ON_DEVICE(in->dev);
     std::vector<uint64_t> offs((size_t)n_hay + 1);

@@ -1,0 +1,60 @@
+// am_config.h -- the library's test / measurement switches in ONE place.  None of them changes a result; they select between
+// equivalent code paths (A/B measurements, tests that force a rarely taken path).  Every switch is read from its environment
+// variable ONCE, when the library first looks at any of them, and can be set afterwards with am_debug_set(name, value) (exported for
+// the tests, not part of include/am.h).  A read is one relaxed atomic load: no getenv on any call path.
+#pragma once
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace am {
+namespace cfg {
+
+enum Key {
+    kSfAblate,            // AM_SF_ABLATE: debug instantiation of k_sf / k_sfx (1, 4, 5, 11: parts switched off; 9: per-phase / per-role cycle sums)
+    kSfPoolBlocks,        // AM_SF_POOL_BLOCKS: size of the record-block pool of the first attempt (tests force overflow + retry)
+    kSfWq,                // AM_SF_WQ: walker-queue entries per wavefront (0: none)
+    kSfWqIters,           // AM_SF_WQ_ITERS: trie steps a resolve batch takes before it parks
+    kSfMaxBloomLog2Words, // AM_SF_MAX_BLOOM_LOG2_WORDS: cap on the LDS filter size (tests: dense filters)
+    kSfx,                 // AM_SFX: 0 = never the role-specialised kernel, 1 = whenever the automaton allows it (tests), unset = by batch size
+    kNoSmallRun,          // AM_NO_SMALL_RUN: am_run on small batches takes the general path
+    kRpFullScans, kRpSplice, kRpPieces, kRpParallelFold, kRpGroups, kRpNoFuse, kRpNoSpin, kRpMatMain, kRpNoRangeReuse, kRpTrace,
+    kCount
+};
+
+struct Table {
+    std::atomic<long> v[kCount];
+    std::once_flag once;
+};
+inline Table& table() { static Table t; return t; }
+inline const char* name_of(int k)
+{
+    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SFX", "AM_NO_SMALL_RUN",
+                                              "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
+                                              "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE"};
+    return names[k];
+}
+constexpr long kUnset = -1;
+inline void init()
+{
+    Table& t = table();
+    std::call_once(t.once, [&t] {
+        for (int k = 0; k < kCount; k++) {
+            const char* e = std::getenv(name_of(k));
+            t.v[k].store(e ? (*e ? std::atol(e) : 1L) : kUnset, std::memory_order_relaxed);
+        }
+    });
+}
+// the switch's value, or kUnset (-1)
+inline long get(Key k) { init(); return table().v[k].load(std::memory_order_relaxed); }
+inline bool on(Key k) { const long v = get(k); return v != kUnset && v != 0; }
+inline bool set(const char* name, long value)
+{
+    init();
+    for (int k = 0; k < kCount; k++) if (std::strcmp(name, name_of(k)) == 0) { table().v[k].store(value, std::memory_order_relaxed); return true; }
+    return false;
+}
+
+}  // namespace cfg
+}  // namespace am

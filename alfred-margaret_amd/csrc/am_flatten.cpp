@@ -5,6 +5,8 @@
 // value order; nothing here changes what a match means.
 #include "am_flatten.h"
 
+#include "am_config.h"
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -496,7 +498,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     {
         uint32_t lw = log2_ceil((total_keys * 16 + 31) / 32);
         uint32_t max_lw = 15;                                  // 128 KiB of the CU's 160 KiB LDS
-        if (const char* env = std::getenv("AM_SF_MAX_BLOOM_LOG2_WORDS")) { int v = std::atoi(env); if (v >= 8 && v <= 15) max_lw = (uint32_t)v; }
+        { const long v = cfg::get(cfg::kSfMaxBloomLog2Words); if (v >= 8 && v <= 15) max_lw = (uint32_t)v; }
         lw = std::max(8u, std::min(max_lw, lw));
         h.sf_bloom_log2_words = lw;
         std::vector<uint32_t> bloom((size_t)1 << lw, 0);

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "am_config.h"
 #include "am_device.h"
 #include "am_wave.h"
 
@@ -734,7 +735,7 @@ static size_t sf_lds_bytes_w(const SfView& s, int waves) { return kSfMaskBytes +
 // walker-queue entries per wavefront that fit next to the rest (0 when fewer than 64 would: the queue must take a whole batch)
 static uint32_t sf_wq_cap(const SfView& s, int waves)
 {
-    static const long forced = [] { const char* e = std::getenv("AM_SF_WQ"); return e ? std::atol(e) : -1L; }();      // A/B: 0 = no queue
+    const long forced = cfg::get(cfg::kSfWq);      // A/B: 0 = no queue
     const size_t base = sf_lds_bytes_w(s, waves), limit = 160 * 1024;
     if (base >= limit) return 0;
     size_t cap = (limit - base) / ((size_t)waves * 64);
@@ -766,7 +767,8 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     if (blocks == 0) return hipSuccess;
     ScanOut oo = o;
     oo.wq_cap = wq_cap;
-    static const uint32_t wq_iters = [] { const char* e = std::getenv("AM_SF_WQ_ITERS"); const int v = e ? std::atoi(e) : 0; return v >= 1 && v <= 16 ? (uint32_t)v : 2u; }();   // A/B: steps a batch walks before it parks
+    const long wqi = cfg::get(cfg::kSfWqIters);
+    const uint32_t wq_iters = wqi >= 1 && wqi <= 16 ? (uint32_t)wqi : 2u;   // A/B: steps a batch walks before it parks
     oo.wq_iters = wq_iters;
     if (n_units <= blocks * waves_per_wg) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
     // (else: *next_unit is zero -- it lives in the batch's 64-byte counter block, which every caller clears before the launch together with
@@ -782,6 +784,16 @@ hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves)
     if (!g_sf_dbg) return hipErrorInvalidValue;
     if (n_waves == 0) { hipError_t e = hipMemcpy(out, g_sf_dbg + 16 + 2 * 8192, 64, hipMemcpyDeviceToHost); if (e == hipSuccess) e = hipMemset(g_sf_dbg + 16 + 2 * 8192, 0, 64); return e; }
     return hipMemcpy(out, g_sf_dbg + 16, 16 * (n_waves < 8192 ? n_waves : 8192), hipMemcpyDeviceToHost);
+}
+
+// debug: per-role cycle sums and event counts of k_sfx launches run with AM_SF_ABLATE=9 (F: 0-4, P: 8-14, R: 16-21; am_sfx.hip)
+hipError_t read_sfx_roles(uint64_t* out24)
+{
+    for (int i = 0; i < 24; i++) out24[i] = 0;
+    if (!g_sf_dbg) return hipSuccess;
+    hipError_t e = hipMemcpy(out24, g_sf_dbg + 32, 24 * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemset(g_sf_dbg + 32, 0, 24 * 8);
+    return e;
 }
 
 hipError_t read_sf_phase_cycles(uint64_t* out5)
@@ -812,13 +824,19 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o_in, int n_cu, hipStream_t st)
 {
     ScanOut o = o_in;
-    static const uint32_t ablate = [] { const char* e = std::getenv("AM_SF_ABLATE"); return e ? (uint32_t)std::atoi(e) : 0u; }();
+    const uint32_t ablate = cfg::get(cfg::kSfAblate) > 0 ? (uint32_t)cfg::get(cfg::kSfAblate) : 0u;
     o.ablate = ablate;
     static uint64_t* dbg = nullptr;
     if (ablate >= 8) {
         if (!dbg) { if (hipMalloc((void**)&dbg, 256 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 256 + 16 * 8192); }
         o.dbg = dbg;
         g_sf_dbg = dbg;
+    }
+    // the role-specialised kernel (am_sfx.hip) for large scans with the 128-KiB filter; AM_SFX = 0 never, 1 whenever the automaton allows it
+    {
+        const long sfx = cfg::get(cfg::kSfx);
+        const bool plain = ablate == 0 || ablate == 9;
+        if (plain && sfx != 0 && sfx_eligible(s, b, o, mode, n_cu, sfx == 1)) return launch_sfx(ic, mode, s, b, o, n_cu, st);
     }
     if (ic) {
         if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);

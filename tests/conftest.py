@@ -20,3 +20,12 @@ def golden():
 
 
 CASES = {"CaseSensitive": 0, "IgnoreCase": 1}
+
+
+@pytest.fixture(autouse=True)
+def _reset_debug_switches():
+    """Tests flip libam's test / measurement switches with am.debug_set (csrc/am_config.h); none may leak into the next test."""
+    yield
+    import alfred_margaret_amd as am
+    if am.api._libam is not None:
+        am.debug_reset()

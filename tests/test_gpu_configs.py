@@ -110,7 +110,7 @@ def test_cfg5_replacer_reduced(monkeypatch, full_scans):
     host = synth.haystacks_host([p[0] for p in pairs], w["mixed"], 0, n_hay * hb // synth.CELL)
     hays = [bytes(host[i * hb:(i + 1) * hb]) for i in range(n_hay)] + [b"", bytes(host[:100])]
     if full_scans:
-        monkeypatch.setenv("AM_RP_FULL_SCANS", "1")
+        am.debug_set("AM_RP_FULL_SCANS", 1)
     r = am.Replacer(w["case"], pairs)
     got = r.run_batch(hays)
     passes, scanned = r.last_stats()

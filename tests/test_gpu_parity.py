@@ -140,9 +140,9 @@ def test_one_document_run_has_the_records_with_the_count():
 
 def test_record_pool_overflow_retry(monkeypatch):
     # the single-pass emit guesses its record pool; force a 1-block pool so the retry path runs
-    monkeypatch.setenv("AM_SF_POOL_BLOCKS", "1")
+    am.debug_set("AM_SF_POOL_BLOCKS", 1)
     check_all_paths(["a", "aa", "aaa", "ab"], ["a" * 3000 + "b" + "a" * 500, "ab" * 700, "", "a"], 0)
-    monkeypatch.delenv("AM_SF_POOL_BLOCKS")
+    am.debug_set("AM_SF_POOL_BLOCKS", -1)
     check_all_paths(["a", "aa", "aaa", "ab"], ["a" * 3000 + "b" + "a" * 500, "ab" * 700, "", "a"], 0)
 
 
@@ -377,15 +377,15 @@ def test_replacer_incremental_rescan_equals_full_scans(monkeypatch):
         r = am.Replacer(case, pairs)
         inc = r.run_batch(hays)
         inc_stats = r.last_stats()
-        monkeypatch.setenv("AM_RP_FULL_SCANS", "1")
+        am.debug_set("AM_RP_FULL_SCANS", 1)
         full = r.run_batch(hays)
         full_stats = r.last_stats()
-        monkeypatch.delenv("AM_RP_FULL_SCANS")
+        am.debug_set("AM_RP_FULL_SCANS", -1)
         assert inc == full, (case, pairs[:5])
         assert inc_stats[0] == full_stats[0] and inc_stats[1] <= full_stats[1]
-        monkeypatch.setenv("AM_RP_PIECES", "1")             # small batches take the splicing loop by default: the piece-table loop on the same inputs
+        am.debug_set("AM_RP_PIECES", 1)             # small batches take the splicing loop by default: the piece-table loop on the same inputs
         assert r.run_batch(hays) == inc
-        monkeypatch.delenv("AM_RP_PIECES")
+        am.debug_set("AM_RP_PIECES", -1)
         o = oracle.Replacer(case, pairs)
         assert inc == [o.run(h) for h in hays]
 
@@ -429,7 +429,7 @@ def test_replacer_concurrent_haystack_groups(monkeypatch, groups):
     pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(2, 4))), "".join(rng.choice("AB" + alpha) for _ in range(rng.randint(0, 6))))
              for _ in range(40)]
     hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 1, 7, 15, 16, 17, 100, 900, 4000)))) for _ in range(157)]
-    monkeypatch.setenv("AM_RP_GROUPS", groups)
+    am.debug_set("AM_RP_GROUPS", int(groups))
     for case in (0, 1):
         r, o = am.Replacer(case, pairs), oracle.Replacer(case, pairs)
         assert r.run_batch(hays) == [o.run(h) for h in hays]
@@ -707,12 +707,12 @@ def test_replacer_record_parallel_fold(monkeypatch):
             exp = [o.run(h, max_len) for h in hays]
             r = am.Replacer(case, pairs)
             for forced in ("1", "0"):
-                monkeypatch.setenv("AM_RP_PARALLEL_FOLD", forced)
+                am.debug_set("AM_RP_PARALLEL_FOLD", int(forced))
                 assert r.run_batch(hays, max_len) == exp, (forced, case, pairs[:4], max_len)
-                monkeypatch.setenv("AM_RP_PIECES", "1")     # and with the texts kept as piece tables (the default only for batches of >= 64 documents)
+                am.debug_set("AM_RP_PIECES", 1)     # and with the texts kept as piece tables (the default only for batches of >= 64 documents)
                 assert r.run_batch(hays, max_len) == exp, (forced, "pieces", case, pairs[:4], max_len)
-                monkeypatch.delenv("AM_RP_PIECES")
-            monkeypatch.delenv("AM_RP_PARALLEL_FOLD")
+                am.debug_set("AM_RP_PIECES", -1)
+            am.debug_set("AM_RP_PARALLEL_FOLD", -1)
     # natural trigger: one document with > 2048 matches per pass
     big = ("short tshirts and sweatshirts " * 4000)
     pairs = [("tshirt", "T"), ("shirts", "S"), ("short", "long"), ("and", "&")]
