@@ -2,23 +2,27 @@
 //
 // k_sf (am_kernels.hip) runs filter, compaction, probe and resolve in every wavefront.  Only the filter needs the 128-KiB LDS table
 // that pins the occupancy at one 1024-thread workgroup per CU = four in-order wavefronts per SIMD, and those four cannot hide the
-// probe's L2 round trips and the resolve's dependent HBM trips.  k_sfx keeps the SAME LDS filter, tables, record
-// format and unit bookkeeping but gives each of the workgroup's 16 wavefronts one job:
+// probe's L2 round trips.  k_sfx keeps the SAME LDS filter, tables, record format and unit bookkeeping but
+// splits the workgroup's 16 wavefronts into two roles:
 //
 //   F  12 wavefronts   stream the haystack (one coalesced 16-B load per lane and KiB), fold, filter against the LDS Bloom filter, compact
 //                      the surviving positions and push (4-byte window, the two bytes before it, offset in the unit) entries into a ring
-//                      in LDS.  No table access, no memory wait but the prefetched stream.
-//   P   3 wavefronts   each serves four F rings: pop <= 64 entries, hash, request both hot cuckoo buckets, and look at them kProbeDepth
-//                      passes later (the requests of kProbeDepth rounds stay in flight: registers rotate by name, the compiler counts
-//                      vmcnt statically); survivors go to the P's ring of deferred positions.
-//   R   1 wavefront    pops deferred positions of all three P rings, <= 128 at a time (two per lane in lock step), resolves them exactly
-//                      (sf_resolve_head / _walk of am_image.h: haystack bytes -> slot line -> trie) and owns ALL record output: per F it
-//                      keeps the current unit's chain of pool blocks; a unit-end marker that travels behind the unit's last deferred
-//                      position closes the unit (unit_counts / unit_first / unit_slots exactly as k_sf writes them).
+//                      in LDS -- no table access, no wait but for the prefetched stream.  The positions their P sends back ("a needle
+//                      may end here") they resolve themselves, 64 at a time, exactly as k_sf does (sf_resolve_head / _walk of am_image.h:
+//                      haystack bytes -> slot line -> trie), and write the records of their own units (block chains, unit_counts /
+//                      unit_first / unit_slots as k_sf writes them).
+//   P   4 wavefronts   one per SIMD; each serves three F rings: pop <= 64 entries, hash, request both hot cuckoo buckets, and look at
+//                      them kProbeDepth passes later -- the requests of kProbeDepth rounds stay in flight (registers rotate by name, the
+//                      compiler counts vmcnt statically: vmcnt(2 * kProbeDepth - 1)).  Survivors go back to their F's ring of deferred
+//                      positions; a unit-end marker follows a unit's last survivor.
 //
-// Every SIMD then holds three wavefronts that never wait for memory next to one that always does.  Hand-over is single-producer /
-// single-consumer everywhere (F -> its P, P -> R, R -> F for unit-slot recycling), so nobody waits in a cycle: R waits for nobody.
-// All waits are bounded (watchdog): a hand-over that does not move sets pool_ctrl[2] and every wavefront leaves.
+// (First version, measured: 12 F + 3 P + ONE resolver wavefront that owned all output -- bit-exact, and 2.3 x slower than k_sf: a
+// resolve batch is a chain of dependent trips, ~35k cycles for 104 positions, and one wavefront per CU cannot take 40 positions per
+// chunk time; the three Ps waited for it half of their time.  profiles/history/r04_sfx_v1_roles.log.)
+//
+// Hand-over is single-producer / single-consumer (F -> its P: candidate ring; P -> that F: deferred ring).  An F that waits for ring
+// room serves its deferred ring meanwhile, so the two directions cannot block each other.  All waits are bounded (watchdog): a
+// hand-over that does not move sets pool_ctrl[2] and every wavefront leaves.
 //
 // Used for the 128-KiB filter (large automata), needles of >= 4 bytes only, count and emit mode, batches large enough to fill the chip;
 // everything else stays with k_sf.  Semantics: Automaton.hs:442-534 as for k_sf (one record per end position, position order per unit).
@@ -36,33 +40,31 @@ namespace dev {
 namespace {
 
 constexpr int kXThreads = 1024;
-constexpr int kXF = 12, kXP = 3, kXFperP = 4;         // wavefronts 0..11 filter, 12..14 probe, 15 resolves
-static_assert(kXF == kXP * kXFperP && kXF + kXP + 1 == kXThreads / 64, "role split");
+constexpr int kXF = 12, kXP = 4, kXFperP = 3;         // wavefronts 0..11 filter (+ resolve), 12..15 probe
+static_assert(kXF == kXP * kXFperP && kXF + kXP == kXThreads / 64, "role split");
 constexpr int kProbeDepth = 4;                         // probe rounds whose bucket requests are in flight per P wavefront
-constexpr int kRN = 2;                                 // deferred positions per lane in one resolve batch
 
 constexpr uint32_t kXMaskBytes = kBloomMasks * 4u;
 constexpr uint32_t kXBloomBytes = 4u << 15;            // the 128-KiB filter only
 constexpr uint32_t kXStage = 1056;                     // per F: copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
-constexpr uint32_t kXQ1 = 128;                         // per F: candidate offsets of one sub-pass (u16)
-constexpr uint32_t kXRing = 128;                       // per F: entries {window, nb << 16 | offset in the unit} (8 B)
-constexpr uint32_t kXUq = 4;                           // per F: unit slots {unit id, end_T}
-constexpr uint32_t kXFCtrl = 16 + kXUq * 8;            // tail, head (by P), uq_r (units retired, by R), uq_w (units announced), slots
-constexpr uint32_t kXFBytes = kXStage + kXQ1 * 2 + kXRing * 8 + kXFCtrl;
-constexpr uint32_t kXQ2 = 128;                         // per P: deferred positions / markers (u32)
-constexpr uint32_t kXPBytes = kXQ2 * 4 + 16;           // ring + {tail, head (by R)}
-constexpr uint32_t kXRState = 16;                      // per F, owned by R: unit_slots, unit_count, cur_block, first_block
+constexpr uint32_t kXQ1 = 64;                          // per F: candidate offsets of one sub-pass (u16)
+constexpr uint32_t kXRing = 128;                       // per F: entries {window, nb << 16 | offset in the unit} (8 B), F -> P
+constexpr uint32_t kXQ2 = 64;                          // per F: deferred positions / unit-end markers (u32), P -> F
+constexpr uint32_t kXUq = 4;                           // units an F may have open or unfinished at a time
+// per-F block: stage | q1 | ring | q2 | control
+constexpr uint32_t kXOffQ1 = kXStage, kXOffRing = kXOffQ1 + kXQ1 * 2, kXOffQ2 = kXOffRing + kXRing * 8, kXOffCtrl = kXOffQ2 + kXQ2 * 4;
+// control: +0 W0 = {tail, units closed | done << 31} (8 B, ONE store, by F)   +8 ring head (by P)   +12 q2 tail (by P)   +16 q2 head (by F)
+//          +32 end_T[kXUq] (by F)   +48 unit ids of the unfinished units [kXUq] (F's own)
+constexpr uint32_t kXFBytes = kXOffCtrl + 64;
 constexpr uint32_t kXBase = kXMaskBytes + kXBloomBytes;
-constexpr uint32_t kXPBase = kXBase + kXF * kXFBytes;
-constexpr uint32_t kXRBase = kXPBase + kXP * kXPBytes;
-constexpr uint32_t kXAbort = kXRBase + kXF * kXRState; // one word: somebody's wait timed out
+constexpr uint32_t kXAbort = kXBase + kXF * kXFBytes;  // one word: somebody's wait timed out
 constexpr uint32_t kXLdsBytes = kXAbort + 16;
 static_assert(kXLdsBytes <= 160 * 1024, "k_sfx LDS budget");
+static_assert((kXOffCtrl & 7u) == 0 && (kXFBytes & 15u) == 0, "alignment of the control words");
 
-constexpr uint32_t kUnitOpen = 0xFFFFFFFFu;            // end_T of a unit that is still being filtered
-constexpr uint32_t kUnitEmpty = 0xFFFFFFFEu;           // unit id of a free slot
-constexpr uint32_t kUnitDone = 0xFFFFFFFDu;            // unit id: this F has no more units
-constexpr uint32_t kQ2Mark = 1u << 31, kQ2PDone = 1u << 30;      // q2 entry: unit-end marker of F (bits 20-23) / this P is done; else F << 20 | hint << 16 | offset
+constexpr uint32_t kDoneBit = 1u << 31;
+constexpr uint32_t kQ2Mark = 1u << 31;                 // q2 entry: end of the F's oldest unfinished unit; else hint << 16 | offset in the unit
+constexpr uint32_t kServe = 40;                        // an F resolves its deferred positions when this many wait (or a wait forces it)
 constexpr uint32_t kSpinLimit = 1u << 21;
 
 // Ordering between the wavefronts of the workgroup concerns LDS only: a wavefront's DS operations execute in issue order, so "everything
@@ -74,24 +76,145 @@ __device__ __forceinline__ void lds_fence()
     __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0), vmcnt and expcnt untouched
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ uint32_t lds_ld_acq(uint32_t byte_addr)
-{
-    const uint32_t v = __hip_atomic_load(reinterpret_cast<lds_u32_t*>((uintptr_t)byte_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    lds_fence();
-    return r;
-}
 __device__ __forceinline__ uint32_t lds_ld(uint32_t byte_addr)
 {
     return __hip_atomic_load(reinterpret_cast<lds_u32_t*>((uintptr_t)byte_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ uint32_t lds_ld_acq(uint32_t byte_addr)      // uniform address -> scalar value, later LDS reads see what was published before it
+{
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ld(byte_addr));
+    lds_fence();
+    return r;
+}
+typedef __attribute__((address_space(3))) uint64_t lds_u64_t;
+__device__ __forceinline__ uint64_t lds_ld64(uint32_t byte_addr)
+{
+    return __hip_atomic_load(reinterpret_cast<lds_u64_t*>((uintptr_t)byte_addr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(uint32_t byte_addr, uint32_t v) { __hip_atomic_store(reinterpret_cast<lds_u32_t*>((uintptr_t)byte_addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // lane 0 publishes a control word after everything this wavefront wrote to LDS before
 __device__ __forceinline__ void lds_st_rel(uint32_t byte_addr, uint32_t v, uint32_t lane)
 {
     lds_fence();
-    if (lane == 0) __hip_atomic_store(reinterpret_cast<lds_u32_t*>((uintptr_t)byte_addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) lds_st(byte_addr, v);
 }
-__device__ __forceinline__ void lds_st(uint32_t byte_addr, uint32_t v) { __hip_atomic_store(reinterpret_cast<lds_u32_t*>((uintptr_t)byte_addr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st64_rel(uint32_t byte_addr, uint32_t lo, uint32_t hi, uint32_t lane)
+{
+    lds_fence();
+    if (lane == 0) __hip_atomic_store(reinterpret_cast<lds_u64_t*>((uintptr_t)byte_addr), ((uint64_t)hi << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The kernel's arguments as they lie in the kernarg segment: sfx_serve reads them from there (scalar loads) instead of taking ~70 dwords of
+// by-value arguments.
+struct XKArgs { SfView s; BatchView b; ScanOut o; uint64_t n_chunks; };
+// What an F wavefront's resolve step reads and updates (copied in and out around the call: the rare path may live in memory, the filter loop not)
+struct XServe {
+    uint32_t unit_count, unit_slots, cur_block, first_block, grant_next, grant_left, Hq2, n_fin, pool_ok, pad;
+    uint64_t nval, d_batches, d_items, d_found, d_resolve;
+};
+
+// ---- an F wavefront's deferred ring: resolve up to 64 positions of the oldest unfinished unit in lock step (item j in lane j = position order),
+// write their records; a marker ends the unit.  force: take whatever is there, until the ring is empty; else one batch.
+// A FUNCTION, not inlined, on purpose: (1) the resolve is ~1500 instructions that run once per ~12 chunks, the filter loop around the call
+// stays small; (2) with the resolve's loads, stores and atomics inlined into the filter loop the compiler's wait-count pass no longer let the
+// chunk prefetch stay in flight across the filter (it waited for "everything" in the middle of the compaction) -- a call is a clean boundary:
+// everything is waited for on entry, nothing is pending on return.
+template <bool IC, int MODE, bool DBG>
+__device__ __attribute__((noinline)) void sfx_serve(const XKArgs* __restrict__ ka, uint32_t fblock, uint32_t force, XServe* __restrict__ st)
+{
+    const SfView& s = ka->s; const BatchView& b = ka->b; const ScanOut& o = ka->o;
+    const uint32_t lane = lane_id();
+    const uint32_t q2 = fblock + kXOffQ2, ctrl = fblock + kXOffCtrl;
+    const uint64_t unit_bytes = (uint64_t)o.unit_chunks * kSfChunk;
+    uint32_t unit_count = st->unit_count, unit_slots = st->unit_slots, cur_block = st->cur_block, first_block = st->first_block;
+    uint32_t grant_next = st->grant_next, grant_left = st->grant_left, Hq2 = st->Hq2, n_fin = st->n_fin;
+    bool pool_ok = st->pool_ok != 0;
+    uint64_t nval = st->nval, d_batches = st->d_batches, d_items = st->d_items, d_found = st->d_found, d_resolve = st->d_resolve;
+    for (;;) {
+        const uint32_t n_wait = lds_ld_acq(ctrl + 12u) - Hq2;
+        if (n_wait == 0) break;
+        uint32_t m = n_wait < 64u ? n_wait : 64u;
+        const uint32_t e = lane < m ? lds_ld(q2 + ((Hq2 + lane) & (kXQ2 - 1u)) * 4u) : 0u;
+        const uint64_t marks = __ballot(lane < m && (e & kQ2Mark) != 0u);
+        bool unit_ends = false;
+        if (marks) { m = (uint32_t)__builtin_ctzll(marks) + 1u; unit_ends = true; }      // the entries behind a marker belong to the next unit
+        const uint32_t n_items = unit_ends ? m - 1u : m;
+        const uint32_t ru = lds_ld_acq(ctrl + 48u + (n_fin & (kXUq - 1u)) * 4u);           // the unit these positions lie in
+        if (n_items) {
+            __builtin_amdgcn_s_setprio(3);
+            const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
+            bool valid[1] = {lane < n_items};
+            uint64_t gpos[1] = {(uint64_t)ru * unit_bytes + (e & 0xFFFFu)};
+            const uint32_t hint[1] = {(e >> 16) & 3u};
+            uint32_t hlo = 0, hhi = 0, hay = 0;
+            uint64_t end_pos[1] = {0};
+            if (valid[0]) { hlo = b.hidx[gpos[0] >> kHidxShift]; hhi = b.hidx[(gpos[0] >> kHidxShift) + 1]; }
+            auto locate = [&]() {      // haystack index -> start offset, while the head's first two trips (haystack bytes -> slot line) are in flight
+                hay = hlo;
+                uint64_t start = valid[0] ? b.offsets[hlo] : 0;
+                if (valid[0] && hlo != hhi) { hay = find_haystack(b, gpos[0]); start = b.offsets[hay]; }
+                end_pos[0] = valid[0] ? gpos[0] - start + 1 : 0;
+            };
+            uint32_t w[1], w2[1], avail[1], best_state[1], best_vlen[1], depth[1], node[1], t16[1][4];
+            bool go[1], have_rec[1];
+            SfNode rec[1];
+            sf_resolve_head<IC, 1>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16);
+            sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, nullptr, 0xFFFFFFFFu, t16);
+            const bool found = valid[0] && best_state[0] != 0;
+            if (DBG) { d_resolve += __builtin_amdgcn_s_memtime() - t0; d_batches++; d_items += n_items; d_found += (uint32_t)__popcll(__ballot(found)); }
+            if (MODE == kModeCount) {
+                if (found) {
+                    nval += best_vlen[0];
+                    if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), (unsigned long long)best_vlen[0]);
+                }
+            } else {
+                const uint64_t take_mask = __ballot(found);
+                const uint32_t Fn = (uint32_t)__popcll(take_mask);
+                if (Fn) {
+                    const uint32_t r = unit_slots & (kPoolBlock - 1u);      // fill of the current block
+                    const bool need_new = r == 0u || r + Fn > kPoolBlock;
+                    uint32_t new_block = kNone;
+                    if (need_new) {
+                        // blocks are drawn from the pool kSfBlockGrant at a time: one atomic on the (single, device-wide) counter costs ~10 ns
+                        if (grant_left == 0) {
+                            uint32_t g = 0;
+                            if (lane == 0) g = atomicAdd(o.pool_ctrl, kSfBlockGrant);
+                            grant_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
+                            grant_left = kSfBlockGrant;
+                        }
+                        const uint32_t id = grant_next++;
+                        grant_left--;
+                        if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; }   // keep counting, the host retries with a larger pool
+                        else {
+                            new_block = id;
+                            if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
+                            if (first_block == kNone) first_block = id;
+                        }
+                    }
+                    if (found && pool_ok) {
+                        const uint32_t p = r + (uint32_t)__popcll(take_mask & ((1ull << lane) - 1ull));
+                        const uint32_t slot = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
+                        reinterpret_cast<uint4*>(o.pool)[slot] = make_uint4((uint32_t)end_pos[0], (uint32_t)(end_pos[0] >> 32), hay, best_state[0] - 1u);
+                    }
+                    if (need_new && pool_ok) cur_block = new_block;
+                    unit_slots += Fn; unit_count += Fn;
+                }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (unit_ends) {
+            if (MODE == kModeEmit && lane == 0) { o.unit_counts[ru] = unit_count; o.unit_first[ru] = first_block; o.unit_slots[ru] = unit_slots; }
+            unit_count = 0; unit_slots = 0; cur_block = kNone; first_block = kNone;
+            n_fin++;
+        }
+        Hq2 += m;
+        lds_st_rel(ctrl + 16u, Hq2, lane);              // the P may overwrite these entries
+        if (!force) break;
+    }
+    st->unit_count = unit_count; st->unit_slots = unit_slots; st->cur_block = cur_block; st->first_block = first_block;
+    st->grant_next = grant_next; st->grant_left = grant_left; st->Hq2 = Hq2; st->n_fin = n_fin; st->pool_ok = pool_ok ? 1u : 0u;
+    st->nval = nval; st->d_batches = d_batches; st->d_items = d_items; st->d_found = d_found; st->d_resolve = d_resolve;
+}
 
 }  // namespace
 
@@ -101,24 +224,16 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     for (uint32_t i = threadIdx.x; i < kBloomMasks; i += kXThreads) lds[i] = bloom_mask_entry(i);
     for (uint32_t i = threadIdx.x; i < (1u << 15); i += kXThreads) lds[kBloomMasks + i] = s.bloom[i];
-    // control blocks: rings empty, every unit slot free, R's per-F unit state empty
-    for (uint32_t i = threadIdx.x; i < kXF; i += kXThreads) {
-        const uint32_t c = kXBase + i * kXFBytes + kXStage + kXQ1 * 2 + kXRing * 8;
-        lds[(c >> 2) + 0] = 0; lds[(c >> 2) + 1] = 0; lds[(c >> 2) + 2] = 0; lds[(c >> 2) + 3] = 0;
-        for (uint32_t k = 0; k < kXUq; k++) { lds[(c >> 2) + 4 + 2 * k] = kUnitEmpty; lds[(c >> 2) + 5 + 2 * k] = kUnitOpen; }
-        const uint32_t r = kXRBase + i * kXRState;
-        lds[(r >> 2) + 0] = 0; lds[(r >> 2) + 1] = 0; lds[(r >> 2) + 2] = kNone; lds[(r >> 2) + 3] = kNone;
-    }
-    if (threadIdx.x < kXP) { const uint32_t c = kXPBase + threadIdx.x * kXPBytes + kXQ2 * 4; lds[(c >> 2)] = 0; lds[(c >> 2) + 1] = 0; }
+    for (uint32_t i = threadIdx.x; i < kXF * 16u; i += kXThreads) lds[((kXBase + (i >> 4) * kXFBytes + kXOffCtrl) >> 2) + (i & 15u)] = 0;      // rings empty, nothing closed
     if (threadIdx.x == 0) lds[kXAbort >> 2] = 0;
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const XKArgs* ka = reinterpret_cast<const XKArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
     const uint32_t UC = o.unit_chunks;
     const uint64_t n_units = (n_chunks + UC - 1) / UC;
     const uint64_t unit_bytes = (uint64_t)UC * kSfChunk;
     const uint64_t t_begin = DBG ? __builtin_amdgcn_s_memtime() : 0;
-    auto f_ctrl = [](uint32_t f) -> uint32_t { return kXBase + f * kXFBytes + kXStage + kXQ1 * 2 + kXRing * 8; };      // tail +0, head +4, uq_r +8, uq_w +12, slots +16
     auto aborted = [&]() -> bool { return lds_ld_acq(kXAbort) != 0u; };
     // a wait that does not end: tell the other wavefronts (LDS only -- a global store inside the spin loops would make the compiler drain every
     // load in flight before each of them); whoever leaves with the flag set reports it to the host (report_abort)
@@ -126,13 +241,20 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
     auto report_abort = [&]() { if (lds_ld_acq(kXAbort) != 0u && lane == 0 && o.pool_ctrl) o.pool_ctrl[2] = 1u; };
 
     if (wave < (uint32_t)kXF) {
-        // =========================================================================== F: filter
+        // =========================================================================== F: filter, and resolve what comes back
         const uint32_t f = wave;
-        const uint32_t stage = kXBase + f * kXFBytes, q1 = stage + kXStage, ring = q1 + kXQ1 * 2, ctrl = ring + kXRing * 8;
+        const uint32_t stage = kXBase + f * kXFBytes, q1 = stage + kXOffQ1, ring = stage + kXOffRing, q2 = stage + kXOffQ2, ctrl = stage + kXOffCtrl;
         const uint64_t n_f = (uint64_t)gridDim.x * kXF;
-        uint32_t T = 0, uq_w = 0;                              // entries pushed so far; units announced so far
-        uint64_t d_wait_ring = 0, d_wait_uq = 0, d_chunks = 0, d_cands = 0;
+        uint32_t T = 0, n_closed = 0;                          // entries pushed so far; units closed so far
+        uint32_t n_open = 0, n_fin = 0;                        // units started / finished (marker seen, outputs written)
+        uint32_t Hq2 = 0;                                      // deferred entries taken
+        // the unit whose deferred positions are being resolved (the oldest unfinished one): its chain of record blocks
+        uint32_t unit_count = 0, unit_slots = 0, cur_block = kNone, first_block = kNone, grant_next = 0, grant_left = 0;
+        bool pool_ok = true, ok = true;
+        uint64_t nval = 0;
+        uint64_t d_wait_ring = 0, d_wait_uq = 0, d_chunks = 0, d_cands = 0, d_batches = 0, d_items = 0, d_found = 0, d_resolve = 0;
         __builtin_amdgcn_s_setprio(0);
+
         auto fetch = [&](uint64_t cc, uint4& v) {
             const uint64_t p = cc * kSfChunk + lane * 16u;
             v = make_uint4(0, 0, 0, 0);
@@ -150,61 +272,49 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
             }
             c3 = IC ? fold_dword(t.x) : t.x; c4 = IC ? fold_dword(t.y) : t.y;
         };
-        // waits until unit slot `uq_w` is free (R has retired the unit that used it), writes {unit, end_t} there and publishes the new count of
-        // announced units (kUnitDone: the last word of this F)
-        auto announce = [&](uint32_t unit, uint32_t end_t) -> bool {
-            uint32_t spins = 0;
-            const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
-            while (uq_w - lds_ld_acq(ctrl + 8u) >= kXUq) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > kSpinLimit) { give_up(); return false; }
-                if ((spins & 63u) == 0 && aborted()) return false;
-            }
-            if (DBG) d_wait_uq += __builtin_amdgcn_s_memtime() - t0;
-            const uint32_t slot = ctrl + 16u + (uq_w & (kXUq - 1u)) * 8u;
-            if (lane == 0) { lds_st(slot, unit); lds_st(slot + 4u, end_t); }
-            uq_w++;
-            lds_st_rel(ctrl + 12u, uq_w, lane);
-            return true;
-        };
+        // The loop over units runs ONE extra, empty trip at the end (`drain`): its only chunk has no candidates and its hand-over step waits
+        // until the last unit's marker has come back.  Every wait of this wavefront -- for ring room, for a free unit slot, for the last
+        // markers -- is that one hand-over step, and `serve` has exactly ONE call site in it: the resolve is ~1500 instructions, and the
+        // instruction cache is shared by the CU's wavefronts (k_sf went 2 % slower with its resolve inlined three times).
         uint64_t u = (uint64_t)blockIdx.x * kXF + f;
         uint4 cur_v; uint32_t carry3, carry4;
         fetch(u * UC, cur_v);
         fetch_before(u * UC, carry3, carry4);
         asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));
         uint64_t u_next = u;
-        bool ok = true;
-        for (; ok && u < n_units; u = u_next) {
-            u_next = u + n_f;
-            if (o.next_unit) {
-                uint32_t ticket = 0;
-                if (lane == 0) ticket = atomicAdd(o.next_unit, 1u);
-                u_next = n_f + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-            }
-            if (!announce((uint32_t)u, kUnitOpen)) { ok = false; break; }
-            const uint32_t my_slot = ctrl + 16u + ((uq_w - 1u) & (kXUq - 1u)) * 8u;
+        for (bool drain = false; ok && !drain; u = u_next) {
+            drain = u >= n_units;
+            if (!drain) {
+                u_next = u + n_f;
+                if (o.next_unit) {
+                    uint32_t ticket = 0;
+                    if (lane == 0) ticket = atomicAdd(o.next_unit, 1u);
+                    u_next = n_f + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+                }
+            } else lds_st64_rel(ctrl, T, n_closed | kDoneBit, lane);      // nothing more will be pushed or closed
             const uint64_t unit_base_chunk = u * UC;
-            const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
+            const uint32_t n_in_unit = drain ? 1u : (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
+            bool unit_started = false;
             for (uint32_t ci = 0; ok && ci < n_in_unit; ci++) {
                 const uint64_t c = unit_base_chunk + ci;
                 uint4 next_v = make_uint4(0, 0, 0, 0);
                 uint32_t next_c3 = 0, next_c4 = 0;
                 const bool last_of_unit = ci + 1 >= n_in_unit;
-                fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
-                if (last_of_unit) fetch_before(u_next * UC, next_c3, next_c4);
-                const uint64_t p0 = c * kSfChunk + lane * 16u;
-                uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
-                if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
-                const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);      // the lane below's last dword (lane 0: the carry)
-                const uint32_t d[5] = {d0, d1, d2, d3, d4};
-                lds_write_u32x4(stage + 16u + lane * 16u, make_uint4(d1, d2, d3, d4));
-                if (lane == 0) lds_write_u32x2(stage + 8u, make_uint2(carry3, carry4));
-                if (!last_of_unit) {
-                    next_c3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63);
-                    next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
-                }
                 uint32_t cand = 0;
-                {
+                if (!drain) {
+                    fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
+                    if (last_of_unit) fetch_before(u_next * UC, next_c3, next_c4);
+                    const uint64_t p0 = c * kSfChunk + lane * 16u;
+                    uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
+                    if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry4, (int)d4, 0x138, 0xf, 0xf, false);      // the lane below's last dword (lane 0: the carry)
+                    const uint32_t d[5] = {d0, d1, d2, d3, d4};
+                    lds_write_u32x4(stage + 16u + lane * 16u, make_uint4(d1, d2, d3, d4));
+                    if (lane == 0) lds_write_u32x2(stage + 8u, make_uint2(carry3, carry4));
+                    if (!last_of_unit) {
+                        next_c3 = (uint32_t)__builtin_amdgcn_readlane((int)d3, 63);
+                        next_c4 = (uint32_t)__builtin_amdgcn_readlane((int)d4, 63);
+                    }
                     uint32_t h[16], v[16], m[16];
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
@@ -219,14 +329,15 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
                     }
 #pragma unroll
                     for (int k = 15; k >= 0; k--) cand = (cand << 1) | (uint32_t)((v[k] & m[k]) == m[k]);
+                    if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
                 }
-                if (p0 + 16 > b.total) cand &= p0 < b.total ? (1u << (uint32_t)(b.total - p0)) - 1u : 0u;
-                // ---- compaction + hand-over, up to 128 candidates per sub-pass
+                // ---- compaction + hand-over, up to 64 candidates per sub-pass (one per lane).  A unit's first chunk always goes through the
+                // hand-over step (with nothing to push, if it comes to that): that is where the unit takes its slot
                 for (;;) {
                     const uint32_t n = __popc(cand);
                     const uint32_t incl = wave_inclusive_sum(n, lane);
                     const uint32_t total = __shfl(incl, 63, 64);
-                    if (total == 0) break;
+                    if (total == 0 && unit_started) break;
                     uint32_t idx = incl - n;
                     while (cand && idx < kXQ1) {
                         const uint32_t k = __builtin_ctz(cand);
@@ -236,77 +347,105 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
                     const uint32_t n_q1 = total < kXQ1 ? total : kXQ1;
                     if (DBG) d_cands += n_q1;
                     wave_lds_fence();
-                    uint32_t ew[2], em[2];
-                    bool ev[2];
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const uint32_t e = 64u * k + lane;
-                        ev[k] = e < n_q1;
-                        const uint32_t pos = ev[k] ? lds_read_u16(q1 + 2u * e) : 0u;
-                        // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on top), nb = the two before it
-                        const uint32_t a = 11u + pos, sh = a & 3u;
-                        const uint32_t sp = stage + (a & ~3u);
-                        const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
-                        const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
-                        const uint32_t nb = (two >> 8) | ((two & 0xFFu) << 8);
-                        ew[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
-                        em[k] = (nb << 16) | ((ci << 10) + pos);
-                    }
-                    // push: entry g may be written once g - head < kXRing
+                    const bool ev = lane < n_q1;
+                    const uint32_t pos = ev ? lds_read_u16(q1 + 2u * lane) : 0u;
+                    // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on top), nb = the two before it
+                    const uint32_t a = 11u + pos, sh = a & 3u;
+                    const uint32_t sp = stage + (a & ~3u);
+                    const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
+                    const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
+                    const uint32_t nb = (two >> 8) | ((two & 0xFFu) << 8);
+                    const uint32_t ew = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
+                    const uint32_t em = (nb << 16) | ((ci << 10) + pos);
+                    // hand-over step.  A unit starts (takes a unit-id slot) once fewer than kXUq units are unfinished; entry g may be written
+                    // once g - head < kXRing; the drain trip waits for the last markers.  Whatever it waits for, it serves the deferred ring
+                    // meanwhile -- the P may be waiting for room THERE, the two directions must not wait for each other.
                     const uint32_t T0 = T, Tend = T0 + n_q1;
                     uint32_t done = T0, spins = 0;
                     for (;;) {
-                        const uint32_t head = lds_ld_acq(ctrl + 4u);
-                        const uint32_t room_end = head + kXRing;
-                        const uint32_t upto = (int32_t)(Tend - room_end) <= 0 ? Tend : room_end;
-                        if (upto != done) {
-#pragma unroll
-                            for (int k = 0; k < 2; k++) {
-                                const uint32_t g = T0 + 64u * k + lane;
-                                if (ev[k] && (int32_t)(g - done) >= 0 && (int32_t)(g - upto) < 0) lds_write_u32x2(ring + (g & (kXRing - 1u)) * 8u, make_uint2(ew[k], em[k]));
-                            }
-                            done = upto;
-                            lds_st_rel(ctrl, done, lane);
+                        if (!unit_started && !drain && n_open - n_fin < kXUq) {
+                            if (lane == 0) lds_st(ctrl + 48u + (n_open & (kXUq - 1u)) * 4u, (uint32_t)u);
+                            n_open++;
+                            unit_started = true;
                         }
-                        if (done == Tend) break;
+                        if ((unit_started || drain) && done != Tend) {
+                            const uint32_t head = lds_ld_acq(ctrl + 8u);
+                            const uint32_t room_end = head + kXRing;
+                            const uint32_t upto = (int32_t)(Tend - room_end) <= 0 ? Tend : room_end;
+                            if (upto != done) {
+                                const uint32_t g = T0 + lane;
+                                if (ev && (int32_t)(g - done) >= 0 && (int32_t)(g - upto) < 0) lds_write_u32x2(ring + (g & (kXRing - 1u)) * 8u, make_uint2(ew, em));
+                                done = upto;
+                                lds_st64_rel(ctrl, done, n_closed, lane);
+                            }
+                        }
+                        const bool complete = drain ? n_fin == n_open : (unit_started && done == Tend);
                         const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
+                        {
+                            // the deferred ring: a batch worth the dependent trips (or whatever is there, when this wavefront is stuck anyway)
+                            const uint32_t n_wait = lds_ld_acq(ctrl + 12u) - Hq2;
+                            if (n_wait != 0u && (!complete || n_wait >= kServe)) {
+                                XServe st{unit_count, unit_slots, cur_block, first_block, grant_next, grant_left, Hq2, n_fin, pool_ok ? 1u : 0u, 0u, nval, d_batches, d_items, d_found, d_resolve};
+                                sfx_serve<IC, MODE, DBG>(ka, stage, complete ? 0u : 1u, &st);
+                                unit_count = st.unit_count; unit_slots = st.unit_slots; cur_block = st.cur_block; first_block = st.first_block;
+                                grant_next = st.grant_next; grant_left = st.grant_left; Hq2 = st.Hq2; n_fin = st.n_fin; pool_ok = st.pool_ok != 0u;
+                                nval = st.nval; d_batches = st.d_batches; d_items = st.d_items; d_found = st.d_found; d_resolve = st.d_resolve;
+                            }
+                        }
+                        if (complete) break;
                         __builtin_amdgcn_s_sleep(1);
-                        if (DBG) d_wait_ring += __builtin_amdgcn_s_memtime() - t0;
+                        if (DBG) { if (unit_started) d_wait_ring += __builtin_amdgcn_s_memtime() - t0; else d_wait_uq += __builtin_amdgcn_s_memtime() - t0; }
                         if (++spins > kSpinLimit) { give_up(); ok = false; break; }
                         if ((spins & 63u) == 0 && aborted()) { ok = false; break; }
                     }
                     T = Tend;
-                    if (!ok || total <= kXQ1) break;
+                    if (!ok || drain || total <= kXQ1) break;
                     wave_lds_fence();
                 }
-                cur_v = next_v; carry3 = next_c3; carry4 = next_c4;
-                if (DBG) d_chunks++;
+                // the prefetched bytes are taken over HERE, after the hand-over (the scheduler had moved these copies into the middle of the
+                // filter, with a wait for the request issued a few hundred instructions earlier)
+                {
+                    u32x4_n nv; nv.x = next_v.x; nv.y = next_v.y; nv.z = next_v.z; nv.w = next_v.w;
+                    asm volatile("" : "+v"(nv));               // (ONE 128-bit operand: the request's four registers stay a tuple)
+                    cur_v = make_uint4(nv.x, nv.y, nv.z, nv.w);
+                }
+                carry3 = next_c3; carry4 = next_c4;
+                if (DBG && !drain) d_chunks++;
             }
-            // close the unit: everything up to T belongs to it
-            lds_st_rel(my_slot + 4u, T, lane);
+            if (!drain && ok) {
+                // close the unit: everything up to T belongs to it
+                if (lane == 0) lds_st(ctrl + 32u + (n_closed & (kXUq - 1u)) * 4u, T);
+                n_closed++;
+                lds_st64_rel(ctrl, T, n_closed, lane);
+            }
         }
-        if (ok) (void)announce(kUnitDone, T);
         report_abort();
+        if (MODE == kModeCount) {
+            nval = wave_sum_u64(nval);
+            if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+        }
         if (DBG && o.dbg && lane == 0) {
             unsigned long long* q = reinterpret_cast<unsigned long long*>(o.dbg + 32);
             atomicAdd(q + 0, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin)); atomicAdd(q + 1, (unsigned long long)d_wait_ring);
             atomicAdd(q + 2, (unsigned long long)d_wait_uq); atomicAdd(q + 3, (unsigned long long)d_chunks); atomicAdd(q + 4, (unsigned long long)d_cands);
+            atomicAdd(q + 18, (unsigned long long)d_batches); atomicAdd(q + 19, (unsigned long long)d_items); atomicAdd(q + 20, (unsigned long long)d_found);
+            atomicAdd(q + 21, (unsigned long long)d_resolve);
         }
         return;
     }
 
-    if (wave < (uint32_t)(kXF + kXP)) {
-        // =========================================================================== P: probe
+    // =============================================================================== P: probe
+    {
         const uint32_t pi = wave - kXF;
-        const uint32_t q2 = kXPBase + pi * kXPBytes, q2c = q2 + kXQ2 * 4;       // ring, {tail, head}
         __builtin_amdgcn_s_setprio(2);
-        // Per-F state lives in VGPR LANES: lane L holds the state of this P's F number L & 3 (replicated 16 times).  Indexed arrays would end up
-        // in scratch memory -- whose loads count under vmcnt and would make every pass wait for all the bucket requests in flight.
+        // Per-F state lives in VGPR LANES: lane L holds the state of this P's F number L & 3 (3: none).  Indexed arrays would end up in scratch
+        // memory -- whose loads count under vmcnt and would make every pass wait for all the bucket requests in flight.
         const uint32_t jf = lane & 3u;
-        const uint32_t fc_l = f_ctrl(pi * kXFperP + jf);         // this lane's F: control block, ring
-        uint32_t vH = 0, vUqi = 0, vInfl = 0;                    // entries popped; units finished with; rounds in flight
-        bool vFin = false;
-        uint32_t Tq = 0;                                         // q2 entries pushed
+        const bool mine = jf < (uint32_t)kXFperP;
+        const uint32_t fb_l = kXBase + (pi * kXFperP + (mine ? jf : 0u)) * kXFBytes;      // this lane's F block
+        const uint32_t fc_l = fb_l + kXOffCtrl;
+        uint32_t vH = 0, vUqi = 0, vInfl = 0, vTq = 0, vQh = 0;  // entries popped; units whose marker went out; rounds in flight; q2 entries pushed; q2 head as last seen
+        bool vFin = !mine;
         uint64_t d_wait_q2 = 0, d_passes = 0, d_rounds = 0, d_cands = 0, d_defer = 0;
         // rounds in flight (slot J of the rotation): raw buckets, the word a matching slot equals, offset | valid, and whose they are
         u32x2 r_a[kProbeDepth], r_b[kProbeDepth];
@@ -316,22 +455,31 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
         const uint32_t lb_hot = s.tier_log2_cap[3];
         bool ok = true, finished = false;
         uint32_t idle_streak = 0;
-        // push one entry per flagged lane (in lane order) to q2; waits for room
-        auto q2_push = [&](bool flag, uint32_t value) -> bool {
+        // push one entry per flagged lane (in lane order) to the deferred ring of F number j; waits for room (the head is re-read only when
+        // the last seen one leaves none)
+        auto q2_push = [&](uint32_t j, bool flag, uint32_t value) -> bool {
             const uint64_t m = __ballot(flag);
             const uint32_t n = (uint32_t)__popcll(m);
             if (!n) return true;
-            uint32_t spins = 0;
-            const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
-            while (Tq + n - lds_ld_acq(q2c + 4u) > kXQ2) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) { give_up(); return false; }
-                if ((spins & 63u) == 0 && aborted()) return false;
+            const uint32_t fb = kXBase + (pi * kXFperP + j) * kXFBytes;
+            const uint32_t tq = (uint32_t)__builtin_amdgcn_readlane((int)vTq, (int)j);
+            uint32_t qh = (uint32_t)__builtin_amdgcn_readlane((int)vQh, (int)j);
+            if (tq + n - qh > kXQ2) {
+                uint32_t spins = 0;
+                const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
+                for (;;) {
+                    qh = lds_ld_acq(fb + kXOffCtrl + 16u);
+                    if (tq + n - qh <= kXQ2) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit) { give_up(); return false; }
+                    if ((spins & 63u) == 0 && aborted()) return false;
+                }
+                if (DBG) d_wait_q2 += __builtin_amdgcn_s_memtime() - t0;
+                if (jf == j) vQh = qh;
             }
-            if (DBG) d_wait_q2 += __builtin_amdgcn_s_memtime() - t0;
-            if (flag) lds_st(q2 + ((Tq + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (kXQ2 - 1u)) * 4u, value);
-            Tq += n;
-            lds_st_rel(q2c, Tq, lane);
+            if (flag) lds_st(fb + kXOffQ2 + ((tq + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & (kXQ2 - 1u)) * 4u, value);
+            if (jf == j) vTq += n;
+            lds_st_rel(fb + kXOffCtrl + 12u, tq + n, lane);
             return true;
         };
         auto pass = [&](auto slot_c) __attribute__((always_inline)) {
@@ -346,37 +494,35 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
                 const u32x2 a1[1] = {r_a[J]}, b1[1] = {r_b[J]};
                 const uint32_t e1[1] = {r_e[J]};
                 sf_probe_decide<1>(s, a1, b1, e1, valid, defer, hint);
-                const uint32_t fg = pi * kXFperP + (r_f[J] & 3u);
                 if (DBG) d_defer += (uint32_t)__popcll(__ballot(defer[0]));
-                if (!q2_push(defer[0], (fg << 20) | (hint[0] << 16) | (r_pos[J] & 0xFFFFu))) ok = false;
+                if (!q2_push(r_f[J] & 3u, defer[0], (hint[0] << 16) | (r_pos[J] & 0xFFFFu))) ok = false;
                 if (jf == r_f[J]) vInfl--;
                 r_f[J] = kNone;
             }
-            // (2) the state of the four rings: tail and announced-unit count FIRST, then the current unit's slot (a tail read before its slot never
-            // reaches into the next unit; a slot is only looked at once its unit has been announced -- before that it still holds an older unit)
-            const uint32_t tl = lds_ld(fc_l), aw = lds_ld(fc_l + 12u);
-            const uint32_t sa = fc_l + 16u + (vUqi & (kXUq - 1u)) * 8u;
+            // (2) the state of the three rings: ONE 8-byte read per F gives {tail, units closed} as they were together -- a tail seen with
+            // "not closed yet" never reaches into the next unit; the end of a closed unit is fetched only when there is one
+            const uint64_t w0 = lds_ld64(fc_l);
             lds_fence();
-            const uint32_t uid = lds_ld(sa), uend = lds_ld(sa + 4u);
-            lds_fence();
-            const bool have_unit = !vFin && (int32_t)(aw - vUqi) > 0;
-            const bool done_word = have_unit && uid == kUnitDone;
-            const bool closed = have_unit && !done_word && uend != kUnitOpen;
-            const uint32_t avail = (have_unit && !done_word) ? (closed ? uend : tl) - vH : 0u;
-            if (done_word && vInfl == 0) vFin = true;
+            const uint32_t tl = (uint32_t)w0, ncl = (uint32_t)(w0 >> 32) & ~kDoneBit;
+            const bool f_done = ((uint32_t)(w0 >> 32) & kDoneBit) != 0u;
+            const bool closed = !vFin && (int32_t)(ncl - vUqi) > 0;
+            uint32_t uend = 0;
+            if (__ballot(closed)) { uend = lds_ld(fc_l + 32u + (vUqi & (kXUq - 1u)) * 4u); lds_fence(); }
+            const uint32_t avail = vFin ? 0u : (closed ? uend : tl) - vH;
+            if (!vFin && f_done && ncl == vUqi && vInfl == 0) vFin = true;
             // a unit that is complete, popped and looked at: its end marker follows its last deferred position
             const bool unit_over = closed && avail == 0 && vInfl == 0;
             {
-                uint32_t mm = (uint32_t)(__ballot(unit_over) & 0xFull);
+                uint32_t mm = (uint32_t)(__ballot(unit_over) & 0x7ull);
                 while (mm) {
                     const uint32_t j = (uint32_t)__builtin_ctz(mm);
                     mm &= mm - 1u;
-                    if (!q2_push(lane == 0, kQ2Mark | ((pi * kXFperP + j) << 20))) ok = false;
+                    if (!q2_push(j, lane == 0, kQ2Mark)) ok = false;
                 }
                 if (unit_over) vUqi++;
             }
             // choose: a full round first (of a complete unit before an open one), else the most entries
-            const uint32_t score = unit_over ? 0u : (avail >= 64u ? 64u + (closed ? 1u : 0u) : avail);
+            const uint32_t score = (unit_over || vFin) ? 0u : (avail >= 64u ? 64u + (closed ? 1u : 0u) : avail);
             uint32_t best = 0, best_j = kNone;
 #pragma unroll
             for (int j = 0; j < kXFperP; j++) {
@@ -391,15 +537,14 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
                 const uint32_t Hj = (uint32_t)__builtin_amdgcn_readlane((int)vH, (int)best_j);
                 const uint32_t av = (uint32_t)__builtin_amdgcn_readlane((int)avail, (int)best_j);
                 const uint32_t m = av < 64u ? av : 64u;
-                const uint32_t fc = f_ctrl(pi * kXFperP + best_j);
-                const uint32_t rg = fc - kXRing * 8u;
+                const uint32_t fb = kXBase + (pi * kXFperP + best_j) * kXFBytes;
                 valid = lane < m;
                 if (valid) {
-                    const u32x2_n e = *reinterpret_cast<const lds_u32x2_t*>((uintptr_t)(rg + ((Hj + lane) & (kXRing - 1u)) * 8u));
+                    const u32x2_n e = *reinterpret_cast<const lds_u32x2_t*>((uintptr_t)(fb + kXOffRing + ((Hj + lane) & (kXRing - 1u)) * 8u));
                     w = e.x; meta = e.y;
                 }
                 asm volatile("" : "+v"(w), "+v"(meta));
-                lds_st_rel(fc + 4u, Hj + m, lane);                 // the entries are in registers: the F may overwrite them
+                lds_st_rel(fb + kXOffCtrl + 8u, Hj + m, lane);     // the entries are in registers: the F may overwrite them
                 if (jf == best_j) { vH += m; vInfl++; }
                 r_f[J] = best_j;
                 idle_streak = 0;
@@ -438,264 +583,12 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
             if ((++guard & 63u) == 0 && aborted()) ok = false;
             if (idle_streak > kSpinLimit) { give_up(); ok = false; }
         }
-        if (ok) (void)q2_push(lane == 0, kQ2PDone);
         report_abort();
         if (DBG && o.dbg && lane == 0) {
             unsigned long long* q = reinterpret_cast<unsigned long long*>(o.dbg + 32);
             atomicAdd(q + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin)); atomicAdd(q + 9, (unsigned long long)d_wait_q2);
             atomicAdd(q + 10, (unsigned long long)d_passes); atomicAdd(q + 11, (unsigned long long)(d_passes - d_rounds)); atomicAdd(q + 12, (unsigned long long)d_rounds);
             atomicAdd(q + 13, (unsigned long long)d_cands); atomicAdd(q + 14, (unsigned long long)d_defer);
-        }
-        return;
-    }
-
-    // =============================================================================== R: resolve + all output
-    {
-        __builtin_amdgcn_s_setprio(3);
-        uint32_t Hq[kXP]; bool pdone[kXP];
-#pragma unroll
-        for (int p = 0; p < kXP; p++) { Hq[p] = 0; pdone[p] = false; }
-        uint64_t nval = 0;
-        uint32_t grant_next = 0, grant_left = 0;
-        bool pool_ok = true;
-        uint64_t d_wait = 0, d_batches = 0, d_items = 0, d_found = 0, d_resolve = 0;
-        uint32_t idle = 0;
-        // a pool block for this wavefront's next records (blocks are drawn kSfBlockGrant at a time: one atomic on the device-wide counter costs ~10 ns)
-        auto new_block = [&]() -> uint32_t {
-            if (grant_left == 0) {
-                uint32_t g = 0;
-                if (lane == 0) g = atomicAdd(o.pool_ctrl, kSfBlockGrant);
-                grant_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)g);
-                grant_left = kSfBlockGrant;
-            }
-            const uint32_t id = grant_next++;
-            grant_left--;
-            if (id >= o.n_blocks) { pool_ok = false; if (lane == 0) o.pool_ctrl[1] = 1u; return kNone; }       // keep counting, the host retries with a larger pool
-            return id;
-        };
-        for (;;) {
-            // ---- gather up to 64 * kRN entries from the three rings (tails first, then the entries)
-            uint32_t cnt[kXP], total = 0;
-#pragma unroll
-            for (int p = 0; p < kXP; p++) {
-                const uint32_t t = lds_ld_acq(kXPBase + (uint32_t)p * kXPBytes + kXQ2 * 4);
-                uint32_t n = t - Hq[p];
-                const uint32_t cap = 64u * kRN - total;
-                if (n > cap) n = cap;
-                cnt[p] = n; total += n;
-            }
-            if (total == 0) {
-                bool all = true;
-#pragma unroll
-                for (int p = 0; p < kXP; p++) all = all && pdone[p];
-                if (all) break;
-                const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
-                __builtin_amdgcn_s_sleep(2);
-                if (DBG) d_wait += __builtin_amdgcn_s_memtime() - t0;
-                if (++idle > kSpinLimit) { give_up(); break; }
-                if ((idle & 63u) == 0 && aborted()) break;
-                continue;
-            }
-            // a small batch waits a little for company (a resolve costs the same ~9k cycles for 10 items as for 128) unless a marker may be waiting in it
-            if (total < 48u && idle < 24u) { idle++; __builtin_amdgcn_s_sleep(8); continue; }
-            idle = 0;
-            uint32_t ent[kRN]; bool have[kRN];
-            for (int round = 0; round < 2; round++) {
-                // item i (< total) sits in lane i % 64, slot i / 64; segment p covers [base_p, base_p + cnt_p)
-                uint32_t first_mark[kXP];
-#pragma unroll
-                for (int p = 0; p < kXP; p++) first_mark[p] = kNone;
-#pragma unroll
-                for (int k = 0; k < kRN; k++) {
-                    const uint32_t i = 64u * k + lane;
-                    have[k] = i < total;
-                    // segment p and the ring index i + (Hq[p] - base_p), by sums of steps (a select chain over the three rings' values would be
-                    // turned into an indexed array in scratch memory)
-                    const uint32_t ge1 = i >= cnt[0] ? 1u : 0u, ge2 = i >= cnt[0] + cnt[1] ? 1u : 0u;
-                    const uint32_t p = ge1 + ge2;
-                    const uint32_t off0 = Hq[0], off1 = Hq[1] - cnt[0], off2 = Hq[2] - cnt[0] - cnt[1];
-                    const uint32_t ri = i + off0 + ge1 * (off1 - off0) + ge2 * (off2 - off1);
-                    ent[k] = have[k] ? lds_ld(kXPBase + p * kXPBytes + (ri & (kXQ2 - 1u)) * 4u) : 0u;
-                    const bool mk = have[k] && (ent[k] & (kQ2Mark | kQ2PDone)) != 0u;
-#pragma unroll
-                    for (int q = 0; q < kXP; q++) {
-                        const uint64_t mm = __ballot(mk && p == (uint32_t)q);
-                        if (mm && first_mark[q] == kNone) first_mark[q] = 64u * k + (uint32_t)__builtin_ctzll(mm);
-                    }
-                }
-                // a segment ends with its first marker (the entries behind it belong to the F's next unit / come after a P's last word)
-                bool cut = false;
-                uint32_t base = 0;
-#pragma unroll
-                for (int p = 0; p < kXP; p++) {
-                    const uint32_t old = cnt[p];
-                    if (first_mark[p] != kNone && first_mark[p] - base + 1u < cnt[p]) { cnt[p] = first_mark[p] - base + 1u; cut = true; }
-                    base += old;
-                }
-                if (!cut) break;
-                total = cnt[0] + cnt[1] + cnt[2];
-            }
-            lds_fence();
-            // ---- the items: F, hint, position; their unit through the F's current unit slot (the slot R retires next)
-            bool valid[kRN]; uint32_t fg[kRN], hint[kRN]; uint64_t gpos[kRN];
-            bool any_item = false;
-#pragma unroll
-            for (int k = 0; k < kRN; k++) {
-                valid[k] = have[k] && (ent[k] & (kQ2Mark | kQ2PDone)) == 0u;
-                fg[k] = (ent[k] >> 20) & 15u; hint[k] = (ent[k] >> 16) & 3u;
-                gpos[k] = 0;
-                if (valid[k]) {
-                    const uint32_t fc = f_ctrl(fg[k]);
-                    const uint32_t r = lds_ld(fc + 8u);
-                    const uint32_t unit = lds_ld(fc + 16u + (r & (kXUq - 1u)) * 8u);
-                    gpos[k] = (uint64_t)unit * unit_bytes + (ent[k] & 0xFFFFu);
-                }
-                any_item = any_item || valid[k];
-            }
-            if (__ballot(any_item)) {
-                const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
-                uint32_t hlo[kRN], hhi[kRN], hay[kRN];
-                uint64_t end_pos[kRN];
-#pragma unroll
-                for (int k = 0; k < kRN; k++) {
-                    hlo[k] = hhi[k] = 0; hay[k] = 0; end_pos[k] = 0;
-                    if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
-                }
-                auto locate = [&]() {
-#pragma unroll
-                    for (int k = 0; k < kRN; k++) {
-                        hay[k] = hlo[k];
-                        uint64_t start = valid[k] ? b.offsets[hlo[k]] : 0;
-                        if (valid[k] && hlo[k] != hhi[k]) { hay[k] = find_haystack(b, gpos[k]); start = b.offsets[hay[k]]; }
-                        end_pos[k] = valid[k] ? gpos[k] - start + 1 : 0;
-                    }
-                };
-                uint32_t w[kRN], w2[kRN], avail[kRN], best_state[kRN], best_vlen[kRN], depth[kRN], node[kRN], t16[kRN][4];
-                bool go[kRN], have_rec[kRN], found[kRN];
-                SfNode rec[kRN];
-                sf_resolve_head<IC, kRN>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16);
-                sf_resolve_walk<IC, kRN>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, nullptr, 0xFFFFFFFFu, t16);
-#pragma unroll
-                for (int k = 0; k < kRN; k++) found[k] = valid[k] && best_state[k] != 0;
-                if (DBG) {
-                    d_resolve += __builtin_amdgcn_s_memtime() - t0; d_batches++;
-#pragma unroll
-                    for (int k = 0; k < kRN; k++) { d_items += (uint32_t)__popcll(__ballot(valid[k])); d_found += (uint32_t)__popcll(__ballot(found[k])); }
-                }
-                if (MODE == kModeCount) {
-#pragma unroll
-                    for (int k = 0; k < kRN; k++) if (found[k]) {
-                        nval += best_vlen[k];
-                        if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay[k]), (unsigned long long)best_vlen[k]);
-                    }
-                } else {
-                    // ---- records: per F (its current unit's chain), slot 0 items of all lanes before slot 1 items = position order
-                    bool rem[kRN];
-#pragma unroll
-                    for (int k = 0; k < kRN; k++) rem[k] = found[k];
-                    for (;;) {
-                        uint64_t rm[kRN]; uint64_t any = 0;
-#pragma unroll
-                        for (int k = 0; k < kRN; k++) { rm[k] = __ballot(rem[k]); any |= rm[k]; }
-                        if (!any) break;
-                        uint32_t f0 = 0;
-                        {
-                            bool got = false;
-#pragma unroll
-                            for (int k = 0; k < kRN; k++) if (!got && rm[k]) { f0 = (uint32_t)__builtin_amdgcn_readlane((int)fg[k], (int)__builtin_ctzll(rm[k])); got = true; }
-                        }
-                        bool sel[kRN]; uint64_t take[kRN]; uint32_t before[kRN], Fn = 0;
-#pragma unroll
-                        for (int k = 0; k < kRN; k++) { sel[k] = rem[k] && fg[k] == f0; take[k] = __ballot(sel[k]); before[k] = Fn; Fn += (uint32_t)__popcll(take[k]); rem[k] = rem[k] && !sel[k]; }
-                        const uint32_t st = kXRBase + f0 * kXRState;
-                        const u32x4_n sv = *reinterpret_cast<const lds_u32x4_t*>((uintptr_t)st);
-                        uint32_t unit_slots = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.x), unit_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.y);
-                        uint32_t cur_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.z), first_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)sv.w);
-                        const uint32_t s0 = unit_slots, have_blocks = (s0 + kPoolBlock - 1u) / kPoolBlock;
-                        const uint32_t n_new = (s0 + Fn + kPoolBlock - 1u) / kPoolBlock - have_blocks;           // <= kRN + 1
-                        const uint32_t prev_block = cur_block;
-                        uint32_t ids[kRN + 1];
-#pragma unroll
-                        for (int t = 0; t < kRN + 1; t++) {
-                            ids[t] = kNone;
-                            if ((uint32_t)t < n_new) {
-                                const uint32_t id = new_block();
-                                if (id != kNone && pool_ok) {
-                                    ids[t] = id;
-                                    if (lane == 0) { o.block_next[id] = kNone; if (cur_block != kNone) o.block_next[cur_block] = id; }
-                                    if (first_block == kNone) first_block = id;
-                                    cur_block = id;
-                                }
-                            }
-                        }
-                        // (the new blocks' ids sit in the lanes 0 .. kRN of one register and are picked with a lane shuffle: a select chain over an
-                        // array gets turned into an indexed array in scratch memory)
-                        uint32_t idv = ids[0];
-#pragma unroll
-                        for (int t = 1; t < kRN + 1; t++) { const uint32_t us = (uint32_t)__builtin_amdgcn_readfirstlane((int)ids[t]); asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(idv) : "s"(us), "n"(t)); }
-#pragma unroll
-                        for (int k = 0; k < kRN; k++) {
-                            const bool wr = sel[k] && pool_ok;
-                            const uint32_t si = s0 + before[k] + (uint32_t)__popcll(take[k] & ((1ull << lane) - 1ull));
-                            const uint32_t q = si / kPoolBlock;
-                            const uint32_t from_new = (uint32_t)__shfl((int)idv, (int)((q - have_blocks) & 63u), 64);      // (all lanes take part in the shuffle)
-                            const uint32_t blk = q < have_blocks ? prev_block : from_new;
-                            if (wr) {
-                                reinterpret_cast<uint4*>(o.pool)[(uint64_t)blk * kPoolBlock + (si & (kPoolBlock - 1u))] =
-                                    make_uint4((uint32_t)end_pos[k], (uint32_t)(end_pos[k] >> 32), hay[k], best_state[k] - 1u);
-                            }
-                        }
-                        unit_slots += Fn; unit_count += Fn;
-                        if (lane == 0) lds_write_u32x4(st, make_uint4(unit_slots, unit_count, cur_block, first_block));
-                        wave_lds_fence();
-                    }
-                }
-            }
-            // ---- markers: a segment's last entry may be one
-            {
-                uint32_t base = 0;
-#pragma unroll
-                for (int p = 0; p < kXP; p++) {
-                    if (cnt[p]) {
-                        const uint32_t i = base + cnt[p] - 1u;
-                        uint32_t e = 0;
-#pragma unroll
-                        for (int k = 0; k < kRN; k++) if ((i >> 6) == (uint32_t)k) e = (uint32_t)__builtin_amdgcn_readlane((int)ent[k], (int)(i & 63u));
-                        if (e & kQ2PDone) pdone[p] = true;
-                        else if (e & kQ2Mark) {
-                            const uint32_t f0 = (e >> 20) & 15u;
-                            const uint32_t fc = f_ctrl(f0);
-                            const uint32_t r = lds_ld_acq(fc + 8u);
-                            const uint32_t slot = fc + 16u + (r & (kXUq - 1u)) * 8u;
-                            const uint32_t unit = lds_ld_acq(slot);
-                            if (MODE == kModeEmit) {
-                                const uint32_t st = kXRBase + f0 * kXRState;
-                                const u32x4_n sv = *reinterpret_cast<const lds_u32x4_t*>((uintptr_t)st);
-                                if (lane == 0) {
-                                    o.unit_slots[unit] = sv.x; o.unit_counts[unit] = sv.y; o.unit_first[unit] = sv.w;
-                                    lds_write_u32x4(st, make_uint4(0u, 0u, kNone, kNone));
-                                }
-                            }
-                            lds_st_rel(fc + 8u, r + 1u, lane);         // the F may announce into this slot again
-                        }
-                    }
-                    base += cnt[p];
-                }
-            }
-            // ---- the entries are done with: the Ps may overwrite them
-#pragma unroll
-            for (int p = 0; p < kXP; p++) if (cnt[p]) { Hq[p] += cnt[p]; lds_st_rel(kXPBase + (uint32_t)p * kXPBytes + kXQ2 * 4 + 4u, Hq[p], lane); }
-        }
-        report_abort();
-        if (MODE == kModeCount) {
-            nval = wave_sum_u64(nval);
-            if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
-        }
-        if (DBG && o.dbg && lane == 0) {
-            unsigned long long* q = reinterpret_cast<unsigned long long*>(o.dbg + 32);
-            atomicAdd(q + 16, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin)); atomicAdd(q + 17, (unsigned long long)d_wait);
-            atomicAdd(q + 18, (unsigned long long)d_batches); atomicAdd(q + 19, (unsigned long long)d_items); atomicAdd(q + 20, (unsigned long long)d_found);
-            atomicAdd(q + 21, (unsigned long long)d_resolve);
         }
     }
 }

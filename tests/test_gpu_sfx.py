@@ -49,7 +49,8 @@ def _ragged_offsets(rng, n_bytes, n_hay):
     offs = np.concatenate([[0], cuts, [n_bytes]]).astype(np.int64)
     # a few empty haystacks and one that ends a few bytes after a 1-KiB boundary
     offs[5] = offs[4]
-    offs[9] = offs[8]
+    if n_hay > 9:
+        offs[9] = offs[8]
     return np.maximum.accumulate(offs)
 
 

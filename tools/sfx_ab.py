@@ -68,13 +68,13 @@ for mode in ("emit",):
     am.api.check(fn(out))
     r = [int(x) for x in out]
     info = am.device_info(); wgs = info["n_cu"]
-    nF, nP, nR = 12 * wgs, 3 * wgs, wgs
     chunks = max(r[3], 1)
+    nF, nP = 12 * wgs, 4 * wgs
     print("  k_sfx roles (%s, instrumented, call %.2f ms): per F wavefront %.0f cycles = %.0f per chunk; waiting for ring room %.1f %%, for a unit slot %.1f %%; candidates per chunk %.1f" % (
         mode, wall, r[0] / nF, r[0] / chunks, 100.0 * r[1] / max(r[0], 1), 100.0 * r[2] / max(r[0], 1), r[4] / chunks))
+    print("    F resolve: batches %d with %.1f positions each, %.0f cycles per batch = %.1f %% of the F time; found %d" % (
+        r[18], r[19] / max(r[18], 1), r[21] / max(r[18], 1), 100.0 * r[21] / max(r[0], 1), r[20]))
     print("    per P wavefront %.0f cycles; passes %d (%.0f cycles each), idle %.1f %%, rounds %d with %.1f entries each; waiting for q2 room %.1f %%; deferred per chunk %.2f" % (
         r[8] / nP, r[10], r[8] / max(r[10], 1), 100.0 * r[11] / max(r[10], 1), r[12], r[13] / max(r[12], 1), 100.0 * r[9] / max(r[8], 1), r[14] / chunks))
-    print("    per R wavefront %.0f cycles; waiting for work %.1f %%; batches %d with %.1f items each, %.0f cycles per resolve (%.1f %% of its time); found %d" % (
-        r[16] / nR, 100.0 * r[17] / max(r[16], 1), r[18], r[19] / max(r[18], 1), r[21] / max(r[18], 1), 100.0 * r[21] / max(r[16], 1), r[20]))
 am.debug_set("AM_SF_ABLATE", -1)
 lib.am_batch_destroy(b)
