@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kXThreads) void k_sfx(SfView s, BatchView b, ScanOu
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const XKArgs* ka = reinterpret_cast<const XKArgs*>(__builtin_amdgcn_kernarg_segment_ptr());
+    const XKArgs* ka = (const XKArgs*)__builtin_amdgcn_kernarg_segment_ptr();      // (address space 4 -> generic)
     const uint32_t UC = o.unit_chunks;
     const uint64_t n_units = (n_chunks + UC - 1) / UC;
     const uint64_t unit_bytes = (uint64_t)UC * kSfChunk;
