@@ -391,7 +391,7 @@ __device__ __forceinline__ void sfx_role_filter(const SfView& s, const BatchView
 // (its arguments by value: the few words it needs.  Handed a pointer to the kernel's arguments it read them -- and the buckets -- with FLAT
 // loads, which count under vmcnt AND lgkmcnt: the static request pipeline below fell apart.  The bucket table is addressed through a
 // global-address-space pointer for the same reason.)
-typedef __attribute__((address_space(1))) const uint2 g_uint2_t;
+typedef __attribute__((address_space(1))) const u32x2_n g_uint2_t;
 typedef __attribute__((address_space(1))) uint32_t g_u32_t;
 typedef __attribute__((address_space(1))) unsigned long long g_u64_t;
 template <bool DBG>
@@ -525,8 +525,8 @@ __device__ __attribute__((noinline)) void sfx_role_probe(uint64_t hot_addr, uint
         {
             const uint32_t ha = t4_hash_a(w), hb = t4_hash_b(w);
             r_e[J] = t4_expect(t4_fingerprint(ha, lb_hot), meta >> 16);
-            const uint2 ra = hot[valid ? t4_bucket(ha, lb_hot) : 0u];
-            const uint2 rb = hot[valid ? t4_bucket(hb, lb_hot) : 0u];
+            const u32x2_n ra = hot[valid ? t4_bucket(ha, lb_hot) : 0u];
+            const u32x2_n rb = hot[valid ? t4_bucket(hb, lb_hot) : 0u];
             r_a[J] = u32x2{ra.x, ra.y}; r_b[J] = u32x2{rb.x, rb.y};
             r_pos[J] = valid ? ((meta & 0xFFFFu) | 0x10000u) : 0u;
         }
