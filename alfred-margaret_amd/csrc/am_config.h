@@ -17,7 +17,7 @@ enum Key {
     kSfWq,                // AM_SF_WQ: walker-queue entries per wavefront (0: none)
     kSfWqIters,           // AM_SF_WQ_ITERS: trie steps a resolve batch takes before it parks
     kSfMaxBloomLog2Words, // AM_SF_MAX_BLOOM_LOG2_WORDS: cap on the LDS filter size (tests: dense filters)
-    kSfx,                 // AM_SFX: 0 = never the role-specialised kernel, 1 = whenever the automaton allows it (tests), unset = by batch size
+    kSfx,                 // AM_SFX: the role-specialised kernel k_sfx: 1 = whenever the automaton allows it (tests, A/B), 2 = for large scans; unset / 0 = never
     kNoSmallRun,          // AM_NO_SMALL_RUN: am_run on small batches takes the general path
     kRpFullScans, kRpSplice, kRpPieces, kRpParallelFold, kRpGroups, kRpNoFuse, kRpNoSpin, kRpMatMain, kRpNoRangeReuse, kRpTrace,
     kCount

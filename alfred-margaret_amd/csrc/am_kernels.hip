@@ -832,11 +832,12 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
         o.dbg = dbg;
         g_sf_dbg = dbg;
     }
-    // the role-specialised kernel (am_sfx.hip) for large scans with the 128-KiB filter; AM_SFX = 0 never, 1 whenever the automaton allows it
+    // the role-specialised kernel (am_sfx.hip): AM_SFX = 1 whenever the automaton allows it (tests, A/B), 2 for large scans only; NOT the default --
+    // measured on cfg3 it is bit-exact and 15 % slower than k_sf (5.08 vs 4.32 ms per 4 GiB: DESIGN.md section 6, profiles/history/r04_sfx_*)
     {
         const long sfx = cfg::get(cfg::kSfx);
         const bool plain = ablate == 0 || ablate == 9;
-        if (plain && sfx != 0 && sfx_eligible(s, b, o, mode, n_cu, sfx == 1)) return launch_sfx(ic, mode, s, b, o, n_cu, st);
+        if (plain && (sfx == 1 || sfx == 2) && sfx_eligible(s, b, o, mode, n_cu, sfx == 1)) return launch_sfx(ic, mode, s, b, o, n_cu, st);
     }
     if (ic) {
         if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);

@@ -111,16 +111,16 @@ struct XServe {
 };
 
 // ---- an F wavefront's deferred ring: resolve up to 64 positions of the oldest unfinished unit in lock step (item j in lane j = position order),
-// write their records; a marker ends the unit.  force: take whatever is there, until the ring is empty; else one batch.  Inlined at its ONE
-// call site (the resolve is ~1500 instructions; the instruction cache is shared by the CU's wavefronts).
+// write their records; a marker ends the unit.  min_batch: nothing is done for fewer waiting entries; force: batch after batch until fewer
+// are left (else one batch).  Inlined at its ONE call site (the resolve is ~1500 instructions; the instruction cache is shared by the CU's wavefronts).
 template <bool IC, int MODE, bool DBG>
-__device__ __forceinline__ void sfx_serve(const SfView& s, const BatchView& b, const ScanOut& o, uint32_t fblock, uint32_t lane, bool force, XServe& st)
+__device__ __forceinline__ void sfx_serve(const SfView& s, const BatchView& b, const ScanOut& o, uint32_t fblock, uint32_t lane, uint32_t min_batch, bool force, XServe& st)
 {
     const uint32_t q2 = fblock + kXOffQ2, ctrl = fblock + kXOffCtrl;
     const uint64_t unit_bytes = (uint64_t)o.unit_chunks * kSfChunk;
     for (;;) {
         const uint32_t n_wait = lds_ld_acq(ctrl + 12u) - st.Hq2;
-        if (n_wait == 0 || (!force && n_wait < kServe)) break;
+        if (n_wait == 0 || n_wait < min_batch) break;
         uint32_t m = n_wait < 64u ? n_wait : 64u;
         const uint32_t e = lane < m ? lds_ld(q2 + q2_slot(st.Hq2 + lane) * 4u) : 0u;
         const uint64_t marks = __ballot(lane < m && (e & kQ2Mark) != 0u);
@@ -317,6 +317,7 @@ __device__ __forceinline__ void sfx_role_filter(const SfView& s, const BatchView
                         n_open++;
                         unit_started = true;
                     }
+                    if (unit_started && !pushed && T + n_p - head > kXRing) head = lds_ld_acq(ctrl + 8u);      // no room by the head last seen: look again
                     if (unit_started && !pushed && T + n_p - head <= kXRing) {
                         uint32_t idx = incl - n;
                         while (cand && idx < 128u) {
@@ -346,12 +347,16 @@ __device__ __forceinline__ void sfx_role_filter(const SfView& s, const BatchView
                         pushed = true;
                     }
                     const bool complete = drain ? st.n_fin == n_open : (unit_started && pushed);
-                    // the deferred ring: when this wavefront is stuck anyway, or -- every fourth chunk -- when a batch worth its dependent trips waits
-                    if (!complete || (ci & 3u) == 3u) sfx_serve<IC, MODE, DBG>(s, b, o, stage, lane, !complete, st);      // (the one call site)
+                    // the deferred ring.  Every fourth chunk: a batch worth its dependent trips (kServe).  Stuck for ring room: the P is behind --
+                    // half a batch, and in any case before the deferred ring is full (the P may be waiting for room THERE: the two directions
+                    // must not wait for each other).  Stuck for a unit slot, or draining: whatever is there -- the marker is what is waited for.
+                    if (!complete || (ci & 3u) == 3u) {
+                        const bool for_marker = !complete && (drain || !unit_started);
+                        sfx_serve<IC, MODE, DBG>(s, b, o, stage, lane, complete ? kServe : (for_marker ? 1u : kServe / 2u), for_marker, st);      // (the one call site)
+                    }
                     if (complete) break;
-                    // stuck: the ring head as it is now; a short sleep; the watchdog
+                    // stuck: a short sleep; the watchdog
                     const uint64_t t0 = DBG ? __builtin_amdgcn_s_memtime() : 0;
-                    head = lds_ld_acq(ctrl + 8u);
                     __builtin_amdgcn_s_sleep(1);
                     if (DBG) { if (unit_started) d_wait_ring += __builtin_amdgcn_s_memtime() - t0; else d_wait_uq += __builtin_amdgcn_s_memtime() - t0; }
                     if (++spins > kSpinLimit) { give_up(); ok = false; break; }
