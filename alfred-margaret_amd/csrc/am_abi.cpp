@@ -266,7 +266,8 @@ struct am_matches {
     int dev = 0;
     Record* d_records = nullptr; uint64_t n = 0; size_t cap_bytes = 0;
     std::vector<am_match> host; bool fetched = false;
-    am_match* big = nullptr; size_t big_cap = 0;         // large results: uninitialised host memory filled through pinned staging (am_matches_data)
+    am_match* big = nullptr; size_t big_cap = 0;         // large results: a host block of the library's own -- page-locked (big_pinned: the records are
+    bool big_pinned = false;                             // DMA'd straight into it), or pageable and filled through pinned staging
 };
 
 // The record array of the last freed result is kept for the next call (one buffer, reused when it is large enough
@@ -1167,6 +1168,29 @@ struct HostCache {
 };
 static HostCache g_host_cache;
 
+// Large results go into PAGE-LOCKED host blocks of the library's own (the caller only ever sees the pointer am_matches_data returns): the
+// records are DMA'd straight into them, no staging copy -- a match-dense result is several times the size of the text that produced it
+// (natural language: 2.5 x) and used to crawl through two 8-MiB staging halves and a single-threaded memcpy (2 GiB of text: 926 ms,
+// round 3).  Page-locking is slow (~1 GiB/s) and page-locked memory is a limited resource, so one freed block is kept for the next result
+// (up to kPinnedKeep) and larger ones are given back at once; if the runtime refuses a block the pageable path below still works.
+struct PinnedCache {
+    std::mutex mu; void* p = nullptr; size_t cap = 0;
+    void* take(size_t need, size_t* cap_out)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (p && cap >= need) { void* r = p; *cap_out = cap; p = nullptr; cap = 0; return r; }
+        return nullptr;
+    }
+    void give(void* q, size_t c, size_t keep_limit)
+    {
+        void* old = q;
+        if (c <= keep_limit) { std::lock_guard<std::mutex> lk(mu); if (c > cap) { old = p; p = q; cap = c; } }
+        if (old) (void)hipHostFree(old);
+    }
+};
+static PinnedCache& pinned_cache() { static PinnedCache* c = new PinnedCache(); return *c; }      // never destroyed: no HIP call in a static destructor
+constexpr size_t kPinnedKeep = (size_t)8 << 30;
+
 constexpr size_t kRecordsDirect = 1u << 20;              // results up to this size: one plain copy
 constexpr size_t kFetchPiece = 8u << 20;
 
@@ -1216,6 +1240,28 @@ extern "C" const am_match* am_matches_data(am_matches* m)
         } else {
             // a large result: no zero-filled vector and no staged copy into pageable memory inside the runtime -- the records cross PCIe in
             // pieces into the calling thread's pinned staging area, and piece i is copied out while piece i + 1 is on its way
+            if (bytes > kFetchPiece) {
+                // page-locked block + one DMA (in 256-MiB requests, so that a huge result does not sit in one multi-second call of the runtime)
+                m->big = (am_match*)pinned_cache().take(bytes, &m->big_cap);
+                if (!m->big) {
+                    void* q = nullptr;
+                    const size_t want = bytes + bytes / 16 + 4096;
+                    if (hipHostMalloc(&q, want, hipHostMallocPortable) == hipSuccess) { m->big = (am_match*)q; m->big_cap = want; }
+                    else (void)hipGetLastError();
+                }
+                if (m->big) {
+                    m->big_pinned = true;
+                    hipStream_t st;
+                    bool good = get_stream(m->dev, &st) == AM_OK;
+                    constexpr size_t kReq = (size_t)256 << 20;
+                    for (size_t lo = 0; good && lo < bytes; lo += kReq)
+                        good = hipMemcpyAsync((uint8_t*)m->big + lo, (const uint8_t*)m->d_records + lo, std::min(kReq, bytes - lo), hipMemcpyDeviceToHost, st) == hipSuccess;
+                    if (good) good = hipStreamSynchronize(st) == hipSuccess;
+                    if (!good) { fail(AM_ERR_HIP, "copying the match records to the host failed"); (void)hipHostFree(m->big); m->big = nullptr; return nullptr; }
+                    m->fetched = true;
+                    return m->big;
+                }
+            }
             m->big = (am_match*)g_host_cache.take(bytes, &m->big_cap);      // (a block used before has its pages: a fresh 100-MB block costs 10 ms of page faults)
             if (!m->big) { m->big_cap = bytes + bytes / 16; m->big = (am_match*)std::malloc(m->big_cap); }
             if (!m->big) { fail(AM_ERR_OOM, "out of host memory for the match records"); return nullptr; }
@@ -1235,7 +1281,7 @@ extern "C" void am_matches_free(am_matches* m)
 {
     if (!m) return;
     if (m->d_records) g_record_cache[m->dev].give(m->d_records, m->cap_bytes);
-    if (m->big) g_host_cache.give(m->big, m->big_cap);
+    if (m->big) { if (m->big_pinned) pinned_cache().give(m->big, m->big_cap, kPinnedKeep); else g_host_cache.give(m->big, m->big_cap); }
     delete m;
 }
 

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         else if (MODE == kModeEmit) {
             if (found && best_state[0] != prior && pool_ok) o.pool[slot].state = best_state[0] - 1u;      // the batch wrote end_pos and haystack into the walker's slot
             unit_count += (uint32_t)__popcll(__ballot(found && prior == 0u));
-        } else if (found) o.flags[hay] = 1;
+        } else if (found) atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay >> 2), 1u << (8u * (hay & 3u)));
     };
 
     // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items in lock step (all belong to the current unit); item j of the batch
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < RN; k++) if (found[k]) o.flags[hay[k]] = 1;
+                for (int k = 0; k < RN; k++) if (found[k]) atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay[k] >> 2), 1u << (8u * (hay[k] & 3u)));      // (an atomic: the other XCDs' wavefronts look at it while the kernel runs)
             }
 #pragma unroll
             for (int k = 0; k < RN; k++) pm[k] = __ballot(parked[k]);
@@ -437,6 +437,10 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     // the top of the loop body would also cover the prefetch of the next chunk that every iteration issues first
     asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));
 
+    // containsAny stops at the first match (Searcher.hs:156-164: `Done True`; Automaton.hs:528-532): in flag mode a wavefront looks at the flag
+    // of the haystack its chunk lies in -- as the whole device has left it, one chunk ago: the load has a chunk's time -- and skips the chunk
+    // if it is set.  A 1-GiB document that matches in its first KiB costs a few chunks per wavefront, not the scan.
+    uint32_t any_word = 0, any_hay = kNone;
     uint64_t u_next = u;
     for (; u < n_units; u = u_next) {
         // the unit after this one (its first chunk is prefetched while this unit's last chunk is processed)
@@ -471,6 +475,13 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 hs0 = uniform_u64(b.offsets[hay0]); he0 = uniform_u64(b.offsets[hay0 + 1]);
             }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
+            bool skip = false;
+            if (MODE == kModeAny) {
+                const uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_word);
+                skip = single && any_hay == hay0 && ((seen >> (8u * (hay0 & 3u))) & 0xFFu) != 0u;
+                any_word = __hip_atomic_load(reinterpret_cast<const uint32_t*>(o.flags) + (hay0 >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                any_hay = hay0;
+            }
 
             uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
             if (IC) { d1 = fold_dword(d1); d2 = fold_dword(d2); d3 = fold_dword(d3); d4 = fold_dword(d4); }
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             // k_sf 10.39 -> 10.26 ms per 10 GiB (cfg3 937 -> 949 GiB/s), cfg2 +1.7 %, cfg4 +0.9 %, natural text +0.2 %.
             __builtin_amdgcn_s_setprio(0);
             uint32_t cand = 0;
-            {
+            if (MODE != kModeAny || !skip) {
                 // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 32 LDS reads (filter word + mask per
                 // position) are all in flight before the first one is tested
                 uint32_t h[16], v[16], m[16];
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
 #pragma unroll
                 for (int k = 15; k >= 0; k--) cand = (cand << 1) | (uint32_t)((v[k] & m[k]) == m[k]);      // bit k of cand = position k
             }
-            if (SHORT) {                                   // automata with 1..3-byte needles: extra probes per position
+            if (SHORT && (MODE != kModeAny || !skip)) {    // automata with 1..3-byte needles: extra probes per position
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int j = k >> 2, sh = k & 3;

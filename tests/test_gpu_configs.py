@@ -177,3 +177,48 @@ def test_cfg1_contains_any_three_needles_one_megabyte():
     p_, v_ = o.run_list(0, big)
     assert [(int(h), int(p), int(v)) for h, p, v in zip(hay_i, pos, val)] == [(0, int(p), int(v)) for p, v in zip(p_, v_)]
     assert len(pos) > 100_000 and o.contains_any(0, quiet) is False
+
+
+def test_contains_any_stops_at_the_first_match():
+    """Searcher.containsAny ends its fold at the first match (Searcher.hs:156-164 `Done True`, Automaton.hs:528-532).  In flag mode k_sf skips a
+    chunk whose haystack is already flagged: a 1-GiB document that matches in its first KiB costs a few chunks per wavefront instead of the scan;
+    the flags are what they were without the short cut (same haystacks as the oracle's containsAny)."""
+    import torch
+    needles, a, o = _cfg3()
+    dev = torch.device("cuda:0")
+    lib = am.api.libam()
+    gib = 1 << 30
+    text = torch.full((gib + 64,), ord("x"), dtype=torch.uint8, device=dev)       # no needle of the benchmark set is made of x's only
+    needle = needles[0].encode()
+    text[100:100 + len(needle)] = torch.tensor(list(needle), dtype=torch.uint8, device=dev)
+    offs = torch.tensor([0, gib], dtype=torch.int64, device=dev)
+    b = C.c_void_p()
+    am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), 1, gib, C.byref(b)))
+    flags = np.zeros(4, np.uint8)
+    try:
+        am.api.check(lib.am_contains_any_batch(a.device, am.IGNORE_CASE, b, flags.ctypes.data))      # (builds the haystack index)
+        assert flags[0] == 1
+        am.api.check(lib.am_profile_enable(1)); am.api.check(lib.am_profile_reset())
+        am.api.check(lib.am_contains_any_batch(a.device, am.IGNORE_CASE, b, flags.ctypes.data))
+        ms, launches = C.c_double(0), C.c_uint64(0)
+        am.api.check(lib.am_profile_read(b"sf", C.byref(ms), C.byref(launches)))
+        hit_ms = ms.value / max(launches.value, 1)
+        # the same document without the match: the whole scan
+        text[100:100 + len(needle)] = ord("x")
+        am.api.check(lib.am_profile_reset())
+        am.api.check(lib.am_contains_any_batch(a.device, am.IGNORE_CASE, b, flags.ctypes.data))
+        am.api.check(lib.am_profile_read(b"sf", C.byref(ms), C.byref(launches)))
+        miss_ms = ms.value / max(launches.value, 1)
+        am.api.check(lib.am_profile_enable(0))
+        assert flags[0] == 0
+        print("containsAny on 1 GiB: first-KiB match %.3f ms, no match %.3f ms" % (hit_ms, miss_ms))
+        assert hit_ms < 0.25 and hit_ms * 4 < miss_ms
+    finally:
+        lib.am_batch_destroy(b)
+    # several haystacks, some matching early, some late, some not at all: the flags are the oracle's containsAny
+    hays = [b"x" * 300_000 + needle + b"x" * 50, needle + b"y" * 400_000, b"z" * 200_000, b"", b"q" * 70_000 + needle.upper()]
+    got = am.Searcher(am.IGNORE_CASE, needles[:2000]).contains_any_batch(hays)
+    o2 = oracle.Machine(needles[:2000])
+    exp = [bool(o2.contains_any(am.IGNORE_CASE, h)) for h in hays]
+    assert exp == [True, True, False, False, True]
+    assert [bool(g) for g in got] == exp
