@@ -49,6 +49,8 @@ ABI = {
     "am_count": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
     "am_contains_any": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, _vp]),
     "am_run": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp)]),
+    "am_run_range": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), C.c_uint64, C.c_uint64, C.POINTER(_vp)]),
+    "am_count_range": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), C.c_uint64, C.c_uint64, _u64p]),
     "am_batch_upload": (C.c_int, [C.POINTER(Slice), _sz, C.POINTER(_vp)]),
     "am_batch_from_device": (C.c_int, [_vp, _vp, _sz, C.c_uint64, C.POINTER(_vp)]),
     "am_batch_destroy": (None, [_vp]),
@@ -100,6 +102,8 @@ ABI = {
     "am_multi_batch_upload": (C.c_int, [_vp, C.c_int, C.POINTER(Slice), _sz, C.POINTER(_vp)]),
     "am_multi_count_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u64p, _u64p]),
     "am_multi_run_batch": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(_vp), C.POINTER(_vp), _u64p]),
+    "am_multi_count_single": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(Slice), _u64p, _u64p]),
+    "am_multi_run_single": (C.c_int, [_vp, C.POINTER(_vp), C.c_int, C.POINTER(Slice), C.POINTER(_vp), C.POINTER(_sz), _u64p]),
     "am_lower_code_point": (C.c_uint32, [C.c_uint32]),
     "am_unicode_version": (C.c_uint32, []),
     "am_image_version": (C.c_uint32, []),

@@ -265,6 +265,7 @@ struct am_batch {
 struct am_matches {
     int dev = 0;
     Record* d_records = nullptr; uint64_t n = 0; size_t cap_bytes = 0;
+    uint64_t first = 0;                                  // the result is records [first, first + n) of the array (am_run_range keeps a sub-range)
     std::vector<am_match> host; bool fetched = false;
     am_match* big = nullptr; size_t big_cap = 0;         // large results: a host block of the library's own -- page-locked (big_pinned: the records are
     bool big_pinned = false;                             // DMA'd straight into it), or pageable and filled through pinned staging
@@ -1082,14 +1083,14 @@ static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, 
     return rc;
 }
 
-extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out)
+static int run_batch_impl(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out, bool allow_small)
 {
     if (!out) return fail(AM_ERR_INVALID, "out is null");
     *out = nullptr;
     if (!cb) return fail(AM_ERR_INVALID, "null batch");
     am_matches* m = new am_matches();
     m->dev = cb->dev;
-    {
+    if (allow_small) {
         bool done = false;
         const int rc = run_records_small(a, case_mode, const_cast<am_batch*>(cb), m, &done);
         if (rc != AM_OK) { am_matches_free(m); return rc; }
@@ -1112,6 +1113,8 @@ extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch
     *out = m;
     return AM_OK;
 }
+
+extern "C" int am_run_batch(const am_automaton* a, int case_mode, const am_batch* cb, am_matches** out) { return run_batch_impl(a, case_mode, cb, out, true); }
 
 // ------------------------------------------------------------------ one-shot host entry points
 
@@ -1143,6 +1146,97 @@ extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay,
     int rc = upload_slices(hay, n_hay, b, true);
     if (rc == AM_OK) rc = am_run_batch(a, case_mode, b, out);
     oneshot_trim(a->dev);
+    return rc;
+}
+
+// ---- ONE haystack in ranges ("a single huge haystack splits into G ranges with maxNeedleCodePoints overlap" -- the same rule as the
+// chunking inside the kernels).  Whether a needle ends at a position depends only on the bytes of one maximal match before it, so scanning
+// text[start, scan_hi) with start = lo - overlap reports exactly the reference's matches with end positions in (lo, hi]; overlap = 4 bytes
+// per code point of the longest needle (under IgnoreCase a haystack code point may be longer than the needle code point it lowers to:
+// KELVIN SIGN, 3 bytes, lowers to k); start is moved back and scan_hi forward to a code point boundary (a slice that ended inside a code
+// point would hand the general kernel a truncated sequence).  The own range is cut out of the sorted records ON THE DEVICE (two binary
+// searches) and rebased to the whole haystack.
+static int range_window(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, uint64_t* start, uint64_t* scan_hi)
+{
+    if (!a || !hay || (hay->len && !hay->ptr)) return fail(AM_ERR_INVALID, "null arguments");
+    if (lo > hi || hi > hay->len) return fail(AM_ERR_INVALID, "range outside the haystack");
+    const Flavor* f; AM_TRY(prepare(a, case_mode, &f));
+    const uint64_t overlap = 4ull * (f->h.max_needle_cps ? f->h.max_needle_cps : 1u);
+    const uint8_t* t = hay->ptr + hay->off;
+    uint64_t s = lo > overlap ? lo - overlap : 0;
+    while (s > 0 && (t[s] & 0xC0u) == 0x80u) s--;
+    uint64_t e = hi;
+    while (e < hay->len && (t[e] & 0xC0u) == 0x80u) e++;
+    *start = s; *scan_hi = e;
+    return AM_OK;
+}
+
+extern "C" int am_run_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, am_matches** out)
+{
+    if (!out) return fail(AM_ERR_INVALID, "out is null");
+    *out = nullptr;
+    uint64_t start = 0, scan_hi = 0;
+    AM_TRY(range_window(a, case_mode, hay, lo, hi, &start, &scan_hi));
+    if (hi == lo) { am_matches* m = new am_matches(); m->dev = a->dev; m->fetched = true; *out = m; return AM_OK; }
+    const am_slice win{hay->ptr, hay->off + start, scan_hi - start};
+    am_batch* b = oneshot_get(a->dev);
+    int rc = upload_slices(&win, 1, b, true);
+    am_matches* m = nullptr;
+    if (rc == AM_OK) rc = run_batch_impl(a, case_mode, b, &m, false);          // (the general path: the records stay on the device, unfetched)
+    oneshot_trim(a->dev);
+    if (rc != AM_OK) return rc;
+    if (m->n) {
+        OnDevice od(m->dev);
+        if (od.rc != AM_OK) { am_matches_free(m); return od.rc; }
+        hipStream_t st;
+        rc = get_stream(m->dev, &st);
+        uint64_t* d_b = nullptr;
+        if (rc == AM_OK && hipMalloc((void**)&d_b, 16) != hipSuccess) rc = fail(AM_ERR_OOM, "hipMalloc failed");
+        uint64_t bounds[2] = {0, 0};
+        if (rc == AM_OK) {
+            hipError_t e = launch_range_bounds(m->d_records, m->n, lo - start, hi - start, d_b, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(bounds, d_b, 16, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = launch_range_rebase(m->d_records + bounds[0], bounds[1] - bounds[0], start, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) rc = fail(AM_ERR_HIP, std::string("am_run_range: ") + hipGetErrorString(e));
+        }
+        if (d_b) (void)hipFree(d_b);
+        if (rc != AM_OK) { am_matches_free(m); return rc; }
+        m->first = bounds[0]; m->n = bounds[1] - bounds[0];
+    }
+    *out = m;
+    return AM_OK;
+}
+
+// countMatches (benchmark/haskell/app/Main.hs:67-76) over the end positions in (lo, hi] of ONE haystack
+extern "C" int am_count_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, uint64_t* count_out)
+{
+    if (!count_out) return fail(AM_ERR_INVALID, "count_out is null");
+    *count_out = 0;
+    am_matches* m = nullptr;
+    AM_TRY(am_run_range(a, case_mode, hay, lo, hi, &m));
+    int rc = AM_OK;
+    if (m->n) {
+        const Flavor* f = nullptr;
+        rc = prepare(a, case_mode, &f);
+        OnDevice od(m->dev);
+        if (rc == AM_OK) rc = od.rc;
+        hipStream_t st;
+        if (rc == AM_OK) rc = get_stream(m->dev, &st);
+        uint64_t* d_t = nullptr;
+        if (rc == AM_OK && hipMalloc((void**)&d_t, 8) != hipSuccess) rc = fail(AM_ERR_OOM, "hipMalloc failed");
+        if (rc == AM_OK) {
+            const AcView ac = make_ac_view(f->d_image, f->h);
+            hipError_t e = hipMemsetAsync(d_t, 0, 8, st);
+            if (e == hipSuccess) e = launch_records_reduce(m->d_records + m->first, m->n, ac.vlen, nullptr, d_t, nullptr, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(count_out, d_t, 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) rc = fail(AM_ERR_HIP, std::string("am_count_range: ") + hipGetErrorString(e));
+        }
+        if (d_t) (void)hipFree(d_t);
+    }
+    am_matches_free(m);
     return rc;
 }
 
@@ -1234,7 +1328,7 @@ extern "C" const am_match* am_matches_data(am_matches* m)
         if (bytes <= kRecordsDirect) {
             m->host.resize(m->n);
             if (m->n) {
-                hipError_t e = hipMemcpy(m->host.data(), m->d_records, bytes, hipMemcpyDeviceToHost);
+                hipError_t e = hipMemcpy(m->host.data(), m->d_records + m->first, bytes, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { fail(AM_ERR_HIP, std::string("hipMemcpy(records): ") + hipGetErrorString(e)); return nullptr; }
             }
         } else {
@@ -1255,7 +1349,7 @@ extern "C" const am_match* am_matches_data(am_matches* m)
                     bool good = get_stream(m->dev, &st) == AM_OK;
                     constexpr size_t kReq = (size_t)256 << 20;
                     for (size_t lo = 0; good && lo < bytes; lo += kReq)
-                        good = hipMemcpyAsync((uint8_t*)m->big + lo, (const uint8_t*)m->d_records + lo, std::min(kReq, bytes - lo), hipMemcpyDeviceToHost, st) == hipSuccess;
+                        good = hipMemcpyAsync((uint8_t*)m->big + lo, (const uint8_t*)(m->d_records + m->first) + lo, std::min(kReq, bytes - lo), hipMemcpyDeviceToHost, st) == hipSuccess;
                     if (good) good = hipStreamSynchronize(st) == hipSuccess;
                     if (!good) { fail(AM_ERR_HIP, "copying the match records to the host failed"); (void)hipHostFree(m->big); m->big = nullptr; return nullptr; }
                     m->fetched = true;
@@ -1266,16 +1360,16 @@ extern "C" const am_match* am_matches_data(am_matches* m)
             if (!m->big) { m->big_cap = bytes + bytes / 16; m->big = (am_match*)std::malloc(m->big_cap); }
             if (!m->big) { fail(AM_ERR_OOM, "out of host memory for the match records"); return nullptr; }
             if (bytes <= kFetchPiece) {                       // a few MiB: the runtime's own staged copy is faster than two pieces of ours (1.8 MB: 290 against 410 us per am_run)
-                hipError_t e = hipMemcpy(m->big, m->d_records, bytes, hipMemcpyDeviceToHost);
+                hipError_t e = hipMemcpy(m->big, m->d_records + m->first, bytes, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { fail(AM_ERR_HIP, std::string("hipMemcpy(records): ") + hipGetErrorString(e)); std::free(m->big); m->big = nullptr; return nullptr; }
-            } else if (fetch_through_pinned(m->big, m->d_records, bytes, m->dev) != AM_OK) { std::free(m->big); m->big = nullptr; return nullptr; }
+            } else if (fetch_through_pinned(m->big, m->d_records + m->first, bytes, m->dev) != AM_OK) { std::free(m->big); m->big = nullptr; return nullptr; }
         }
         m->fetched = true;
     }
     return m->big ? m->big : m->host.data();
 }
 
-extern "C" const void* am_matches_device_data(const am_matches* m) { return m ? m->d_records : nullptr; }
+extern "C" const void* am_matches_device_data(const am_matches* m) { return m ? (m->d_records ? m->d_records + m->first : nullptr) : nullptr; }
 
 extern "C" void am_matches_free(am_matches* m)
 {
@@ -2531,7 +2625,7 @@ extern "C" int am_matches_fold_hash(const am_matches* m, const am_needle_ids* id
     AM_TRY(rec_first.ensure((n_hay + 1) * 8));
     AM_TRY(out.ensure(n_hay * 16));
     AM_TRY(dummy.ensure(sizeof(Record)));
-    const Record* recs = m->n ? m->d_records : (const Record*)dummy.p;
+    const Record* recs = m->n ? m->d_records + m->first : (const Record*)dummy.p;
     HIP_TRY(launch_rp_ranges(recs, m->n, (uint64_t*)rec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, (uint32_t)n_hay, st));
     { Prof pr("fold_hash", st);
       HIP_TRY(launch_fold_hash(recs, (const uint64_t*)rec_first.p, (const uint64_t*)ids->vals_off.p, (const uint32_t*)ids->vals.p, (uint32_t)n_hay,

@@ -170,5 +170,32 @@ hipError_t launch_records_reduce(const Record* recs, uint64_t n, const uint32_t*
     return hipGetLastError();
 }
 
+// ---- one haystack scanned in ranges (am_run_range): the records of ONE haystack are sorted by end position
+// out[0] = records with end_pos <= x0, out[1] = records with end_pos <= x1 (two binary searches)
+__global__ void k_range_bounds(const Record* __restrict__ recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* __restrict__ out)
+{
+    if (threadIdx.x > 1 || blockIdx.x) return;
+    const uint64_t x = threadIdx.x ? x1 : x0;
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (recs[mid].end_pos <= x) lo = mid + 1; else hi = mid; }
+    out[threadIdx.x] = lo;
+}
+__global__ void k_range_rebase(Record* __restrict__ recs, uint64_t n, uint64_t add)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) recs[i].end_pos += add;
+}
+hipError_t launch_range_bounds(const Record* recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* out2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_range_bounds, dim3(1), dim3(64), 0, st, recs, n, x0, x1, out2);
+    return hipGetLastError();
+}
+hipError_t launch_range_rebase(Record* recs, uint64_t n, uint64_t add, hipStream_t st)
+{
+    if (n == 0 || add == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_range_rebase, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, recs, n, add);
+    return hipGetLastError();
+}
+
 }  // namespace dev
 }  // namespace am

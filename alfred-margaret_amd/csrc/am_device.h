@@ -76,6 +76,9 @@ hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, ui
 hipError_t launch_dense(bool ic, bool write, const AcView& a, const BatchView& b, const Record* sparse, const uint64_t* sparse_offsets, uint32_t unit_chunks,
                         uint64_t n_units, uint32_t* unit_totals, const uint64_t* out_offsets, Record* out, hipStream_t st);
 hipError_t launch_records_reduce(const Record* recs, uint64_t n, const uint32_t* vlen, uint64_t* hay_counts, uint64_t* total, uint8_t* flags, hipStream_t st);
+// one haystack scanned in ranges (am_run_range): out2 = {records with end_pos <= x0, records with end_pos <= x1}; end_pos += add
+hipError_t launch_range_bounds(const Record* recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* out2, hipStream_t st);
+hipError_t launch_range_rebase(Record* recs, uint64_t n, uint64_t add, hipStream_t st);
 
 // ---- Replacer pass (am_replace.hip) ----------------------------------------------------------
 // same layout as am_payload in include/am.h (Replacer.hs:59-70 Payload, replacement text as a slice of one blob)

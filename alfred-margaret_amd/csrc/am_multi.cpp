@@ -107,7 +107,7 @@ struct am_multi {
 };
 
 namespace {
-constexpr size_t kSmallBytes = 4096;
+constexpr size_t kSmallBytes = 4096 + 64;      // 512 values of an all-reduce + the error flag word that travels with them
 
 struct DeviceGuard {
     int prev = 0;
@@ -229,12 +229,21 @@ int allreduce_flagged(am_multi* m, uint64_t* values, size_t count, int local_rc)
     const std::string local_msg = local_rc != AM_OK ? std::string(am_last_error()) : std::string();
     std::vector<uint64_t> row(count + 1);
     int rc = AM_OK;
-    for (int i = 0; i < n && rc == AM_OK; i++) {
-        for (size_t k = 0; k < count; k++) row[k] = local_rc == AM_OK ? values[(size_t)i * count + k] : 0;
-        row[count] = local_rc == AM_OK ? 0 : 1;
+    // (a staging failure on one device must not leave the others with the previous call's row -- possibly flag 0: from the first failure on
+    // every device of this process gets {0..., 1}, so the peers see the failure whatever this process could still stage)
+    for (int i = 0; i < n; i++) {
+        const bool bad = local_rc != AM_OK || rc != AM_OK;
+        for (size_t k = 0; k < count; k++) row[k] = bad ? 0 : values[(size_t)i * count + k];
+        row[count] = bad ? 1 : 0;
         hipError_t e = hipSetDevice(m->devs[i]);
         if (e == hipSuccess) e = hipMemcpy(m->small[i], row.data(), (count + 1) * 8, hipMemcpyHostToDevice);
-        if (e != hipSuccess) rc = abi_fail(AM_ERR_HIP, std::string("all-reduce staging: ") + hipGetErrorString(e));      // still enter the collective below
+        if (e != hipSuccess && rc == AM_OK) {
+            rc = abi_fail(AM_ERR_HIP, std::string("all-reduce staging: ") + hipGetErrorString(e));      // still enter the collective below
+            for (int j = 0; j < i; j++) {                        // the rows already staged as "fine": flag them, too
+                const uint64_t one = 1;
+                if (hipSetDevice(m->devs[j]) == hipSuccess) (void)hipMemcpy(m->small[j] + count, &one, 8, hipMemcpyHostToDevice);
+            }
+        }
     }
     const ncclResult_t r = in_group(n, [&](int i) { return ncclAllReduce(m->small[i], m->small[i], count + 1, ncclUint64, ncclSum, m->comms[i], m->streams[i]); });
     if (r != ncclSuccess && rc == AM_OK) rc = abi_fail(AM_ERR_HIP, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
@@ -316,7 +325,7 @@ extern "C" int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, 
 extern "C" int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count)
 {
     if (!m || (count && !values)) return abi_fail(AM_ERR_INVALID, "null arguments");
-    if ((count + 1) * 8 > kSmallBytes) return abi_fail(AM_ERR_INVALID, "too many values for one all-reduce (511 at most)");
+    if (count > 512) return abi_fail(AM_ERR_INVALID, "too many values for one all-reduce (512 at most)");
     if (count == 0) return AM_OK;
     return allreduce_flagged(m, values, count, AM_OK);
 }
@@ -444,3 +453,55 @@ extern "C" int am_multi_run(am_multi* m, am_automaton* const* autos, int case_mo
 }
 
 extern "C" void am_multi_matches_free(am_match* p) { std::free(p); }
+
+// ---- ONE haystack on all devices: global device g of W owns the end positions in (len * g / W, len * (g + 1) / W]; it uploads and
+// scans only its window of the text (am_run_range: the range plus one maximal match of overlap before it), cuts its own range out of the sorted
+// records on the device and rebases them.  No data-path collective; the counts are all-reduced.
+namespace {
+void range_of(uint64_t len, int g, int world, uint64_t* lo, uint64_t* hi) { *lo = (uint64_t)((unsigned __int128)len * (unsigned)g / (unsigned)world); *hi = (uint64_t)((unsigned __int128)len * (unsigned)(g + 1) / (unsigned)world); }
+}  // namespace
+
+extern "C" int am_multi_count_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, uint64_t* local_counts_out, uint64_t* total_out)
+{
+    if (!m || !autos || !hay) return abi_fail(AM_ERR_INVALID, "null arguments");
+    const int n = (int)m->devs.size();
+    std::vector<uint64_t> totals(n, 0);
+    const int local = per_device(m, [&](int i) -> int {
+        uint64_t lo, hi; range_of(hay->len, m->first_rank + i, m->world, &lo, &hi);
+        return am_count_range(autos[i], case_mode, hay, lo, hi, &totals[i]);
+    });
+    if (local_counts_out && local == AM_OK) for (int i = 0; i < n; i++) local_counts_out[i] = totals[i];
+    AM_TRY(allreduce_flagged(m, totals.data(), 1, local));
+    if (total_out) *total_out = totals[0];
+    return AM_OK;
+}
+
+extern "C" int am_multi_run_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, am_match** matches_out, size_t* n_out, uint64_t* total_records_out)
+{
+    if (!m || !autos || !hay || !matches_out || !n_out) return abi_fail(AM_ERR_INVALID, "null arguments");
+    *matches_out = nullptr; *n_out = 0;
+    const int n = (int)m->devs.size();
+    std::vector<am_matches*> res(n, nullptr);
+    struct Free { std::vector<am_matches*>& r; ~Free() { for (am_matches* x : r) am_matches_free(x); } } free_results{res};
+    const int local = per_device(m, [&](int i) -> int {
+        uint64_t lo, hi; range_of(hay->len, m->first_rank + i, m->world, &lo, &hi);
+        AM_TRY(am_run_range(autos[i], case_mode, hay, lo, hi, &res[i]));
+        return am_matches_data(res[i]) || am_matches_size(res[i]) == 0 ? AM_OK : AM_ERR_HIP;      // D2H on the device's own thread
+    });
+    std::vector<uint64_t> sizes(n, 0);
+    if (local == AM_OK) for (int i = 0; i < n; i++) sizes[i] = am_matches_size(res[i]);
+    size_t total = 0;
+    for (int i = 0; i < n; i++) total += (size_t)sizes[i];
+    AM_TRY(allreduce_flagged(m, sizes.data(), 1, local));                 // (every rank enters it, whatever happened locally)
+    am_match* all = (am_match*)std::malloc((total ? total : 1) * sizeof(am_match));
+    if (!all) return abi_fail(AM_ERR_OOM, "malloc(matches) failed");
+    size_t at = 0;
+    for (int i = 0; i < n; i++) {                                         // the local devices' ranges follow each other: position order
+        const size_t k = (size_t)am_matches_size(res[i]);
+        if (k) std::memcpy(all + at, am_matches_data(res[i]), k * sizeof(am_match));
+        at += k;
+    }
+    *matches_out = all; *n_out = total;
+    if (total_records_out) *total_records_out = sizes[0];
+    return AM_OK;
+}

@@ -22,6 +22,8 @@ HAYSTACK_SEED = 0xA1F2ED02
 WORKLOADS = {
     # name: (n_needles, case, haystack_bytes, n_haystacks, mixed_case)
     "cfg2_runText_10k_1GiB": dict(n_needles=10_000, case=api.CASE_SENSITIVE, hay_bytes=64 << 10, n_hay=16384, mixed=False),
+    # SURVEY 8d shape (i) of configs[1]: the same gibibyte as ONE haystack (the reference scans one Text of any size, Automaton.hs:468-480)
+    "cfg2_single_1GiB": dict(n_needles=10_000, case=api.CASE_SENSITIVE, hay_bytes=1 << 30, n_hay=1, mixed=False),
     "cfg3_runLower_100k_10GiB": dict(n_needles=100_000, case=api.IGNORE_CASE, hay_bytes=1 << 20, n_hay=10240, mixed=True),
     "cfg4_100k_1M_haystacks": dict(n_needles=100_000, case=api.IGNORE_CASE, hay_bytes=100 << 10, n_hay=1 << 20, mixed=True, sharded_total=True),
     "cfg5_replacer_50k_1GiB": dict(n_needles=50_000, case=api.CASE_SENSITIVE, hay_bytes=64 << 10, n_hay=16384, mixed=False),

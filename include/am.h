@@ -125,6 +125,17 @@ int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n
 int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
 int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out);
 
+/* ---- ONE haystack in ranges (the reference folds one Text of any size, Automaton.hs:468-480) --
+ * am_run_range:   the records of runWithCase on `hay` whose end position lies in (lo, hi], 0 <= lo <= hi <= hay->len; end_pos relative to the
+ *                 whole slice, haystack = 0.  Only a window of the text is uploaded and scanned: the range plus, before it, 4 bytes per code
+ *                 point of the longest needle (whether a needle ends at a position depends only on one maximal match before it), both ends on
+ *                 code point boundaries.  Ranges that partition (0, len] give, concatenated, exactly the records of am_run on the whole
+ *                 haystack: that is how am_multi_run_single spreads one document over several GPUs, and how a caller scans a document
+ *                 larger than device memory.
+ * am_count_range: countMatches (benchmark/haskell/app/Main.hs:67-76) over the same positions. */
+int am_run_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, am_matches** out);
+int am_count_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, uint64_t* count_out);
+
 /* ---- device-resident batches (bulk callers; what bench.py times) ----------------------------- */
 int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out);
 /* Borrow a batch that already lives in HBM: d_bytes = concatenated haystacks (16-byte aligned,
@@ -251,8 +262,8 @@ int am_multi_device(const am_multi* m, int i);     /* HIP device id of local dev
 /* ncclBroadcast of the flattened image of `a` (held by global rank `root`; NULL in processes that do not hold the
  * root) to every device; autos_out[i] = a handle on local device i attached to its copy (am_automaton_destroy each). */
 int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out);
-/* ncclAllReduce(sum) of `count` (<= 511) uint64 per device: values = local_devices x count, row i belongs to local
- * device i; every row holds the sums afterwards (511 values at most). */
+/* ncclAllReduce(sum) of `count` (<= 512) uint64 per device: values = local_devices x count, row i belongs to local
+ * device i; every row holds the sums afterwards. */
 int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count);
 /* This process's haystacks cut into contiguous blocks, one per local device (block i = haystacks [n*i/D, n*(i+1)/D)),
  * scanned concurrently; counts_out (nullable) per haystack in order; *total_out = sum over ALL devices (all-reduce):
@@ -276,6 +287,16 @@ int am_multi_batch_upload(const am_multi* m, int local_device, const am_slice* h
 int am_multi_count_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, uint64_t* const* counts_out,
                          uint64_t* local_totals_out, uint64_t* total_out);
 int am_multi_run_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, am_matches** results_out, uint64_t* total_records_out);
+
+/* ONE haystack on all devices ("a single huge haystack splits into G ranges with maxNeedleCodePoints overlap"; BASELINE configs[1]
+ * shape (i), 1 x 1 GiB): global device g of W owns the end positions in (len * g / W, len * (g + 1) / W] (am_run_range on its own device).
+ * Every process passes the WHOLE haystack; each device uploads only its window of it.
+ *   am_multi_count_single  local_counts_out (nullable): one count per local device; *total_out: the whole haystack (all-reduce)
+ *   am_multi_run_single    *matches_out = the records of this process's ranges in position order (haystack = 0, end_pos relative to the whole
+ *                          haystack; am_multi_matches_free); with one process per GPU the launcher concatenates the ranks' arrays in rank
+ *                          order.  *total_records_out (nullable) = records on all devices. */
+int am_multi_count_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, uint64_t* local_counts_out, uint64_t* total_out);
+int am_multi_run_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, am_match** matches_out, size_t* n_out, uint64_t* total_records_out);
 
 /* ---- multi-GPU: move the flattened automaton between devices -----------------------------------
  * The image is one position-independent blob, so rank 0 flattens once and the blob is broadcast

@@ -109,6 +109,29 @@ int main(int argc, char** argv)
         free(batches); free(res); free(dcounts); free(local_totals);
         if (!ok) return 1;
     }
+    /* ONE haystack on all D devices: the whole text as a single document, cut into D ranges with one maximal match of overlap;
+       the ranges' records, concatenated, and the all-reduced count must equal a one-device scan of the same document (autos[0], am_run / am_count) */
+    {
+        am_slice doc; doc.ptr = text; doc.off = 0; doc.len = nh;
+        am_matches* whole = NULL;
+        check(am_run(autos[0], case_mode, &doc, 1, &whole), "am_run (whole document)");
+        const size_t kw = (size_t)am_matches_size(whole);
+        const am_match* wsrc = kw ? am_matches_data(whole) : NULL;
+        uint64_t count_whole = 0, count_single = 0, nrec_all = 0;
+        check(am_count(autos[0], case_mode, &doc, 1, &count_whole), "am_count (whole document)");
+        uint64_t* local_counts = (uint64_t*)calloc((size_t)D, sizeof(uint64_t));
+        check(am_multi_count_single(m, autos, case_mode, &doc, local_counts, &count_single), "am_multi_count_single");
+        am_match* srecs = NULL; size_t ks = 0;
+        check(am_multi_run_single(m, autos, case_mode, &doc, &srecs, &ks, &nrec_all), "am_multi_run_single");
+        int ok = count_single == count_whole && ks == kw && nrec_all == (uint64_t)kw;
+        uint64_t sum_local = 0;
+        for (int i = 0; i < D; i++) sum_local += local_counts[i];
+        ok = ok && sum_local == count_whole;
+        for (size_t j = 0; j < kw && ok; j++) ok = srecs[j].haystack == 0 && srecs[j].end_pos == wsrc[j].end_pos && srecs[j].state == wsrc[j].state;
+        printf("single %s (%llu records, %llu matches)\n", ok ? "ok" : "MISMATCH", (unsigned long long)kw, (unsigned long long)count_whole);
+        am_multi_matches_free(srecs); am_matches_free(whole); free(local_counts);
+        if (!ok) return 1;
+    }
     am_multi_matches_free(recs);
     for (int i = 0; i < D; i++) am_automaton_destroy(autos[i]);
     am_automaton_destroy(a);

@@ -222,3 +222,31 @@ def test_contains_any_stops_at_the_first_match():
     exp = [bool(o2.contains_any(am.IGNORE_CASE, h)) for h in hays]
     assert exp == [True, True, False, False, True]
     assert [bool(g) for g in got] == exp
+
+
+def test_cfg2_single_haystack_equals_the_oracle():
+    """BASELINE configs[1], SURVEY 8d shape (i): ONE large haystack (here 64 MiB of the 1-GiB workload `cfg2_single_1GiB`; the reference scans a
+    Text of any size in one fold, Automaton.hs:468-480).  Every (matchPos, value) of the fold against the oracle, and the general kernel on
+    the same document."""
+    import torch
+    w = synth.WORKLOADS["cfg2_single_1GiB"]
+    needles = synth.needles_for("cfg2_single_1GiB")
+    assert len(needles) == 10_000 and w["n_hay"] == 1
+    a, o = am.Automaton(needles), oracle.Machine(needles)
+    n_bytes = 64 << 20
+    dev = torch.device("cuda:0")
+    text, _ = synth.haystacks_device(needles, w["mixed"], 0, n_bytes // synth.CELL, dev)
+    offs = torch.tensor([0, n_bytes], dtype=torch.int64, device=dev)
+    out = {}
+    for k in (2, 1):
+        a.set_kernel(k)
+        out[k], _ = _run_device(a, w["case"], text.data_ptr(), offs.data_ptr(), 1, n_bytes)
+    a.set_kernel(0)
+    assert out[1].tobytes() == out[2].tobytes()
+    recs = out[2]
+    assert len(recs) > 64 * 1024 and not recs["haystack"].any()
+    assert np.all(recs["end_pos"][1:] > recs["end_pos"][:-1]) and int(recs["end_pos"][-1]) > (63 << 20)      # positions are 64-bit offsets into the ONE document
+    pos, val = o.run_list(w["case"], text[:n_bytes].cpu().numpy())
+    got = expand_records(o.values_off(), o.values(), recs["haystack"], recs["state"], recs["end_pos"])
+    assert len(got) == len(pos)
+    assert got == [(0, int(p), int(v)) for p, v in zip(pos, val)]

@@ -790,3 +790,40 @@ def test_replacer_compose_property():
             o12 = oracle.Replacer(case, p1 + p2)
             assert r12.run_batch(hays) == [o12.run(h) for h in hays]
         assert am.Replacer.compose(am.Replacer(0, p1), am.Replacer(1, p2)) is None
+
+
+def test_run_range_partitions_equal_the_whole_scan():
+    """am_run_range / am_count_range (one haystack in ranges with a one-match overlap): ranges that partition (0, len] give,
+    concatenated, the records of am_run on the whole haystack -- positions relative to the whole document, cuts inside multi-byte code points,
+    IgnoreCase with code points that are longer than what they lower to (K -> k), the empty needle (a record at almost every position)."""
+    lib = am.libam()
+    rng = random.Random(5)
+    cases = []
+    needles = synth.needles_for("cfg3_runLower_100k_10GiB")[:5000]
+    cases.append((needles, bytes(synth.haystacks_host(needles, True, 3, 300)), 1))
+    cases.append((["k", "kk", "åk", "ß", "straße"], ("KKk ÅK Straße ẞ " * 3000).encode(), 1))
+    cases.append((["a", "ab", "", "bab"], ("abab baba " * 2000).encode(), 0))
+    for needles, text, case in cases:
+        a = am.Automaton(needles)
+        whole = a.run_records(case, [text])
+        total = int(a.count_matches(case, [text])[0])
+        n = len(text)
+        buf = C.create_string_buffer(text, n + 1)
+        sl = am.api.Slice(C.addressof(buf), 0, n)
+        for world in (1, 2, 3, 7):
+            cuts = [0] + sorted(rng.randint(0, n) for _ in range(world - 1)) + [n]
+            parts, counts = [], 0
+            for lo, hi in zip(cuts[:-1], cuts[1:]):
+                m = C.c_void_p()
+                am.check(lib.am_run_range(a.device, case, C.byref(sl), lo, hi, C.byref(m)))
+                parts.append(am.api.matches_to_numpy(m))
+                lib.am_matches_free(m)
+                c = C.c_uint64(0)
+                am.check(lib.am_count_range(a.device, case, C.byref(sl), lo, hi, C.byref(c)))
+                counts += int(c.value)
+                assert all(lo < int(e) <= hi for e in parts[-1]["end_pos"][:50])
+            got = np.concatenate(parts)
+            assert got.tobytes() == whole.tobytes(), (world, cuts)
+            assert counts == total
+        m = C.c_void_p()
+        assert lib.am_run_range(a.device, case, C.byref(sl), 5, n + 1, C.byref(m)) == am.AM_ERR_INVALID

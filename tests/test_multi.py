@@ -77,6 +77,10 @@ def test_multi_driver_same_answer_for_any_device_count(tmp_path, n_devices):
     assert got == oracle_triples(m, 1, hays) and k > 100
     # the device-resident entry points (am_multi_batch_upload / am_multi_count_batch / am_multi_run_batch) gave the same job the same answer
     assert lines[4 + k] == "resident ok", lines[4 + k:]
+    # ONE haystack (the whole text as a single document) cut into n_devices ranges: am_multi_run_single / am_multi_count_single == a one-device
+    # scan of the document, and that count is the oracle's for the document
+    assert lines[5 + k].startswith("single ok"), lines[5 + k:]
+    assert int(lines[5 + k].split("(")[1].split()[2]) == m.count_matches(1, bytes(text))
 
 
 @pytest.mark.gpu
