@@ -135,7 +135,8 @@ struct ThreadState {
     // the thread's stream and the results come back the same way -- a call costs one stream synchronisation, not four blocking copies
     uint8_t* pin = nullptr; size_t pin_cap = 0;          // upload staging (two halves that take turns for inputs above kPinPiece)
     uint8_t* pin_res = nullptr; size_t pin_res_cap = 0;  // results
-    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr}; int pin_ev_dev = -1;      // (events belong to the device they were made on)
+    bool pins_adopted = false;                           // looked for an ended thread's pinned buffers and events already
     ~ThreadState();
 };
 thread_local ThreadState tl_state;
@@ -156,13 +157,18 @@ int get_stream(int dev, hipStream_t* st)
 constexpr size_t kSmallUpload = 4u << 20;       // one-shot batches up to this size take the pinned single-copy path
 constexpr size_t kPinPiece = 256u << 10;        // above this the gather into pinned memory and the DMA of the previous piece overlap
 
+void adopt_pins();
+int pin_events(int dev);
+std::atomic<size_t> g_pinned_staging_bytes{0};           // page-locked staging memory of all threads, living or parked (am_debug_pinned_bytes: the leak test)
 int pin_ensure(uint8_t*& p, size_t& cap, size_t need)
 {
+    if (!tl_state.pins_adopted) adopt_pins();             // the page-locked buffers of a thread that has ended, before any new ones are made
     if (need <= cap) return AM_OK;
-    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    if (p) { (void)hipHostFree(p); g_pinned_staging_bytes.fetch_sub(cap, std::memory_order_relaxed); p = nullptr; cap = 0; }
     const size_t want = need + need / 4 + 4096;
     if (hipHostMalloc((void**)&p, want, hipHostMallocPortable) != hipSuccess) { p = nullptr; (void)hipGetLastError(); return fail(AM_ERR_OOM, "hipHostMalloc(pinned staging) failed"); }
     cap = want;
+    g_pinned_staging_bytes.fetch_add(want, std::memory_order_relaxed);
     return AM_OK;
 }
 
@@ -299,6 +305,11 @@ struct Orphans {
     std::mutex mu;
     std::vector<hipStream_t> streams[kMaxDev];
     std::vector<am_batch*> batches[kMaxDev];
+    // page-locked staging of ended threads (am_multi_* and the Replacer's group threads start fresh threads per call: without this every
+    // call left ~0.3 .. 20 MiB of page-locked host memory behind per device -- ADVICE r3)
+    struct Pins { uint8_t* pin; size_t pin_cap; uint8_t* pin_res; size_t pin_res_cap; };
+    std::vector<Pins> pins;
+    std::vector<hipEvent_t> events[kMaxDev];
 };
 Orphans& orphans() { static Orphans* o = new Orphans(); return *o; }      // never destroyed: no static-destruction order to worry about
 hipStream_t adopt_stream(int dev)
@@ -318,6 +329,33 @@ am_batch* adopt_batch(int dev)
     return b;
 }
 
+void adopt_pins()
+{
+    tl_state.pins_adopted = true;
+    if (tl_state.pin || tl_state.pin_res) return;
+    Orphans& o = orphans();
+    std::lock_guard<std::mutex> lk(o.mu);
+    if (o.pins.empty()) return;
+    const Orphans::Pins p = o.pins.back(); o.pins.pop_back();
+    tl_state.pin = p.pin; tl_state.pin_cap = p.pin_cap; tl_state.pin_res = p.pin_res; tl_state.pin_res_cap = p.pin_res_cap;
+}
+
+// the calling thread's two staging events, on device `dev` (events of an ended thread are taken over; a thread that moves to another device
+// leaves its old ones for that device's next user)
+int pin_events(int dev)
+{
+    if (tl_state.pin_ev[0] && tl_state.pin_ev_dev == dev) return AM_OK;
+    {
+        Orphans& o = orphans();
+        std::lock_guard<std::mutex> lk(o.mu);
+        if (tl_state.pin_ev[0] && tl_state.pin_ev_dev >= 0) { o.events[tl_state.pin_ev_dev].push_back(tl_state.pin_ev[0]); o.events[tl_state.pin_ev_dev].push_back(tl_state.pin_ev[1]); }
+        tl_state.pin_ev[0] = tl_state.pin_ev[1] = nullptr; tl_state.pin_ev_dev = dev;
+        for (int k = 0; k < 2 && !o.events[dev].empty(); k++) { tl_state.pin_ev[k] = o.events[dev].back(); o.events[dev].pop_back(); }
+    }
+    AM_TRY(pin_events(dev));
+    return AM_OK;
+}
+
 ThreadState::~ThreadState()
 {
     Orphans& o = orphans();
@@ -326,7 +364,9 @@ ThreadState::~ThreadState()
         if (oneshot[d]) { o.batches[d].push_back(oneshot[d]); oneshot[d] = nullptr; }
         if (own[d]) { o.streams[d].push_back(own[d]); own[d] = nullptr; }
     }
-    // the pinned buffers and events of an ended thread are left to the process (a thread-exit destructor must not call into HIP)
+    // the pinned buffers and events wait for the next new thread, too (a thread-exit destructor must not call into HIP, so they are not freed)
+    if (pin || pin_res) { o.pins.push_back(Orphans::Pins{pin, pin_cap, pin_res, pin_res_cap}); pin = pin_res = nullptr; }
+    for (int k = 0; k < 2; k++) if (pin_ev[k] && pin_ev_dev >= 0) { o.events[pin_ev_dev].push_back(pin_ev[k]); pin_ev[k] = nullptr; }
 }
 }  // namespace
 
@@ -582,7 +622,7 @@ static int upload_slices(const am_slice* hay, size_t n_hay, am_batch* b, bool on
             gather(0, padded, pin + text_off);
             HIP_TRY(hipMemcpyAsync(b->combo.p, pin, bytes, hipMemcpyHostToDevice, st));
         } else {
-            for (int k = 0; k < 2; k++) if (!tl_state.pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&tl_state.pin_ev[k], hipEventDisableTiming));
+            AM_TRY(pin_events(b->dev));
             HIP_TRY(hipMemcpyAsync(b->combo.p, pin, text_off, hipMemcpyHostToDevice, st));
             bool used[2] = {false, false};
             int turn = 0;
@@ -1293,7 +1333,7 @@ static int fetch_through_pinned(void* dst, const void* d_src, size_t bytes, int 
 {
     hipStream_t st; AM_TRY(get_stream(dev, &st));
     AM_TRY(pin_ensure(tl_state.pin, tl_state.pin_cap, 2 * kFetchPiece));
-    for (int k = 0; k < 2; k++) if (!tl_state.pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&tl_state.pin_ev[k], hipEventDisableTiming));
+    AM_TRY(pin_events(dev));
     // pieces of an eighth of the result (256 KiB .. 8 MiB): a result of a few MiB still overlaps its copy-out with the transfer
     size_t piece = (bytes / 8 + 4095) & ~(size_t)4095;
     if (piece < ((size_t)256 << 10)) piece = (size_t)256 << 10;
@@ -1438,6 +1478,8 @@ extern "C" int am_debug_set(const char* name, long value)
     if (!name || !cfg::set(name, value)) return fail(AM_ERR_INVALID, "no such switch");
     return AM_OK;
 }
+
+extern "C" uint64_t am_debug_pinned_bytes(void) { return (uint64_t)g_pinned_staging_bytes.load(std::memory_order_relaxed); }
 
 extern "C" int am_debug_sfx_roles(uint64_t* out24)
 {

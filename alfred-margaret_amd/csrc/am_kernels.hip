@@ -659,6 +659,7 @@ __global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __re
     const uint4* pool4 = reinterpret_cast<const uint4*>(o.pool);
     uint4* out4 = reinterpret_cast<uint4*>(out);
     for (uint32_t done = 0; done < n; done += kPoolBlock) {
+        if (blk == kNone) break;                           // (a chain shorter than its slot count: only after a pool overflow, whose result the host discards)
         uint4 r = make_uint4(0u, 0u, 0u, kNone);
         if (done + lane < n) r = pool4[(uint64_t)blk * kPoolBlock + lane];
         const uint64_t m = __ballot(r.w != kNone);

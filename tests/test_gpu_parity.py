@@ -827,3 +827,22 @@ def test_run_range_partitions_equal_the_whole_scan():
             assert counts == total
         m = C.c_void_p()
         assert lib.am_run_range(a.device, case, C.byref(sl), 5, n + 1, C.byref(m)) == am.AM_ERR_INVALID
+
+
+def test_threads_started_per_call_do_not_leak_pinned_memory():
+    """ADVICE r3: the Replacer's group threads (and am_multi's per-device threads) are fresh std::threads on every call; their page-locked
+    staging buffers are parked when a thread ends and taken over by the next new thread, so repeated calls do not grow page-locked memory."""
+    fn = am.libam().am_debug_pinned_bytes
+    fn.restype, fn.argtypes = C.c_uint64, []
+    rng = random.Random(9)
+    pairs = [("".join(rng.choice("abcd") for _ in range(3)), "".join(rng.choice("XY") for _ in range(rng.randint(0, 3)))) for _ in range(20)]
+    hays = ["".join(rng.choice("abcd ") for _ in range(rng.choice((50, 900, 4000)))) for _ in range(120)]
+    am.debug_set("AM_RP_GROUPS", 3)
+    r, o = am.Replacer(0, pairs), oracle.Replacer(0, pairs)
+    exp = [o.run(h) for h in hays]
+    seen = []
+    for it in range(8):
+        assert r.run_batch(hays) == exp
+        seen.append(int(fn()))
+    assert seen[-1] == seen[2], seen                     # flat after the first calls (the pool of parked buffers has reached its size)
+    assert seen[-1] < (256 << 20)
