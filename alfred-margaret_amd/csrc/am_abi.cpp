@@ -955,7 +955,7 @@ static int run_records(const am_automaton* a, int case_mode, am_batch* b, const 
     AM_TRY(b->unit_offsets.ensure(n * sizeof(uint64_t)));
     AM_TRY(b->small.ensure(64));
     size_t tmp_bytes = 0;
-    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
     Record* d_records = nullptr;
     // general kernel: count pass -> exclusive scan -> emit pass (unit = one lane's chunk)
@@ -1073,7 +1073,7 @@ static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, 
     AM_TRY(b->small.ensure(64));
     AM_TRY(b->unit_first.ensure(2 * p.n_units * sizeof(uint32_t)));
     size_t tmp_bytes = 0;
-    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
     uint64_t want_blocks = b->total / (128 * kPoolBlock) + p.n_units + 1024 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);
     if (b->pool.cap / (kPoolBlock * sizeof(Record)) > want_blocks) want_blocks = b->pool.cap / (kPoolBlock * sizeof(Record));
@@ -1726,7 +1726,7 @@ static int run_records_async(const am_automaton* a, int case_mode, am_batch* b, 
     AM_TRY(b->small.ensure(64));
     AM_TRY(b->unit_first.ensure(2 * p.n_units * sizeof(uint32_t)));
     size_t tmp_bytes = 0;
-    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    if (scan_temp_bytes(n, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
     AM_TRY(b->scan_tmp.ensure(tmp_bytes + 16));
     const uint64_t want_blocks = b->total / kPoolBlock + p.n_units + 8 + pool_grant_slack(p.n_cu, p.n_units, sf_lds_bytes(p.sf) <= 80 * 1024);          // ceil(records / 64) per unit, records <= bytes; + the grants' unused remainders
     if (want_blocks >= (1ull << 26)) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call (2^32 record slots); split the batch");      // k_sf addresses record slots with 32 bits
@@ -1774,7 +1774,7 @@ static int rp_fold(RpSession& s, const am_replacer* r, bool ic, const uint8_t* t
             AM_TRY(s.pf_selflag.ensure(nb * 4)); AM_TRY(s.pf_sidx.ensure(nb * 8)); AM_TRY(s.pf_cand.ensure(nb * sizeof(RpSel))); AM_TRY(s.pf_sel.ensure(nb * sizeof(RpSel)));
             AM_TRY(s.pf_keep.ensure(nb * 4)); AM_TRY(s.pf_kflag.ensure(nb * 4)); AM_TRY(s.pf_kdelta.ensure(nb * 8)); AM_TRY(s.pf_kidx.ensure(nb * 8)); AM_TRY(s.pf_kdpre.ensure(nb * 8));
             size_t t32b = 0, t64b = 0;
-            if (scan_temp_bytes(nb, &t32b) != hipSuccess || scan64_temp_bytes(nb, &t64b) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+            if (scan_temp_bytes(nb, &t32b) != hipSuccess || scan64_temp_bytes(nb, &t64b) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
             AM_TRY(s.pf_tmp.ensure(std::max(t32b, t64b) + 16));
             const size_t ptmp = s.pf_tmp.cap - 16;
             HIP_TRY(hipMemsetAsync(s.pf_delta.p, 0, n1 * 8, st)); HIP_TRY(hipMemsetAsync(s.pf_payload.p, 0, n1 * 4, st));
@@ -1912,7 +1912,7 @@ int replacer_run_pt(const am_replacer* r, const am_batch* in, uint64_t max_lengt
         AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8)); AM_TRY(s.pt_need.ensure(n1 * 4)); AM_TRY(s.pt_need_off.ensure(n1 * 8));
         AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
         size_t t32 = 0, t64 = 0, tw = 0;
-        if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess || scan_temp_bytes(n_rec + 2, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+        if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess || scan_temp_bytes(n_rec + 2, &tw) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
         AM_TRY(s.scan_tmp.ensure(std::max(std::max(t32, t64), tw) + 16));
         const size_t tmp2 = s.scan_tmp.cap - 16;
         AM_TRY(records.ensure(sizeof(Record)));
@@ -2216,7 +2216,7 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         AM_TRY(s.len_next.ensure(n1 * 8)); AM_TRY(s.len_fin.ensure(n1 * 8)); AM_TRY(s.tiles.ensure(n1 * 4)); AM_TRY(s.act.ensure(n1 * 4)); AM_TRY(s.fin.ensure(n1 * 4));
         AM_TRY(s.off_next.ensure(n1 * 8)); AM_TRY(s.off_fin.ensure(n1 * 8)); AM_TRY(s.tile_off.ensure(n1 * 8)); AM_TRY(s.act_idx.ensure(n1 * 8)); AM_TRY(s.fin_idx.ensure(n1 * 8));
         size_t t32 = 0, t64 = 0;
-        if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+        if (scan_temp_bytes(n1, &t32) != hipSuccess || scan64_temp_bytes(n1, &t64) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
         const size_t tmp_bytes = t32 > t64 ? t32 : t64;
         AM_TRY(s.scan_tmp.ensure(tmp_bytes + 16));
         AM_TRY(records.ensure(sizeof(Record)));            // a valid pointer even when nothing matched
@@ -2226,14 +2226,14 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
         RpRouted rt{(const uint64_t*)s.off_next.p, (const uint64_t*)s.off_fin.p, (const uint64_t*)s.tile_off.p, (const uint64_t*)s.act_idx.p, (const uint64_t*)s.fin_idx.p};
         // windows of the incremental re-scan (their geometry follows from the kept matches alone, the text is copied after the splice)
         const bool try_inc = inc_enabled && n_rec > 0;
-        const bool small = n1 <= (1u << 18);          // bookkeeping sums in one launch (k_scan_jobs) instead of a dozen hipcub launches
+        const bool small = n1 <= (1u << 18);          // bookkeeping sums in one launch (k_scan_jobs) instead of a dozen scan launches
         size_t tmp2 = tmp_bytes;
         uint64_t woffs_last = n_rec;
         if (try_inc) {
             AM_TRY(s.nwin.ensure(n1 * 4)); AM_TRY(s.win_off.ensure(n1 * 8));
             AM_TRY(s.wins.ensure((n_rec + 1) * sizeof(RpWin))); AM_TRY(s.wlen.ensure((n_rec + 2) * 4)); AM_TRY(s.woffs.ensure((n_rec + 2) * 8));
             size_t tw = 0;
-            if (scan_temp_bytes(n_rec + 1, &tw) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+            if (scan_temp_bytes(n_rec + 1, &tw) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
             AM_TRY(s.scan_tmp.ensure(std::max(tw, tmp_bytes) + 16));
             tmp2 = s.scan_tmp.cap - 16;
             HIP_TRY(launch_rp_win_count((const RpHay*)s.hs.p, n_act, (uint32_t*)s.nwin.p, st));
@@ -2505,7 +2505,7 @@ extern "C" int am_run_priority(const am_replacer* r, const am_slice* hay, size_t
     AM_TRY(rec_first.ensure(n1 * 8)); AM_TRY(kept.ensure((n_rec + 1) * sizeof(RpKept))); AM_TRY(hs.ensure(n1 * sizeof(RpHay)));
     AM_TRY(nk.ensure(n1 * 4)); AM_TRY(off.ensure(n1 * 8)); AM_TRY(thr.ensure(n1 * 8)); AM_TRY(best.ensure(n1 * 8));
     size_t tmp_bytes = 0;
-    if (scan_temp_bytes(n1, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "hipcub scan sizing failed");
+    if (scan_temp_bytes(n1, &tmp_bytes) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
     AM_TRY(tmp.ensure(tmp_bytes + 16));
     HIP_TRY(hipMemcpyAsync(thr.p, thresholds, (size_t)n * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync((uint32_t*)nk.p + n, 0, 4, st));

@@ -17,7 +17,6 @@
 // No MFMA anywhere: this is integer pointer chasing; the roofline is HBM bandwidth
 // (1 B read per haystack byte + 16 B per record).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <atomic>
 #include <cstdlib>
@@ -882,32 +881,6 @@ hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, con
     if (mode == kModeCount) return launch_ac_t<false, kModeCount>(a, b, o, st);
     if (mode == kModeEmit) return launch_ac_t<false, kModeEmit>(a, b, o, st);
     return launch_ac_t<false, kModeAny>(a, b, o, st);
-}
-
-// exclusive prefix sum of n u32 counts into n u64 offsets (n includes the trailing zero pad, so
-// offsets[n-1] is the total)
-struct CastU64 { __host__ __device__ uint64_t operator()(uint32_t x) const { return x; } };
-
-hipError_t scan_temp_bytes(uint64_t n, size_t* bytes)
-{
-    // the sizing call costs several microseconds of host time (device queries inside the library) and is made on every launch path: the size
-    // for a larger n always suffices, so one answer per power of two is remembered
-    static std::atomic<size_t> memo[40];
-    int k = 10; while (k < 39 && (1ull << k) < n) k++;
-    const size_t have = memo[k].load(std::memory_order_relaxed);
-    if (have) { *bytes = have; return hipSuccess; }
-    hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> in((const uint32_t*)nullptr, CastU64());
-    *bytes = 0;
-    const uint64_t n_up = (1ull << k) > 0x7FFFFFFFull ? 0x7FFFFFFFull : (1ull << k);
-    const hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, in, (uint64_t*)nullptr, (int)(n > n_up ? n : n_up), (hipStream_t)0);
-    if (e == hipSuccess && n <= n_up) memo[k].store(*bytes ? *bytes : 1, std::memory_order_relaxed);
-    return e;
-}
-
-hipError_t launch_scan(void* temp, size_t temp_bytes, const uint32_t* counts, uint64_t* offsets, uint64_t n, hipStream_t st)
-{
-    hipcub::TransformInputIterator<uint64_t, CastU64, const uint32_t*> in(counts, CastU64());
-    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, offsets, (int)n, st);
 }
 
 }  // namespace dev

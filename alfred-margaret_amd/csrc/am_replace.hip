@@ -17,7 +17,6 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstdlib>
-#include <hipcub/hipcub.hpp>
 
 #include "am_device.h"
 
@@ -1051,7 +1050,7 @@ hipError_t launch_fold_hash(const Record* recs, const uint64_t* rec_first, const
     return hipGetLastError();
 }
 
-// ---- several small exclusive sums in ONE launch (the Replacer's per-pass bookkeeping: a dozen hipcub launches otherwise).
+// ---- several small exclusive sums in ONE launch (the Replacer's per-pass bookkeeping: a dozen scan launches otherwise).
 // One 1024-thread workgroup per job walks its array in tiles of 4096 elements: 4 elements per thread, wave scan with
 // shuffles, wave totals through LDS, running carry.  Meant for arrays up to a few hundred thousand elements.
 __global__ void __launch_bounds__(1024) k_scan_jobs(ScanJobs jobs)
@@ -1109,24 +1108,6 @@ hipError_t launch_scan_jobs(const ScanJobs& jobs, hipStream_t st)
     if (jobs.n_jobs == 0) return hipSuccess;
     hipLaunchKernelGGL(k_scan_jobs, dim3(jobs.n_jobs), dim3(1024), 0, st, jobs);
     return hipGetLastError();
-}
-
-hipError_t scan64_temp_bytes(uint64_t n, size_t* bytes)
-{
-    static std::atomic<size_t> memo[40];             // (as scan_temp_bytes: one answer per power of two)
-    int k = 10; while (k < 39 && (1ull << k) < n) k++;
-    const size_t have = memo[k].load(std::memory_order_relaxed);
-    if (have) { *bytes = have; return hipSuccess; }
-    *bytes = 0;
-    const uint64_t n_up = (1ull << k) > 0x7FFFFFFFull ? 0x7FFFFFFFull : (1ull << k);
-    const hipError_t e = hipcub::DeviceScan::ExclusiveSum(nullptr, *bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)(n > n_up ? n : n_up), (hipStream_t)0);
-    if (e == hipSuccess && n <= n_up) memo[k].store(*bytes ? *bytes : 1, std::memory_order_relaxed);
-    return e;
-}
-
-hipError_t launch_scan64(void* temp, size_t temp_bytes, const uint64_t* in, uint64_t* out, uint64_t n, hipStream_t st)
-{
-    return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, in, out, (int)n, st);
 }
 
 }  // namespace dev
