@@ -352,7 +352,7 @@ int pin_events(int dev)
         tl_state.pin_ev[0] = tl_state.pin_ev[1] = nullptr; tl_state.pin_ev_dev = dev;
         for (int k = 0; k < 2 && !o.events[dev].empty(); k++) { tl_state.pin_ev[k] = o.events[dev].back(); o.events[dev].pop_back(); }
     }
-    AM_TRY(pin_events(dev));
+    for (int k = 0; k < 2; k++) if (!tl_state.pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&tl_state.pin_ev[k], hipEventDisableTiming));
     return AM_OK;
 }
 
