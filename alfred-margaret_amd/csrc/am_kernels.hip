@@ -458,6 +458,8 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             uint4 next_v = make_uint4(0, 0, 0, 0);
             uint32_t next_c3 = 0, next_c4 = 0;
             const bool last_of_unit = ci + 1 >= n_in_unit;
+            uint32_t seen = 0;                             // flag mode: the flag word requested one chunk ago (taken BEFORE the next prefetch goes out:
+            if (MODE == kModeAny) seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_word);      // loads return in order, a wait after it would cover it)
             fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
             if (last_of_unit) fetch_before(u_next * UC, next_c3, next_c4);
 
@@ -476,7 +478,6 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
             bool skip = false;
             if (MODE == kModeAny) {
-                const uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_word);
                 skip = single && any_hay == hay0 && ((seen >> (8u * (hay0 & 3u))) & 0xFFu) != 0u;
                 any_word = __hip_atomic_load(reinterpret_cast<const uint32_t*>(o.flags) + (hay0 >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 any_hay = hay0;
