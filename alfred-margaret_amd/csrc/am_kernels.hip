@@ -439,12 +439,13 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     // containsAny stops at the first match (Searcher.hs:156-164: `Done True`; Automaton.hs:528-532): in flag mode a wavefront looks at the flag
     // of the haystack its chunk lies in -- as the whole device has left it, one chunk ago: the load has a chunk's time -- and skips the chunk
     // if it is set.  A 1-GiB document that matches in its first KiB costs a few chunks per wavefront, not the scan.
-    uint32_t any_word = 0, any_hay = kNone;
+    uint32_t any_word = 0, any_hay = kNone, flagged_hay = kNone;      // the flag word requested last, whose it is; the haystack known to be flagged
+    constexpr uint32_t kEpoch = MODE == kModeAny ? 4u : kSfEpochChunks;      // (flag mode drains its ring every 4 chunks: the first match is what everybody waits for)
     uint64_t u_next = u;
     for (; u < n_units; u = u_next) {
         // the unit after this one (its first chunk is prefetched while this unit's last chunk is processed)
         u_next = u + n_waves;
-        if (o.next_unit) {
+        if (o.next_unit && MODE != kModeAny) {                // (flag mode draws at the unit's last chunk, when it knows whether it goes on at all)
             uint32_t ticket = 0;
             if (lane == 0) ticket = atomicAdd(o.next_unit, 1u);
             u_next = n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
@@ -452,14 +453,47 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         unit_base_chunk = u * UC;
         unit_count = 0; unit_slots = 0; cur_block = kNone; first_block = kNone;
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
+        if (MODE == kModeAny && flagged_hay != kNone && hay0 == flagged_hay) {
+            // flag mode: a unit that lies inside a haystack known to be flagged is not looked at at all (only the next unit's first bytes are
+            // fetched); and when that haystack is the batch's last, the wavefront is done: units are handed out in ascending order, whatever it
+            // would get from here on lies behind this one (a draw from the unit counter costs more than skipping a unit does)
+            const uint64_t ub = unit_base_chunk * kSfChunk, ue0 = ub + (uint64_t)n_in_unit * kSfChunk, ue = ue0 < b.total ? ue0 : b.total;
+            if (ub >= hs0 && he0 >= b.total) break;
+            if (ub >= hs0 && ue <= he0) {
+                fetch(u_next * UC, cur_v);
+                fetch_before(u_next * UC, carry3, carry4);
+                asm volatile("" : "+v"(cur_v.x), "+v"(cur_v.y), "+v"(cur_v.z), "+v"(cur_v.w));
+                continue;
+            }
+        }
+        bool jumped = false;                                  // flag mode: the loop went from a skipped chunk to the unit's last one
         for (uint32_t ci = 0; ci < n_in_unit; ci++) {
             const uint64_t c = unit_base_chunk + ci;
-            if ((ci & (kSfEpochChunks - 1u)) == 0) epoch_base_chunk = c;
+            if ((ci & (kEpoch - 1u)) == 0 && !jumped) epoch_base_chunk = c;      // (after a jump the ring may still hold items of the epoch that was left)
             uint4 next_v = make_uint4(0, 0, 0, 0);
             uint32_t next_c3 = 0, next_c4 = 0;
             const bool last_of_unit = ci + 1 >= n_in_unit;
-            uint32_t seen = 0;                             // flag mode: the flag word requested one chunk ago (taken BEFORE the next prefetch goes out:
-            if (MODE == kModeAny) seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_word);      // loads return in order, a wait after it would cover it)
+            // flag mode: the flag word requested one chunk ago is looked at BEFORE the next prefetch goes out (loads return in order: a wait for
+            // it after the prefetch would cover the prefetch).  A chunk inside a haystack that is flagged is skipped -- and so will the next one be
+            // if it lies in the same haystack (known from the bracket of the chunk before): its bytes are not even requested.
+            if (MODE == kModeAny && any_hay != kNone) {
+                const uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_word);
+                if (((seen >> (8u * (any_hay & 3u))) & 0xFFu) != 0u) flagged_hay = any_hay;
+                any_hay = kNone;
+            }
+            if (MODE == kModeAny && last_of_unit) {
+                // the next unit: none when everything behind this one lies in a flagged haystack (the 1-GiB document that matches in its first KiB:
+                // 4096 draws from the unit counter would be 45 us, the rest of the launch is 20)
+                if (flagged_hay != kNone && flagged_hay == hay0 && he0 >= b.total && unit_base_chunk * kSfChunk >= hs0) u_next = n_units;
+                else if (o.next_unit) {
+                    uint32_t ticket = 0;
+                    if (lane == 0) ticket = atomicAdd(o.next_unit, 1u);
+                    u_next = n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+                }
+            }
+            const bool next_skipped = MODE == kModeAny && !last_of_unit && flagged_hay != kNone && flagged_hay == hay0 &&
+                                      (c + 1) * kSfChunk >= hs0 && (c + 2) * kSfChunk <= he0;
+            if (!next_skipped)
             fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
             if (last_of_unit) fetch_before(u_next * UC, next_c3, next_c4);
 
@@ -478,9 +512,19 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
             bool skip = false;
             if (MODE == kModeAny) {
-                skip = single && any_hay == hay0 && ((seen >> (8u * (hay0 & 3u))) & 0xFFu) != 0u;
-                any_word = __hip_atomic_load(reinterpret_cast<const uint32_t*>(o.flags) + (hay0 >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                any_hay = hay0;
+                skip = single && flagged_hay == hay0;
+                // ... and when the rest of the unit lies in that haystack too, the loop goes straight to the unit's last chunk (which is skipped
+                // like this one, drains what is pending and fetches the next unit's first chunk): a skipped chunk still costs half a filtered one
+                if (skip && ci + 2 < n_in_unit) {
+                    const uint64_t ue0 = (unit_base_chunk + n_in_unit) * kSfChunk;
+                    if ((ue0 < b.total ? ue0 : b.total) <= he0) { ci = n_in_unit - 2u; jumped = true; }
+                }
+                // the flag of this chunk's haystack as the whole device has left it: asked for every 8th chunk (4096 wavefronts polling one word
+                // on every chunk cost more than the scan: requests for one address are served one at a time), looked at one chunk later
+                if (!skip && (ci & 7u) == 0u) {
+                    any_word = __hip_atomic_load(reinterpret_cast<const uint32_t*>(o.flags) + (hay0 >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    any_hay = hay0;
+                }
             }
 
             uint32_t d1 = cur_v.x, d2 = cur_v.y, d3 = cur_v.z, d4 = cur_v.w;
@@ -586,7 +630,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                         p_pos[k] = valid[k] ? (pos | 0x8000u) : 0u;
                     }
                     sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
-                    p_ci = ci & (kSfEpochChunks - 1u);
+                    p_ci = ci & (kEpoch - 1u);
                     pending = true;
                     if (timing) { n_probes++; tick(t_probe_pre); }
                 }
@@ -595,14 +639,16 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             }
             cur_v = next_v; carry3 = next_c3; carry4 = next_c4;
             // end of an epoch (and of the unit): drain the ring, so that every item of a batch belongs to one epoch of one unit
-            if ((ci & (kSfEpochChunks - 1u)) == kSfEpochChunks - 1u || last_of_unit) {
+            if ((ci & (kEpoch - 1u)) == kEpoch - 1u || last_of_unit) {
                 if (pending) consume_round();                 // not overlapped: once per 16 chunks
                 wave_lds_fence();
                 tick(t_compact);
                 // (at the end of a unit the last call also walks every parked walker to the end: they all belong to this unit)
-                while (q2_tail != q2_head || (last_of_unit && wq_n)) {
+                // (flag mode walks them at the end of every epoch: a parked walker may be the match everybody is waiting for)
+                const bool walk_all = last_of_unit || MODE == kModeAny;
+                while (q2_tail != q2_head || (walk_all && wq_n)) {
                     const uint32_t left = q2_tail - q2_head, nb = left < 64u * RN ? left : 64u * RN;
-                    resolve_batch(nb, last_of_unit && left == nb);
+                    resolve_batch(nb, walk_all && left == nb);
                 }
                 tick(t_resolve);
             }
@@ -724,14 +770,19 @@ hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, h
 
 uint64_t sf_chunks(const BatchView& b) { return (b.total + kSfChunk - 1) / kSfChunk; }
 
-// chunks per work unit: 64 KiB units for big batches, smaller ones when that would leave wavefronts idle
+// chunks per work unit.  Big batches: 64-KiB units, four or more per wavefront, drawn from the unit counter (balance: see k_sf).  A draw is
+// a device-scope atomic on ONE word and the memory side serves those one at a time, ~11 ns each (measured in round 4: 16384 one-chunk units
+// of a 16-MiB batch took 0.196 ms, the same batch as 4096 four-chunk units without the counter takes a tenth of that; tools/any_exit.py).
+// So a draw has to be paid for by >= 32 chunks of work: up to 64 chunks per wavefront (256 MiB on 256 CUs) every wavefront gets ONE unit and
+// nothing is drawn; up to 256 the batch is cut into two or three units per wavefront of 33-64 chunks each.
 uint32_t sf_unit_chunks(const BatchView& b, int n_cu)
 {
-    const uint64_t n_chunks = sf_chunks(b), waves = (uint64_t)n_cu * kSfWaves * 4;      // (8 units per wavefront: -2 %, 16: -10 %: the unit counter's atomics)
-    uint64_t uc = n_chunks / (waves ? waves : 1);
-    if (uc < 1) uc = 1;
-    if (uc > kSfMaxUnitChunks) uc = kSfMaxUnitChunks;
-    return (uint32_t)uc;
+    const uint64_t n_chunks = sf_chunks(b), waves = (uint64_t)(n_cu > 0 ? n_cu : 1) * kSfWaves;
+    const uint64_t per_wave = (n_chunks + waves - 1) / waves;                     // chunks per wavefront
+    const uint64_t k = (per_wave + kSfMaxUnitChunks - 1) / kSfMaxUnitChunks;      // units per wavefront
+    if (k >= 4) return kSfMaxUnitChunks;      // (8 units per wavefront: -2 %, 16: -10 %: the unit counter's atomics)
+    const uint64_t uc = k <= 1 ? per_wave : (n_chunks + waves * k - 1) / (waves * k);
+    return (uint32_t)(uc < 1 ? 1 : uc);
 }
 
 hipError_t launch_permute(const ScanOut& o, const uint64_t* unit_offsets, Record* out, uint64_t n_units, hipStream_t st)
