@@ -1539,6 +1539,7 @@ struct am_replacer {
     int case_mode = 0;
     DevBuf vals_off, vals, payloads, repl;
     RpTables t{};
+    uint32_t max_repl_len = 0;                        // longest replacement (bounds the re-scan window of the one-kernel loop)
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
     // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
     mutable std::mutex session_mu;
@@ -1613,6 +1614,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
     ON_DEVICE(a->dev);
     const uint64_t n_states = f->h.n_states;
     if (!values_offsets || values_offsets[0] != 0) return fail(AM_ERR_INVALID, "values_offsets[0] must be 0");
+    uint32_t max_repl = 0;
     const uint64_t n_values = values_offsets[n_states];
     if ((n_values && !values) || (n_payloads && !payloads) || (n_repl_bytes && !repl_bytes)) return fail(AM_ERR_INVALID, "null table");
     for (uint64_t s = 0; s < n_states; s++) {
@@ -1626,6 +1628,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         std::vector<int64_t> pr(n_payloads);
         for (size_t i = 0; i < n_payloads; i++) {
             pr[i] = payloads[i].priority;
+            if (payloads[i].repl_len > max_repl) max_repl = payloads[i].repl_len;
             if (pr[i] > 0) return fail(AM_ERR_INVALID, "priorities must be <= 0 (the initial threshold is 1, Replacer.hs:211)");
             if ((uint64_t)payloads[i].repl_off + payloads[i].repl_len > n_repl_bytes) return fail(AM_ERR_INVALID, "replacement slice out of range");
             if (case_mode == AM_IGNORE_CASE && payloads[i].len_code_points == 0)
@@ -1635,7 +1638,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         for (size_t i = 1; i < n_payloads; i++) if (pr[i] == pr[i - 1]) return fail(AM_ERR_INVALID, "payload priorities must be distinct");
     }
     am_replacer* r = new am_replacer();
-    r->a = a; r->case_mode = case_mode;
+    r->a = a; r->case_mode = case_mode; r->max_repl_len = max_repl;
     auto up = [&](DevBuf& d, const void* src, size_t bytes) -> int {
         AM_TRY(d.ensure(bytes + 64));
         if (bytes) HIP_TRY(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
@@ -1684,11 +1687,24 @@ struct RpSession {
     am_batch ws;                         // workspace holder for the scans; never owns its text
     DevBuf first_orig, first_thr;
     DevBuf pt_pieces[2], pt_start[2], pt_cnt[2], pt_need, pt_need_off, pt_fin_start, pt_fin_cnt;      // piece-table path
+    DevBuf lp_rec, lp_pc, lp_kept, lp_wtext, lp_out, lp_ctrl, lp_cap_r, lp_cap_p, lp_rec_base, lp_pc_base, lp_fin, lp_fin_start, lp_fin_cnt;      // one-kernel loop (am_rploop.hip)
+    void* lp_host = nullptr; size_t lp_host_cap = 0;                        // pinned: the loop's per-haystack results, then the materialise tables
+    int pin_loop(size_t bytes)
+    {
+        if (bytes <= lp_host_cap) return AM_OK;
+        if (lp_host) (void)hipHostFree(lp_host);
+        lp_host = nullptr; lp_host_cap = 0;
+        const size_t want = bytes + bytes / 2 + 4096;
+        if (hipHostMalloc(&lp_host, want, hipHostMallocPortable) != hipSuccess) { lp_host = nullptr; return fail(AM_ERR_OOM, "hipHostMalloc failed"); }
+        lp_host_cap = want;
+        return AM_OK;
+    }
     DevBuf pf_best, pf_delta, pf_payload, pf_selflag, pf_sidx, pf_cand, pf_sel, pf_keep, pf_kflag, pf_kdelta, pf_kidx, pf_kdpre, pf_tmp;   // record-parallel fold
     size_t device_bytes() const
     {
         size_t n = 0;
-        for (const DevBuf* d : {&text[0], &text[1], &recbuf[0], &recbuf[1], &kept, &wins, &wtext, &wrec, &fin_text, &ws.pool, &ws2.pool, &ws.hidx, &ws2.hidx, &pf_cand, &pf_sel, &pf_sidx}) n += d->cap;
+        for (const DevBuf* d : {&text[0], &text[1], &recbuf[0], &recbuf[1], &kept, &wins, &wtext, &wrec, &fin_text, &ws.pool, &ws2.pool, &ws.hidx, &ws2.hidx, &pf_cand, &pf_sel, &pf_sidx,
+                                &lp_rec, &lp_pc, &lp_kept, &lp_wtext}) n += d->cap;
         return n;
     }
     ~RpSession()
@@ -1697,7 +1713,9 @@ struct RpSession {
                           &recbuf[0], &recbuf[1], &nwin, &win_off, &wins, &wlen, &woffs, &wtext, &wrec, &wrec_first, &mcount, &moff, &tile_hay,
                           &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr,
                           &pf_best, &pf_delta, &pf_payload, &pf_selflag, &pf_sidx, &pf_cand, &pf_sel, &pf_keep, &pf_kflag, &pf_kdelta, &pf_kidx, &pf_kdpre, &pf_tmp,
-                          &pt_pieces[0], &pt_pieces[1], &pt_start[0], &pt_start[1], &pt_cnt[0], &pt_cnt[1], &pt_need, &pt_need_off, &pt_fin_start, &pt_fin_cnt}) d->release();
+                          &pt_pieces[0], &pt_pieces[1], &pt_start[0], &pt_start[1], &pt_cnt[0], &pt_cnt[1], &pt_need, &pt_need_off, &pt_fin_start, &pt_fin_cnt,
+                          &lp_rec, &lp_pc, &lp_kept, &lp_wtext, &lp_out, &lp_ctrl, &lp_cap_r, &lp_cap_p, &lp_rec_base, &lp_pc_base, &lp_fin, &lp_fin_start, &lp_fin_cnt}) d->release();
+        if (lp_host) (void)hipHostFree(lp_host);
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
         if (copy_stream) { (void)hipStreamSynchronize(copy_stream); (void)hipStreamDestroy(copy_stream); }
@@ -2362,12 +2380,159 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
 
 }  // namespace
 
+// All passes of every haystack in ONE kernel (am_rploop.hip): a wavefront takes a haystack and runs its loop to the end.  *handled = false:
+// the batch is not for this path (or a haystack outgrew its regions) and nothing of `res` was touched: the caller takes the pass-by-pass paths.
+static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res, bool* handled)
+{
+    *handled = false;
+    const uint32_t n_hay = in->n_hay;
+    if (n_hay == 0 || in->dev != r->a->dev) return AM_OK;
+    const long sw = cfg::get(cfg::kRpLoop);
+    if (sw == 0) return AM_OK;
+    const Flavor* fl = nullptr;
+    AM_TRY(prepare(r->a, r->case_mode, &fl));
+    if (r->case_mode != AM_CASE_SENSITIVE || !fl->h.sf_enabled || fl->h.root_vlen != 0 || r->a->kernel_pref == 1) return AM_OK;
+    if (sw != 1) {
+        // unset: batches of many documents, and no switch that asks for one of the other loops
+        if (!(n_hay >= 64 && in->total / n_hay <= (1ull << 20))) return AM_OK;
+        for (cfg::Key k : {cfg::kRpFullScans, cfg::kRpSplice, cfg::kRpPieces, cfg::kRpParallelFold, cfg::kRpGroups, cfg::kRpNoFuse, cfg::kRpNoRangeReuse})
+            if (cfg::get(k) != cfg::kUnset) return AM_OK;
+    }
+    const uint32_t ov = 4u * (fl->h.max_needle_cps ? fl->h.max_needle_cps : 1u) + 4u;
+    const uint64_t wcap64 = ((2ull * ov + r->max_repl_len + 16ull) + 63ull) & ~63ull;
+    if (wcap64 > 4096 || wcap64 * n_hay > (1ull << 30) || in->total >= (1ull << 40)) return AM_OK;
+    ON_DEVICE(in->dev);
+    hipStream_t st; AM_TRY(get_stream(in->dev, &st));
+    RpSession* sp = nullptr;
+    { std::lock_guard<std::mutex> lk(r->session_mu); if (!r->sessions.empty()) { sp = static_cast<RpSession*>(r->sessions.back()); r->sessions.pop_back(); } }
+    if (!sp) sp = new RpSession();
+    struct Return {
+        const am_replacer* r; RpSession* sp;
+        ~Return()
+        {
+            if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
+            if (sp->device_bytes() > (2048ull << 20)) { delete sp; return; }
+            std::vector<RpSession*> doomed;
+            { std::lock_guard<std::mutex> lk(r->session_mu);
+              const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
+              r->sessions.push_back(sp);
+              for (;;) {
+                  size_t held = 0;
+                  for (void* q : r->sessions) held += static_cast<RpSession*>(q)->device_bytes();
+                  if (r->sessions.size() <= 1 || (r->sessions.size() <= 8 && held <= (4096ull << 20))) break;
+                  doomed.push_back(static_cast<RpSession*>(r->sessions.front()));
+                  r->sessions.erase(r->sessions.begin());
+              } }
+            for (RpSession* q : doomed) delete q;
+        }
+    } give_back{r, sp};
+    RpSession& s = *sp;
+    const bool trace = cfg::on(cfg::kRpTrace);
+    auto say = [&](const char* what) { if (trace) { (void)hipStreamSynchronize(st); std::fprintf(stderr, "[am_replacer loop] %s\n", what); std::fflush(stderr); } };
+    // the first (and only full) scan
+    say("first scan");
+    uint64_t n_rec = 0;
+    s.ws.dev = in->dev; s.ws.d_text = in->d_text; s.ws.d_offsets = in->d_offsets; s.ws.owns = false; s.ws.total = in->total; s.ws.n_hay = n_hay;
+    AM_TRY(finish_batch(&s.ws));
+    {
+        auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(s.recbuf[0].ensure((n + 1) * sizeof(Record))); *ptr = (Record*)s.recbuf[0].p; return AM_OK; };
+        AM_TRY(run_records(r->a, r->case_mode, &s.ws, sink, &n_rec));
+    }
+    if (n_rec >= (1ull << 26)) return AM_OK;                 // (the regions below would not fit: the pass-by-pass loop scans again)
+    const uint64_t n1 = (uint64_t)n_hay + 1;
+    const uint64_t rec_total = 4 * n_rec + 128ull * n_hay, pc_total = 8 * n_rec + 128ull * n_hay;      // = the sums of k_rp_loop_caps' region sizes
+    AM_TRY(s.recbuf[0].ensure(sizeof(Record)));
+    AM_TRY(s.rec_first.ensure(n1 * 8));
+    AM_TRY(s.lp_cap_r.ensure(n1 * 4)); AM_TRY(s.lp_cap_p.ensure(n1 * 4)); AM_TRY(s.lp_rec_base.ensure(n1 * 8)); AM_TRY(s.lp_pc_base.ensure(n1 * 8));
+    AM_TRY(s.lp_rec.ensure((rec_total + 1) * sizeof(Record))); AM_TRY(s.lp_pc.ensure((pc_total + 1) * sizeof(RpPiece)));
+    AM_TRY(s.lp_kept.ensure((rec_total / 2 + 1) * sizeof(RpKept)));
+    AM_TRY(s.lp_wtext.ensure(wcap64 * n_hay + 64)); AM_TRY(s.lp_out.ensure(n1 * sizeof(RpLoopOut))); AM_TRY(s.lp_ctrl.ensure(64));
+    size_t t32 = 0;
+    if (scan_temp_bytes(n1, &t32) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
+    AM_TRY(s.scan_tmp.ensure(t32 + 16));
+    { Prof pr("rp_ranges", st);
+      HIP_TRY(launch_rp_ranges((const Record*)s.recbuf[0].p, n_rec, (uint64_t*)s.rec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, n_hay, st)); }
+    { Prof pr("rp_scans", st);
+      HIP_TRY(launch_rp_loop_caps((const uint64_t*)s.rec_first.p, n_hay, (uint32_t*)s.lp_cap_r.p, (uint32_t*)s.lp_cap_p.p, st));
+      HIP_TRY(launch_scan(s.scan_tmp.p, t32, (const uint32_t*)s.lp_cap_r.p, (uint64_t*)s.lp_rec_base.p, n1, st));
+      HIP_TRY(launch_scan(s.scan_tmp.p, t32, (const uint32_t*)s.lp_cap_p.p, (uint64_t*)s.lp_pc_base.p, n1, st)); }
+    say("ranges + region sizes");
+    HIP_TRY(hipMemsetAsync(s.lp_ctrl.p, 0, 64, st));
+    RpLoop a{};
+    a.t = r->t; a.s = make_sf_view(fl->d_image, fl->h);
+    a.text = (const uint8_t*)in->d_text; a.offsets = in->d_offsets; a.n_hay = n_hay; a.ov = ov;
+    a.recs0 = (const Record*)s.recbuf[0].p; a.rec_first0 = (const uint64_t*)s.rec_first.p;
+    a.rec_buf = (Record*)s.lp_rec.p; a.rec_base = (const uint64_t*)s.lp_rec_base.p;
+    a.pc_buf = (RpPiece*)s.lp_pc.p; a.pc_base = (const uint64_t*)s.lp_pc_base.p;
+    a.kept_buf = (RpKept*)s.lp_kept.p; a.wtext = (uint8_t*)s.lp_wtext.p; a.wcap = (uint32_t)wcap64;
+    a.max_len = max_length; a.out = (RpLoopOut*)s.lp_out.p; a.ctrl = (uint32_t*)s.lp_ctrl.p;
+    say("launch");
+    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(a, g_rt.dev[in->dev].n_cu, st)); }
+    say("launched");
+    // what every haystack ended as
+    const size_t out_bytes = (size_t)n_hay * sizeof(RpLoopOut);
+    const size_t tab_bytes = (size_t)n_hay * (sizeof(RpFin) + 8 + 4) + 64;
+    AM_TRY(s.pin_loop(64 + out_bytes + tab_bytes));
+    uint32_t* ctrl_h = (uint32_t*)s.lp_host;
+    RpLoopOut* out_h = (RpLoopOut*)((uint8_t*)s.lp_host + 64);
+    HIP_TRY(hipMemcpyAsync(ctrl_h, s.lp_ctrl.p, 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(out_h, s.lp_out.p, out_bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (trace) { std::fprintf(stderr, "[am_replacer loop] kernel done: overflow %u passes %u watchdog %u\n", ctrl_h[0], ctrl_h[1], ctrl_h[5]); std::fflush(stderr); }
+    if (ctrl_h[0] != 0) return AM_OK;                        // a haystack outgrew its regions: the pass-by-pass loop takes the batch
+    // the finished texts: one materialise launch over the final piece lists
+    RpFin* fin_h = (RpFin*)((uint8_t*)s.lp_host + 64 + out_bytes);
+    uint64_t* fstart_h = (uint64_t*)(fin_h + n_hay);
+    uint32_t* fcnt_h = (uint32_t*)(fstart_h + n_hay);
+    uint64_t total_fin = 0;
+    for (uint32_t i = 0; i < n_hay; i++) {
+        const RpLoopOut& o = out_h[i];
+        if (o.status > kRpNothing || o.pieces_at + o.n_pieces + 1 > pc_total) return fail(AM_ERR_HIP, "replacer loop produced inconsistent metadata (internal error)");
+        fin_h[i] = RpFin{total_fin, o.len, i, o.status};
+        fstart_h[i] = o.pieces_at; fcnt_h[i] = o.n_pieces;
+        total_fin += o.len;
+    }
+    AM_TRY(s.lp_fin.ensure((size_t)n_hay * sizeof(RpFin))); AM_TRY(s.lp_fin_start.ensure((size_t)n_hay * 8)); AM_TRY(s.lp_fin_cnt.ensure((size_t)n_hay * 4));
+    HIP_TRY(hipMemcpyAsync(s.lp_fin.p, fin_h, (size_t)n_hay * sizeof(RpFin), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.lp_fin_start.p, fstart_h, (size_t)n_hay * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s.lp_fin_cnt.p, fcnt_h, (size_t)n_hay * 4, hipMemcpyHostToDevice, st));
+    res->text.assign(n_hay, am_replaced::Item());
+    res->just.assign(n_hay, 1);
+    uint8_t* home = nullptr;
+    if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
+    uint8_t* d_fin = home;
+    if (res->dev < 0) { AM_TRY(s.fin_text.ensure(total_fin + 16)); d_fin = (uint8_t*)s.fin_text.p; }
+    { Prof pr("pt_materialise", st);
+      HIP_TRY(launch_pt_materialise((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p, (const uint32_t*)s.lp_fin_cnt.p, (const RpFin*)s.lp_fin.p, n_hay,
+                                    (const uint8_t*)in->d_text, r->t.repl, d_fin, st)); }
+    if (res->dev < 0 && total_fin) {
+        // home in requests of 256 MiB (one huge request keeps the copy engine from overlapping with anything else queued behind it)
+        for (uint64_t off = 0; off < total_fin; off += (256ull << 20)) {
+            const uint64_t n = std::min<uint64_t>(256ull << 20, total_fin - off);
+            HIP_TRY(hipMemcpyAsync(home + off, d_fin + off, n, hipMemcpyDeviceToHost, st));
+        }
+    }
+    say("materialise queued");
+    HIP_TRY(hipStreamSynchronize(st));
+    say("done");
+    for (uint32_t i = 0; i < n_hay; i++) {
+        if (fin_h[i].status == kRpNothing) res->just[i] = 0;
+        else res->text[i] = am_replaced::Item{home + fin_h[i].off, (size_t)fin_h[i].len};
+    }
+    res->passes = ctrl_h[1];
+    res->scanned += in->total + (((uint64_t)ctrl_h[3] << 32) | ctrl_h[2]);
+    res->spliced += total_fin;
+    *handled = true;
+    return AM_OK;
+}
+
 // Large batches are cut into a few groups of haystacks that run the pass loop CONCURRENTLY, one host thread and HIP stream per
 // group: a pass is a chain of small kernels bound by launch and dependency latency, not by throughput, so the chains of
 // different groups overlap on the GPU.  The groups share nothing but the (read-only) batch text and the replacer tables.
 static int replacer_run_groups(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res)
 {
     const uint32_t n_hay = in->n_hay;
+    { bool handled = false; AM_TRY(replacer_run_loop(r, in, max_length, res, &handled)); if (handled) return AM_OK; }
     uint32_t groups = n_hay / 2048u;
     if (groups > 2) groups = 2;        // measured on config 5: 1 -> 82 ms, 2 -> 54 ms, 4 -> 77 ms, 8 -> 109 ms (the groups' kernels start to queue behind each other)
     { const long v = cfg::get(cfg::kRpGroups); if (v >= 1 && v <= 16) groups = (uint32_t)v; }

@@ -123,6 +123,23 @@ hipError_t launch_rp_win_meta(const RpTables& t, const RpRouted& rt, const RpHay
                               const RpKept* kept, const uint64_t* win_off, uint32_t ov, RpWin* wins, uint32_t* wlen, uint32_t n_act, hipStream_t st, bool pt = false);
 // piece table (am_replace.hip): the text of a haystack between passes as (source, logical start) pairs + a sentinel
 struct RpPiece { uint64_t src; uint64_t lstart; };
+constexpr uint64_t kPieceRepl = 1ull << 63;             // RpPiece::src: offset into the replacement blob instead of the batch text
+// all passes of a haystack in one kernel (am_rploop.hip): every haystack owns two record lists, two piece lists, a kept list and a window scratch
+struct RpLoopOut { uint64_t len; uint64_t pieces_at; uint32_t n_pieces, status, passes, pad; };      // pieces_at: index of the final list in pc_buf
+struct RpLoop {
+    RpTables t; SfView s;
+    const uint8_t* text; const uint64_t* offsets; uint32_t n_hay, ov;
+    const Record* recs0; const uint64_t* rec_first0;        // the first scan's sorted records and their range per haystack
+    Record* rec_buf; const uint64_t* rec_base;              // haystack h: records [rec_base[h], rec_base[h + 1]), two halves
+    RpPiece* pc_buf; const uint64_t* pc_base;               // the same for its piece lists
+    RpKept* kept_buf;                                       // haystack h: from rec_base[h] / 2, half a record region long
+    uint8_t* wtext; uint32_t wcap, pad;                     // haystack h: wcap bytes of window scratch
+    uint64_t max_len;
+    RpLoopOut* out;
+    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time
+};
+hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, hipStream_t st);
+hipError_t launch_rp_loop(const RpLoop& a, int n_cu, hipStream_t st);
 hipError_t launch_pt_init(const uint64_t* offsets, uint32_t n_act, RpPiece* pieces, uint64_t* pc_start, uint32_t* pc_cnt, hipStream_t st);
 hipError_t launch_pt_count(const RpHay* hs, const uint32_t* pc_cnt, uint32_t n_act, uint32_t* need, uint32_t* nwin, hipStream_t st);
 hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const RpPiece* pieces, const uint64_t* pc_start,

@@ -751,7 +751,6 @@ hipError_t launch_rp_merge(bool write, const Record* recs, const uint64_t* rec_f
 // bytes move only twice: into the small windows that are re-scanned (k_pt_win_copy) and, once per haystack, into the result when
 // the haystack is finished (k_pt_materialise).  CaseSensitive replacers only: makeMatch of an IgnoreCase replacer walks the
 // text backwards (skipCodePointsBackwards), those keep the splicing path.
-constexpr uint64_t kPieceRepl = 1ull << 63;             // Piece::src: offset into the replacement blob instead of the batch text
 
 __global__ void __launch_bounds__(256) k_pt_init(const uint64_t* __restrict__ offsets, uint32_t n_act, RpPiece* __restrict__ pieces, uint64_t* __restrict__ pc_start,
                                                  uint32_t* __restrict__ pc_cnt)

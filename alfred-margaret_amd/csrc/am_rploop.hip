@@ -1,0 +1,361 @@
+// am_rploop.hip -- Replacer.run with ALL passes of a haystack inside one kernel (reference: src/Data/Text/AhoCorasick/Replacer.hs:203-274).
+//
+// The pass loop of `runWithLimit.go` is per haystack: nothing of one haystack's passes depends on another haystack.  The piece-table path
+// (am_replace.hip, replacer_run_pt) nevertheless runs a pass as ~16 dependent launches over ALL active haystacks plus one host look at the
+// totals -- on BASELINE config 5 (16 384 haystacks, 159 passes, one replacement per haystack and pass) 159 x 240 us of latency-bound
+// kernels.  Here a wavefront takes one haystack and runs its loop to the end:
+//   fold      prependMatch / makeMatch / removeOverlap over the haystack's sorted records (as k_rp_pass)
+//   pieces    the next piece list (as k_pt_build)
+//   windows   per kept match: gather the window around the replacement through the new piece list into the wavefront's scratch, test its
+//             own positions against the Bloom filter (read from L2: a window is ~150 positions) and verify the survivors exactly
+//             (sf_verify: the same probe + resolve k_sf runs), and merge: shifted old records + the window's records -> next list
+// Every haystack owns fixed regions (two record lists, two piece lists, a kept list, a window scratch) sized from its first scan; a
+// haystack that outgrows them raises the overflow flag and the host runs the batch through the piece-table path instead.
+// CaseSensitive replacers on the suffix-filter route (IgnoreCase: makeMatch walks the text backwards, replacer_run keeps those).
+#include <hip/hip_runtime.h>
+
+#include "am_device.h"
+#include "am_wave.h"
+
+namespace am {
+namespace dev {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int64_t lp_wave_max_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int64_t o = __shfl_xor(v, d, kWave); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int64_t lp_wave_sum_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+__device__ __forceinline__ int64_t lp_wave_incl_i64(int64_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) { const int64_t o = __shfl_up(v, d, kWave); if (lane >= d) v += o; }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lp_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }      // a value that is the same in every lane: scalar from here on
+
+// what the lanes of this wavefront wrote to global memory is visible to its other lanes (one L1 per workgroup: a wait, no cache control)
+__device__ __forceinline__ void lp_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// number of elements of the sorted key(0..n) that are <= x: a 64-ary search, one trip per factor of 64 (all arguments uniform)
+template <class Key>
+__device__ __forceinline__ uint64_t lp_count_le(Key key, uint64_t n, uint64_t x, int lane, uint64_t deadline)
+{
+    uint64_t lo = 0, hi = n;
+    while (hi > lo) {
+        if (__builtin_amdgcn_s_memtime() > deadline) return lo;       // (watchdog: the caller gives up at its next step)
+        const uint64_t m = hi - lo, step = (m + 63) / 64;
+        const bool in = (uint64_t)lane * step < m;                       // the lane's block is not empty
+        uint64_t i = lo + ((uint64_t)lane + 1) * step - 1;                // its last element
+        if (i >= hi) i = hi - 1;
+        const bool le = in && key(i) <= x;                                // then the whole block is <= x
+        const uint64_t c = (uint64_t)__popcll(__ballot(le));              // such blocks are a prefix
+        if (step == 1) return uniform_u64(lo + c);
+        const uint64_t nlo = uniform_u64(lo + c * step);
+        if (nlo >= hi) return hi;
+        lo = nlo; hi = nlo + step < hi ? nlo + step : hi;               // the first element > x lies in block c
+    }
+    return lo;
+}
+
+// bytes [lo, lo + len) of a piece list (P[n] = sentinel) into dst
+__device__ __forceinline__ void lp_gather(const RpPiece* __restrict__ P, uint32_t n, const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl,
+                                          uint64_t lo, uint64_t len, uint8_t* __restrict__ dst, int lane, uint64_t deadline)
+{
+    if (len == 0) return;
+    const uint64_t cnt = lp_count_le([&](uint64_t i) { return P[i].lstart; }, n, lo, lane, deadline);      // pieces that start at or before lo (>= 1: P[0] starts at 0)
+    uint64_t pos = lo;
+    const uint64_t end = lo + len;
+    for (uint64_t i = cnt - 1; pos < end && i < n; i++) {
+        const uint64_t ps = P[i].lstart, pn = P[i + 1].lstart, pe = pn < end ? pn : end, s = P[i].src;
+        if (pe <= pos) continue;                                         // (an empty piece)
+        if (__builtin_amdgcn_s_memtime() > deadline) return;
+        const uint8_t* from = ((s & kPieceRepl) ? repl + (s & ~kPieceRepl) : text + s) + (pos - ps);
+        uint8_t* to = dst + (pos - lo);
+        for (uint64_t x = lane; x < pe - pos; x += kWave) to[x] = from[x];
+        pos = pe;
+    }
+}
+
+// Watchdog: the loops of a haystack's run look at the clock; a run that lasts longer than kLpMaxTicks (a corrupt table, a bug) gives up with
+// the overflow flag and the number of the loop in ctrl[5], and the host takes the pass-by-pass loop: the kernel cannot hang.
+constexpr uint64_t kLpMaxTicks = 400000000ull;            // of s_memtime's 100 MHz: 4 s for ONE haystack
+#define LP_STEP(code) do { if (__builtin_amdgcn_s_memtime() > deadline) { if (lane == 0) atomicMax(a.ctrl + 5, (uint32_t)(code)); overflow = true; } } while (0)
+
+template <bool IC>
+__device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lane)
+{
+    const uint64_t deadline = __builtin_amdgcn_s_memtime() + kLpMaxTicks;
+    // (everything every lane agrees on goes through readfirstlane: the compiler then keeps it in scalar registers and branches on it with
+    // scalar branches -- the loops below are uniform by construction, and it cannot know that)
+    const uint64_t hoff = uniform_u64(a.offsets[h]);
+    uint64_t curlen = uniform_u64(a.offsets[h + 1]) - hoff;
+    const uint64_t rb = uniform_u64(a.rec_base[h]), cap_r = (uniform_u64(a.rec_base[h + 1]) - rb) >> 1;
+    const uint64_t pb = uniform_u64(a.pc_base[h]), cap_p = (uniform_u64(a.pc_base[h + 1]) - pb) >> 1;
+    const uint64_t rf0 = uniform_u64(a.rec_first0[h]);
+    const Record* R = a.recs0 + rf0;                                     // pass 1 reads the first scan's records where they lie
+    uint64_t nr = uniform_u64(a.rec_first0[h + 1]) - rf0;
+    Record* const Rbuf0 = a.rec_buf + rb; Record* const Rbuf1 = Rbuf0 + cap_r;
+    uint32_t rsel = 0;                                                   // the list the next pass's records go to
+    RpPiece* P = a.pc_buf + pb; RpPiece* Q = P + cap_p;
+    RpKept* const K = a.kept_buf + (rb >> 1);
+    uint8_t* const wt = a.wtext + (uint64_t)h * a.wcap;
+    if (lane == 0) { P[0] = RpPiece{hoff, 0}; P[1] = RpPiece{0, curlen}; }
+    uint32_t np = 1;
+    int64_t threshold = 1;                                               // initialThreshold (Replacer.hs:211)
+    uint32_t passes = 0, status = kRpFinished;
+    uint64_t scanned = 0;
+    bool overflow = nr > cap_r || cap_p < 4;
+    lp_sync();
+
+    while (!overflow) {
+        passes++;
+        LP_STEP(1);
+        // ---- prependMatch, first half: the best priority below the threshold (Replacer.hs:255-258)
+        int64_t best = INT64_MIN;
+        for (uint64_t r = lane; r < nr; r += kWave) {
+            const uint32_t st = R[r].state;
+            for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+                const int64_t p = a.t.payloads[a.t.vals[k]].priority;
+                if (p < threshold && p > best) best = p;
+            }
+        }
+        best = (int64_t)uniform_u64((uint64_t)lp_wave_max_i64(best));
+        if (best == INT64_MIN) { status = kRpFinished; break; }           // no match below the threshold: the text stays (:228-230)
+
+        // ---- second half: the matches that carry it, makeMatch (:264-267), removeOverlap (:191-198)
+        int64_t delta_all = 0, delta_kept = 0;
+        uint64_t last_end = 0;
+        uint32_t nkept = 0, payload = 0;
+        for (uint64_t base = 0; base < nr && !overflow; base += kWave) {
+            const uint64_t r = base + lane;
+            LP_STEP(3);
+            bool sel = false; uint32_t pl = 0; uint64_t end_pos = 0;
+            if (r < nr) {
+                const Record rec = R[r];
+                end_pos = rec.end_pos;
+                for (uint64_t k = a.t.vals_off[rec.state], ke = a.t.vals_off[rec.state + 1]; k < ke; k++) {
+                    const uint32_t v = a.t.vals[k];
+                    if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
+                }
+            }
+            uint64_t start = 0, len = 0; int64_t delta = 0;
+            if (sel) {
+                const RpPayload pp = a.t.payloads[pl];
+                len = pp.len_bytes; start = end_pos - len;
+                delta = (int64_t)pp.repl_len - (int64_t)len;
+            }
+            delta_all += delta;
+            uint64_t pending = __ballot(sel);
+            bool keep = false;
+            while (pending && !overflow) {
+                LP_STEP(4);
+                const uint64_t ok = __ballot(sel && start >= last_end) & pending;
+                if (!ok) break;
+                const int l = __ffsll((unsigned long long)ok) - 1;
+                if (lane == l) keep = true;
+                last_end = uniform_u64(__shfl(start + len, l, kWave));
+                pending &= l == 63 ? 0ull : ~((2ull << l) - 1ull);
+            }
+            const uint64_t keepmask = __ballot(keep);
+            if (keepmask) {
+                const int64_t kd = keep ? delta : 0;
+                const int64_t incl = lp_wave_incl_i64(kd, lane);
+                if (keep) {
+                    const uint32_t rank = __popcll(keepmask & ((1ull << lane) - 1ull));
+                    RpKept e; e.src_start = start; e.src_len = len; e.dst = (uint64_t)((int64_t)start + delta_kept + (incl - kd));
+                    K[nkept + rank] = e;
+                    payload = pl;
+                }
+                delta_kept += (int64_t)uniform_u64((uint64_t)__shfl(incl, kWave - 1, kWave));
+                nkept += __popcll(keepmask);
+            }
+        }
+        delta_all = (int64_t)uniform_u64((uint64_t)lp_wave_sum_i64(delta_all));
+        payload = lp_u32((uint32_t)lp_wave_max_i64((int64_t)payload));    // uniform: every kept match has the same payload
+        const int64_t newlen_all = (int64_t)curlen + delta_all;           // replacementLength over ALL matches (:240)
+        if (newlen_all > 0 && (uint64_t)newlen_all > a.max_len) { status = kRpNothing; break; }
+        const uint64_t newlen = (uint64_t)((int64_t)curlen + delta_kept);
+        status = best == a.t.min_priority ? kRpFinished : kRpActive;    // :241-242
+        lp_sync();                                                       // K is read by every lane from here on
+
+        // ---- replace (:163-180) on the piece list: P -> Q (the scheme of k_pt_build)
+        RpPayload pp = a.t.payloads[payload];
+        pp.repl_off = uniform_u64(pp.repl_off); pp.repl_len = lp_u32(pp.repl_len);
+        const uint64_t repl_len = nkept ? pp.repl_len : 0;
+        if ((uint64_t)np + 2ull * nkept + 2ull > cap_p) { overflow = true; break; }
+        uint32_t nq = 0;
+        {
+            const uint32_t nk = nkept;
+            auto span = [&](uint64_t ls, uint64_t le, uint32_t& ja, uint32_t& jb) {
+                uint32_t lo = 0, hi = nk;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (K[mid].src_start + K[mid].src_len <= ls) lo = mid + 1; else hi = mid; }
+                ja = lo; jb = lo;
+                while (jb < nk && K[jb].src_start < le) jb++;
+            };
+            auto emit = [&](uint32_t i, auto&& f) {
+                const uint64_t ls = P[i].lstart, le = P[i + 1].lstart;
+                if (le == ls) return;
+                uint32_t ja, jb; span(ls, le, ja, jb);
+                uint64_t x = ls;
+                auto new_pos = [&](uint64_t xx, uint32_t jprev_plus1) -> uint64_t {
+                    if (jprev_plus1 == 0) return xx;
+                    const RpKept k = K[jprev_plus1 - 1];
+                    return k.dst + repl_len + (xx - (k.src_start + k.src_len));
+                };
+                uint32_t jp = ja;
+                for (uint32_t j = ja; j < jb; j++) {
+                    const RpKept k = K[j];
+                    if (k.src_start > x) f(P[i].src + (x - ls), new_pos(x, jp));
+                    if (k.src_start >= ls && repl_len) f(kPieceRepl | pp.repl_off, k.dst);
+                    x = k.src_start + k.src_len;
+                    jp = j + 1;
+                    if (x >= le) break;
+                }
+                if (x < le) f(P[i].src + (x - ls), new_pos(x, jp));
+            };
+            for (uint32_t r0 = 0; r0 < np && !overflow; r0 += kWave) {
+                LP_STEP(5);
+                const uint32_t i = r0 + lane;
+                uint32_t c = 0;
+                if (i < np) emit(i, [&](uint64_t, uint64_t) { c++; });
+                const uint32_t incl = wave_inclusive_sum(c, (uint32_t)lane);
+                uint32_t at = nq + incl - c;
+                if (i < np) emit(i, [&](uint64_t src, uint64_t pos) { Q[at++] = RpPiece{src, pos}; });
+                nq += lp_u32(__shfl(incl, kWave - 1, kWave));
+            }
+            if (lane == 0) Q[nq] = RpPiece{0, newlen};                    // sentinel
+        }
+        { RpPiece* t = P; P = Q; Q = t; }
+        np = nq;
+        lp_sync();
+        if (status == kRpFinished) { curlen = newlen; break; }
+
+        // ---- the next pass's records: old records outside the neighbourhood of the replacements, shifted, + the records of the windows
+        // (k_rp_win_meta + k_pt_win_copy + the window scan + k_rp_merge of the piece-table path, one window at a time)
+        Record* const Rn = rsel ? Rbuf1 : Rbuf0;
+        uint64_t cursor = 0, at = 0;
+        auto end_of = [&](uint64_t i) { return R[i].end_pos; };
+        auto copy_shifted = [&](uint64_t from, uint64_t to, int64_t shift) {
+            for (uint64_t i = from + lane; i < to; i += kWave) { Record r = R[i]; r.end_pos = (uint64_t)((int64_t)r.end_pos + shift); r.haystack = h; Rn[cursor + (i - from)] = r; }
+        };
+        for (uint32_t j = 0; j < nkept && !overflow; j++) {
+            LP_STEP(6);
+            RpKept k = K[j];
+            k.src_start = uniform_u64(k.src_start); k.src_len = uniform_u64(k.src_len); k.dst = uniform_u64(k.dst);
+            // old records that end at or before the replaced region: unchanged context, they move with the text
+            const uint64_t e = at + lp_count_le([&](uint64_t i) { return end_of(at + i); }, nr - at, k.src_start, lane, deadline);
+            if (cursor + (e - at) > cap_r) { overflow = true; break; }
+            copy_shifted(at, e, (int64_t)k.dst - (int64_t)k.src_start);
+            cursor += e - at;
+            // the window of match j in the new text
+            const uint64_t dst = k.dst;
+            uint64_t hi = dst + repl_len + a.ov;
+            if (hi > newlen) hi = newlen;
+            if (j + 1 < nkept) { const uint64_t nd = uniform_u64(K[j + 1].dst); if (nd < hi) hi = nd; }
+            const uint64_t ws = dst > a.ov ? dst - a.ov : 0;
+            const uint32_t wlen = hi > dst ? (uint32_t)(hi - ws) : 0u, own_lo = (uint32_t)(dst - ws);
+            if (wlen > a.wcap) { overflow = true; break; }
+            if (wlen) {
+                lp_gather(P, np, a.text, a.t.repl, ws, wlen, wt, lane, deadline);
+                lp_sync();
+                scanned += wlen;
+                for (uint32_t base = own_lo; base < wlen && !overflow; base += kWave) {
+                    LP_STEP(7);
+                    const uint32_t g = base + (uint32_t)lane;
+                    bool found = false; uint32_t state = 0, vlen = 0;
+                    if (g < wlen) {
+                        uint32_t w, w2;
+                        load_suffix8(wt, g, w, w2);
+                        if (IC) w = fold_dword(w);
+                        if (sf_filter_window(a.s.bloom, a.s.bloom_log2_words, a.s.tiers, w)) found = sf_verify<IC>(a.s, wt, g, (uint64_t)g + 1, state, vlen);
+                    }
+                    const uint64_t fm = __ballot(found);
+                    const uint32_t nf = (uint32_t)__popcll(fm);      // (a ballot is scalar already)
+                    if (nf) {
+                        if (cursor + nf > cap_r) { overflow = true; break; }
+                        if (found) Rn[cursor + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))] = Record{ws + g + 1, h, state};
+                        cursor += nf;
+                    }
+                }
+                lp_sync();                                               // (the scratch is rewritten by the next window)
+            }
+            // old records that touch the replaced bytes are gone
+            at = e + lp_count_le([&](uint64_t i) { return end_of(e + i); }, nr - e, k.src_start + k.src_len + a.ov, lane, deadline);
+        }
+        if (overflow) break;
+        if (cursor + (nr - at) > cap_r) { overflow = true; break; }
+        copy_shifted(at, nr, (int64_t)newlen - (int64_t)curlen);
+        cursor += nr - at;
+        R = Rn; nr = cursor; rsel ^= 1u;
+        curlen = newlen; threshold = best;
+        lp_sync();
+    }
+
+    if (lane == 0) {
+        RpLoopOut o;
+        o.len = status == kRpNothing ? 0 : curlen; o.pieces_at = (uint64_t)(P - a.pc_buf); o.n_pieces = np; o.status = status; o.passes = passes; o.pad = 0;
+        a.out[h] = o;
+        if (overflow) atomicOr(a.ctrl + 0, 1u);
+        atomicMax(a.ctrl + 1, passes);
+        if (scanned) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 2), (unsigned long long)scanned);
+    }
+}
+
+}  // namespace
+
+// one wavefront (= one workgroup) per haystack: the hardware hands the workgroups out as wavefront slots become free.  (A loop over haystacks
+// inside the kernel -- wavefronts drawing haystack numbers from a counter -- was the first version: the compiler merged that loop with the
+// pass loop, the haystack number became a loop-carried value of a loop it took for divergent, and the kernel never ended; a haystack number
+// that comes from blockIdx is uniform for the compiler too.)
+template <bool IC>
+__global__ void __launch_bounds__(64) k_rp_loop(RpLoop a)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t h = blockIdx.x;
+    if (h >= a.n_hay) return;
+    lp_run_haystack<IC>(a, h, lane);
+}
+
+// region sizes per haystack from its first scan: records 2 x (2 n + 64), pieces 2 x (4 n + 64)  (n = its records; element n_hay: 0)
+__global__ void __launch_bounds__(256) k_rp_loop_caps(const uint64_t* __restrict__ rec_first, uint32_t n_hay, uint32_t* __restrict__ cap_r2, uint32_t* __restrict__ cap_p2)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_hay) return;
+    if (h == n_hay) { cap_r2[h] = 0; cap_p2[h] = 0; return; }
+    const uint64_t n = rec_first[h + 1] - rec_first[h];
+    cap_r2[h] = (uint32_t)(2 * (2 * n + 64));
+    cap_p2[h] = (uint32_t)(2 * (4 * n + 64));
+}
+
+hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rp_loop_caps, dim3((n_hay + 1 + 255) / 256), dim3(256), 0, st, rec_first, n_hay, cap_r2, cap_p2);
+    return hipGetLastError();
+}
+
+hipError_t launch_rp_loop(const RpLoop& a, int /*n_cu*/, hipStream_t st)
+{
+    if (a.n_hay == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rp_loop<false>, dim3(a.n_hay), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace dev
+}  // namespace am

@@ -1,0 +1,97 @@
+"""Replacer.run with all passes of a haystack in ONE kernel (csrc/am_rploop.hip, Replacer.hs:203-274): forced with AM_RP_LOOP=1 on the
+inputs the pass-by-pass loops are tested on, it must give the oracle's texts, the same Nothing entries and the same number of passes."""
+import random
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+import alfred_margaret_amd as am
+from alfred_margaret_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _loop_equals_oracle(pairs, hays, max_len=-1):
+    r = am.Replacer(0, pairs)
+    am.debug_set("AM_RP_LOOP", 0)
+    ref = r.run_batch(hays, max_len)
+    ref_stats = r.last_stats()
+    am.debug_set("AM_RP_LOOP", 1)
+    got = r.run_batch(hays, max_len)
+    stats = r.last_stats()
+    am.debug_set("AM_RP_LOOP", -1)
+    o = oracle.Replacer(0, pairs)
+    exp = [o.run(h, max_len) for h in hays]
+    assert got == exp, (pairs[:6], max_len)
+    assert ref == exp
+    assert stats[0] == ref_stats[0], "number of passes"
+    return got, stats
+
+
+def test_loop_overlaps_chains_and_long_match_lists():
+    _loop_equals_oracle([("aa", "b")], ["a" * n for n in (0, 1, 2, 3, 64, 65, 127, 128, 129, 1000, 4097)])
+    _loop_equals_oracle([("abab", "X"), ("ab", "yy")], ["ab" * 300, "abab" * 77 + "a", "b" + "ab" * 129])
+    _loop_equals_oracle([("aaa", ""), ("a", "bbbbb")], ["a" * 500, "a" * 7 + "c" + "a" * 200])
+    _loop_equals_oracle([("a", "b"), ("b", "c"), ("c", "dd"), ("dd", "")], ["abcabc" * 50, "", "dddd", "x"])
+    _loop_equals_oracle([("b", "a"), ("a", "b")], ["abba" * 40])
+    big = ("x" * 1021 + "needle") * 40
+    _loop_equals_oracle([("needle", "R" * 37), ("xR", "<>")], [big, big[3:], big[:16384], big[:16385]])
+    _loop_equals_oracle([("x" * 16, "y")], ["x" * 40000])
+    _loop_equals_oracle([("ab", "X"), ("Xc", "abab"), ("ba", ""), ("aX", "yy")], ["abcabcab" * 50, "ab", "bab", "", "cab" * 200])
+    _loop_equals_oracle([("aaa", "a"), ("a", "bb"), ("bbbb", "c")], ["a" * 1000, "a" * 7, "baab" * 100])
+
+
+def test_loop_length_limit_and_multibyte_text():
+    r = [("a", "bbbb"), ("c", "")]
+    hays = ["aa", "a", "", "acac", "cccc", "aaaa" * 10]
+    for lim in (0, 1, 4, 7, 8, 9, 40, 160, 161):
+        got, _ = _loop_equals_oracle(r, hays, lim)
+        assert got[2] == b""
+    _loop_equals_oracle([("aa", "bbb")], ["aaa"], 4)
+    _loop_equals_oracle([("aa", "bbb")], ["aaa"], 5)
+    _loop_equals_oracle([("ß", "ss"), ("İ", "i"), ("ss", "ẞ"), ("å", "")], ["ẞßẞ", "ÅåÅ" * 30, "İẞKÅß" * 100, "aİ" * 70, "straße" * 40])
+
+
+def test_loop_random_pair_sets_many_haystacks_many_passes():
+    rng = random.Random(41)
+    for _ in range(8):
+        alpha = rng.choice(["abc ", "abİKß", "xyzXYZ", "abcde "])
+        pairs = [("".join(rng.choice(alpha) for _ in range(rng.randint(1, 5))), "".join(rng.choice(alpha + "Q") for _ in range(rng.randint(0, 6)))) for _ in range(rng.randint(2, 60))]
+        pairs = [p for p in pairs if p[0]]
+        hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 1, 3, 50, 800, 5000)))) for _ in range(rng.choice((1, 30, 200)))]
+        _, stats = _loop_equals_oracle(pairs, hays)
+        _loop_equals_oracle(pairs, hays, 1000)
+
+
+def test_loop_falls_back_when_a_haystack_outgrows_its_regions():
+    """Every haystack's record and piece lists are sized from its first scan (2 n + 64 records); replacements that double the number of
+    matches per pass outgrow them, the kernel raises its overflow flag and the batch takes the pass-by-pass loop: same answer."""
+    pairs = [("a", "bb"), ("b", "cc"), ("c", "dd"), ("d", "ee")]
+    hays = ["a" * 200, "abcd" * 64, "x"]
+    got, stats = _loop_equals_oracle(pairs, hays)
+    assert got[0] == b"e" * 3200 and stats[0] == 4
+
+
+def test_loop_cfg5_reduced_and_what_it_scans():
+    """BASELINE configs[4] reduced to 256 x 64 KiB: the default route for batches of many documents; the oracle on the first 48 of them."""
+    workload = "cfg5_replacer_50k_1GiB"
+    w = synth.WORKLOADS[workload]
+    pairs = synth.replacer_pairs(workload)
+    n_hay, hb = 256, w["hay_bytes"]
+    host = synth.haystacks_host([p[0] for p in pairs], w["mixed"], 0, n_hay * hb // synth.CELL)
+    hays = [bytes(host[i * hb:(i + 1) * hb]) for i in range(n_hay)] + [b"", bytes(host[:100])]
+    r = am.Replacer(w["case"], pairs)
+    got = r.run_batch(hays)                                  # switches unset: >= 64 documents take the one-kernel loop
+    passes, scanned = r.last_stats()
+    am.debug_set("AM_RP_LOOP", 0)
+    ref = r.run_batch(hays)
+    ref_passes, ref_scanned = r.last_stats()
+    am.debug_set("AM_RP_LOOP", -1)
+    assert got == ref and passes == ref_passes and passes > 100
+    total = sum(len(h) for h in hays)
+    assert total < scanned < total * 4 and scanned == ref_scanned        # the same windows
+    orc = oracle.Replacer(w["case"], pairs)
+    with ThreadPoolExecutor(8) as pool:
+        exp = list(pool.map(orc.run, hays[:48]))
+    assert got[:48] == exp

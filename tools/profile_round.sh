@@ -7,7 +7,7 @@ TAG=$1
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 cd $R
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_default.log 2>$OUT/bench_default.err; echo "bench default rc=$?"
-[ "${2:-all}" = "core" ] && WL="" || WL="cfg2_runText_10k_1GiB cfg4_100k_1M_haystacks cfg5_replacer_50k_1GiB natural_100k_10GiB"
+[ "${2:-all}" = "core" ] && WL="" || WL="cfg2_runText_10k_1GiB cfg2_single_1GiB cfg4_100k_1M_haystacks cfg5_replacer_50k_1GiB natural_100k_10GiB"
 for w in $WL; do
   timeout 600 python bench.py --workload $w --no-cpu-baseline > $OUT/bench_$w.log 2>$OUT/bench_$w.err; echo "bench $w rc=$?"
 done
