@@ -1537,7 +1537,7 @@ static_assert(sizeof(am_payload) == sizeof(RpPayload) && offsetof(am_payload, re
 struct am_replacer {
     const am_automaton* a = nullptr;
     int case_mode = 0;
-    DevBuf vals_off, vals, payloads, repl;
+    DevBuf vals_off, vals, payloads, repl, one;
     RpTables t{};
     uint32_t max_repl_len = 0;                        // longest replacement (bounds the re-scan window of the one-kernel loop)
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
@@ -1649,8 +1649,18 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
     if (rc == AM_OK) rc = up(r->payloads, payloads, n_payloads * sizeof(am_payload));
     if (rc == AM_OK && n_payloads == 0) { hipError_t e = hipMemset(r->payloads.p, 0, sizeof(am_payload)); if (e != hipSuccess) rc = fail(AM_ERR_HIP, hipGetErrorString(e)); }
     if (rc == AM_OK) rc = up(r->repl, repl_bytes, n_repl_bytes);
+    if (rc == AM_OK) {
+        std::vector<RpStateOne> one(n_states);
+        for (uint64_t s = 0; s < n_states; s++) {
+            const uint64_t n = values_offsets[s + 1] - values_offsets[s];
+            RpStateOne e{0, 0, (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n), 0, 0};
+            if (n == 1) { const am_payload& pl = payloads[values[values_offsets[s]]]; e.priority = pl.priority; e.payload = values[values_offsets[s]]; e.len_bytes = pl.len_bytes; e.repl_len = pl.repl_len; }
+            one[s] = e;
+        }
+        rc = up(r->one, one.data(), one.size() * sizeof(RpStateOne));
+    }
     if (rc != AM_OK) { am_replacer_destroy(r); return rc; }
-    r->t = RpTables{(const uint64_t*)r->vals_off.p, (const uint32_t*)r->vals.p, (const RpPayload*)r->payloads.p, (const uint8_t*)r->repl.p, min_priority};
+    r->t = RpTables{(const uint64_t*)r->vals_off.p, (const uint32_t*)r->vals.p, (const RpPayload*)r->payloads.p, (const uint8_t*)r->repl.p, min_priority, (const RpStateOne*)r->one.p};
     *out = r;
     return AM_OK;
 }
@@ -1659,7 +1669,7 @@ extern "C" void am_replacer_destroy(am_replacer* r)
 {
     if (!r) return;
     if (r->session_delete) for (void* p : r->sessions) r->session_delete(p);
-    for (DevBuf* d : {&r->vals_off, &r->vals, &r->payloads, &r->repl}) d->release();
+    for (DevBuf* d : {&r->vals_off, &r->vals, &r->payloads, &r->repl, &r->one}) d->release();
     delete r;
 }
 
@@ -2467,7 +2477,7 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     a.kept_buf = (RpKept*)s.lp_kept.p; a.wtext = (uint8_t*)s.lp_wtext.p; a.wcap = (uint32_t)wcap64;
     a.max_len = max_length; a.out = (RpLoopOut*)s.lp_out.p; a.ctrl = (uint32_t*)s.lp_ctrl.p;
     say("launch");
-    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(a, g_rt.dev[in->dev].n_cu, st)); }
+    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(a, (int)cfg::get(cfg::kRpLoopWaves), st)); }
     say("launched");
     // what every haystack ended as
     const size_t out_bytes = (size_t)n_hay * sizeof(RpLoopOut);

@@ -131,7 +131,9 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         int64_t best = INT64_MIN;
         for (uint64_t r = lane; r < nr; r += kWave) {
             const uint32_t st = R[r].state;
-            for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+            const RpStateOne one = a.t.one[st];
+            if (one.nvals == 1) { if (one.priority < threshold && one.priority > best) best = one.priority; }
+            else for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
                 const int64_t p = a.t.payloads[a.t.vals[k]].priority;
                 if (p < threshold && p > best) best = p;
             }
@@ -147,19 +149,21 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
             const uint64_t r = base + lane;
             LP_STEP(3);
             bool sel = false; uint32_t pl = 0; uint64_t end_pos = 0;
+            uint64_t start = 0, len = 0; int64_t delta = 0;
             if (r < nr) {
                 const Record rec = R[r];
                 end_pos = rec.end_pos;
-                for (uint64_t k = a.t.vals_off[rec.state], ke = a.t.vals_off[rec.state + 1]; k < ke; k++) {
-                    const uint32_t v = a.t.vals[k];
-                    if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
+                const RpStateOne one = a.t.one[rec.state];
+                if (one.nvals == 1) {
+                    if (one.priority == best) { sel = true; pl = one.payload; len = one.len_bytes; delta = (int64_t)one.repl_len - (int64_t)len; }
+                } else {
+                    for (uint64_t k = a.t.vals_off[rec.state], ke = a.t.vals_off[rec.state + 1]; k < ke; k++) {
+                        const uint32_t v = a.t.vals[k];
+                        if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
+                    }
+                    if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; delta = (int64_t)pp.repl_len - (int64_t)len; }
                 }
-            }
-            uint64_t start = 0, len = 0; int64_t delta = 0;
-            if (sel) {
-                const RpPayload pp = a.t.payloads[pl];
-                len = pp.len_bytes; start = end_pos - len;
-                delta = (int64_t)pp.repl_len - (int64_t)len;
+                start = end_pos - len;                                   // makeMatch (Replacer.hs:266-267)
             }
             delta_all += delta;
             uint64_t pending = __ballot(sel);
@@ -324,8 +328,8 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
 // inside the kernel -- wavefronts drawing haystack numbers from a counter -- was the first version: the compiler merged that loop with the
 // pass loop, the haystack number became a loop-carried value of a loop it took for divergent, and the kernel never ended; a haystack number
 // that comes from blockIdx is uniform for the compiler too.)
-template <bool IC>
-__global__ void __launch_bounds__(64) k_rp_loop(RpLoop a)
+template <bool IC, int W>
+__global__ void __launch_bounds__(64, W) k_rp_loop(RpLoop a)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t h = blockIdx.x;
@@ -350,10 +354,16 @@ hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_rp_loop(const RpLoop& a, int /*n_cu*/, hipStream_t st)
+hipError_t launch_rp_loop(const RpLoop& a, int waves, hipStream_t st)
 {
     if (a.n_hay == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_rp_loop<false>, dim3(a.n_hay), dim3(64), 0, st, a);
+    // wavefronts per SIMD the register budget is cut for (AM_RP_LOOP_WAVES, A/B; the exact phase -- sf_verify -- wants ~125 registers)
+    switch (waves) {
+    case 5: hipLaunchKernelGGL((k_rp_loop<false, 5>), dim3(a.n_hay), dim3(64), 0, st, a); break;
+    case 6: hipLaunchKernelGGL((k_rp_loop<false, 6>), dim3(a.n_hay), dim3(64), 0, st, a); break;
+    case 8: hipLaunchKernelGGL((k_rp_loop<false, 8>), dim3(a.n_hay), dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL((k_rp_loop<false, 4>), dim3(a.n_hay), dim3(64), 0, st, a); break;
+    }
     return hipGetLastError();
 }
 

@@ -462,7 +462,7 @@ def bench_replacer(args, w, rank, world, dev):
     am.api.check(lib.am_profile_enable(0))
     prof_steps = 1
     prof = {}
-    for k in (b"sf", b"ac", b"rp_pass", b"rp_splice", b"rp_scans", b"rp_windows", b"rp_merge", b"permute", b"rp_ranges", b"rp_route", b"pt_build", b"pt_materialise", b"scan", b"hidx"):
+    for k in (b"sf", b"ac", b"rp_loop", b"rp_pass", b"rp_splice", b"rp_scans", b"rp_windows", b"rp_merge", b"permute", b"rp_ranges", b"rp_route", b"pt_build", b"pt_materialise", b"scan", b"hidx"):
         ms, n = C.c_double(0), C.c_uint64(0)
         am.api.check(lib.am_profile_read(k, C.byref(ms), C.byref(n)))
         prof[k.decode()] = (ms.value, int(n.value))
