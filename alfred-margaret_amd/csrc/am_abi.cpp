@@ -1653,8 +1653,11 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         std::vector<RpStateOne> one(n_states);
         for (uint64_t s = 0; s < n_states; s++) {
             const uint64_t n = values_offsets[s + 1] - values_offsets[s];
-            RpStateOne e{0, 0, (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n), 0, 0};
-            if (n == 1) { const am_payload& pl = payloads[values[values_offsets[s]]]; e.priority = pl.priority; e.payload = values[values_offsets[s]]; e.len_bytes = pl.len_bytes; e.repl_len = pl.repl_len; }
+            RpStateOne e{0, 0, (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n), 0, 0, 0, 0};
+            if (n == 1) {
+                const am_payload& pl = payloads[values[values_offsets[s]]];
+                e.priority = pl.priority; e.payload = values[values_offsets[s]]; e.len_bytes = pl.len_bytes; e.repl_len = pl.repl_len; e.len_code_points = pl.len_code_points;
+            }
             one[s] = e;
         }
         rc = up(r->one, one.data(), one.size() * sizeof(RpStateOne));
@@ -2401,11 +2404,11 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     if (sw == 0) return AM_OK;
     const Flavor* fl = nullptr;
     AM_TRY(prepare(r->a, r->case_mode, &fl));
-    if (r->case_mode != AM_CASE_SENSITIVE || !fl->h.sf_enabled || fl->h.root_vlen != 0 || r->a->kernel_pref == 1) return AM_OK;
+    if (!fl->h.sf_enabled || fl->h.root_vlen != 0 || r->a->kernel_pref == 1) return AM_OK;
     if (sw != 1) {
         // unset: batches of many documents, and no switch that asks for one of the other loops
         if (!(n_hay >= 64 && in->total / n_hay <= (1ull << 20))) return AM_OK;
-        for (cfg::Key k : {cfg::kRpFullScans, cfg::kRpSplice, cfg::kRpPieces, cfg::kRpParallelFold, cfg::kRpGroups, cfg::kRpNoFuse, cfg::kRpNoRangeReuse})
+        for (cfg::Key k : {cfg::kRpFullScans, cfg::kRpSplice, cfg::kRpPieces, cfg::kRpParallelFold, cfg::kRpGroups, cfg::kRpNoFuse, cfg::kRpNoRangeReuse, cfg::kRpNoSpin, cfg::kRpMatMain})
             if (cfg::get(k) != cfg::kUnset) return AM_OK;
     }
     const uint32_t ov = 4u * (fl->h.max_needle_cps ? fl->h.max_needle_cps : 1u) + 4u;
@@ -2477,7 +2480,7 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     a.kept_buf = (RpKept*)s.lp_kept.p; a.wtext = (uint8_t*)s.lp_wtext.p; a.wcap = (uint32_t)wcap64;
     a.max_len = max_length; a.out = (RpLoopOut*)s.lp_out.p; a.ctrl = (uint32_t*)s.lp_ctrl.p;
     say("launch");
-    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(a, (int)cfg::get(cfg::kRpLoopWaves), st)); }
+    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, (int)cfg::get(cfg::kRpLoopWaves), st)); }
     say("launched");
     // what every haystack ended as
     const size_t out_bytes = (size_t)n_hay * sizeof(RpLoopOut);

@@ -86,7 +86,7 @@ struct RpPayload { int64_t priority; uint32_t len_bytes; uint32_t len_code_point
 // machineValues of the Replacer's automaton in CSR form: the list of state s is payloads[vals[vals_off[s] .. vals_off[s+1])]
 // per state, for the states that carry exactly ONE value (almost all of them): that value's payload, so that the fold reads one entry instead of
 // walking state -> value list -> payload (three dependent loads); nvals != 1: walk the list
-struct RpStateOne { int64_t priority; uint32_t payload, nvals, len_bytes, repl_len; };
+struct RpStateOne { int64_t priority; uint32_t payload, nvals, len_bytes, repl_len, len_code_points, pad; };
 struct RpTables { const uint64_t* vals_off; const uint32_t* vals; const RpPayload* payloads; const uint8_t* repl; int64_t min_priority; const RpStateOne* one; };
 struct RpKept { uint64_t src_start, src_len, dst; };     // a match that survives removeOverlap; dst = where its replacement starts in the new text
 constexpr uint32_t kRpActive = 0, kRpFinished = 1, kRpNothing = 2;
@@ -142,7 +142,7 @@ struct RpLoop {
     uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time
 };
 hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, hipStream_t st);
-hipError_t launch_rp_loop(const RpLoop& a, int waves_per_simd, hipStream_t st);
+hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves_per_simd, hipStream_t st);
 hipError_t launch_pt_init(const uint64_t* offsets, uint32_t n_act, RpPiece* pieces, uint64_t* pc_start, uint32_t* pc_cnt, hipStream_t st);
 hipError_t launch_pt_count(const RpHay* hs, const uint32_t* pc_cnt, uint32_t n_act, uint32_t* need, uint32_t* nwin, hipStream_t st);
 hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const RpPiece* pieces, const uint64_t* pc_start,

@@ -11,7 +11,7 @@
 //             (sf_verify: the same probe + resolve k_sf runs), and merge: shifted old records + the window's records -> next list
 // Every haystack owns fixed regions (two record lists, two piece lists, a kept list, a window scratch) sized from its first scan; a
 // haystack that outgrows them raises the overflow flag and the host runs the batch through the piece-table path instead.
-// CaseSensitive replacers on the suffix-filter route (IgnoreCase: makeMatch walks the text backwards, replacer_run keeps those).
+// Replacers on the suffix-filter route, both case modes (IgnoreCase: makeMatch walks the text backwards through the piece list).
 #include <hip/hip_runtime.h>
 
 #include "am_device.h"
@@ -93,6 +93,29 @@ __device__ __forceinline__ void lp_gather(const RpPiece* __restrict__ P, uint32_
     }
 }
 
+// Utf8.hs:256-276 skipCodePointsBackwards on the text a piece list describes (makeMatch of an IgnoreCase replacer, Replacer.hs:268-274): from
+// byte `index` back over n code points, to the first byte of the code point reached; never leaves the text.  One lane, its own cursor into the
+// list (the bytes of a match almost always lie in one piece).
+__device__ __forceinline__ uint64_t lp_skip_code_points_backwards(const RpPiece* __restrict__ P, uint32_t np, const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl,
+                                                               uint64_t index, uint64_t n)
+{
+    uint32_t lo = 0, hi = np;                                // last piece that starts at or before index (np >= 1 here: the text holds a match)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (P[mid].lstart <= index) lo = mid; else hi = mid; }
+    uint32_t pi = lo;
+    uint64_t ls = P[pi].lstart, src = P[pi].src;
+    auto byte_at = [&](uint64_t pos) -> uint32_t {
+        while (pos < ls) { pi--; ls = P[pi].lstart; src = P[pi].src; }      // (pieces may be empty: a loop)
+        const uint8_t* from = (src & kPieceRepl) ? repl + (src & ~kPieceRepl) : text + src;
+        return from[pos - ls];
+    };
+    int64_t i = (int64_t)index;
+    for (;;) {
+        while (i > 0 && (byte_at((uint64_t)i) & 0xC0u) == 0x80u) i--;      // atTrailingByte
+        if (n == 0 || i <= 0) return (uint64_t)(i < 0 ? 0 : i);
+        i--; n--;
+    }
+}
+
 // Watchdog: the loops of a haystack's run look at the clock; a run that lasts longer than kLpMaxTicks (a corrupt table, a bug) gives up with
 // the overflow flag and the number of the loop in ctrl[5], and the host takes the pass-by-pass loop: the kernel cannot hang.
 constexpr uint64_t kLpMaxTicks = 400000000ull;            // of s_memtime's 100 MHz: 4 s for ONE haystack
@@ -154,16 +177,22 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
                 const Record rec = R[r];
                 end_pos = rec.end_pos;
                 const RpStateOne one = a.t.one[rec.state];
+                uint32_t cps = 0, rl = 0;
                 if (one.nvals == 1) {
-                    if (one.priority == best) { sel = true; pl = one.payload; len = one.len_bytes; delta = (int64_t)one.repl_len - (int64_t)len; }
+                    if (one.priority == best) { sel = true; pl = one.payload; len = one.len_bytes; cps = one.len_code_points; rl = one.repl_len; }
                 } else {
                     for (uint64_t k = a.t.vals_off[rec.state], ke = a.t.vals_off[rec.state + 1]; k < ke; k++) {
                         const uint32_t v = a.t.vals[k];
                         if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
                     }
-                    if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; delta = (int64_t)pp.repl_len - (int64_t)len; }
+                    if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; cps = pp.len_code_points; rl = pp.repl_len; }
                 }
-                start = end_pos - len;                                   // makeMatch (Replacer.hs:266-267)
+                start = end_pos - len;                                   // makeMatch, CaseSensitive (Replacer.hs:266-267)
+                if (IC && sel) {                                         // IgnoreCase (:268-274): the match is as long as its code points are in the haystack
+                    start = cps == 0 ? end_pos : lp_skip_code_points_backwards(P, np, a.text, a.t.repl, end_pos - 1, cps - 1);
+                    len = end_pos - start;
+                }
+                if (sel) delta = (int64_t)rl - (int64_t)len;
             }
             delta_all += delta;
             uint64_t pending = __ballot(sel);
@@ -354,15 +383,18 @@ hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_rp_loop(const RpLoop& a, int waves, hipStream_t st)
+hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves, hipStream_t st)
 {
     if (a.n_hay == 0) return hipSuccess;
-    // wavefronts per SIMD the register budget is cut for (AM_RP_LOOP_WAVES, A/B; the exact phase -- sf_verify -- wants ~125 registers)
+    // wavefronts per SIMD the register budget is cut for (AM_RP_LOOP_WAVES, A/B: the exact phase -- sf_verify -- wants ~125 registers, and cfg5 ran
+    // at 68.0 GiB/s with 4 wavefronts per SIMD, 61.9 / 64.4 / 56.4 with budgets cut for 5 / 6 / 8: the spills cost more than the wavefronts bring)
+    const dim3 grid(a.n_hay), block(64);
+    if (ic) { hipLaunchKernelGGL((k_rp_loop<true, 4>), grid, block, 0, st, a); return hipGetLastError(); }
     switch (waves) {
-    case 5: hipLaunchKernelGGL((k_rp_loop<false, 5>), dim3(a.n_hay), dim3(64), 0, st, a); break;
-    case 6: hipLaunchKernelGGL((k_rp_loop<false, 6>), dim3(a.n_hay), dim3(64), 0, st, a); break;
-    case 8: hipLaunchKernelGGL((k_rp_loop<false, 8>), dim3(a.n_hay), dim3(64), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_rp_loop<false, 4>), dim3(a.n_hay), dim3(64), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_rp_loop<false, 5>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((k_rp_loop<false, 6>), grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL((k_rp_loop<false, 8>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((k_rp_loop<false, 4>), grid, block, 0, st, a); break;
     }
     return hipGetLastError();
 }

@@ -12,8 +12,8 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 
-def _loop_equals_oracle(pairs, hays, max_len=-1):
-    r = am.Replacer(0, pairs)
+def _loop_equals_oracle(pairs, hays, max_len=-1, case=0):
+    r = am.Replacer(case, pairs)
     am.debug_set("AM_RP_LOOP", 0)
     ref = r.run_batch(hays, max_len)
     ref_stats = r.last_stats()
@@ -21,9 +21,9 @@ def _loop_equals_oracle(pairs, hays, max_len=-1):
     got = r.run_batch(hays, max_len)
     stats = r.last_stats()
     am.debug_set("AM_RP_LOOP", -1)
-    o = oracle.Replacer(0, pairs)
+    o = oracle.Replacer(case, pairs)
     exp = [o.run(h, max_len) for h in hays]
-    assert got == exp, (pairs[:6], max_len)
+    assert got == exp, (case, pairs[:6], max_len)
     assert ref == exp
     assert stats[0] == ref_stats[0], "number of passes"
     return got, stats
@@ -53,6 +53,23 @@ def test_loop_length_limit_and_multibyte_text():
     _loop_equals_oracle([("ß", "ss"), ("İ", "i"), ("ss", "ẞ"), ("å", "")], ["ẞßẞ", "ÅåÅ" * 30, "İẞKÅß" * 100, "aİ" * 70, "straße" * 40])
 
 
+def test_loop_ignore_case_walks_back_through_the_piece_list():
+    """makeMatch of an IgnoreCase replacer (Replacer.hs:268-274): the match is as long as its code points are in the HAYSTACK (İ 2 -> 1 bytes,
+    ẞ 3 -> 2, K 3 -> 1, Å 3 -> 2 under lower-casing), found by skipCodePointsBackwards -- here through the piece list, after earlier passes have cut
+    the text into pieces."""
+    pairs = [("i", "<I>"), ("ß", "ss"), ("k", "K!"), ("å", "")]
+    hays = ["İxİİ", "ẞßẞ", "KkK", "ÅåÅ" * 30, "İẞKÅ" * 100, "aİ" * 70]
+    _loop_equals_oracle(pairs, hays, case=1)
+    _loop_equals_oracle([("straße", "STR"), ("i", "İİ"), ("k", ""), ("å", "K")], ["Straße İstanbul KÅ" * 80, "strasse", "ẞ" * 50 + "straße"], case=1)
+    rng = random.Random(11)
+    for _ in range(10):
+        pairs = [("".join(rng.choice("abikßå") for _ in range(rng.randint(1, 3))),
+                  "".join(rng.choice("xyİK") for _ in range(rng.randint(0, 3)))) for _ in range(rng.randint(1, 6))]
+        hays = ["".join(rng.choice("abikABIK" * 4 + "İẞKÅßå") for _ in range(rng.randint(0, 300))) for _ in range(rng.choice((9, 80)))]
+        _loop_equals_oracle(pairs, hays, case=1)
+        _loop_equals_oracle(pairs, hays, 400, case=1)
+
+
 def test_loop_random_pair_sets_many_haystacks_many_passes():
     rng = random.Random(41)
     for _ in range(8):
@@ -62,6 +79,7 @@ def test_loop_random_pair_sets_many_haystacks_many_passes():
         hays = ["".join(rng.choice(alpha) for _ in range(rng.choice((0, 1, 3, 50, 800, 5000)))) for _ in range(rng.choice((1, 30, 200)))]
         _, stats = _loop_equals_oracle(pairs, hays)
         _loop_equals_oracle(pairs, hays, 1000)
+        _loop_equals_oracle(pairs, hays, case=1)
 
 
 def test_loop_falls_back_when_a_haystack_outgrows_its_regions():
