@@ -19,6 +19,7 @@ struct am_replacer {
     DevBuf vals_off, vals, payloads, repl, one;
     RpTables t{};
     uint32_t max_repl_len = 0;                        // longest replacement (bounds the re-scan window of the one-kernel loop)
+    uint32_t max_needle_bytes = 0;                    // longest needle in bytes as the payloads give it (exact for CaseSensitive replacers)
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
     // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
     mutable std::mutex session_mu;
@@ -93,7 +94,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
     ON_DEVICE(a->dev);
     const uint64_t n_states = f->h.n_states;
     if (!values_offsets || values_offsets[0] != 0) return fail(AM_ERR_INVALID, "values_offsets[0] must be 0");
-    uint32_t max_repl = 0;
+    uint32_t max_repl = 0, max_needle = 0;
     const uint64_t n_values = values_offsets[n_states];
     if ((n_values && !values) || (n_payloads && !payloads) || (n_repl_bytes && !repl_bytes)) return fail(AM_ERR_INVALID, "null table");
     for (uint64_t s = 0; s < n_states; s++) {
@@ -108,6 +109,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         for (size_t i = 0; i < n_payloads; i++) {
             pr[i] = payloads[i].priority;
             if (payloads[i].repl_len > max_repl) max_repl = payloads[i].repl_len;
+            if (payloads[i].len_bytes > max_needle) max_needle = payloads[i].len_bytes;
             if (pr[i] > 0) return fail(AM_ERR_INVALID, "priorities must be <= 0 (the initial threshold is 1, Replacer.hs:211)");
             if ((uint64_t)payloads[i].repl_off + payloads[i].repl_len > n_repl_bytes) return fail(AM_ERR_INVALID, "replacement slice out of range");
             if (case_mode == AM_IGNORE_CASE && payloads[i].len_code_points == 0)
@@ -117,7 +119,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         for (size_t i = 1; i < n_payloads; i++) if (pr[i] == pr[i - 1]) return fail(AM_ERR_INVALID, "payload priorities must be distinct");
     }
     am_replacer* r = new am_replacer();
-    r->a = a; r->case_mode = case_mode; r->max_repl_len = max_repl;
+    r->a = a; r->case_mode = case_mode; r->max_repl_len = max_repl; r->max_needle_bytes = max_needle;
     auto up = [&](DevBuf& d, const void* src, size_t bytes) -> int {
         AM_TRY(d.ensure(bytes + 64));
         if (bytes) HIP_TRY(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
@@ -845,7 +847,11 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
         for (cfg::Key k : {cfg::kRpFullScans, cfg::kRpSplice, cfg::kRpPieces, cfg::kRpParallelFold, cfg::kRpGroups, cfg::kRpNoFuse, cfg::kRpNoRangeReuse, cfg::kRpNoSpin, cfg::kRpMatMain})
             if (cfg::get(k) != cfg::kUnset) return AM_OK;
     }
-    const uint32_t ov = 4u * (fl->h.max_needle_cps ? fl->h.max_needle_cps : 1u) + 4u;
+    // how far a replacement's neighbourhood reaches = the longest needle in haystack bytes: exact for CaseSensitive replacers (the payloads carry
+    // the needles' byte lengths; 4 bytes per code point + 4 would make the windows of ASCII needles four times as long), the bound by code points
+    // under IgnoreCase (the matched text may be longer than the lower-cased needle)
+    const uint32_t ov_cps = 4u * (fl->h.max_needle_cps ? fl->h.max_needle_cps : 1u) + 4u;
+    const uint32_t ov = r->case_mode == AM_CASE_SENSITIVE && r->max_needle_bytes > 0 && r->max_needle_bytes < ov_cps ? r->max_needle_bytes : ov_cps;
     const uint64_t wcap64 = ((2ull * ov + r->max_repl_len + 16ull) + 63ull) & ~63ull;
     if (wcap64 > 4096 || wcap64 * n_hay > (1ull << 30) || in->total >= (1ull << 40)) return AM_OK;
     ON_DEVICE(in->dev);

@@ -23,6 +23,7 @@ namespace dev {
 namespace {
 
 constexpr int kWave = 64;
+constexpr int kFold = 4;                                  // records per lane the fold keeps in registers (lists of up to 256 records are read once per pass)
 
 __device__ __forceinline__ int64_t lp_wave_max_i64(int64_t v)
 {
@@ -150,55 +151,71 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
     while (!overflow) {
         passes++;
         LP_STEP(1);
-        // ---- prependMatch, first half: the best priority below the threshold (Replacer.hs:255-258)
+        // ---- prependMatch, first half: the best priority below the threshold (Replacer.hs:255-258).
+        // The first kFold x 64 records are taken kFold per lane with all their loads in flight together (record -> its state's entry: two trips for
+        // the lot instead of two per 64) and stay in registers for the second half; longer lists go on 64 at a time.
         int64_t best = INT64_MIN;
-        for (uint64_t r = lane; r < nr; r += kWave) {
-            const uint32_t st = R[r].state;
-            const RpStateOne one = a.t.one[st];
-            if (one.nvals == 1) { if (one.priority < threshold && one.priority > best) best = one.priority; }
-            else for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+        int64_t c_prio[kFold]; uint64_t c_end[kFold]; uint32_t c_st[kFold], c_pl[kFold], c_len[kFold], c_rl[kFold], c_cps[kFold]; bool c_one[kFold], c_valid[kFold];
+#pragma unroll
+        for (int u = 0; u < kFold; u++) {
+            const uint64_t r = (uint64_t)u * kWave + lane;
+            c_valid[u] = r < nr;
+            Record rec{0, 0, 0};
+            if (c_valid[u]) rec = R[r];
+            c_st[u] = rec.state; c_end[u] = rec.end_pos;
+        }
+#pragma unroll
+        for (int u = 0; u < kFold; u++) {
+            RpStateOne one{0, 0, 0, 0, 0, 0, 0};
+            if (c_valid[u]) one = a.t.one[c_st[u]];
+            c_one[u] = one.nvals == 1; c_prio[u] = one.priority; c_pl[u] = one.payload; c_len[u] = one.len_bytes; c_rl[u] = one.repl_len; c_cps[u] = one.len_code_points;
+        }
+        auto best_of_list = [&](uint32_t st) {
+            for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
                 const int64_t p = a.t.payloads[a.t.vals[k]].priority;
                 if (p < threshold && p > best) best = p;
             }
+        };
+#pragma unroll
+        for (int u = 0; u < kFold; u++) {
+            if (c_valid[u]) {
+                if (c_one[u]) { if (c_prio[u] < threshold && c_prio[u] > best) best = c_prio[u]; }
+                else best_of_list(c_st[u]);
+            }
+        }
+        for (uint64_t r = (uint64_t)kFold * kWave + lane; r < nr; r += kWave) {
+            const uint32_t st = R[r].state;
+            const RpStateOne one = a.t.one[st];
+            if (one.nvals == 1) { if (one.priority < threshold && one.priority > best) best = one.priority; }
+            else best_of_list(st);
         }
         best = (int64_t)uniform_u64((uint64_t)lp_wave_max_i64(best));
         if (best == INT64_MIN) { status = kRpFinished; break; }           // no match below the threshold: the text stays (:228-230)
 
-        // ---- second half: the matches that carry it, makeMatch (:264-267), removeOverlap (:191-198)
+        // ---- second half: the matches that carry it, makeMatch (:264-267), removeOverlap (:191-198), 64 records at a time in position order
         int64_t delta_all = 0, delta_kept = 0;
         uint64_t last_end = 0;
         uint32_t nkept = 0, payload = 0;
-        for (uint64_t base = 0; base < nr && !overflow; base += kWave) {
-            const uint64_t r = base + lane;
-            LP_STEP(3);
-            bool sel = false; uint32_t pl = 0; uint64_t end_pos = 0;
-            uint64_t start = 0, len = 0; int64_t delta = 0;
-            if (r < nr) {
-                const Record rec = R[r];
-                end_pos = rec.end_pos;
-                const RpStateOne one = a.t.one[rec.state];
-                uint32_t cps = 0, rl = 0;
-                if (one.nvals == 1) {
-                    if (one.priority == best) { sel = true; pl = one.payload; len = one.len_bytes; cps = one.len_code_points; rl = one.repl_len; }
-                } else {
-                    for (uint64_t k = a.t.vals_off[rec.state], ke = a.t.vals_off[rec.state + 1]; k < ke; k++) {
-                        const uint32_t v = a.t.vals[k];
-                        if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
-                    }
-                    if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; cps = pp.len_code_points; rl = pp.repl_len; }
-                }
-                start = end_pos - len;                                   // makeMatch, CaseSensitive (Replacer.hs:266-267)
-                if (IC && sel) {                                         // IgnoreCase (:268-274): the match is as long as its code points are in the haystack
-                    start = cps == 0 ? end_pos : lp_skip_code_points_backwards(P, np, a.text, a.t.repl, end_pos - 1, cps - 1);
-                    len = end_pos - start;
-                }
-                if (sel) delta = (int64_t)rl - (int64_t)len;
+        // the value of the state's list that carries `best` (a state with several values)
+        auto pick_of_list = [&](uint32_t st, bool& sel, uint32_t& pl, uint64_t& len, uint32_t& cps, uint32_t& rl) {
+            for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+                const uint32_t v = a.t.vals[k];
+                if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
             }
+            if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; cps = pp.len_code_points; rl = pp.repl_len; }
+        };
+        // one block of 64 records: sel = carries the best priority (then pl, len, cps, rl are its payload's)
+        auto block = [&](bool sel, uint32_t pl, uint64_t len, uint32_t cps, uint32_t rl, uint64_t end_pos) {
+            uint64_t start = end_pos - len;                              // makeMatch, CaseSensitive (Replacer.hs:266-267)
+            if (IC && sel) {                                             // IgnoreCase (:268-274): the match is as long as its code points are in the haystack
+                start = cps == 0 ? end_pos : lp_skip_code_points_backwards(P, np, a.text, a.t.repl, end_pos - 1, cps - 1);
+                len = end_pos - start;
+            }
+            const int64_t delta = sel ? (int64_t)rl - (int64_t)len : 0;
             delta_all += delta;
             uint64_t pending = __ballot(sel);
             bool keep = false;
-            while (pending && !overflow) {
-                LP_STEP(4);
+            while (pending) {
                 const uint64_t ok = __ballot(sel && start >= last_end) & pending;
                 if (!ok) break;
                 const int l = __ffsll((unsigned long long)ok) - 1;
@@ -219,6 +236,30 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
                 delta_kept += (int64_t)uniform_u64((uint64_t)__shfl(incl, kWave - 1, kWave));
                 nkept += __popcll(keepmask);
             }
+        };
+#pragma unroll
+        for (int u = 0; u < kFold; u++) {
+            if ((uint64_t)u * kWave < nr) {                              // (uniform)
+                bool sel = false; uint32_t pl = 0, cps = 0, rl = 0; uint64_t len = 0;
+                if (c_valid[u]) {
+                    if (c_one[u]) { if (c_prio[u] == best) { sel = true; pl = c_pl[u]; len = c_len[u]; cps = c_cps[u]; rl = c_rl[u]; } }
+                    else pick_of_list(c_st[u], sel, pl, len, cps, rl);
+                }
+                block(sel, pl, len, cps, rl, c_end[u]);
+            }
+        }
+        for (uint64_t base = (uint64_t)kFold * kWave; base < nr && !overflow; base += kWave) {
+            const uint64_t r = base + lane;
+            LP_STEP(3);
+            bool sel = false; uint32_t pl = 0, cps = 0, rl = 0; uint64_t len = 0, end_pos = 0;
+            if (r < nr) {
+                const Record rec = R[r];
+                end_pos = rec.end_pos;
+                const RpStateOne one = a.t.one[rec.state];
+                if (one.nvals == 1) { if (one.priority == best) { sel = true; pl = one.payload; len = one.len_bytes; cps = one.len_code_points; rl = one.repl_len; } }
+                else pick_of_list(rec.state, sel, pl, len, cps, rl);
+            }
+            block(sel, pl, len, cps, rl, end_pos);
         }
         delta_all = (int64_t)uniform_u64((uint64_t)lp_wave_sum_i64(delta_all));
         payload = lp_u32((uint32_t)lp_wave_max_i64((int64_t)payload));    // uniform: every kept match has the same payload
@@ -234,7 +275,40 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         const uint64_t repl_len = nkept ? pp.repl_len : 0;
         if ((uint64_t)np + 2ull * nkept + 2ull > cap_p) { overflow = true; break; }
         uint32_t nq = 0;
-        {
+        if (nkept == 1) {
+            // ONE kept match (a pass of a haystack usually makes one replacement): every piece knows what it becomes from K[0] alone -- untouched
+            // before the match, moved behind it, cut where it overlaps (at most: head, replacement, tail) -- one sweep, no look at K per piece
+            // (matches are not empty here: automata with the empty needle do not take this kernel)
+            RpKept k = K[0];
+            k.src_start = uniform_u64(k.src_start); k.src_len = uniform_u64(k.src_len); k.dst = uniform_u64(k.dst);
+            const uint64_t ms = k.src_start, me = k.src_start + k.src_len;
+            const int64_t shift = (int64_t)(k.dst + repl_len) - (int64_t)me;      // new position - old position behind the match
+            for (uint32_t r0 = 0; r0 < np && !overflow; r0 += kWave) {
+                LP_STEP(5);
+                const uint32_t i = r0 + lane;
+                RpPiece e[3]; uint32_t c = 0;
+                if (i < np) {
+                    const RpPiece pc = P[i];
+                    const uint64_t ls = pc.lstart, le = P[i + 1].lstart;
+                    if (le > ls) {
+                        if (le <= ms) { e[c++] = RpPiece{pc.src, ls}; }                       // ends at or before the match
+                        else if (ls >= me) { e[c++] = RpPiece{pc.src, (uint64_t)((int64_t)ls + shift)}; }      // starts behind it
+                        else {
+                            if (ms > ls) e[c++] = RpPiece{pc.src, ls};                                               // head
+                            if (ms >= ls && repl_len) e[c++] = RpPiece{kPieceRepl | pp.repl_off, k.dst};   // the match starts in this piece: its replacement
+                            if (me < le) e[c++] = RpPiece{pc.src + (me - ls), (uint64_t)((int64_t)me + shift)};      // tail
+                        }
+                    }
+                }
+                const uint32_t incl = wave_inclusive_sum(c, (uint32_t)lane);
+                uint32_t at = nq + incl - c;
+                if (c > 0) Q[at] = e[0];
+                if (c > 1) Q[at + 1] = e[1];
+                if (c > 2) Q[at + 2] = e[2];
+                nq += lp_u32(__shfl(incl, kWave - 1, kWave));
+            }
+            if (lane == 0) Q[nq] = RpPiece{0, newlen};                    // sentinel
+        } else {
             const uint32_t nk = nkept;
             auto span = [&](uint64_t ls, uint64_t le, uint32_t& ja, uint32_t& jb) {
                 uint32_t lo = 0, hi = nk;

@@ -108,7 +108,7 @@ def test_loop_cfg5_reduced_and_what_it_scans():
     am.debug_set("AM_RP_LOOP", -1)
     assert got == ref and passes == ref_passes and passes > 100
     total = sum(len(h) for h in hays)
-    assert total < scanned < total * 4 and scanned == ref_scanned        # the same windows
+    assert total < scanned <= ref_scanned < total * 4                    # windows as long as the longest needle needs (the pass-by-pass loop: 4 bytes per code point + 4)
     orc = oracle.Replacer(w["case"], pairs)
     with ThreadPoolExecutor(8) as pool:
         exp = list(pool.map(orc.run, hays[:48]))
