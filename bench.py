@@ -228,11 +228,12 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
-            # a profile of another workload, kernel or image layout says nothing about this run: refuse it
-            if pt.get("workload") == args.workload and pt.get("kernel") == "k_" + kname.decode() and int(pt.get("image_version", -1)) == am.api.image_version():
-                traffic = int(pt["hbm_bytes_per_scanned_byte"] * n_bytes)
-                traffic_source = "profiles/pmc_traffic.json (%s; rocprofv3 --pmc on a %s launch, 2 x FETCH_SIZE + WRITE_SIZE, scaled to this launch's bytes; NOT read in this run)" % (
-                    pt.get("profile", "?"), pt.get("launch", "?"))
+            # keyed by workload; a profile of another kernel or image layout says nothing about this run: refuse it
+            e = pt.get("workloads", {}).get(args.workload)
+            if e and e.get("kernel") == "k_" + kname.decode() and int(pt.get("image_version", -1)) == am.api.image_version() and args.plants == 1:
+                traffic = int(e["hbm_bytes_per_scanned_byte"] * n_bytes)
+                traffic_source = "profiles/pmc_traffic.json (%s; rocprofv3 --pmc on a %.1f-GiB launch of this workload, 2 x FETCH_SIZE + WRITE_SIZE, scaled to this launch's bytes; NOT read in this run)" % (
+                    e.get("profile", "?"), e.get("launch_bytes", 0) / float(1 << 30))
         except (OSError, ValueError, KeyError, TypeError):
             traffic, traffic_source = None, None
         out = {

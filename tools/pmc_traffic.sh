@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): HBM traffic of k_sf per workload -- FETCH_SIZE and WRITE_SIZE, each in its own rocprofv3 pass (only
+# --kernel-trace next to --pmc), on a ~2-GiB launch of every workload.  Usage: tools/pmc_traffic.sh <outdir>   -> <outdir>/<workload>.txt
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$1
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+for spec in cfg3_runLower_100k_10GiB:2048 cfg2_runText_10k_1GiB:32768 cfg4_100k_1M_haystacks:20480 natural_100k_10GiB:2048; do
+  W=${spec%%:*}; N=${spec##*:}
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$OUT/$W/$C" -o p -- python "$R/bench.py" --workload $W --hay-count $N --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-h2d > "$OUT/$W.$C.log" 2>&1
+    echo "$W $C rc=$?"
+  done
+  python "$R/tools/pmc_summary.py" "$OUT/$W" "k_sf" > "$OUT/$W.txt" 2>&1
+  rm -rf "$OUT/$W"
+done

@@ -18,5 +18,6 @@ python $R/tools/rocprof_summary.py $OUT/kt > $OUT/kt_summary.md 2>&1
 python $R/tools/rocprof_summary.py $OUT/kt5 > $OUT/kt5_summary.md 2>&1
 bash $R/tools/pmc_profile.sh $OUT/pmc --no-parity
 python $R/tools/pmc_summary.py $OUT/pmc "k_sf" > $OUT/pmc_summary.txt 2>&1
+[ "${2:-all}" = "core" ] || bash $R/tools/pmc_traffic.sh $OUT/traffic
 rm -rf $OUT/kt $OUT/kt5 $OUT/pmc/*/
 ls $OUT

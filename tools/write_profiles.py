@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns one gpurun_out/<tag>/ directory made by tools/profile_round.sh (bench logs, rocprofv3 kernel-trace summary, PMC summary)
-into profiles/<round>_kernel_trace_<tag>.md, profiles/<round>_pmc_<tag>.md, profiles/<round>_replacer_trace_<tag>.md and
-profiles/pmc_traffic.json; the bench logs go to profiles/history/.
+into profiles/<round>_kernel_trace_<tag>.md, profiles/<round>_pmc_<tag>.md and profiles/<round>_replacer_trace_<tag>.md; the bench logs go to
+profiles/history/ (profiles/pmc_traffic.json: tools/pmc_traffic.py).
 Usage: python tools/write_profiles.py r02 r02b "514 (r01 v15), 478 (v16e)" """
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -82,14 +82,7 @@ LDS bank-conflict cycles / LDS active cycles = %.0f %%.
        split / 1e9, split / scanned, other / chunks, 100 * vals["TCC_HIT_sum"] / (vals["TCC_HIT_sum"] + vals["TCC_MISS_sum"]), vals["SQ_INSTS_VALU"] / chunks, hist,
        vals["SQ_INSTS_SALU"] / chunks, vals["SQ_INSTS_LDS"] / chunks, vals["SQ_INSTS_VMEM_RD"] / chunks, 100 * vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"],
        100 * vals["SQ_LDS_BANK_CONFLICT"] / vals["SQ_LDS_IDX_ACTIVE"]))
-sys.path.insert(0, ROOT)
-import alfred_margaret_amd as _am
-tr = {"source": "profiles/%s_pmc_%s.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, cfg3 automaton, 2 GiB launch)" % (RND, V), "kernel": "k_sf", "workload": "cfg3_runLower_100k_10GiB",
-      "profile": "profiles/%s_pmc_%s.md" % (RND, V), "launch": "2-GiB", "image_version": _am.api.image_version(),
-      "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"], "scanned_bytes": scanned,
-      "hbm_bytes_per_scanned_byte": upper / scanned, "by_request_count": split / scanned,
-      "correction": "2 x FETCH_SIZE (gfx950 counts 128-B streaming requests at 64 B) + WRITE_SIZE, per MI355X_MICROARCH.md; by_request_count = stream at 128 B/request + the other requests at 64 B"}
-json.dump(tr, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+# (profiles/pmc_traffic.json -- the figure bench.py scales into roofline.traffic, per workload -- is written by tools/pmc_traffic.py)
 
 # Replacer (config 5)
 if os.path.exists(os.path.join(D, "bench_cfg5_replacer_50k_1GiB.log")) and os.path.getsize(os.path.join(D, "bench_cfg5_replacer_50k_1GiB.log")):
@@ -98,7 +91,7 @@ if os.path.exists(os.path.join(D, "bench_cfg5_replacer_50k_1GiB.log")) and os.pa
     open(os.path.join(P, "%s_replacer_trace_%s.md" % (RND, V)), "w").write('''# %s -- Replacer.run on config 5 (%s), rocprofv3 --kernel-trace --stats
 
     Command: `rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg5_replacer_50k_1GiB --steps 3 --warmup 1 --no-cpu-baseline`
-    (16384 x 64 KiB, 50 000 pairs; every step runs ~160 passes in two concurrent haystack groups; the trace covers the device-resident steps, the
+    (16384 x 64 KiB, 50 000 pairs; every step is one full scan, ONE k_rp_loop launch that runs all ~160 passes of every haystack, and one materialise launch; the trace covers the device-resident steps, the
     host-result steps (am_replacer_run_batch: the `__amd_rocclr_copyBuffer` rows are their device-to-host copies) and one profiled step)
 
     %s
