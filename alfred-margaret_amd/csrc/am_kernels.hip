@@ -896,7 +896,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
         g_sf_dbg = dbg;
     }
     // the role-specialised kernel (am_sfx.hip): AM_SFX = 1 whenever the automaton allows it (tests, A/B), 2 for large scans only; NOT the default --
-    // measured on cfg3 it is bit-exact and 15 % slower than k_sf (5.08 vs 4.32 ms per 4 GiB: DESIGN.md section 6, profiles/history/r04_sfx_*)
+    // measured on cfg3 it is bit-exact and 15 % slower than k_sf (5.08 vs 4.32 ms per 4 GiB: LABNOTES.md R4.1, profiles/history/r04_sfx_*)
     {
         const long sfx = cfg::get(cfg::kSfx);
         const bool plain = ablate == 0 || ablate == 9;
