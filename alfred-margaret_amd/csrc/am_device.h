@@ -139,9 +139,9 @@ struct RpLoop {
     uint8_t* wtext; uint32_t wcap, pad;                     // haystack h: wcap bytes of window scratch
     uint64_t max_len;
     RpLoopOut* out;
-    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time
+    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time, [6] the longest record list of the batch (k_rp_loop_caps)
 };
-hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, hipStream_t st);
+hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, uint32_t* max_records /* atomic max, cleared by the caller */, hipStream_t st);
 hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves_per_simd, hipStream_t st);
 hipError_t launch_pt_init(const uint64_t* offsets, uint32_t n_act, RpPiece* pieces, uint64_t* pc_start, uint32_t* pc_cnt, hipStream_t st);
 hipError_t launch_pt_count(const RpHay* hs, const uint32_t* pc_cnt, uint32_t n_act, uint32_t* need, uint32_t* nwin, hipStream_t st);

@@ -905,12 +905,21 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     AM_TRY(s.scan_tmp.ensure(t32 + 16));
     { Prof pr("rp_ranges", st);
       HIP_TRY(launch_rp_ranges((const Record*)s.recbuf[0].p, n_rec, (uint64_t*)s.rec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, n_hay, st)); }
+    HIP_TRY(hipMemsetAsync(s.lp_ctrl.p, 0, 64, st));
     { Prof pr("rp_scans", st);
-      HIP_TRY(launch_rp_loop_caps((const uint64_t*)s.rec_first.p, n_hay, (uint32_t*)s.lp_cap_r.p, (uint32_t*)s.lp_cap_p.p, st));
+      HIP_TRY(launch_rp_loop_caps((const uint64_t*)s.rec_first.p, n_hay, (uint32_t*)s.lp_cap_r.p, (uint32_t*)s.lp_cap_p.p, (uint32_t*)s.lp_ctrl.p + 6, st));
       HIP_TRY(launch_scan(s.scan_tmp.p, t32, (const uint32_t*)s.lp_cap_r.p, (uint64_t*)s.lp_rec_base.p, n1, st));
       HIP_TRY(launch_scan(s.scan_tmp.p, t32, (const uint32_t*)s.lp_cap_p.p, (uint64_t*)s.lp_pc_base.p, n1, st)); }
     say("ranges + region sizes");
-    HIP_TRY(hipMemsetAsync(s.lp_ctrl.p, 0, 64, st));
+    if (sw != 1) {
+        // a wavefront walks its haystack's whole record list in every pass: one document with very many matches would be the tail of the launch
+        // (the pass-by-pass loop folds such lists in parallel over the records)
+        AM_TRY(s.pin_loop(64));
+        uint32_t* c = (uint32_t*)s.lp_host;
+        HIP_TRY(hipMemcpyAsync(c, s.lp_ctrl.p, 64, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c[6] > 4096u) return AM_OK;
+    }
     RpLoop a{};
     a.t = r->t; a.s = make_sf_view(fl->d_image, fl->h);
     a.text = (const uint8_t*)in->d_text; a.offsets = in->d_offsets; a.n_hay = n_hay; a.ov = ov;

@@ -441,19 +441,21 @@ __global__ void __launch_bounds__(64, W) k_rp_loop(RpLoop a)
 }
 
 // region sizes per haystack from its first scan: records 2 x (2 n + 64), pieces 2 x (4 n + 64)  (n = its records; element n_hay: 0)
-__global__ void __launch_bounds__(256) k_rp_loop_caps(const uint64_t* __restrict__ rec_first, uint32_t n_hay, uint32_t* __restrict__ cap_r2, uint32_t* __restrict__ cap_p2)
+__global__ void __launch_bounds__(256) k_rp_loop_caps(const uint64_t* __restrict__ rec_first, uint32_t n_hay, uint32_t* __restrict__ cap_r2, uint32_t* __restrict__ cap_p2,
+                                                      uint32_t* __restrict__ max_records)
 {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h > n_hay) return;
     if (h == n_hay) { cap_r2[h] = 0; cap_p2[h] = 0; return; }
     const uint64_t n = rec_first[h + 1] - rec_first[h];
+    if (n > 64) atomicMax(max_records, (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n));      // the longest list of the batch (one wavefront will walk it in every pass)
     cap_r2[h] = (uint32_t)(2 * (2 * n + 64));
     cap_p2[h] = (uint32_t)(2 * (4 * n + 64));
 }
 
-hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, hipStream_t st)
+hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, uint32_t* max_records, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_rp_loop_caps, dim3((n_hay + 1 + 255) / 256), dim3(256), 0, st, rec_first, n_hay, cap_r2, cap_p2);
+    hipLaunchKernelGGL(k_rp_loop_caps, dim3((n_hay + 1 + 255) / 256), dim3(256), 0, st, rec_first, n_hay, cap_r2, cap_p2, max_records);
     return hipGetLastError();
 }
 

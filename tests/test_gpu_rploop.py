@@ -91,6 +91,20 @@ def test_loop_falls_back_when_a_haystack_outgrows_its_regions():
     assert got[0] == b"e" * 3200 and stats[0] == 4
 
 
+def test_long_match_lists_take_the_pass_by_pass_loop():
+    """A wavefront walks its haystack's whole record list in every pass, so a batch in which some document has more than 4 096 matches goes to the
+    pass-by-pass loop (parallel over the records) by default; forced through the one-kernel loop it gives the same texts."""
+    pairs = [("aa", "b"), ("bb", "a"), ("ab", "cc")]
+    hays = ["abba" * 20] * 70 + ["aa" * 6000, "x"]
+    r = am.Replacer(0, pairs)
+    got = r.run_batch(hays)
+    o = oracle.Replacer(0, pairs)
+    assert got == [o.run(h) for h in hays]
+    am.debug_set("AM_RP_LOOP", 1)
+    assert r.run_batch(hays) == got
+    am.debug_set("AM_RP_LOOP", -1)
+
+
 def test_loop_cfg5_reduced_and_what_it_scans():
     """BASELINE configs[4] reduced to 256 x 64 KiB: the default route for batches of many documents; the oracle on the first 48 of them."""
     workload = "cfg5_replacer_50k_1GiB"
