@@ -37,6 +37,7 @@ struct ScanOut {
     uint64_t* hay_counts;         // count mode, may be null
     uint64_t* total_values;       // count mode
     uint8_t* flags;               // any mode
+    uint32_t probe_two;           // A/B (AM_SF_PROBE_TWO=1): the two-candidates-per-lane instantiation also for automata with few 4-byte-suffix keys
     uint32_t ablate;              // timing experiments only (AM_SF_ABLATE); 0 in production
     uint64_t* dbg;                // timing experiments only: per-phase cycle sums
 };

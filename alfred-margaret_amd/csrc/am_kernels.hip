@@ -68,7 +68,9 @@ constexpr uint32_t kSfEpochChunks = 16;          // the ring is drained every 16
 constexpr int kSfStage = 1056;                   // per-wave copy of the current chunk (folded): 8 bytes before it at offset 8, the chunk at 16, padding
 constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table: first thing in LDS, the filter words follow
 
-// ILP: unused since the probe always takes two candidates per lane (kept in the instantiation names).
+// ILP: 2 = a probe round always looks at two candidates per lane (up to 128 per round: automata with many needles, ~83 candidates per KiB on the
+// benchmark text); 1 = rounds of at most 64 candidates look at one per lane -- half the probe's instructions -- chosen for automata with a small
+// 4-byte-suffix table, which leave a handful of candidates per chunk (cfg2: +4.7 %; the same branches cost cfg3 1.5 %, hence two instantiations).
 //
 // Work unit = `unit_chunks` consecutive 1-KiB chunks.  A wavefront starts with unit (workgroup, wave) and draws every further
 // one from a global counter: with a fixed stride the slowest wavefront (they differ by +-20 %: contents, the memory channels
@@ -384,21 +386,33 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     u32x2 p_a[2], p_b[2];                                  // the raw buckets (loads possibly still in flight)
     uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};           // the word a matching slot equals; offset in the chunk | 0x8000 (0: no candidate)
     uint32_t p_ci = 0;                                     // chunk (within its epoch) the round belongs to
-    bool pending = false;
+    bool pending = false, p_two = false;                   // p_two: the round has more than 64 candidates (two per lane; else only item 0 is live)
     p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
     auto consume_round = [&]() {
-        bool valid[2], defer[2];
-        uint32_t hint[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x8000u) != 0;
-        sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
-        if (ablate == 4) { defer[0] = false; defer[1] = false; }      // timing experiment only: no resolve
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint64_t m = __ballot(defer[k]);
-            if (defer[k]) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | (hint[k] << 10) | (p_pos[k] & 1023u));
+        auto park = [&](bool defer, uint32_t hint, uint32_t pos) {
+            const uint64_t m = __ballot(defer);
+            if (defer) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | (hint << 10) | (pos & 1023u));
             q2_tail += (uint32_t)__popcll(m);
             if (timing) n_defer += (uint32_t)__popcll(m);
+        };
+        if (ILP == 2 || p_two) {
+            bool valid[2], defer[2];
+            uint32_t hint[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x8000u) != 0;
+            sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
+            if (ablate == 4) { defer[0] = false; defer[1] = false; }      // timing experiment only: no resolve
+            park(defer[0], hint[0], p_pos[0]);
+            park(defer[1], hint[1], p_pos[1]);
+        } else {
+            // at most 64 candidates (automata with few needles leave a handful per chunk): one per lane, half the work
+            const u32x2 a1[1] = {p_a[0]}, b1[1] = {p_b[0]};
+            const uint32_t e1[1] = {p_e[0]};
+            const bool valid[1] = {(p_pos[0] & 0x8000u) != 0};
+            bool defer[1]; uint32_t hint[1];
+            sf_probe_decide<1>(s, a1, b1, e1, valid, defer, hint);
+            if (ablate == 4) defer[0] = false;
+            park(defer[0], hint[0], p_pos[0]);
         }
         pending = false;
     };
@@ -608,11 +622,14 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 }
                 // request this round: up to 128 survivors, two per lane
                 if (n_q1 && ablate != 5) {
-                    uint64_t avail[2];
-                    uint32_t w[2], nb[2];
-                    bool valid[2];
+                    uint64_t avail[2] = {0, 0};
+                    uint32_t w[2] = {0, 0}, nb[2] = {0, 0};
+                    bool valid[2] = {false, false};
+                    const bool two = ILP == 2 || n_q1 > 64u || o.probe_two;      // (uniform; ILP == 2: a constant, the branches below are not there)
+                    p_pos[1] = 0u;
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
+                        if (k == 1 && !two) break;
                         const uint32_t e = 64u * k + lane;
                         valid[k] = e < n_q1;
                         const uint32_t pos = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
@@ -629,7 +646,16 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                         p_pos[k] = valid[k] ? (pos | 0x8000u) : 0u;
                     }
-                    sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
+                    if (two) sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
+                    else {
+                        const uint32_t w1[1] = {w[0]}, nb1[1] = {nb[0]};
+                        const uint64_t av1[1] = {avail[0]};
+                        const bool v1[1] = {valid[0]};
+                        u32x2 a1[1], b1[1]; uint32_t e1[1];
+                        sf_probe_issue<1>(s, w1, nb1, av1, v1, a1, b1, e1);
+                        p_a[0] = a1[0]; p_b[0] = b1[0]; p_e[0] = e1[0];
+                    }
+                    p_two = two;
                     p_ci = ci & (kEpoch - 1u);
                     pending = true;
                     if (timing) { n_probes++; tick(t_probe_pre); }
@@ -878,9 +904,13 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
     }
     if (sf_chunks(b) <= kSfLightChunks)                                                     // one small document: the light configuration
         return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true, false, kSfLightThreads>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false, false, kSfLightThreads>(s, b, o, n_cu, st);
+    // few 4-byte-suffix keys (a hot table of <= 2^15 buckets: up to ~30k needles) = a handful of candidates per chunk: the one-per-lane probe round
+    const bool few = s.tier_log2_cap[3] <= 15u && !o.probe_two;
     if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
+        if (few) return lw15 ? launch_sf_v<IC, MODE, 1, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 1, 0, true>(s, b, o, n_cu, st);
         return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
+    if (few) return lw15 ? launch_sf_v<IC, MODE, 1, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 1, 0, false>(s, b, o, n_cu, st);
     return lw15 ? launch_sf_v<IC, MODE, 2, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
 }
 
@@ -889,6 +919,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     ScanOut o = o_in;
     const uint32_t ablate = cfg::get(cfg::kSfAblate) > 0 ? (uint32_t)cfg::get(cfg::kSfAblate) : 0u;
     o.ablate = ablate;
+    o.probe_two = cfg::on(cfg::kSfProbeTwo) ? 1u : 0u;
     static uint64_t* dbg = nullptr;
     if (ablate >= 8) {
         if (!dbg) { if (hipMalloc((void**)&dbg, 256 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 256 + 16 * 8192); }
