@@ -119,7 +119,7 @@ __device__ __forceinline__ uint64_t lp_skip_code_points_backwards(const RpPiece*
 
 // Watchdog: the loops of a haystack's run look at the clock; a run that lasts longer than kLpMaxTicks (a corrupt table, a bug) gives up with
 // the overflow flag and the number of the loop in ctrl[5], and the host takes the pass-by-pass loop: the kernel cannot hang.
-constexpr uint64_t kLpMaxTicks = 400000000ull;            // of s_memtime's 100 MHz: 4 s for ONE haystack
+constexpr uint64_t kLpMaxTicks = 4000000000ull;           // s_memtime ticks at about the shader clock here (~2 GHz, measured in round 2): ~2 s for ONE haystack
 #define LP_STEP(code) do { if (__builtin_amdgcn_s_memtime() > deadline) { if (lane == 0) atomicMax(a.ctrl + 5, (uint32_t)(code)); overflow = true; } } while (0)
 
 template <bool IC>

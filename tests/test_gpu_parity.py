@@ -668,7 +668,7 @@ def test_shared_handles_from_several_threads():
 
 
 def test_replacer_many_tiny_haystacks_large_bookkeeping():
-    """More than 2^18 haystacks: the per-pass bookkeeping goes through the hipcub scans instead of the single-launch
+    """More than 2^18 haystacks: the per-pass bookkeeping goes through the multi-launch scans (csrc/am_scan.hip) instead of the single-launch
     k_scan_jobs; same answers."""
     pairs = [("ab", "X"), ("Xc", "ba"), ("b", "yy"), ("zz", "")]
     distinct = ["", "a", "ab", "abc", "cab", "abcab", "zzabzz", "bbbb", "Xc", "abab" * 3]
@@ -677,10 +677,12 @@ def test_replacer_many_tiny_haystacks_large_bookkeeping():
     n = (1 << 18) + 1500
     hays = [distinct[(i * 7 + i // 11) % len(distinct)] for i in range(n)]
     r = am.Replacer(0, pairs)
-    got = r.run_batch(hays)
-    assert len(got) == n
-    bad = [i for i in range(n) if got[i] != exp[hays[i]]]
-    assert not bad, (bad[:5], [got[i] for i in bad[:5]])
+    for loop in (0, -1):                              # the pass-by-pass loop (what this test is about), then the default: one workgroup per haystack in k_rp_loop
+        am.debug_set("AM_RP_LOOP", loop)
+        got = r.run_batch(hays)
+        assert len(got) == n
+        bad = [i for i in range(n) if got[i] != exp[hays[i]]]
+        assert not bad, (loop, bad[:5], [got[i] for i in bad[:5]])
 
 
 def test_replacer_record_parallel_fold(monkeypatch):
