@@ -191,7 +191,11 @@ int am_matches_fold_hash(const am_matches* m, const am_needle_ids* values, size_
  *                   and code points (:112-113), replacement = repl_bytes[repl_off .. +repl_len)
  *   min_priority    1 - numNeedles (:217)
  * Priorities must be distinct and <= 0, as build (:100-104) and compose (:127-131) make them.
- * `a` must outlive the replacer.  case_mode is the Replacer's replacerCaseSensitivity. */
+ * `a` must outlive the replacer.  case_mode is the Replacer's replacerCaseSensitivity.
+ * Batches of many documents (>= 64, <= 1 MiB on average, no document with more than 4096 matches) run ALL passes of a
+ * haystack inside one kernel (one wavefront per haystack, csrc/am_rploop.hip); everything else goes pass by pass
+ * (csrc/am_replace.hip).  The results are the same texts either way; am_replaced_passes reports the passes of the
+ * haystack that needed the most. */
 typedef struct am_payload {
     int64_t priority;
     uint32_t len_bytes;
