@@ -85,9 +85,11 @@ hipError_t launch_range_rebase(Record* recs, uint64_t n, uint64_t add, hipStream
 // same layout as am_payload in include/am.h (Replacer.hs:59-70 Payload, replacement text as a slice of one blob)
 struct RpPayload { int64_t priority; uint32_t len_bytes; uint32_t len_code_points; uint64_t repl_off; uint32_t repl_len; uint32_t reserved; };
 // machineValues of the Replacer's automaton in CSR form: the list of state s is payloads[vals[vals_off[s] .. vals_off[s+1])]
-// per state, for the states that carry exactly ONE value (almost all of them): that value's payload, so that the fold reads one entry instead of
-// walking state -> value list -> payload (three dependent loads); nvals != 1: walk the list
-struct RpStateOne { int64_t priority; uint32_t payload, nvals, len_bytes, repl_len, len_code_points, pad; };
+// per state, 8 bytes: for the states that carry exactly ONE value (almost all of them) that value's priority and payload index, so that the fold
+// reads one small entry -- the table of a 50k-needle automaton stays in L2 -- instead of walking state -> value list -> payload (three dependent
+// loads); payload == kRpWalkList: several values (or a priority beyond 32 bits): walk the list
+struct RpStateOne { int32_t priority; uint32_t payload; };
+constexpr uint32_t kRpWalkList = 0xFFFFFFFFu;
 struct RpTables { const uint64_t* vals_off; const uint32_t* vals; const RpPayload* payloads; const uint8_t* repl; int64_t min_priority; const RpStateOne* one; };
 struct RpKept { uint64_t src_start, src_len, dst; };     // a match that survives removeOverlap; dst = where its replacement starts in the new text
 constexpr uint32_t kRpActive = 0, kRpFinished = 1, kRpNothing = 2;
@@ -137,10 +139,10 @@ struct RpLoop {
     Record* rec_buf; const uint64_t* rec_base;              // haystack h: records [rec_base[h], rec_base[h + 1]), two halves
     RpPiece* pc_buf; const uint64_t* pc_base;               // the same for its piece lists
     RpKept* kept_buf;                                       // haystack h: from rec_base[h] / 2, half a record region long
-    uint8_t* wtext; uint32_t wcap, pad;                     // haystack h: wcap bytes of window scratch
+    uint8_t* wtext; uint32_t wcap, pad;                     // haystack h: wcap bytes of window scratch; pad != 0: the instrumented instantiation
     uint64_t max_len;
     RpLoopOut* out;
-    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time, [6] the longest record list of the batch (k_rp_loop_caps)
+    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time, [6] the longest record list of the batch (k_rp_loop_caps), [8..23] eight 64-bit phase sums of the instrumented instantiation
 };
 hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, uint32_t* max_records /* atomic max, cleared by the caller */, hipStream_t st);
 hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves_per_simd, hipStream_t st);

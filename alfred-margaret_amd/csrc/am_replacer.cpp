@@ -134,10 +134,11 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         std::vector<RpStateOne> one(n_states);
         for (uint64_t s = 0; s < n_states; s++) {
             const uint64_t n = values_offsets[s + 1] - values_offsets[s];
-            RpStateOne e{0, 0, (uint32_t)(n > 0xFFFFFFFFull ? 0xFFFFFFFFull : n), 0, 0, 0, 0};
+            RpStateOne e{0, kRpWalkList};
             if (n == 1) {
-                const am_payload& pl = payloads[values[values_offsets[s]]];
-                e.priority = pl.priority; e.payload = values[values_offsets[s]]; e.len_bytes = pl.len_bytes; e.repl_len = pl.repl_len; e.len_code_points = pl.len_code_points;
+                const uint32_t v = values[values_offsets[s]];
+                const int64_t pr = payloads[v].priority;
+                if (pr >= INT32_MIN) { e.priority = (int32_t)pr; e.payload = v; }
             }
             one[s] = e;
         }
@@ -899,13 +900,13 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     AM_TRY(s.lp_cap_r.ensure(n1 * 4)); AM_TRY(s.lp_cap_p.ensure(n1 * 4)); AM_TRY(s.lp_rec_base.ensure(n1 * 8)); AM_TRY(s.lp_pc_base.ensure(n1 * 8));
     AM_TRY(s.lp_rec.ensure((rec_total + 1) * sizeof(Record))); AM_TRY(s.lp_pc.ensure((pc_total + 1) * sizeof(RpPiece)));
     AM_TRY(s.lp_kept.ensure((rec_total / 2 + 1) * sizeof(RpKept)));
-    AM_TRY(s.lp_wtext.ensure(wcap64 * n_hay + 64)); AM_TRY(s.lp_out.ensure(n1 * sizeof(RpLoopOut))); AM_TRY(s.lp_ctrl.ensure(64));
+    AM_TRY(s.lp_wtext.ensure(wcap64 * n_hay + 64)); AM_TRY(s.lp_out.ensure(n1 * sizeof(RpLoopOut))); AM_TRY(s.lp_ctrl.ensure(128));
     size_t t32 = 0;
     if (scan_temp_bytes(n1, &t32) != hipSuccess) return fail(AM_ERR_HIP, "scan sizing failed");
     AM_TRY(s.scan_tmp.ensure(t32 + 16));
     { Prof pr("rp_ranges", st);
       HIP_TRY(launch_rp_ranges((const Record*)s.recbuf[0].p, n_rec, (uint64_t*)s.rec_first.p, RpRoute{nullptr, nullptr, nullptr, nullptr, nullptr}, n_hay, st)); }
-    HIP_TRY(hipMemsetAsync(s.lp_ctrl.p, 0, 64, st));
+    HIP_TRY(hipMemsetAsync(s.lp_ctrl.p, 0, 128, st));
     { Prof pr("rp_scans", st);
       HIP_TRY(launch_rp_loop_caps((const uint64_t*)s.rec_first.p, n_hay, (uint32_t*)s.lp_cap_r.p, (uint32_t*)s.lp_cap_p.p, (uint32_t*)s.lp_ctrl.p + 6, st));
       HIP_TRY(launch_scan(s.scan_tmp.p, t32, (const uint32_t*)s.lp_cap_r.p, (uint64_t*)s.lp_rec_base.p, n1, st));
@@ -928,10 +929,19 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     a.pc_buf = (RpPiece*)s.lp_pc.p; a.pc_base = (const uint64_t*)s.lp_pc_base.p;
     a.kept_buf = (RpKept*)s.lp_kept.p; a.wtext = (uint8_t*)s.lp_wtext.p; a.wcap = (uint32_t)wcap64;
     a.max_len = max_length; a.out = (RpLoopOut*)s.lp_out.p; a.ctrl = (uint32_t*)s.lp_ctrl.p;
+    a.pad = cfg::get(cfg::kRpTrace) >= 3 ? 1u : 0u;
     say("launch");
     { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, (int)cfg::get(cfg::kRpLoopWaves), st)); }
     say("launched");
     // what every haystack ended as
+    if (a.pad) {
+        uint64_t ph[8];
+        HIP_TRY(hipMemcpy(ph, (const uint8_t*)s.lp_ctrl.p + 32, 64, hipMemcpyDeviceToHost));
+        static const char* const names[7] = {"fold 1 (best priority)", "fold 2 (select, overlaps)", "pieces", "record copies + searches", "gather", "window scan", "whole run"};
+        for (int i = 0; i < 7; i++) std::fprintf(stderr, "[am_replacer loop] %-26s %14llu cycles = %5.1f %% of the wavefronts' time, %8.0f per pass\n", names[i], (unsigned long long)ph[i],
+                                                 100.0 * (double)ph[i] / (double)(ph[6] ? ph[6] : 1), (double)ph[i] / (double)(ph[7] ? ph[7] : 1));
+        std::fprintf(stderr, "[am_replacer loop] passes of all haystacks: %llu\n", (unsigned long long)ph[7]);
+    }
     const size_t out_bytes = (size_t)n_hay * sizeof(RpLoopOut);
     const size_t tab_bytes = (size_t)n_hay * (sizeof(RpFin) + 8 + 4) + 64;
     AM_TRY(s.pin_loop(64 + out_bytes + tab_bytes));

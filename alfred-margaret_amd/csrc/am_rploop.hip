@@ -122,10 +122,15 @@ __device__ __forceinline__ uint64_t lp_skip_code_points_backwards(const RpPiece*
 constexpr uint64_t kLpMaxTicks = 4000000000ull;           // s_memtime ticks at about the shader clock here (~2 GHz, measured in round 2): ~2 s for ONE haystack
 #define LP_STEP(code) do { if (__builtin_amdgcn_s_memtime() > deadline) { if (lane == 0) atomicMax(a.ctrl + 5, (uint32_t)(code)); overflow = true; } } while (0)
 
-template <bool IC>
+// DBG (AM_RP_TRACE >= 3): s_memtime per phase of every pass, summed over all haystacks into ctrl[8..23] (64-bit: fold 1, fold 2, pieces, record copies + searches,
+// gather, window scan, the whole run, passes)
+template <bool IC, bool DBG>
 __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lane)
 {
     const uint64_t deadline = __builtin_amdgcn_s_memtime() + kLpMaxTicks;
+    uint64_t t_mark = DBG ? __builtin_amdgcn_s_memtime() : 0, t_ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    const uint64_t t_begin = t_mark;
+    auto tick = [&](int ph) { if (DBG) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_ph[ph] += now - t_mark; t_mark = now; } };
     // (everything every lane agrees on goes through readfirstlane: the compiler then keeps it in scalar registers and branches on it with
     // scalar branches -- the loops below are uniform by construction, and it cannot know that)
     const uint64_t hoff = uniform_u64(a.offsets[h]);
@@ -155,7 +160,7 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         // The first kFold x 64 records are taken kFold per lane with all their loads in flight together (record -> its state's entry: two trips for
         // the lot instead of two per 64) and stay in registers for the second half; longer lists go on 64 at a time.
         int64_t best = INT64_MIN;
-        int64_t c_prio[kFold]; uint64_t c_end[kFold]; uint32_t c_st[kFold], c_pl[kFold], c_len[kFold], c_rl[kFold], c_cps[kFold]; bool c_one[kFold], c_valid[kFold];
+        uint64_t c_end[kFold]; int32_t c_prio[kFold]; uint32_t c_st[kFold], c_pl[kFold]; bool c_valid[kFold];
 #pragma unroll
         for (int u = 0; u < kFold; u++) {
             const uint64_t r = (uint64_t)u * kWave + lane;
@@ -166,9 +171,9 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         }
 #pragma unroll
         for (int u = 0; u < kFold; u++) {
-            RpStateOne one{0, 0, 0, 0, 0, 0, 0};
+            RpStateOne one{0, kRpWalkList};
             if (c_valid[u]) one = a.t.one[c_st[u]];
-            c_one[u] = one.nvals == 1; c_prio[u] = one.priority; c_pl[u] = one.payload; c_len[u] = one.len_bytes; c_rl[u] = one.repl_len; c_cps[u] = one.len_code_points;
+            c_prio[u] = one.priority; c_pl[u] = one.payload;
         }
         auto best_of_list = [&](uint32_t st) {
             for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
@@ -179,17 +184,18 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
 #pragma unroll
         for (int u = 0; u < kFold; u++) {
             if (c_valid[u]) {
-                if (c_one[u]) { if (c_prio[u] < threshold && c_prio[u] > best) best = c_prio[u]; }
+                if (c_pl[u] != kRpWalkList) { if ((int64_t)c_prio[u] < threshold && (int64_t)c_prio[u] > best) best = c_prio[u]; }
                 else best_of_list(c_st[u]);
             }
         }
         for (uint64_t r = (uint64_t)kFold * kWave + lane; r < nr; r += kWave) {
             const uint32_t st = R[r].state;
             const RpStateOne one = a.t.one[st];
-            if (one.nvals == 1) { if (one.priority < threshold && one.priority > best) best = one.priority; }
+            if (one.payload != kRpWalkList) { if ((int64_t)one.priority < threshold && (int64_t)one.priority > best) best = one.priority; }
             else best_of_list(st);
         }
         best = (int64_t)uniform_u64((uint64_t)lp_wave_max_i64(best));
+        tick(0);
         if (best == INT64_MIN) { status = kRpFinished; break; }           // no match below the threshold: the text stays (:228-230)
 
         // ---- second half: the matches that carry it, makeMatch (:264-267), removeOverlap (:191-198), 64 records at a time in position order
@@ -197,15 +203,16 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         uint64_t last_end = 0;
         uint32_t nkept = 0, payload = 0;
         // the value of the state's list that carries `best` (a state with several values)
-        auto pick_of_list = [&](uint32_t st, bool& sel, uint32_t& pl, uint64_t& len, uint32_t& cps, uint32_t& rl) {
+        auto pick_of_list = [&](uint32_t st, bool& sel, uint32_t& pl) {
             for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
                 const uint32_t v = a.t.vals[k];
                 if (a.t.payloads[v].priority == best) { sel = true; pl = v; }
             }
-            if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; cps = pp.len_code_points; rl = pp.repl_len; }
         };
         // one block of 64 records: sel = carries the best priority (then pl, len, cps, rl are its payload's)
-        auto block = [&](bool sel, uint32_t pl, uint64_t len, uint32_t cps, uint32_t rl, uint64_t end_pos) {
+        auto block = [&](bool sel, uint32_t pl, uint64_t end_pos) {
+            uint64_t len = 0; uint32_t cps = 0, rl = 0;
+            if (sel) { const RpPayload pp = a.t.payloads[pl]; len = pp.len_bytes; cps = pp.len_code_points; rl = pp.repl_len; }      // (the few records that carry the best priority)
             uint64_t start = end_pos - len;                              // makeMatch, CaseSensitive (Replacer.hs:266-267)
             if (IC && sel) {                                             // IgnoreCase (:268-274): the match is as long as its code points are in the haystack
                 start = cps == 0 ? end_pos : lp_skip_code_points_backwards(P, np, a.text, a.t.repl, end_pos - 1, cps - 1);
@@ -240,26 +247,26 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
 #pragma unroll
         for (int u = 0; u < kFold; u++) {
             if ((uint64_t)u * kWave < nr) {                              // (uniform)
-                bool sel = false; uint32_t pl = 0, cps = 0, rl = 0; uint64_t len = 0;
+                bool sel = false; uint32_t pl = 0;
                 if (c_valid[u]) {
-                    if (c_one[u]) { if (c_prio[u] == best) { sel = true; pl = c_pl[u]; len = c_len[u]; cps = c_cps[u]; rl = c_rl[u]; } }
-                    else pick_of_list(c_st[u], sel, pl, len, cps, rl);
+                    if (c_pl[u] != kRpWalkList) { if ((int64_t)c_prio[u] == best) { sel = true; pl = c_pl[u]; } }
+                    else pick_of_list(c_st[u], sel, pl);
                 }
-                block(sel, pl, len, cps, rl, c_end[u]);
+                block(sel, pl, c_end[u]);
             }
         }
         for (uint64_t base = (uint64_t)kFold * kWave; base < nr && !overflow; base += kWave) {
             const uint64_t r = base + lane;
             LP_STEP(3);
-            bool sel = false; uint32_t pl = 0, cps = 0, rl = 0; uint64_t len = 0, end_pos = 0;
+            bool sel = false; uint32_t pl = 0; uint64_t end_pos = 0;
             if (r < nr) {
                 const Record rec = R[r];
                 end_pos = rec.end_pos;
                 const RpStateOne one = a.t.one[rec.state];
-                if (one.nvals == 1) { if (one.priority == best) { sel = true; pl = one.payload; len = one.len_bytes; cps = one.len_code_points; rl = one.repl_len; } }
-                else pick_of_list(rec.state, sel, pl, len, cps, rl);
+                if (one.payload != kRpWalkList) { if ((int64_t)one.priority == best) { sel = true; pl = one.payload; } }
+                else pick_of_list(rec.state, sel, pl);
             }
-            block(sel, pl, len, cps, rl, end_pos);
+            block(sel, pl, end_pos);
         }
         delta_all = (int64_t)uniform_u64((uint64_t)lp_wave_sum_i64(delta_all));
         payload = lp_u32((uint32_t)lp_wave_max_i64((int64_t)payload));    // uniform: every kept match has the same payload
@@ -268,13 +275,14 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         const uint64_t newlen = (uint64_t)((int64_t)curlen + delta_kept);
         status = best == a.t.min_priority ? kRpFinished : kRpActive;    // :241-242
         lp_sync();                                                       // K is read by every lane from here on
+        tick(1);
 
         // ---- replace (:163-180) on the piece list: P -> Q (the scheme of k_pt_build)
         RpPayload pp = a.t.payloads[payload];
         pp.repl_off = uniform_u64(pp.repl_off); pp.repl_len = lp_u32(pp.repl_len);
         const uint64_t repl_len = nkept ? pp.repl_len : 0;
         if ((uint64_t)np + 2ull * nkept + 2ull > cap_p) { overflow = true; break; }
-        uint32_t nq = 0;
+        uint32_t nq = 0, near = 0;                                       // near: index (new list) of the first entry of the piece the match starts in: where the window's gather begins to look
         if (nkept == 1) {
             // ONE kept match (a pass of a haystack usually makes one replacement): every piece knows what it becomes from K[0] alone -- untouched
             // before the match, moved behind it, cut where it overlaps (at most: head, replacement, tail) -- one sweep, no look at K per piece
@@ -287,9 +295,11 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
                 LP_STEP(5);
                 const uint32_t i = r0 + lane;
                 RpPiece e[3]; uint32_t c = 0;
+                bool has_ms = false;
                 if (i < np) {
                     const RpPiece pc = P[i];
                     const uint64_t ls = pc.lstart, le = P[i + 1].lstart;
+                    has_ms = ls <= ms && ms < le;
                     if (le > ls) {
                         if (le <= ms) { e[c++] = RpPiece{pc.src, ls}; }                       // ends at or before the match
                         else if (ls >= me) { e[c++] = RpPiece{pc.src, (uint64_t)((int64_t)ls + shift)}; }      // starts behind it
@@ -305,6 +315,8 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
                 if (c > 0) Q[at] = e[0];
                 if (c > 1) Q[at + 1] = e[1];
                 if (c > 2) Q[at + 2] = e[2];
+                const uint64_t hm = __ballot(has_ms);
+                if (hm) near = lp_u32(__shfl(at, __ffsll((unsigned long long)hm) - 1, kWave));
                 nq += lp_u32(__shfl(incl, kWave - 1, kWave));
             }
             if (lane == 0) Q[nq] = RpPiece{0, newlen};                    // sentinel
@@ -352,6 +364,7 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         { RpPiece* t = P; P = Q; Q = t; }
         np = nq;
         lp_sync();
+        tick(2);
         if (status == kRpFinished) { curlen = newlen; break; }
 
         // ---- the next pass's records: old records outside the neighbourhood of the replacements, shifted, + the records of the windows
@@ -360,18 +373,84 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         uint64_t cursor = 0, at = 0;
         auto end_of = [&](uint64_t i) { return R[i].end_pos; };
         auto copy_shifted = [&](uint64_t from, uint64_t to, int64_t shift) {
-            for (uint64_t i = from + lane; i < to; i += kWave) { Record r = R[i]; r.end_pos = (uint64_t)((int64_t)r.end_pos + shift); r.haystack = h; Rn[cursor + (i - from)] = r; }
+            for (uint64_t base = from; base < to; base += 2 * kWave) {
+                const uint64_t i0 = base + lane, i1 = i0 + kWave;
+                Record r0{0, 0, 0}, r1{0, 0, 0};
+                if (i0 < to) r0 = R[i0];
+                if (i1 < to) r1 = R[i1];
+                if (i0 < to) { r0.end_pos = (uint64_t)((int64_t)r0.end_pos + shift); r0.haystack = h; Rn[cursor + (i0 - from)] = r0; }
+                if (i1 < to) { r1.end_pos = (uint64_t)((int64_t)r1.end_pos + shift); r1.haystack = h; Rn[cursor + (i1 - from)] = r1; }
+            }
+        };
+        // how many of R[from .. nr) end at or before x1 / x2 (x1 <= x2): lists of up to 512 records are looked at whole, eight end positions per lane in
+        // flight -- one trip instead of two 64-ary searches of two trips each
+        auto count2_le = [&](uint64_t from, uint64_t x1, uint64_t x2, uint64_t& c1, uint64_t& c2) {
+            const uint64_t m = nr - from;
+            if (m > 16u * kWave) {
+                c1 = lp_count_le([&](uint64_t i) { return end_of(from + i); }, m, x1, lane, deadline);
+                c2 = c1 + lp_count_le([&](uint64_t i) { return end_of(from + c1 + i); }, m - c1, x2, lane, deadline);
+                return;
+            }
+            uint64_t a1 = 0, a2 = 0;
+            for (uint64_t g = 0; g < m; g += 4u * kWave) {                // 256 end positions per trip; the list is sorted: stop behind x2
+                uint64_t e[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const uint64_t i = g + (uint64_t)u * kWave + lane; e[u] = ~0ull; if (i < m) e[u] = R[from + i].end_pos; }
+                uint64_t in2 = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { a1 += (uint64_t)__popcll(__ballot(e[u] <= x1)); in2 += (uint64_t)__popcll(__ballot(e[u] <= x2)); }
+                a2 += in2;
+                if (in2 < 4u * kWave) break;
+            }
+            c1 = a1; c2 = a2;
+        };
+        // A window of up to 128 bytes that lies in at most four pieces next to `near` (the usual case: pieces are hundreds of bytes, a window tens): the six
+        // entries around `near` in one trip (one per lane, read into scalar registers), every lane's bytes in a second one -- instead of a search through
+        // the list and two trips per piece.  false: not such a window, the general gather does it.
+        auto gather_small = [&](uint64_t ws, uint32_t wlen) -> bool {
+            if (wlen > 2u * kWave) return false;
+            const uint32_t first = near > 0 ? near - 1u : 0u;
+            RpPiece pc{0, ~0ull};
+            if (lane < 6) { const uint32_t idx = first + (uint32_t)lane; pc = P[idx < np ? idx : np]; }      // (P[np]: the sentinel, starts where the text ends)
+            uint64_t ls[6], sr[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) { ls[q] = uniform_u64(__shfl(pc.lstart, q, kWave)); sr[q] = uniform_u64(__shfl(pc.src, q, kWave)); }
+            // the piece the window starts in: entry 1 (= near) if it starts at or before ws, else entry 0; the five entries from there, by name (an
+            // array indexed with a run-time value would live in scratch memory)
+            const uint64_t wend = ws + wlen;
+            const bool from1 = ls[1] <= ws && first + 1u <= np;
+            if (!from1 && ls[0] > ws) return false;
+            const uint64_t l0 = from1 ? ls[1] : ls[0], l1 = from1 ? ls[2] : ls[1], l2 = from1 ? ls[3] : ls[2], l3 = from1 ? ls[4] : ls[3], l4 = from1 ? ls[5] : ls[4];
+            const uint64_t s0 = from1 ? sr[1] : sr[0], s1 = from1 ? sr[2] : sr[1], s2 = from1 ? sr[3] : sr[2], s3 = from1 ? sr[4] : sr[3];
+            if (l4 < wend && first + (from1 ? 5u : 4u) < np) return false;          // the window reaches beyond the fourth piece
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const uint32_t x = (uint32_t)lane + (uint32_t)t * kWave;
+                if (x < wlen) {
+                    const uint64_t pp = ws + x;
+                    uint64_t pls = l0, psr = s0;
+                    if (pp >= l1) { pls = l1; psr = s1; }
+                    if (pp >= l2) { pls = l2; psr = s2; }
+                    if (pp >= l3) { pls = l3; psr = s3; }
+                    const uint8_t* from = (psr & kPieceRepl) ? a.t.repl + (psr & ~kPieceRepl) : a.text + psr;
+                    wt[x] = from[pp - pls];
+                }
+            }
+            return true;
         };
         for (uint32_t j = 0; j < nkept && !overflow; j++) {
             LP_STEP(6);
             RpKept k = K[j];
             k.src_start = uniform_u64(k.src_start); k.src_len = uniform_u64(k.src_len); k.dst = uniform_u64(k.dst);
             // old records that end at or before the replaced region: unchanged context, they move with the text
-            const uint64_t e = at + lp_count_le([&](uint64_t i) { return end_of(at + i); }, nr - at, k.src_start, lane, deadline);
+            uint64_t c_before = 0, c_gone = 0;                           // records of R[at ..) that end at or before the match's start / within reach of its end
+            count2_le(at, k.src_start, k.src_start + k.src_len + a.ov, c_before, c_gone);
+            const uint64_t e = at + c_before;
             if (cursor + (e - at) > cap_r) { overflow = true; break; }
             copy_shifted(at, e, (int64_t)k.dst - (int64_t)k.src_start);
             cursor += e - at;
             // the window of match j in the new text
+            tick(3);
             const uint64_t dst = k.dst;
             uint64_t hi = dst + repl_len + a.ov;
             if (hi > newlen) hi = newlen;
@@ -380,8 +459,9 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
             const uint32_t wlen = hi > dst ? (uint32_t)(hi - ws) : 0u, own_lo = (uint32_t)(dst - ws);
             if (wlen > a.wcap) { overflow = true; break; }
             if (wlen) {
-                lp_gather(P, np, a.text, a.t.repl, ws, wlen, wt, lane, deadline);
+                if (!(nkept == 1 && gather_small(ws, wlen))) lp_gather(P, np, a.text, a.t.repl, ws, wlen, wt, lane, deadline);
                 lp_sync();
+                tick(4);
                 scanned += wlen;
                 for (uint32_t base = own_lo; base < wlen && !overflow; base += kWave) {
                     LP_STEP(7);
@@ -401,10 +481,11 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
                         cursor += nf;
                     }
                 }
-                lp_sync();                                               // (the scratch is rewritten by the next window)
+                if (j + 1 < nkept) lp_sync();                            // (the scratch is rewritten by the next window; after the last one the pass's closing wait covers it)
+                tick(5);
             }
             // old records that touch the replaced bytes are gone
-            at = e + lp_count_le([&](uint64_t i) { return end_of(e + i); }, nr - e, k.src_start + k.src_len + a.ov, lane, deadline);
+            at += c_gone;
         }
         if (overflow) break;
         if (cursor + (nr - at) > cap_r) { overflow = true; break; }
@@ -413,6 +494,7 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         R = Rn; nr = cursor; rsel ^= 1u;
         curlen = newlen; threshold = best;
         lp_sync();
+        tick(3);
     }
 
     if (lane == 0) {
@@ -422,6 +504,11 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         if (overflow) atomicOr(a.ctrl + 0, 1u);
         atomicMax(a.ctrl + 1, passes);
         if (scanned) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 2), (unsigned long long)scanned);
+        if (DBG) {
+            t_ph[6] = __builtin_amdgcn_s_memtime() - t_begin;
+            for (int i = 0; i < 7; i++) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 8) + i, (unsigned long long)t_ph[i]);
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 8) + 7, (unsigned long long)passes);
+        }
     }
 }
 
@@ -431,13 +518,13 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
 // inside the kernel -- wavefronts drawing haystack numbers from a counter -- was the first version: the compiler merged that loop with the
 // pass loop, the haystack number became a loop-carried value of a loop it took for divergent, and the kernel never ended; a haystack number
 // that comes from blockIdx is uniform for the compiler too.)
-template <bool IC, int W>
+template <bool IC, int W, bool DBG = false>
 __global__ void __launch_bounds__(64, W) k_rp_loop(RpLoop a)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const uint32_t h = blockIdx.x;
     if (h >= a.n_hay) return;
-    lp_run_haystack<IC>(a, h, lane);
+    lp_run_haystack<IC, DBG>(a, h, lane);
 }
 
 // region sizes per haystack from its first scan: records 2 x (2 n + 64), pieces 2 x (4 n + 64)  (n = its records; element n_hay: 0)
@@ -466,6 +553,7 @@ hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves, hipStream_t st)
     // at 68.0 GiB/s with 4 wavefronts per SIMD, 61.9 / 64.4 / 56.4 with budgets cut for 5 / 6 / 8: the spills cost more than the wavefronts bring)
     const dim3 grid(a.n_hay), block(64);
     if (ic) { hipLaunchKernelGGL((k_rp_loop<true, 4>), grid, block, 0, st, a); return hipGetLastError(); }
+    if (a.pad) { hipLaunchKernelGGL((k_rp_loop<false, 4, true>), grid, block, 0, st, a); return hipGetLastError(); }      // per-phase cycle sums (AM_RP_TRACE >= 3)
     switch (waves) {
     case 5: hipLaunchKernelGGL((k_rp_loop<false, 5>), grid, block, 0, st, a); break;
     case 6: hipLaunchKernelGGL((k_rp_loop<false, 6>), grid, block, 0, st, a); break;
