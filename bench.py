@@ -229,7 +229,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
             # keyed by workload; a profile of another kernel or image layout says nothing about this run: refuse it
-            e = pt.get("workloads", {}).get(args.workload)
+            e = pt.get("workloads", {}).get("cfg2_runText_10k_1GiB" if args.workload == "cfg2_single_1GiB" else args.workload)      # (one 1-GiB haystack: the same automaton over the same text cells)
             if e and e.get("kernel") == "k_" + kname.decode() and int(pt.get("image_version", -1)) == am.api.image_version() and args.plants == 1:
                 traffic = int(e["hbm_bytes_per_scanned_byte"] * n_bytes)
                 traffic_source = "profiles/pmc_traffic.json (%s; rocprofv3 --pmc on a %.1f-GiB launch of this workload, 2 x FETCH_SIZE + WRITE_SIZE, scaled to this launch's bytes; NOT read in this run)" % (
@@ -479,6 +479,17 @@ def bench_replacer(args, w, rank, world, dev):
         avg_ms = prof[kname][0] / max(prof[kname][1], 1)
         alg_bytes = {"rp_splice": 2.0 * spliced, "rp_loop": float(max(scanned - n_bytes, 0))}.get(kname, float(scanned)) * prof_steps / max(prof[kname][1], 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        rp_traffic, rp_traffic_source = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            e = pt.get("workloads", {}).get(args.workload)
+            if e and e.get("kernel") == "k_" + kname and int(pt.get("image_version", -1)) == am.api.image_version():
+                rp_traffic = int(e["hbm_bytes_per_scanned_byte"] * n_bytes)
+                rp_traffic_source = "profiles/pmc_traffic.json (%s; rocprofv3 --pmc on a %.2f-GiB run of this workload, 2 x FETCH_SIZE + WRITE_SIZE per input byte, scaled; NOT read in this run)" % (
+                    e.get("profile", "?"), e.get("launch_bytes", 0) / float(1 << 30))
+        except (OSError, ValueError, KeyError, TypeError):
+            rp_traffic, rp_traffic_source = None, None
         out = {
             "metric": "GiB/s of input rewritten by Replacer.run (50k pairs, all passes)", "value": round(n_bytes * world / float(1 << 30) * args.steps / elapsed, 3),
             "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -491,7 +502,7 @@ def bench_replacer(args, w, rank, world, dev):
             "passes": passes, "scanned_gib_per_step": round(total_scanned / float(1 << 30), 2), "spliced_gib_per_step": round(spliced / float(1 << 30), 2),
             "kernel_ms_per_step": {k: round(v[0] / prof_steps, 3) for k, v in prof.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": prof[kname][1],
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": rp_traffic, "traffic_source": rp_traffic_source, "avg_launch_ms": round(avg_ms, 4), "launches": prof[kname][1],
                          "alg_bytes_per_launch": int(alg_bytes),
                          "note": "k_rp_loop runs every pass of every haystack (one wavefront per haystack): bound by dependent-load latency and registers, not by HBM" if kname == "rp_loop" else None},
         }

@@ -7,7 +7,7 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 D, TAG = sys.argv[1], sys.argv[2]
-SPEC = {"cfg3_runLower_100k_10GiB": (2048, 1 << 20), "cfg2_runText_10k_1GiB": (32768, 64 << 10), "cfg4_100k_1M_haystacks": (20480, 100 << 10), "natural_100k_10GiB": (2048, 1 << 20)}
+SPEC = {"cfg5_replacer_50k_1GiB": (4096, 64 << 10), "cfg3_runLower_100k_10GiB": (2048, 1 << 20), "cfg2_runText_10k_1GiB": (32768, 64 << 10), "cfg4_100k_1M_haystacks": (20480, 100 << 10), "natural_100k_10GiB": (2048, 1 << 20)}
 version = int(re.search(r"kImageVersion\s*=\s*(\d+)", open(os.path.join(ROOT, "alfred-margaret_amd", "csrc", "am_image.h")).read()).group(1))
 out = {"correction": "2 x FETCH_SIZE (gfx950 counts 128-B streaming requests at 64 B) + WRITE_SIZE, per MI355X_MICROARCH.md; one rocprofv3 --pmc pass per counter",
        "image_version": version, "source": "tools/pmc_traffic.sh on the MI355X box (%s)" % TAG, "workloads": {}}
@@ -16,7 +16,8 @@ for w, (n_hay, hb) in SPEC.items():
     if not os.path.exists(f):
         continue
     blocks = open(f).read().split("### ")
-    emit = [b for b in blocks if re.match(r"void am::dev::k_sf<(true|false), 1,", b)]      # MODE = 1: the match-emitting instantiation
+    kernel = "k_rp_loop" if w.startswith("cfg5") else "k_sf"
+    emit = [b for b in blocks if re.match(r"void am::dev::k_rp_loop<false, 4, false>" if kernel == "k_rp_loop" else r"void am::dev::k_sf<(true|false), 1,", b)]      # k_sf: MODE = 1, the match-emitting instantiation
     if not emit:
         continue
     vals = {}
@@ -27,10 +28,10 @@ for w, (n_hay, hb) in SPEC.items():
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
         continue
     scanned = n_hay * hb
-    out["workloads"][w] = {"kernel": "k_sf", "launch_bytes": scanned, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
+    out["workloads"][w] = {"kernel": kernel, "launch_bytes": scanned, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                            "hbm_bytes_per_scanned_byte": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / scanned, "profile": "profiles/%s_pmc_traffic.md" % TAG}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-lines = ["# %s -- HBM traffic of k_sf per workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, ~2-GiB launches; tools/pmc_traffic.sh)" % TAG, "",
+lines = ["# %s -- HBM traffic of the dominant kernel per workload (k_sf; config 5: k_rp_loop, per byte of INPUT text) (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, ~2-GiB launches; tools/pmc_traffic.sh)" % TAG, "",
          "| workload | launch | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes per scanned byte (2 x FETCH + WRITE) |", "|---|---|---|---|---|"]
 for w, e in out["workloads"].items():
     lines.append("| %s | %.2f GiB | %.0f | %.0f | %.3f |" % (w, e["launch_bytes"] / 2**30, e["fetch_size_kib"], e["write_size_kib"], e["hbm_bytes_per_scanned_byte"]))
