@@ -117,6 +117,49 @@ __device__ __forceinline__ uint64_t lp_skip_code_points_backwards(const RpPiece*
     }
 }
 
+// how many of the sorted key(0 .. m) are <= x1 / <= x2 (x1 <= x2): lists of up to 1024 keys are looked at 256 per trip (four per lane in flight), stopping
+// behind x2 -- one or two trips instead of two 64-ary searches of two trips each
+template <class Key>
+__device__ __forceinline__ void lp_count2_le(Key key, uint64_t m, uint64_t x1, uint64_t x2, uint64_t& c1, uint64_t& c2, int lane, uint64_t deadline)
+{
+    if (m > 16u * kWave) {
+        c1 = lp_count_le(key, m, x1, lane, deadline);
+        c2 = c1 + lp_count_le([&](uint64_t i) { return key(c1 + i); }, m - c1, x2, lane, deadline);
+        return;
+    }
+    uint64_t a1 = 0, a2 = 0;
+    for (uint64_t g = 0; g < m; g += 4u * kWave) {
+        uint64_t e[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint64_t i = g + (uint64_t)u * kWave + lane; e[u] = ~0ull; if (i < m) e[u] = key(i); }
+        uint64_t in2 = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a1 += (uint64_t)__popcll(__ballot(e[u] <= x1)); in2 += (uint64_t)__popcll(__ballot(e[u] <= x2)); }
+        a2 += in2;
+        if (in2 < 4u * kWave) break;
+    }
+    c1 = a1; c2 = a2;
+}
+
+// elements [from, to) of A go to [from + g, to + g), each through fix(): 128 per trip, from the end backwards when they move up (what a store overwrites
+// has been loaded: within a trip all loads precede the stores, across trips the stores land behind everything still to be read), forwards otherwise
+template <class T, class F>
+__device__ __forceinline__ void lp_move(T* A, uint64_t from, uint64_t to, int64_t g, F fix, int lane)
+{
+    if (to <= from) return;
+    const uint64_t nb = (to - from + 2 * kWave - 1) / (2 * kWave);
+    for (uint64_t b = 0; b < nb; b++) {
+        const uint64_t blk = g > 0 ? nb - 1 - b : b;
+        const uint64_t i0 = from + blk * 2 * kWave + (uint64_t)lane, i1 = i0 + kWave;
+        const bool v0 = i0 < to, v1 = i1 < to;
+        T x0{}, x1{};
+        if (v0) x0 = A[i0];
+        if (v1) x1 = A[i1];
+        if (v0) { fix(x0); A[(uint64_t)((int64_t)i0 + g)] = x0; }
+        if (v1) { fix(x1); A[(uint64_t)((int64_t)i1 + g)] = x1; }
+    }
+}
+
 // Watchdog: the loops of a haystack's run look at the clock; a run that lasts longer than kLpMaxTicks (a corrupt table, a bug) gives up with
 // the overflow flag and the number of the loop in ctrl[5], and the host takes the pass-by-pass loop: the kernel cannot hang.
 constexpr uint64_t kLpMaxTicks = 4000000000ull;           // s_memtime ticks at about the shader clock here (~2 GHz, measured in round 2): ~2 s for ONE haystack
@@ -141,7 +184,6 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
     const Record* R = a.recs0 + rf0;                                     // pass 1 reads the first scan's records where they lie
     uint64_t nr = uniform_u64(a.rec_first0[h + 1]) - rf0;
     Record* const Rbuf0 = a.rec_buf + rb; Record* const Rbuf1 = Rbuf0 + cap_r;
-    uint32_t rsel = 0;                                                   // the list the next pass's records go to
     RpPiece* P = a.pc_buf + pb; RpPiece* Q = P + cap_p;
     RpKept* const K = a.kept_buf + (rb >> 1);
     uint8_t* const wt = a.wtext + (uint64_t)h * a.wcap;
@@ -369,8 +411,12 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
 
         // ---- the next pass's records: old records outside the neighbourhood of the replacements, shifted, + the records of the windows
         // (k_rp_win_meta + k_pt_win_copy + the window scan + k_rp_merge of the piece-table path, one window at a time)
-        Record* const Rn = rsel ? Rbuf1 : Rbuf0;
-        uint64_t cursor = 0, at = 0;
+        // A pass with ONE kept match on a list that lives in the haystack's own buffer is done IN PLACE: the records before the match stay where they are,
+        // the window's records are collected in the other buffer, the records behind the replaced region move by the difference (and shift with the text),
+        // the window's records go into the gap.  (The PMC pass of round 4: rewriting the whole list in every pass was 2 TB/s of traffic.)
+        Record* const Rn = R == Rbuf0 ? Rbuf1 : Rbuf0;                   // the other buffer
+        const bool inplace = nkept == 1 && (R == Rbuf0 || R == Rbuf1);
+        uint64_t cursor = 0, at = 0, e_first = 0;
         auto end_of = [&](uint64_t i) { return R[i].end_pos; };
         auto copy_shifted = [&](uint64_t from, uint64_t to, int64_t shift) {
             for (uint64_t base = from; base < to; base += 2 * kWave) {
@@ -382,27 +428,8 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
                 if (i1 < to) { r1.end_pos = (uint64_t)((int64_t)r1.end_pos + shift); r1.haystack = h; Rn[cursor + (i1 - from)] = r1; }
             }
         };
-        // how many of R[from .. nr) end at or before x1 / x2 (x1 <= x2): lists of up to 512 records are looked at whole, eight end positions per lane in
-        // flight -- one trip instead of two 64-ary searches of two trips each
-        auto count2_le = [&](uint64_t from, uint64_t x1, uint64_t x2, uint64_t& c1, uint64_t& c2) {
-            const uint64_t m = nr - from;
-            if (m > 16u * kWave) {
-                c1 = lp_count_le([&](uint64_t i) { return end_of(from + i); }, m, x1, lane, deadline);
-                c2 = c1 + lp_count_le([&](uint64_t i) { return end_of(from + c1 + i); }, m - c1, x2, lane, deadline);
-                return;
-            }
-            uint64_t a1 = 0, a2 = 0;
-            for (uint64_t g = 0; g < m; g += 4u * kWave) {                // 256 end positions per trip; the list is sorted: stop behind x2
-                uint64_t e[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const uint64_t i = g + (uint64_t)u * kWave + lane; e[u] = ~0ull; if (i < m) e[u] = R[from + i].end_pos; }
-                uint64_t in2 = 0;
-#pragma unroll
-                for (int u = 0; u < 4; u++) { a1 += (uint64_t)__popcll(__ballot(e[u] <= x1)); in2 += (uint64_t)__popcll(__ballot(e[u] <= x2)); }
-                a2 += in2;
-                if (in2 < 4u * kWave) break;
-            }
-            c1 = a1; c2 = a2;
+        auto count2_le = [&](uint64_t from, uint64_t x1, uint64_t x2, uint64_t& c1, uint64_t& c2) {      // records of R[from .. nr) that end at or before x1 / x2
+            lp_count2_le([&](uint64_t i) { return end_of(from + i); }, nr - from, x1, x2, c1, c2, lane, deadline);
         };
         // A window of up to 128 bytes that lies in at most four pieces next to `near` (the usual case: pieces are hundreds of bytes, a window tens): the six
         // entries around `near` in one trip (one per lane, read into scalar registers), every lane's bytes in a second one -- instead of a search through
@@ -446,9 +473,12 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
             uint64_t c_before = 0, c_gone = 0;                           // records of R[at ..) that end at or before the match's start / within reach of its end
             count2_le(at, k.src_start, k.src_start + k.src_len + a.ov, c_before, c_gone);
             const uint64_t e = at + c_before;
-            if (cursor + (e - at) > cap_r) { overflow = true; break; }
-            copy_shifted(at, e, (int64_t)k.dst - (int64_t)k.src_start);
-            cursor += e - at;
+            if (inplace) e_first = e;
+            else {
+                if (cursor + (e - at) > cap_r) { overflow = true; break; }
+                copy_shifted(at, e, (int64_t)k.dst - (int64_t)k.src_start);
+                cursor += e - at;
+            }
             // the window of match j in the new text
             tick(3);
             const uint64_t dst = k.dst;
@@ -488,10 +518,21 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
             at += c_gone;
         }
         if (overflow) break;
-        if (cursor + (nr - at) > cap_r) { overflow = true; break; }
-        copy_shifted(at, nr, (int64_t)newlen - (int64_t)curlen);
-        cursor += nr - at;
-        R = Rn; nr = cursor; rsel ^= 1u;
+        if (inplace) {
+            const uint64_t nf = cursor;                                  // the window's records lie in Rn[0 .. nf)
+            const int64_t g = (int64_t)(e_first + nf) - (int64_t)at, delta = (int64_t)newlen - (int64_t)curlen;
+            if ((int64_t)nr + g > (int64_t)cap_r) { overflow = true; break; }
+            Record* const Rw = const_cast<Record*>(R);
+            lp_sync();                                                   // (the lanes that found them wrote the window's records)
+            if (g != 0 || delta != 0) lp_move(Rw, at, nr, g, [&](Record& r) { r.end_pos = (uint64_t)((int64_t)r.end_pos + delta); }, lane);
+            for (uint64_t i = lane; i < nf; i += kWave) Rw[e_first + i] = Rn[i];
+            nr = (uint64_t)((int64_t)nr + g);
+        } else {
+            if (cursor + (nr - at) > cap_r) { overflow = true; break; }
+            copy_shifted(at, nr, (int64_t)newlen - (int64_t)curlen);
+            cursor += nr - at;
+            R = Rn; nr = cursor;
+        }
         curlen = newlen; threshold = best;
         lp_sync();
         tick(3);
