@@ -4,11 +4,12 @@
 // (am_replace.hip, replacer_run_pt) nevertheless runs a pass as ~16 dependent launches over ALL active haystacks plus one host look at the
 // totals -- on BASELINE config 5 (16 384 haystacks, 159 passes, one replacement per haystack and pass) 159 x 240 us of latency-bound
 // kernels.  Here a wavefront takes one haystack and runs its loop to the end:
-//   fold      prependMatch / makeMatch / removeOverlap over the haystack's sorted records (as k_rp_pass)
-//   pieces    the next piece list (as k_pt_build)
-//   windows   per kept match: gather the window around the replacement through the new piece list into the wavefront's scratch, test its
-//             own positions against the Bloom filter (read from L2: a window is ~150 positions) and verify the survivors exactly
-//             (sf_verify: the same probe + resolve k_sf runs), and merge: shifted old records + the window's records -> next list
+//   fold      prependMatch / makeMatch / removeOverlap over the haystack's sorted records (as k_rp_pass); lists of up to 256 records are read once per pass
+//   pieces    the next piece list (as k_pt_build; with one kept match every piece knows what it becomes from that match alone: one sweep)
+//   windows   per kept match: gather the window around the replacement through the new piece list into the haystack's scratch (a small window through six
+//             piece entries held in scalar registers), test its own positions against the Bloom filter (read from L2: a window is tens of positions) and
+//             verify the survivors exactly (sf_verify: the same probe + resolve k_sf runs), and merge: old records + the window's records -> next list
+//             (one kept match: in place -- the records before it stay, those behind move by the difference; several: rebuilt in the second buffer)
 // Every haystack owns fixed regions (two record lists, two piece lists, a kept list, a window scratch) sized from its first scan; a
 // haystack that outgrows them raises the overflow flag and the host runs the batch through the piece-table path instead.
 // Replacers on the suffix-filter route, both case modes (IgnoreCase: makeMatch walks the text backwards through the piece list).
@@ -319,7 +320,7 @@ __device__ void lp_run_haystack(const RpLoop& a, const uint32_t h, const int lan
         lp_sync();                                                       // K is read by every lane from here on
         tick(1);
 
-        // ---- replace (:163-180) on the piece list: P -> Q (the scheme of k_pt_build)
+        // ---- replace (:163-180) on the piece list: P -> Q (the scheme of k_pt_build; the two lists of a haystack take turns)
         RpPayload pp = a.t.payloads[payload];
         pp.repl_off = uniform_u64(pp.repl_off); pp.repl_len = lp_u32(pp.repl_len);
         const uint64_t repl_len = nkept ? pp.repl_len : 0;
