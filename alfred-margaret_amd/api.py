@@ -154,10 +154,22 @@ _HOST = {
     "amh_free_u64": (None, [_vp]),
     "amh_skip_code_points_backwards": (C.c_int64, [C.c_char_p, _sz, _sz, _sz]),
     "amh_lower_utf8": (_sz, [C.c_char_p, _sz, _vp, _sz]),
+    "amh_is_case_invariant": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _sz]),
+    "amh_needle_casings": (C.c_int, [C.c_char_p, _sz, _vp, _vp, _sz, C.POINTER(_vp), C.POINTER(_vp), _u64p]),
+}
+
+# include/am_debug.h: tests and measurements only
+DEBUG_ABI = {
+    "am_debug_set": (C.c_int, [C.c_char_p, C.c_long]),
+    "am_debug_pinned_bytes": (C.c_uint64, []),
+    "am_debug_sf_phase_cycles": (C.c_int, [_vp]),
+    "am_debug_sf_wave_records": (C.c_int, [_vp, _sz]),
+    "am_debug_set_general_kernel": (C.c_int, [_vp, C.c_uint32]),
 }
 
 _libam = None
 _libhost = None
+_libcheck = None
 
 
 def _bind(lib, table):
@@ -175,8 +187,26 @@ def libam():
         path = os.path.join(_build.LIB, "libam.so")
         if not os.path.exists(path):
             path = _build.build_libam()
-        _libam = _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), ABI)
+        _libam = _bind(_bind(C.CDLL(path, mode=C.RTLD_GLOBAL), ABI), DEBUG_ABI)
     return _libam
+
+
+def load_check():
+    """TEST INFRASTRUCTURE: loads libam_check.so (tests/native/am_ac.hip), which hands k_ac -- the general AC-walk kernel, the parity gate's
+    independent second algorithm -- to libam; Automaton.set_kernel(1) works afterwards.  Called by tests/conftest.py, bench.py's parity gate
+    and __graft_entry__.smoke(); nothing in this package calls it."""
+    global _libcheck
+    if _libcheck is None:
+        libam()
+        path = os.path.join(_build.LIB, "libam_check.so")
+        if not os.path.exists(path):
+            path = _build.build_check()
+        lib = C.CDLL(path)
+        lib.am_check_registered.restype = C.c_int
+        if lib.am_check_registered() != 1:
+            raise RuntimeError("libam_check.so could not register k_ac with libam (built against another image version?)")
+        _libcheck = lib
+    return _libcheck
 
 
 def libhost():
@@ -235,17 +265,25 @@ class _Slices:
             self.arr[i] = Slice(ptr, off, size - off if ln is None else ln)
 
 
-def _lower_arrays(pairs):
-    if pairs is None:
-        return None, None, 0
-    f = np.ascontiguousarray([p[0] for p in pairs], dtype=np.uint32)
-    t = np.ascontiguousarray([p[1] for p in pairs], dtype=np.uint32)
-    return f, t, len(f)
+class _LowerArrays:
+    """The caller's lower-case table as the two arrays the C ABI takes.  None = the built-in table (NULL, NULL, 0); an EMPTY list is a
+    table of its own -- ASCII-only lower-casing -- and travels as two valid pointers with n = 0, as am_automaton_create_ex reads it."""
+
+    def __init__(self, pairs):
+        self.n = 0 if pairs is None else len(pairs)
+        self.f = self.t = None
+        if pairs is not None:
+            self.f = np.zeros(max(self.n, 1), dtype=np.uint32)
+            self.t = np.zeros(max(self.n, 1), dtype=np.uint32)
+            for i, (a, b) in enumerate(pairs):
+                self.f[i], self.t[i] = a, b
+        self.from_ptr = None if self.f is None else self.f.ctypes.data
+        self.to_ptr = None if self.t is None else self.t.ctypes.data
 
 
 def lower_table_hash(pairs=None):
-    f, t, n = _lower_arrays(pairs)
-    return int(libam().am_lower_table_hash(f.ctypes.data if n else None, t.ctypes.data if n else None, n))
+    la = _LowerArrays(pairs)
+    return int(libam().am_lower_table_hash(la.from_ptr, la.to_ptr, la.n))
 
 
 class Automaton:
@@ -260,8 +298,8 @@ class Automaton:
             self._vals = np.ascontiguousarray(values, dtype=np.uint32)
             vptr = self._vals.ctypes.data
         h = _vp()
-        lf, lt, ln = _lower_arrays(lower_pairs)
-        _hcheck(libhost().amh_build_ex(blob, offs.ctypes.data, len(needles), vptr, lf.ctypes.data if ln else None, lt.ctypes.data if ln else None, ln, C.byref(h)))
+        la = _LowerArrays(lower_pairs)
+        _hcheck(libhost().amh_build_ex(blob, offs.ctypes.data, len(needles), vptr, la.from_ptr, la.to_ptr, la.n, C.byref(h)))
         self._h = h
 
     @property
@@ -482,9 +520,8 @@ class Replacer:
         nb, no = pack_texts([p[0] for p in pairs])
         rb, ro = pack_texts([p[1] for p in pairs])
         h = _vp()
-        lf, lt, ln = _lower_arrays(lower_pairs)
-        _hcheck(libhost().amh_replacer_build_ex(case, nb, no.ctypes.data, rb, ro.ctypes.data, len(pairs), lf.ctypes.data if ln else None,
-                                               lt.ctypes.data if ln else None, ln, C.byref(h)))
+        la = _LowerArrays(lower_pairs)
+        _hcheck(libhost().amh_replacer_build_ex(case, nb, no.ctypes.data, rb, ro.ctypes.data, len(pairs), la.from_ptr, la.to_ptr, la.n, C.byref(h)))
         self._h = h
         self.pairs = list(pairs)
 
@@ -614,16 +651,14 @@ class Splitter:
         return self.split_batch([text], True)[0]
 
 
-DEBUG_SWITCHES = ("AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_PROBE_TWO", "AM_SFX", "AM_NO_SMALL_RUN",
+DEBUG_SWITCHES = ("AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN",
                   "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
                   "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LOOP")
 
 
 def debug_set(name, value):
     """A test / measurement switch of libam (csrc/am_config.h) by the name of its environment variable; -1 = unset.  No switch changes a result."""
-    fn = libam().am_debug_set
-    fn.restype, fn.argtypes = C.c_int, [C.c_char_p, C.c_long]
-    check(fn(name.encode(), int(value)))
+    check(libam().am_debug_set(name.encode(), int(value)))
 
 
 def debug_reset():
@@ -652,6 +687,31 @@ def lower_utf8(text):
     out = C.create_string_buffer(len(b) * 4 + 4)
     n = libhost().amh_lower_utf8(b, len(b), out, len(b) * 4 + 4)
     return out.raw[:n]
+
+
+def is_case_invariant(text, lower_pairs=None):
+    """Utf8.isCaseInvariant (Utf8.hs:169-171)."""
+    b = _as_bytes(text)
+    la = _LowerArrays(lower_pairs)
+    r = libhost().amh_is_case_invariant(b, len(b), la.from_ptr, la.to_ptr, la.n)
+    if r < 0:
+        raise AmError(AM_ERR_INVALID, (libhost().amh_last_error() or b"").decode("utf-8", "replace"))
+    return bool(r)
+
+
+def needle_casings(text, lower_pairs=None):
+    """Automaton.needleCasings (Automaton.hs:555-566): list[bytes], in the reference's order."""
+    b = _as_bytes(text)
+    la = _LowerArrays(lower_pairs)
+    blob, offs, n = _vp(), _vp(), C.c_uint64(0)
+    _hcheck(libhost().amh_needle_casings(b, len(b), la.from_ptr, la.to_ptr, la.n, C.byref(blob), C.byref(offs), C.byref(n)))
+    try:
+        o = np.ctypeslib.as_array(C.cast(offs, _u64p), shape=(n.value + 1,)).copy()
+        raw = C.string_at(blob, int(o[-1]))
+    finally:
+        libhost().amh_free_blob(blob)
+        libhost().amh_free_u64(offs)
+    return [raw[int(o[i]):int(o[i + 1])] for i in range(int(n.value))]
 
 
 def skip_code_points_backwards(text, index, n):

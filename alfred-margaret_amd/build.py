@@ -1,8 +1,10 @@
 """Builds the native libraries in-tree (alfred-margaret_amd/lib/*.so) for gfx950.
 
-  libam.so           the product: C ABI (include/am.h) + HIP kernels, hipcc --offload-arch=gfx950
+  libam.so           the product: C ABI (include/am.h) + HIP kernels, hipcc --offload-arch=gfx950, -fvisibility=hidden (exports = am.h + am_debug.h)
   libam_host.so      C++ host mirror of the reference API (host/), links libam.so
-  libam_imgcheck.so  TEST-ONLY host interpreter of the device image (g++, no HIP)
+  libam_check.so     TEST-ONLY (tests/native/am_ac.hip): k_ac, the general AC-walk kernel = the parity gate's independent second algorithm;
+                     registers itself with libam when loaded (tests, bench.py's gate, smoke()); the product never loads it
+  libam_imgcheck.so  TEST-ONLY (tests/native/am_imgcheck.cpp) host interpreter of the device image (g++, no HIP)
   libam_synth.so     synthetic haystack generator (bench/test input; device kernel + identical host loop)
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so files travel to
@@ -16,6 +18,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
+NATIVE_TESTS = os.path.join(ROOT, "tests", "native")
 LIB = os.path.join(PKG, "lib")
 ARCH = "gfx950"
 LINK_EXTRA = ["-ldl"]        # RCCL (am_multi_*) is bound with dlopen at first use, not at link time
@@ -51,22 +54,22 @@ def build_libam(force=False):
     obj_dir = os.path.join(LIB, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     target = os.path.join(LIB, "libam.so")
-    names = ("am_abi.cpp", "am_replacer.cpp", "am_contains_all.cpp", "am_flatten.cpp", "am_kernels.hip", "am_sfx.hip", "am_scan.hip", "am_replace.hip", "am_rploop.hip", "am_dense.hip", "am_multi.cpp")
+    names = ("am_abi.cpp", "am_replacer.cpp", "am_contains_all.cpp", "am_flatten.cpp", "am_kernels.hip", "am_scan.hip", "am_replace.hip", "am_rploop.hip", "am_dense.hip", "am_multi.cpp")
     srcs = [os.path.join(CSRC, f) for f in names if os.path.exists(os.path.join(CSRC, f))]
-    headers = [d for d in _glob_deps(CSRC) if d.endswith((".h", ".hpp", ".inc"))] + [os.path.join(ROOT, "include", "am.h")]
+    headers = [d for d in _glob_deps(CSRC) if d.endswith((".h", ".hpp", ".inc"))] + [os.path.join(ROOT, "include", "am.h"), os.path.join(ROOT, "include", "am_debug.h")]
     objs = [os.path.join(obj_dir, os.path.basename(f) + ".o") for f in srcs]
 
     def compile_one(pair):
         src, obj = pair
         if force or _stale(obj, [src] + headers):
-            subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src, "-o", obj + ".tmp"])
+            subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-c", src, "-o", obj + ".tmp"])
             os.replace(obj + ".tmp", obj)
         return obj
 
     with ThreadPoolExecutor(len(srcs)) as pool:
         list(pool.map(compile_one, zip(srcs, objs)))
-    if force or _stale(target, objs):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *objs, "-o", target + ".tmp"] + LINK_EXTRA
+    if force or _stale(target, objs + [os.path.join(CSRC, "libam.map")]):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *objs, "-Wl,--version-script=" + os.path.join(CSRC, "libam.map"), "-o", target + ".tmp"] + LINK_EXTRA
         subprocess.check_call(cmd)
         os.replace(target + ".tmp", target)
     return target
@@ -75,9 +78,23 @@ def build_libam(force=False):
 def build_imgcheck(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libam_imgcheck.so")
-    srcs = [os.path.join(CSRC, f) for f in ("am_imgcheck.cpp", "am_flatten.cpp")]
-    if force or _stale(target, _glob_deps(CSRC)):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", *srcs, "-o", target + ".tmp"])
+    srcs = [os.path.join(NATIVE_TESTS, "am_imgcheck.cpp"), os.path.join(CSRC, "am_flatten.cpp")]
+    if force or _stale(target, _glob_deps(CSRC) + srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, *srcs, "-o", target + ".tmp"])
+        os.replace(target + ".tmp", target)
+    return target
+
+
+def build_check(force=False):
+    """libam_check.so: k_ac (tests/native/am_ac.hip) against libam's own headers; links libam.so for the registration call."""
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libam_check.so")
+    libam = build_libam(force)
+    src = os.path.join(NATIVE_TESTS, "am_ac.hip")
+    deps = [src, libam] + [d for d in _glob_deps(CSRC) if d.endswith((".h", ".inc"))] + [os.path.join(ROOT, "include", "am_debug.h")]
+    if force or _stale(target, deps):
+        subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-shared", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
+                               src, "-L", LIB, "-lam", "-Wl,-rpath,$ORIGIN", "-o", target + ".tmp"])
         os.replace(target + ".tmp", target)
     return target
 
@@ -107,7 +124,7 @@ def build_synth(force=False):
 
 
 def build_all(force=False):
-    return {"libam": build_libam(force), "libam_host": build_host(force), "libam_imgcheck": build_imgcheck(force),
+    return {"libam": build_libam(force), "libam_host": build_host(force), "libam_check": build_check(force), "libam_imgcheck": build_imgcheck(force),
             "libam_synth": build_synth(force)}
 
 

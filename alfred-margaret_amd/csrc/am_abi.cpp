@@ -652,6 +652,10 @@ extern "C" uint64_t am_batch_total_bytes(const am_batch* b) { return b ? b->tota
 
 namespace {
 
+// k_ac's launcher, handed over by libam_check.so when a test or bench.py's parity gate loads it (am_debug_set_general_kernel); never set in a product process
+using AcLauncher = hipError_t (*)(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
+std::atomic<AcLauncher> g_ac_launcher{nullptr};
+
 struct Plan {
     const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
     bool dense;          // automaton with the empty needle on the suffix-filter route: k_sf's records + the dense pass (am_dense.hip)
@@ -669,6 +673,8 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     p.ic = case_mode == AM_IGNORE_CASE;
     if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run this automaton (empty needle with too many prefix terminals)");
     p.use_sf = p.f->h.sf_enabled && a->kernel_pref != 1;
+    if (!p.use_sf && !g_ac_launcher.load(std::memory_order_acquire))
+        return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 1): the general AC kernel is test infrastructure (libam_check.so) and is not loaded in this process");
     p.dense = p.use_sf && p.f->h.root_vlen > 0;
     p.ac = make_ac_view(p.f->d_image, p.f->h);
     p.sf = make_sf_view(p.f->d_image, p.f->h);
@@ -694,7 +700,13 @@ int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st
         Prof pr("sf", st);
         HIP_TRY(launch_sf(p.ic, mode, p.sf, p.bv, os, p.n_cu, st));
     }
-    else { Prof pr("ac", st); HIP_TRY(launch_ac(p.ic, mode, p.ac, p.bv, o, st)); }
+    else {
+        // the general AC-walk kernel is test infrastructure (libam_check.so, tests/native/am_ac.hip): make_plan refused the scan if it is not loaded
+        const AcLauncher ac = g_ac_launcher.load(std::memory_order_acquire);
+        if (!ac) return fail(AM_ERR_UNSUPPORTED, "the general AC kernel is not loaded");
+        Prof pr("ac", st);
+        HIP_TRY(ac(p.ic, mode, p.ac, p.bv, o, st));
+    }
     return AM_OK;
 }
 
@@ -1386,7 +1398,15 @@ extern "C" int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t n
     return AM_OK;
 }
 
-// debug only (not declared in am.h): cycle sums per k_sf phase for launches made under AM_SF_ABLATE=9
+// ---- include/am_debug.h: tests and measurements only
+extern "C" int am_debug_set_general_kernel(void* launcher, uint32_t image_version)
+{
+    if (launcher && image_version != kImageVersion) return fail(AM_ERR_INVALID, "libam_check.so was built against another image version");
+    g_ac_launcher.store(reinterpret_cast<AcLauncher>(launcher), std::memory_order_release);
+    return AM_OK;
+}
+
+// cycle sums per k_sf phase for launches made under AM_SF_ABLATE=9
 extern "C" int am_debug_sf_phase_cycles(uint64_t* out5)
 {
     HIP_TRY(hipDeviceSynchronize());
@@ -1402,13 +1422,6 @@ extern "C" int am_debug_set(const char* name, long value)
 }
 
 extern "C" uint64_t am_debug_pinned_bytes(void) { return (uint64_t)g_pinned_staging_bytes.load(std::memory_order_relaxed); }
-
-extern "C" int am_debug_sfx_roles(uint64_t* out24)
-{
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(read_sfx_roles(out24));
-    return AM_OK;
-}
 
 extern "C" int am_debug_sf_wave_records(uint64_t* out, size_t n_waves)
 {

@@ -12,13 +12,12 @@ namespace am {
 namespace cfg {
 
 enum Key {
-    kSfAblate,            // AM_SF_ABLATE: debug instantiation of k_sf / k_sfx (1, 4, 5, 11: parts switched off; 9: per-phase / per-role cycle sums)
+    kSfAblate,            // AM_SF_ABLATE: debug instantiation of k_sf (1, 4, 5, 11: parts switched off; 9: per-phase cycle sums)
     kSfPoolBlocks,        // AM_SF_POOL_BLOCKS: size of the record-block pool of the first attempt (tests force overflow + retry)
     kSfWq,                // AM_SF_WQ: walker-queue entries per wavefront (0: none)
     kSfWqIters,           // AM_SF_WQ_ITERS: trie steps a resolve batch takes before it parks
     kSfMaxBloomLog2Words, // AM_SF_MAX_BLOOM_LOG2_WORDS: cap on the LDS filter size (tests: dense filters)
     kSfProbeTwo,          // AM_SF_PROBE_TWO: A/B -- automata with few 4-byte-suffix keys also take the instantiation whose probe rounds always look at two candidates per lane
-    kSfx,                 // AM_SFX: the role-specialised kernel k_sfx: 1 = whenever the automaton allows it (tests, A/B), 2 = for large scans; unset / 0 = never
     kNoSmallRun,          // AM_NO_SMALL_RUN: am_run on small batches takes the general path
     kRpFullScans, kRpSplice, kRpPieces, kRpParallelFold, kRpGroups, kRpNoFuse, kRpNoSpin, kRpMatMain, kRpNoRangeReuse, kRpTrace,
     kRpLoopWaves,         // AM_RP_LOOP_WAVES: wavefronts per SIMD k_rp_loop's register budget is cut for (4, 5, 6, 8)
@@ -33,7 +32,7 @@ struct Table {
 inline Table& table() { static Table t; return t; }
 inline const char* name_of(int k)
 {
-    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_PROBE_TWO", "AM_SFX", "AM_NO_SMALL_RUN",
+    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN",
                                               "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
                                               "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LOOP"};
     return names[k];

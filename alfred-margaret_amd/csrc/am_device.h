@@ -63,10 +63,6 @@ uint64_t ac_units(const AcView& a, const BatchView& b);
 size_t sf_lds_bytes(const SfView& s);
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
-// the role-specialised variant of the suffix-filter scan (am_sfx.hip): same inputs, same outputs as launch_sf's k_sf
-bool sfx_eligible(const SfView& s, const BatchView& b, const ScanOut& o, int mode, int n_cu, bool any_size);
-hipError_t launch_sfx(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
-hipError_t read_sfx_roles(uint64_t* out24);
 hipError_t read_sf_phase_cycles(uint64_t* out5);
 hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);

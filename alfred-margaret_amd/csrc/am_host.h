@@ -3,6 +3,7 @@
 // include/am.h and the few scan entry points the Replacer drives.  Internal: nothing here is part of the C ABI.
 #pragma once
 #include "../../include/am.h"
+#include "../../include/am_debug.h"
 
 #include <hip/hip_runtime.h>
 

@@ -741,50 +741,6 @@ __global__ __launch_bounds__(256) void k_permute(ScanOut o, const uint64_t* __re
     }
 }
 
-// ------------------------------------------------------------------ AC kernel
-
-struct EmitCount {
-    uint32_t nrec; uint64_t nval; uint64_t* hay_counts;
-    __device__ __forceinline__ void operator()(uint32_t hay, uint64_t, uint32_t, uint32_t vlen)
-    {
-        nrec++; nval += vlen;
-        if (hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(hay_counts + hay), (unsigned long long)vlen);
-    }
-};
-struct EmitWrite {
-    Record* out;
-    __device__ __forceinline__ void operator()(uint32_t hay, uint64_t end_pos, uint32_t state, uint32_t) { *out++ = Record{end_pos, hay, state}; }
-};
-struct EmitFlag {
-    uint8_t* flags;
-    __device__ __forceinline__ void operator()(uint32_t hay, uint64_t, uint32_t, uint32_t) { flags[hay] = 1; }
-};
-
-template <bool IC, int MODE>
-__global__ __launch_bounds__(256) void k_ac(AcView a, BatchView b, ScanOut o, uint64_t n_units)
-{
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t nval = 0;
-    if (u < n_units) {
-        if (MODE == kModeCount) {
-            EmitCount e{0, 0, o.hay_counts};
-            ac_scan_unit<IC>(a, b, u, e);
-            o.unit_counts[u] = e.nrec;
-            nval = e.nval;
-        } else if (MODE == kModeEmit) {
-            EmitWrite e{o.records + o.unit_offsets[u]};
-            ac_scan_unit<IC>(a, b, u, e);
-        } else {
-            EmitFlag e{o.flags};
-            ac_scan_unit<IC>(a, b, u, e);
-        }
-    }
-    if (MODE == kModeCount) {
-        nval = wave_sum_u64(nval);
-        if (lane_id() == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
-    }
-}
-
 // ------------------------------------------------------------------ launchers
 
 hipError_t launch_hidx(const BatchView& b, uint32_t* hidx, uint64_t n_entries, hipStream_t st, uint32_t* z0, uint64_t n0, uint32_t* z1, uint64_t n1)
@@ -875,16 +831,6 @@ hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves)
     return hipMemcpy(out, g_sf_dbg + 16, 16 * (n_waves < 8192 ? n_waves : 8192), hipMemcpyDeviceToHost);
 }
 
-// debug: per-role cycle sums and event counts of k_sfx launches run with AM_SF_ABLATE=9 (F: 0-4, P: 8-14, R: 16-21; am_sfx.hip)
-hipError_t read_sfx_roles(uint64_t* out24)
-{
-    for (int i = 0; i < 24; i++) out24[i] = 0;
-    if (!g_sf_dbg) return hipSuccess;
-    hipError_t e = hipMemcpy(out24, g_sf_dbg + 32, 24 * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemset(g_sf_dbg + 32, 0, 24 * 8);
-    return e;
-}
-
 hipError_t read_sf_phase_cycles(uint64_t* out5)
 {
     for (int i = 0; i < 16; i++) out5[i] = 0;
@@ -926,13 +872,6 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
         o.dbg = dbg;
         g_sf_dbg = dbg;
     }
-    // the role-specialised kernel (am_sfx.hip): AM_SFX = 1 whenever the automaton allows it (tests, A/B), 2 for large scans only; NOT the default --
-    // measured on cfg3 it is bit-exact and 15 % slower than k_sf (5.08 vs 4.32 ms per 4 GiB: LABNOTES.md R4.1, profiles/history/r04_sfx_*)
-    {
-        const long sfx = cfg::get(cfg::kSfx);
-        const bool plain = ablate == 0 || ablate == 9;
-        if (plain && (sfx == 1 || sfx == 2) && sfx_eligible(s, b, o, mode, n_cu, sfx == 1)) return launch_sfx(ic, mode, s, b, o, n_cu, st);
-    }
     if (ic) {
         if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);
         if (mode == kModeEmit) return launch_sf_t<true, kModeEmit>(s, b, o, n_cu, st);
@@ -941,29 +880,6 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     if (mode == kModeCount) return launch_sf_t<false, kModeCount>(s, b, o, n_cu, st);
     if (mode == kModeEmit) return launch_sf_t<false, kModeEmit>(s, b, o, n_cu, st);
     return launch_sf_t<false, kModeAny>(s, b, o, n_cu, st);
-}
-
-template <bool IC, int MODE>
-static hipError_t launch_ac_t(const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st)
-{
-    const uint64_t n_units = ac_units(a, b);
-    if (n_units == 0) return hipSuccess;
-    const uint64_t blocks = (n_units + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_ac<IC, MODE>), dim3((uint32_t)blocks), dim3(256), 0, st, a, b, o, n_units);
-    return hipGetLastError();
-}
-
-hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st)
-{
-    if (ic) {
-        if (mode == kModeCount) return launch_ac_t<true, kModeCount>(a, b, o, st);
-        if (mode == kModeEmit) return launch_ac_t<true, kModeEmit>(a, b, o, st);
-        return launch_ac_t<true, kModeAny>(a, b, o, st);
-    }
-    if (mode == kModeCount) return launch_ac_t<false, kModeCount>(a, b, o, st);
-    if (mode == kModeEmit) return launch_ac_t<false, kModeEmit>(a, b, o, st);
-    return launch_ac_t<false, kModeAny>(a, b, o, st);
 }
 
 }  // namespace dev

@@ -161,9 +161,12 @@ template <class V> AcMachine<V> build(const std::vector<std::pair<Text, V>>& nee
     m.machineOffsets = std::move(p.offsets);
     m.machineRootAsciiTransitions = std::move(p.rootAscii);
     am_automaton* a = nullptr;
+    // an EMPTY caller table is a table (ASCII-only lower-casing): two valid pointers with n = 0, never NULL (= the built-in table)
+    static const uint32_t none = 0;
+    const uint32_t* lf = !lower ? nullptr : (lower->from.empty() ? &none : lower->from.data());
+    const uint32_t* lt = !lower ? nullptr : (lower->to.empty() ? &none : lower->to.data());
     amCheck(am_automaton_create_ex(m.machineTransitions.data(), m.machineTransitions.size(), m.machineOffsets.data(), m.numStates(),
-                                   m.machineRootAsciiTransitions.data(), valuesLen.data(), lower ? lower->from.data() : nullptr,
-                                   lower ? lower->to.data() : nullptr, lower ? lower->from.size() : 0, &a));
+                                   m.machineRootAsciiTransitions.data(), valuesLen.data(), lf, lt, lower ? lower->from.size() : 0, &a));
     m.device.reset(a, detail::AutomatonDeleter());
     return m;
 }
@@ -213,5 +216,23 @@ A runWithCase(CaseSensitivity cs, A seed, F f, const AcMachine<V>& machine, cons
 
 template <class A, class V, class F> A runText(A seed, F f, const AcMachine<V>& m, const Text& t) { return runWithCase(CaseSensitivity::CaseSensitive, std::move(seed), f, m, t); }   // :539-541
 template <class A, class V, class F> A runLower(A seed, F f, const AcMachine<V>& m, const Text& t) { return runWithCase(CaseSensitivity::IgnoreCase, std::move(seed), f, m, t); }     // :551-553
+
+
+// Automaton.hs:555-566 needleCasings: every text that lower-cases to the given (lower case) text: the product of unlowerCodePoint over its code
+// points, first code point slowest, each in the reference's order ("abc" -> abc abC aBc aBC Abc AbC ABc ABC; "ABC" -> nothing).
+inline std::vector<std::string> needleCasings(const Text& needle, const utf8::LowerTable* lt = nullptr)
+{
+    std::vector<std::vector<uint32_t>> sets;
+    const uint8_t* d = needle.begin();
+    for (size_t i = 0; i < needle.len;) { size_t u; const uint32_t cp = utf8::decodeAt(d, i, needle.len, u); i += u; sets.push_back(utf8::unlowerCodePoint(cp, lt)); }
+    std::vector<std::string> out{std::string()};
+    for (size_t k = sets.size(); k-- > 0;) {                  // loop (c:cs) = (:) <$> unlowerCodePoint c <*> loop cs
+        std::vector<std::string> next;
+        next.reserve(out.size() * sets[k].size());
+        for (uint32_t c : sets[k]) { std::string head; utf8::encode(c, head); for (const std::string& tail : out) next.push_back(head + tail); }
+        out.swap(next);
+    }
+    return out;
+}
 
 }  // namespace alfred_margaret

@@ -244,4 +244,32 @@ size_t amh_lower_utf8(const uint8_t* d, size_t len, uint8_t* out, size_t cap)
     return s.size();
 }
 
+// Utf8.isCaseInvariant (Utf8.hs:169-171): 1 / 0; -1 on error
+int amh_is_case_invariant(const uint8_t* d, size_t len, const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs)
+{
+    try {
+        std::unique_ptr<utf8::LowerTable> lt;
+        if (lower_from && lower_to) lt.reset(new utf8::LowerTable(lower_from, lower_to, n_pairs));
+        return utf8::isCaseInvariant(Text(d, 0, len), lt.get()) ? 1 : 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+// Automaton.needleCasings (Automaton.hs:555-566): the casings concatenated + their offsets (n + 1); free with amh_free_blob / amh_free_u64
+int amh_needle_casings(const uint8_t* d, size_t len, const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs, uint8_t** blob_out, uint64_t** offs_out, uint64_t* n_out)
+{
+    *blob_out = nullptr; *offs_out = nullptr; *n_out = 0;
+    return guarded([&] {
+        std::unique_ptr<utf8::LowerTable> lt;
+        if (lower_from && lower_to) lt.reset(new utf8::LowerTable(lower_from, lower_to, n_pairs));
+        const std::vector<std::string> cs = needleCasings(Text(d, 0, len), lt.get());
+        uint64_t total = 0;
+        for (auto& c : cs) total += c.size();
+        uint8_t* blob = (uint8_t*)malloc(total ? total : 1);
+        uint64_t* offs = (uint64_t*)malloc((cs.size() + 1) * sizeof(uint64_t));
+        uint64_t at = 0;
+        for (size_t i = 0; i < cs.size(); i++) { offs[i] = at; if (!cs[i].empty()) std::memcpy(blob + at, cs[i].data(), cs[i].size()); at += cs[i].size(); }
+        offs[cs.size()] = at;
+        *blob_out = blob; *offs_out = offs; *n_out = cs.size();
+    });
+}
+
 }  // extern "C"

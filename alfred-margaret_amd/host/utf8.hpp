@@ -48,14 +48,27 @@ inline void encode(uint32_t c, std::string& out)
 
 // The lower-casing of the host language as data: what Data.Char.toLower of the caller's GHC does (Utf8.hs:151), as the (c, toLower c) pairs
 // with toLower c /= c.  Handed to am_automaton_create_ex by build(); null everywhere = libam's built-in Unicode 14.0 table.
+// Same rules as libam's own table (am_automaton_create_ex): pairs below 128 and identity pairs are ignored, duplicates collapse, one code
+// point with two different images (or a code point beyond U+10FFFF) is refused -- so the host-side lower-casing of the needles and the
+// device-side table can never disagree about a table the device would have rejected.
 struct LowerTable {
-    std::vector<uint32_t> from, to;      // sorted by from
+    std::vector<uint32_t> from, to;                            // sorted by from
+    std::vector<std::pair<uint32_t, uint32_t>> inverse;        // (to, from), sorted: unlowerCodePoint
     LowerTable(const uint32_t* f, const uint32_t* t, size_t n)
     {
-        std::vector<std::pair<uint32_t, uint32_t>> v(n);
-        for (size_t i = 0; i < n; i++) v[i] = {f[i], t[i]};
+        std::vector<std::pair<uint32_t, uint32_t>> v;
+        for (size_t i = 0; i < n; i++) {
+            if (f[i] > 0x10FFFFu || t[i] > 0x10FFFFu) throw std::invalid_argument("lower-case pair beyond U+10FFFF");
+            if (f[i] < 128u || f[i] == t[i]) continue;
+            v.emplace_back(f[i], t[i]);
+        }
         std::sort(v.begin(), v.end());
-        for (auto& p : v) { from.push_back(p.first); to.push_back(p.second); }
+        for (size_t i = 1; i < v.size(); i++)
+            if (v[i].first == v[i - 1].first && v[i].second != v[i - 1].second) throw std::invalid_argument("lower-case table maps one code point to two different ones");
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+        for (auto& p : v) { from.push_back(p.first); to.push_back(p.second); inverse.emplace_back(p.second, p.first); }
+        for (uint32_t c = 'A'; c <= 'Z'; c++) inverse.emplace_back(c + 0x20u, c);
+        std::sort(inverse.begin(), inverse.end());
     }
     uint32_t lower(uint32_t cp) const
     {
@@ -76,6 +89,38 @@ inline std::string lowerUtf8(const Text& t, const LowerTable* lt = nullptr)
     const uint8_t* d = t.begin();
     for (size_t i = 0; i < t.len;) { size_t u; uint32_t cp = decodeAt(d, i, t.len, u); encode(lowerCodePoint(cp, lt), out); i += u; }
     return out;
+}
+
+// Utf8/Unlower.hs:26-40 unlowerCodePoint: every code point whose lower case is `cp`, in the reference's order -- its table is filled by
+// `insertWith (++) (toLower c) [c]` over ascending c, so a list runs from the HIGHEST code point down: unlowerCodePoint 'i' == "\304iI",
+// 'a' == "aA", 'A' == "" (Utf8Spec.hs:55-62).
+inline std::vector<uint32_t> unlowerCodePoint(uint32_t cp, const LowerTable* lt = nullptr)
+{
+    std::vector<uint32_t> out;
+    if (!lt) {
+        uint32_t buf[16];
+        size_t n = am_unlower_code_point(cp, buf, 16);                   // ascending set (built-in table)
+        if (n > 16) { std::vector<uint32_t> big(n); n = am_unlower_code_point(cp, big.data(), n); out.assign(big.begin(), big.begin() + n); }
+        else out.assign(buf, buf + n);
+    } else {
+        if (lt->lower(cp) == cp) out.push_back(cp);
+        for (auto it = std::lower_bound(lt->inverse.begin(), lt->inverse.end(), std::make_pair(cp, 0u)); it != lt->inverse.end() && it->first == cp; ++it) out.push_back(it->second);
+        std::sort(out.begin(), out.end());
+    }
+    std::reverse(out.begin(), out.end());
+    return out;
+}
+
+// Utf8.hs:169-171 isCaseInvariant = Text.all (\c -> unlowerCodePoint (lowerCodePoint c) == [c])
+inline bool isCaseInvariant(const Text& t, const LowerTable* lt = nullptr)
+{
+    const uint8_t* d = t.begin();
+    for (size_t i = 0; i < t.len;) {
+        size_t u; const uint32_t cp = decodeAt(d, i, t.len, u); i += u;
+        const std::vector<uint32_t> back = unlowerCodePoint(lowerCodePoint(cp, lt), lt);
+        if (back.size() != 1 || back[0] != cp) return false;
+    }
+    return true;
 }
 
 // Text.length: code points

@@ -625,6 +625,7 @@ def parity_gate(args, w, needles, machine, handle, case, batch, text, n_hay, ran
     import torch.distributed as dist
     import alfred_margaret_amd as am
     from alfred_margaret_amd import synth
+    am.api.load_check()            # k_ac, the gate's independent second algorithm, is test infrastructure (libam_check.so); loaded after the timed region
     # machineValues in flat form: rank 0 built the machine, the others attached to the broadcast image
     if rank == 0:
         voff = np.ascontiguousarray(machine.values_off(), dtype=np.uint64)

@@ -39,6 +39,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* libam.so is built with -fvisibility=hidden: the functions below (and include/am_debug.h's, for tests and measurements) are
+ * everything it exports. */
+#ifndef AM_API
+#define AM_API __attribute__((visibility("default")))
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -77,7 +83,7 @@ typedef struct am_match {
     uint32_t state;      /* fold (machineValues ! state) here */
 } am_match;
 
-const char* am_last_error(void);
+AM_API const char* am_last_error(void);
 
 /* ---- automaton ------------------------------------------------------------------------------
  * am_automaton_create: second half of `build` (Automaton.hs:176-200).  Takes the AcMachine fields
@@ -89,7 +95,7 @@ const char* am_last_error(void);
  * and flattens them into the device image (LDS filter, cuckoo fingerprint table and Patricia trie of
  * the reversed needles, goto hash of the general path).  The image for each case mode
  * is built and uploaded on first use. */
-int am_automaton_create(const uint64_t* transitions, size_t n_transitions,
+AM_API int am_automaton_create(const uint64_t* transitions, size_t n_transitions,
                         const uint32_t* offsets, size_t n_states,
                         const uint64_t* root_ascii,
                         const uint32_t* values_len,
@@ -103,27 +109,27 @@ int am_automaton_create(const uint64_t* transitions, size_t n_transitions,
  * with two different images is AM_ERR_INVALID).  NULL, NULL, 0 = the built-in Unicode 14.0 table (am_unicode_version()).
  * The IgnoreCase image bakes the table in (byte edges of every x with toLower x == c; the general kernel's delta table) and
  * records a hash of it: am_automaton_lower_hash(a) == am_lower_table_hash(pairs). */
-int am_automaton_create_ex(const uint64_t* transitions, size_t n_transitions,
+AM_API int am_automaton_create_ex(const uint64_t* transitions, size_t n_transitions,
                            const uint32_t* offsets, size_t n_states,
                            const uint64_t* root_ascii,
                            const uint32_t* values_len,
                            const uint32_t* lower_from, const uint32_t* lower_to, size_t n_lower_pairs,
                            am_automaton** out);
-uint32_t am_automaton_lower_hash(const am_automaton* a);
-uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs);   /* NULL: the built-in table's; 0 on error */
-void am_automaton_destroy(am_automaton* a);
+AM_API uint32_t am_automaton_lower_hash(const am_automaton* a);
+AM_API uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs);   /* NULL: the built-in table's; 0 on error */
+AM_API void am_automaton_destroy(am_automaton* a);
 /* Route k: 0 = automatic, 1 = force the general AC kernel, 2 = force the suffix-filter kernel
  * (fails with AM_ERR_UNSUPPORTED at run time for automata that contain the empty needle). */
-int am_automaton_set_kernel(am_automaton* a, int k);
+AM_API int am_automaton_set_kernel(am_automaton* a, int k);
 
 /* ---- one-shot entry points on host slices (what the Haskell shim binds) ----------------------
  * am_count:        runWithCase cs 0 (\n _ -> Step (n+1))  per haystack
  *                  (benchmark/haskell/app/Main.hs:67-76 countMatches; counts VALUES, i.e. fold calls)
  * am_contains_any: Searcher.containsAny (Searcher.hs:156-164) per haystack
  * am_run:          runWithCase / runText / runLower (Automaton.hs:442-553): all records */
-int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out);
-int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
-int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out);
+AM_API int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out);
+AM_API int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
+AM_API int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out);
 
 /* ---- ONE haystack in ranges (the reference folds one Text of any size, Automaton.hs:468-480) --
  * am_run_range:   the records of runWithCase on `hay` whose end position lies in (lo, hi], 0 <= lo <= hi <= hay->len; end_pos relative to the
@@ -133,39 +139,39 @@ int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_h
  *                 haystack: that is how am_multi_run_single spreads one document over several GPUs, and how a caller scans a document
  *                 larger than device memory.
  * am_count_range: countMatches (benchmark/haskell/app/Main.hs:67-76) over the same positions. */
-int am_run_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, am_matches** out);
-int am_count_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, uint64_t* count_out);
+AM_API int am_run_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, am_matches** out);
+AM_API int am_count_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, uint64_t* count_out);
 
 /* ---- device-resident batches (bulk callers; what bench.py times) ----------------------------- */
-int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out);
+AM_API int am_batch_upload(const am_slice* hay, size_t n_hay, am_batch** out);
 /* Borrow a batch that already lives in HBM: d_bytes = concatenated haystacks (16-byte aligned,
  * readable up to round_up(total, 16) bytes), d_offsets = n_hay + 1 ascending uint64 byte offsets
  * with d_offsets[0] == 0 and d_offsets[n_hay] == total_bytes.  The offsets must not change while the batch
  * exists (the text may). */
-int am_batch_from_device(const void* d_bytes, const void* d_offsets, size_t n_hay, uint64_t total_bytes, am_batch** out);
-void am_batch_destroy(am_batch* b);
-uint64_t am_batch_total_bytes(const am_batch* b);
+AM_API int am_batch_from_device(const void* d_bytes, const void* d_offsets, size_t n_hay, uint64_t total_bytes, am_batch** out);
+AM_API void am_batch_destroy(am_batch* b);
+AM_API uint64_t am_batch_total_bytes(const am_batch* b);
 
-int am_count_batch(const am_automaton* a, int case_mode, const am_batch* b, uint64_t* counts_out /* n_hay, nullable */, uint64_t* total_out /* nullable */);
-int am_contains_any_batch(const am_automaton* a, int case_mode, const am_batch* b, uint8_t* flags_out);
-int am_run_batch(const am_automaton* a, int case_mode, const am_batch* b, am_matches** out);
+AM_API int am_count_batch(const am_automaton* a, int case_mode, const am_batch* b, uint64_t* counts_out /* n_hay, nullable */, uint64_t* total_out /* nullable */);
+AM_API int am_contains_any_batch(const am_automaton* a, int case_mode, const am_batch* b, uint8_t* flags_out);
+AM_API int am_run_batch(const am_automaton* a, int case_mode, const am_batch* b, am_matches** out);
 
 /* ---- results ----------------------------------------------------------------------------------
  * Records are produced in HBM; am_matches_data copies them to the host on first use. */
-uint64_t am_matches_size(const am_matches* m);
-const am_match* am_matches_data(am_matches* m);           /* host pointer, owned by m; NULL on error */
-const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
-void am_matches_free(am_matches* m);
+AM_API uint64_t am_matches_size(const am_matches* m);
+AM_API const am_match* am_matches_data(am_matches* m);           /* host pointer, owned by m; NULL on error */
+AM_API const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
+AM_API void am_matches_free(am_matches* m);
 
 /* ---- Searcher.containsAll (src/Data/Text/AhoCorasick/Searcher.hs:167-187) ------------------------
  * For a `Searcher Int` made by buildNeedleIdSearcher (:167-169): machineValues in flat form (the list
  * of state s is values[values_offsets[s] .. values_offsets[s+1]), needle ids 0 .. n_needles-1).  The
  * IntSet fold (:175-183) becomes one bitmap row per haystack in HBM; flags_out[i] = 1 iff every id was
  * reported in haystack i (IS.null of the final set; all ones when n_needles == 0).  `a` must outlive ids. */
-int am_needle_ids_create(const am_automaton* a, const uint64_t* values_offsets, const uint32_t* values, uint32_t n_needles, am_needle_ids** out);
-void am_needle_ids_destroy(am_needle_ids* ids);
-int am_contains_all(const am_needle_ids* ids, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
-int am_contains_all_batch(const am_needle_ids* ids, int case_mode, const am_batch* b, uint8_t* flags_out);
+AM_API int am_needle_ids_create(const am_automaton* a, const uint64_t* values_offsets, const uint32_t* values, uint32_t n_needles, am_needle_ids** out);
+AM_API void am_needle_ids_destroy(am_needle_ids* ids);
+AM_API int am_contains_all(const am_needle_ids* ids, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
+AM_API int am_contains_all_batch(const am_needle_ids* ids, int case_mode, const am_batch* b, uint8_t* flags_out);
 
 /* Checksum of the fold sequence of a result (harness aid; SURVEY 8d "parity check at scale",
  * benchmark/benchmark.py:65-69 asserts count identity on every run).  For every haystack i < n_hay:
@@ -177,7 +183,7 @@ int am_contains_all_batch(const am_needle_ids* ids, int case_mode, const am_batc
  * `values` carries machineValues in flat form (am_needle_ids_create; any uint32 payload handles, n_needles unused).
  * Computed on the device from the records in HBM; two runs agree on hash and count iff they fold the same
  * (matchPos, value) sequences (up to 64-bit collisions). */
-int am_matches_fold_hash(const am_matches* m, const am_needle_ids* values, size_t n_hay, uint64_t* hash_out, uint64_t* count_out);
+AM_API int am_matches_fold_hash(const am_matches* m, const am_needle_ids* values, size_t n_hay, uint64_t* hash_out, uint64_t* count_out);
 
 /* ---- Replacer: all passes of Replacer.run on the device -----------------------------------------
  * Replaces the loop `runWithLimit.go` (src/Data/Text/AhoCorasick/Replacer.hs:219-242) for a batch of
@@ -204,19 +210,19 @@ typedef struct am_payload {
     uint32_t repl_len;
     uint32_t reserved;
 } am_payload;
-int am_replacer_create(const am_automaton* a, int case_mode,
+AM_API int am_replacer_create(const am_automaton* a, int case_mode,
                        const uint64_t* values_offsets, const uint32_t* values,
                        const am_payload* payloads, size_t n_payloads,
                        const uint8_t* repl_bytes, size_t n_repl_bytes,
                        int64_t min_priority, am_replacer** out);
-void am_replacer_destroy(am_replacer* r);
+AM_API void am_replacer_destroy(am_replacer* r);
 /* max_length: runWithLimit's maxLength (:203); UINT64_MAX = `run` (:200-201, maxBound). */
-int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out);
-int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);   /* b is not modified */
+AM_API int am_replacer_run(const am_replacer* r, const am_slice* hay, size_t n_hay, uint64_t max_length, am_replaced** out);
+AM_API int am_replacer_run_batch(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);   /* b is not modified */
 /* The same, but the rewritten texts STAY IN DEVICE MEMORY (the batch's device), for callers that feed them to the next device
    stage: am_replaced_get then returns device pointers, am_replaced_read copies one text to the host.  This is what a
    device-resident pipeline measures; am_replacer_run_batch additionally moves every result over PCIe into pinned host memory. */
-int am_replacer_run_batch_device(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);
+AM_API int am_replacer_run_batch_device(const am_replacer* r, const am_batch* b, uint64_t max_length, am_replaced** out);
 /* One pass only, for callers that keep sort / removeOverlap / replace (Replacer.hs:159-198) on their side: the fold
  * `prependMatch` (:252-260) with seed (minBound, []) and the given threshold per haystack.  best_out[i] = the best
  * priority below thresholds[i] among the matches of haystack i (INT64_MIN: none); *matches_out = every match that
@@ -228,19 +234,19 @@ typedef struct am_prio_match {
     uint32_t haystack;
     uint32_t payload;    /* index into the payload table given to am_replacer_create */
 } am_prio_match;
-int am_run_priority(const am_replacer* r, const am_slice* hay, size_t n_hay, const int64_t* thresholds,
+AM_API int am_run_priority(const am_replacer* r, const am_slice* hay, size_t n_hay, const int64_t* thresholds,
                     int64_t* best_out, am_prio_match** matches_out, size_t* n_matches_out);
-void am_prio_matches_free(am_prio_match* m);
-uint64_t am_replaced_size(const am_replaced* r);
+AM_API void am_prio_matches_free(am_prio_match* m);
+AM_API uint64_t am_replaced_size(const am_replaced* r);
 /* Returns 1 and the text for `Just`, 0 for `Nothing` (longer than max_length), < 0 on error.  *ptr is owned by r. */
-int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len);
-int am_replaced_device(const am_replaced* r);               /* -1: the texts are in host memory; otherwise the device that holds them */
+AM_API int am_replaced_get(const am_replaced* r, size_t i, const uint8_t** ptr, size_t* len);
+AM_API int am_replaced_device(const am_replaced* r);               /* -1: the texts are in host memory; otherwise the device that holds them */
 /* Copies text i into dst (host memory, cap bytes) wherever the result lives; *len = its length.  Returns like am_replaced_get. */
-int am_replaced_read(const am_replaced* r, size_t i, uint8_t* dst, size_t cap, size_t* len);
-uint64_t am_replaced_passes(const am_replaced* r);          /* scans that were needed (max over the batch) */
-uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes scanned over all passes (after the first pass only windows around the replacements) */
-uint64_t am_replaced_spliced_bytes(const am_replaced* r);   /* bytes of rewritten text produced over all passes */
-void am_replaced_free(am_replaced* r);
+AM_API int am_replaced_read(const am_replaced* r, size_t i, uint8_t* dst, size_t cap, size_t* len);
+AM_API uint64_t am_replaced_passes(const am_replaced* r);          /* scans that were needed (max over the batch) */
+AM_API uint64_t am_replaced_scanned_bytes(const am_replaced* r);   /* haystack bytes scanned over all passes (after the first pass only windows around the replacements) */
+AM_API uint64_t am_replaced_spliced_bytes(const am_replaced* r);   /* bytes of rewritten text produced over all passes */
+AM_API void am_replaced_free(am_replaced* r);
 
 /* ---- several GPUs ---------------------------------------------------------------------
  * Every handle lives on one device: an automaton / batch on the device that was current when it was made (or that its
@@ -256,27 +262,27 @@ void am_replaced_free(am_replaced* r);
  * Reference shape of a foreign binding: benchmark/rust-ffi/app/Main.hs:28-45 (`foreign import ccall`, slices). */
 typedef struct am_multi am_multi;
 #define AM_UNIQUE_ID_BYTES 128
-int am_multi_unique_id(uint8_t id_out[AM_UNIQUE_ID_BYTES]);
-int am_multi_create(int n_devices, am_multi** out);
-int am_multi_create_rank(int n_ranks, int rank, const uint8_t id[AM_UNIQUE_ID_BYTES], am_multi** out);
-void am_multi_destroy(am_multi* m);
-int am_multi_local_devices(const am_multi* m);     /* devices this process drives */
-int am_multi_world_size(const am_multi* m);        /* devices in all */
-int am_multi_device(const am_multi* m, int i);     /* HIP device id of local device i */
+AM_API int am_multi_unique_id(uint8_t id_out[AM_UNIQUE_ID_BYTES]);
+AM_API int am_multi_create(int n_devices, am_multi** out);
+AM_API int am_multi_create_rank(int n_ranks, int rank, const uint8_t id[AM_UNIQUE_ID_BYTES], am_multi** out);
+AM_API void am_multi_destroy(am_multi* m);
+AM_API int am_multi_local_devices(const am_multi* m);     /* devices this process drives */
+AM_API int am_multi_world_size(const am_multi* m);        /* devices in all */
+AM_API int am_multi_device(const am_multi* m, int i);     /* HIP device id of local device i */
 /* ncclBroadcast of the flattened image of `a` (held by global rank `root`; NULL in processes that do not hold the
  * root) to every device; autos_out[i] = a handle on local device i attached to its copy (am_automaton_destroy each). */
-int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out);
+AM_API int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, int case_mode, int root, am_automaton** autos_out);
 /* ncclAllReduce(sum) of `count` (<= 512) uint64 per device: values = local_devices x count, row i belongs to local
  * device i; every row holds the sums afterwards. */
-int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count);
+AM_API int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count);
 /* This process's haystacks cut into contiguous blocks, one per local device (block i = haystacks [n*i/D, n*(i+1)/D)),
  * scanned concurrently; counts_out (nullable) per haystack in order; *total_out = sum over ALL devices (all-reduce):
  * countMatches (benchmark/haskell/app/Main.hs:67-76) of the whole job. */
-int am_multi_count(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out, uint64_t* total_out);
+AM_API int am_multi_count(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out, uint64_t* total_out);
 /* runWithCase on every local device's block; the records of all blocks concatenated on the host in haystack order
  * (haystack = index into `hay`).  Free with am_multi_matches_free. */
-int am_multi_run(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, am_match** matches_out, size_t* n_out);
-void am_multi_matches_free(am_match* p);
+AM_API int am_multi_run(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, size_t n_hay, am_match** matches_out, size_t* n_out);
+AM_API void am_multi_matches_free(am_match* p);
 /* The same on DEVICE-RESIDENT batches: batches[i] lives on local device i (made there by am_batch_upload or
  * am_batch_from_device; NULL = no work for that device); one host thread and stream per device; nothing but the counts
  * leaves the devices.  BASELINE configs[3] (100 GiB of haystacks spread over the HBM of 8 GPUs) from a C / Haskell host.
@@ -287,10 +293,10 @@ void am_multi_matches_free(am_match* p);
  * Error behaviour of every am_multi_* collective: a failure on one device is carried into the collective as a flag, so
  * every rank returns (none blocks) and every rank returns an error. */
 /* am_batch_upload onto local device i of m (a host without HIP of its own has no other way to choose the device). */
-int am_multi_batch_upload(const am_multi* m, int local_device, const am_slice* hay, size_t n_hay, am_batch** out);
-int am_multi_count_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, uint64_t* const* counts_out,
+AM_API int am_multi_batch_upload(const am_multi* m, int local_device, const am_slice* hay, size_t n_hay, am_batch** out);
+AM_API int am_multi_count_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, uint64_t* const* counts_out,
                          uint64_t* local_totals_out, uint64_t* total_out);
-int am_multi_run_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, am_matches** results_out, uint64_t* total_records_out);
+AM_API int am_multi_run_batch(am_multi* m, am_automaton* const* autos, int case_mode, am_batch* const* batches, am_matches** results_out, uint64_t* total_records_out);
 
 /* ONE haystack on all devices ("a single huge haystack splits into G ranges with maxNeedleCodePoints overlap"; BASELINE configs[1]
  * shape (i), 1 x 1 GiB): global device g of W owns the end positions in (len * g / W, len * (g + 1) / W] (am_run_range on its own device).
@@ -299,22 +305,22 @@ int am_multi_run_batch(am_multi* m, am_automaton* const* autos, int case_mode, a
  *   am_multi_run_single    *matches_out = the records of this process's ranges in position order (haystack = 0, end_pos relative to the whole
  *                          haystack; am_multi_matches_free); with one process per GPU the launcher concatenates the ranks' arrays in rank
  *                          order.  *total_records_out (nullable) = records on all devices. */
-int am_multi_count_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, uint64_t* local_counts_out, uint64_t* total_out);
-int am_multi_run_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, am_match** matches_out, size_t* n_out, uint64_t* total_records_out);
+AM_API int am_multi_count_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, uint64_t* local_counts_out, uint64_t* total_out);
+AM_API int am_multi_run_single(am_multi* m, am_automaton* const* autos, int case_mode, const am_slice* hay, am_match** matches_out, size_t* n_out, uint64_t* total_records_out);
 
 /* ---- multi-GPU: move the flattened automaton between devices -----------------------------------
  * The image is one position-independent blob, so rank 0 flattens once and the blob is broadcast
  * over xGMI (RCCL broadcast of a byte tensor); every other rank attaches to its received copy. */
-int am_automaton_image_size(const am_automaton* a, int case_mode, size_t* nbytes);
-int am_automaton_image_copy(const am_automaton* a, int case_mode, void* d_dst, size_t nbytes);   /* device -> device */
-int am_automaton_from_image(const void* d_image, size_t nbytes, am_automaton** out);            /* copies the blob; TRUSTED input: a blob made by am_automaton_image_copy in this job (header checked only) */
+AM_API int am_automaton_image_size(const am_automaton* a, int case_mode, size_t* nbytes);
+AM_API int am_automaton_image_copy(const am_automaton* a, int case_mode, void* d_dst, size_t nbytes);   /* device -> device */
+AM_API int am_automaton_from_image(const void* d_image, size_t nbytes, am_automaton** out);            /* copies the blob; TRUSTED input: a blob made by am_automaton_image_copy in this job (header checked only) */
 /* Serialised automaton: the same blob in host memory (write it to a file as is).  Loading checks the
  * header (magic, version, every section inside the blob), a checksum of the body and every index the kernels
  * follow (states, node and edge ids, table slots), so a truncated, damaged or stale file is refused with
  * AM_ERR_INVALID; it skips build + flatten entirely (the reference's JSON instances store only
  * the needles and rebuild, Searcher.hs:68-77).  A handle made from an image serves the image's case mode. */
-int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst, size_t nbytes);   /* device -> host */
-int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out);
+AM_API int am_automaton_image_read(const am_automaton* a, int case_mode, void* host_dst, size_t nbytes);   /* device -> host */
+AM_API int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton** out);
 
 /* ---- UTF-8 helpers on the path -------------------------------------------------------------------
  * am_lower_code_point: Utf8.lowerCodePoint (src/Data/Text/Utf8.hs:145-151) with the BUILT-IN table: simple mapping of
@@ -324,19 +330,19 @@ int am_automaton_from_host_image(const void* image, size_t nbytes, am_automaton*
  * am_unlower_code_point: Utf8.unlowerCodePoint (src/Data/Text/Utf8/Unlower.hs:26-28) as an ascending set, built-in table;
  * returns the set size (may exceed cap).
  * am_image_version: layout version of the flattened image (am_automaton_image_*); images of another version are refused. */
-uint32_t am_lower_code_point(uint32_t cp);
-uint32_t am_unicode_version(void);
-uint32_t am_image_version(void);
-size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
+AM_API uint32_t am_lower_code_point(uint32_t cp);
+AM_API uint32_t am_unicode_version(void);
+AM_API uint32_t am_image_version(void);
+AM_API size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
 
 /* ---- runtime knobs ------------------------------------------------------------------------------ */
-int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches OF THE CALLING THREAD; NULL = the thread's library stream */
-int am_get_stream(void** hip_stream);  /* the stream the calling thread's launches on the current device go to (to order other work after them) */
-int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
+AM_API int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches OF THE CALLING THREAD; NULL = the thread's library stream */
+AM_API int am_get_stream(void** hip_stream);  /* the stream the calling thread's launches on the current device go to (to order other work after them) */
+AM_API int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
-int am_profile_enable(int on);
-int am_profile_reset(void);
-int am_profile_read(const char* kernel /* "sf" | "ac" | "hidx" | "scan" | "permute" | "rp_pass" | "rp_splice" | ... */, double* total_ms, uint64_t* launches);
+AM_API int am_profile_enable(int on);
+AM_API int am_profile_reset(void);
+AM_API int am_profile_read(const char* kernel /* "sf" | "ac" | "hidx" | "scan" | "permute" | "rp_pass" | "rp_splice" | ... */, double* total_ms, uint64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,31 @@
+/*
+ * am_debug.h -- the entry points libam.so exports for TESTS AND MEASUREMENTS, next to the product ABI of include/am.h.  Nothing here is
+ * needed by (or meant for) a caller of the library: a Haskell / C host binds am.h only.  None of these functions changes a result.
+ */
+#ifndef AM_DEBUG_H
+#define AM_DEBUG_H
+
+#include "am.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* A test / measurement switch of csrc/am_config.h by the name of its environment variable ("AM_RP_LOOP", "AM_SF_POOL_BLOCKS", ...);
+ * value -1 = unset.  AM_ERR_INVALID: no such switch. */
+AM_API int am_debug_set(const char* name, long value);
+/* Page-locked staging memory of all threads, living or parked (the leak test). */
+AM_API uint64_t am_debug_pinned_bytes(void);
+/* Cycle sums per k_sf phase / per-wavefront record counts of launches made under AM_SF_ABLATE=9 (tools/phase_timing.py). */
+AM_API int am_debug_sf_phase_cycles(uint64_t* out5);
+AM_API int am_debug_sf_wave_records(uint64_t* out, size_t n_waves);
+/* The general AC-walk kernel (k_ac) is test infrastructure and lives in libam_check.so (tests/native/am_ac.hip).  Loading that library
+ * hands its launcher to libam through this call; `launcher` is am::dev::launch_ac of a build with the same csrc/am_device.h
+ * (image_version must equal am_image_version()), NULL takes it away again.  Without a launcher am_automaton_set_kernel(a, 1) makes every
+ * scan of `a` fail with AM_ERR_UNSUPPORTED. */
+AM_API int am_debug_set_general_kernel(void* launcher, uint32_t image_version);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AM_DEBUG_H */

@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _checker_kernel():
+    """The general AC-walk kernel k_ac -- the tests' independent second algorithm, Automaton.set_kernel(1) -- is test infrastructure: it lives
+    in libam_check.so (tests/native/am_ac.hip), not in the product library, and registers itself with libam when loaded."""
+    import alfred_margaret_amd as am
+    am.api.load_check()
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     with open(os.path.join(ROOT, "tests", "golden", "reference_known_answers.json")) as f:

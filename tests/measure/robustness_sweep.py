@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 import alfred_margaret_amd as am
+am.api.load_check()          # k_ac (set_kernel(1)) is test infrastructure: libam_check.so
 from alfred_margaret_amd import synth
 from oracle import oracle
 

@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import numpy as np
 import alfred_margaret_amd as am
+am.api.load_check()          # k_ac (set_kernel(1)) is test infrastructure: libam_check.so
 from oracle import oracle
 from tests.helpers import expand_records, fragment_case, oracle_triples
 

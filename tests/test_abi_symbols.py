@@ -9,8 +9,8 @@ import alfred_margaret_amd as am
 from tests.conftest import ROOT
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "am.h")).read()
+def _declared(header="am.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(am_[a-z0-9_]+)\s*\(", src)))
 
@@ -22,6 +22,33 @@ def test_every_declared_symbol_is_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(am.api.ABI) == names      # the Python binding table covers the header exactly
+    assert sorted(am.api.DEBUG_ABI) == _declared("am_debug.h")
+
+
+def test_the_library_exports_the_two_headers_and_nothing_else():
+    """libam.so is linked with -fvisibility=hidden + csrc/libam.map: its dynamic symbol table is include/am.h + include/am_debug.h -- no C++
+    internals, no kernel handles, and no k_ac (the checker kernel lives in libam_check.so) or oracle symbol."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(am.build.LIB, "libam.so")], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == sorted(_declared() + _declared("am_debug.h")), set(exported) ^ set(_declared() + _declared("am_debug.h"))
+    assert not [s for s in exported if "k_ac" in s or "orc_" in s or "launch_" in s]
+
+
+def test_general_kernel_is_refused_without_the_checker_library():
+    """In a process that did not load libam_check.so -- every product process -- am_automaton_set_kernel(a, 1) leads to AM_ERR_UNSUPPORTED, never to
+    a silent other path.  (Runs in a child: this process has the checker loaded by conftest.)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import ctypes as C, alfred_margaret_amd as am\n"
+            "lib = am.api.libam(); a = am.Automaton(['abc']); a.set_kernel(1)\n"
+            "b = C.c_void_p(); s = (am.api.Slice * 1)(); buf = C.create_string_buffer(b'xabcx'); s[0].ptr = C.addressof(buf); s[0].off = 0; s[0].len = 5\n"
+            "rc = lib.am_batch_upload(s, 1, C.byref(b))\n"
+            "if rc == am.AM_ERR_NO_DEVICE: print('NODEV'); sys.exit(0)\n"
+            "m = C.c_void_p(); rc = lib.am_run_batch(a.device, 0, b, C.byref(m)); print('RC', rc, lib.am_last_error())\n" % ROOT)
+    out = subprocess.check_output([sys.executable, "-c", code], text=True)
+    assert "NODEV" in out or ("RC %d" % am.AM_ERR_UNSUPPORTED in out and "libam_check" in out), out
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -38,9 +65,9 @@ def test_no_cpu_fallback_without_gpu():
 
 def test_product_does_not_reference_the_oracle():
     bad = []
-    for top in ("alfred-margaret_amd", "tools", "include"):
+    for top in ("alfred-margaret_amd", "tools", "include", os.path.join("tests", "native")):
       for base, _, files in os.walk(os.path.join(ROOT, top)):
-        if os.path.basename(base) in ("lib", "__pycache__"):
+        if os.path.basename(base) in ("lib", "__pycache__") or os.sep + "experiments" in base:      # tools/experiments: archived experiments with their own (oracle-checked) tests
             continue
         for f in files:
             if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip", ".sh")):
