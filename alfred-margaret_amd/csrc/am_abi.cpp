@@ -331,8 +331,10 @@ extern "C" int am_automaton_create(const uint64_t* transitions, size_t n_transit
 extern "C" uint32_t am_automaton_lower_hash(const am_automaton* a)
 {
     if (!a) return 0;
-    for (const Flavor& f : a->fl) if (f.ready && !a->has_ref) return f.h.flags;      // attached to an image: what the image says
-    return a->lower ? a->lower->hash : builtin_lower_table().hash;
+    if (a->has_ref) return a->lower ? a->lower->hash : builtin_lower_table().hash;   // immutable after creation: no lock
+    std::lock_guard<std::mutex> lk(const_cast<am_automaton*>(a)->mu);                 // prepare() writes fl[] under this lock
+    for (const Flavor& f : a->fl) if (f.ready) return f.h.flags;                      // attached to an image: what the image says
+    return builtin_lower_table().hash;
 }
 
 extern "C" uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs)
@@ -1183,35 +1185,28 @@ extern "C" int am_run_range(const am_automaton* a, int case_mode, const am_slice
     return AM_OK;
 }
 
-// countMatches (benchmark/haskell/app/Main.hs:67-76) over the end positions in (lo, hi] of ONE haystack
+// countMatches (benchmark/haskell/app/Main.hs:67-76) over the end positions in (lo, hi] of ONE haystack.  No record is written: the count-mode scan
+// runs over two slices of the window in one call -- text[start, hi') and its prefix text[start, lo') (lo', hi' = lo, hi moved back to a code point
+// boundary: no match ends inside a code point) -- and the answer is their difference.  A scan of a prefix reports exactly the matches of the longer
+// scan that end inside the prefix, and whatever the window misses before `start` (matches that begin before it) it misses in both; every match
+// ending behind lo' lies inside the window (range_window's overlap).  The prefix is at most the overlap: a few dozen bytes.
 extern "C" int am_count_range(const am_automaton* a, int case_mode, const am_slice* hay, uint64_t lo, uint64_t hi, uint64_t* count_out)
 {
     if (!count_out) return fail(AM_ERR_INVALID, "count_out is null");
     *count_out = 0;
-    am_matches* m = nullptr;
-    AM_TRY(am_run_range(a, case_mode, hay, lo, hi, &m));
-    int rc = AM_OK;
-    if (m->n) {
-        const Flavor* f = nullptr;
-        rc = prepare(a, case_mode, &f);
-        OnDevice od(m->dev);
-        if (rc == AM_OK) rc = od.rc;
-        hipStream_t st;
-        if (rc == AM_OK) rc = get_stream(m->dev, &st);
-        uint64_t* d_t = nullptr;
-        if (rc == AM_OK && hipMalloc((void**)&d_t, 8) != hipSuccess) rc = fail(AM_ERR_OOM, "hipMalloc failed");
-        if (rc == AM_OK) {
-            const AcView ac = make_ac_view(f->d_image, f->h);
-            hipError_t e = hipMemsetAsync(d_t, 0, 8, st);
-            if (e == hipSuccess) e = launch_records_reduce(m->d_records + m->first, m->n, ac.vlen, nullptr, d_t, nullptr, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(count_out, d_t, 8, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) rc = fail(AM_ERR_HIP, std::string("am_count_range: ") + hipGetErrorString(e));
-        }
-        if (d_t) (void)hipFree(d_t);
-    }
-    am_matches_free(m);
-    return rc;
+    uint64_t start = 0, scan_hi = 0;
+    AM_TRY(range_window(a, case_mode, hay, lo, hi, &start, &scan_hi));
+    if (hi == lo) return AM_OK;
+    const uint8_t* t = hay->ptr + hay->off;
+    uint64_t lo_b = lo, hi_b = hi;
+    while (lo_b > start && lo_b < hay->len && (t[lo_b] & 0xC0u) == 0x80u) lo_b--;
+    while (hi_b > start && hi_b < hay->len && (t[hi_b] & 0xC0u) == 0x80u) hi_b--;
+    if (hi_b <= lo_b) return AM_OK;
+    const am_slice two[2] = {{hay->ptr, hay->off + start, hi_b - start}, {hay->ptr, hay->off + start, lo_b - start}};
+    uint64_t counts[2] = {0, 0};
+    AM_TRY(am_count(a, case_mode, two, 2, counts));
+    *count_out = counts[0] - counts[1];
+    return AM_OK;
 }
 
 // ------------------------------------------------------------------ results
@@ -1232,6 +1227,12 @@ struct HostCache {
         { std::lock_guard<std::mutex> lk(mu); old = p; p = q; cap = c; }
         std::free(old);
     }
+    void trim()
+    {
+        void* old = nullptr;
+        { std::lock_guard<std::mutex> lk(mu); old = p; p = nullptr; cap = 0; }
+        std::free(old);
+    }
     ~HostCache() { std::free(p); }
 };
 static HostCache g_host_cache;
@@ -1240,14 +1241,22 @@ static HostCache g_host_cache;
 // records are DMA'd straight into them, no staging copy -- a match-dense result is several times the size of the text that produced it
 // (natural language: 2.5 x) and used to crawl through two 8-MiB staging halves and a single-threaded memcpy (2 GiB of text: 926 ms,
 // round 3).  Page-locking is slow (~1 GiB/s) and page-locked memory is a limited resource, so one freed block is kept for the next result
-// (up to kPinnedKeep) and larger ones are given back at once; if the runtime refuses a block the pageable path below still works.
+// (up to kPinnedKeep = 1 GiB) and larger ones are given back at once; a kept block serves a result of at least half its size (a 9-MiB result
+// does not sit in a 1-GiB block); am_release_host_memory() gives the kept block back; if the runtime refuses a block the pageable path below
+// still works.
 struct PinnedCache {
     std::mutex mu; void* p = nullptr; size_t cap = 0;
     void* take(size_t need, size_t* cap_out)
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (p && cap >= need) { void* r = p; *cap_out = cap; p = nullptr; cap = 0; return r; }
+        if (p && cap >= need && cap <= 2 * need + ((size_t)16 << 20)) { void* r = p; *cap_out = cap; p = nullptr; cap = 0; return r; }
         return nullptr;
+    }
+    void trim()
+    {
+        void* old = nullptr;
+        { std::lock_guard<std::mutex> lk(mu); old = p; p = nullptr; cap = 0; }
+        if (old) (void)hipHostFree(old);
     }
     void give(void* q, size_t c, size_t keep_limit)
     {
@@ -1257,7 +1266,7 @@ struct PinnedCache {
     }
 };
 static PinnedCache& pinned_cache() { static PinnedCache* c = new PinnedCache(); return *c; }      // never destroyed: no HIP call in a static destructor
-constexpr size_t kPinnedKeep = (size_t)8 << 30;
+constexpr size_t kPinnedKeep = (size_t)1 << 30;
 
 constexpr size_t kRecordsDirect = 1u << 20;              // results up to this size: one plain copy
 constexpr size_t kFetchPiece = 8u << 20;
@@ -1288,6 +1297,13 @@ static int fetch_through_pinned(void* dst, const void* d_src, size_t bytes, int 
     AM_TRY(issue(0));
     for (size_t i = 1; i < n_pieces; i++) { AM_TRY(issue(i)); AM_TRY(take(i - 1)); }
     AM_TRY(take(n_pieces - 1));
+    return AM_OK;
+}
+
+extern "C" int am_release_host_memory(void)
+{
+    pinned_cache().trim();
+    g_host_cache.trim();
     return AM_OK;
 }
 

@@ -19,7 +19,7 @@ struct am_replacer {
     DevBuf vals_off, vals, payloads, repl, one;
     RpTables t{};
     uint32_t max_repl_len = 0;                        // longest replacement (bounds the re-scan window of the one-kernel loop)
-    uint32_t max_needle_bytes = 0;                    // longest needle in bytes as the payloads give it (exact for CaseSensitive replacers)
+    uint32_t max_needle_bytes = 0;                    // longest needle of the AUTOMATON in bytes (depth of its trie in UTF-8 bytes; 0: unknown) = the longest CaseSensitive match
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
     // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
     mutable std::mutex session_mu;
@@ -109,7 +109,6 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         for (size_t i = 0; i < n_payloads; i++) {
             pr[i] = payloads[i].priority;
             if (payloads[i].repl_len > max_repl) max_repl = payloads[i].repl_len;
-            if (payloads[i].len_bytes > max_needle) max_needle = payloads[i].len_bytes;
             if (pr[i] > 0) return fail(AM_ERR_INVALID, "priorities must be <= 0 (the initial threshold is 1, Replacer.hs:211)");
             if ((uint64_t)payloads[i].repl_off + payloads[i].repl_len > n_repl_bytes) return fail(AM_ERR_INVALID, "replacement slice out of range");
             if (case_mode == AM_IGNORE_CASE && payloads[i].len_code_points == 0)
@@ -117,6 +116,28 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         }
         std::sort(pr.begin(), pr.end());
         for (size_t i = 1; i < n_payloads; i++) if (pr[i] == pr[i - 1]) return fail(AM_ERR_INVALID, "payload priorities must be distinct");
+    }
+    // How far a CaseSensitive match reaches back = the longest needle IN THE AUTOMATON, in bytes.  The payloads' len_bytes are the lengths of the
+    // ORIGINAL needles (Replacer.hs:112) and say nothing about that: a replacer built IgnoreCase holds the lower-cased needles, and lower-casing can
+    // add bytes (U+023A, two bytes, becomes U+2C65, three); setCaseSensitivity (Replacer.hs:148-153) then runs those needles CaseSensitive.  So the
+    // bound is read off the trie: the deepest state, each goto edge counted with the UTF-8 length of its code point.  Handles attached to a received image
+    // carry no arrays: 0 = unknown, and the loop falls back to the bound by code points.
+    max_needle = 0;
+    if (a->has_ref) {
+        const size_t S = a->offsets.size() - 1;
+        std::vector<uint32_t> depth(S, 0), queue; queue.reserve(S); queue.push_back(0);
+        for (size_t q = 0; q < queue.size(); q++) {
+            const uint32_t st = queue[q];
+            for (uint64_t i = a->offsets[st]; i < a->transitions.size(); i++) {
+                const uint64_t t = a->transitions[i];
+                if (t & kWildcard) break;
+                const uint32_t cp = (uint32_t)(t & 0x1fffffu), nx = (uint32_t)(t >> 32);
+                if (nx >= S || nx == 0) break;                               // (validated at creation; never taken)
+                depth[nx] = depth[st] + (cp < 0x80u ? 1u : cp < 0x800u ? 2u : cp < 0x10000u ? 3u : 4u);
+                if (depth[nx] > max_needle) max_needle = depth[nx];
+                queue.push_back(nx);
+            }
+        }
     }
     am_replacer* r = new am_replacer();
     r->a = a; r->case_mode = case_mode; r->max_repl_len = max_repl; r->max_needle_bytes = max_needle;
@@ -848,9 +869,9 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
         for (cfg::Key k : {cfg::kRpFullScans, cfg::kRpSplice, cfg::kRpPieces, cfg::kRpParallelFold, cfg::kRpGroups, cfg::kRpNoFuse, cfg::kRpNoRangeReuse, cfg::kRpNoSpin, cfg::kRpMatMain})
             if (cfg::get(k) != cfg::kUnset) return AM_OK;
     }
-    // how far a replacement's neighbourhood reaches = the longest needle in haystack bytes: exact for CaseSensitive replacers (the payloads carry
-    // the needles' byte lengths; 4 bytes per code point + 4 would make the windows of ASCII needles four times as long), the bound by code points
-    // under IgnoreCase (the matched text may be longer than the lower-cased needle)
+    // how far a replacement's neighbourhood reaches = the longest needle in haystack bytes: for CaseSensitive replacers the byte depth of the
+    // automaton's trie (am_replacer_create; 4 bytes per code point + 4 would make the windows of ASCII needles four times as long), the bound by code
+    // points under IgnoreCase (the matched text may be longer than the lower-cased needle) and for automata attached to an image (depth unknown)
     const uint32_t ov_cps = 4u * (fl->h.max_needle_cps ? fl->h.max_needle_cps : 1u) + 4u;
     const uint32_t ov = r->case_mode == AM_CASE_SENSITIVE && r->max_needle_bytes > 0 && r->max_needle_bytes < ov_cps ? r->max_needle_bytes : ov_cps;
     const uint64_t wcap64 = ((2ull * ov + r->max_repl_len + 16ull) + 63ull) & ~63ull;

@@ -339,6 +339,9 @@ AM_API size_t am_unlower_code_point(uint32_t cp, uint32_t* out, size_t cap);
 AM_API int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent launches OF THE CALLING THREAD; NULL = the thread's library stream */
 AM_API int am_get_stream(void** hip_stream);  /* the stream the calling thread's launches on the current device go to (to order other work after them) */
 AM_API int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
+/* Host blocks of large results are the library's own (am_matches_data); one freed block -- page-locked, up to 1 GiB -- is kept for the next
+ * large result.  This gives it back to the system now (page-locked memory is a shared, limited resource). */
+AM_API int am_release_host_memory(void);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 AM_API int am_profile_enable(int on);
 AM_API int am_profile_reset(void);

@@ -511,6 +511,10 @@ orc_replacer* orc_replacer_build(int ignore_case, const uint8_t* nbytes, const u
     return r;
 }
 
+/* Replacer.hs:148-153 setCaseSensitivity: the needles in the automaton stay as they are (an IgnoreCase-built replacer keeps its
+ * lower-cased needles), the payloads keep the ORIGINAL needles' lengths; only the mode of the scan and of makeMatch (:264-274) changes. */
+void orc_replacer_set_case(orc_replacer* r, int ignore_case) { r->ignore_case = ignore_case; }
+
 void orc_replacer_free(orc_replacer* r)
 {
     if (!r) return;

@@ -59,6 +59,8 @@ def _load():
     lib.orc_replacer_build.restype = C.c_void_p
     lib.orc_replacer_build.argtypes = [C.c_int, C.c_char_p, u64p, C.c_char_p, u64p, C.c_size_t]
     lib.orc_replacer_free.argtypes = [C.c_void_p]
+    lib.orc_replacer_set_case.restype = None
+    lib.orc_replacer_set_case.argtypes = [C.c_void_p, C.c_int]
     lib.orc_replacer_run.restype = C.c_void_p
     lib.orc_replacer_run.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.POINTER(C.c_size_t)]
     lib.orc_free_bytes.argtypes = [C.c_void_p]
@@ -236,6 +238,11 @@ class Replacer:
         if getattr(self, "_h", None) and lib is not None:      # module globals may be gone at interpreter exit
             lib().orc_replacer_free(self._h)
             self._h = None
+
+    def set_case_sensitivity(self, case):
+        """Replacer.setCaseSensitivity (Replacer.hs:148-153), in place: needles and payload lengths untouched."""
+        lib().orc_replacer_set_case(self._h, int(case))
+        return self
 
     def run(self, text, max_len=-1):
         b = _as_bytes(text)

@@ -809,6 +809,7 @@ def test_run_range_partitions_equal_the_whole_scan():
         a = am.Automaton(needles)
         whole = a.run_records(case, [text])
         total = int(a.count_matches(case, [text])[0])
+        vlen = np.diff(a.values_off()).astype(np.int64)
         n = len(text)
         buf = C.create_string_buffer(text, n + 1)
         sl = am.api.Slice(C.addressof(buf), 0, n)
@@ -823,6 +824,7 @@ def test_run_range_partitions_equal_the_whole_scan():
                 c = C.c_uint64(0)
                 am.check(lib.am_count_range(a.device, case, C.byref(sl), lo, hi, C.byref(c)))
                 counts += int(c.value)
+                assert int(c.value) == int(vlen[parts[-1]["state"].astype(np.int64)].sum()), (lo, hi)      # the count-mode route == the records of the same range
                 assert all(lo < int(e) <= hi for e in parts[-1]["end_pos"][:50])
             got = np.concatenate(parts)
             assert got.tobytes() == whole.tobytes(), (world, cuts)

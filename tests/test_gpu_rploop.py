@@ -127,3 +127,28 @@ def test_loop_cfg5_reduced_and_what_it_scans():
     with ThreadPoolExecutor(8) as pool:
         exp = list(pool.map(orc.run, hays[:48]))
     assert got[:48] == exp
+
+
+def test_loop_reach_comes_from_the_automaton_not_from_the_payload_lengths():
+    """ADVICE r4 (medium): a replacer built IgnoreCase holds LOWER-CASED needles, and lower-casing can add bytes (U+023A, 2 bytes -> U+2C65, 3 bytes;
+    U+023E -> U+2C66) while the payloads keep the ORIGINAL lengths (Replacer.hs:112-113).  setCaseSensitivity CaseSensitive (Replacer.hs:148-153) then runs
+    those 3-byte needles CaseSensitive: the re-scan reach of the one-kernel loop must be the automaton's longest needle in bytes, or matches that start more
+    than `payload bytes` before a replacement are missed.  AM_RP_LOOP=1 == AM_RP_LOOP=0 == the oracle with the same setCaseSensitivity."""
+    needles = ["ȺȾȺȾȺȾȺȾ", "Ⱥb", "ȾȺȾȺȾȺȾa", "xȺ"]
+    pairs = list(zip(needles, ["<1>", "Ⱦ", "ⱥⱦⱥⱦⱥⱦⱥⱦ", "ⱦⱥⱦⱥⱦⱥ"]))
+    low = "ⱥⱦ"
+    rng = random.Random(23)
+    hays = ["".join(rng.choice([low[0], low[1], "a", "b", "x", "ⱥⱦ" * 4]) for _ in range(rng.randint(0, 400))) for _ in range(96)]
+    hays += ["xⱥⱦⱥⱦⱥⱦⱥⱦⱥⱦa" * 30, "ⱦⱥⱦⱥⱦⱥⱦ" + "a" * 5 + "xⱥb", ""]
+    r = am.Replacer(1, pairs).set_case_sensitivity(0)
+    o = oracle.Replacer(1, pairs).set_case_sensitivity(0)
+    exp = [o.run(h) for h in hays]
+    assert any(e != h.encode() for e, h in zip(exp, hays))
+    am.debug_set("AM_RP_LOOP", 0)
+    ref = r.run_batch(hays)
+    am.debug_set("AM_RP_LOOP", 1)
+    got = r.run_batch(hays)
+    am.debug_set("AM_RP_LOOP", -1)
+    assert ref == exp
+    assert got == exp
+    assert r.run_batch(hays) == exp                          # the default route (>= 64 documents: the one-kernel loop)
