@@ -99,6 +99,19 @@ def build_check(force=False):
     return target
 
 
+def build_rccl_stub(force=False):
+    """TEST-ONLY libam_rccl_stub.so (tests/native/rccl_stub.cpp), soname librccl.so.1: file-based stand-ins for the RCCL calls of csrc/am_multi.cpp, so
+    that its N-rank code runs as N processes on a one-GPU box (tests/test_multi_ranks.py).  Not part of build_all()'s product set, built on demand."""
+    os.makedirs(LIB, exist_ok=True)
+    target = os.path.join(LIB, "libam_rccl_stub.so")
+    src = os.path.join(NATIVE_TESTS, "rccl_stub.cpp")
+    if force or _stale(target, [src]):
+        subprocess.check_call([_hipcc(), "-O1", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-shared", "-x", "hip", "--offload-arch=" + ARCH, src,
+                               "-Wl,-soname,librccl.so.1", "-o", target + ".tmp"])
+        os.replace(target + ".tmp", target)
+    return target
+
+
 def build_host(force=False):
     os.makedirs(LIB, exist_ok=True)
     target = os.path.join(LIB, "libam_host.so")
@@ -125,7 +138,7 @@ def build_synth(force=False):
 
 def build_all(force=False):
     return {"libam": build_libam(force), "libam_host": build_host(force), "libam_check": build_check(force), "libam_imgcheck": build_imgcheck(force),
-            "libam_synth": build_synth(force)}
+            "libam_synth": build_synth(force), "libam_rccl_stub": build_rccl_stub(force)}
 
 
 if __name__ == "__main__":

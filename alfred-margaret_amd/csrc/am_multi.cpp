@@ -29,6 +29,7 @@ using am::abi_fail;
 
 // RCCL is bound at first use (dlopen), not at link time: single-GPU callers never load it, and a process that already
 // holds an RCCL (PyTorch ships its own copy) keeps using that one instead of getting a second copy of the library.
+// AM_RCCL_LIBRARY=<path> names the library to bind instead (a site's own RCCL build; the test suite's file-based stand-in).
 namespace {
 struct Rccl {
     void* lib = nullptr;
@@ -46,7 +47,13 @@ struct Rccl {
     {
         if (lib) return true;
         if (!why.empty()) return false;
-        for (const char* name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }      // one that is already in the process
+        if (const char* named = std::getenv("AM_RCCL_LIBRARY")) {
+            if (*named) {
+                lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+                if (!lib) { why = std::string("AM_RCCL_LIBRARY: ") + dlerror(); return false; }
+            }
+        }
+        if (!lib) for (const char* name : {"librccl.so.1", "librccl.so"}) { lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (lib) break; }      // one that is already in the process
         if (!lib) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) { why = std::string("RCCL not found: ") + dlerror(); return false; }
         bool ok = true;
