@@ -684,11 +684,11 @@ def replacer_parity(args, w, pairs, case, rdev, batch, text, n_hay, n_bytes, res
         return res
 
     def view(res, i):
-        ptr, ln = C.POINTER(C.c_uint8)(), C.c_size_t(0)
+        ptr, ln = C.c_void_p(), C.c_size_t(0)
         just = lib.am_replaced_get(res, i, C.byref(ptr), C.byref(ln))
         if just != 1:
             return None
-        return np.ctypeslib.as_array(ptr, shape=(ln.value,)) if ln.value else np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(ln.value,)) if ln.value else np.zeros(0, np.uint8)
 
     t0 = time.perf_counter()
     a, b = host_texts(-1), host_texts(0)

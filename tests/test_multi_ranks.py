@@ -108,7 +108,7 @@ def test_image_written_by_one_process_scanned_by_another(tmp_path):
     """process A flattens and writes the serialised image (am_automaton_image_read); process B -- which never sees the needles --
     loads the file (am_automaton_from_host_image: checksum, bounds, table hash) and scans with k_sf; the records are the oracle's."""
     needles = synth.needles_for("cfg3_runLower_100k_10GiB")[:5000]
-    text = bytes(synth.haystacks_host(needles, True, 7, 64))
+    text = bytes(synth.haystacks_host(needles, True, 7, 256))
     img_path, hay_path, out_path = (str(tmp_path / n) for n in ("image.bin", "hay.bin", "recs.bin"))
     open(hay_path, "wb").write(text)
     writer = ("import sys; sys.path.insert(0, %r)\n"
