@@ -166,6 +166,7 @@ DEBUG_ABI = {
     "am_debug_sf_phase_cycles": (C.c_int, [_vp]),
     "am_debug_sf_wave_records": (C.c_int, [_vp, _sz]),
     "am_debug_set_general_kernel": (C.c_int, [_vp, C.c_uint32]),
+    "am_debug_rp_lds_haystacks": (C.c_uint32, []),
 }
 
 _libam = None
@@ -654,7 +655,7 @@ class Splitter:
 
 DEBUG_SWITCHES = ("AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN",
                   "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
-                  "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LOOP")
+                  "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_LOOP")
 
 
 def debug_set(name, value):

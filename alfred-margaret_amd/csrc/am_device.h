@@ -138,10 +138,13 @@ struct RpLoop {
     uint8_t* wtext; uint32_t wcap, pad;                     // haystack h: wcap bytes of window scratch; pad != 0: the instrumented instantiation
     uint64_t max_len;
     RpLoopOut* out;
-    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time, [6] the longest record list of the batch (k_rp_loop_caps), [8..23] eight 64-bit phase sums of the instrumented instantiation
+    uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time (100 +: in k_rp_lds), [6] the longest record list of the batch (k_rp_loop_caps), [7] haystacks k_rp_lds finished, [8..23] eight 64-bit phase sums of the instrumented instantiation
+    uint32_t* redo;                                         // per haystack: 1 = k_rp_lds (LDS-resident lists, am_rplds.hip) gave it up, k_rp_loop runs it; null: k_rp_loop runs every haystack
+    uint32_t h_first, pad2;                                 // the launch covers haystacks h_first + blockIdx.x (groups of a batch, one launch each)
 };
 hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, uint32_t* max_records /* atomic max, cleared by the caller */, hipStream_t st);
-hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves_per_simd, hipStream_t st);
+hipError_t launch_rp_loop(bool ic, const RpLoop& a, uint32_t n /* haystacks from a.h_first */, int waves_per_simd, hipStream_t st);
+hipError_t launch_rp_lds(bool ic, const RpLoop& a, uint32_t n /* haystacks from a.h_first */, hipStream_t st);
 hipError_t launch_pt_init(const uint64_t* offsets, uint32_t n_act, RpPiece* pieces, uint64_t* pc_start, uint32_t* pc_cnt, hipStream_t st);
 hipError_t launch_pt_count(const RpHay* hs, const uint32_t* pc_cnt, uint32_t n_act, uint32_t* need, uint32_t* nwin, hipStream_t st);
 hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* rec_first, const RpKept* kept, const RpPiece* pieces, const uint64_t* pc_start,

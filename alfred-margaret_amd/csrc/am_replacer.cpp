@@ -19,6 +19,7 @@ struct am_replacer {
     DevBuf vals_off, vals, payloads, repl, one;
     RpTables t{};
     uint32_t max_repl_len = 0;                        // longest replacement (bounds the re-scan window of the one-kernel loop)
+    uint64_t n_repl_bytes = 0;                        // size of the replacement blob
     uint32_t max_needle_bytes = 0;                    // longest needle of the AUTOMATON in bytes (depth of its trie in UTF-8 bytes; 0: unknown) = the longest CaseSensitive match
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
     // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
@@ -140,7 +141,7 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         }
     }
     am_replacer* r = new am_replacer();
-    r->a = a; r->case_mode = case_mode; r->max_repl_len = max_repl; r->max_needle_bytes = max_needle;
+    r->a = a; r->case_mode = case_mode; r->max_repl_len = max_repl; r->max_needle_bytes = max_needle; r->n_repl_bytes = n_repl_bytes;
     auto up = [&](DevBuf& d, const void* src, size_t bytes) -> int {
         AM_TRY(d.ensure(bytes + 64));
         if (bytes) HIP_TRY(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
@@ -203,7 +204,7 @@ struct RpSession {
     am_batch ws;                         // workspace holder for the scans; never owns its text
     DevBuf first_orig, first_thr;
     DevBuf pt_pieces[2], pt_start[2], pt_cnt[2], pt_need, pt_need_off, pt_fin_start, pt_fin_cnt;      // piece-table path
-    DevBuf lp_rec, lp_pc, lp_kept, lp_wtext, lp_out, lp_ctrl, lp_cap_r, lp_cap_p, lp_rec_base, lp_pc_base, lp_fin, lp_fin_start, lp_fin_cnt;      // one-kernel loop (am_rploop.hip)
+    DevBuf lp_rec, lp_pc, lp_kept, lp_wtext, lp_out, lp_ctrl, lp_cap_r, lp_cap_p, lp_rec_base, lp_pc_base, lp_fin, lp_fin_start, lp_fin_cnt, lp_redo;      // one-kernel loops (am_rplds.hip, am_rploop.hip)
     void* lp_host = nullptr; size_t lp_host_cap = 0;                        // pinned: the loop's per-haystack results, then the materialise tables
     int pin_loop(size_t bytes)
     {
@@ -230,7 +231,7 @@ struct RpSession {
                           &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr,
                           &pf_best, &pf_delta, &pf_payload, &pf_selflag, &pf_sidx, &pf_cand, &pf_sel, &pf_keep, &pf_kflag, &pf_kdelta, &pf_kidx, &pf_kdpre, &pf_tmp,
                           &pt_pieces[0], &pt_pieces[1], &pt_start[0], &pt_start[1], &pt_cnt[0], &pt_cnt[1], &pt_need, &pt_need_off, &pt_fin_start, &pt_fin_cnt,
-                          &lp_rec, &lp_pc, &lp_kept, &lp_wtext, &lp_out, &lp_ctrl, &lp_cap_r, &lp_cap_p, &lp_rec_base, &lp_pc_base, &lp_fin, &lp_fin_start, &lp_fin_cnt}) d->release();
+                          &lp_rec, &lp_pc, &lp_kept, &lp_wtext, &lp_out, &lp_ctrl, &lp_cap_r, &lp_cap_p, &lp_rec_base, &lp_pc_base, &lp_fin, &lp_fin_start, &lp_fin_cnt, &lp_redo}) d->release();
         if (lp_host) (void)hipHostFree(lp_host);
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
@@ -853,6 +854,10 @@ int replacer_run(const am_replacer* r, const am_batch* in, uint64_t max_length, 
 
 // All passes of every haystack in ONE kernel (am_rploop.hip): a wavefront takes a haystack and runs its loop to the end.  *handled = false:
 // the batch is not for this path (or a haystack outgrew its regions) and nothing of `res` was touched: the caller takes the pass-by-pass paths.
+// (tests, include/am_debug.h) haystacks the last one-kernel run finished out of LDS (k_rp_lds); the others went through k_rp_loop
+static std::atomic<uint32_t> g_last_lds_haystacks{0};
+extern "C" uint32_t am_debug_rp_lds_haystacks(void) { return g_last_lds_haystacks.load(std::memory_order_relaxed); }
+
 static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t max_length, am_replaced* res, bool* handled)
 {
     *handled = false;
@@ -951,8 +956,20 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     a.kept_buf = (RpKept*)s.lp_kept.p; a.wtext = (uint8_t*)s.lp_wtext.p; a.wcap = (uint32_t)wcap64;
     a.max_len = max_length; a.out = (RpLoopOut*)s.lp_out.p; a.ctrl = (uint32_t*)s.lp_ctrl.p;
     a.pad = cfg::get(cfg::kRpTrace) >= 3 ? 1u : 0u;
+    // k_rp_lds first: a haystack's lists in LDS for all its passes (am_rplds.hip); what does not fit there raises its redo flag and k_rp_loop, launched
+    // right behind, runs exactly those haystacks (lists in global memory).  AM_RP_LDS=0 (A/B, tests), the instrumented instantiation and replacement
+    // blobs beyond 2 GiB (piece sources are 31-bit offsets in LDS): k_rp_loop alone.
+    const bool use_lds = cfg::get(cfg::kRpLds) != 0 && !a.pad && r->n_repl_bytes < (1ull << 31);
+    a.redo = nullptr; a.h_first = 0;
+    if (use_lds) {
+        AM_TRY(s.lp_redo.ensure((size_t)n_hay * 4 + 64));
+        HIP_TRY(hipMemsetAsync(s.lp_redo.p, 0, (size_t)n_hay * 4, st));
+        a.redo = (uint32_t*)s.lp_redo.p;
+        say("launch (lds)");
+        { Prof pr("rp_lds", st); HIP_TRY(launch_rp_lds(r->case_mode == AM_IGNORE_CASE, a, n_hay, st)); }
+    }
     say("launch");
-    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, (int)cfg::get(cfg::kRpLoopWaves), st)); }
+    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, n_hay, (int)cfg::get(cfg::kRpLoopWaves), st)); }
     say("launched");
     // what every haystack ended as
     if (a.pad) {
@@ -971,7 +988,8 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     HIP_TRY(hipMemcpyAsync(ctrl_h, s.lp_ctrl.p, 64, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(out_h, s.lp_out.p, out_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (trace) { std::fprintf(stderr, "[am_replacer loop] kernel done: overflow %u passes %u watchdog %u\n", ctrl_h[0], ctrl_h[1], ctrl_h[5]); std::fflush(stderr); }
+    if (trace) { std::fprintf(stderr, "[am_replacer loop] kernels done: overflow %u passes %u watchdog %u; %u of %u haystacks out of LDS\n", ctrl_h[0], ctrl_h[1], ctrl_h[5], ctrl_h[7], n_hay); std::fflush(stderr); }
+    g_last_lds_haystacks.store(use_lds ? ctrl_h[7] : 0u, std::memory_order_relaxed);
     if (ctrl_h[0] != 0) return AM_OK;                        // a haystack outgrew its regions: the pass-by-pass loop takes the batch
     // the finished texts: one materialise launch over the final piece lists
     RpFin* fin_h = (RpFin*)((uint8_t*)s.lp_host + 64 + out_bytes);

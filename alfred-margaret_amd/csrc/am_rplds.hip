@@ -1,0 +1,418 @@
+// am_rplds.hip -- Replacer.run, all passes of a haystack in one wavefront WITH THE HAYSTACK'S LISTS IN LDS (round 5; reference:
+// src/Data/Text/AhoCorasick/Replacer.hs:203-274).
+//
+// k_rp_loop (am_rploop.hip, round 4) keeps a haystack's record list and piece list in global memory: every pass re-reads the whole record list,
+// rewrites the piece list, moves half the records -- ~13 dependent trips through L2 per pass (2 000-3 000 cycles each under load) and 16 bytes of HBM
+// traffic per input byte (profiles/r04_pmc_traffic.md).  But the working set of a haystack is small -- a few hundred records, a few hundred pieces --
+// and it lives for ~100 passes: it belongs in LDS.  Here one wavefront (= one workgroup) owns a haystack and 9.6 KiB of LDS:
+//   records   up to 512, as {end position, priority, payload} (12 B; priority and payload looked up ONCE, when a record enters the list -- the
+//             fold of a pass is three sweeps over LDS, no table look-up)
+//   pieces    up to 448, as {source, logical start} (8 B; sources relative to the haystack / the replacement blob), edited IN PLACE
+// A pass touches global memory for: the selected payload (one uniform load), the window's bytes (one gather), the window's Bloom / probe / resolve
+// look-ups (sf_verify, as k_sf runs it) and the state entries of the records the window adds.  The kept matches of a pass are applied one at a time,
+// from the LAST to the first: replacing one match is a self-contained step on a consistent (text, records) pair -- records ending at or before the match
+// stay, those ending more than `ov` bytes behind it move with the text, those in between are dropped and that stretch of the NEW text is scanned again --
+// and right-to-left the positions left of the match are still the pass's own.  After the last step the list is the scan of the new text, which is what the
+// pass-by-pass loops and k_rp_loop compute.  Records that can never be chosen again (priority at or above the pass's -- the threshold only falls,
+// Replacer.hs:236-242) are not entered.
+// 16 workgroups per CU by LDS = 4 wavefronts per SIMD, the occupancy sf_verify's registers allow anyway.
+// A haystack that does not fit (more records / pieces than the LDS lists hold, positions beyond 2^31, more than 64 new records in one window, a pass
+// that keeps more matches than its kept list holds) raises ITS redo flag and k_rp_loop -- launched right behind this kernel -- runs that haystack from
+// its first scan; nothing is shared between haystacks, so nothing else repeats.
+#include <hip/hip_runtime.h>
+
+#include "am_device.h"
+#include "am_wave.h"
+
+namespace am {
+namespace dev {
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr uint32_t kLdsRec = 512;                         // records a haystack may hold (8 blocks of 64: the fold's sweeps are unrolled over them)
+constexpr uint32_t kLdsBlocks = kLdsRec / kWave;
+constexpr uint32_t kLdsPc = 448;                          // pieces (+ the sentinel)
+constexpr uint32_t kReplBit = 0x80000000u;                // piece source: offset into the replacement blob instead of the haystack
+
+struct LpLds {
+    uint32_t end[kLdsRec]; int32_t prio[kLdsRec]; uint32_t pl[kLdsRec];
+    uint32_t psrc[kLdsPc + 2]; uint32_t pls[kLdsPc + 2];
+};
+
+__device__ __forceinline__ int64_t ld_wave_max_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int64_t o = __shfl_xor(v, d, kWave); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ int64_t ld_wave_sum_i64(int64_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+__device__ __forceinline__ uint32_t ld_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// what the lanes of this wavefront wrote to GLOBAL memory is visible to its other lanes (the window scratch, the kept list)
+__device__ __forceinline__ void ld_global_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// elements [from, to) of an LDS array move to [from + g, to + g), `add` added to each: 64 per trip, from the top down when they move up (a trip's
+// reads are issued before its writes and DS operations of a wavefront execute in order; across trips the writes land where everything has been read)
+__device__ __forceinline__ void ld_move(uint32_t* A, uint32_t from, uint32_t to, int32_t g, uint32_t add, int lane)
+{
+    if (to <= from || (g == 0 && add == 0)) return;
+    const uint32_t nb = (to - from + kWave - 1) / kWave;
+    for (uint32_t b = 0; b < nb; b++) {
+        const uint32_t blk = g > 0 ? nb - 1 - b : b;
+        const uint32_t i = from + blk * kWave + (uint32_t)lane;
+        uint32_t x = 0;
+        if (i < to) x = A[i];
+        wave_lds_fence();
+        if (i < to) A[(uint32_t)((int32_t)i + g)] = x + add;
+        wave_lds_fence();
+    }
+}
+
+constexpr uint64_t kLdMaxTicks = 4000000000ull;           // watchdog, as in k_rp_loop: ~2 s for ONE haystack, then the redo flag
+
+template <bool IC>
+__device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const uint32_t h, const int lane)
+{
+    const uint64_t deadline = __builtin_amdgcn_s_memtime() + kLdMaxTicks;
+    const uint64_t hoff = uniform_u64(a.offsets[h]);
+    const uint64_t len0 = uniform_u64(a.offsets[h + 1]) - hoff;
+    const uint64_t rb = uniform_u64(a.rec_base[h]), cap_r = (uniform_u64(a.rec_base[h + 1]) - rb) >> 1;
+    const uint64_t pb = uniform_u64(a.pc_base[h]), cap_p = uniform_u64(a.pc_base[h + 1]) - pb;
+    const uint64_t rf0 = uniform_u64(a.rec_first0[h]);
+    const uint64_t nr0 = uniform_u64(a.rec_first0[h + 1]) - rf0;
+    RpKept* const K = a.kept_buf + (rb >> 1);                           // kept matches of a pass that keeps several (cap_r entries)
+    uint8_t* const wt = a.wtext + (uint64_t)h * a.wcap;
+    const uint8_t* const htext = a.text + hoff;
+    bool redo = len0 >= 0x7FFFF000ull || nr0 > kLdsRec || cap_p < 4;
+    uint32_t nr = 0, np = 1, passes = 0, status = kRpFinished;
+    uint64_t curlen = len0, scanned = 0;
+    int64_t threshold = 1;                                               // initialThreshold (Replacer.hs:211)
+    auto timed_out = [&](uint32_t code) -> bool {
+        if (__builtin_amdgcn_s_memtime() <= deadline) return false;
+        if (lane == 0) atomicMax(a.ctrl + 5, 100u + code);
+        return true;
+    };
+
+    if (!redo) {
+        // ---- the first scan's records of this haystack enter the LDS lists with their priority and payload
+        nr = (uint32_t)nr0;
+        for (uint32_t r = (uint32_t)lane; r < nr; r += kWave) {
+            const Record rec = a.recs0[rf0 + r];
+            const RpStateOne one = a.t.one[rec.state];
+            L.end[r] = (uint32_t)rec.end_pos;
+            L.prio[r] = one.payload != kRpWalkList ? one.priority : (int32_t)rec.state;      // several values: the state, its list is walked
+            L.pl[r] = one.payload;
+        }
+        if (lane == 0) { L.psrc[0] = 0; L.pls[0] = 0; L.pls[1] = (uint32_t)len0; }
+        wave_lds_fence();
+    }
+
+    // byte at logical position p of the text the LDS piece list describes, piece index known
+    auto byte_in = [&](uint32_t idx, uint32_t p) -> uint32_t {
+        const uint32_t s = L.psrc[idx];
+        const uint8_t* base = (s & kReplBit) ? a.t.repl + (s & ~kReplBit) : htext + s;
+        return base[p - L.pls[idx]];
+    };
+    // pieces that start at or before x (uniform x): the index of the piece that holds byte x is this minus one
+    auto pieces_le = [&](uint32_t x) -> uint32_t {
+        uint32_t c = 0;
+        for (uint32_t k0 = 0; k0 < np; k0 += kWave) {
+            const uint32_t k = k0 + (uint32_t)lane;
+            c += (uint32_t)__popcll(__ballot(k < np && L.pls[k] <= x));
+        }
+        return c;
+    };
+
+    while (!redo) {
+        passes++;
+        if (timed_out(1)) { redo = true; break; }
+        // ---- prependMatch, first half (Replacer.hs:255-258): the best priority below the threshold -- one sweep over LDS
+        int64_t best = INT64_MIN;
+        auto best_of_list = [&](uint32_t st) {
+            for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+                const int64_t p = a.t.payloads[a.t.vals[k]].priority;
+                if (p < threshold && p > best) best = p;
+            }
+        };
+#pragma unroll
+        for (uint32_t b = 0; b < kLdsBlocks; b++) {
+            if (b * kWave < nr) {
+                const uint32_t r = b * kWave + (uint32_t)lane;
+                if (r < nr) {
+                    const int32_t pr = L.prio[r];
+                    if (L.pl[r] != kRpWalkList) { if ((int64_t)pr < threshold && (int64_t)pr > best) best = pr; }
+                    else best_of_list((uint32_t)pr);
+                }
+            }
+        }
+        best = (int64_t)uniform_u64((uint64_t)ld_wave_max_i64(best));
+        if (best == INT64_MIN) { status = kRpFinished; break; }           // no match below the threshold: the text stays (:228-230)
+
+        // ---- which records carry it: priorities are distinct, so every one of them has the same payload
+        uint64_t selmask[kLdsBlocks];
+        uint32_t payload = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < kLdsBlocks; b++) {
+            selmask[b] = 0;
+            if (b * kWave < nr) {
+                const uint32_t r = b * kWave + (uint32_t)lane;
+                bool sel = false; uint32_t plv = 0;
+                if (r < nr) {
+                    const uint32_t pl = L.pl[r];
+                    if (pl != kRpWalkList) { if ((int64_t)L.prio[r] == best) { sel = true; plv = pl; } }
+                    else {
+                        const uint32_t st = (uint32_t)L.prio[r];
+                        for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+                            const uint32_t v = a.t.vals[k];
+                            if (a.t.payloads[v].priority == best) { sel = true; plv = v; }
+                        }
+                    }
+                }
+                selmask[b] = __ballot(sel);
+                if (sel && plv > payload) payload = plv;
+            }
+        }
+        payload = ld_u32((uint32_t)ld_wave_max_i64((int64_t)payload));
+        RpPayload pp = a.t.payloads[payload];                             // uniform index: one load for the pass
+        const uint64_t m_len = uniform_u64((uint64_t)pp.len_bytes);
+        const uint32_t m_cps = ld_u32(pp.len_code_points), rl = ld_u32(pp.repl_len);
+        const uint64_t repl_off = uniform_u64(pp.repl_off);
+
+        // ---- makeMatch (:264-274) + removeOverlap (:191-198): 64 records at a time, in position order
+        int64_t delta_all = 0;
+        uint64_t last_end = 0, k0_start = 0, k0_len = 0;
+        uint32_t nkept = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < kLdsBlocks; b++) {
+            if (selmask[b] == 0) continue;                                // (uniform)
+            const uint32_t r = b * kWave + (uint32_t)lane;
+            const bool sel = (selmask[b] >> lane) & 1ull;
+            const uint64_t end_pos = sel ? L.end[r] : 0;
+            uint64_t len = m_len, start = end_pos - m_len;                // CaseSensitive (:266-267)
+            if (IC && sel) {                                             // IgnoreCase: as long as its code points are in the haystack (skipCodePointsBackwards, Utf8.hs:256-276)
+                if (m_cps == 0) start = end_pos;
+                else {
+                    uint32_t lo = 0, hi = np;                            // last piece that starts at or before the match's last byte
+                    const uint32_t index = (uint32_t)end_pos - 1u;
+                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.pls[mid] <= index) lo = mid; else hi = mid; }
+                    uint32_t pi = lo;
+                    int64_t i = (int64_t)index; uint32_t n = m_cps - 1u;
+                    for (;;) {
+                        for (;;) {
+                            if (i <= 0) break;
+                            while ((uint32_t)i < L.pls[pi]) pi--;         // (pieces may be empty: a loop)
+                            if ((byte_in(pi, (uint32_t)i) & 0xC0u) != 0x80u) break;      // atTrailingByte
+                            i--;
+                        }
+                        if (n == 0 || i <= 0) break;
+                        i--; n--;
+                    }
+                    start = (uint64_t)(i < 0 ? 0 : i);
+                }
+                len = end_pos - start;
+            }
+            if (sel) delta_all += (int64_t)rl - (int64_t)len;
+            uint64_t pending = selmask[b];
+            bool keep = false;
+            while (pending) {
+                const uint64_t ok = __ballot(sel && start >= last_end) & pending;
+                if (!ok) break;
+                const int l = __ffsll((unsigned long long)ok) - 1;
+                if (lane == l) keep = true;
+                last_end = uniform_u64(__shfl(start + len, l, kWave));
+                pending &= l == 63 ? 0ull : ~((2ull << l) - 1ull);
+            }
+            const uint64_t keepmask = __ballot(keep);
+            if (keepmask) {
+                const uint32_t nk = (uint32_t)__popcll(keepmask);
+                if ((uint64_t)nkept + nk > cap_r) { redo = true; break; }
+                if (nkept == 0) {                                        // the first kept match stays in scalar registers (a pass usually keeps one)
+                    const int l = __ffsll((unsigned long long)keepmask) - 1;
+                    k0_start = uniform_u64(__shfl(start, l, kWave)); k0_len = uniform_u64(__shfl(len, l, kWave));
+                }
+                if (keep) {
+                    const uint32_t rank = (uint32_t)__popcll(keepmask & ((1ull << lane) - 1ull));
+                    RpKept e; e.src_start = start; e.src_len = len; e.dst = 0;
+                    K[nkept + rank] = e;
+                }
+                nkept += nk;
+            }
+        }
+        if (redo) break;
+        delta_all = (int64_t)uniform_u64((uint64_t)ld_wave_sum_i64(delta_all));
+        const int64_t newlen_all = (int64_t)curlen + delta_all;           // replacementLength over ALL matches (:240), before removeOverlap
+        if (newlen_all > 0 && (uint64_t)newlen_all > a.max_len) { status = kRpNothing; break; }
+        status = best == a.t.min_priority ? kRpFinished : kRpActive;    // :241-242
+        if (nkept > 1) ld_global_sync();                                  // K is read back below
+
+        // ---- replace (:163-180), one kept match at a time, the last one first
+        for (uint32_t jj = nkept; jj-- > 0 && !redo;) {
+            if (timed_out(2)) { redo = true; break; }
+            uint64_t ms64 = k0_start, ml64 = k0_len;
+            if (nkept > 1) { const RpKept k = K[jj]; ms64 = uniform_u64(k.src_start); ml64 = uniform_u64(k.src_len); }
+            const uint32_t ms = (uint32_t)ms64, me = (uint32_t)(ms64 + ml64);
+            const int32_t delta = (int32_t)rl - (int32_t)ml64;
+            const uint64_t newlen = (uint64_t)((int64_t)curlen + delta);
+            if (newlen >= 0x7FFFF000ull) { redo = true; break; }
+
+            // (a) the piece list, in place: pieces i .. j2 hold the match; what is left of them is a head, the replacement, a tail
+            const uint32_t i = ld_u32(pieces_le(ms)) - 1u;                // (>= 0: piece 0 starts at 0)
+            const uint32_t j2 = ld_u32(pieces_le(me - 1u)) - 1u;          // the match is not empty here (automata with the empty needle do not take this route)
+            const uint32_t pi_ls = ld_u32(L.pls[i]);
+            const uint32_t pj_ls = ld_u32(L.pls[j2]), pj_src = ld_u32(L.psrc[j2]), pj_le = ld_u32(L.pls[j2 + 1]);
+            const uint32_t keep_head = ms > pi_ls ? 1u : 0u, has_repl = rl ? 1u : 0u, has_tail = me < pj_le ? 1u : 0u;
+            const int32_t s = (int32_t)(keep_head + has_repl + has_tail) - (int32_t)(j2 - i + 1u);
+            if ((int64_t)np + s + 1 > (int64_t)kLdsPc) { redo = true; break; }
+            wave_lds_fence();
+            ld_move(L.psrc, j2 + 1u, np + 1u, s, 0u, lane);
+            ld_move(L.pls, j2 + 1u, np + 1u, s, (uint32_t)delta, lane);      // (the sentinel moves too: the new length)
+            if (lane == 0) {
+                uint32_t at = i + keep_head;
+                if (has_repl) { L.psrc[at] = kReplBit | (uint32_t)repl_off; L.pls[at] = ms; at++; }
+                if (has_tail) { L.psrc[at] = pj_src + (me - pj_ls); L.pls[at] = ms + rl; }
+            }
+            np = (uint32_t)((int32_t)np + s);
+            wave_lds_fence();
+            if (status == kRpFinished) { curlen = newlen; continue; }      // the last pass (:241): nobody looks at the records again
+
+            // (b) old records: those that end at or before the match's start stay, those within reach of its end go
+            uint32_t c_before = 0, c_gone = 0;
+            {
+                const uint32_t x2 = me + a.ov;
+#pragma unroll
+                for (uint32_t b = 0; b < kLdsBlocks; b++) {
+                    if (b * kWave < nr) {
+                        const uint32_t r = b * kWave + (uint32_t)lane;
+                        const uint32_t e = r < nr ? L.end[r] : 0xFFFFFFFFu;
+                        c_before += (uint32_t)__popcll(__ballot(e <= ms));
+                        c_gone += (uint32_t)__popcll(__ballot(e <= x2));
+                    }
+                }
+            }
+
+            // (c) the window of the replacement in the new text: gather its bytes through the piece list, scan its own positions
+            uint32_t hi = ms + rl + a.ov;
+            if ((uint64_t)hi > newlen) hi = (uint32_t)newlen;
+            const uint32_t ws = ms > a.ov ? ms - a.ov : 0u;
+            const uint32_t wlen = hi > ms ? hi - ws : 0u, own_lo = ms - ws;
+            if (wlen > a.wcap) { redo = true; break; }
+            uint32_t nf = 0;
+            if (wlen) {
+                const uint32_t first = ld_u32(pieces_le(ws)) - 1u;
+                for (uint32_t x = (uint32_t)lane; x < wlen; x += kWave) {
+                    const uint32_t p = ws + x;
+                    uint32_t idx = first;
+                    while (idx + 1u < np && L.pls[idx + 1u] <= p) idx++;
+                    wt[x] = (uint8_t)byte_in(idx, p);
+                }
+                ld_global_sync();
+                scanned += wlen;
+                for (uint32_t base = own_lo; base < wlen && !redo; base += kWave) {
+                    if (timed_out(3)) { redo = true; break; }
+                    const uint32_t g = base + (uint32_t)lane;
+                    bool found = false; uint32_t state = 0, vlen = 0;
+                    if (g < wlen) {
+                        uint32_t w, w2;
+                        load_suffix8(wt, g, w, w2);
+                        if (IC) w = fold_dword(w);
+                        if (sf_filter_window(a.s.bloom, a.s.bloom_log2_words, a.s.tiers, w)) found = sf_verify<IC>(a.s, wt, g, (uint64_t)g + 1, state, vlen);
+                    }
+                    // a record enters the list with its priority and payload; one that can never be chosen again does not enter at all
+                    RpStateOne one{0, kRpWalkList};
+                    if (found) {
+                        one = a.t.one[state];
+                        if (one.payload != kRpWalkList && (int64_t)one.priority >= best) found = false;
+                    }
+                    const uint64_t fm = __ballot(found);
+                    const uint32_t nfb = (uint32_t)__popcll(fm);
+                    if (nfb) {
+                        if (nf + nfb > (uint32_t)kWave || nr + nf + nfb > kLdsRec) { redo = true; break; }
+                        if (found) {                                     // staged behind the list; they move into the gap below
+                            const uint32_t at = nr + nf + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                            L.end[at] = ws + g + 1u;
+                            L.prio[at] = one.payload != kRpWalkList ? one.priority : (int32_t)state;
+                            L.pl[at] = one.payload;
+                        }
+                        nf += nfb;
+                    }
+                }
+                if (redo) break;
+                if (nkept > 1) ld_global_sync();                          // (the scratch is rewritten by the next window)
+            }
+
+            // (d) the record list, in place: [0, c_before) stays, the window's records follow, [c_gone, nr) moves behind them and shifts with the text
+            {
+                const int32_t g = (int32_t)(c_before + nf) - (int32_t)c_gone;
+                if ((int64_t)nr + g > (int64_t)kLdsRec) { redo = true; break; }
+                wave_lds_fence();
+                uint32_t s_end = 0, s_pl = 0; int32_t s_prio = 0;
+                if ((uint32_t)lane < nf) { s_end = L.end[nr + lane]; s_prio = L.prio[nr + lane]; s_pl = L.pl[nr + lane]; }
+                wave_lds_fence();
+                ld_move(L.end, c_gone, nr, g, (uint32_t)delta, lane);
+                ld_move(reinterpret_cast<uint32_t*>(L.prio), c_gone, nr, g, 0u, lane);
+                ld_move(L.pl, c_gone, nr, g, 0u, lane);
+                if ((uint32_t)lane < nf) { L.end[c_before + lane] = s_end; L.prio[c_before + lane] = s_prio; L.pl[c_before + lane] = s_pl; }
+                nr = (uint32_t)((int32_t)nr + g);
+                wave_lds_fence();
+            }
+            curlen = newlen;
+        }
+        if (redo) break;
+        if (status == kRpFinished) break;
+        threshold = best;
+    }
+
+    if (redo) {
+        if (lane == 0) a.redo[h] = 1u;                                    // k_rp_loop, launched behind this kernel, runs this haystack from its first scan
+        return;
+    }
+    // the final piece list, in the form k_pt_materialise reads (the haystack's own region of the piece buffer)
+    if ((uint64_t)np + 1u > cap_p) { if (lane == 0) a.redo[h] = 1u; return; }
+    RpPiece* const P = a.pc_buf + pb;
+    for (uint32_t k = (uint32_t)lane; k <= np; k += kWave) {
+        const uint32_t s = L.psrc[k];
+        RpPiece e; e.lstart = k < np ? L.pls[k] : curlen;
+        e.src = k < np ? ((s & kReplBit) ? (kPieceRepl | (uint64_t)(s & ~kReplBit)) : hoff + s) : 0;
+        P[k] = e;
+    }
+    if (lane == 0) {
+        RpLoopOut o;
+        o.len = status == kRpNothing ? 0 : curlen; o.pieces_at = pb; o.n_pieces = np; o.status = status; o.passes = passes; o.pad = 0;
+        a.out[h] = o;
+        atomicMax(a.ctrl + 1, passes);
+        if (scanned) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 2), (unsigned long long)scanned);
+        atomicAdd(a.ctrl + 7, 1u);                                        // haystacks finished here (the rest: k_rp_loop)
+    }
+}
+
+}  // namespace
+
+template <bool IC>
+__global__ void __launch_bounds__(64, 4) k_rp_lds(RpLoop a)
+{
+    __shared__ LpLds L;
+    const uint32_t h = a.h_first + blockIdx.x;
+    ld_run_haystack<IC>(a, L, h, (int)(threadIdx.x & (kWave - 1)));
+}
+
+hipError_t launch_rp_lds(bool ic, const RpLoop& a, uint32_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    if (ic) hipLaunchKernelGGL((k_rp_lds<true>), dim3(n), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((k_rp_lds<false>), dim3(n), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace dev
+}  // namespace am

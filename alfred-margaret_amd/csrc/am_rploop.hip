@@ -564,8 +564,9 @@ template <bool IC, int W, bool DBG = false>
 __global__ void __launch_bounds__(64, W) k_rp_loop(RpLoop a)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const uint32_t h = blockIdx.x;
+    const uint32_t h = a.h_first + blockIdx.x;
     if (h >= a.n_hay) return;
+    if (a.redo && a.redo[h] == 0) return;                                 // k_rp_lds (am_rplds.hip) finished this haystack out of LDS
     lp_run_haystack<IC, DBG>(a, h, lane);
 }
 
@@ -588,12 +589,12 @@ hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32
     return hipGetLastError();
 }
 
-hipError_t launch_rp_loop(bool ic, const RpLoop& a, int waves, hipStream_t st)
+hipError_t launch_rp_loop(bool ic, const RpLoop& a, uint32_t n, int waves, hipStream_t st)
 {
-    if (a.n_hay == 0) return hipSuccess;
+    if (n == 0) return hipSuccess;
     // wavefronts per SIMD the register budget is cut for (AM_RP_LOOP_WAVES, A/B: the exact phase -- sf_verify -- wants ~125 registers, and cfg5 ran
     // at 68.0 GiB/s with 4 wavefronts per SIMD, 61.9 / 64.4 / 56.4 with budgets cut for 5 / 6 / 8: the spills cost more than the wavefronts bring)
-    const dim3 grid(a.n_hay), block(64);
+    const dim3 grid(n), block(64);
     if (ic) { hipLaunchKernelGGL((k_rp_loop<true, 4>), grid, block, 0, st, a); return hipGetLastError(); }
     if (a.pad) { hipLaunchKernelGGL((k_rp_loop<false, 4, true>), grid, block, 0, st, a); return hipGetLastError(); }      // per-phase cycle sums (AM_RP_TRACE >= 3)
     switch (waves) {

@@ -19,6 +19,8 @@ AM_API uint64_t am_debug_pinned_bytes(void);
 /* Cycle sums per k_sf phase / per-wavefront record counts of launches made under AM_SF_ABLATE=9 (tools/phase_timing.py). */
 AM_API int am_debug_sf_phase_cycles(uint64_t* out5);
 AM_API int am_debug_sf_wave_records(uint64_t* out, size_t n_waves);
+/* Haystacks the calling process's last one-kernel Replacer run finished with their lists in LDS (k_rp_lds); the rest took k_rp_loop. */
+AM_API uint32_t am_debug_rp_lds_haystacks(void);
 /* The general AC-walk kernel (k_ac) is test infrastructure and lives in libam_check.so (tests/native/am_ac.hip).  Loading that library
  * hands its launcher to libam through this call; `launcher` is am::dev::launch_ac of a build with the same csrc/am_device.h
  * (image_version must equal am_image_version()), NULL takes it away again.  Without a launcher am_automaton_set_kernel(a, 1) makes every

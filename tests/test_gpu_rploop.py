@@ -10,6 +10,7 @@ from alfred_margaret_amd import synth
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
+LDS_SEEN = []               # haystacks each one-kernel run finished out of LDS (am_debug_rp_lds_haystacks)
 
 
 def _loop_equals_oracle(pairs, hays, max_len=-1, case=0):
@@ -18,14 +19,20 @@ def _loop_equals_oracle(pairs, hays, max_len=-1, case=0):
     ref = r.run_batch(hays, max_len)
     ref_stats = r.last_stats()
     am.debug_set("AM_RP_LOOP", 1)
-    got = r.run_batch(hays, max_len)
+    got = r.run_batch(hays, max_len)                        # k_rp_lds (lists in LDS) + k_rp_loop for the haystacks it gives up
     stats = r.last_stats()
+    LDS_SEEN.append(int(am.libam().am_debug_rp_lds_haystacks()))
+    am.debug_set("AM_RP_LDS", 0)
+    got_global = r.run_batch(hays, max_len)                 # k_rp_loop alone (lists in global memory: round 4's kernel)
+    stats_global = r.last_stats()
+    am.debug_set("AM_RP_LDS", -1)
     am.debug_set("AM_RP_LOOP", -1)
     o = oracle.Replacer(case, pairs)
     exp = [o.run(h, max_len) for h in hays]
     assert got == exp, (case, pairs[:6], max_len)
+    assert got_global == exp, (case, pairs[:6], max_len)
     assert ref == exp
-    assert stats[0] == ref_stats[0], "number of passes"
+    assert stats[0] == ref_stats[0] == stats_global[0], "number of passes"
     return got, stats
 
 
@@ -152,3 +159,11 @@ def test_loop_reach_comes_from_the_automaton_not_from_the_payload_lengths():
     assert ref == exp
     assert got == exp
     assert r.run_batch(hays) == exp                          # the default route (>= 64 documents: the one-kernel loop)
+
+
+def test_the_lds_kernel_is_what_runs():
+    """(after the tests above, same process) the runs of this file went through k_rp_lds for most haystacks -- and not for all: the long lists, the
+    growing ones and the windows with many new records took k_rp_loop, which the same runs compared with AM_RP_LDS=0 as well."""
+    if not LDS_SEEN:
+        pytest.skip("runs on its own: nothing recorded")
+    assert sum(1 for n in LDS_SEEN if n > 0) >= len(LDS_SEEN) // 2, LDS_SEEN
