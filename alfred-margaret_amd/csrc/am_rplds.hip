@@ -4,11 +4,12 @@
 // k_rp_loop (am_rploop.hip, round 4) keeps a haystack's record list and piece list in global memory: every pass re-reads the whole record list,
 // rewrites the piece list, moves half the records -- ~13 dependent trips through L2 per pass (2 000-3 000 cycles each under load) and 16 bytes of HBM
 // traffic per input byte (profiles/r04_pmc_traffic.md).  But the working set of a haystack is small -- a few hundred records, a few hundred pieces --
-// and it lives for ~100 passes: it belongs in LDS.  Here one wavefront (= one workgroup) owns a haystack and 9.6 KiB of LDS:
+// and it lives for ~100 passes: it belongs in LDS.  Here one wavefront (= one workgroup) owns a haystack and 10 KiB of LDS:
 //   records   up to 512, as {end position, priority, payload} (12 B; priority and payload looked up ONCE, when a record enters the list -- the
 //             fold of a pass is three sweeps over LDS, no table look-up)
 //   pieces    up to 448, as {source, logical start} (8 B; sources relative to the haystack / the replacement blob), edited IN PLACE
-// A pass touches global memory for: the selected payload (one uniform load), the window's bytes (one gather), the window's Bloom / probe / resolve
+//   window    the re-scanned stretch of the new text (up to 448 bytes), gathered through the piece list and read back by the verifying lanes
+// A pass touches global memory for: the selected payload (one uniform load), the window's bytes (one gather), the window's probe / resolve
 // look-ups (sf_verify, as k_sf runs it) and the state entries of the records the window adds.  The kept matches of a pass are applied one at a time,
 // from the LAST to the first: replacing one match is a self-contained step on a consistent (text, records) pair -- records ending at or before the match
 // stay, those ending more than `ov` bytes behind it move with the text, those in between are dropped and that stretch of the NEW text is scanned again --
@@ -34,10 +35,12 @@ constexpr uint32_t kLdsRec = 512;                         // records a haystack 
 constexpr uint32_t kLdsBlocks = kLdsRec / kWave;
 constexpr uint32_t kLdsPc = 448;                          // pieces (+ the sentinel)
 constexpr uint32_t kReplBit = 0x80000000u;                // piece source: offset into the replacement blob instead of the haystack
+constexpr uint32_t kLdsWin = 448;                         // bytes of a re-scan window (the replacement and `ov` bytes either side of it); a longer one: k_rp_loop
 
 struct LpLds {
     uint32_t end[kLdsRec]; int32_t prio[kLdsRec]; uint32_t pl[kLdsRec];
     uint32_t psrc[kLdsPc + 2]; uint32_t pls[kLdsPc + 2];
+    alignas(16) uint8_t win[kLdsWin + 16];                // the window's text: gathered through the piece list, read back by the probe / resolve lanes
 };
 
 __device__ __forceinline__ int64_t ld_wave_max_i64(int64_t v)
@@ -92,7 +95,6 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
     const uint64_t rf0 = uniform_u64(a.rec_first0[h]);
     const uint64_t nr0 = uniform_u64(a.rec_first0[h + 1]) - rf0;
     RpKept* const K = a.kept_buf + (rb >> 1);                           // kept matches of a pass that keeps several (cap_r entries)
-    uint8_t* const wt = a.wtext + (uint64_t)h * a.wcap;
     const uint8_t* const htext = a.text + hoff;
     bool redo = len0 >= 0x7FFFF000ull || nr0 > kLdsRec || cap_p < 4;
     uint32_t nr = 0, np = 1, passes = 0, status = kRpFinished;
@@ -306,7 +308,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             if ((uint64_t)hi > newlen) hi = (uint32_t)newlen;
             const uint32_t ws = ms > a.ov ? ms - a.ov : 0u;
             const uint32_t wlen = hi > ms ? hi - ws : 0u, own_lo = ms - ws;
-            if (wlen > a.wcap) { redo = true; break; }
+            if (wlen > kLdsWin) { redo = true; break; }
             uint32_t nf = 0;
             if (wlen) {
                 const uint32_t first = ld_u32(pieces_le(ws)) - 1u;
@@ -314,19 +316,25 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     const uint32_t p = ws + x;
                     uint32_t idx = first;
                     while (idx + 1u < np && L.pls[idx + 1u] <= p) idx++;
-                    wt[x] = (uint8_t)byte_in(idx, p);
+                    L.win[x] = (uint8_t)byte_in(idx, p);
                 }
-                ld_global_sync();
+                wave_lds_fence();
                 scanned += wlen;
                 for (uint32_t base = own_lo; base < wlen && !redo; base += kWave) {
                     if (timed_out(3)) { redo = true; break; }
                     const uint32_t g = base + (uint32_t)lane;
                     bool found = false; uint32_t state = 0, vlen = 0;
                     if (g < wlen) {
-                        uint32_t w, w2;
-                        load_suffix8(wt, g, w, w2);
-                        if (IC) w = fold_dword(w);
-                        if (sf_filter_window(a.s.bloom, a.s.bloom_log2_words, a.s.tiers, w)) found = sf_verify<IC>(a.s, wt, g, (uint64_t)g + 1, state, vlen);
+                        // the probe decides exactly whether a needle of >= 4 bytes may end here (its bucket loads go out for every position of the
+                        // window at once: one trip); the Bloom filter is a trip of its own and only pays when 1-3-byte needles make every position defer
+                        bool look = true;
+                        if (a.s.tiers & 7u) {
+                            uint32_t w, w2;
+                            load_suffix8(L.win, g, w, w2);
+                            if (IC) w = fold_dword(w);
+                            look = sf_filter_window(a.s.bloom, a.s.bloom_log2_words, a.s.tiers, w);
+                        }
+                        if (look) found = sf_verify<IC>(a.s, L.win, g, (uint64_t)g + 1, state, vlen);
                     }
                     // a record enters the list with its priority and payload; one that can never be chosen again does not enter at all
                     RpStateOne one{0, kRpWalkList};
@@ -348,7 +356,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     }
                 }
                 if (redo) break;
-                if (nkept > 1) ld_global_sync();                          // (the scratch is rewritten by the next window)
+                wave_lds_fence();                                         // (the window is rewritten by the next kept match's)
             }
 
             // (d) the record list, in place: [0, c_before) stays, the window's records follow, [c_gone, nr) moves behind them and shifts with the text
