@@ -126,20 +126,18 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         const uint8_t* base = (s & kReplBit) ? a.t.repl + (s & ~kReplBit) : htext + s;
         return base[p - L.pls[idx]];
     };
-    // pieces that start at or before x (uniform x): the index of the piece that holds byte x is this minus one
-    auto pieces_le = [&](uint32_t x) -> uint32_t {
-        uint32_t c = 0;
-        for (uint32_t k0 = 0; k0 < np; k0 += kWave) {
-            const uint32_t k = k0 + (uint32_t)lane;
-            c += (uint32_t)__popcll(__ballot(k < np && L.pls[k] <= x));
-        }
-        return c;
-    };
+    constexpr uint32_t kPcBlocks = (kLdsPc + 1 + kWave - 1) / kWave;      // blocks of 64 piece entries (sentinel included)
+    constexpr int32_t kDead = 0x7FFFFFFF;                                  // priority of a record that is gone: never below a threshold (its slot is reused by the next window's records)
 
     while (!redo) {
         passes++;
         if (timed_out(1)) { redo = true; break; }
-        // ---- prependMatch, first half (Replacer.hs:255-258): the best priority below the threshold -- one sweep over LDS
+        // ---- the record list, ONE batch of LDS reads (24 in flight, one wait): lane l holds records l, 64 + l, ... for the fold, the overlap removal and
+        // the counts of the first replacement; nothing below reads a record from LDS again unless a pass keeps several matches
+        uint32_t e_[kLdsBlocks], l_[kLdsBlocks]; int32_t p_[kLdsBlocks];
+#pragma unroll
+        for (uint32_t b = 0; b < kLdsBlocks; b++) { const uint32_t r = b * kWave + (uint32_t)lane; e_[b] = L.end[r]; p_[b] = L.prio[r]; l_[b] = L.pl[r]; }
+        // ---- prependMatch, first half (Replacer.hs:255-258): the best priority below the threshold
         int64_t best = INT64_MIN;
         auto best_of_list = [&](uint32_t st) {
             for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
@@ -149,13 +147,10 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         };
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) {
-            if (b * kWave < nr) {
-                const uint32_t r = b * kWave + (uint32_t)lane;
-                if (r < nr) {
-                    const int32_t pr = L.prio[r];
-                    if (L.pl[r] != kRpWalkList) { if ((int64_t)pr < threshold && (int64_t)pr > best) best = pr; }
-                    else best_of_list((uint32_t)pr);
-                }
+            const uint32_t r = b * kWave + (uint32_t)lane;
+            if (r < nr) {
+                if (l_[b] != kRpWalkList) { if ((int64_t)p_[b] < threshold && (int64_t)p_[b] > best) best = p_[b]; }
+                else best_of_list((uint32_t)p_[b]);
             }
         }
         best = (int64_t)uniform_u64((uint64_t)ld_wave_max_i64(best));
@@ -166,24 +161,20 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         uint32_t payload = 0;
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) {
-            selmask[b] = 0;
-            if (b * kWave < nr) {
-                const uint32_t r = b * kWave + (uint32_t)lane;
-                bool sel = false; uint32_t plv = 0;
-                if (r < nr) {
-                    const uint32_t pl = L.pl[r];
-                    if (pl != kRpWalkList) { if ((int64_t)L.prio[r] == best) { sel = true; plv = pl; } }
-                    else {
-                        const uint32_t st = (uint32_t)L.prio[r];
-                        for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
-                            const uint32_t v = a.t.vals[k];
-                            if (a.t.payloads[v].priority == best) { sel = true; plv = v; }
-                        }
+            const uint32_t r = b * kWave + (uint32_t)lane;
+            bool sel = false; uint32_t plv = 0;
+            if (r < nr) {
+                if (l_[b] != kRpWalkList) { if ((int64_t)p_[b] == best) { sel = true; plv = l_[b]; } }
+                else {
+                    const uint32_t st = (uint32_t)p_[b];
+                    for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+                        const uint32_t v = a.t.vals[k];
+                        if (a.t.payloads[v].priority == best) { sel = true; plv = v; }
                     }
                 }
-                selmask[b] = __ballot(sel);
-                if (sel && plv > payload) payload = plv;
             }
+            selmask[b] = __ballot(sel);
+            if (sel && plv > payload) payload = plv;
         }
         payload = ld_u32((uint32_t)ld_wave_max_i64((int64_t)payload));
         RpPayload pp = a.t.payloads[payload];                             // uniform index: one load for the pass
@@ -198,9 +189,8 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) {
             if (selmask[b] == 0) continue;                                // (uniform)
-            const uint32_t r = b * kWave + (uint32_t)lane;
             const bool sel = (selmask[b] >> lane) & 1ull;
-            const uint64_t end_pos = sel ? L.end[r] : 0;
+            const uint64_t end_pos = sel ? e_[b] : 0;
             uint64_t len = m_len, start = end_pos - m_len;                // CaseSensitive (:266-267)
             if (IC && sel) {                                             // IgnoreCase: as long as its code points are in the haystack (skipCodePointsBackwards, Utf8.hs:256-276)
                 if (m_cps == 0) start = end_pos;
@@ -243,11 +233,12 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     const int l = __ffsll((unsigned long long)keepmask) - 1;
                     k0_start = uniform_u64(__shfl(start, l, kWave)); k0_len = uniform_u64(__shfl(len, l, kWave));
                 }
-                if (keep) {
+                if (nkept + nk > 1u && keep) {                           // several: the list goes through the haystack's kept region (global memory)
                     const uint32_t rank = (uint32_t)__popcll(keepmask & ((1ull << lane) - 1ull));
                     RpKept e; e.src_start = start; e.src_len = len; e.dst = 0;
                     K[nkept + rank] = e;
                 }
+                if (nkept == 1u && lane == 0) { RpKept e; e.src_start = k0_start; e.src_len = k0_len; e.dst = 0; K[0] = e; }      // (the one held in registers joins it)
                 nkept += nk;
             }
         }
@@ -267,18 +258,74 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             const int32_t delta = (int32_t)rl - (int32_t)ml64;
             const uint64_t newlen = (uint64_t)((int64_t)curlen + delta);
             if (newlen >= 0x7FFFF000ull) { redo = true; break; }
+            const bool last_pass = status == kRpFinished;                 // (:241) nobody looks at the records again: the piece list alone is edited
+            uint32_t hi = ms + rl + a.ov;                                 // the window of the replacement in the new text: [ws, hi), its own positions from ms on
+            if ((uint64_t)hi > newlen) hi = (uint32_t)newlen;
+            const uint32_t ws = ms > a.ov ? ms - a.ov : 0u;
+            const uint32_t wlen = hi > ms ? hi - ws : 0u, own_lo = ms - ws;
+            if (wlen > kLdsWin) { redo = true; break; }
 
-            // (a) the piece list, in place: pieces i .. j2 hold the match; what is left of them is a head, the replacement, a tail
-            const uint32_t i = ld_u32(pieces_le(ms)) - 1u;                // (>= 0: piece 0 starts at 0)
-            const uint32_t j2 = ld_u32(pieces_le(me - 1u)) - 1u;          // the match is not empty here (automata with the empty needle do not take this route)
+            // (b) old records: [0, c_before) end at or before the match's start and stay; [c_before, c_gone) end within reach of its end and are gone --
+            // their slots are marked dead where they are (the window's records go there); the rest shift with the text.  From the registers of the pass's
+            // batch read for the first replacement; a pass that keeps several matches reads the ends again.
+            uint32_t c_before = 0, c_gone = 0;
+            if (!last_pass) {
+                if (jj + 1u != nkept) {
+#pragma unroll
+                    for (uint32_t b = 0; b < kLdsBlocks; b++) e_[b] = L.end[b * kWave + (uint32_t)lane];
+                }
+                const uint32_t x2 = me + a.ov;
+#pragma unroll
+                for (uint32_t b = 0; b < kLdsBlocks; b++) {
+                    const uint32_t r = b * kWave + (uint32_t)lane;
+                    const uint32_t e = r < nr ? e_[b] : 0xFFFFFFFFu;
+                    c_before += (uint32_t)__popcll(__ballot(e <= ms));
+                    c_gone += (uint32_t)__popcll(__ballot(e <= x2));
+                }
+#pragma unroll
+                for (uint32_t b = 0; b < kLdsBlocks; b++) {
+                    const uint32_t r = b * kWave + (uint32_t)lane;
+                    if (r >= c_before && r < c_gone) { L.end[r] = hi; L.prio[r] = kDead; L.pl[r] = 0u; }      // (end = the window's upper bound: the list stays sorted)
+                    else if (r >= c_gone && r < nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
+                }
+            }
+
+            // (a) the piece list, in place: pieces i .. j2 hold the match; what is left of them is a head, the replacement, a tail.  One batch of reads
+            // answers "which piece holds byte x" for the match's first and last byte and for the window's first byte.
+            uint32_t c_ms = 0, c_me = 0, c_ws = 0;
+            {
+                uint32_t v[kPcBlocks];
+#pragma unroll
+                for (uint32_t b = 0; b < kPcBlocks; b++) { const uint32_t k = b * kWave + (uint32_t)lane; v[b] = L.pls[k < kLdsPc + 2u ? k : 0u]; }
+#pragma unroll
+                for (uint32_t b = 0; b < kPcBlocks; b++) {
+                    const uint32_t k = b * kWave + (uint32_t)lane;
+                    const bool in = k < np;
+                    c_ms += (uint32_t)__popcll(__ballot(in && v[b] <= ms));
+                    c_me += (uint32_t)__popcll(__ballot(in && v[b] <= me - 1u));      // the match is not empty here (automata with the empty needle do not take this route)
+                    c_ws += (uint32_t)__popcll(__ballot(in && v[b] <= ws));
+                }
+            }
+            const uint32_t i = c_ms - 1u, j2 = c_me - 1u, first = c_ws - 1u;     // (>= 0: piece 0 starts at 0; first <= i: ws <= ms)
             const uint32_t pi_ls = ld_u32(L.pls[i]);
             const uint32_t pj_ls = ld_u32(L.pls[j2]), pj_src = ld_u32(L.psrc[j2]), pj_le = ld_u32(L.pls[j2 + 1]);
             const uint32_t keep_head = ms > pi_ls ? 1u : 0u, has_repl = rl ? 1u : 0u, has_tail = me < pj_le ? 1u : 0u;
             const int32_t s = (int32_t)(keep_head + has_repl + has_tail) - (int32_t)(j2 - i + 1u);
             if ((int64_t)np + s + 1 > (int64_t)kLdsPc) { redo = true; break; }
             wave_lds_fence();
-            ld_move(L.psrc, j2 + 1u, np + 1u, s, 0u, lane);
-            ld_move(L.pls, j2 + 1u, np + 1u, s, (uint32_t)delta, lane);      // (the sentinel moves too: the new length)
+            if (s != 0 || delta != 0) {                                   // entries j2 + 1 .. np (the sentinel: the new length) move by s and shift with the text; both arrays per trip
+                const uint32_t from = j2 + 1u, to = np + 1u;
+                const uint32_t nb = (to - from + kWave - 1) / kWave;
+                for (uint32_t b = 0; b < nb; b++) {
+                    const uint32_t blk = s > 0 ? nb - 1 - b : b;
+                    const uint32_t k = from + blk * kWave + (uint32_t)lane;
+                    uint32_t x = 0, y = 0;
+                    if (k < to) { x = L.psrc[k]; y = L.pls[k]; }
+                    wave_lds_fence();
+                    if (k < to) { L.psrc[(uint32_t)((int32_t)k + s)] = x; L.pls[(uint32_t)((int32_t)k + s)] = y + (uint32_t)delta; }
+                    wave_lds_fence();
+                }
+            }
             if (lane == 0) {
                 uint32_t at = i + keep_head;
                 if (has_repl) { L.psrc[at] = kReplBit | (uint32_t)repl_off; L.pls[at] = ms; at++; }
@@ -286,37 +333,35 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             }
             np = (uint32_t)((int32_t)np + s);
             wave_lds_fence();
-            if (status == kRpFinished) { curlen = newlen; continue; }      // the last pass (:241): nobody looks at the records again
+            if (last_pass) { curlen = newlen; continue; }
 
-            // (b) old records: those that end at or before the match's start stay, those within reach of its end go
-            uint32_t c_before = 0, c_gone = 0;
-            {
-                const uint32_t x2 = me + a.ov;
-#pragma unroll
-                for (uint32_t b = 0; b < kLdsBlocks; b++) {
-                    if (b * kWave < nr) {
-                        const uint32_t r = b * kWave + (uint32_t)lane;
-                        const uint32_t e = r < nr ? L.end[r] : 0xFFFFFFFFu;
-                        c_before += (uint32_t)__popcll(__ballot(e <= ms));
-                        c_gone += (uint32_t)__popcll(__ballot(e <= x2));
-                    }
-                }
-            }
-
-            // (c) the window of the replacement in the new text: gather its bytes through the piece list, scan its own positions
-            uint32_t hi = ms + rl + a.ov;
-            if ((uint64_t)hi > newlen) hi = (uint32_t)newlen;
-            const uint32_t ws = ms > a.ov ? ms - a.ov : 0u;
-            const uint32_t wlen = hi > ms ? hi - ws : 0u, own_lo = ms - ws;
-            if (wlen > kLdsWin) { redo = true; break; }
+            // (c) gather the window's bytes through the piece list, scan its own positions
             uint32_t nf = 0;
             if (wlen) {
-                const uint32_t first = ld_u32(pieces_le(ws)) - 1u;
-                for (uint32_t x = (uint32_t)lane; x < wlen; x += kWave) {
-                    const uint32_t p = ws + x;
-                    uint32_t idx = first;
-                    while (idx + 1u < np && L.pls[idx + 1u] <= p) idx++;
-                    L.win[x] = (uint8_t)byte_in(idx, p);
+                {
+                    // the six entries from the piece that holds the window's first byte, in scalar registers (one batch of broadcast reads): a window usually
+                    // lies in three or four pieces (text, replacement, text); a lane that needs a later one walks the list
+                    uint32_t ls[6], sr[6];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { const uint32_t k = first + (uint32_t)q <= np ? first + (uint32_t)q : np; ls[q] = L.pls[k]; sr[q] = L.psrc[k]; }
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { ls[q] = ld_u32(ls[q]); sr[q] = ld_u32(sr[q]); }
+                    const bool all_here = first + 5u >= np || ls[5] >= ws + wlen;      // the window ends inside the five pieces
+                    for (uint32_t x = (uint32_t)lane; x < wlen; x += kWave) {
+                        const uint32_t p = ws + x;
+                        uint32_t pls = ls[0], psr = sr[0];
+                        if (p >= ls[1] && first + 1u < np) { pls = ls[1]; psr = sr[1]; }
+                        if (p >= ls[2] && first + 2u < np) { pls = ls[2]; psr = sr[2]; }
+                        if (p >= ls[3] && first + 3u < np) { pls = ls[3]; psr = sr[3]; }
+                        if (p >= ls[4] && first + 4u < np) { pls = ls[4]; psr = sr[4]; }
+                        if (!all_here && p >= ls[5]) {
+                            uint32_t idx = first + 5u;
+                            while (idx + 1u < np && L.pls[idx + 1u] <= p) idx++;
+                            pls = L.pls[idx]; psr = L.psrc[idx];
+                        }
+                        const uint8_t* base = (psr & kReplBit) ? a.t.repl + (psr & ~kReplBit) : htext + psr;
+                        L.win[x] = base[p - pls];
+                    }
                 }
                 wave_lds_fence();
                 scanned += wlen;
@@ -346,7 +391,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     const uint32_t nfb = (uint32_t)__popcll(fm);
                     if (nfb) {
                         if (nf + nfb > (uint32_t)kWave || nr + nf + nfb > kLdsRec) { redo = true; break; }
-                        if (found) {                                     // staged behind the list; they move into the gap below
+                        if (found) {                                     // staged behind the list; they move into the dead slots below
                             const uint32_t at = nr + nf + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
                             L.end[at] = ws + g + 1u;
                             L.prio[at] = one.payload != kRpWalkList ? one.priority : (int32_t)state;
@@ -359,19 +404,21 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                 wave_lds_fence();                                         // (the window is rewritten by the next kept match's)
             }
 
-            // (d) the record list, in place: [0, c_before) stays, the window's records follow, [c_gone, nr) moves behind them and shifts with the text
-            {
-                const int32_t g = (int32_t)(c_before + nf) - (int32_t)c_gone;
-                if ((int64_t)nr + g > (int64_t)kLdsRec) { redo = true; break; }
-                wave_lds_fence();
+            // (d) the window's records (rarely any) go where the dead ones lie: [c_before, c_before + nf); more of them than slots: the rest of the list moves up
+            if (nf) {
+                const uint32_t room = c_gone - c_before;
                 uint32_t s_end = 0, s_pl = 0; int32_t s_prio = 0;
                 if ((uint32_t)lane < nf) { s_end = L.end[nr + lane]; s_prio = L.prio[nr + lane]; s_pl = L.pl[nr + lane]; }
                 wave_lds_fence();
-                ld_move(L.end, c_gone, nr, g, (uint32_t)delta, lane);
-                ld_move(reinterpret_cast<uint32_t*>(L.prio), c_gone, nr, g, 0u, lane);
-                ld_move(L.pl, c_gone, nr, g, 0u, lane);
+                if (nf > room) {
+                    const int32_t g = (int32_t)(nf - room);
+                    if ((int64_t)nr + g > (int64_t)kLdsRec) { redo = true; break; }
+                    ld_move(L.end, c_gone, nr, g, 0u, lane);
+                    ld_move(reinterpret_cast<uint32_t*>(L.prio), c_gone, nr, g, 0u, lane);
+                    ld_move(L.pl, c_gone, nr, g, 0u, lane);
+                    nr = (uint32_t)((int32_t)nr + g);
+                }
                 if ((uint32_t)lane < nf) { L.end[c_before + lane] = s_end; L.prio[c_before + lane] = s_prio; L.pl[c_before + lane] = s_pl; }
-                nr = (uint32_t)((int32_t)nr + g);
                 wave_lds_fence();
             }
             curlen = newlen;
