@@ -959,7 +959,7 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     // k_rp_lds first: a haystack's lists in LDS for all its passes (am_rplds.hip); what does not fit there raises its redo flag and k_rp_loop, launched
     // right behind, runs exactly those haystacks (lists in global memory).  AM_RP_LDS=0 (A/B, tests), the instrumented instantiation and replacement
     // blobs beyond 2 GiB (piece sources are 31-bit offsets in LDS): k_rp_loop alone.
-    const bool use_lds = cfg::get(cfg::kRpLds) != 0 && !a.pad && r->n_repl_bytes < (1ull << 31);
+    const bool use_lds = cfg::get(cfg::kRpLds) != 0 && r->n_repl_bytes < (1ull << 31);
     a.redo = nullptr; a.h_first = 0;
     if (use_lds) {
         AM_TRY(s.lp_redo.ensure((size_t)n_hay * 4 + 64));
@@ -972,7 +972,14 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, n_hay, (int)cfg::get(cfg::kRpLoopWaves), st)); }
     say("launched");
     // what every haystack ended as
-    if (a.pad) {
+    if (a.pad && use_lds) {
+        uint64_t ph[10];
+        HIP_TRY(hipMemcpy(ph, (const uint8_t*)s.lp_ctrl.p + 32, 80, hipMemcpyDeviceToHost));
+        static const char* const names[9] = {"records in + fold", "select + payload", "overlap removal", "counts + dead slots", "piece list", "gather", "window scan", "inserts", "whole run"};
+        for (int i = 0; i < 9; i++) std::fprintf(stderr, "[am_replacer lds] %-22s %14llu cycles = %5.1f %% of the wavefronts' time, %8.0f per pass\n", names[i], (unsigned long long)ph[i],
+                                                 100.0 * (double)ph[i] / (double)(ph[8] ? ph[8] : 1), (double)ph[i] / (double)(ph[9] ? ph[9] : 1));
+        std::fprintf(stderr, "[am_replacer lds] passes of all haystacks: %llu\n", (unsigned long long)ph[9]);
+    } else if (a.pad) {
         uint64_t ph[8];
         HIP_TRY(hipMemcpy(ph, (const uint8_t*)s.lp_ctrl.p + 32, 64, hipMemcpyDeviceToHost));
         static const char* const names[7] = {"fold 1 (best priority)", "fold 2 (select, overlaps)", "pieces", "record copies + searches", "gather", "window scan", "whole run"};

@@ -55,6 +55,17 @@ __device__ __forceinline__ int64_t ld_wave_sum_i64(int64_t v)
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
     return v;
 }
+// maximum over the 64 lanes with DPP (the shape of am_wave.h's prefix sum: inside each row of 16, then across the rows); uniform result
+__device__ __forceinline__ int32_t ld_wave_max_i32(int32_t x)
+{
+    x = [&] { const int32_t o = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x111, 0xf, 0xf, false); return o > x ? o : x; }();      // row_shr:1
+    x = [&] { const int32_t o = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x112, 0xf, 0xf, false); return o > x ? o : x; }();      // row_shr:2
+    x = [&] { const int32_t o = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x114, 0xf, 0xf, false); return o > x ? o : x; }();      // row_shr:4
+    x = [&] { const int32_t o = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x118, 0xf, 0xf, false); return o > x ? o : x; }();      // row_shr:8
+    x = [&] { const int32_t o = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x142, 0xa, 0xf, false); return o > x ? o : x; }();      // row_bcast:15 -> rows 1, 3
+    x = [&] { const int32_t o = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x143, 0xc, 0xf, false); return o > x ? o : x; }();      // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(x, 63);
+}
 __device__ __forceinline__ uint32_t ld_u32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
 // what the lanes of this wavefront wrote to GLOBAL memory is visible to its other lanes (the window scratch, the kept list)
@@ -84,10 +95,15 @@ __device__ __forceinline__ void ld_move(uint32_t* A, uint32_t from, uint32_t to,
 
 constexpr uint64_t kLdMaxTicks = 4000000000ull;           // watchdog, as in k_rp_loop: ~2 s for ONE haystack, then the redo flag
 
-template <bool IC>
+// DBG (AM_RP_TRACE >= 3): s_memtime per phase of every pass, summed over all haystacks into ctrl[8..27] (64-bit: records in + fold, select + payload, overlap removal,
+// counts + dead slots, piece list, gather, window scan, inserts, the whole run, passes)
+template <bool IC, bool DBG>
 __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const uint32_t h, const int lane)
 {
     const uint64_t deadline = __builtin_amdgcn_s_memtime() + kLdMaxTicks;
+    uint64_t t_mark = DBG ? __builtin_amdgcn_s_memtime() : 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t t_begin = t_mark;
+    auto tick = [&](int ph) { if (DBG) { __builtin_amdgcn_s_waitcnt(0); const uint64_t now = __builtin_amdgcn_s_memtime(); t_ph[ph] += now - t_mark; t_mark = now; } };
     const uint64_t hoff = uniform_u64(a.offsets[h]);
     const uint64_t len0 = uniform_u64(a.offsets[h + 1]) - hoff;
     const uint64_t rb = uniform_u64(a.rec_base[h]), cap_r = (uniform_u64(a.rec_base[h + 1]) - rb) >> 1;
@@ -106,17 +122,30 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         return true;
     };
 
+    constexpr uint32_t kPcBlocks = (kLdsPc + 1 + kWave - 1) / kWave;      // blocks of 64 piece entries (sentinel included)
+    constexpr int32_t kDead = 0x7FFFFFFF;                                  // priority of a record that is gone: never below a threshold (its slot is reused by the next window's records)
+    constexpr uint32_t kNoPos = 0xFFFFFFFFu;
+    // Invariants that keep the sweeps below free of bounds tests: record slots from nr on hold {end = kNoPos, priority = kDead}, piece slots behind
+    // the sentinel (index np: the text's length) hold start = kNoPos.
+    bool has_walk = false;                                               // some record's state carries several values (its list is walked: the slow side of the fold)
     if (!redo) {
         // ---- the first scan's records of this haystack enter the LDS lists with their priority and payload
         nr = (uint32_t)nr0;
-        for (uint32_t r = (uint32_t)lane; r < nr; r += kWave) {
-            const Record rec = a.recs0[rf0 + r];
-            const RpStateOne one = a.t.one[rec.state];
-            L.end[r] = (uint32_t)rec.end_pos;
-            L.prio[r] = one.payload != kRpWalkList ? one.priority : (int32_t)rec.state;      // several values: the state, its list is walked
-            L.pl[r] = one.payload;
+#pragma unroll
+        for (uint32_t b = 0; b < kLdsBlocks; b++) {
+            const uint32_t r = b * kWave + (uint32_t)lane;
+            uint32_t e = kNoPos, pl = 0; int32_t pr = kDead;
+            if (r < nr) {
+                const Record rec = a.recs0[rf0 + r];
+                const RpStateOne one = a.t.one[rec.state];
+                e = (uint32_t)rec.end_pos; pl = one.payload;
+                pr = one.payload != kRpWalkList ? one.priority : (int32_t)rec.state;      // several values: the state (> 0, never below a threshold), its list is walked
+            }
+            L.end[r] = e; L.prio[r] = pr; L.pl[r] = pl;
+            has_walk = has_walk || __ballot(pl == kRpWalkList) != 0ull;
         }
-        if (lane == 0) { L.psrc[0] = 0; L.pls[0] = 0; L.pls[1] = (uint32_t)len0; }
+#pragma unroll
+        for (uint32_t b = 0; b < kPcBlocks; b++) { const uint32_t k = b * kWave + (uint32_t)lane; if (k < kLdsPc + 2u) { L.pls[k] = k == 0 ? 0u : k == 1 ? (uint32_t)len0 : kNoPos; L.psrc[k] = 0; } }
         wave_lds_fence();
     }
 
@@ -126,8 +155,6 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         const uint8_t* base = (s & kReplBit) ? a.t.repl + (s & ~kReplBit) : htext + s;
         return base[p - L.pls[idx]];
     };
-    constexpr uint32_t kPcBlocks = (kLdsPc + 1 + kWave - 1) / kWave;      // blocks of 64 piece entries (sentinel included)
-    constexpr int32_t kDead = 0x7FFFFFFF;                                  // priority of a record that is gone: never below a threshold (its slot is reused by the next window's records)
 
     while (!redo) {
         passes++;
@@ -137,84 +164,100 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         uint32_t e_[kLdsBlocks], l_[kLdsBlocks]; int32_t p_[kLdsBlocks];
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) { const uint32_t r = b * kWave + (uint32_t)lane; e_[b] = L.end[r]; p_[b] = L.prio[r]; l_[b] = L.pl[r]; }
-        // ---- prependMatch, first half (Replacer.hs:255-258): the best priority below the threshold
-        int64_t best = INT64_MIN;
-        auto best_of_list = [&](uint32_t st) {
-            for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
-                const int64_t p = a.t.payloads[a.t.vals[k]].priority;
-                if (p < threshold && p > best) best = p;
-            }
-        };
+        // ---- prependMatch, first half (Replacer.hs:255-258): the best priority below the threshold.  Priorities of single-valued states are 32-bit and
+        // <= 0, dead and unused slots hold kDead, states with several values hold their (positive) state id: one compare + select + max per block
+        const int32_t thr32 = threshold < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)threshold;      // (threshold <= 1)
+        int32_t b32 = INT32_MIN;
 #pragma unroll
-        for (uint32_t b = 0; b < kLdsBlocks; b++) {
-            const uint32_t r = b * kWave + (uint32_t)lane;
-            if (r < nr) {
-                if (l_[b] != kRpWalkList) { if ((int64_t)p_[b] < threshold && (int64_t)p_[b] > best) best = p_[b]; }
-                else best_of_list((uint32_t)p_[b]);
+        for (uint32_t b = 0; b < kLdsBlocks; b++) { const int32_t v = p_[b] < thr32 ? p_[b] : INT32_MIN; b32 = v > b32 ? v : b32; }
+        b32 = ld_wave_max_i32(b32);
+        int64_t best = b32 == INT32_MIN ? INT64_MIN : (int64_t)b32;
+        if (has_walk) {                                                  // ... and the value lists of the states that carry several
+            int64_t bw = INT64_MIN;
+#pragma unroll
+            for (uint32_t b = 0; b < kLdsBlocks; b++) {
+                if (l_[b] == kRpWalkList && p_[b] != kDead) {
+                    const uint32_t st = (uint32_t)p_[b];
+                    for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
+                        const int64_t p = a.t.payloads[a.t.vals[k]].priority;
+                        if (p < threshold && p > bw) bw = p;
+                    }
+                }
             }
+            bw = (int64_t)uniform_u64((uint64_t)ld_wave_max_i64(bw));
+            if (bw > best) best = bw;
         }
-        best = (int64_t)uniform_u64((uint64_t)ld_wave_max_i64(best));
+        tick(0);
         if (best == INT64_MIN) { status = kRpFinished; break; }           // no match below the threshold: the text stays (:228-230)
 
         // ---- which records carry it: priorities are distinct, so every one of them has the same payload
         uint64_t selmask[kLdsBlocks];
         uint32_t payload = 0;
+        const bool fast_sel = best >= (int64_t)INT32_MIN + 1 && best <= 0;
+        const int32_t best32 = fast_sel ? (int32_t)best : kDead - 1;      // (no slot holds kDead - 1)
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) {
-            const uint32_t r = b * kWave + (uint32_t)lane;
-            bool sel = false; uint32_t plv = 0;
-            if (r < nr) {
-                if (l_[b] != kRpWalkList) { if ((int64_t)p_[b] == best) { sel = true; plv = l_[b]; } }
-                else {
+            selmask[b] = __ballot(p_[b] == best32);
+            if (selmask[b]) payload = (uint32_t)__builtin_amdgcn_readlane((int)l_[b], __ffsll((unsigned long long)selmask[b]) - 1);
+        }
+        if (has_walk) {
+            uint32_t pw = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < kLdsBlocks; b++) {
+                bool sel = false;
+                if (l_[b] == kRpWalkList && p_[b] != kDead) {
                     const uint32_t st = (uint32_t)p_[b];
                     for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
                         const uint32_t v = a.t.vals[k];
-                        if (a.t.payloads[v].priority == best) { sel = true; plv = v; }
+                        if (a.t.payloads[v].priority == best) { sel = true; pw = v; }
                     }
                 }
+                selmask[b] |= __ballot(sel);
             }
-            selmask[b] = __ballot(sel);
-            if (sel && plv > payload) payload = plv;
+            pw = ld_u32((uint32_t)ld_wave_max_i64((int64_t)pw));
+            if (pw > payload) payload = pw;
         }
-        payload = ld_u32((uint32_t)ld_wave_max_i64((int64_t)payload));
         RpPayload pp = a.t.payloads[payload];                             // uniform index: one load for the pass
-        const uint64_t m_len = uniform_u64((uint64_t)pp.len_bytes);
-        const uint32_t m_cps = ld_u32(pp.len_code_points), rl = ld_u32(pp.repl_len);
-        const uint64_t repl_off = uniform_u64(pp.repl_off);
+        const uint32_t m_len = ld_u32(pp.len_bytes), m_cps = ld_u32(pp.len_code_points), rl = ld_u32(pp.repl_len);
+        const uint32_t repl_off = ld_u32((uint32_t)pp.repl_off);
+        tick(1);
 
-        // ---- makeMatch (:264-274) + removeOverlap (:191-198): 64 records at a time, in position order
-        int64_t delta_all = 0;
-        uint64_t last_end = 0, k0_start = 0, k0_len = 0;
-        uint32_t nkept = 0;
+        // ---- makeMatch (:264-274) + removeOverlap (:191-198): 64 records at a time, in position order (positions are 32-bit here)
+        int32_t delta_sum = 0;                                           // IgnoreCase: the sum of (replacement - match) over this lane's selected records
+        uint32_t n_sel = 0;
+        uint32_t last_end = 0, k0_start = 0, k0_len = 0, nkept = 0;
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) {
             if (selmask[b] == 0) continue;                                // (uniform)
+            n_sel += (uint32_t)__popcll(selmask[b]);
             const bool sel = (selmask[b] >> lane) & 1ull;
-            const uint64_t end_pos = sel ? e_[b] : 0;
-            uint64_t len = m_len, start = end_pos - m_len;                // CaseSensitive (:266-267)
-            if (IC && sel) {                                             // IgnoreCase: as long as its code points are in the haystack (skipCodePointsBackwards, Utf8.hs:256-276)
-                if (m_cps == 0) start = end_pos;
-                else {
-                    uint32_t lo = 0, hi = np;                            // last piece that starts at or before the match's last byte
-                    const uint32_t index = (uint32_t)end_pos - 1u;
-                    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.pls[mid] <= index) lo = mid; else hi = mid; }
-                    uint32_t pi = lo;
-                    int64_t i = (int64_t)index; uint32_t n = m_cps - 1u;
-                    for (;;) {
+            const uint32_t end_pos = sel ? e_[b] : 0u;
+            uint32_t len = m_len, start = end_pos - m_len;                // CaseSensitive (:266-267)
+            if (IC) {
+                if (sel) {                                               // IgnoreCase: as long as its code points are in the haystack (skipCodePointsBackwards, Utf8.hs:256-276)
+                    if (m_cps == 0) start = end_pos;
+                    else {
+                        uint32_t lo = 0, hi = np;                        // last piece that starts at or before the match's last byte
+                        const uint32_t index = end_pos - 1u;
+                        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.pls[mid] <= index) lo = mid; else hi = mid; }
+                        uint32_t pi = lo;
+                        int64_t i = (int64_t)index; uint32_t n = m_cps - 1u;
                         for (;;) {
-                            if (i <= 0) break;
-                            while ((uint32_t)i < L.pls[pi]) pi--;         // (pieces may be empty: a loop)
-                            if ((byte_in(pi, (uint32_t)i) & 0xC0u) != 0x80u) break;      // atTrailingByte
-                            i--;
+                            for (;;) {
+                                if (i <= 0) break;
+                                while ((uint32_t)i < L.pls[pi]) pi--;     // (pieces may be empty: a loop)
+                                if ((byte_in(pi, (uint32_t)i) & 0xC0u) != 0x80u) break;      // atTrailingByte
+                                i--;
+                            }
+                            if (n == 0 || i <= 0) break;
+                            i--; n--;
                         }
-                        if (n == 0 || i <= 0) break;
-                        i--; n--;
+                        start = (uint32_t)(i < 0 ? 0 : i);
                     }
-                    start = (uint64_t)(i < 0 ? 0 : i);
+                    len = end_pos - start;
+                    delta_sum += (int32_t)rl - (int32_t)len;
                 }
-                len = end_pos - start;
             }
-            if (sel) delta_all += (int64_t)rl - (int64_t)len;
             uint64_t pending = selmask[b];
             bool keep = false;
             while (pending) {
@@ -222,7 +265,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                 if (!ok) break;
                 const int l = __ffsll((unsigned long long)ok) - 1;
                 if (lane == l) keep = true;
-                last_end = uniform_u64(__shfl(start + len, l, kWave));
+                last_end = (uint32_t)__builtin_amdgcn_readlane((int)(start + len), l);
                 pending &= l == 63 ? 0ull : ~((2ull << l) - 1ull);
             }
             const uint64_t keepmask = __ballot(keep);
@@ -231,7 +274,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                 if ((uint64_t)nkept + nk > cap_r) { redo = true; break; }
                 if (nkept == 0) {                                        // the first kept match stays in scalar registers (a pass usually keeps one)
                     const int l = __ffsll((unsigned long long)keepmask) - 1;
-                    k0_start = uniform_u64(__shfl(start, l, kWave)); k0_len = uniform_u64(__shfl(len, l, kWave));
+                    k0_start = (uint32_t)__builtin_amdgcn_readlane((int)start, l); k0_len = (uint32_t)__builtin_amdgcn_readlane((int)len, l);
                 }
                 if (nkept + nk > 1u && keep) {                           // several: the list goes through the haystack's kept region (global memory)
                     const uint32_t rank = (uint32_t)__popcll(keepmask & ((1ull << lane) - 1ull));
@@ -243,19 +286,21 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             }
         }
         if (redo) break;
-        delta_all = (int64_t)uniform_u64((uint64_t)ld_wave_sum_i64(delta_all));
-        const int64_t newlen_all = (int64_t)curlen + delta_all;           // replacementLength over ALL matches (:240), before removeOverlap
+        int64_t delta_all = (int64_t)n_sel * ((int64_t)rl - (int64_t)m_len);      // replacementLength over ALL matches (:240), before removeOverlap
+        if (IC) delta_all = (int64_t)uniform_u64((uint64_t)ld_wave_sum_i64((int64_t)delta_sum));
+        const int64_t newlen_all = (int64_t)curlen + delta_all;
         if (newlen_all > 0 && (uint64_t)newlen_all > a.max_len) { status = kRpNothing; break; }
         status = best == a.t.min_priority ? kRpFinished : kRpActive;    // :241-242
         if (nkept > 1) ld_global_sync();                                  // K is read back below
+        tick(2);
 
         // ---- replace (:163-180), one kept match at a time, the last one first
         for (uint32_t jj = nkept; jj-- > 0 && !redo;) {
             if (timed_out(2)) { redo = true; break; }
-            uint64_t ms64 = k0_start, ml64 = k0_len;
-            if (nkept > 1) { const RpKept k = K[jj]; ms64 = uniform_u64(k.src_start); ml64 = uniform_u64(k.src_len); }
-            const uint32_t ms = (uint32_t)ms64, me = (uint32_t)(ms64 + ml64);
-            const int32_t delta = (int32_t)rl - (int32_t)ml64;
+            uint32_t ms = k0_start, ml = k0_len;
+            if (nkept > 1) { const RpKept k = K[jj]; ms = ld_u32((uint32_t)k.src_start); ml = ld_u32((uint32_t)k.src_len); }
+            const uint32_t me = ms + ml;
+            const int32_t delta = (int32_t)rl - (int32_t)ml;
             const uint64_t newlen = (uint64_t)((int64_t)curlen + delta);
             if (newlen >= 0x7FFFF000ull) { redo = true; break; }
             const bool last_pass = status == kRpFinished;                 // (:241) nobody looks at the records again: the piece list alone is edited
@@ -276,34 +321,40 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                 }
                 const uint32_t x2 = me + a.ov;
 #pragma unroll
-                for (uint32_t b = 0; b < kLdsBlocks; b++) {
-                    const uint32_t r = b * kWave + (uint32_t)lane;
-                    const uint32_t e = r < nr ? e_[b] : 0xFFFFFFFFu;
-                    c_before += (uint32_t)__popcll(__ballot(e <= ms));
-                    c_gone += (uint32_t)__popcll(__ballot(e <= x2));
+                for (uint32_t b = 0; b < kLdsBlocks; b++) {              // (unused slots hold kNoPos: never counted)
+                    c_before += (uint32_t)__popcll(__ballot(e_[b] <= ms));
+                    c_gone += (uint32_t)__popcll(__ballot(e_[b] <= x2));
                 }
 #pragma unroll
                 for (uint32_t b = 0; b < kLdsBlocks; b++) {
-                    const uint32_t r = b * kWave + (uint32_t)lane;
-                    if (r >= c_before && r < c_gone) { L.end[r] = hi; L.prio[r] = kDead; L.pl[r] = 0u; }      // (end = the window's upper bound: the list stays sorted)
-                    else if (r >= c_gone && r < nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
+                    const uint32_t r0 = b * kWave;
+                    if (r0 >= nr || r0 + kWave <= c_before) continue;    // (uniform) nothing of this block changes
+                    const uint32_t r = r0 + (uint32_t)lane;
+                    if (r0 < c_gone) {                                   // the block holds dead slots (end = the window's upper bound: the list stays sorted)
+                        if (r >= c_before && r < c_gone) { L.end[r] = hi; L.prio[r] = kDead; L.pl[r] = 0u; }
+                        else if (r >= c_gone && r < nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
+                    } else if (delta != 0) {
+                        if (r0 + kWave <= nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
+                        else if (r < nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
+                    }
                 }
             }
+            tick(3);
 
             // (a) the piece list, in place: pieces i .. j2 hold the match; what is left of them is a head, the replacement, a tail.  One batch of reads
-            // answers "which piece holds byte x" for the match's first and last byte and for the window's first byte.
+            // answers "which piece holds byte x" for the match's first and last byte and for the window's first byte (slots behind the sentinel hold
+            // kNoPos, the sentinel the text's length: neither is ever <= a position inside the text).
             uint32_t c_ms = 0, c_me = 0, c_ws = 0;
             {
                 uint32_t v[kPcBlocks];
 #pragma unroll
-                for (uint32_t b = 0; b < kPcBlocks; b++) { const uint32_t k = b * kWave + (uint32_t)lane; v[b] = L.pls[k < kLdsPc + 2u ? k : 0u]; }
+                for (uint32_t b = 0; b < kPcBlocks; b++) { const uint32_t k = b * kWave + (uint32_t)lane; v[b] = L.pls[k < kLdsPc + 2u ? k : kLdsPc + 1u]; }
 #pragma unroll
                 for (uint32_t b = 0; b < kPcBlocks; b++) {
-                    const uint32_t k = b * kWave + (uint32_t)lane;
-                    const bool in = k < np;
-                    c_ms += (uint32_t)__popcll(__ballot(in && v[b] <= ms));
-                    c_me += (uint32_t)__popcll(__ballot(in && v[b] <= me - 1u));      // the match is not empty here (automata with the empty needle do not take this route)
-                    c_ws += (uint32_t)__popcll(__ballot(in && v[b] <= ws));
+                    if (b * kWave >= np) continue;                        // (uniform)
+                    c_ms += (uint32_t)__popcll(__ballot(v[b] <= ms));
+                    c_me += (uint32_t)__popcll(__ballot(v[b] <= me - 1u));      // the match is not empty here (automata with the empty needle do not take this route)
+                    c_ws += (uint32_t)__popcll(__ballot(v[b] <= ws));
                 }
             }
             const uint32_t i = c_ms - 1u, j2 = c_me - 1u, first = c_ws - 1u;     // (>= 0: piece 0 starts at 0; first <= i: ws <= ms)
@@ -325,14 +376,17 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     if (k < to) { L.psrc[(uint32_t)((int32_t)k + s)] = x; L.pls[(uint32_t)((int32_t)k + s)] = y + (uint32_t)delta; }
                     wave_lds_fence();
                 }
+                if (s < 0 && (uint32_t)lane < (uint32_t)(-s)) L.pls[np + 1u - (uint32_t)(-s) + (uint32_t)lane] = kNoPos;      // the slots the list shrank out of (|s| <= pieces of one match <= 64 here, else ...)
+                if (s < -(int32_t)kWave) { for (uint32_t k = np + 1u - (uint32_t)(-s) + (uint32_t)lane; k <= np; k += kWave) L.pls[k] = kNoPos; }
             }
             if (lane == 0) {
                 uint32_t at = i + keep_head;
-                if (has_repl) { L.psrc[at] = kReplBit | (uint32_t)repl_off; L.pls[at] = ms; at++; }
+                if (has_repl) { L.psrc[at] = kReplBit | repl_off; L.pls[at] = ms; at++; }
                 if (has_tail) { L.psrc[at] = pj_src + (me - pj_ls); L.pls[at] = ms + rl; }
             }
             np = (uint32_t)((int32_t)np + s);
             wave_lds_fence();
+            tick(4);
             if (last_pass) { curlen = newlen; continue; }
 
             // (c) gather the window's bytes through the piece list, scan its own positions
@@ -364,6 +418,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     }
                 }
                 wave_lds_fence();
+                tick(5);
                 scanned += wlen;
                 for (uint32_t base = own_lo; base < wlen && !redo; base += kWave) {
                     if (timed_out(3)) { redo = true; break; }
@@ -397,18 +452,22 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                             L.prio[at] = one.payload != kRpWalkList ? one.priority : (int32_t)state;
                             L.pl[at] = one.payload;
                         }
+                        has_walk = has_walk || __ballot(found && one.payload == kRpWalkList) != 0ull;
                         nf += nfb;
                     }
                 }
                 if (redo) break;
                 wave_lds_fence();                                         // (the window is rewritten by the next kept match's)
             }
+            tick(6);
 
             // (d) the window's records (rarely any) go where the dead ones lie: [c_before, c_before + nf); more of them than slots: the rest of the list moves up
             if (nf) {
-                const uint32_t room = c_gone - c_before;
+                const uint32_t room = c_gone - c_before, staged = nr;
                 uint32_t s_end = 0, s_pl = 0; int32_t s_prio = 0;
-                if ((uint32_t)lane < nf) { s_end = L.end[nr + lane]; s_prio = L.prio[nr + lane]; s_pl = L.pl[nr + lane]; }
+                if ((uint32_t)lane < nf) { s_end = L.end[staged + lane]; s_prio = L.prio[staged + lane]; s_pl = L.pl[staged + lane]; }
+                wave_lds_fence();
+                if ((uint32_t)lane < nf) { L.end[staged + lane] = kNoPos; L.prio[staged + lane] = kDead; L.pl[staged + lane] = 0u; }      // (unused slots again, unless the list grows into them)
                 wave_lds_fence();
                 if (nf > room) {
                     const int32_t g = (int32_t)(nf - room);
@@ -422,6 +481,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                 wave_lds_fence();
             }
             curlen = newlen;
+            tick(7);
         }
         if (redo) break;
         if (status == kRpFinished) break;
@@ -448,23 +508,29 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         atomicMax(a.ctrl + 1, passes);
         if (scanned) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 2), (unsigned long long)scanned);
         atomicAdd(a.ctrl + 7, 1u);                                        // haystacks finished here (the rest: k_rp_loop)
+        if (DBG) {
+            for (int i = 0; i < 8; i++) atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 8) + i, (unsigned long long)t_ph[i]);
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 8) + 8, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_begin));
+            atomicAdd(reinterpret_cast<unsigned long long*>(a.ctrl + 8) + 9, (unsigned long long)passes);
+        }
     }
 }
 
 }  // namespace
 
-template <bool IC>
+template <bool IC, bool DBG = false>
 __global__ void __launch_bounds__(64, 4) k_rp_lds(RpLoop a)
 {
     __shared__ LpLds L;
     const uint32_t h = a.h_first + blockIdx.x;
-    ld_run_haystack<IC>(a, L, h, (int)(threadIdx.x & (kWave - 1)));
+    ld_run_haystack<IC, DBG>(a, L, h, (int)(threadIdx.x & (kWave - 1)));
 }
 
 hipError_t launch_rp_lds(bool ic, const RpLoop& a, uint32_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     if (ic) hipLaunchKernelGGL((k_rp_lds<true>), dim3(n), dim3(64), 0, st, a);
+    else if (a.pad) hipLaunchKernelGGL((k_rp_lds<false, true>), dim3(n), dim3(64), 0, st, a);          // per-phase cycle sums (AM_RP_TRACE >= 3)
     else hipLaunchKernelGGL((k_rp_lds<false>), dim3(n), dim3(64), 0, st, a);
     return hipGetLastError();
 }
