@@ -152,6 +152,10 @@ hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* r
                            uint64_t* fin_start, uint32_t* fin_cnt, hipStream_t st);
 hipError_t launch_pt_materialise(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
                                  const uint8_t* repl, uint8_t* text_fin, hipStream_t st);
+// the same, output-centred (am_rplds.hip): every haystack's piece count <= kPtMatLdsPieces and length < 2^32
+constexpr uint32_t kPtMatLdsPieces = 1024;
+hipError_t launch_pt_materialise_lds(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
+                                     const uint8_t* repl, uint8_t* text_fin, hipStream_t st);
 hipError_t launch_pt_materialise_next(const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint64_t* next_offsets, uint32_t n_next,
                                       const uint8_t* text, const uint8_t* repl, uint8_t* out, hipStream_t st);
 hipError_t launch_pt_win_copy(const RpWin* wins, const uint64_t* woffs, const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint8_t* text,

@@ -1003,9 +1003,11 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     uint64_t* fstart_h = (uint64_t*)(fin_h + n_hay);
     uint32_t* fcnt_h = (uint32_t*)(fstart_h + n_hay);
     uint64_t total_fin = 0;
+    bool mat_lds = cfg::get(cfg::kRpLds) != 0;               // every finished text through the output-centred kernel (am_rplds.hip): piece lists that fit its LDS, lengths below 2^32
     for (uint32_t i = 0; i < n_hay; i++) {
         const RpLoopOut& o = out_h[i];
         if (o.status > kRpNothing || o.pieces_at + o.n_pieces + 1 > pc_total) return fail(AM_ERR_HIP, "replacer loop produced inconsistent metadata (internal error)");
+        if (o.n_pieces > kPtMatLdsPieces || o.len >= (1ull << 32) - 64) mat_lds = false;
         fin_h[i] = RpFin{total_fin, o.len, i, o.status};
         fstart_h[i] = o.pieces_at; fcnt_h[i] = o.n_pieces;
         total_fin += o.len;
@@ -1021,8 +1023,8 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     uint8_t* d_fin = home;
     if (res->dev < 0) { AM_TRY(s.fin_text.ensure(total_fin + 16)); d_fin = (uint8_t*)s.fin_text.p; }
     { Prof pr("pt_materialise", st);
-      HIP_TRY(launch_pt_materialise((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p, (const uint32_t*)s.lp_fin_cnt.p, (const RpFin*)s.lp_fin.p, n_hay,
-                                    (const uint8_t*)in->d_text, r->t.repl, d_fin, st)); }
+      HIP_TRY((mat_lds ? launch_pt_materialise_lds : launch_pt_materialise)((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p, (const uint32_t*)s.lp_fin_cnt.p,
+                                                                            (const RpFin*)s.lp_fin.p, n_hay, (const uint8_t*)in->d_text, r->t.repl, d_fin, st)); }
     if (res->dev < 0 && total_fin) {
         // home in requests of 256 MiB (one huge request keeps the copy engine from overlapping with anything else queued behind it)
         for (uint64_t off = 0; off < total_fin; off += (256ull << 20)) {
