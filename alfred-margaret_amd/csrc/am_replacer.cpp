@@ -205,6 +205,7 @@ struct RpSession {
     DevBuf first_orig, first_thr;
     DevBuf pt_pieces[2], pt_start[2], pt_cnt[2], pt_need, pt_need_off, pt_fin_start, pt_fin_cnt;      // piece-table path
     DevBuf lp_rec, lp_pc, lp_kept, lp_wtext, lp_out, lp_ctrl, lp_cap_r, lp_cap_p, lp_rec_base, lp_pc_base, lp_fin, lp_fin_start, lp_fin_cnt, lp_redo;      // one-kernel loops (am_rplds.hip, am_rploop.hip)
+    DevBuf lp_stage[8];                  // device staging of the haystack groups' finished texts on their way to the host
     void* lp_host = nullptr; size_t lp_host_cap = 0;                        // pinned: the loop's per-haystack results, then the materialise tables
     int pin_loop(size_t bytes)
     {
@@ -221,7 +222,7 @@ struct RpSession {
     {
         size_t n = 0;
         for (const DevBuf* d : {&text[0], &text[1], &recbuf[0], &recbuf[1], &kept, &wins, &wtext, &wrec, &fin_text, &ws.pool, &ws2.pool, &ws.hidx, &ws2.hidx, &pf_cand, &pf_sel, &pf_sidx,
-                                &lp_rec, &lp_pc, &lp_kept, &lp_wtext}) n += d->cap;
+                                &lp_rec, &lp_pc, &lp_kept, &lp_wtext, &lp_stage[0], &lp_stage[1], &lp_stage[2], &lp_stage[3], &lp_stage[4], &lp_stage[5], &lp_stage[6], &lp_stage[7]}) n += d->cap;
         return n;
     }
     ~RpSession()
@@ -231,7 +232,7 @@ struct RpSession {
                           &totals, &tiles, &act, &fin, &off_next, &off_fin, &tile_off, &act_idx, &fin_idx, &scan_tmp, &fin_text, &fin_meta, &first_orig, &first_thr,
                           &pf_best, &pf_delta, &pf_payload, &pf_selflag, &pf_sidx, &pf_cand, &pf_sel, &pf_keep, &pf_kflag, &pf_kdelta, &pf_kidx, &pf_kdpre, &pf_tmp,
                           &pt_pieces[0], &pt_pieces[1], &pt_start[0], &pt_start[1], &pt_cnt[0], &pt_cnt[1], &pt_need, &pt_need_off, &pt_fin_start, &pt_fin_cnt,
-                          &lp_rec, &lp_pc, &lp_kept, &lp_wtext, &lp_out, &lp_ctrl, &lp_cap_r, &lp_cap_p, &lp_rec_base, &lp_pc_base, &lp_fin, &lp_fin_start, &lp_fin_cnt, &lp_redo}) d->release();
+                          &lp_rec, &lp_pc, &lp_kept, &lp_wtext, &lp_out, &lp_ctrl, &lp_cap_r, &lp_cap_p, &lp_rec_base, &lp_pc_base, &lp_fin, &lp_fin_start, &lp_fin_cnt, &lp_redo, &lp_stage[0], &lp_stage[1], &lp_stage[2], &lp_stage[3], &lp_stage[4], &lp_stage[5], &lp_stage[6], &lp_stage[7]}) d->release();
         if (lp_host) (void)hipHostFree(lp_host);
         if (tot_host) (void)hipHostFree(tot_host);
         if (fin_host) (void)hipHostFree(fin_host);
@@ -891,7 +892,7 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
         ~Return()
         {
             if (sp->copy_stream) (void)hipStreamSynchronize(sp->copy_stream);
-            if (sp->device_bytes() > (2048ull << 20)) { delete sp; return; }
+            if (sp->device_bytes() > (8192ull << 20)) { delete sp; return; }      // (the loop's regions + the groups' staging of a 1-GiB batch are ~3 GiB of the 288)
             std::vector<RpSession*> doomed;
             { std::lock_guard<std::mutex> lk(r->session_mu);
               const_cast<am_replacer*>(r)->session_delete = [](void* p) { delete static_cast<RpSession*>(p); };
@@ -965,13 +966,92 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
         AM_TRY(s.lp_redo.ensure((size_t)n_hay * 4 + 64));
         HIP_TRY(hipMemsetAsync(s.lp_redo.p, 0, (size_t)n_hay * 4, st));
         a.redo = (uint32_t*)s.lp_redo.p;
-        say("launch (lds)");
-        { Prof pr("rp_lds", st); HIP_TRY(launch_rp_lds(r->case_mode == AM_IGNORE_CASE, a, n_hay, st)); }
     }
+    // Haystack GROUPS.  Results that stay on the device: one group, one launch.  Results that go to the host (Replacer.run :: Text -> Text returns host text;
+    // a gibibyte takes 20 ms over PCIe, four times what the passes take): the batch is cut into up to eight groups of >= 2048 haystacks, every group's
+    // kernels are queued at once, and while the later groups still run their passes the finished ones are materialised and copied home on a second
+    // stream -- the wire is busy from the first group's end to the last byte.  Nothing is shared between haystacks, so a group is just a launch over a
+    // range of them (RpLoop::h_first).
+    uint32_t n_groups = 1;
+    if (res->dev < 0 && n_hay >= 4096 && in->total >= (64ull << 20) && !a.pad && !cfg::on(cfg::kRpMatMain)) { n_groups = n_hay / 2048u; if (n_groups > 8) n_groups = 8; }
+    if (n_groups > 1 && !s.copy_stream && (hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&s.ev_spliced, hipEventDisableTiming) != hipSuccess))
+        return fail(AM_ERR_HIP, "could not create the copy stream");
+    const size_t out_bytes = (size_t)n_hay * sizeof(RpLoopOut);
+    const size_t tab_bytes = (size_t)n_hay * (sizeof(RpFin) + 8 + 4) + 64;
+    AM_TRY(s.pin_loop(64 + out_bytes + tab_bytes));
+    uint32_t* ctrl_h = (uint32_t*)s.lp_host;
+    RpLoopOut* out_h = (RpLoopOut*)((uint8_t*)s.lp_host + 64);
+    RpFin* fin_h = (RpFin*)((uint8_t*)s.lp_host + 64 + out_bytes);
+    uint64_t* fstart_h = (uint64_t*)(fin_h + n_hay);
+    uint32_t* fcnt_h = (uint32_t*)(fstart_h + n_hay);
+    AM_TRY(s.lp_fin.ensure((size_t)n_hay * sizeof(RpFin))); AM_TRY(s.lp_fin_start.ensure((size_t)n_hay * 8)); AM_TRY(s.lp_fin_cnt.ensure((size_t)n_hay * 4));
+    struct Events {
+        std::vector<hipEvent_t> ev;
+        ~Events() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); }
+    } done;
+    done.ev.assign(n_groups, nullptr);
+    auto group_lo = [&](uint32_t g) { return (uint32_t)((uint64_t)n_hay * g / n_groups); };
     say("launch");
-    { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, n_hay, (int)cfg::get(cfg::kRpLoopWaves), st)); }
+    for (uint32_t g = 0; g < n_groups; g++) {
+        const uint32_t h0 = group_lo(g), h1 = group_lo(g + 1);
+        a.h_first = h0;
+        if (use_lds) { Prof pr("rp_lds", st); HIP_TRY(launch_rp_lds(r->case_mode == AM_IGNORE_CASE, a, h1 - h0, st)); }
+        { Prof pr("rp_loop", st); HIP_TRY(launch_rp_loop(r->case_mode == AM_IGNORE_CASE, a, h1 - h0, (int)cfg::get(cfg::kRpLoopWaves), st)); }
+        HIP_TRY(hipMemcpyAsync(out_h + h0, (const RpLoopOut*)s.lp_out.p + h0, (size_t)(h1 - h0) * sizeof(RpLoopOut), hipMemcpyDeviceToHost, st));
+        if (g + 1 == n_groups) HIP_TRY(hipMemcpyAsync(ctrl_h, s.lp_ctrl.p, 64, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventCreateWithFlags(&done.ev[g], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(done.ev[g], st));
+    }
     say("launched");
-    // what every haystack ended as
+    res->text.assign(n_hay, am_replaced::Item());
+    res->just.assign(n_hay, 1);
+    std::vector<uint8_t*> home_of(n_groups, nullptr);
+    uint64_t total_all = 0;
+    bool gave_up = false;
+    for (uint32_t g = 0; g < n_groups && !gave_up; g++) {
+        const uint32_t h0 = group_lo(g), h1 = group_lo(g + 1);
+        HIP_TRY(hipEventSynchronize(done.ev[g]));
+        // what every haystack of the group ended as; the finished texts: one materialise launch over the final piece lists
+        uint64_t total_fin = 0;
+        bool mat_lds = cfg::get(cfg::kRpLds) != 0;           // every finished text through the output-centred kernel (am_rplds.hip): piece lists that fit its LDS, lengths below 2^32
+        for (uint32_t i = h0; i < h1; i++) {
+            const RpLoopOut& o = out_h[i];
+            if (o.status > kRpNothing || o.pieces_at + o.n_pieces + 1 > pc_total) { gave_up = true; break; }      // a haystack that was given up (overflow: nothing written) or inconsistent metadata: see below
+            if (o.n_pieces > kPtMatLdsPieces || o.len >= (1ull << 32) - 64) mat_lds = false;
+            fin_h[i] = RpFin{total_fin, o.len, i, o.status};
+            fstart_h[i] = o.pieces_at; fcnt_h[i] = o.n_pieces;
+            total_fin += o.len;
+        }
+        if (gave_up) break;
+        hipStream_t ms = n_groups > 1 ? s.copy_stream : st;
+        if (n_groups > 1) HIP_TRY(hipStreamWaitEvent(ms, done.ev[g], 0));
+        HIP_TRY(hipMemcpyAsync((RpFin*)s.lp_fin.p + h0, fin_h + h0, (size_t)(h1 - h0) * sizeof(RpFin), hipMemcpyHostToDevice, ms));
+        HIP_TRY(hipMemcpyAsync((uint64_t*)s.lp_fin_start.p + h0, fstart_h + h0, (size_t)(h1 - h0) * 8, hipMemcpyHostToDevice, ms));
+        HIP_TRY(hipMemcpyAsync((uint32_t*)s.lp_fin_cnt.p + h0, fcnt_h + h0, (size_t)(h1 - h0) * 4, hipMemcpyHostToDevice, ms));
+        uint8_t* home = nullptr;
+        if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
+        home_of[g] = home;
+        uint8_t* d_fin = home;
+        if (res->dev < 0) {
+            DevBuf& sb = n_groups > 1 ? s.lp_stage[g] : s.fin_text;      // (the session keeps them: no allocation in the steady state)
+            AM_TRY(sb.ensure(total_fin + 16));
+            d_fin = (uint8_t*)sb.p;
+        }
+        { Prof pr("pt_materialise", ms);
+          HIP_TRY((mat_lds ? launch_pt_materialise_lds : launch_pt_materialise)((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p + h0, (const uint32_t*)s.lp_fin_cnt.p + h0,
+                                                                                (const RpFin*)s.lp_fin.p + h0, h1 - h0, (const uint8_t*)in->d_text, r->t.repl, d_fin, ms)); }
+        if (res->dev < 0 && total_fin) {
+            // home in requests of 256 MiB (one huge request keeps the copy engine from overlapping with anything else queued behind it)
+            for (uint64_t off = 0; off < total_fin; off += (256ull << 20)) {
+                const uint64_t n = std::min<uint64_t>(256ull << 20, total_fin - off);
+                HIP_TRY(hipMemcpyAsync(home + off, d_fin + off, n, hipMemcpyDeviceToHost, ms));
+            }
+        }
+        total_all += total_fin;
+    }
+    say("materialise queued");
+    HIP_TRY(hipStreamSynchronize(st));
+    if (n_groups > 1) HIP_TRY(hipStreamSynchronize(s.copy_stream));
     if (a.pad && use_lds) {
         uint64_t ph[10];
         HIP_TRY(hipMemcpy(ph, (const uint8_t*)s.lp_ctrl.p + 32, 80, hipMemcpyDeviceToHost));
@@ -987,61 +1067,26 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
                                                  100.0 * (double)ph[i] / (double)(ph[6] ? ph[6] : 1), (double)ph[i] / (double)(ph[7] ? ph[7] : 1));
         std::fprintf(stderr, "[am_replacer loop] passes of all haystacks: %llu\n", (unsigned long long)ph[7]);
     }
-    const size_t out_bytes = (size_t)n_hay * sizeof(RpLoopOut);
-    const size_t tab_bytes = (size_t)n_hay * (sizeof(RpFin) + 8 + 4) + 64;
-    AM_TRY(s.pin_loop(64 + out_bytes + tab_bytes));
-    uint32_t* ctrl_h = (uint32_t*)s.lp_host;
-    RpLoopOut* out_h = (RpLoopOut*)((uint8_t*)s.lp_host + 64);
-    HIP_TRY(hipMemcpyAsync(ctrl_h, s.lp_ctrl.p, 64, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(out_h, s.lp_out.p, out_bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (trace) { std::fprintf(stderr, "[am_replacer loop] kernels done: overflow %u passes %u watchdog %u; %u of %u haystacks out of LDS\n", ctrl_h[0], ctrl_h[1], ctrl_h[5], ctrl_h[7], n_hay); std::fflush(stderr); }
+    if (trace) { std::fprintf(stderr, "[am_replacer loop] kernels done: overflow %u passes %u watchdog %u; %u of %u haystacks out of LDS, %u group(s)\n", ctrl_h[0], ctrl_h[1], ctrl_h[5], ctrl_h[7], n_hay, n_groups); std::fflush(stderr); }
     g_last_lds_haystacks.store(use_lds ? ctrl_h[7] : 0u, std::memory_order_relaxed);
-    if (ctrl_h[0] != 0) return AM_OK;                        // a haystack outgrew its regions: the pass-by-pass loop takes the batch
-    // the finished texts: one materialise launch over the final piece lists
-    RpFin* fin_h = (RpFin*)((uint8_t*)s.lp_host + 64 + out_bytes);
-    uint64_t* fstart_h = (uint64_t*)(fin_h + n_hay);
-    uint32_t* fcnt_h = (uint32_t*)(fstart_h + n_hay);
-    uint64_t total_fin = 0;
-    bool mat_lds = cfg::get(cfg::kRpLds) != 0;               // every finished text through the output-centred kernel (am_rplds.hip): piece lists that fit its LDS, lengths below 2^32
-    for (uint32_t i = 0; i < n_hay; i++) {
-        const RpLoopOut& o = out_h[i];
-        if (o.status > kRpNothing || o.pieces_at + o.n_pieces + 1 > pc_total) return fail(AM_ERR_HIP, "replacer loop produced inconsistent metadata (internal error)");
-        if (o.n_pieces > kPtMatLdsPieces || o.len >= (1ull << 32) - 64) mat_lds = false;
-        fin_h[i] = RpFin{total_fin, o.len, i, o.status};
-        fstart_h[i] = o.pieces_at; fcnt_h[i] = o.n_pieces;
-        total_fin += o.len;
+    if (ctrl_h[0] != 0 || gave_up) {
+        // a haystack outgrew its regions (its result was never written): the pass-by-pass loop takes the batch; what the groups before it brought home is dropped
+        if (ctrl_h[0] == 0) return fail(AM_ERR_HIP, "replacer loop produced inconsistent metadata (internal error)");
+        res->text.clear(); res->just.clear();
+        for (const Slab& sl : res->slabs) res->pool().give(sl);
+        res->slabs.clear();
+        return AM_OK;
     }
-    AM_TRY(s.lp_fin.ensure((size_t)n_hay * sizeof(RpFin))); AM_TRY(s.lp_fin_start.ensure((size_t)n_hay * 8)); AM_TRY(s.lp_fin_cnt.ensure((size_t)n_hay * 4));
-    HIP_TRY(hipMemcpyAsync(s.lp_fin.p, fin_h, (size_t)n_hay * sizeof(RpFin), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s.lp_fin_start.p, fstart_h, (size_t)n_hay * 8, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s.lp_fin_cnt.p, fcnt_h, (size_t)n_hay * 4, hipMemcpyHostToDevice, st));
-    res->text.assign(n_hay, am_replaced::Item());
-    res->just.assign(n_hay, 1);
-    uint8_t* home = nullptr;
-    if (total_fin) AM_TRY(res->room((size_t)total_fin, &home));
-    uint8_t* d_fin = home;
-    if (res->dev < 0) { AM_TRY(s.fin_text.ensure(total_fin + 16)); d_fin = (uint8_t*)s.fin_text.p; }
-    { Prof pr("pt_materialise", st);
-      HIP_TRY((mat_lds ? launch_pt_materialise_lds : launch_pt_materialise)((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p, (const uint32_t*)s.lp_fin_cnt.p,
-                                                                            (const RpFin*)s.lp_fin.p, n_hay, (const uint8_t*)in->d_text, r->t.repl, d_fin, st)); }
-    if (res->dev < 0 && total_fin) {
-        // home in requests of 256 MiB (one huge request keeps the copy engine from overlapping with anything else queued behind it)
-        for (uint64_t off = 0; off < total_fin; off += (256ull << 20)) {
-            const uint64_t n = std::min<uint64_t>(256ull << 20, total_fin - off);
-            HIP_TRY(hipMemcpyAsync(home + off, d_fin + off, n, hipMemcpyDeviceToHost, st));
-        }
-    }
-    say("materialise queued");
-    HIP_TRY(hipStreamSynchronize(st));
     say("done");
-    for (uint32_t i = 0; i < n_hay; i++) {
-        if (fin_h[i].status == kRpNothing) res->just[i] = 0;
-        else res->text[i] = am_replaced::Item{home + fin_h[i].off, (size_t)fin_h[i].len};
+    for (uint32_t g = 0; g < n_groups; g++) {
+        for (uint32_t i = group_lo(g); i < group_lo(g + 1); i++) {
+            if (fin_h[i].status == kRpNothing) res->just[i] = 0;
+            else res->text[i] = am_replaced::Item{home_of[g] + fin_h[i].off, (size_t)fin_h[i].len};
+        }
     }
     res->passes = ctrl_h[1];
     res->scanned += in->total + (((uint64_t)ctrl_h[3] << 32) | ctrl_h[2]);
-    res->spliced += total_fin;
+    res->spliced += total_all;
     *handled = true;
     return AM_OK;
 }
