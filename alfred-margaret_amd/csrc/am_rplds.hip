@@ -156,8 +156,6 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         return base[p - L.pls[idx]];
     };
 
-    uint32_t spec_idx = kNoPos;                                           // payload requested a pass ahead (kNoPos: none)
-    RpPayload spec_pp{};
     while (!redo) {
         passes++;
         if ((passes & 15u) == 0u && timed_out(1)) { redo = true; break; }      // (s_memtime is a scalar memory round trip: not in every pass)
@@ -219,30 +217,9 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             pw = ld_u32((uint32_t)ld_wave_max_i64((int64_t)pw));
             if (pw > payload) payload = pw;
         }
-        // the payload of the pass: one load with a uniform index -- requested a pass AHEAD when the guess made then holds (below): its trip through L2 then
-        // ran under the previous pass's work
-        RpPayload pp;
-        if (spec_idx == payload) pp = spec_pp;
-        else pp = a.t.payloads[payload];
+        RpPayload pp = a.t.payloads[payload];                             // uniform index: one load for the pass (requesting it a pass ahead on a guess was measured: no gain)
         const uint32_t m_len = ld_u32(pp.len_bytes), m_cps = ld_u32(pp.len_code_points), rl = ld_u32(pp.repl_len);
         const uint32_t repl_off = ld_u32((uint32_t)pp.repl_off);
-        // the guess for the NEXT pass: the best priority below this one among the records as they are now (this pass's replacement may still drop that
-        // record or add a better one: then the guess is not used)
-        spec_idx = kNoPos;
-        if (!has_walk && fast_sel) {
-            int32_t n32 = INT32_MIN;
-#pragma unroll
-            for (uint32_t b = 0; b < kLdsBlocks; b++) { const int32_t v = p_[b] < best32 ? p_[b] : INT32_MIN; n32 = v > n32 ? v : n32; }
-            n32 = ld_wave_max_i32(n32);
-            if (n32 != INT32_MIN) {
-#pragma unroll
-                for (uint32_t b = 0; b < kLdsBlocks; b++) {
-                    const uint64_t m = __ballot(p_[b] == n32);
-                    if (m) spec_idx = (uint32_t)__builtin_amdgcn_readlane((int)l_[b], __ffsll((unsigned long long)m) - 1);
-                }
-                if (spec_idx != kNoPos) spec_pp = a.t.payloads[spec_idx];
-            }
-        }
         tick(1);
 
         // ---- makeMatch (:264-274) + removeOverlap (:191-198): 64 records at a time, in position order (positions are 32-bit here)
@@ -625,22 +602,36 @@ __global__ void __launch_bounds__(kMatThreads) k_pt_materialise_lds(const RpPiec
         for (uint32_t k = 0; k < kMatPer; k++) { const uint32_t v = map[tid * kMatPer + k]; run = v > run ? v : run; map[tid * kMatPer + k] = (uint16_t)run; }
         __syncthreads();
         carry = map[segn - 1];
-        for (uint32_t c = tid; c < segn; c += kMatThreads) {
-            const uint32_t pos = lo_pos + 16u * c;
-            uint32_t i = map[c];
-            const uint32_t ls = pls[i], le = pls[i + 1];
-            u32x4_a out;
-            if (pos + 16u <= le) {
-                const uint64_t s = psrc[i];
-                const uint8_t* from = ((s & kPieceRepl) ? repl + (s & ~kPieceRepl) : text + s) + (pos - ls);
-                const u32x4_u v = *reinterpret_cast<const u32x4_u*>(from);
-                out.x = v.x; out.y = v.y; out.z = v.z; out.w = v.w;
-            } else {
-                uint32_t w[4] = {0, 0, 0, 0};
-                for (uint32_t k = 0; k < 16u; k++) w[k >> 2] |= (uint32_t)byte_at(pos + k, i) << (8u * (k & 3u));
-                out.x = w[0]; out.y = w[1]; out.z = w[2]; out.w = w[3];
+        // four chunks per lane and trip: their sources from LDS, the four loads in flight together, then the four aligned stores
+        for (uint32_t c0 = tid; c0 < segn; c0 += 4u * kMatThreads) {
+            const uint8_t* from[4]; bool whole[4], in[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t c = c0 + u * kMatThreads;
+                in[u] = c < segn;
+                const uint32_t pos = lo_pos + 16u * c;
+                const uint32_t i = map[in[u] ? c : 0u];
+                const uint32_t ls = pls[i], le = pls[i + 1];
+                const uint64_t sr = psrc[i];
+                whole[u] = in[u] && pos + 16u <= le;
+                from[u] = ((sr & kPieceRepl) ? repl + (sr & ~kPieceRepl) : text + sr) + (pos - ls);
             }
-            *reinterpret_cast<u32x4_a*>(dst + pos) = out;
+            u32x4_u v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) { v[u] = u32x4_u{0, 0, 0, 0}; if (whole[u]) v[u] = *reinterpret_cast<const u32x4_u*>(from[u]); }
+#pragma unroll
+            for (uint32_t u = 0; u < 4; u++) {
+                const uint32_t c = c0 + u * kMatThreads;
+                const uint32_t pos = lo_pos + 16u * c;
+                if (whole[u]) { u32x4_a out; out.x = v[u].x; out.y = v[u].y; out.z = v[u].z; out.w = v[u].w; *reinterpret_cast<u32x4_a*>(dst + pos) = out; }
+                else if (in[u]) {                                // the chunk straddles a piece boundary: byte by byte
+                    uint32_t i = map[c];
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t k = 0; k < 16u; k++) w[k >> 2] |= (uint32_t)byte_at(pos + k, i) << (8u * (k & 3u));
+                    u32x4_a out; out.x = w[0]; out.y = w[1]; out.z = w[2]; out.w = w[3];
+                    *reinterpret_cast<u32x4_a*>(dst + pos) = out;
+                }
+            }
         }
         __syncthreads();
     }
