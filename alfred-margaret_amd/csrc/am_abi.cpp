@@ -825,6 +825,32 @@ extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const
     return AM_OK;
 }
 
+int am::host::scan_needle_ids(const am_automaton* a, int case_mode, am_batch* b, const uint64_t* d_vals_off, const uint32_t* d_vals, uint32_t n_needles,
+                              uint32_t* d_bits, uint32_t words, uint32_t* d_missing, uint8_t* flags_out, bool* taken)
+{
+    *taken = false;
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p));
+    if (p.nothing || p.dense || !p.use_sf) return AM_OK;
+    std::lock_guard<std::mutex> lk(b->mu);
+    ON_DEVICE(b->dev);
+    hipStream_t st; AM_TRY(get_stream(b->dev, &st));
+    AM_TRY(b->flags.ensure(((size_t)b->n_hay + 3) & ~(size_t)3));
+    AM_TRY(b->small.ensure(64));
+    ScanOut o{};
+    o.unit_chunks = p.unit_chunks;
+    o.flags = (uint8_t*)b->flags.p;
+    o.ids_vals_off = d_vals_off; o.ids_vals = d_vals; o.ids_bits = d_bits; o.ids_missing = d_missing; o.ids_words = words; o.ids_n = n_needles;
+    HIP_TRY(hipMemsetAsync(d_bits, 0, (size_t)b->n_hay * words * 4, st));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)d_missing, (int)n_needles, b->n_hay, st));
+    AM_TRY(build_hidx_and_clear(p, b, st, b->flags.p, ((size_t)b->n_hay + 3) & ~(size_t)3, b->small.p, 64));      // (the counter block: k_sf's unit ticket)
+    AM_TRY(launch_scan_kernel(p, kModeIds, o, st));
+    ResultCopies rc;
+    AM_TRY(rc.add(flags_out, b->flags.p, b->n_hay, st));
+    AM_TRY(rc.finish(st));
+    *taken = true;
+    return AM_OK;
+}
+
 // The whole scan: leaves every record of the batch, sorted by (haystack, end_pos), in device memory
 // obtained from `sink(total, &ptr)` (called once, only when total > 0); *n_out = number of records.
 int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock)

@@ -64,11 +64,22 @@ extern "C" int am_contains_all_batch(const am_needle_ids* ids, int case_mode, co
     hipStream_t st; AM_TRY(get_stream(b->dev, &st));
     DevBuf records, rec_first, bits, flags;
     struct Release { DevBuf &a, &b, &c, &d; ~Release() { a.release(); b.release(); c.release(); d.release(); } } rel{records, rec_first, bits, flags};
+    const uint32_t words = (ids->n_needles + 31) / 32;
+    // The direct route (round 5): the scan itself sets the bit of every needle id it reports -- no record is written -- and a haystack whose set is
+    // complete is not looked at any further (`Done`, Searcher.hs:181), like containsAny's first match.  One bitmap row per haystack, up to 8 GiB of them;
+    // wider batches, the general kernel and automata with the empty needle fold the records (below).
+    if ((uint64_t)n_hay * words * 4 <= (8ull << 30) && !cfg::on(cfg::kNoIdsScan)) {
+        AM_TRY(bits.ensure((uint64_t)n_hay * words * 4 + 64));
+        AM_TRY(flags.ensure((size_t)n_hay * 4 + 64));                  // (here: the haystacks' missing-id counters)
+        bool taken = false;
+        AM_TRY(scan_needle_ids(ids->a, case_mode, b, (const uint64_t*)ids->vals_off.p, (const uint32_t*)ids->vals.p, ids->n_needles, (uint32_t*)bits.p, words,
+                               (uint32_t*)flags.p, flags_out, &taken));
+        if (taken) return AM_OK;
+    }
     uint64_t n_rec = 0;
     auto sink = [&](uint64_t n, Record** ptr) -> int { AM_TRY(records.ensure(n * sizeof(Record))); *ptr = (Record*)records.p; return AM_OK; };
     AM_TRY(run_records(ids->a, case_mode, b, sink, &n_rec));
     if (n_rec == 0) { std::memset(flags_out, 0, n_hay); return AM_OK; }
-    const uint32_t words = (ids->n_needles + 31) / 32;
     // one bitmap row per haystack; very wide batches go through in groups of haystacks (records are sorted by haystack)
     const uint64_t budget = 1ull << 30;
     const uint32_t group = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_hay, budget / ((uint64_t)words * 4)));

@@ -10,6 +10,8 @@ namespace dev {
 constexpr int kModeCount = 0;   // unit_counts[u] = records of unit u; optional per-haystack value counts; total values
 constexpr int kModeEmit = 1;    // write records at unit_offsets[u]
 constexpr int kModeAny = 2;     // flags[haystack] = 1 if anything matches
+constexpr int kModeIds = 3;     // Searcher.containsAll: the needle ids of everything that matches into the haystack's bitmap row; flags[haystack] = 1 when the row is full
+                                // (k_sf only: a flag mode like kModeAny -- a flagged haystack is not looked at any further)
 
 // 16-byte match record in HBM.  Same layout as am_match in include/am.h.
 struct alignas(16) Record { uint64_t end_pos; uint32_t haystack; uint32_t state; };
@@ -36,7 +38,10 @@ struct ScanOut {
     // all kernels
     uint64_t* hay_counts;         // count mode, may be null
     uint64_t* total_values;       // count mode
-    uint8_t* flags;               // any mode
+    uint8_t* flags;               // any mode; ids mode: the haystack's row is full
+    // ids mode (containsAll): machineValues in flat form = the needle ids a state reports; one row of ids_words 32-bit words per haystack;
+    // ids_missing[h] = ids of haystack h not seen yet (starts at the number of needles: the bit that brings it to 0 raises flags[h])
+    const uint64_t* ids_vals_off; const uint32_t* ids_vals; uint32_t* ids_bits; uint32_t* ids_missing; uint32_t ids_words, ids_n;
     uint32_t probe_two;           // A/B (AM_SF_PROBE_TWO=1): the two-candidates-per-lane instantiation also for automata with few 4-byte-suffix keys
     uint32_t ablate;              // timing experiments only (AM_SF_ABLATE); 0 in production
     uint64_t* dbg;                // timing experiments only: per-phase cycle sums
@@ -152,10 +157,6 @@ hipError_t launch_pt_build(const RpTables& t, const RpHay* hs, const uint64_t* r
                            uint64_t* fin_start, uint32_t* fin_cnt, hipStream_t st);
 hipError_t launch_pt_materialise(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
                                  const uint8_t* repl, uint8_t* text_fin, hipStream_t st);
-// the same, output-centred (am_rplds.hip): every haystack's piece count <= kPtMatLdsPieces and length < 2^32
-constexpr uint32_t kPtMatLdsPieces = 1024;
-hipError_t launch_pt_materialise_lds(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
-                                     const uint8_t* repl, uint8_t* text_fin, hipStream_t st);
 hipError_t launch_pt_materialise_next(const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint64_t* next_offsets, uint32_t n_next,
                                       const uint8_t* text, const uint8_t* repl, uint8_t* out, hipStream_t st);
 hipError_t launch_pt_win_copy(const RpWin* wins, const uint64_t* woffs, const RpPiece* pieces, const uint64_t* next_start, const uint32_t* next_cnt, const uint8_t* text,

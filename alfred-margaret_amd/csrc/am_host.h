@@ -166,6 +166,11 @@ namespace host {
 int prepare(const am_automaton* ca, int case_mode, const Flavor** out);                      // the automaton's image for a case mode, on its device
 int finish_batch(am_batch* b);                                                               // workspaces of a batch whose text and offsets are in place
 // sorted records of a batch: sink_final(n, &ptr) names the destination once the count is known
+// Searcher.containsAll without records (k_sf's ids mode): every reported needle id into the haystack's row of d_bits (n_hay x words, cleared here),
+// flags_out[h] = 1 iff all n_needles ids were seen; *taken = false when the automaton does not go this way (general kernel forced, the empty needle's
+// dense pass, nothing to scan) and the caller folds the records instead.
+int scan_needle_ids(const am_automaton* a, int case_mode, am_batch* b, const uint64_t* d_vals_off, const uint32_t* d_vals, uint32_t n_needles,
+                    uint32_t* d_bits, uint32_t words, uint32_t* d_missing, uint8_t* flags_out, bool* taken);
 int run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock = false);
 // the same without a host round trip (suffix-filter route, worst-case pool): the count stays on the device
 int run_records_async(const am_automaton* a, int case_mode, am_batch* b, Record* d_out, const uint64_t** n_dev, hipStream_t st);

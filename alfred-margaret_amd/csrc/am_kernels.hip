@@ -94,6 +94,7 @@ template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG, int NT = kSf
 __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     constexpr int kSfThreads = NT, kSfWaves = NT / 64;      // (shadow the namespace constants: the body is written against these names)
+    constexpr bool kFlagMode = MODE == kModeAny || MODE == kModeIds;      // a flagged haystack is not looked at any further (containsAny: matched; containsAll: every needle seen)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         else if (MODE == kModeEmit) {
             if (found && best_state[0] != prior && pool_ok) o.pool[slot].state = best_state[0] - 1u;      // the batch wrote end_pos and haystack into the walker's slot
             unit_count += (uint32_t)__popcll(__ballot(found && prior == 0u));
-        } else if (found) atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay >> 2), 1u << (8u * (hay & 3u)));
+        } else if (MODE == kModeAny && found) atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay >> 2), 1u << (8u * (hay & 3u)));      // (the flag modes have no walker queue: not reached)
     };
 
     // ---- phase 2: resolve the oldest `nb` (<= 64) deferred items in lock step (all belong to the current unit); item j of the batch
@@ -339,9 +340,27 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                     unit_slots += F;
                     unit_count += n_found_recs;
                 }
-            } else {
+            } else if (MODE == kModeAny) {
 #pragma unroll
                 for (int k = 0; k < RN; k++) if (found[k]) atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay[k] >> 2), 1u << (8u * (hay[k] & 3u)));      // (an atomic: the other XCDs' wavefronts look at it while the kernel runs)
+            } else {
+                // containsAll (Searcher.hs:173-187): every needle id the state reports leaves the haystack's set -- here: its bit enters the haystack's row;
+                // the bit that empties the set (`Done`, :181) raises the haystack's flag, and flagged haystacks are skipped like containsAny's
+#pragma unroll
+                for (int k = 0; k < RN; k++) {
+                    if (found[k]) {
+                        const uint32_t st = best_state[k] - 1u;
+                        uint32_t* row = o.ids_bits + (uint64_t)hay[k] * o.ids_words;
+                        for (uint64_t v = o.ids_vals_off[st], ve = o.ids_vals_off[st + 1]; v < ve; v++) {
+                            const uint32_t id = o.ids_vals[v];
+                            if (id >= o.ids_n) continue;                  // IS.delete of an absent key
+                            const uint32_t bit = 1u << (id & 31u);
+                            if (row[id >> 5] & bit) continue;             // (a stale read only costs an atomic)
+                            if (!(atomicOr(row + (id >> 5), bit) & bit) && atomicSub(o.ids_missing + hay[k], 1u) == 1u)
+                                atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay[k] >> 2), 1u << (8u * (hay[k] & 3u)));
+                        }
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < RN; k++) pm[k] = __ballot(parked[k]);
@@ -454,12 +473,12 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     // of the haystack its chunk lies in -- as the whole device has left it, one chunk ago: the load has a chunk's time -- and skips the chunk
     // if it is set.  A 1-GiB document that matches in its first KiB costs a few chunks per wavefront, not the scan.
     uint32_t any_word = 0, any_hay = kNone, flagged_hay = kNone;      // the flag word requested last, whose it is; the haystack known to be flagged
-    constexpr uint32_t kEpoch = MODE == kModeAny ? 4u : kSfEpochChunks;      // (flag mode drains its ring every 4 chunks: the first match is what everybody waits for)
+    constexpr uint32_t kEpoch = kFlagMode ? 4u : kSfEpochChunks;      // (flag mode drains its ring every 4 chunks: the first match is what everybody waits for)
     uint64_t u_next = u;
     for (; u < n_units; u = u_next) {
         // the unit after this one (its first chunk is prefetched while this unit's last chunk is processed)
         u_next = u + n_waves;
-        if (o.next_unit && MODE != kModeAny) {                // (flag mode draws at the unit's last chunk, when it knows whether it goes on at all)
+        if (o.next_unit && !kFlagMode) {                // (flag mode draws at the unit's last chunk, when it knows whether it goes on at all)
             uint32_t ticket = 0;
             if (lane == 0) ticket = atomicAdd(o.next_unit, 1u);
             u_next = n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
@@ -467,7 +486,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         unit_base_chunk = u * UC;
         unit_count = 0; unit_slots = 0; cur_block = kNone; first_block = kNone;
         const uint32_t n_in_unit = (uint32_t)(unit_base_chunk + UC <= n_chunks ? UC : n_chunks - unit_base_chunk);
-        if (MODE == kModeAny && flagged_hay != kNone && hay0 == flagged_hay) {
+        if (kFlagMode && flagged_hay != kNone && hay0 == flagged_hay) {
             // flag mode: a unit that lies inside a haystack known to be flagged is not looked at at all (only the next unit's first bytes are
             // fetched); and when that haystack is the batch's last, the wavefront is done: units are handed out in ascending order, whatever it
             // would get from here on lies behind this one (a draw from the unit counter costs more than skipping a unit does)
@@ -490,12 +509,12 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             // flag mode: the flag word requested one chunk ago is looked at BEFORE the next prefetch goes out (loads return in order: a wait for
             // it after the prefetch would cover the prefetch).  A chunk inside a haystack that is flagged is skipped -- and so will the next one be
             // if it lies in the same haystack (known from the bracket of the chunk before): its bytes are not even requested.
-            if (MODE == kModeAny && any_hay != kNone) {
+            if (kFlagMode && any_hay != kNone) {
                 const uint32_t seen = (uint32_t)__builtin_amdgcn_readfirstlane((int)any_word);
                 if (((seen >> (8u * (any_hay & 3u))) & 0xFFu) != 0u) flagged_hay = any_hay;
                 any_hay = kNone;
             }
-            if (MODE == kModeAny && last_of_unit) {
+            if (kFlagMode && last_of_unit) {
                 // the next unit: none when everything behind this one lies in a flagged haystack (the 1-GiB document that matches in its first KiB:
                 // 4096 draws from the unit counter would be 45 us, the rest of the launch is 20)
                 if (flagged_hay != kNone && flagged_hay == hay0 && he0 >= b.total && unit_base_chunk * kSfChunk >= hs0) u_next = n_units;
@@ -505,7 +524,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                     u_next = n_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
                 }
             }
-            const bool next_skipped = MODE == kModeAny && !last_of_unit && flagged_hay != kNone && flagged_hay == hay0 &&
+            const bool next_skipped = kFlagMode && !last_of_unit && flagged_hay != kNone && flagged_hay == hay0 &&
                                       (c + 1) * kSfChunk >= hs0 && (c + 2) * kSfChunk <= he0;
             if (!next_skipped)
             fetch(!last_of_unit ? c + 1 : u_next * UC, next_v);
@@ -525,7 +544,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             }
             const bool single = (c0 + kSfChunk < b.total ? c0 + kSfChunk : b.total) <= he0;
             bool skip = false;
-            if (MODE == kModeAny) {
+            if (kFlagMode) {
                 skip = single && flagged_hay == hay0;
                 // ... and when the rest of the unit lies in that haystack too, the loop goes straight to the unit's last chunk (which is skipped
                 // like this one, drains what is pending and fetches the next unit's first chunk): a skipped chunk still costs half a filtered one
@@ -558,7 +577,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             // k_sf 10.39 -> 10.26 ms per 10 GiB (cfg3 937 -> 949 GiB/s), cfg2 +1.7 %, cfg4 +0.9 %, natural text +0.2 %.
             __builtin_amdgcn_s_setprio(0);
             uint32_t cand = 0;
-            if (MODE != kModeAny || !skip) {
+            if (!kFlagMode || !skip) {
                 // tier 4 (needles of >= 4 bytes): straight-line code, the lane's 32 LDS reads (filter word + mask per
                 // position) are all in flight before the first one is tested
                 uint32_t h[16], v[16], m[16];
@@ -578,7 +597,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
 #pragma unroll
                 for (int k = 15; k >= 0; k--) cand = (cand << 1) | (uint32_t)((v[k] & m[k]) == m[k]);      // bit k of cand = position k
             }
-            if (SHORT && (MODE != kModeAny || !skip)) {    // automata with 1..3-byte needles: extra probes per position
+            if (SHORT && (!kFlagMode || !skip)) {    // automata with 1..3-byte needles: extra probes per position
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
                     const int j = k >> 2, sh = k & 3;
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 tick(t_compact);
                 // (at the end of a unit the last call also walks every parked walker to the end: they all belong to this unit)
                 // (flag mode walks them at the end of every epoch: a parked walker may be the match everybody is waiting for)
-                const bool walk_all = last_of_unit || MODE == kModeAny;
+                const bool walk_all = last_of_unit || kFlagMode;
                 while (q2_tail != q2_head || (walk_all && wq_n)) {
                     const uint32_t left = q2_tail - q2_head, nb = left < 64u * RN ? left : 64u * RN;
                     resolve_batch(nb, walk_all && left == nb);
@@ -794,7 +813,8 @@ template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false, int 
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     constexpr int waves_per_wg = NT / 64;
-    const uint32_t wq_cap = MODE == kModeAny ? 0u : sf_wq_cap(s, waves_per_wg);
+    constexpr bool kFlagMode = MODE == kModeAny || MODE == kModeIds;
+    const uint32_t wq_cap = kFlagMode ? 0u : sf_wq_cap(s, waves_per_wg);
     const size_t lds = sf_lds_bytes_w(s, waves_per_wg) + (size_t)waves_per_wg * wq_cap * 64;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
@@ -844,7 +864,15 @@ template <bool IC, int MODE>
 static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const bool lw15 = s.bloom_log2_words == 15;
-    if ((o.ablate || o.dbg) && MODE != kModeAny) {                                          // experiments (AM_SF_ABLATE)
+    constexpr bool kFlagMode = MODE == kModeAny || MODE == kModeIds;
+    if constexpr (MODE == kModeIds) {
+        // containsAll: two instantiations per case mode and workgroup size (any filter size, two candidates per lane) -- its time goes into the value lists
+        // and the bitmap atomics of the matches, not into the filter the other variants are tuned for
+        if (sf_chunks(b) <= kSfLightChunks)
+            return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true, false, kSfLightThreads>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false, false, kSfLightThreads>(s, b, o, n_cu, st);
+        return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
+    }
+    if ((o.ablate || o.dbg) && !kFlagMode) {                                          // experiments (AM_SF_ABLATE)
         if (!lw15) return launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
         return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, true, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st);
     }
@@ -875,10 +903,12 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     if (ic) {
         if (mode == kModeCount) return launch_sf_t<true, kModeCount>(s, b, o, n_cu, st);
         if (mode == kModeEmit) return launch_sf_t<true, kModeEmit>(s, b, o, n_cu, st);
+        if (mode == kModeIds) return launch_sf_t<true, kModeIds>(s, b, o, n_cu, st);
         return launch_sf_t<true, kModeAny>(s, b, o, n_cu, st);
     }
     if (mode == kModeCount) return launch_sf_t<false, kModeCount>(s, b, o, n_cu, st);
     if (mode == kModeEmit) return launch_sf_t<false, kModeEmit>(s, b, o, n_cu, st);
+    if (mode == kModeIds) return launch_sf_t<false, kModeIds>(s, b, o, n_cu, st);
     return launch_sf_t<false, kModeAny>(s, b, o, n_cu, st);
 }
 

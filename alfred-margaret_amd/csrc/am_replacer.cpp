@@ -1013,11 +1013,9 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
         HIP_TRY(hipEventSynchronize(done.ev[g]));
         // what every haystack of the group ended as; the finished texts: one materialise launch over the final piece lists
         uint64_t total_fin = 0;
-        bool mat_lds = cfg::get(cfg::kRpLds) != 0;           // every finished text through the output-centred kernel (am_rplds.hip): piece lists that fit its LDS, lengths below 2^32
         for (uint32_t i = h0; i < h1; i++) {
             const RpLoopOut& o = out_h[i];
             if (o.status > kRpNothing || o.pieces_at + o.n_pieces + 1 > pc_total) { gave_up = true; break; }      // a haystack that was given up (overflow: nothing written) or inconsistent metadata: see below
-            if (o.n_pieces > kPtMatLdsPieces || o.len >= (1ull << 32) - 64) mat_lds = false;
             fin_h[i] = RpFin{total_fin, o.len, i, o.status};
             fstart_h[i] = o.pieces_at; fcnt_h[i] = o.n_pieces;
             total_fin += o.len;
@@ -1038,8 +1036,8 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
             d_fin = (uint8_t*)sb.p;
         }
         { Prof pr("pt_materialise", ms);
-          HIP_TRY((mat_lds ? launch_pt_materialise_lds : launch_pt_materialise)((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p + h0, (const uint32_t*)s.lp_fin_cnt.p + h0,
-                                                                                (const RpFin*)s.lp_fin.p + h0, h1 - h0, (const uint8_t*)in->d_text, r->t.repl, d_fin, ms)); }
+          HIP_TRY(launch_pt_materialise((const RpPiece*)s.lp_pc.p, (const uint64_t*)s.lp_fin_start.p + h0, (const uint32_t*)s.lp_fin_cnt.p + h0, (const RpFin*)s.lp_fin.p + h0, h1 - h0,
+                                        (const uint8_t*)in->d_text, r->t.repl, d_fin, ms)); }      // (an output-centred variant -- aligned 16-byte chunks, chunk -> piece map in LDS -- was measured in round 5: the same 0.98 ms per GiB)
         if (res->dev < 0 && total_fin) {
             // home in requests of 256 MiB (one huge request keeps the copy engine from overlapping with anything else queued behind it)
             for (uint64_t off = 0; off < total_fin; off += (256ull << 20)) {

@@ -525,126 +525,6 @@ __global__ void __launch_bounds__(64, 4) k_rp_lds(RpLoop a)
     ld_run_haystack<IC, DBG>(a, L, h, (int)(threadIdx.x & (kWave - 1)));
 }
 
-// ---- the finished texts, written OUTPUT-centred (round 5).  k_pt_materialise (am_replace.hip) gives a piece to a wavefront: a piece of a few hundred bytes
-// keeps 20 of 64 lanes busy with 16-byte copies and finishes byte by byte -- 2.2 TB/s.  Here a workgroup owns a finished haystack, its piece list
-// sits in LDS, and every lane writes ALIGNED 16-byte chunks of the output: a chunk -> piece map (one 16-bit entry per chunk, built per 64-KiB segment: every
-// piece marks the first chunk that starts inside it, a running maximum fills the rest) tells a lane where its chunk's bytes come from -- one unaligned
-// 16-byte load, one aligned store; the few chunks that straddle a piece boundary are assembled byte by byte.
-constexpr uint32_t kMatPieces = kPtMatLdsPieces;           // pieces of a haystack this kernel takes (the host checks; more: k_pt_materialise)
-constexpr uint32_t kMatThreads = 256, kMatPer = 16;        // a segment = 256 threads x 16 chunks x 16 bytes = 64 KiB of output
-constexpr uint32_t kMatSegChunks = kMatThreads * kMatPer;
-
-__global__ void __launch_bounds__(kMatThreads) k_pt_materialise_lds(const RpPiece* __restrict__ pieces, const uint64_t* __restrict__ fin_start, const uint32_t* __restrict__ fin_cnt,
-                                                                  const RpFin* __restrict__ fin, const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl,
-                                                                  uint8_t* __restrict__ text_fin)
-{
-    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
-    typedef uint32_t u32x4_a __attribute__((ext_vector_type(4)));
-    __shared__ uint64_t psrc[kMatPieces + 1];
-    __shared__ uint32_t pls[kMatPieces + 2];
-    __shared__ uint16_t map[kMatSegChunks];
-    __shared__ uint16_t part[kMatThreads];
-    const uint32_t f = blockIdx.x, tid = threadIdx.x;
-    const RpFin m = fin[f];
-    if (m.status == kRpNothing || m.len == 0) return;
-    const RpPiece* P = pieces + fin_start[f];
-    const uint32_t n = fin_cnt[f];                             // <= kMatPieces, and m.len < 2^32 (launch_pt_materialise_lds's caller checked)
-    for (uint32_t i = tid; i <= n; i += kMatThreads) { const RpPiece pc = P[i]; pls[i] = (uint32_t)pc.lstart; psrc[i] = pc.src; }
-    __syncthreads();
-    const uint32_t len = (uint32_t)m.len;
-    uint8_t* const dst = text_fin + m.off;
-    auto byte_at = [&](uint32_t pos, uint32_t& i) -> uint8_t {  // i: a piece at or before the one that holds pos; moved up to it
-        while (pls[i + 1] <= pos) i++;
-        const uint64_t s = psrc[i];
-        const uint8_t* from = (s & kPieceRepl) ? repl + (s & ~kPieceRepl) : text + s;
-        return from[pos - pls[i]];
-    };
-    auto piece_of = [&](uint32_t pos) -> uint32_t {            // last piece that starts at or before pos
-        uint32_t lo = 0, hi = n;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pls[mid] <= pos) lo = mid; else hi = mid; }
-        return lo;
-    };
-    uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u);
-    if (head > len) head = len;
-    const uint32_t n_chunks = (len - head) / 16u, tail0 = head + 16u * n_chunks;
-    if (tid < head) { uint32_t i = piece_of(tid); dst[tid] = byte_at(tid, i); }
-    if (tid >= 32 && tid - 32 < len - tail0) { const uint32_t pos = tail0 + (tid - 32); uint32_t i = piece_of(pos); dst[pos] = byte_at(pos, i); }
-    uint32_t carry = 0;                                        // the piece that holds the byte before the segment (0 for the first)
-    for (uint32_t seg0 = 0; seg0 < n_chunks; seg0 += kMatSegChunks) {
-        const uint32_t segn = n_chunks - seg0 < kMatSegChunks ? n_chunks - seg0 : kMatSegChunks;
-        const uint32_t lo_pos = head + 16u * seg0, hi_pos = lo_pos + 16u * segn;
-        for (uint32_t c = tid; c < kMatSegChunks; c += kMatThreads) map[c] = 0;
-        __syncthreads();
-        for (uint32_t i = tid; i < n; i += kMatThreads) {       // the first chunk of the segment that STARTS inside piece i (if any) gets i
-            const uint32_t ls = pls[i], le = pls[i + 1];
-            const uint32_t a0 = ls > lo_pos ? ls : lo_pos;
-            if (le <= a0 || a0 >= hi_pos) continue;
-            const uint32_t c = (a0 - head + 15u) / 16u;          // first chunk whose start is >= a0
-            if (head + 16u * c < le && c < seg0 + segn) map[c - seg0] = (uint16_t)i;
-        }
-        __syncthreads();
-        // running maximum over the map (piece indices ascend with the position): 16 entries per thread, then the threads' maxima
-        uint32_t mx = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < kMatPer; k++) { const uint32_t v = map[tid * kMatPer + k]; mx = v > mx ? v : mx; }
-        part[tid] = (uint16_t)mx;
-        __syncthreads();
-        for (uint32_t d = 1; d < kMatThreads; d <<= 1) {
-            uint32_t o = 0;
-            if (tid >= d) o = part[tid - d];
-            __syncthreads();
-            if (tid >= d && o > part[tid]) part[tid] = (uint16_t)o;
-            __syncthreads();
-        }
-        uint32_t run = tid ? part[tid - 1] : 0u;
-        if (carry > run) run = carry;
-#pragma unroll
-        for (uint32_t k = 0; k < kMatPer; k++) { const uint32_t v = map[tid * kMatPer + k]; run = v > run ? v : run; map[tid * kMatPer + k] = (uint16_t)run; }
-        __syncthreads();
-        carry = map[segn - 1];
-        // four chunks per lane and trip: their sources from LDS, the four loads in flight together, then the four aligned stores
-        for (uint32_t c0 = tid; c0 < segn; c0 += 4u * kMatThreads) {
-            const uint8_t* from[4]; bool whole[4], in[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t c = c0 + u * kMatThreads;
-                in[u] = c < segn;
-                const uint32_t pos = lo_pos + 16u * c;
-                const uint32_t i = map[in[u] ? c : 0u];
-                const uint32_t ls = pls[i], le = pls[i + 1];
-                const uint64_t sr = psrc[i];
-                whole[u] = in[u] && pos + 16u <= le;
-                from[u] = ((sr & kPieceRepl) ? repl + (sr & ~kPieceRepl) : text + sr) + (pos - ls);
-            }
-            u32x4_u v[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) { v[u] = u32x4_u{0, 0, 0, 0}; if (whole[u]) v[u] = *reinterpret_cast<const u32x4_u*>(from[u]); }
-#pragma unroll
-            for (uint32_t u = 0; u < 4; u++) {
-                const uint32_t c = c0 + u * kMatThreads;
-                const uint32_t pos = lo_pos + 16u * c;
-                if (whole[u]) { u32x4_a out; out.x = v[u].x; out.y = v[u].y; out.z = v[u].z; out.w = v[u].w; *reinterpret_cast<u32x4_a*>(dst + pos) = out; }
-                else if (in[u]) {                                // the chunk straddles a piece boundary: byte by byte
-                    uint32_t i = map[c];
-                    uint32_t w[4] = {0, 0, 0, 0};
-                    for (uint32_t k = 0; k < 16u; k++) w[k >> 2] |= (uint32_t)byte_at(pos + k, i) << (8u * (k & 3u));
-                    u32x4_a out; out.x = w[0]; out.y = w[1]; out.z = w[2]; out.w = w[3];
-                    *reinterpret_cast<u32x4_a*>(dst + pos) = out;
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
-hipError_t launch_pt_materialise_lds(const RpPiece* pieces, const uint64_t* fin_start, const uint32_t* fin_cnt, const RpFin* fin, uint32_t n_fin, const uint8_t* text,
-                                     const uint8_t* repl, uint8_t* text_fin, hipStream_t st)
-{
-    if (n_fin == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_pt_materialise_lds, dim3(n_fin), dim3(kMatThreads), 0, st, pieces, fin_start, fin_cnt, fin, text, repl, text_fin);
-    return hipGetLastError();
-}
-
 hipError_t launch_rp_lds(bool ic, const RpLoop& a, uint32_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;

@@ -359,6 +359,7 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
         gate_args = copy.copy(args)
         gate_args.kernel, gate_args.parity_oracle_mib = 0, args.workloads_oracle_mib
         parity = parity_gate(gate_args, w, needles, machine, handle, case, batch, text, n_hay, 0, 1, dev, lib)
+        contains_all = contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib) if name == "cfg2_runText_10k_1GiB" else None
     finally:
         lib.am_batch_destroy(batch)
     avg_ms = ms.value / max(int(launches.value), 1)
@@ -372,7 +373,47 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
             "roofline": {"kernel": "k_sf", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes),
                          "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic},
             "parity": {k: parity.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "full_lists_checked", "matches_in_checked")},
-            "build_s": round(build_s, 2)}
+            "build_s": round(build_s, 2), **({"contains_all": contains_all} if contains_all else {})}
+
+
+def contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib):
+    """Searcher.containsAll (Searcher.hs:173-187) over the same resident batch, for the `Searcher Int` of buildNeedleIdSearcher: the direct route (k_sf's
+    ids mode: the scan sets the needle-id bits itself, no record is written, a complete haystack is left) against the record route (full scan + k_idset),
+    flags equal on every haystack and equal to the oracle's on the first ones."""
+    import numpy as np
+    import alfred_margaret_amd as am
+    voff = np.ascontiguousarray(machine.values_off(), dtype=np.uint64)
+    vals = np.ascontiguousarray(machine.values(), dtype=np.uint32)
+    ids = C.c_void_p()
+    am.api.check(lib.am_needle_ids_create(handle, voff.ctypes.data, vals.ctypes.data, len(needles), C.byref(ids)))
+    try:
+        def run():
+            f = np.zeros(n_hay, np.uint8)
+            t0 = time.perf_counter()
+            am.api.check(lib.am_contains_all_batch(ids, case, batch, f.ctypes.data))
+            return f, time.perf_counter() - t0
+        run()
+        direct, t_direct = min((run() for _ in range(3)), key=lambda x: x[1])
+        am.debug_set("AM_NO_IDS_SCAN", 1)
+        try:
+            run()
+            folded, t_fold = min((run() for _ in range(2)), key=lambda x: x[1])
+        finally:
+            am.debug_set("AM_NO_IDS_SCAN", -1)
+    finally:
+        lib.am_needle_ids_destroy(ids)
+    if not np.array_equal(direct, folded):
+        raise SystemExit("PARITY FAILURE: containsAll's direct route and its record route disagree")
+    o, _ = get_oracle(needles)
+    hb = w["hay_bytes"]
+    k = min(n_hay, 64)
+    host = text[:k * hb].cpu().numpy()
+    exp = [o.contains_all(case, host[i * hb:(i + 1) * hb]) for i in range(k)]
+    if [bool(x) for x in direct[:k]] != exp:
+        raise SystemExit("PARITY FAILURE: containsAll differs from the oracle")
+    gib = n_bytes / float(1 << 30)
+    return {"gibps": round(gib / t_direct, 1), "ms": round(t_direct * 1e3, 3), "record_route_ms": round(t_fold * 1e3, 3), "routes_agree": n_hay, "oracle_checked": k,
+            "true_flags": int(direct.sum())}
 
 
 def extra_workloads(args, dev, lib, cfg3_machine, cfg3_needles):

@@ -520,13 +520,54 @@ def test_contains_all_device_bitmap():
             s = am.Searcher.build_needle_id(case, needles) if hasattr(am.Searcher, "build_needle_id") else am.Searcher(case, needles)
             o = oracle.Machine(needles)
             exp = [o.contains_all(case, h) for h in hays]
-            assert [bool(x) for x in s.contains_all_batch(hays)] == exp, (case, needles)
+            assert [bool(x) for x in s.contains_all_batch(hays)] == exp, (case, needles)      # the direct route: k_sf's ids mode, no record written
+            am.debug_set("AM_NO_IDS_SCAN", 1)
+            assert [bool(x) for x in s.contains_all_batch(hays)] == exp, (case, needles)      # the record route (k_idset over a full scan)
+            am.debug_set("AM_NO_IDS_SCAN", -1)
             assert [bool(x) for x in s.contains_all_batch(hays, host_fold=True)] == exp
     # AhoCorasickSpec.hs:202-218: a haystack made of all needles contains all of them
     needles = synth.needles_for("cfg2_runText_10k_1GiB")[:3000]
     s = am.Searcher(0, needles)
     joined = " ".join(n if isinstance(n, str) else n.decode() for n in needles)
     assert list(s.contains_all_batch([joined, joined[: len(joined) // 2], ""])) == [True, False, False]
+
+
+def test_contains_all_writes_no_records_and_stops_when_the_set_is_complete():
+    """VERDICT r4 item 9 / Searcher.hs:173-187 (`Done` when the set is empty, :181): the default route runs k_sf in its ids mode -- no permute, no
+    record fold -- and a document whose first part already contains every needle is not scanned to its end: like containsAny's first match, the full
+    row raises the haystack's flag and the wavefronts skip what is left of it."""
+    needles = synth.needles_for("cfg2_runText_10k_1GiB")[:200]
+    s = am.Searcher(0, needles)
+    joined = (" ".join(needles)).encode()
+    filler = bytes(synth.haystacks_host(needles, False, 0, 64 << 10, plants=0))     # 64 MiB without planted needles
+    early = joined + filler
+    late = filler + joined
+    never = filler
+    lib = am.libam()
+
+    def kernel_ms(hays):
+        am.check(lib.am_profile_reset()); am.check(lib.am_profile_enable(1))
+        out = list(s.contains_all_batch(hays))
+        am.check(lib.am_profile_enable(0))
+        t = {}
+        for k in (b"sf", b"permute", b"idset"):
+            ms, n = C.c_double(0), C.c_uint64(0)
+            am.check(lib.am_profile_read(k, C.byref(ms), C.byref(n)))
+            t[k.decode()] = (ms.value, int(n.value))
+        return out, t
+
+    kernel_ms([early])                                                             # warm-up (flatten, workspaces)
+    got, t_early = kernel_ms([early])
+    assert got == [True] and t_early["permute"][1] == 0 and t_early["idset"][1] == 0 and t_early["sf"][1] == 1
+    got, t_late = kernel_ms([late])
+    assert got == [True]
+    got, t_never = kernel_ms([never])
+    assert got == [False]
+    assert t_early["sf"][0] < 0.5 * t_late["sf"][0], (t_early, t_late, t_never)     # stopped early: a fraction of the full scan
+    am.debug_set("AM_NO_IDS_SCAN", 1)
+    got, t_rec = kernel_ms([early, late, never])
+    am.debug_set("AM_NO_IDS_SCAN", -1)
+    assert got == [True, True, False] and t_rec["idset"][1] >= 1
 
 
 def test_serialised_image_round_trip(tmp_path):
