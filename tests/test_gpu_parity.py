@@ -535,39 +535,58 @@ def test_contains_all_device_bitmap():
 def test_contains_all_writes_no_records_and_stops_when_the_set_is_complete():
     """VERDICT r4 item 9 / Searcher.hs:173-187 (`Done` when the set is empty, :181): the default route runs k_sf in its ids mode -- no permute, no
     record fold -- and a document whose first part already contains every needle is not scanned to its end: like containsAny's first match, the full
-    row raises the haystack's flag and the wavefronts skip what is left of it."""
+    row raises the haystack's flag and the wavefronts skip what is left of it.  1-GiB documents resident in HBM (x's around the needles)."""
+    import torch
     needles = synth.needles_for("cfg2_runText_10k_1GiB")[:200]
-    s = am.Searcher(0, needles)
-    joined = (" ".join(needles)).encode()
-    filler = bytes(synth.haystacks_host(needles, False, 0, 64 << 10, plants=0))     # 64 MiB without planted needles
-    early = joined + filler
-    late = filler + joined
-    never = filler
+    a = am.Automaton(needles)
+    voff = np.ascontiguousarray(a.values_off(), dtype=np.uint64)
+    vals = np.ascontiguousarray(a.values(), dtype=np.uint32)
     lib = am.libam()
+    dev = torch.device("cuda:0")
+    gib = 1 << 30
+    joined = torch.tensor(list((" ".join(needles)).encode()), dtype=torch.uint8, device=dev)
+    text = torch.full((gib + 64,), ord("x"), dtype=torch.uint8, device=dev)
+    offs = torch.tensor([0, gib], dtype=torch.int64, device=dev)
+    ids, b = C.c_void_p(), C.c_void_p()
+    am.check(lib.am_needle_ids_create(a.device, voff.ctypes.data, vals.ctypes.data, len(needles), C.byref(ids)))
+    am.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), 1, gib, C.byref(b)))
+    flags = np.zeros(4, np.uint8)
 
-    def kernel_ms(hays):
+    def run():
         am.check(lib.am_profile_reset()); am.check(lib.am_profile_enable(1))
-        out = list(s.contains_all_batch(hays))
+        am.check(lib.am_contains_all_batch(ids, 0, b, flags.ctypes.data))
         am.check(lib.am_profile_enable(0))
         t = {}
         for k in (b"sf", b"permute", b"idset"):
             ms, n = C.c_double(0), C.c_uint64(0)
             am.check(lib.am_profile_read(k, C.byref(ms), C.byref(n)))
             t[k.decode()] = (ms.value, int(n.value))
-        return out, t
+        return bool(flags[0]), t
 
-    kernel_ms([early])                                                             # warm-up (flatten, workspaces)
-    got, t_early = kernel_ms([early])
-    assert got == [True] and t_early["permute"][1] == 0 and t_early["idset"][1] == 0 and t_early["sf"][1] == 1
-    got, t_late = kernel_ms([late])
-    assert got == [True]
-    got, t_never = kernel_ms([never])
-    assert got == [False]
-    assert t_early["sf"][0] < 0.5 * t_late["sf"][0], (t_early, t_late, t_never)     # stopped early: a fraction of the full scan
-    am.debug_set("AM_NO_IDS_SCAN", 1)
-    got, t_rec = kernel_ms([early, late, never])
-    am.debug_set("AM_NO_IDS_SCAN", -1)
-    assert got == [True, True, False] and t_rec["idset"][1] >= 1
+    try:
+        run()                                                                      # (haystack index, workspaces)
+        text[4096:4096 + joined.numel()] = joined                                  # every needle within the first KiBs
+        got, t_early = run()
+        assert got is True and t_early["permute"][1] == 0 and t_early["idset"][1] == 0 and t_early["sf"][1] == 1, t_early
+        text[4096:4096 + joined.numel()] = ord("x")
+        text[gib - 8192:gib - 8192 + joined.numel()] = joined                      # ... within the last ones: the whole document is scanned
+        got, t_late = run()
+        assert got is True
+        text[gib - 8192:gib - 8192 + 40] = ord("x")                                # one needle short
+        got, t_never = run()
+        assert got is False
+        print("containsAll on 1 GiB: complete in the first KiBs %.3f ms, in the last %.3f ms, never %.3f ms" % (t_early["sf"][0], t_late["sf"][0], t_never["sf"][0]))
+        assert t_early["sf"][0] * 3 < t_late["sf"][0], (t_early, t_late, t_never)
+        am.debug_set("AM_NO_IDS_SCAN", 1)                                          # the record route on the same documents
+        got, t_rec = run()
+        assert got is False and t_rec["idset"][1] >= 1
+        text[gib - 8192:gib - 8192 + joined.numel()] = joined
+        got, _ = run()
+        am.debug_set("AM_NO_IDS_SCAN", -1)
+        assert got is True
+    finally:
+        lib.am_batch_destroy(b)
+        lib.am_needle_ids_destroy(ids)
 
 
 def test_serialised_image_round_trip(tmp_path):
