@@ -1021,29 +1021,45 @@ def cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib):
     import alfred_margaret_amd as am
     REPS = 5
     n_hay = int(lib.am_batch_total_bytes(batch)) // w["hay_bytes"]
-    prev, core = pin_to_one_core()
-    try:
-        # calibration: one haystack (also warms the page cache of the tables)
-        o, build0 = get_oracle(needles)
-        hay0 = synth.haystacks_host(needles, w["mixed"], 0, hay_cells, plants=args.plants, natural=bool(w.get("natural")))
-        t1 = time.perf_counter(); o.count_matches(case, hay0); per_hay = time.perf_counter() - t1
-        k = int(max(1, min(n_hay, 64, (args.cpu_seconds / REPS) / max(per_hay, 1e-6))))
-        hays = [hay0] + [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells, plants=args.plants, natural=bool(w.get("natural"))) for i in range(1, k)]
-        scanned = sum(h.size for h in hays)
-        run_s, build_s, counts = [], [], None
-        for _ in range(REPS):
-            t1 = time.perf_counter()
-            m = oracle.Machine(needles)                              # build inside the timed region, as the reference does
-            t2 = time.perf_counter()
-            c = [m.count_matches(case, h) for h in hays]
-            t3 = time.perf_counter()
-            assert counts is None or counts == c, "oracle should have consistent output"      # benchmark.py:65-69
-            counts = c
-            build_s.append(t2 - t1); run_s.append(t3 - t2)
-            del m
-    finally:
-        if prev is not None:
-            os.sched_setaffinity(0, prev)
+    box = {}
+
+    def pinned_leg():
+        # in a THREAD OF ITS OWN: sched_setaffinity(0) pins the calling thread, and threads created while a thread is pinned inherit its mask -- pinning
+        # the main thread would leave every runtime thread HIP starts later (copy-completion handlers ...) on that one core for the rest of the process
+        # (seen in round 5: the Replacer's host-result rate fell from 44 to 26 GiB/s in runs that had taken this leg first)
+        prev, core = pin_to_one_core()
+        try:
+            # calibration: one haystack (also warms the page cache of the tables)
+            o, build0 = get_oracle(needles)
+            hay0 = synth.haystacks_host(needles, w["mixed"], 0, hay_cells, plants=args.plants, natural=bool(w.get("natural")))
+            t1 = time.perf_counter(); o.count_matches(case, hay0); per_hay = time.perf_counter() - t1
+            k = int(max(1, min(n_hay, 64, (args.cpu_seconds / REPS) / max(per_hay, 1e-6))))
+            hays = [hay0] + [synth.haystacks_host(needles, w["mixed"], i * hay_cells, hay_cells, plants=args.plants, natural=bool(w.get("natural"))) for i in range(1, k)]
+            run_s, build_s, counts = [], [], None
+            for _ in range(REPS):
+                t1 = time.perf_counter()
+                m = oracle.Machine(needles)                              # build inside the timed region, as the reference does
+                t2 = time.perf_counter()
+                c = [m.count_matches(case, h) for h in hays]
+                t3 = time.perf_counter()
+                assert counts is None or counts == c, "oracle should have consistent output"      # benchmark.py:65-69
+                counts = c
+                build_s.append(t2 - t1); run_s.append(t3 - t2)
+                del m
+            box.update(o=o, k=k, hays=hays, run_s=run_s, build_s=build_s, counts=counts, core=core)
+        except BaseException as e:                                        # noqa: BLE001 (carried to the caller's thread)
+            box["error"] = e
+        finally:
+            if prev is not None:
+                os.sched_setaffinity(0, prev)
+
+    import threading
+    t = threading.Thread(target=pinned_leg)
+    t.start(); t.join()
+    if "error" in box:
+        raise box["error"]
+    o, k, hays, run_s, build_s, counts, core = (box[x] for x in ("o", "k", "hays", "run_s", "build_s", "counts", "core"))
+    scanned = sum(h.size for h in hays)
     gpu_counts = np.zeros(n_hay, np.uint64)
     am.api.check(lib.am_count_batch(handle, case, batch, gpu_counts.ctypes.data, None))
     if [int(c) for c in gpu_counts[:k]] != counts:
