@@ -17,6 +17,7 @@ enum Key {
     kSfWq,                // AM_SF_WQ: walker-queue entries per wavefront (0: none)
     kSfWqIters,           // AM_SF_WQ_ITERS: trie steps a resolve batch takes before it parks
     kSfMaxBloomLog2Words, // AM_SF_MAX_BLOOM_LOG2_WORDS: cap on the LDS filter size (tests: dense filters)
+    kSfNoChildren,        // AM_SF_NO_CHILDREN: the flattener gives heavy depth-4 nodes no five-byte child entries (A/B; read when an image is flattened)
     kSfProbeTwo,          // AM_SF_PROBE_TWO: A/B -- automata with few 4-byte-suffix keys also take the instantiation whose probe rounds always look at two candidates per lane
     kNoSmallRun,          // AM_NO_SMALL_RUN: am_run on small batches takes the general path
     kNoIdsScan,           // AM_NO_IDS_SCAN: containsAll folds the records of a full scan (k_idset) instead of setting the id bits inside k_sf
@@ -34,7 +35,7 @@ struct Table {
 inline Table& table() { static Table t; return t; }
 inline const char* name_of(int k)
 {
-    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_NO_IDS_SCAN",
+    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_NO_IDS_SCAN",
                                               "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
                                               "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_LOOP"};
     return names[k];

@@ -532,77 +532,121 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         // before the suffix (k/K/KELVIN SIGN, i/I/İ, any non-ASCII letter) makes such a node, and left as "always look
         // closer" entries they are half of the candidates that reach phase 2.  The copies share key and node; the probe
         // ORs over the four candidate slots anyway.
-        struct HotEntry { uint32_t key, node, edge; };
+        // HEAVY nodes (round 5): a branching depth-4 node without a needle end that could not be split in place -- more than four children, or no room
+        // among its four candidate slots -- gets kT4Heavy in its hot word and one entry per child under the FIVE-byte key t4_key5(key, child byte),
+        // placed like any key (am_image.h, kT4Heavy).  Only automata with a small LDS filter (few distinct 4-byte suffixes) whose suffixes branch as a rule
+        // take them: that is the signature of a dictionary whose words share their endings (natural language: 100k words, 12k suffixes), and it is the
+        // k_sf instantiations with LW = 0 that look for them; the benchmark automata (random needles) have next to no such nodes and keep their probe as it was.
+        struct HotEntry { uint32_t key, node, edge; bool remote; };      // edge: 0 = the node as a whole, i + 1 = its child i; remote: placed under the five-byte key
+        auto place_key = [&](const HotEntry& e) -> uint32_t {
+            if (!e.remote) return e.key;
+            return t4_key5(e.key, edges_out[nodes[e.node].z + e.edge - 1].byte & 0xFFu);
+        };
+        bool want_children = h.sf_bloom_log2_words < 15 && !cfg::on(cfg::kSfNoChildren);
+        size_t potential_children = 0;
+        if (want_children) {
+            for (const TierEntry& e : tier_entries[3]) { const SfNode& nd = nodes[e.node]; const uint32_t c = nd.w & 0xFFFFu; if (!nd.x && c >= 2) potential_children += c; }
+            // worth it when branching is the rule (a dictionary: several children per suffix), not the odd IgnoreCase variant of a random needle set
+            if (potential_children < tier_entries[3].size()) { want_children = false; potential_children = 0; }
+        }
         std::vector<HotEntry> ents;
-        ents.reserve(tier_entries[3].size() + tier_entries[3].size() / 4);
-        for (const TierEntry& e : tier_entries[3]) ents.push_back(HotEntry{e.key, e.node, 0});
-        const size_t n_base = ents.size();
-        uint32_t lb = 2;
-        while (((uint64_t)2 << lb) * 75 < (uint64_t)ents.size() * 100) lb++;
         std::vector<uint32_t> owner;          // slot -> entry index
+        std::vector<uint8_t> heavy;           // per base entry: its children have entries of their own
+        size_t n_base = 0;
+        uint32_t lb = 2;
+        while (((uint64_t)2 << lb) * 75 < (uint64_t)(tier_entries[3].size() + potential_children) * 100) lb++;
+        uint32_t n_children = 0;
         for (;; lb++) {
             if (lb > 27) { err = "suffix table too large"; return -1; }
+            ents.clear();
+            ents.reserve(tier_entries[3].size() + tier_entries[3].size() / 4 + potential_children);
+            for (const TierEntry& e : tier_entries[3]) ents.push_back(HotEntry{e.key, e.node, 0, false});
+            n_base = ents.size();
+            heavy.assign(n_base, 0);
+            n_children = 0;
             owner.assign((size_t)2 << lb, kNone);
-            bool ok = true;
             uint32_t rng = 0x12345u;
-            for (uint32_t k = 0; k < n_base && ok; k++) {
-                uint32_t cur = k;
-                uint32_t bucket = t4_bucket(t4_hash_a(ents[cur].key), lb);
+            // one entry into the table, evicting along the way (cuckoo); false: no place found, the table grows
+            auto insert = [&](uint32_t first) -> int {
+                uint32_t cur = first;
+                uint32_t bucket = t4_bucket(t4_hash_a(place_key(ents[cur])), lb);
                 for (int kicks = 0;; kicks++) {
-                    const uint32_t ba = t4_bucket(t4_hash_a(ents[cur].key), lb), bb = t4_bucket(t4_hash_b(ents[cur].key), lb);
-                    bool placed = false;
+                    const uint32_t pk = place_key(ents[cur]);
+                    const uint32_t ba = t4_bucket(t4_hash_a(pk), lb), bb = t4_bucket(t4_hash_b(pk), lb);
                     for (uint32_t bsel : {ba, bb}) {
-                        for (uint32_t j = 0; j < 2 && !placed; j++) {
+                        for (uint32_t j = 0; j < 2; j++) {
                             uint32_t& o = owner[2u * bsel + j];
-                            if (o != kNone && ents[o].key == ents[cur].key && ents[o].edge == ents[cur].edge) { err = "duplicate suffix key (internal error)"; return -1; }
-                            if (o == kNone) { o = cur; placed = true; }
+                            if (o != kNone && ents[o].key == ents[cur].key && ents[o].edge == ents[cur].edge && ents[o].remote == ents[cur].remote) return -1;
+                            if (o == kNone) { o = cur; return 1; }
                         }
-                        if (placed) break;
                     }
-                    if (placed) break;
-                    if (kicks > 2000) { ok = false; break; }
+                    if (kicks > 2000) return 0;
                     // evict a pseudo-random resident of the bucket we did not come from
                     bucket = (bucket == ba) ? bb : ba;
                     rng = rng * 1664525u + 1013904223u;
                     std::swap(cur, owner[2u * bucket + (rng >> 31)]);
                 }
+            };
+            bool ok = true;
+            for (uint32_t k = 0; k < n_base && ok; k++) {
+                const int r = insert(k);
+                if (r < 0) { err = "duplicate suffix key (internal error)"; return -1; }
+                ok = r > 0;
+            }
+            if (!ok) continue;
+            // upgrade branching nodes IN PLACE: free slots among the key's four candidates, plus slots freed by moving a neighbour
+            // to a free slot of ITS other bucket (one step, no chains)
+            {
+                std::vector<uint32_t> where(n_base, kNone);
+                for (size_t sl = 0; sl < owner.size(); sl++) if (owner[sl] != kNone) where[owner[sl]] = (uint32_t)sl;
+                for (uint32_t k = 0; k < n_base; k++) {
+                    const SfNode& nd = nodes[ents[k].node];
+                    const uint32_t c = nd.w & 0xFFFFu;
+                    if (nd.x || c < 2 || c > 4) continue;
+                    const uint32_t ba = t4_bucket(t4_hash_a(ents[k].key), lb), bb = t4_bucket(t4_hash_b(ents[k].key), lb);
+                    uint32_t cand[4] = {2u * ba, 2u * ba + 1u, 2u * bb, 2u * bb + 1u};
+                    const uint32_t n_cand = ba == bb ? 2u : 4u;
+                    std::vector<uint32_t> room;
+                    for (uint32_t i = 0; i < n_cand; i++) if (owner[cand[i]] == kNone) room.push_back(cand[i]);
+                    for (uint32_t i = 0; i < n_cand && room.size() + 1 < c; i++) {
+                        const uint32_t o = owner[cand[i]];
+                        if (o == kNone || o == k || ents[o].key == ents[k].key) continue;
+                        const uint32_t oa = t4_bucket(t4_hash_a(ents[o].key), lb), ob = t4_bucket(t4_hash_b(ents[o].key), lb);
+                        const uint32_t other = (cand[i] >> 1) == oa ? ob : oa;
+                        if (other == ba || other == bb) continue;
+                        for (uint32_t j = 0; j < 2; j++) {
+                            if (owner[2u * other + j] != kNone) continue;
+                            owner[2u * other + j] = o;
+                            if (o < n_base) where[o] = 2u * other + j;
+                            owner[cand[i]] = kNone;
+                            room.push_back(cand[i]);
+                            break;
+                        }
+                    }
+                    if (room.size() + 1 < c) continue;                         // no room: the node keeps its single entry
+                    ents[k].edge = 1;
+                    for (uint32_t i = 1; i < c; i++) { owner[room[i - 1]] = (uint32_t)ents.size(); ents.push_back(HotEntry{ents[k].key, ents[k].node, i + 1, false}); }
+                }
+            }
+            // ... and the rest of them -- still one entry for a branching node without a needle end -- through five-byte entries anywhere in the table
+            if (want_children) {
+                for (uint32_t k = 0; k < n_base && ok; k++) {
+                    const SfNode& nd = nodes[ents[k].node];
+                    const uint32_t c = nd.w & 0xFFFFu;
+                    if (nd.x || c < 2 || ents[k].edge != 0) continue;
+                    heavy[k] = 1;
+                    for (uint32_t i = 0; i < c && ok; i++) {
+                        ents.push_back(HotEntry{ents[k].key, ents[k].node, i + 1, true});
+                        const int r = insert((uint32_t)ents.size() - 1u);
+                        if (r < 0) { err = "duplicate child key (internal error)"; return -1; }
+                        ok = r > 0;
+                        n_children++;
+                    }
+                }
             }
             if (ok) break;
         }
-        // upgrade branching nodes: free slots among the key's four candidates, plus slots freed by moving a neighbour
-        // to a free slot of ITS other bucket (one step, no chains)
-        {
-            std::vector<uint32_t> where(n_base, kNone);
-            for (size_t sl = 0; sl < owner.size(); sl++) if (owner[sl] != kNone) where[owner[sl]] = (uint32_t)sl;
-            for (uint32_t k = 0; k < n_base; k++) {
-                const SfNode& nd = nodes[ents[k].node];
-                const uint32_t c = nd.w & 0xFFFFu;
-                if (nd.x || c < 2 || c > 4) continue;
-                const uint32_t ba = t4_bucket(t4_hash_a(ents[k].key), lb), bb = t4_bucket(t4_hash_b(ents[k].key), lb);
-                uint32_t cand[4] = {2u * ba, 2u * ba + 1u, 2u * bb, 2u * bb + 1u};
-                const uint32_t n_cand = ba == bb ? 2u : 4u;
-                std::vector<uint32_t> room;
-                for (uint32_t i = 0; i < n_cand; i++) if (owner[cand[i]] == kNone) room.push_back(cand[i]);
-                for (uint32_t i = 0; i < n_cand && room.size() + 1 < c; i++) {
-                    const uint32_t o = owner[cand[i]];
-                    if (o == kNone || o == k || ents[o].key == ents[k].key) continue;
-                    const uint32_t oa = t4_bucket(t4_hash_a(ents[o].key), lb), ob = t4_bucket(t4_hash_b(ents[o].key), lb);
-                    const uint32_t other = (cand[i] >> 1) == oa ? ob : oa;
-                    if (other == ba || other == bb) continue;
-                    for (uint32_t j = 0; j < 2; j++) {
-                        if (owner[2u * other + j] != kNone) continue;
-                        owner[2u * other + j] = o;
-                        if (o < n_base) where[o] = 2u * other + j;
-                        owner[cand[i]] = kNone;
-                        room.push_back(cand[i]);
-                        break;
-                    }
-                }
-                if (room.size() + 1 < c) continue;                         // no room: the node keeps its single entry
-                ents[k].edge = 1;
-                for (uint32_t i = 1; i < c; i++) { owner[room[i - 1]] = (uint32_t)ents.size(); ents.push_back(HotEntry{ents[k].key, ents[k].node, i + 1}); }
-            }
-        }
+        h.sf_t4_children = n_children;
         h.tier_log2_cap[3] = lb;
         std::vector<u32x2> hot((size_t)1 << lb, u32x2{0, 0});
         std::vector<SfSlot> slots((size_t)2 << lb, SfSlot{0, 0, 0, 0, 0, 0, 0, 0, {0, 0, 0, 0}, 0, 0, 0, 0});
@@ -624,7 +668,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     if (!ch.x && (ch.w & 0xFFFFu) == 1u) { fixed = 2; sel2 = (ch.w >> 16) & 0xFFu; }
                 }
             }
-            if (e.edge) {                                                      // one child of a branching node
+            if (e.edge && !e.remote) {                                         // one child of a branching node, in one of the key's own slots
                 const SfEdge& ed = edges_out[nd.z + e.edge - 1];
                 fixed = 1; sel1 = ed.byte & 0xFFu;
                 if (ed.skip >= 1) { fixed = 2; sel2 = ed.label[3] >> 24; }
@@ -633,11 +677,30 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     if (!ch.x && (ch.w & 0xFFFFu) == 1u) { fixed = 2; sel2 = (ch.w >> 16) & 0xFFu; }
                 }
             }
-            const uint32_t word = t4_slot_word(t4_fingerprint(t4_hash_a(e.key), lb), fixed, sel1, sel2);
+            if (e.remote) {
+                // one child of a HEAVY node under the five-byte key: the child byte is part of the key, the selectors are the bytes BEHIND it (bytes six
+                // and seven of the context, in walk order) as far as the trie fixes them without a needle ending on the way
+                const SfEdge& ed = edges_out[nd.z + e.edge - 1];
+                fixed = 0;
+                if (ed.skip >= 2) { fixed = 2; sel1 = ed.label[3] >> 24; sel2 = (ed.label[3] >> 16) & 0xFFu; }
+                else {
+                    const SfNode& ch = nodes[ed.child];
+                    const bool chain = !ch.x && (ch.w & 0xFFFFu) == 1u;       // behind the edge: no needle end, one way on
+                    if (ed.skip == 1) {
+                        fixed = 1; sel1 = ed.label[3] >> 24;
+                        if (chain) { fixed = 2; sel2 = (ch.w >> 16) & 0xFFu; }
+                    } else if (chain) {
+                        fixed = 1; sel1 = (ch.w >> 16) & 0xFFu;
+                        if ((ch.w >> 24) >= 1u) { fixed = 2; sel2 = ch.label[3] >> 24; }
+                    }
+                }
+            }
+            uint32_t word = t4_slot_word(t4_fingerprint(t4_hash_a(place_key(e)), lb), fixed, sel1, sel2);
+            if (!e.edge && owner[sl] < n_base && heavy[owner[sl]]) word |= kT4Heavy;      // (fixed = 0 here: the bits above 15 are free)
             (&hot[sl >> 1].x)[sl & 1] = word;
             // the slot's line for phase 2: the depth-4 node, its single edge (or this copy's child edge) and that edge's child
             SfSlot& so = slots[sl];
-            so.key = e.key; so.flags = kSlotOccupied | (e.edge ? kSlotChildCopy : 0u);
+            so.key = e.key; so.flags = kSlotOccupied | (e.edge ? kSlotChildCopy : 0u);      // (a remote child's line is never asked for -- phase 2 reads the node's own slot -- but says the right thing)
             so.x = nd.x; so.y = nd.y;
             const SfNode* ch = nullptr;
             if (e.edge) {

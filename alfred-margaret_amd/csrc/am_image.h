@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 10;
+constexpr uint32_t kImageVersion = 11;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -70,6 +70,8 @@ struct ImageHeader {
     uint64_t checksum;          // of everything after the header (checked when an image comes from the host)
     uint64_t off_goto;          // AC: u32x4{state, cp, next, used}[1 << ac_goto_log2_cap], open addressing: (state, cp) -> goto target
     uint64_t off_fail;          // AC: u32[n_states] fallback state (the target of each state's wildcard entry)
+    uint32_t sf_t4_children;    // hot entries keyed by FIVE bytes (a heavy depth-4 node's children, am_flatten.cpp); 0: none, the probe never looks for them
+    uint32_t pad0;
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -154,6 +156,7 @@ struct SfView {
     uint32_t bloom_log2_words, tiers;
     uint32_t tier_log2_cap[4];
     uint32_t n_nodes;
+    uint32_t t4_children;    // the table holds five-byte child entries of heavy depth-4 nodes (sf_probe_children)
 };
 
 struct BatchView {
@@ -192,6 +195,7 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     v.edges = (const SfEdge*)(b + h.off_edges);
     v.edge_maps = (const SfEdgeMap*)(b + h.off_edge_maps);
     v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers; v.n_nodes = h.sf_n_nodes;
+    v.t4_children = h.sf_t4_children;
     return v;
 }
 
@@ -383,6 +387,15 @@ AM_HD uint32_t t4_fingerprint(uint32_t ha, uint32_t log2_buckets) { return (ha >
 // slot itself as the amount) blanks the selector fields that are not fixed.  Whether those bytes lie inside the
 // haystack is not checked here; phase 2 is exact, a candidate at the very start of a haystack is merely deferred.
 constexpr uint32_t kT4Occupied = 1u << 15;
+// HEAVY depth-4 nodes (round 5).  A node that branches, with no needle ending at it, fixes no byte before the suffix (k8 = 0): every position
+// with its 4-byte suffix is deferred.  Dictionaries of natural-language words are full of them ("tion", "ing ", "ness" have dozens of different
+// bytes before them): 329 deferred positions per KiB of natural text where 203 share SIX bytes with some needle.  Such a node's hot word carries
+// kT4Heavy (bits 16-31 of a k8 = 0 word are ignored by t4_slot_diff) and each of its children has a hot entry of its own under the FIVE-byte key
+// t4_key5(key, child byte), placed by the same cuckoo scheme anywhere in the table, with the child's own fixed bytes as selectors (bytes six
+// and seven of the context).  A position whose agreeing slot is heavy is deferred only if one of its child entries agrees as well
+// (sf_probe_children: two more buckets, requested when the first two have been looked at).
+constexpr uint32_t kT4Heavy = 1u << 16;
+AM_HD uint32_t t4_key5(uint32_t key, uint32_t b) { return (key ^ ((b + 1u) * 0x9E3779B1u)) + 0x7F4A7C15u; }
 AM_HD uint32_t t4_slot_word(uint32_t fp, uint32_t fixed_bytes, uint32_t sel1, uint32_t sel2)
 {
     return (8u * fixed_bytes) | (fp << 5) | kT4Occupied | (fixed_bytes >= 1 ? sel1 << 16 : 0u) | (fixed_bytes >= 2 ? sel2 << 24 : 0u);
@@ -439,6 +452,65 @@ AM_HD void sf_probe_decide(const SfView& s, const u32x2 (&ba)[N], const u32x2 (&
     }
 }
 
+// ... and whether EVERY slot that agreed is a heavy node's (kT4Heavy): then -- and only then: a plain slot of another key that agrees by its
+// fingerprint keeps the position deferred, as before -- the position is deferred only if a child entry agrees too (sf_probe_children)
+template <int N>
+AM_HD void sf_probe_heavy(const SfView& s, const u32x2 (&ba)[N], const u32x2 (&bb)[N], const uint32_t (&expect)[N], const bool (&defer)[N], bool (&heavy)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const uint32_t e = expect[k], words[4] = {ba[k].x, ba[k].y, bb[k].x, bb[k].y};
+        bool plain = false, hv = false;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const bool agree = t4_slot_diff(words[c], e) == 0u;
+            const bool is_heavy = (words[c] & (kT4Heavy | 0x1Fu)) == kT4Heavy;      // (k8 = 0: bits 16-31 are not selector bytes)
+            plain = plain || (agree && !is_heavy);
+            hv = hv || (agree && is_heavy);
+        }
+        // (with 1..3-byte needles every position is deferred for their tables' sake)
+        heavy[k] = defer[k] && (s.tiers & 7u) == 0u && hv && !plain;
+    }
+}
+
+// the child entries of heavy candidates: key5 = t4_key5(w, nearest byte before the window), expect5 = t4_expect(fingerprint of key5, the two bytes
+// before that); defer stays true only where one of the four slots of key5's two buckets agrees
+// hint[k] of a position a child entry speaks for becomes 4 | (which of key5's four slots): phase 2 then reads THAT slot's line -- the child's edge
+// and the node behind it, one or two steps further down than the heavy node's own line
+template <int N>
+AM_HD void sf_probe_children(const SfView& s, const uint32_t (&key5)[N], const uint32_t (&expect5)[N], const bool (&heavy)[N], bool (&defer)[N], uint32_t (&hint)[N])
+{
+    const uint32_t lb = s.tier_log2_cap[3];
+    u32x2 ca[N], cb[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        ca[k] = u32x2{0, 0}; cb[k] = ca[k];
+        if (heavy[k]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint2 ra = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(t4_hash_a(key5[k]), lb)), rb = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(t4_hash_b(key5[k]), lb));
+            ca[k] = u32x2{ra.x, ra.y}; cb[k] = u32x2{rb.x, rb.y};
+#else
+            ca[k] = s.t4_hot[t4_bucket(t4_hash_a(key5[k]), lb)]; cb[k] = s.t4_hot[t4_bucket(t4_hash_b(key5[k]), lb)];
+#endif
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (!heavy[k]) continue;
+        const uint32_t e = expect5[k];
+        const uint32_t za = t4_slot_diff(ca[k].x, e), zb = t4_slot_diff(ca[k].y, e), zc = t4_slot_diff(cb[k].x, e), zd = t4_slot_diff(cb[k].y, e);
+        defer[k] = za == 0u || zb == 0u || zc == 0u || zd == 0u;
+        if (defer[k]) hint[k] = 4u | (za == 0u ? 0u : zb == 0u ? 1u : zc == 0u ? 2u : 3u);
+    }
+}
+// the two inputs of sf_probe_children from the window and the THREE bytes before it (nbs: nearest in bits 0-7)
+AM_HD void t4_child_inputs(const SfView& s, uint32_t w, uint32_t nbs3, uint32_t& key5, uint32_t& expect5)
+{
+    key5 = t4_key5(w, nbs3 & 0xFFu);
+    expect5 = t4_expect(t4_fingerprint(t4_hash_a(key5), s.tier_log2_cap[3]), (nbs3 >> 8) & 0xFFFFu);
+}
+
+// nbs: the THREE bytes before the window (nearest in bits 0-7); the third only matters to heavy nodes' child entries
 template <int N>
 AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N],
                       const bool (&valid)[N], bool (&defer)[N], uint32_t (&hint)[N])
@@ -447,6 +519,13 @@ AM_HD void sf_probe_n(const SfView& s, const uint32_t (&w)[N], const uint32_t (&
     uint32_t expect[N];
     sf_probe_issue<N>(s, w, nbs, avail, valid, ba, bb, expect);
     sf_probe_decide<N>(s, ba, bb, expect, valid, defer, hint);
+    if (s.t4_children) {
+        bool heavy[N]; uint32_t key5[N], expect5[N];
+        sf_probe_heavy<N>(s, ba, bb, expect, defer, heavy);
+#pragma unroll
+        for (int k = 0; k < N; k++) t4_child_inputs(s, w[k], nbs[k], key5[k], expect5[k]);
+        sf_probe_children<N>(s, key5, expect5, heavy, defer, hint);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -473,7 +552,8 @@ AM_HD void node_from_raw(const u32x4& a, const u32x4& b, SfNode& n)
 // SHORT = false promises that the automaton has no needle (variant) shorter than 4 bytes (s.tiers & 7 == 0): step 5 and the
 // three small tables drop out of the kernel.  Depths are 32-bit: a needle is far shorter than 4 GiB, and the bytes
 // available in the haystack only matter up to that.
-// `hint` = which of the four candidate slots the probe saw agree (sf_probe_n); any value is correct, the right one saves loads.
+// `hint` = which of the four candidate slots the probe saw agree (sf_probe_n), or 4 | which of the four slots of the position's five-byte key (a child
+// entry of a heavy node); any value is correct, the right one saves loads.
 // `between` runs after the slot-line loads have been issued and before they are used: the kernel computes avail64 there
 // (haystack index -> offsets: two dependent loads of its own), so that chain overlaps with haystack bytes -> slot line
 // instead of preceding it.  avail64 is not read before that.
@@ -518,7 +598,11 @@ AM_HD void sf_resolve_head(const SfView& s, const uint8_t* text, const uint64_t 
             const uint32_t ba = look[k] ? t4_bucket(t4_hash_a(w[k]), lb) : 0u, bb = look[k] ? t4_bucket(t4_hash_b(w[k]), lb) : 0u;
             slot_of[0][k] = 2u * ba; slot_of[1][k] = 2u * ba + 1u; slot_of[2][k] = 2u * bb; slot_of[3][k] = 2u * bb + 1u;
             const uint32_t h = hint[k] & 3u;
-            const uint32_t idx = h == 0 ? slot_of[0][k] : h == 1 ? slot_of[1][k] : h == 2 ? slot_of[2][k] : slot_of[3][k];
+            uint32_t idx = h == 0 ? slot_of[0][k] : h == 1 ? slot_of[1][k] : h == 2 ? slot_of[2][k] : slot_of[3][k];
+            if (look[k] && (hint[k] & 4u)) {                     // a heavy node's child spoke for the position: its line sits under the five-byte key
+                const uint32_t k5 = t4_key5(w[k], w2[k] >> 24);
+                idx = 2u * ((h & 2u) ? t4_bucket(t4_hash_b(k5), lb) : t4_bucket(t4_hash_a(k5), lb)) + (h & 1u);
+            }
             q0[k] = slots16[4u * idx]; q1[k] = slots16[4u * idx + 1u]; q2[k] = slots16[4u * idx + 2u]; q3[k] = slots16[4u * idx + 3u];
         }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -773,7 +857,7 @@ AM_HD bool sf_verify(const SfView& s, const uint8_t* text, uint64_t gpos, uint64
     uint32_t w, w2;
     load_suffix8(text, gpos, w, w2);
     if (IC) { w = fold_dword(w); w2 = fold_dword(w2); }
-    const uint32_t wa[1] = {w}, nba[1] = {(w2 >> 24) | (((w2 >> 16) & 0xFFu) << 8)};
+    const uint32_t wa[1] = {w}, nba[1] = {(w2 >> 24) | (((w2 >> 16) & 0xFFu) << 8) | (((w2 >> 8) & 0xFFu) << 16)};
     const uint64_t a[1] = {avail};
     const bool v[1] = {true};
     bool defer[1]; uint32_t hint[1];

@@ -95,6 +95,14 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
 {
     constexpr int kSfThreads = NT, kSfWaves = NT / 64;      // (shadow the namespace constants: the body is written against these names)
     constexpr bool kFlagMode = MODE == kModeAny || MODE == kModeIds;      // a flagged haystack is not looked at any further (containsAny: matched; containsAll: every needle seen)
+    // CH: this instantiation looks for the five-byte child entries of heavy depth-4 nodes (am_image.h kT4Heavy) -- LW 0: a small LDS filter, i.e. few
+    // distinct 4-byte suffixes: with many needles that is a dictionary whose words share their endings (natural language: 100k words, 12k suffixes); the
+    // 128-KiB-filter instantiations carry none of it (the flattener makes such entries for small filters only, and a kernel that ignores them defers
+    // every position of a heavy node, as before)
+    constexpr bool CH = LW == 0 && !kFlagMode;
+    // chunks per ring epoch (the ring is drained at its end; an entry names its chunk within the epoch): flag mode drains every 4 chunks -- the first match is
+    // what everybody waits for --, CH every 8 (bit 15 of an entry says "the slot of a child entry")
+    constexpr uint32_t kEpoch = kFlagMode ? 4u : CH ? 8u : kSfEpochChunks;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
@@ -222,8 +230,8 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             for (int k = 0; k < RN; k++) {
                 valid[k] = 64u * k + lane < nb;
                 const uint32_t item = valid[k] ? lds_read_u16(q2 + 2u * ((q2_head + 64u * k + lane) % kSfQ2)) : 0u;
-                gpos[k] = (epoch_base_chunk + (item >> 12)) * kSfChunk + (item & 1023u);
-                hint[k] = (item >> 10) & 3u;
+                gpos[k] = (epoch_base_chunk + ((item >> 12) & (kEpoch - 1u))) * kSfChunk + (item & 1023u);
+                hint[k] = ((item >> 10) & 3u) | (CH ? (item >> 13) & 4u : 0u);
                 hlo[k] = hhi[k] = 0; end_pos[k] = 0;
                 if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
             }
@@ -404,13 +412,15 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     // ---- phase 1, second half: look at the buckets requested by the last probe round, park the survivors in the ring
     u32x2 p_a[2], p_b[2];                                  // the raw buckets (loads possibly still in flight)
     uint32_t p_e[2] = {0, 0}, p_pos[2] = {0, 0};           // the word a matching slot equals; offset in the chunk | 0x8000 (0: no candidate)
+    uint32_t p_k5[2] = {0, 0}, p_e5[2] = {0, 0};           // CH: the candidates' five-byte key and the word a matching child entry equals
     uint32_t p_ci = 0;                                     // chunk (within its epoch) the round belongs to
     bool pending = false, p_two = false;                   // p_two: the round has more than 64 candidates (two per lane; else only item 0 is live)
     p_a[0] = p_a[1] = p_b[0] = p_b[1] = u32x2{0, 0};
     auto consume_round = [&]() {
         auto park = [&](bool defer, uint32_t hint, uint32_t pos) {
             const uint64_t m = __ballot(defer);
-            if (defer) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | (hint << 10) | (pos & 1023u));
+            // (CH: epochs of 8 chunks leave bit 15 for "the slot of a child entry", hint bit 2)
+            if (defer) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | ((hint & 3u) << 10) | (pos & 1023u) | (CH ? (hint & 4u) << 13 : 0u));
             q2_tail += (uint32_t)__popcll(m);
             if (timing) n_defer += (uint32_t)__popcll(m);
         };
@@ -420,6 +430,13 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
 #pragma unroll
             for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x8000u) != 0;
             sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
+            if (CH && s.t4_children) {
+                // candidates whose only agreeing slot is a heavy node's: their child entries decide -- two more buckets, requested now and waited for
+                // (one more trip through L2 for the round; what it spares is a 64-byte slot line and a walk per rejected position)
+                bool heavy[2];
+                sf_probe_heavy<2>(s, p_a, p_b, p_e, defer, heavy);
+                if (wave_any(heavy[0] || heavy[1])) sf_probe_children<2>(s, p_k5, p_e5, heavy, defer, hint);
+            }
             if (ablate == 4) { defer[0] = false; defer[1] = false; }      // timing experiment only: no resolve
             park(defer[0], hint[0], p_pos[0]);
             park(defer[1], hint[1], p_pos[1]);
@@ -430,6 +447,11 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             const bool valid[1] = {(p_pos[0] & 0x8000u) != 0};
             bool defer[1]; uint32_t hint[1];
             sf_probe_decide<1>(s, a1, b1, e1, valid, defer, hint);
+            if (CH && s.t4_children) {
+                bool heavy[1];
+                sf_probe_heavy<1>(s, a1, b1, e1, defer, heavy);
+                if (wave_any(heavy[0])) { const uint32_t k5[1] = {p_k5[0]}, e5[1] = {p_e5[0]}; sf_probe_children<1>(s, k5, e5, heavy, defer, hint); }
+            }
             if (ablate == 4) defer[0] = false;
             park(defer[0], hint[0], p_pos[0]);
         }
@@ -473,7 +495,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     // of the haystack its chunk lies in -- as the whole device has left it, one chunk ago: the load has a chunk's time -- and skips the chunk
     // if it is set.  A 1-GiB document that matches in its first KiB costs a few chunks per wavefront, not the scan.
     uint32_t any_word = 0, any_hay = kNone, flagged_hay = kNone;      // the flag word requested last, whose it is; the haystack known to be flagged
-    constexpr uint32_t kEpoch = kFlagMode ? 4u : kSfEpochChunks;      // (flag mode drains its ring every 4 chunks: the first match is what everybody waits for)
+
     uint64_t u_next = u;
     for (; u < n_units; u = u_next) {
         // the unit after this one (its first chunk is prefetched while this unit's last chunk is processed)
@@ -654,12 +676,24 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                         const uint32_t pos = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
                         // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on
                         // top), nb = the two before it, nearest in bits 0-7
+                        if (CH) {
+                            // bytes pos-6 .. pos (stage offset 10 + pos): the THIRD byte before the window too -- a child entry may fix it
+                            const uint32_t a = 10u + pos, sh = a & 3u;
+                            const uint32_t sp = stage + (a & ~3u);
+                            const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
+                            const uint32_t three = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFFFu;      // bytes pos-6, pos-5, pos-4
+                            const uint32_t nbs3 = (three >> 16) | (three & 0xFF00u) | ((three & 0xFFu) << 16);      // nearest in bits 0-7
+                            nb[k] = nbs3 & 0xFFFFu;
+                            w[k] = sh < 1u ? __builtin_amdgcn_alignbyte(x1, x0, 3u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 1u);
+                            if (s.t4_children) t4_child_inputs(s, w[k], nbs3, p_k5[k], p_e5[k]);
+                        } else {
                         const uint32_t a = 11u + pos, sh = a & 3u;
                         const uint32_t sp = stage + (a & ~3u);
                         const uint32_t x0 = lds_read_u32(sp), x1 = lds_read_u32(sp + 4u), x2 = lds_read_u32(sp + 8u);
                         const uint32_t two = __builtin_amdgcn_alignbyte(x1, x0, sh) & 0xFFFFu;
                         nb[k] = (two >> 8) | ((two & 0xFFu) << 8);
                         w[k] = sh < 2u ? __builtin_amdgcn_alignbyte(x1, x0, sh + 2u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 2u);
+                        }
                         const uint64_t gpos = c0 + pos;
                         avail[k] = gpos - hs0 + 1;
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
@@ -871,7 +905,7 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
         if (sf_chunks(b) <= kSfLightChunks)
             return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true, false, kSfLightThreads>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false, false, kSfLightThreads>(s, b, o, n_cu, st);
         return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
-    }
+    } else {
     if ((o.ablate || o.dbg) && !kFlagMode) {                                          // experiments (AM_SF_ABLATE)
         if (!lw15) return launch_sf_v<IC, MODE, 2, 0, true, true>(s, b, o, n_cu, st);
         return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 15, true, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 15, false, true>(s, b, o, n_cu, st);
@@ -886,6 +920,7 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
     }
     if (few) return lw15 ? launch_sf_v<IC, MODE, 1, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 1, 0, false>(s, b, o, n_cu, st);
     return lw15 ? launch_sf_v<IC, MODE, 2, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
+    }
 }
 
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o_in, int n_cu, hipStream_t st)

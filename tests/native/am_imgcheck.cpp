@@ -13,6 +13,10 @@
 
 using namespace am;
 
+// which == 1 scans: candidates that passed the Bloom filter, positions the probe deferred, positions where a needle ends (measurement aid:
+// how good the probe is on a given automaton + text, without a GPU)
+static uint64_t g_stats[3] = {0, 0, 0};
+
 namespace {
 struct Rec { uint32_t hay; uint32_t state; uint64_t end_pos; uint32_t vlen; };
 struct Collect {
@@ -22,6 +26,8 @@ struct Collect {
 }  // namespace
 
 extern "C" {
+void amchk_stats(uint64_t* out3, int reset) { for (int i = 0; i < 3; i++) { out3[i] = g_stats[i]; if (reset) g_stats[i] = 0; } }
+
 
 // Flatten only: returns image size (or -1) -- lets tests inspect the header.
 // (lower_from / lower_to / n_pairs: the caller's lower-case table as am_automaton_create_ex takes it; null = built-in)
@@ -107,11 +113,12 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                         bool defer[2]; uint32_t hint[2] = {0, 0};
                         for (int k = 0; k < 2; k++) if (valid[k]) {
                             for (uint32_t j = 0; j < 4; j++) { uint32_t byte = g[k] >= j ? padded[(size_t)(g[k] - j)] : 0u; wv[k] |= byte << (24u - 8u * j); }
-                            uint32_t b1 = g[k] >= 4 ? padded[(size_t)(g[k] - 4)] : 0u, b2 = g[k] >= 5 ? padded[(size_t)(g[k] - 5)] : 0u;
-                            if (ic) { wv[k] = fold_dword(wv[k]); b1 = fold_byte(b1); b2 = fold_byte(b2); }
-                            nbv[k] = b1 | (b2 << 8);
+                            uint32_t b1 = g[k] >= 4 ? padded[(size_t)(g[k] - 4)] : 0u, b2 = g[k] >= 5 ? padded[(size_t)(g[k] - 5)] : 0u, b3 = g[k] >= 6 ? padded[(size_t)(g[k] - 6)] : 0u;
+                            if (ic) { wv[k] = fold_dword(wv[k]); b1 = fold_byte(b1); b2 = fold_byte(b2); b3 = fold_byte(b3); }
+                            nbv[k] = b1 | (b2 << 8) | (b3 << 16);
                         }
                         sf_probe_n<2>(s, wv, nbv, a, valid, defer, hint);
+                        for (int k = 0; k < 2; k++) if (valid[k]) { g_stats[0]++; if (defer[k]) g_stats[1]++; }
                         // phase 2, two items in lock step as in the kernel
                         bool todo[2] = {valid[0] && defer[0], valid[1] && defer[1]};
                         if (ic) sf_resolve_n<true, 2>(s, padded.data(), g, a, todo, hint, found, st, vl);
@@ -124,7 +131,7 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                             found[k] = ic ? sf_resolve<true>(s, padded.data(), g[k], a[k], st[k], vl[k], hint) : sf_resolve<false>(s, padded.data(), g[k], a[k], st[k], vl[k], hint);
                         }
                     }
-                    for (int k = 0; k < 2; k++) if (valid[k] && found[k]) recs.push_back({hay[k], st[k], a[k], vl[k]});
+                    for (int k = 0; k < 2; k++) if (valid[k] && found[k]) { recs.push_back({hay[k], st[k], a[k], vl[k]}); if (which == 1) g_stats[2]++; }
                 }
             }
         }

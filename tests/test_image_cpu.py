@@ -193,3 +193,37 @@ def test_wide_fan_out_below_the_suffix(chk, seed):
                 n, recs = chk.scan(img, which, hays)
                 assert n >= 0
                 assert expand_records(vo, vals, recs[0], recs[1], recs[2]) == exp, (case, which, needles[:6])
+
+
+def test_heavy_suffix_nodes_get_five_byte_child_entries():
+    """Round 5 (am_image.h kT4Heavy): in a dictionary of natural-language words the 4-byte suffixes branch as a rule ("tion", "ing ", "ness": dozens of
+    different bytes before them; 100k words share 12k suffixes), and a branching depth-4 node used to defer every position with its suffix.  The flattener
+    now gives such nodes one hot entry per child under the five-byte key, the probe asks for them where a heavy node is all that speaks for a position,
+    and phase 2 starts from the child's slot line.  On the CPU (the image interpreter = the kernels' own probe / resolve code): the records are the
+    oracle's through both scan modes, and the probe defers a quarter fewer positions than the suffix alone would."""
+    import ctypes as C
+    import struct
+    from alfred_margaret_amd import synth
+    needles = synth.needles_for("natural_100k_10GiB")
+    m = oracle.Machine(needles)
+    chk = ImgCheck()
+    img = chk.flatten(m, 1)
+    n_children, = struct.unpack_from("<I", img[:256].tobytes(), 248)          # ImageHeader::sf_t4_children
+    assert n_children > 5_000, n_children
+    text = bytes(synth.haystacks_host(needles, True, 5, 192, natural=True))
+    hays = [text[:65536], text[65536:65536 + 70000], b"", text[140000:]]
+    exp = oracle_triples(m, 1, hays)
+    chk.lib.amchk_stats.restype = None
+    stats = (C.c_uint64 * 3)()
+    chk.lib.amchk_stats(stats, 1)
+    for which in (1, 2):
+        n, recs = chk.scan(img, which, hays)
+        hay, st, end, vl = recs
+        assert expand_records(m.values_off(), m.values(), hay, st, end) == exp, which
+    chk.lib.amchk_stats(stats, 1)
+    kib = len(text) / 1024.0
+    cand, deferred, found = (stats[i] / kib for i in range(3))
+    assert found > 120 and deferred < 0.7 * cand and deferred < 270, (cand, deferred, found)      # 403 candidates, 328 deferred without the child entries, 242 with them
+    # the benchmark automata (random needles: branching suffixes are the exception) get none
+    img3 = chk.flatten(oracle.Machine(synth.needles_for("cfg3_runLower_100k_10GiB")[:20000]), 1)
+    assert struct.unpack_from("<I", img3[:256].tobytes(), 248)[0] == 0
