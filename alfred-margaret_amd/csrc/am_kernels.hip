@@ -100,9 +100,10 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
     // 128-KiB-filter instantiations carry none of it (the flattener makes such entries for small filters only, and a kernel that ignores them defers
     // every position of a heavy node, as before)
     constexpr bool CH = LW == 0 && !kFlagMode;
+    const bool children = CH && s.t4_children != 0u;      // (uniform) the image has such entries: an automaton without them runs exactly the code it ran before
     // chunks per ring epoch (the ring is drained at its end; an entry names its chunk within the epoch): flag mode drains every 4 chunks -- the first match is
-    // what everybody waits for --, CH every 8 (bit 15 of an entry says "the slot of a child entry")
-    constexpr uint32_t kEpoch = kFlagMode ? 4u : CH ? 8u : kSfEpochChunks;
+    // what everybody waits for --, with child entries every 8 (bit 15 of an entry says "the slot of a child entry")
+    const uint32_t kEpoch = kFlagMode ? 4u : children ? 8u : kSfEpochChunks;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 valid[k] = 64u * k + lane < nb;
                 const uint32_t item = valid[k] ? lds_read_u16(q2 + 2u * ((q2_head + 64u * k + lane) % kSfQ2)) : 0u;
                 gpos[k] = (epoch_base_chunk + ((item >> 12) & (kEpoch - 1u))) * kSfChunk + (item & 1023u);
-                hint[k] = ((item >> 10) & 3u) | (CH ? (item >> 13) & 4u : 0u);
+                hint[k] = ((item >> 10) & 3u) | ((CH && children) ? (item >> 13) & 4u : 0u);
                 hlo[k] = hhi[k] = 0; end_pos[k] = 0;
                 if (valid[k]) { hlo[k] = b.hidx[gpos[k] >> kHidxShift]; hhi[k] = b.hidx[(gpos[k] >> kHidxShift) + 1]; }
             }
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         auto park = [&](bool defer, uint32_t hint, uint32_t pos) {
             const uint64_t m = __ballot(defer);
             // (CH: epochs of 8 chunks leave bit 15 for "the slot of a child entry", hint bit 2)
-            if (defer) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | ((hint & 3u) << 10) | (pos & 1023u) | (CH ? (hint & 4u) << 13 : 0u));
+            if (defer) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | ((hint & 3u) << 10) | (pos & 1023u) | (CH ? (hint & 4u) << 13 : 0u));      // (hint bit 2 is only ever set with child entries)
             q2_tail += (uint32_t)__popcll(m);
             if (timing) n_defer += (uint32_t)__popcll(m);
         };
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
 #pragma unroll
             for (int k = 0; k < 2; k++) valid[k] = (p_pos[k] & 0x8000u) != 0;
             sf_probe_decide<2>(s, p_a, p_b, p_e, valid, defer, hint);
-            if (CH && s.t4_children) {
+            if (CH && children) {
                 // candidates whose only agreeing slot is a heavy node's: their child entries decide -- two more buckets, requested now and waited for
                 // (one more trip through L2 for the round; what it spares is a 64-byte slot line and a walk per rejected position)
                 bool heavy[2];
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             const bool valid[1] = {(p_pos[0] & 0x8000u) != 0};
             bool defer[1]; uint32_t hint[1];
             sf_probe_decide<1>(s, a1, b1, e1, valid, defer, hint);
-            if (CH && s.t4_children) {
+            if (CH && children) {
                 bool heavy[1];
                 sf_probe_heavy<1>(s, a1, b1, e1, defer, heavy);
                 if (wave_any(heavy[0])) { const uint32_t k5[1] = {p_k5[0]}, e5[1] = {p_e5[0]}; sf_probe_children<1>(s, k5, e5, heavy, defer, hint); }
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                         const uint32_t pos = valid[k] ? lds_read_u16(q1 + 2u * e) : 0u;
                         // bytes pos-5 .. pos of the staged chunk (stage offset 11 + pos): window = the last four (newest on
                         // top), nb = the two before it, nearest in bits 0-7
-                        if (CH) {
+                        if (CH && children) {
                             // bytes pos-6 .. pos (stage offset 10 + pos): the THIRD byte before the window too -- a child entry may fix it
                             const uint32_t a = 10u + pos, sh = a & 3u;
                             const uint32_t sp = stage + (a & ~3u);
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                             const uint32_t nbs3 = (three >> 16) | (three & 0xFF00u) | ((three & 0xFFu) << 16);      // nearest in bits 0-7
                             nb[k] = nbs3 & 0xFFFFu;
                             w[k] = sh < 1u ? __builtin_amdgcn_alignbyte(x1, x0, 3u) : __builtin_amdgcn_alignbyte(x2, x1, sh - 1u);
-                            if (s.t4_children) t4_child_inputs(s, w[k], nbs3, p_k5[k], p_e5[k]);
+                            t4_child_inputs(s, w[k], nbs3, p_k5[k], p_e5[k]);
                         } else {
                         const uint32_t a = 11u + pos, sh = a & 3u;
                         const uint32_t sp = stage + (a & ~3u);
