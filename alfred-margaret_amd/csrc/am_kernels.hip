@@ -90,20 +90,20 @@ constexpr uint32_t kSfMaskBytes = kBloomMasks * 4u;      // the Bloom mask table
 // reads an SGPR or needs the VOP3 encoding on gfx950, tools/microbench/valu_rates*.hip); 0 = any size
 // DBG: the timing / ablation experiments (AM_SF_ABLATE) live in their own instantiations, the production kernel
 // carries none of their code, registers or branches.
-template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG, int NT = kSfThreads>
+template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG, int NT = kSfThreads, bool CHILDREN = false>
 __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uint64_t n_chunks)
 {
     constexpr int kSfThreads = NT, kSfWaves = NT / 64;      // (shadow the namespace constants: the body is written against these names)
     constexpr bool kFlagMode = MODE == kModeAny || MODE == kModeIds;      // a flagged haystack is not looked at any further (containsAny: matched; containsAll: every needle seen)
-    // CH: this instantiation looks for the five-byte child entries of heavy depth-4 nodes (am_image.h kT4Heavy) -- LW 0: a small LDS filter, i.e. few
-    // distinct 4-byte suffixes: with many needles that is a dictionary whose words share their endings (natural language: 100k words, 12k suffixes); the
-    // 128-KiB-filter instantiations carry none of it (the flattener makes such entries for small filters only, and a kernel that ignores them defers
-    // every position of a heavy node, as before)
-    constexpr bool CH = LW == 0 && !kFlagMode;
-    const bool children = CH && s.t4_children != 0u;      // (uniform) the image has such entries: an automaton without them runs exactly the code it ran before
+    // CHILDREN: this instantiation looks for the five-byte child entries of heavy depth-4 nodes (am_image.h kT4Heavy).  It exists for <ILP 2, LW 0, no short
+    // needles> only and is launched for images that have such entries: many needles behind a small LDS filter, i.e. few distinct 4-byte suffixes -- a
+    // dictionary whose words share their endings (natural language: 100k words, 12k suffixes).  Every other instantiation carries none of it (this kernel's
+    // hot loop pays for every instruction and register it does not need: compiled in behind a run-time flag the same code cost cfg2 20 %); a kernel that
+    // ignores the entries defers every position of a heavy node, as before.
+    constexpr bool CH = CHILDREN, children = CHILDREN;
     // chunks per ring epoch (the ring is drained at its end; an entry names its chunk within the epoch): flag mode drains every 4 chunks -- the first match is
     // what everybody waits for --, with child entries every 8 (bit 15 of an entry says "the slot of a child entry")
-    const uint32_t kEpoch = kFlagMode ? 4u : children ? 8u : kSfEpochChunks;
+    constexpr uint32_t kEpoch = kFlagMode ? 4u : CH ? 8u : kSfEpochChunks;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const uint32_t words = 1u << s.bloom_log2_words;
     uint32_t* masks = lds;                                            // LDS bytes [0, kSfMaskBytes)
@@ -844,7 +844,7 @@ static uint32_t sf_wq_cap(const SfView& s, int waves)
 }
 size_t sf_lds_bytes(const SfView& s) { return sf_lds_bytes_w(s, kSfWaves); }
 
-template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false, int NT = kSfThreads>
+template <bool IC, int MODE, int ILP, int LW, bool SHORT, bool DBG = false, int NT = kSfThreads, bool CHILDREN = false>
 static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     constexpr int waves_per_wg = NT / 64;
@@ -854,7 +854,7 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         // allow the full 160 KiB of a CU's LDS as dynamic shared memory (not fatal if the runtime objects)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT, CHILDREN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             (void)hipGetLastError();
         attr_set = true;
     }
@@ -873,7 +873,7 @@ static hipError_t launch_sf_v(const SfView& s, const BatchView& b, const ScanOut
     if (n_units <= blocks * waves_per_wg) oo.next_unit = nullptr;          // one unit per wavefront at most: nothing to draw
     // (else: *next_unit is zero -- it lives in the batch's 64-byte counter block, which every caller clears before the launch together with
     // its other counters; a memset of its own here was one more dispatch in every call)
-    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT>), dim3((uint32_t)blocks), dim3(NT), lds, st, s, b, oo, n_chunks);
+    hipLaunchKernelGGL((k_sf<IC, MODE, ILP, LW, SHORT, DBG, NT, CHILDREN>), dim3((uint32_t)blocks), dim3(NT), lds, st, s, b, oo, n_chunks);
     return hipGetLastError();
 }
 
@@ -920,6 +920,7 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
         return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
     if (few) return lw15 ? launch_sf_v<IC, MODE, 1, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 1, 0, false>(s, b, o, n_cu, st);
+    if (!lw15 && s.t4_children && !kFlagMode) return launch_sf_v<IC, MODE, 2, 0, false, false, kSfThreads, true>(s, b, o, n_cu, st);      // a dictionary with heavy suffix nodes
     return lw15 ? launch_sf_v<IC, MODE, 2, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
     }
 }
