@@ -178,12 +178,13 @@ def test_slices_with_offsets():
     assert [(int(h), int(p), int(v)) for h, p, v in zip(hay, pos, val)] == [(0, 12, 0), (0, 13, 1), (1, 12, 0), (1, 13, 1)]
 
 
-@pytest.mark.parametrize("workload,n_cells,hay_cells", [("cfg2_runText_10k_1GiB", 4096, 64), ("cfg3_runLower_100k_10GiB", 2048, 256)])
+@pytest.mark.parametrize("workload,n_cells,hay_cells", [("cfg2_runText_10k_1GiB", 4096, 64), ("cfg3_runLower_100k_10GiB", 2048, 256), ("natural_100k_10GiB", 1024, 100)])
 def test_synthetic_workload_reduced(workload, n_cells, hay_cells):
-    """BASELINE configs at a size the oracle finishes in seconds; full record lists compared."""
+    """BASELINE configs at a size the oracle finishes in seconds; full record lists compared.  natural: a dictionary of natural-language words over text
+    made of them -- a match every five bytes, heavy suffix nodes with five-byte child entries (k_sf's CHILDREN instantiation), the walker queue."""
     w = synth.WORKLOADS[workload]
     needles = synth.needles_for(workload)
-    text = synth.haystacks_host(needles, w["mixed"], 0, n_cells)
+    text = synth.haystacks_host(needles, w["mixed"], 0, n_cells, natural=bool(w.get("natural")))
     hays = [text[i * hay_cells * 1024:(i + 1) * hay_cells * 1024] for i in range(n_cells // hay_cells)]
     o = oracle.Machine(needles)
     a = am.Automaton(needles)
