@@ -358,8 +358,8 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
         count_s = time.perf_counter() - t1
         gate_args = copy.copy(args)
         gate_args.kernel, gate_args.parity_oracle_mib = 0, args.workloads_oracle_mib
-        parity = parity_gate(gate_args, w, needles, machine, handle, case, batch, text, n_hay, 0, 1, dev, lib)
-        contains_all = contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib) if name == "cfg2_runText_10k_1GiB" else None
+        parity = parity_gate(gate_args, w, needles, machine, handle, case, batch, text, n_hay, 0, 1, dev, lib) if not args.no_parity else {}
+        contains_all = contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib) if name == "cfg2_runText_10k_1GiB" and not args.no_parity else None
     finally:
         lib.am_batch_destroy(batch)
     avg_ms = ms.value / max(int(launches.value), 1)
@@ -435,7 +435,7 @@ def extra_workloads(args, dev, lib, cfg3_machine, cfg3_needles):
                  "config": {k: r["config"][k] for k in ("n_pairs", "case", "haystacks_per_gpu", "haystack_bytes", "bytes_per_gpu")}, "passes": r["passes"],
                  "kernel_ms_per_step": {k: v for k, v in r["kernel_ms_per_step"].items() if v >= 0.05},
                  "roofline": {k: r["roofline"][k] for k in ("kernel", "avg_launch_ms", "launches", "alg_bytes_per_launch", "achieved", "frac", "traffic")},
-                 "parity": {k: r["parity"][k] for k in ("loops_agree", "oracle_checked")}, "build_s": r["config"]["build_s"]}
+                 "parity": {k: r["parity"][k] for k in ("loops_agree", "oracle_checked")} if "parity" in r else None, "build_s": r["config"]["build_s"]}
         elif name == "cfg4_100k_1M_haystacks":
             e = measure_scan_workload(args, name, dev, lib, machine=cfg3_machine, needles=cfg3_needles, n_hay=synth.WORKLOADS[name]["n_hay"] // 8, steps=args.workload_steps)
             e["config"]["share"] = "one rank's block of 8 (dist.shard_bounds): 131072 of 1048576 haystacks"
@@ -678,12 +678,13 @@ def measure_replacer(args, workload, rank, world, dev, steps=None, warmup=None, 
                          "alg_bytes_per_launch": int(alg_bytes),
                          "note": "k_%s runs every pass of every haystack (one wavefront per haystack): bound by dependent-load latency, not by HBM" % kname if kname in ("rp_loop", "rp_lds") else None},
         }
-        if world == 1:
+        if world == 1 and not args.no_parity:
             out["parity"] = replacer_parity(args, w, pairs, case, rdev, batch, text, n_hay, n_bytes, last["res"], lib, dev, cpu_seconds=2.0 if extra else args.cpu_seconds)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = out["parity"].pop("cpu_baseline")
             else:
                 out["parity"].pop("cpu_baseline")
+        if world == 1:
             out["host_results"]["d2h_wire_gibps"] = d2h_wire_rate(dev)
     lib.am_replaced_free(last["res"])
     lib.am_batch_destroy(batch)

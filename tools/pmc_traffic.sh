@@ -15,11 +15,11 @@ for spec in cfg3_runLower_100k_10GiB:2048 cfg2_runText_10k_1GiB:32768 cfg4_100k_
   python "$R/tools/pmc_summary.py" "$OUT/$W" "k_sf" > "$OUT/$W.txt" 2>&1
   rm -rf "$OUT/$W"
 done
-# the Replacer's one-kernel loop on config 5 (4096 haystacks = 256 MiB of input: every wavefront slot busy once)
+# the Replacer's one-kernel loop (k_rp_lds: a haystack's lists in LDS) on config 5 (4096 haystacks = 256 MiB of input: every wavefront slot busy once)
 W=cfg5_replacer_50k_1GiB
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$OUT/$W/$C" -o p -- python "$R/bench.py" --workload $W --hay-count 4096 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/$W.$C.log" 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$OUT/$W/$C" -o p -- python "$R/bench.py" --workload $W --hay-count 4096 --steps 2 --warmup 1 --no-cpu-baseline --no-parity > "$OUT/$W.$C.log" 2>&1
   echo "$W $C rc=$?"
 done
-python "$R/tools/pmc_summary.py" "$OUT/$W" "k_rp_loop" > "$OUT/$W.txt" 2>&1
+python "$R/tools/pmc_summary.py" "$OUT/$W" "k_rp_lds" > "$OUT/$W.txt" 2>&1
 rm -rf "$OUT/$W"
