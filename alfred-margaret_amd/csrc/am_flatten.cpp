@@ -8,6 +8,7 @@
 #include "am_config.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -545,7 +546,10 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         bool want_children = h.sf_bloom_log2_words < 15 && !cfg::on(cfg::kSfNoChildren);
         size_t potential_children = 0;
         if (want_children) {
-            for (const TierEntry& e : tier_entries[3]) { const SfNode& nd = nodes[e.node]; const uint32_t c = nd.w & 0xFFFFu; if (!nd.x && c >= 2) potential_children += c; }
+            for (const TierEntry& e : tier_entries[3]) {
+                const SfNode& nd = nodes[e.node]; const uint32_t c = nd.w & 0xFFFFu;
+                if (!nd.x && c >= 2) potential_children += c;
+            }
             // worth it when branching is the rule (a dictionary: several children per suffix), not the odd IgnoreCase variant of a random needle set
             if (potential_children < tier_entries[3].size()) { want_children = false; potential_children = 0; }
         }
@@ -595,8 +599,10 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             }
             if (!ok) continue;
             // upgrade branching nodes IN PLACE: free slots among the key's four candidates, plus slots freed by moving a neighbour
-            // to a free slot of ITS other bucket (one step, no chains)
-            {
+            // to a free slot of ITS other bucket (one step, no chains).  Not for a dictionary (want_children): in-place copies and their siblings fill the
+            // two buckets of their key and cannot move, and a table a third of whose buckets are such blocks has no room for the walk that places the five-byte
+            // entries (measured: 26k entries needed 2^18 slots); there every branching node takes the five-byte route.
+            if (!want_children) {
                 std::vector<uint32_t> where(n_base, kNone);
                 for (size_t sl = 0; sl < owner.size(); sl++) if (owner[sl] != kNone) where[owner[sl]] = (uint32_t)sl;
                 for (uint32_t k = 0; k < n_base; k++) {

@@ -914,13 +914,15 @@ static hipError_t launch_sf_t(const SfView& s, const BatchView& b, const ScanOut
     if (sf_chunks(b) <= kSfLightChunks)                                                     // one small document: the light configuration
         return (s.tiers & 7u) ? launch_sf_v<IC, MODE, 2, 0, true, false, kSfLightThreads>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false, false, kSfLightThreads>(s, b, o, n_cu, st);
     // few 4-byte-suffix keys (a hot table of <= 2^15 buckets: up to ~30k needles) = a handful of candidates per chunk: the one-per-lane probe round
+    // a dictionary with heavy suffix nodes (the image has five-byte child entries): its own instantiation, two candidates per lane whatever the table's size
+    // (such text leaves hundreds of candidates per chunk)
+    if (!lw15 && s.t4_children && !(s.tiers & 7u) && !kFlagMode) return launch_sf_v<IC, MODE, 2, 0, false, false, kSfThreads, true>(s, b, o, n_cu, st);
     const bool few = s.tier_log2_cap[3] <= 15u && !o.probe_two;
     if (s.tiers & 7u) {                                                                     // needles shorter than 4 bytes present
         if (few) return lw15 ? launch_sf_v<IC, MODE, 1, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 1, 0, true>(s, b, o, n_cu, st);
         return lw15 ? launch_sf_v<IC, MODE, 2, 15, true>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, true>(s, b, o, n_cu, st);
     }
     if (few) return lw15 ? launch_sf_v<IC, MODE, 1, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 1, 0, false>(s, b, o, n_cu, st);
-    if (!lw15 && s.t4_children && !kFlagMode) return launch_sf_v<IC, MODE, 2, 0, false, false, kSfThreads, true>(s, b, o, n_cu, st);      // a dictionary with heavy suffix nodes
     return lw15 ? launch_sf_v<IC, MODE, 2, 15, false>(s, b, o, n_cu, st) : launch_sf_v<IC, MODE, 2, 0, false>(s, b, o, n_cu, st);
     }
 }
