@@ -572,6 +572,9 @@ def bench_single_process(args, w):
     lib.am_multi_destroy(multi)
 
 
+VRAM_WIPE_SETTLE_S = 3.0
+
+
 def measure_replacer(args, workload, rank, world, dev, steps=None, warmup=None, extra=False):
     """--workload cfg5_replacer_50k_1GiB (BASELINE.json configs[4]): one step = Replacer.run over the whole batch,
     every pass on the device.  Like the scan metric (records stay in HBM), `value` is measured with the rewritten texts
@@ -628,7 +631,12 @@ def measure_replacer(args, workload, rank, world, dev, steps=None, warmup=None, 
         passes, scanned = step()
     fence()
     elapsed = amdist.allreduce_max(time.perf_counter() - t0, dev)
-    # the same steps with the results brought to the host (PCIe-inclusive; reported next to `value`, never as `value`)
+    # the same steps with the results brought to the host (PCIe-inclusive; reported next to `value`, never as `value`).
+    # First let the driver finish wiping VRAM that was freed a moment ago (the workload before this one, the generator's temporaries): amdgpu clears freed
+    # VRAM in the background THROUGH THE SDMA ENGINES, and for about a second after a large hipFree every device->host copy runs at 27 instead of 53 GiB/s
+    # (measured in round 5, tools/experiments/host_results/: 39 ms per step in that second, 22.4 ms before and after; LABNOTES R5.6)
+    fence()
+    time.sleep(VRAM_WIPE_SETTLE_S)
     step(False)
     fence()
     t0 = time.perf_counter()
@@ -670,7 +678,8 @@ def measure_replacer(args, workload, rank, world, dev, steps=None, warmup=None, 
                        "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": n_bytes, "parallelism": "haystack-sharded x%d" % world, "build_s": round(build_s, 2)},
             "results": "device-resident (am_replacer_run_batch_device)",
             "host_results": {"value": round(n_bytes * world / float(1 << 30) * steps / elapsed_host, 3), "unit": "GiB/s", "ms_per_step": round(elapsed_host / steps * 1e3, 3),
-                             "what": "am_replacer_run_batch: the same passes plus every rewritten text copied over PCIe into pinned host memory"},
+                             "what": "am_replacer_run_batch: the same passes plus every rewritten text copied over PCIe into pinned host memory",
+                             "settled_s": VRAM_WIPE_SETTLE_S},
             "passes": passes, "scanned_gib_per_step": round(total_scanned / float(1 << 30), 2), "spliced_gib_per_step": round(spliced / float(1 << 30), 2),
             "kernel_ms_per_step": {k: round(v[0] / prof_steps, 3) for k, v in prof.items() if v[1]},
             "roofline": {"bound": "hbm", "kernel": "k_" + kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
