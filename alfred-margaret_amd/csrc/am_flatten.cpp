@@ -282,7 +282,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 
     std::vector<SfNode> nodes;
     std::vector<SfEdge> edges_out;
-    std::vector<SfEdgeMap> edge_maps;
+    std::vector<uint32_t> many_nodes;                 // nodes with more than 4 children (they get a row of edge lines)
+    uint32_t row_first = 0;
     std::vector<TierEntry> tier_entries[4];
 
     if (h.sf_enabled && !terminals.empty()) {
@@ -449,19 +450,16 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 rec.w = n;
                 if (n <= 4) for (uint32_t i = 0; i < n; i++) rec.label[0] |= cedges[c_order[c_first[x] + i]].byte << (8u * i);   // inline selectors
                 else {
-                    // more children: a map of the selector bytes with running counts (the edges are sorted by selector byte)
-                    SfEdgeMap mp{{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
+                    // more children: the node gets a ROW of edge lines below (row displacement); here only the order of the edges is checked
                     uint32_t prev = 0;
                     for (uint32_t i = 0; i < n; i++) {
                         const uint32_t b = cedges[c_order[c_first[x] + i]].byte & 0xFFu;
                         if (i && b <= prev) { err = "edges of a node are not sorted by selector byte (internal error)"; return -1; }
                         prev = b;
-                        mp.bits[b >> 5] |= 1u << (b & 31u);
+                        const uint32_t f = b % 96u;
+                        rec.label[1 + f / 32u] |= 1u << (f & 31u);
                     }
-                    uint32_t run = 0;
-                    for (uint32_t wv = 0; wv < 8; wv++) { mp.cum[wv] = (uint8_t)run; run += (uint32_t)__builtin_popcount(mp.bits[wv]); }
-                    rec.label[0] = (uint32_t)edge_maps.size();
-                    edge_maps.push_back(mp);
+                    many_nodes.push_back(new_id[x]);
                 }
                 for (uint32_t e = c_first[x]; e < c_first[x + 1]; e++) {
                     const CEdge& ce = cedges[c_order[e]];
@@ -471,7 +469,47 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 }
             }
         }
+        // Row displacement for the nodes with more than 4 children: node -> row offset r such that the lines r + b of all its selector bytes b are free
+        // (first fit, largest nodes first); the edge of byte b is then ONE load away, edges[label[0] + b], and that line names its owner (SfEdge::pad).
+        row_first = (uint32_t)edges_out.size();
+        std::vector<uint32_t> row_of(many_nodes.size(), 0);
+        std::vector<uint8_t> occ;
+        {
+            std::vector<uint32_t> order(many_nodes.size());
+            for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (nodes[many_nodes[a]].w & 0xFFFFu) > (nodes[many_nodes[b]].w & 0xFFFFu); });
+            size_t first_free = 0;
+            for (uint32_t oi : order) {
+                const SfNode& nd = nodes[many_nodes[oi]];
+                const uint32_t n = nd.w & 0xFFFFu, b_min = edges_out[nd.z].byte, b_max = edges_out[nd.z + n - 1].byte;
+                while (first_free < occ.size() && occ[first_free]) first_free++;
+                size_t r = first_free > b_min ? first_free - b_min : 0;
+                for (uint32_t tries = 0;; r++, tries++) {
+                    if (tries == 8192) { r = occ.size(); break; }                     // (a crowded table: open a fresh stretch instead of searching on)
+                    bool fits = true;
+                    for (uint32_t i = 0; i < n && fits; i++) { const size_t at = r + edges_out[nd.z + i].byte; fits = at >= occ.size() || !occ[at]; }
+                    if (fits) break;
+                }
+                if (occ.size() < r + b_max + 1) occ.resize(r + b_max + 1, 0);
+                for (uint32_t i = 0; i < n; i++) occ[r + edges_out[nd.z + i].byte] = 1;
+                row_of[oi] = (uint32_t)r;
+            }
+            if (!many_nodes.empty()) occ.resize(occ.size() + 256, 0);             // label[0] + b stays inside the array for every byte b
+            if ((uint64_t)row_first + occ.size() >= 0xFFFFFFF0ull) { err = "too many edge lines"; return -1; }
+            for (uint32_t i = 0; i < many_nodes.size(); i++) nodes[many_nodes[i]].label[0] = row_first + row_of[i];
+        }
         for (SfEdge& ed : edges_out) ed.to = nodes[ed.child];          // every edge's line carries its child's (now final) record
+        if (!many_nodes.empty()) {
+            edges_out.resize((size_t)row_first + occ.size(), SfEdge{0, 0, 0, kNone, {0, 0, 0, 0}, SfNode{0, 0, 0, 0, {0, 0, 0, 0}}});
+            for (uint32_t i = 0; i < many_nodes.size(); i++) {
+                const SfNode& nd = nodes[many_nodes[i]];
+                for (uint32_t e = 0; e < (nd.w & 0xFFFFu); e++) {
+                    SfEdge line = edges_out[nd.z + e];
+                    line.pad = nd.z + 1u;
+                    edges_out[(size_t)nd.label[0] + line.byte] = line;
+                }
+            }
+        }
 
         // suffix tables: every byte path of length <= 4 from the root (never inside a compressed edge)
         struct Frame { uint32_t node, depth, key; };
@@ -492,7 +530,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
 
     h.sf_n_nodes = (uint32_t)nodes.size();
     h.n_edges = edges_out.size();
-    h.n_edge_maps = edge_maps.size();
+    h.n_edge_maps = 0; h.sf_row_first = row_first;
     h.sf_tiers = 0;
     size_t total_keys = 0;
     for (int t = 0; t < 4; t++) { if (!tier_entries[t].empty()) h.sf_tiers |= 1u << t; total_keys += tier_entries[t].size(); }
@@ -722,7 +760,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             } else if (n_edges == 0) {
                 so.w = 0; so.z = 0;
             } else {
-                so.w = n_edges; so.z = e.node; so.ez = nd.z; so.el0 = nd.label[0];      // branching and not split: phase 2 starts its walk from this line
+                so.w = n_edges; so.z = e.node; so.ez = nd.z; so.el0 = nd.label[0]; so.label[1] = nd.label[1]; so.label[2] = nd.label[2]; so.label[3] = nd.label[3];      // branching and not split: phase 2 starts its walk from this line
             }
             if (ch) { so.cx = ch->x; so.cy = ch->y; so.cw = ch->w; }
         }
@@ -731,7 +769,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     }
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);
-    h.off_edge_maps = blob.put(edge_maps);
+    h.off_edge_maps = 0;
     blob.reserve_section(16);      // tail padding
     h.total_bytes = blob.bytes.size();
     h.checksum = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
@@ -813,20 +851,24 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         if (ne == 1 && (n.z >= h.sf_n_nodes || (n.w >> 24) > kMaxSkip)) { err = "image: node child out of range"; return false; }
         if (ne > 1 && ((uint64_t)n.z + ne > h.n_edges)) { err = "image: node edge range out of range"; return false; }
     }
+    if (h.sf_row_first > h.n_edges) { err = "image: row region out of range"; return false; }
     for (uint64_t i = 0; i < h.n_edges; i++) {
-        if (edges[i].child >= h.sf_n_nodes || edges[i].skip > kMaxSkip) { err = "image: edge out of range"; return false; }
+        if (i >= h.sf_row_first && edges[i].pad == kNone) continue;                                        // an empty line of the row region
+        if ((i < h.sf_row_first) != (edges[i].pad == 0)) { err = "image: edge line with a wrong owner mark"; return false; }
+        if (edges[i].child >= h.sf_n_nodes || edges[i].skip > kMaxSkip || edges[i].byte > 0xFFu) { err = "image: edge out of range"; return false; }
         if (std::memcmp(&edges[i].to, &nodes[edges[i].child], sizeof(SfNode)) != 0) { err = "image: an edge's copy of its child differs from the child"; return false; }
     }
-    {
-        const SfEdgeMap* maps = (const SfEdgeMap*)(img + h.off_edge_maps);
-        for (uint32_t i = 0; i < h.sf_n_nodes; i++) {
-            const uint32_t ne = nodes[i].w & 0xFFFFu;
-            if (ne <= 4) continue;
-            if (nodes[i].label[0] >= h.n_edge_maps) { err = "image: selector map out of range"; return false; }
-            const SfEdgeMap& mp = maps[nodes[i].label[0]];
-            uint32_t run = 0;
-            for (uint32_t wv = 0; wv < 8; wv++) { if (mp.cum[wv] != (uint8_t)run) { err = "image: selector map counts are wrong"; return false; } run += (uint32_t)__builtin_popcount(mp.bits[wv]); }
-            if (run != ne) { err = "image: selector map does not match the edge count"; return false; }
+    for (uint32_t i = 0; i < h.sf_n_nodes; i++) {
+        const uint32_t ne = nodes[i].w & 0xFFFFu;
+        if (ne <= 4) continue;
+        // its row: inside the array for every selector byte, and each of its edges is there under its byte, marked as this node's
+        if (nodes[i].label[0] < h.sf_row_first || (uint64_t)nodes[i].label[0] + 256u > h.n_edges) { err = "image: a node's row is out of range"; return false; }
+        for (uint32_t e = 0; e < ne; e++) {
+            const SfEdge& own = edges[nodes[i].z + e];
+            const SfEdge& line = edges[(uint64_t)nodes[i].label[0] + own.byte];
+            const uint32_t f = own.byte % 96u;
+            if (line.pad != nodes[i].z + 1u || line.byte != own.byte || line.child != own.child || line.skip != own.skip || std::memcmp(line.label, own.label, 16) != 0 ||
+                !((nodes[i].label[1 + f / 32u] >> (f & 31u)) & 1u)) { err = "image: a node's row does not hold its edges"; return false; }
         }
     }
     for (int t = 0; t < 3; t++) {
@@ -857,7 +899,7 @@ bool image_sections_in_bounds(const ImageHeader& h)
                 h.ac_goto_log2_cap >= 4 && h.ac_goto_log2_cap <= 31 && ok(h.off_goto, 1ull << h.ac_goto_log2_cap, 16) && ok(h.off_fail, h.n_states, 4);
     if (h.sf_enabled) {
         if (h.sf_bloom_log2_words > 20) return false;
-        good = good && ok(h.off_bloom, 1ull << h.sf_bloom_log2_words, 4) && ok(h.off_nodes, h.sf_n_nodes, 32) && ok(h.off_edges, h.n_edges, 64) && ok(h.off_edge_maps, h.n_edge_maps, 64);
+        good = good && ok(h.off_bloom, 1ull << h.sf_bloom_log2_words, 4) && ok(h.off_nodes, h.sf_n_nodes, 32) && ok(h.off_edges, h.n_edges, 64) && h.n_edge_maps == 0;
         for (int t = 0; t < 4; t++) {
             if (!(h.sf_tiers & (1u << t))) continue;
             if (h.tier_log2_cap[t] > 30) return false;

@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 11;
+constexpr uint32_t kImageVersion = 12;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -64,14 +64,14 @@ struct ImageHeader {
     uint64_t off_nodes;         // SfNode[sf_n_nodes]  (32 B: record + inline label of the single outgoing edge)
     uint64_t off_edges;         // SfEdge[n_edges]     (64 B: out-edges of nodes with more than one child, each with a copy of its child's record)
     uint64_t n_edges;
-    uint64_t off_edge_maps;     // SfEdgeMap[n_edge_maps] (64 B: which selector bytes a node with more than 4 children has, with running counts)
+    uint64_t off_edge_maps;     // (images before version 12: selector maps of the nodes with more than 4 children; now 0, see sf_row_first)
     uint64_t n_edge_maps;
     uint64_t off_t4_slots;      // cold side of tier 4: one 64-byte SfSlot per cuckoo slot (2 per bucket): full key + the depth-4 node, its single edge and that edge's child
     uint64_t checksum;          // of everything after the header (checked when an image comes from the host)
     uint64_t off_goto;          // AC: u32x4{state, cp, next, used}[1 << ac_goto_log2_cap], open addressing: (state, cp) -> goto target
     uint64_t off_fail;          // AC: u32[n_states] fallback state (the target of each state's wildcard entry)
     uint32_t sf_t4_children;    // hot entries keyed by FIVE bytes (a heavy depth-4 node's children, am_flatten.cpp); 0: none, the probe never looks for them
-    uint32_t pad0;
+    uint32_t sf_row_first;      // edges[sf_row_first .. n_edges): the ROWS of the nodes with more than 4 children (SfNode::label, SfEdge::pad)
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -102,22 +102,20 @@ struct alignas(32) SfNode {
     uint32_t z;          // n_edges == 1: child node; n_edges > 1: first SfEdge index
     uint32_t w;          // n_edges (bits 0-15) | selector byte of the single edge (16-23) | its skip length (24-31)
     uint32_t label[4];   // n_edges == 1: skip bytes of the single edge; 2..4 edges: label[0] = their selector bytes (edge i in byte i);
-                         // more: label[0] = index of the node's SfEdgeMap
+                         // more: label[0] = the node's ROW: the edge of selector byte b is the line edges[label[0] + b], if that line is this
+                         // node's (SfEdge::pad); label[1..3] = which selector bytes exist, folded to 96 bits (bit b % 96): a clear bit saves the load
 };
 // An out-edge of a branching node, one 64-byte line: the edge AND a copy of the child's record, so that one step of the walk
 // (choose the edge, compare its label, arrive at the child) is one dependent load.
 struct alignas(64) SfEdge {
-    uint32_t byte, child, skip, pad;
+    uint32_t byte, child, skip;
+    uint32_t pad;        // 0 in a node's contiguous run of edges [z, z + n); in the row region (>= sf_row_first): owner's SfNode::z + 1, kNone = empty line
     uint32_t label[4];
     SfNode to;           // = nodes[child]
 };
-// Which selector bytes a node with more than 4 children has: edge of byte b = first edge + cum[b >> 5] + popcount(bits[b >> 5] below bit b & 31)
-// (the edges are sorted by selector byte).  One 64-byte line instead of a binary search over the edges (one dependent load per probe).
-struct alignas(64) SfEdgeMap {
-    uint32_t bits[8];
-    uint8_t cum[8];
-    uint32_t pad[6];
-};
+// A node with more than 4 children finds the edge of selector byte b WITHOUT a lookup structure of its own: row displacement.  The flattener gives the
+// node a row offset such that the lines  row + b  of all its selector bytes are free, and puts copies of its edges there (am_flatten.cpp); a line
+// says whose it is.  One dependent load per step for every kind of node (a selector map per node, as before version 12, cost such a step a second trip).
 constexpr uint32_t kMaxSkip = 16;
 
 // Cold side of the 4-byte-suffix table: one 64-byte line per cuckoo slot, so that the position of a hot slot that matched IS the
@@ -132,9 +130,9 @@ struct alignas(64) SfSlot {
                            // bits 16-23 selector byte, 24-31 skip length of that edge
     uint32_t z;            // w & 0xFFFF == 1: child node id; >= 2: the depth-4 node's own id
     uint32_t cx, cy;       // needle end at the child (state + 1, vlen)
-    uint32_t label[4];     // skip bytes of the edge (text order, right-aligned)
+    uint32_t label[4];     // skip bytes of the edge (text order, right-aligned); branching node: label[1..3] = its SfNode::label[1..3]
     uint32_t cw;           // the child's SfNode::w (its edge count decides whether the walk goes on)
-    uint32_t ez, el0;      // branching node (w & 0xFFFF >= 2): its SfNode::z (first edge) and label[0] (inline selectors / selector map), so
+    uint32_t ez, el0;      // branching node (w & 0xFFFF >= 2): its SfNode::z (first edge) and label[0] (inline selectors / row), so
                            // that the walk starts from this line without loading the node's record
     uint32_t pad;
 };
@@ -152,7 +150,6 @@ struct SfView {
     const SfSlot* t4_slots;  // 2 per bucket, same index as the hot slot
     const SfNode* nodes;
     const SfEdge* edges;
-    const SfEdgeMap* edge_maps;
     uint32_t bloom_log2_words, tiers;
     uint32_t tier_log2_cap[4];
     uint32_t n_nodes;
@@ -193,7 +190,6 @@ inline SfView make_sf_view(const void* base, const ImageHeader& h)
     for (int t = 0; t < 4; t++) v.tier_log2_cap[t] = h.tier_log2_cap[t];
     v.nodes = (const SfNode*)(b + h.off_nodes);
     v.edges = (const SfEdge*)(b + h.off_edges);
-    v.edge_maps = (const SfEdgeMap*)(b + h.off_edge_maps);
     v.bloom_log2_words = h.sf_bloom_log2_words; v.tiers = h.sf_tiers; v.n_nodes = h.sf_n_nodes;
     v.t4_children = h.sf_t4_children;
     return v;
@@ -675,6 +671,7 @@ AM_HD void sf_resolve_head(const SfView& s, const uint8_t* text, const uint64_t 
         } else {                                                                                           // branching: the walk starts at the depth-4 node itself
             go[k] = true; node[k] = sl[k].z; have_rec[k] = true;
             rec[k].x = sl[k].x; rec[k].y = sl[k].y; rec[k].z = sl[k].ez; rec[k].w = kind; rec[k].label[0] = sl[k].el0;
+            rec[k].label[1] = sl[k].label[1]; rec[k].label[2] = sl[k].label[2]; rec[k].label[3] = sl[k].label[3];      // (more than 4 children: which selector bytes exist)
         }
     }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -691,7 +688,6 @@ AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t 
 {
     const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
     const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 4 x 16 B per edge
-    const u32x4* maps16 = reinterpret_cast<const u32x4*>(s.edge_maps);   // 4 x 16 B per map
     bool any_load = false;
 #pragma unroll
     for (int k = 0; k < N; k++) any_load = any_load || (go[k] && !have_rec[k]);
@@ -716,40 +712,26 @@ AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t 
         }
         // One step of the walk = ONE round of loads for all lanes: a single-edge node has its edge inline (selector, skip, label) and
         // needs its child's record; a branching node needs the chosen edge's 64-byte line, which carries the child's record; the 16
-        // haystack bytes the label is compared with depend only on the depth.  Only a node with more than 4 children takes a round of
-        // its own first (its selector map).
-        uint32_t which[N], next[N], skip[N], label[N][4], bsel[N];
-        bool many[N], any_many = false;
+        // haystack bytes the label is compared with depend only on the depth.  A node with more than 4 children reads the line of its
+        // row that the selector byte names, and sees there whether that line is its own.
+        uint32_t which[N], next[N], skip[N], label[N][4], owner[N];
 #pragma unroll
         for (int k = 0; k < N; k++) {
-            which[k] = kNone; next[k] = kNone; skip[k] = 0; many[k] = false; bsel[k] = 0;
+            which[k] = kNone; next[k] = kNone; skip[k] = 0; owner[k] = 0;
             label[k][0] = rec[k].label[0]; label[k][1] = rec[k].label[1]; label[k][2] = rec[k].label[2]; label[k][3] = rec[k].label[3];
             if (!go[k]) continue;
             const uint32_t n_edges = rec[k].w & 0xFFFFu;
             uint32_t b;
             if (depth[k] < 8) b = (w2[k] >> (8u * (7u - depth[k]))) & 0xFFu;
             else { b = text[gpos[k] - depth[k]]; if (IC) b = fold_byte(b); }
-            bsel[k] = b;
             if (n_edges == 1) {
                 if (((rec[k].w >> 16) & 0xFFu) == b) { next[k] = rec[k].z; skip[k] = rec[k].w >> 24; }
             } else if (n_edges <= 4) {
                 for (uint32_t i = 0; i < n_edges; i++) if (((rec[k].label[0] >> (8u * i)) & 0xFFu) == b) which[k] = rec[k].z + i;
-            } else many[k] = true;
-            any_many = any_many || many[k];
-        }
-        if (wave_any(any_many)) {
-            u32x4 m0[N], m1[N], m2[N];
-#pragma unroll
-            for (int k = 0; k < N; k++) { const uint32_t mi = many[k] ? rec[k].label[0] : 0u; m0[k] = maps16[4u * mi]; m1[k] = maps16[4u * mi + 1u]; m2[k] = maps16[4u * mi + 2u]; }
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                if (!many[k]) continue;
-                const uint32_t b = bsel[k], wi = b >> 5;
-                const uint32_t bits[8] = {m0[k].x, m0[k].y, m0[k].z, m0[k].w, m1[k].x, m1[k].y, m1[k].z, m1[k].w};
-                uint32_t word = 0, cum = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < 8; i++) if (i == wi) { word = bits[i]; cum = ((i < 4 ? m2[k].x : m2[k].y) >> (8u * (i & 3u))) & 0xFFu; }
-                if ((word >> (b & 31u)) & 1u) which[k] = rec[k].z + cum + (uint32_t)__builtin_popcount(word & ((1u << (b & 31u)) - 1u));
+            } else {
+                const uint32_t f = b >= 192u ? b - 192u : b >= 96u ? b - 96u : b;                                  // b % 96
+                const uint32_t fw = f < 32u ? rec[k].label[1] : f < 64u ? rec[k].label[2] : rec[k].label[3];
+                if ((fw >> (f & 31u)) & 1u) { which[k] = rec[k].label[0] + b; owner[k] = rec[k].z + 1u; }
             }
         }
         SfNode child[N];
@@ -773,6 +755,7 @@ AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t 
             }
 #pragma unroll
             for (int k = 0; k < N; k++) {
+                if (which[k] != kNone && owner[k] && e0[k].w != owner[k]) which[k] = kNone;      // a row line of another node (or an empty one): no such edge
                 if (which[k] != kNone) {
                     next[k] = e0[k].y; skip[k] = e0[k].z;                       // SfEdge {byte, child, skip, pad, label[4], to}
                     label[k][0] = e1[k].x; label[k][1] = e1[k].y; label[k][2] = e1[k].z; label[k][3] = e1[k].w;
