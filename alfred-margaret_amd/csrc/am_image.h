@@ -679,15 +679,32 @@ AM_HD void sf_resolve_head(const SfView& s, const uint8_t* text, const uint64_t 
 #endif
 }
 
+constexpr uint32_t kSelUnknown = 0x100u;
+// byte `idx` (0..15, text order) of 16 haystack bytes held as four little-endian dwords
+AM_HD uint32_t byte_of_16(const uint32_t (&t)[4], uint32_t idx)
+{
+    const uint32_t t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];      // (unconditional loads with constant indices: the array stays in registers)
+    const uint32_t d = idx < 8u ? (idx < 4u ? t0 : t1) : (idx < 12u ? t2 : t3);
+    return (d >> (8u * (idx & 3u))) & 0xFFu;
+}
+
 // ---- step 4: walk the compressed trie backwards along the haystack to the deepest needle end
 template <bool IC, int N>
 AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t (&gpos)[N], const uint32_t (&avail)[N], const uint32_t (&w2)[N],
                            bool (&go)[N], const uint32_t (&node)[N], SfNode (&rec)[N], const bool (&have_rec)[N], uint32_t (&depth)[N],
                            uint32_t (&best_state)[N], uint32_t (&best_vlen)[N], uint64_t* dbg_iters = nullptr, uint32_t max_iters = 0xFFFFFFFFu,
-                           const uint32_t (*t16)[4] = nullptr)      // t16 (optional): the head's 16 folded bytes before the 4-byte suffix = what a step at depth 4 compares with
+                           const uint32_t (*t16)[4] = nullptr,      // t16 (optional): the head's 16 folded bytes before the 4-byte suffix = what a step at depth 4 compares with
+                           uint32_t* sel_io = nullptr)              // (optional, N values, in and out) the next selector byte where a previous step already saw it, else kSelUnknown
 {
     const u32x4* nodes16 = reinterpret_cast<const u32x4*>(s.nodes);      // 2 x 16 B per node
     const u32x4* edges16 = reinterpret_cast<const u32x4*>(s.edges);      // 4 x 16 B per edge
+    // The selector byte of a step (the haystack byte at gpos - depth) comes from registers whenever something already loaded it: the 8 bytes of the
+    // suffix word (depth < 8), the head's 16 bytes (depth 5..20), or the 16 bytes the PREVIOUS step compared its label with (they end right before
+    // that step's selector, and the label is at most 16 long: only a 16-byte label leaves the next selector outside).  A load of its own would be a
+    // dependent trip in front of the edge line's.
+    uint32_t sel[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) sel[k] = sel_io ? sel_io[k] : kSelUnknown;
     bool any_load = false;
 #pragma unroll
     for (int k = 0; k < N; k++) any_load = any_load || (go[k] && !have_rec[k]);
@@ -722,7 +739,9 @@ AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t 
             if (!go[k]) continue;
             const uint32_t n_edges = rec[k].w & 0xFFFFu;
             uint32_t b;
-            if (depth[k] < 8) b = (w2[k] >> (8u * (7u - depth[k]))) & 0xFFu;
+            if (sel[k] != kSelUnknown) b = sel[k];
+            else if (depth[k] < 8) b = (w2[k] >> (8u * (7u - depth[k]))) & 0xFFu;
+            else if (t16 && depth[k] <= 20) b = byte_of_16(t16[k], 20u - depth[k]);
             else { b = text[gpos[k] - depth[k]]; if (IC) b = fold_byte(b); }
             if (n_edges == 1) {
                 if (((rec[k].w >> 16) & 0xFFu) == b) { next[k] = rec[k].z; skip[k] = rec[k].w >> 24; }
@@ -769,11 +788,16 @@ AM_HD void sf_resolve_walk(const SfView& s, const uint8_t* text, const uint64_t 
         for (int k = 0; k < N; k++) {
             if (!go[k]) continue;
             if (skip[k] && !label_match(t[k], label[k], skip[k])) { go[k] = false; continue; }
+            sel[k] = skip[k] < 16u ? byte_of_16(t[k], 15u - skip[k]) : kSelUnknown;      // t = the 16 bytes before this step's selector
             depth[k] += 1u + skip[k];
             rec[k] = child[k];
             if (rec[k].x) { best_state[k] = rec[k].x; best_vlen[k] = rec[k].y; }
             go[k] = depth[k] < avail[k] && (rec[k].w & 0xFFFFu) != 0;
         }
+    }
+    if (sel_io) {
+#pragma unroll
+        for (int k = 0; k < N; k++) sel_io[k] = sel[k];
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (dbg_iters) { const uint64_t now = __builtin_amdgcn_s_memtime(); dbg_iters[5] += now - dbg_iters[7]; dbg_iters[7] = now; }

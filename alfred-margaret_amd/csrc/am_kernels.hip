@@ -180,7 +180,8 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         SfNode rec[1] = {SfNode{0, 0, a2.x, a2.y, {a2.z, a2.w, a3.x, a3.y}}};
         bool go[1] = {valid}, have_rec[1] = {true};
         wave_lds_fence();                                   // the entries are in registers before anything overwrites them
-        sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen);
+        uint32_t sel[1] = {a3.w};
+        sf_resolve_walk<IC, 1>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, nullptr, 0xFFFFFFFFu, nullptr, sel);
         if (SHORT) {
             const bool vv[1] = {valid && !best_state[0]};
             uint32_t w[1] = {0}, dummy = 0;
@@ -214,14 +215,14 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         __builtin_amdgcn_s_setprio(3);                       // (wave priorities: see the filter below)
         if (timing) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_r0 += now - t_mark; t_mark = now; n_batches++; }
         uint64_t gpos[RN];
-        uint32_t w2[RN], avail[RN], best_state[RN], best_vlen[RN], depth[RN], hay[RN], slot[RN];
+        uint32_t w2[RN], avail[RN], best_state[RN], best_vlen[RN], depth[RN], hay[RN], slot[RN], sel[RN];
         SfNode rec[RN];
         bool parked[RN];
         uint64_t pm[RN];
 #pragma unroll
         for (int k = 0; k < RN; k++) {
             gpos[k] = 0; w2[k] = avail[k] = best_state[k] = best_vlen[k] = depth[k] = hay[k] = slot[k] = 0;
-            rec[k] = SfNode{0, 0, 0, 0, {0, 0, 0, 0}}; parked[k] = false; pm[k] = 0;
+            rec[k] = SfNode{0, 0, 0, 0, {0, 0, 0, 0}}; parked[k] = false; pm[k] = 0; sel[k] = kSelUnknown;
         }
         if (nb) {
             bool valid[RN];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
             uint32_t w[RN], node[RN], t16[RN][4];
             bool go[RN], have_rec[RN], found[RN];
             sf_resolve_head<IC, RN>(s, b.text, gpos, end_pos, valid, hint, locate, w, w2, avail, best_state, best_vlen, depth, go, node, rec, have_rec, t16, timing ? dbg_iters : nullptr);
-            if (ablate != 11) sf_resolve_walk<IC, RN>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? o.wq_iters : 0xFFFFFFFFu, t16);
+            if (ablate != 11) sf_resolve_walk<IC, RN>(s, b.text, gpos, avail, w2, go, node, rec, have_rec, depth, best_state, best_vlen, timing ? dbg_iters : nullptr, wq_cap ? o.wq_iters : 0xFFFFFFFFu, t16, sel);
 #pragma unroll
             for (int k = 0; k < RN; k++) parked[k] = go[k] && valid[k];      // still walking after two steps (only with a walker queue)
             if (SHORT) {
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                                 lds_write_u32x4(e, make_uint4((uint32_t)gpos[k], (uint32_t)(gpos[k] >> 32), avail[k], slot[k]));
                                 lds_write_u32x4(e + 16u, make_uint4(depth[k], best_state[k], best_vlen[k], w2[k]));
                                 lds_write_u32x4(e + 32u, make_uint4(rec[k].z, rec[k].w, rec[k].label[0], rec[k].label[1]));
-                                lds_write_u32x4(e + 48u, make_uint4(rec[k].label[2], rec[k].label[3], hay[k], 0u));
+                                lds_write_u32x4(e + 48u, make_uint4(rec[k].label[2], rec[k].label[3], hay[k], sel[k]));
                             }
                             wq_n += n_park;
                             wave_lds_fence();
