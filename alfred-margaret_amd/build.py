@@ -54,7 +54,7 @@ def build_libam(force=False):
     obj_dir = os.path.join(LIB, "obj")
     os.makedirs(obj_dir, exist_ok=True)
     target = os.path.join(LIB, "libam.so")
-    names = ("am_abi.cpp", "am_replacer.cpp", "am_contains_all.cpp", "am_flatten.cpp", "am_kernels.hip", "am_scan.hip", "am_replace.hip", "am_rploop.hip", "am_rplds.hip", "am_dense.hip", "am_multi.cpp")
+    names = ("am_abi.cpp", "am_replacer.cpp", "am_contains_all.cpp", "am_flatten.cpp", "am_kernels.hip", "am_dfa.hip", "am_scan.hip", "am_replace.hip", "am_rploop.hip", "am_rplds.hip", "am_dense.hip", "am_multi.cpp")
     srcs = [os.path.join(CSRC, f) for f in names if os.path.exists(os.path.join(CSRC, f))]
     headers = [d for d in _glob_deps(CSRC) if d.endswith((".h", ".hpp", ".inc"))] + [os.path.join(ROOT, "include", "am.h"), os.path.join(ROOT, "include", "am_debug.h")]
     objs = [os.path.join(obj_dir, os.path.basename(f) + ".o") for f in srcs]

@@ -354,7 +354,7 @@ extern "C" void am_automaton_destroy(am_automaton* a)
 
 extern "C" int am_automaton_set_kernel(am_automaton* a, int k)
 {
-    if (!a || k < 0 || k > 2) return fail(AM_ERR_INVALID, "bad arguments");
+    if (!a || k < 0 || k > 3) return fail(AM_ERR_INVALID, "bad arguments");
     a->kernel_pref = k;
     return AM_OK;
 }
@@ -658,15 +658,20 @@ namespace {
 using AcLauncher = hipError_t (*)(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
 std::atomic<AcLauncher> g_ac_launcher{nullptr};
 
+constexpr uint64_t kDfaMinBytes = 1ull << 20;      // below this the suffix-filter route (its one-document path) is the faster one whatever the text
+
 struct Plan {
     const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
+    bool use_dfa;        // the table-walk kernel (am_dfa.hip) on the general route's two passes; never together with use_sf
+    DfaView dfa;
     bool dense;          // automaton with the empty needle on the suffix-filter route: k_sf's records + the dense pass (am_dense.hip)
     AcView ac; SfView sf; BatchView bv;
     am_batch* batch;
     uint32_t* next_unit; // k_sf's unit counter (in the batch's `small` block: [0..1] total_values, [4] block counter, [5] overflow, [8] this)
 };
 
-int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
+// allow_dfa: the caller's route works for the general two-pass protocol (am_count_batch, am_contains_any_batch, run_records)
+int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool allow_dfa = false)
 {
     if (!b) return fail(AM_ERR_INVALID, "null batch");
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
@@ -674,8 +679,12 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     AM_TRY(prepare(a, case_mode, &p.f));
     p.ic = case_mode == AM_IGNORE_CASE;
     if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run this automaton (empty needle with too many prefix terminals)");
-    p.use_sf = p.f->h.sf_enabled && a->kernel_pref != 1;
-    if (!p.use_sf && !g_ac_launcher.load(std::memory_order_acquire))
+    const bool has_dfa = p.f->h.dfa_n_states != 0 && p.f->h.root_vlen == 0;
+    if (a->kernel_pref == 3 && !has_dfa) return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 3): this automaton's image has no DFA section");
+    p.use_dfa = has_dfa && allow_dfa && (a->kernel_pref == 3 || (a->kernel_pref == 0 && b->total >= kDfaMinBytes && cfg::get(cfg::kDfa) != 0));
+    p.dfa = make_dfa_view(p.f->d_image, p.f->h);
+    p.use_sf = p.f->h.sf_enabled && a->kernel_pref != 1 && !p.use_dfa;
+    if (!p.use_sf && !p.use_dfa && !g_ac_launcher.load(std::memory_order_acquire))
         return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 1): the general AC kernel is test infrastructure (libam_check.so) and is not loaded in this process");
     p.dense = p.use_sf && p.f->h.root_vlen > 0;
     p.ac = make_ac_view(p.f->d_image, p.f->h);
@@ -689,7 +698,7 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p)
     if (p.use_sf) { if (!b->small.p) return fail(AM_ERR_INVALID, "batch without its counter block (not made by am_batch_upload / am_batch_from_device)"); p.next_unit = (uint32_t*)b->small.p + 8; }
     p.n_cu = g_rt.dev[b->dev].n_cu;
     p.batch = b;
-    p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : ac_units(p.ac, p.bv));
+    p.n_units = p.nothing ? 0 : (p.use_sf ? (sf_chunks(p.bv) + p.unit_chunks - 1) / p.unit_chunks : p.use_dfa ? dfa_units(p.dfa, p.bv) : ac_units(p.ac, p.bv));
     if (p.n_units >= 0x7FFFFFF0ull) return fail(AM_ERR_UNSUPPORTED, "batch too large for one launch; split it");
     return AM_OK;
 }
@@ -701,6 +710,10 @@ int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st
         os.next_unit = p.next_unit;
         Prof pr("sf", st);
         HIP_TRY(launch_sf(p.ic, mode, p.sf, p.bv, os, p.n_cu, st));
+    }
+    else if (p.use_dfa) {
+        Prof pr("dfa", st);
+        HIP_TRY(launch_dfa(mode, p.dfa, p.bv, o, st));
     }
     else {
         // the general AC-walk kernel is test infrastructure (libam_check.so, tests/native/am_ac.hip): make_plan refused the scan if it is not loaded
@@ -771,7 +784,7 @@ static int reduce_dense(const am_automaton* a, int case_mode, am_batch* b, uint6
 extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_batch* cb, uint64_t* counts_out, uint64_t* total_out)
 {
     am_batch* b = const_cast<am_batch*>(cb);
-    Plan p; AM_TRY(make_plan(a, case_mode, b, p));
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p, true));
     if (total_out) *total_out = 0;
     if (counts_out && b->n_hay) std::memset(counts_out, 0, (size_t)b->n_hay * sizeof(uint64_t));
     if (p.nothing) return AM_OK;
@@ -804,7 +817,7 @@ extern "C" int am_count_batch(const am_automaton* a, int case_mode, const am_bat
 extern "C" int am_contains_any_batch(const am_automaton* a, int case_mode, const am_batch* cb, uint8_t* flags_out)
 {
     am_batch* b = const_cast<am_batch*>(cb);
-    Plan p; AM_TRY(make_plan(a, case_mode, b, p));
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p, true));
     if (!flags_out && b->n_hay) return fail(AM_ERR_INVALID, "flags_out is null");
     if (b->n_hay) std::memset(flags_out, 0, b->n_hay);
     if (p.nothing) return AM_OK;
@@ -856,7 +869,7 @@ int am::host::scan_needle_ids(const am_automaton* a, int case_mode, am_batch* b,
 int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock)
 {
     *n_out = 0;
-    Plan p; AM_TRY(make_plan(a, case_mode, b, p));
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p, true));
     if (p.nothing) return AM_OK;
     std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
     if (!have_lock) lk.lock();
@@ -897,6 +910,45 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
         AM_TRY(launch_scan_kernel(p, kModeEmit, w, st));
         HIP_TRY(hipStreamSynchronize(st));
         return AM_OK;
+    };
+    // table-walk kernel: ONE walk drops a token per match into the pool (superblocks per wavefront, any order) and counts per unit; scan(unit_counts) + k_dfa_place
+    // put token (unit, seq) where its record belongs.  The pool is sized by a guess (a record per 6 haystack bytes: the density these automata are made for);
+    // if it is exhausted the counts are still exact and the walk is repeated once with the pool they ask for.
+    auto body_dfa = [&]() -> int {
+        const uint32_t n_waves = dfa_token_waves(p.dfa, p.bv, p.n_cu);
+        const uint64_t sb_bytes = dfa_superblock_bytes();
+        uint64_t want = dfa_token_superblocks(b->total / 6u, n_waves);
+        if (b->pool.cap / sb_bytes > want) want = b->pool.cap / sb_bytes;
+        if (cfg::get(cfg::kSfPoolBlocks) > 0) want = (uint64_t)cfg::get(cfg::kSfPoolBlocks);       // tests: force the exhausted-pool path
+        for (int attempt = 0; attempt < 3; attempt++) {
+            if (want >= (1ull << 31)) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
+            AM_TRY(b->pool.ensure(want * sb_bytes));
+            AM_TRY(b->block_next.ensure(want * sizeof(uint32_t)));
+            ScanOut o{};
+            o.unit_counts = (uint32_t*)b->unit_counts.p;
+            o.pool = (Record*)b->pool.p;
+            o.block_next = (uint32_t*)b->block_next.p;           // here: tokens in each superblock
+            o.pool_ctrl = (uint32_t*)b->small.p + 4;             // small: [4] superblocks drawn, [5] pool exhausted
+            o.n_blocks = (uint32_t)want;
+            HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
+            HIP_TRY(hipMemsetAsync(b->block_next.p, 0, want * sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync((uint32_t*)b->unit_counts.p + p.n_units, 0, sizeof(uint32_t), st));
+            AM_TRY(build_hidx(p, b, st));
+            { Prof pr("dfa", st); HIP_TRY(launch_dfa_tokens(p.dfa, p.bv, o, p.n_cu, st)); }
+            { Prof pr("scan", st); HIP_TRY(launch_scan(b->scan_tmp.p, tmp_bytes, (const uint32_t*)b->unit_counts.p, (uint64_t*)b->unit_offsets.p, n, st)); }
+            uint64_t total = 0; uint32_t ctrl[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (ctrl[1]) { want = dfa_token_superblocks(total, n_waves); continue; }
+            *n_scan = total;
+            if (total == 0) return AM_OK;
+            AM_TRY(sink(total, &d_records));
+            { Prof pr("dfa_place", st); HIP_TRY(launch_dfa_place(p.dfa, p.bv, o, ctrl[0] < o.n_blocks ? ctrl[0] : o.n_blocks, (const uint64_t*)b->unit_offsets.p, d_records, st)); }
+            HIP_TRY(hipStreamSynchronize(st));
+            return AM_OK;
+        }
+        return fail(AM_ERR_HIP, "token pool exhausted repeatedly (internal error)");
     };
     // suffix-filter kernel: ONE scan pass writes records into pool blocks (chained per unit), then
     // scan(unit_counts) + k_permute put them in order.  The pool size is a guess (1 record per 128
@@ -940,7 +992,7 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
         }
         return fail(AM_ERR_HIP, "record pool overflowed repeatedly (internal error)");
     };
-    if (!p.dense) return p.use_sf ? body_sf() : body_ac();
+    if (!p.dense) return p.use_sf ? body_sf() : (p.use_dfa && dfa_tokens_ok(p.dfa)) ? body_dfa() : body_ac();
     if (p.f->h.sf_tiers != 0) AM_TRY(body_sf());
     else {                                                  // no needle end is reachable (e.g. upper-case needles under IgnoreCase): only the dense part
         HIP_TRY(hipMemsetAsync(b->unit_offsets.p, 0, n * sizeof(uint64_t), st));
@@ -1022,7 +1074,7 @@ int am::host::run_records_async(const am_automaton* a, int case_mode, am_batch* 
 static int run_records_small(const am_automaton* a, int case_mode, am_batch* b, am_matches* m, bool* done)
 {
     *done = false;
-    if (b->total == 0 || b->total > kSmallRunBytes) return AM_OK;
+    if (b->total == 0 || b->total > kSmallRunBytes || a->kernel_pref == 3) return AM_OK;
     Plan p; AM_TRY(make_plan(a, case_mode, b, p));
     if (p.nothing || p.dense || !p.use_sf) return AM_OK;
     if (cfg::on(cfg::kNoSmallRun)) return AM_OK;                             // A/B

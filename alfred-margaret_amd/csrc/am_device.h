@@ -68,6 +68,17 @@ uint64_t ac_units(const AcView& a, const BatchView& b);
 size_t sf_lds_bytes(const SfView& s);
 hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
+// table-walk kernel (am_dfa.hip): same two-pass protocol as the general kernel (count -> scan -> emit), unit = one lane's DfaView::chunk bytes
+uint64_t dfa_units(const DfaView& d, const BatchView& b);
+hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, hipStream_t st);
+// records in ONE walk: tokens into ScanOut::pool (superblocks; ScanOut::block_next = their fill counts, zeroed before the launch; pool_ctrl[0] superblocks drawn,
+// [1] pool exhausted; n_blocks = superblocks in the pool), unit_counts as in count mode; then scan(unit_counts) and launch_dfa_place
+bool dfa_tokens_ok(const DfaView& d);
+uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu);
+uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves);
+uint64_t dfa_superblock_bytes();
+hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, Record* out, hipStream_t st);
 hipError_t read_sf_phase_cycles(uint64_t* out5);
 hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);

@@ -1,0 +1,233 @@
+// am_dfa.hip -- k_dfa: the byte-level Aho-Corasick automaton with every transition resolved (ImageHeader::off_dfa_next, built by am_flatten.cpp for
+// dictionaries that meet match-dense text), walked one lane per stretch of the batch.  Reference semantics: Automaton.hs:482-520 (followCodePoint /
+// collectMatches) -- the fallback loop is folded into the table, so a step is ONE dependent 4-byte load: next = table[state << log2_classes | class(byte)].
+//
+// Why a second scan kernel: k_sf is a filter.  On natural-language text against a 100k-word dictionary four positions in ten pass its LDS filter and a needle
+// ends every 6.6 bytes; its resolve phase then costs ~19 divergent 16-byte loads and ~22 VALU instructions per deferred position and the kernel runs at the
+// issue limit of the CUs' address units and vector ALUs (profiles/r05_pmc_natural_units.md).  A table walk costs one 4-byte load and ~8 instructions per BYTE
+// whatever the text is -- slower than k_sf where matches are rare (it cannot skip anything), several times faster where they are dense.
+//
+// Work split: unit u = bytes [u * chunk, (u + 1) * chunk) of the concatenated batch, one lane each; the lane owns the matches whose LAST byte lies in its unit and
+// warms its state up from the root over the `warm` bytes before it (clipped to the haystack start; a haystack boundary inside the unit resets the state).
+// Bytes are read 16 at a time (aligned, nontemporal: the text is a stream, the table is what the caches are for); the byte -> class map sits in LDS.
+//   count / any  one launch; unit_counts[u] = the unit's records (what the exclusive scan turns into the records' final places).
+//   records      ONE walk as well (kModeEmit with ScanOut::pool set): a lane knows the running number `seq` of each of its matches, so it drops a 16-byte TOKEN
+//                {unit, seq, offset in the unit, haystack, state} into its wavefront's current superblock of the pool (slot = one LDS atomic; a superblock = 4096
+//                tokens, one device atomic each; order inside does not matter), and after the scan k_dfa_place puts token (u, seq) at unit_offsets[u] + seq as the
+//                record it stands for: position order without a sort and without walking the text a second time.  A pool that turns out too small only costs the
+//                tokens (the counts stay exact): the host repeats the call with the size the kernel reports, as for k_sf's record blocks.
+//                (kModeEmit with ScanOut::records set is the second pass of the plain count -> scan -> emit protocol, kept for chunks beyond 65536 bytes.)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "am_device.h"
+#include "am_wave.h"
+
+namespace am {
+namespace dev {
+
+namespace {
+
+constexpr uint32_t kWave = 64;
+constexpr int kModeTokens = 16;               // template value only: kModeEmit with a token pool
+constexpr uint32_t kDfaSuper = 4096;          // tokens per superblock (64 KiB)
+constexpr uint32_t kDfaSuperReserve = 1024;   // free slots a wavefront makes sure of before 64 lanes take (at most) 16 steps
+
+template <int MODE>
+struct DfaLane {
+    const DfaView& d; const BatchView& b; const ScanOut& o;
+    Record* out;                              // emit mode: where this unit's next record goes
+    uint32_t* wv;                             // token mode: this wavefront's {fill, superblock id} in LDS
+    uint64_t unit;
+    uint32_t nrec = 0; uint64_t nval = 0;
+    uint32_t run_hay = kNone; uint64_t run_val = 0;      // count mode: values of the haystack the lane is in, added with one atomic when it leaves it
+    __device__ __forceinline__ void flush()
+    {
+        if (MODE == kModeCount && o.hay_counts && run_hay != kNone && run_val) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + run_hay), (unsigned long long)run_val);
+        run_val = 0;
+    }
+    // g = index of the match's last byte in the batch, hs = where its haystack starts
+    __device__ __forceinline__ void found(uint32_t hay, uint64_t g, uint64_t hs, uint32_t state)
+    {
+        const uint64_t end_pos = g + 1u - hs;
+        if (MODE == kModeAny) { o.flags[hay] = 1; return; }
+        const u32x2 e = d.out[state];
+        if (MODE == kModeTokens) {
+            const uint32_t sb = wv[1];
+            if (sb != kNone) {
+                const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the step loop)
+                const uint64_t pos = g - unit * d.chunk;                   // offset of the match's last byte in the unit
+                o.pool[(uint64_t)sb * kDfaSuper + slot] = Record{(unit << 32) | ((uint64_t)nrec << 16) | pos, hay, e.x - 1u};
+            }
+            nrec++;
+            return;
+        }
+        if (MODE == kModeCount) {
+            nrec++; nval += e.y;
+            if (o.hay_counts) { if (hay != run_hay) { flush(); run_hay = hay; } run_val += e.y; }
+        } else {
+            out[nrec++] = Record{end_pos, hay, e.x - 1u};
+        }
+    }
+};
+
+}  // namespace
+
+// one lane's unit (see the head of the file); s_cls = the byte -> class map in LDS
+template <int MODE>
+__device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s_cls, uint64_t u)
+{
+    const DfaView& d = L.d; const BatchView& b = L.b; const ScanOut& o = L.o;
+    const uint32_t lc = d.log2_classes;
+    const uint64_t cs = u * d.chunk;
+    const uint64_t ce = (cs + d.chunk < b.total) ? cs + d.chunk : b.total;
+    uint32_t h = find_haystack(b, cs);
+    uint64_t hs = b.offsets[h], he = b.offsets[h + 1];
+    uint64_t offset = hs;
+    if (cs - hs > d.warm) { offset = (cs - d.warm) & ~15ull; if (offset < hs) offset = hs; }      // a longer warm-up is as exact; 16-byte blocks from the start
+    uint32_t state = 0;
+    typedef uint32_t u32x4_n __attribute__((ext_vector_type(4)));
+    while (offset < ce) {
+        if (MODE == kModeTokens) {
+            // the lanes that are still walking agree (they read the same LDS words) on whether their wavefront's superblock can take what the next
+            // step may produce (64 lanes x 16 bytes); if not, the first of them seals it and draws the next one
+            volatile uint32_t* wv = L.wv;
+            const uint32_t fill = wv[0], sb = wv[1], exhausted = wv[2];
+            if (!exhausted && (sb == kNone || fill + kDfaSuperReserve > kDfaSuper)) {
+                const uint64_t act = __ballot(1);
+                if (lane_id() == (uint32_t)__ffsll((unsigned long long)act) - 1u) {
+                    if (sb != kNone) o.block_next[sb] = fill;
+                    const uint32_t id = atomicAdd(o.pool_ctrl, 1u);
+                    if (id >= o.n_blocks) { o.pool_ctrl[1] = 1u; wv[1] = kNone; wv[2] = 1u; }      // the counts stay exact; the host repeats the call with a pool sized by them
+                    else wv[1] = id;
+                    wv[0] = 0u;
+                }
+                wave_lds_fence();
+            }
+        }
+        if (offset >= he) {                                 // the next non-empty haystack starts here
+            do { h++; hs = he; he = b.offsets[h + 1]; } while (he == hs);
+            state = 0;
+        }
+        const uint64_t lim = he < ce ? he : ce;
+        if ((offset & 15u) == 0 && offset + 16 <= lim) {
+            const u32x4_n t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_n*>(b.text + offset));
+            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
+            const bool mine = offset >= cs;                 // (cs is a multiple of 16: a block lies on one side of it)
+            if (MODE == kModeAny && mine && o.flags[h]) { offset = he; continue; }      // the haystack is already flagged: on to the next one
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                const uint32_t e = d.next[((uint64_t)state << lc) + s_cls[byte]];
+                state = e & ~kDfaEnds;
+                if ((e & kDfaEnds) && mine) L.found(h, offset + (uint64_t)i, hs, state);
+            }
+            offset += 16;
+        } else {
+            const uint32_t e = d.next[((uint64_t)state << lc) + s_cls[b.text[offset]]];
+            state = e & ~kDfaEnds;
+            offset++;
+            if ((e & kDfaEnds) && offset > cs) L.found(h, offset - 1u, hs, state);
+        }
+    }
+    L.flush();
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units)
+{
+    __shared__ uint8_t s_cls[256];
+    s_cls[threadIdx.x] = d.cls[threadIdx.x];
+    __syncthreads();
+    const uint64_t u = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    DfaLane<MODE> L{d, b, o, nullptr, nullptr, u};
+    if (u < n_units) {
+        if (MODE == kModeEmit) L.out = o.records + o.unit_offsets[u];
+        dfa_walk_unit<MODE>(L, s_cls, u);
+        if (MODE == kModeCount) o.unit_counts[u] = L.nrec;
+    }
+    if (MODE == kModeCount) {
+        const uint64_t nval = wave_sum_u64(L.nval);
+        if (lane_id() == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+    }
+}
+
+// records in one walk: persistent wavefronts (a wavefront's superblock serves all the groups of 64 units it takes), tokens into the pool, counts per unit
+__global__ __launch_bounds__(256) void k_dfa_tokens(DfaView d, BatchView b, ScanOut o, uint64_t n_units)
+{
+    __shared__ uint8_t s_cls[256];
+    __shared__ uint32_t s_wave[4][4];                        // per wavefront: tokens in its superblock, the superblock's id, pool exhausted
+    s_cls[threadIdx.x] = d.cls[threadIdx.x];
+    const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if (lane == 0) { s_wave[w][0] = 0u; s_wave[w][1] = kNone; s_wave[w][2] = 0u; }
+    __syncthreads();
+    const uint64_t n_groups = (n_units + kWave - 1) / kWave, n_waves = (uint64_t)gridDim.x * 4u;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4u + w; g < n_groups; g += n_waves) {
+        const uint64_t u = g * kWave + lane;
+        if (u < n_units) {
+            DfaLane<kModeTokens> L{d, b, o, nullptr, &s_wave[w][0], u};
+            dfa_walk_unit<kModeTokens>(L, s_cls, u);
+            o.unit_counts[u] = L.nrec;
+        }
+        wave_lds_fence();                                   // (the token slots of this group are taken before the next group's first reserve looks at the fill)
+    }
+    if (lane == 0 && s_wave[w][1] != kNone) o.block_next[s_wave[w][1]] = s_wave[w][0];      // the last superblock's fill
+}
+
+// token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq
+__global__ __launch_bounds__(256) void k_dfa_place(const Record* __restrict__ pool, const uint32_t* __restrict__ fill, uint32_t n_super, const uint64_t* __restrict__ unit_offsets,
+                                                   const uint64_t* __restrict__ hay_offsets, uint32_t chunk, Record* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint32_t sb = (uint32_t)(i / kDfaSuper), s = (uint32_t)(i % kDfaSuper);
+    if (sb >= n_super || s >= fill[sb]) return;
+    const Record t = pool[i];
+    const uint64_t u = t.end_pos >> 32, seq = (t.end_pos >> 16) & 0xFFFFu, pos = t.end_pos & 0xFFFFu;
+    out[unit_offsets[u] + seq] = Record{u * chunk + pos + 1u - hay_offsets[t.haystack], t.haystack, t.state};
+}
+
+uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
+
+hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, hipStream_t st)
+{
+    const uint64_t n_units = dfa_units(d, b);
+    if (n_units == 0) return hipSuccess;
+    const uint64_t blocks = (n_units + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if (mode == kModeCount) hipLaunchKernelGGL((k_dfa<kModeCount>), dim3((uint32_t)blocks), dim3(256), 0, st, d, b, o, n_units);
+    else if (mode == kModeEmit) hipLaunchKernelGGL((k_dfa<kModeEmit>), dim3((uint32_t)blocks), dim3(256), 0, st, d, b, o, n_units);
+    else if (mode == kModeAny) hipLaunchKernelGGL((k_dfa<kModeAny>), dim3((uint32_t)blocks), dim3(256), 0, st, d, b, o, n_units);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// records in one walk: is the unit small enough for a token's 16-bit fields, and how many wavefronts walk (= superblocks that may end up partly filled)
+bool dfa_tokens_ok(const DfaView& d) { return d.chunk != 0 && d.chunk <= 65536u; }
+uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu)
+{
+    const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;
+    const uint64_t wgs = std::min<uint64_t>((uint64_t)n_cu * 8u, (n_groups + 3) / 4);
+    return (uint32_t)(wgs * 4u);
+}
+// superblocks that hold `records` tokens whatever the split between the wavefronts: a sealed superblock holds at least kDfaSuper - kDfaSuperReserve
+uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves) { return records / (kDfaSuper - kDfaSuperReserve) + n_waves + 16; }
+uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(Record); }
+hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+{
+    const uint64_t n_units = dfa_units(d, b);
+    if (n_units == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dfa_tokens, dim3(dfa_token_waves(d, b, n_cu) / 4u), dim3(256), 0, st, d, b, o, n_units);
+    return hipGetLastError();
+}
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, Record* out, hipStream_t st)
+{
+    if (n_super == 0) return hipSuccess;
+    const uint64_t blocks = (uint64_t)n_super * (kDfaSuper / 256u);
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dfa_place, dim3((uint32_t)blocks), dim3(256), 0, st, o.pool, o.block_next, n_super, unit_offsets, b.offsets, d.chunk, out);
+    return hipGetLastError();
+}
+
+}  // namespace dev
+}  // namespace am

@@ -770,6 +770,102 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);
     h.off_edge_maps = 0;
+
+    // ---- DFA section.  A dictionary of natural-language words meets text in which a needle ends every few bytes: there the suffix filter filters nothing
+    // (four positions in ten pass it) and k_sf is bound by the divergent loads and the instructions of its resolve phase (LABNOTES R5.7).  For such an automaton
+    // the image also carries the classic alternative: the byte-level Aho-Corasick automaton with EVERY transition resolved (delta(state, byte) = one table entry,
+    // the fallback chain folded in), so that a lane walks its stretch of the haystack with one dependent load per byte and nothing else (k_dfa).
+    //   states   = the reference's states + the nodes inside multi-byte code points, numbered breadth-first (the states natural text dwells in come first);
+    //              a code point edge becomes the UTF-8 of every haystack code point that lowers to it (variants_of, as in the suffix trie), so an IgnoreCase
+    //              automaton is a DAG: both spellings of a letter lead to the same state.  Its fallback is that of the reference (a property of the folded string);
+    //   classes  = the bytes that occur on some edge (IgnoreCase: upper-case ASCII shares the class of its fold); every other byte leads to the root from anywhere;
+    //   needle ends: only at the reference's states (a needle ends with a whole code point): vlen[s] > 0, reported as canon[s] like everywhere else.
+    {
+        const long dfa_cfg = cfg::get(cfg::kDfa);
+        const bool want = dfa_cfg == cfg::kUnset ? h.sf_t4_children > 0 : dfa_cfg != 0;
+        if (want && vlen[0] == 0 && S > 1) {
+            struct BEdge { uint32_t src, byte, dst; };
+            std::vector<BEdge> be; be.reserve(S + S / 8);
+            uint32_t n_nodes = (uint32_t)S;
+            std::vector<uint32_t> bdepth(S, 0);                                  // longest spelling of the state's string, in bytes
+            std::unordered_map<uint32_t, std::vector<std::string>> vcache;
+            std::vector<BEdge> local;
+            bool present[256] = {false};
+            for (uint32_t u : bfs) {
+                local.clear();
+                for (uint32_t k = 0; k < edge_count[u]; k++) {
+                    const uint64_t t = ref.transitions[edge_begin[u] + k];
+                    const uint32_t c = (uint32_t)(t & 0x1fffffu), v = (uint32_t)(t >> 32);
+                    auto it = vcache.find(c);
+                    if (it == vcache.end()) { std::vector<std::string> vs; variants_of(lt, c, ic, vs); it = vcache.emplace(c, std::move(vs)).first; }
+                    for (const std::string& var : it->second) {
+                        uint32_t cur = u;
+                        for (size_t j = 0; j + 1 < var.size(); j++) {
+                            const uint32_t b = (uint8_t)var[j];
+                            uint32_t nx = kNone;
+                            for (const BEdge& le : local) if (le.src == cur && le.byte == b) { nx = le.dst; break; }
+                            if (nx == kNone) { nx = n_nodes++; local.push_back({cur, b, nx}); be.push_back({cur, b, nx}); present[b] = true; }
+                            cur = nx;
+                        }
+                        be.push_back({cur, (uint32_t)(uint8_t)var.back(), v});
+                        present[(uint8_t)var.back()] = true;
+                        bdepth[v] = std::max(bdepth[v], bdepth[u] + (uint32_t)var.size());
+                    }
+                }
+            }
+            uint32_t n_cls = 1;
+            std::vector<uint8_t> cls(256, 0);
+            for (uint32_t b = 0; b < 256; b++) if (present[b]) cls[b] = (uint8_t)n_cls++;
+            if (ic) for (uint32_t b = 'A'; b <= 'Z'; b++) cls[b] = cls[b + 0x20u];       // the kernels fold ASCII; the variants hold the folded byte only
+            const uint32_t lc = std::max(1u, log2_ceil(n_cls));
+            const uint64_t table_bytes = ((uint64_t)n_nodes << lc) * 4ull;
+            if (n_cls <= 256 && n_nodes < 0x7FFFFFF0u && table_bytes <= (1ull << 30)) {
+                // adjacency by source
+                std::vector<uint32_t> first(n_nodes + 1, 0);
+                for (const BEdge& e : be) first[e.src + 1]++;
+                for (uint32_t i = 0; i < n_nodes; i++) first[i + 1] += first[i];
+                std::vector<BEdge> adj(be.size());
+                { std::vector<uint32_t> cur(first.begin(), first.end() - 1); for (const BEdge& e : be) adj[cur[e.src]++] = e; }
+                // breadth-first numbering; a node's fallback is set when it is first reached: delta(fallback(parent), byte), the root's children fall back to the root
+                std::vector<uint32_t> id(n_nodes, kNone), order; order.reserve(n_nodes);
+                std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a DFA state id
+                std::vector<uint32_t> next((size_t)n_nodes << lc, 0);
+                const uint32_t C = 1u << lc;
+                id[0] = 0; order.push_back(0);
+                for (size_t qi = 0; qi < order.size(); qi++) {
+                    const uint32_t x = order[qi], xi = (uint32_t)qi;
+                    uint32_t* row = next.data() + ((size_t)xi << lc);
+                    if (xi != 0) std::memcpy(row, next.data() + ((size_t)fb[xi] << lc), (size_t)C * 4);      // (the root's row starts as all-root = zeros)
+                    for (uint32_t e = first[x]; e < first[x + 1]; e++) {
+                        const uint32_t y = adj[e].dst, cb = cls[adj[e].byte];
+                        if (id[y] == kNone) {
+                            id[y] = (uint32_t)order.size(); order.push_back(y);
+                            fb[id[y]] = xi == 0 ? 0u : next[((size_t)fb[xi] << lc) + cb];
+                        }
+                        row[cb] = id[y];
+                    }
+                }
+                {
+                    // (nodes no byte string reaches -- an upper-case needle letter under IgnoreCase has no spelling -- get no state: the reference never reaches them either)
+                    const uint32_t n_reached = (uint32_t)order.size();
+                    next.resize((size_t)n_reached << lc);
+                    std::vector<u32x2> out(n_reached, u32x2{0, 0});
+                    for (uint32_t x = 1; x < (uint32_t)S; x++) if (vlen[x] > 0 && id[x] != kNone) out[id[x]] = u32x2{canon[x] + 1u, vlen[x]};
+                    for (uint32_t& e : next) if (out[e].x) e |= kDfaEnds;
+                    uint32_t warm = 1;
+                    for (uint32_t x = 0; x < (uint32_t)S; x++) warm = std::max(warm, bdepth[x]);
+                    long chunk = cfg::get(cfg::kDfaChunk);
+                    if (chunk < 64 || chunk > (1 << 20)) chunk = 512;
+                    chunk = (chunk + 15) & ~15L;
+                    while ((uint64_t)chunk < 4ull * warm && chunk < (1 << 20)) chunk *= 2;          // the warm-up stays a fraction of the lane's own bytes
+                    h.off_dfa_next = blob.put(next);
+                    h.off_dfa_out = blob.put(out);
+                    h.off_dfa_cls = blob.put(cls);
+                    h.dfa_n_states = n_reached; h.dfa_log2_classes = lc; h.dfa_warm = warm - 1u > 0 ? warm - 1u : 1u; h.dfa_chunk = (uint32_t)chunk;
+                }
+            }
+        }
+    }
     blob.reserve_section(16);      // tail padding
     h.total_bytes = blob.bytes.size();
     h.checksum = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
@@ -886,6 +982,20 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
             if ((kind != 0 && slots[i].z >= h.sf_n_nodes) || (kind == 1 && (slots[i].w >> 24) > kMaxSkip)) { err = "image: suffix slot out of range"; return false; }
         }
     }
+    if (h.dfa_n_states) {
+        const uint32_t* next = (const uint32_t*)(img + h.off_dfa_next);
+        const u32x2* out = (const u32x2*)(img + h.off_dfa_out);
+        const uint8_t* cls = img + h.off_dfa_cls;
+        const uint32_t* vl = (const uint32_t*)(img + h.off_vlen);
+        for (uint32_t b = 0; b < 256; b++) if (cls[b] >= (1u << h.dfa_log2_classes)) { err = "image: DFA byte class out of range"; return false; }
+        for (uint32_t i = 0; i < h.dfa_n_states; i++)
+            if (out[i].x > S || (out[i].x != 0 && (canon[out[i].x - 1u] != out[i].x - 1u || vl[out[i].x - 1u] == 0 || out[i].y == 0))) { err = "image: DFA needle end out of range"; return false; }
+        const uint64_t n = (uint64_t)h.dfa_n_states << h.dfa_log2_classes;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint32_t to = next[i] & ~kDfaEnds;
+            if (to >= h.dfa_n_states || ((next[i] & kDfaEnds) != 0) != (out[to].x != 0)) { err = "image: DFA transition out of range"; return false; }
+        }
+    }
     return true;
 }
 
@@ -906,6 +1016,11 @@ bool image_sections_in_bounds(const ImageHeader& h)
             good = good && ok(h.off_tier[t], 1ull << h.tier_log2_cap[t], 8);
             if (t == 3) good = good && ok(h.off_t4_slots, 2ull << h.tier_log2_cap[t], 64) && (h.off_t4_slots & 63u) == 0;
         }
+    }
+    if (h.dfa_n_states) {
+        if (h.dfa_log2_classes < 1 || h.dfa_log2_classes > 8 || h.dfa_n_states >= 0x7FFFFFF0u || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
+        good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_states << h.dfa_log2_classes, 4) && ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&
+               (h.off_dfa_next & 15u) == 0 && (h.off_dfa_out & 7u) == 0;
     }
     return good;
 }

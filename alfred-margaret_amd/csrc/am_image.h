@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 12;
+constexpr uint32_t kImageVersion = 13;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -72,6 +72,14 @@ struct ImageHeader {
     uint64_t off_fail;          // AC: u32[n_states] fallback state (the target of each state's wildcard entry)
     uint32_t sf_t4_children;    // hot entries keyed by FIVE bytes (a heavy depth-4 node's children, am_flatten.cpp); 0: none, the probe never looks for them
     uint32_t sf_row_first;      // edges[sf_row_first .. n_edges): the ROWS of the nodes with more than 4 children (SfNode::label, SfEdge::pad)
+    // DFA section (version 13; dfa_n_states == 0: none): the byte-level automaton with every transition resolved, for dictionaries that meet text in which
+    // a needle ends every few bytes (am_flatten.cpp decides; k_dfa in am_dfa.hip)
+    uint64_t off_dfa_next;      // u32[dfa_n_states << dfa_log2_classes]: next state (bits 0-30) | bit 31: a needle ends there
+    uint64_t off_dfa_out;       // u32x2[dfa_n_states] {canonical reference state + 1 (0: no needle ends), vlen}
+    uint64_t off_dfa_cls;       // u8[256]: byte -> class (IgnoreCase: the ASCII fold is part of the map); class 0 = bytes no needle contains
+    uint32_t dfa_n_states, dfa_log2_classes;
+    uint32_t dfa_warm;          // bytes of history that determine the state: longest needle (variant) in bytes - 1
+    uint32_t dfa_chunk;         // bytes of the batch one lane owns (multiple of 16)
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -156,6 +164,14 @@ struct SfView {
     uint32_t t4_children;    // the table holds five-byte child entries of heavy depth-4 nodes (sf_probe_children)
 };
 
+struct DfaView {
+    const uint32_t* next;
+    const u32x2* out;
+    const uint8_t* cls;
+    uint32_t n_states, log2_classes, warm, chunk;
+};
+constexpr uint32_t kDfaEnds = 0x80000000u;
+
 struct BatchView {
     const uint8_t* text;       // concatenated haystack bytes, 16-B aligned, readable up to round_up(total, 16)
     const uint64_t* offsets;   // n_hay + 1
@@ -176,6 +192,15 @@ inline AcView make_ac_view(const void* base, const ImageHeader& h)
     v.lower = (const int32_t*)(b + h.off_lower);
     v.n_lower = h.n_lower; v.max_needle_cps = h.max_needle_cps; v.chunk = h.ac_chunk; v.root_vlen = h.root_vlen;
     v.goto_tab = (const u32x4*)(b + h.off_goto); v.fail = (const uint32_t*)(b + h.off_fail); v.goto_log2_cap = h.ac_goto_log2_cap;
+    return v;
+}
+
+inline DfaView make_dfa_view(const void* base, const ImageHeader& h)
+{
+    const uint8_t* b = (const uint8_t*)base;
+    DfaView v;
+    v.next = (const uint32_t*)(b + h.off_dfa_next); v.out = (const u32x2*)(b + h.off_dfa_out); v.cls = b + h.off_dfa_cls;
+    v.n_states = h.dfa_n_states; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk;
     return v;
 }
 
@@ -1011,6 +1036,29 @@ AM_HD void ac_scan_unit(const AcView& a, const BatchView& b, uint64_t unit, Emit
             const uint32_t v = a.vlen[state];
             if (v) emit((uint32_t)h, nend - hs, a.canon[state], v);
         }
+    }
+}
+
+// One lane's unit of the DFA kernel, the plain form (the host image interpreter runs this; k_dfa in am_dfa.hip is the same walk with wide loads): bytes
+// [unit*chunk, (unit+1)*chunk) of the batch; the lane owns every match whose LAST byte lies there and warms the state up from the root over `warm` bytes
+// (any byte offset will do: a needle starts with no continuation byte, so a walk that starts inside a code point stays at the root until the next one).
+// emit(haystack, end_pos_in_haystack, canon_state, vlen) -- Automaton.hs:482-520 with every fallback step folded into the table.
+template <class Emit>
+AM_HD void dfa_scan_unit(const DfaView& d, const BatchView& b, uint64_t unit, Emit& emit)
+{
+    const uint64_t cs = unit * d.chunk;
+    if (cs >= b.total) return;
+    const uint64_t ce = (cs + d.chunk < b.total) ? cs + d.chunk : b.total;
+    uint32_t h = find_haystack(b, cs);
+    uint64_t hs = b.offsets[h], he = b.offsets[h + 1];
+    uint64_t offset = (cs - hs > d.warm) ? cs - d.warm : hs;
+    uint32_t state = 0;
+    while (offset < ce) {
+        if (offset >= he) { do { h++; hs = he; he = b.offsets[h + 1]; } while (he == hs); state = 0; }
+        const uint32_t e = d.next[((uint64_t)state << d.log2_classes) + d.cls[b.text[offset]]];
+        state = e & ~kDfaEnds;
+        offset++;
+        if ((e & kDfaEnds) && offset > cs) { const u32x2 o = d.out[state]; emit((uint32_t)h, offset - hs, o.x - 1u, o.y); }
     }
 }
 

@@ -118,8 +118,10 @@ AM_API int am_automaton_create_ex(const uint64_t* transitions, size_t n_transiti
 AM_API uint32_t am_automaton_lower_hash(const am_automaton* a);
 AM_API uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs);   /* NULL: the built-in table's; 0 on error */
 AM_API void am_automaton_destroy(am_automaton* a);
-/* Route k: 0 = automatic, 1 = force the general AC kernel, 2 = force the suffix-filter kernel
- * (fails with AM_ERR_UNSUPPORTED at run time for automata that contain the empty needle). */
+/* Route k: 0 = automatic (the suffix-filter kernel; the table-walk kernel k_dfa for automata whose image carries a DFA section -- dictionaries with
+ * heavy suffix nodes -- on batches of 1 MiB and more), 1 = force the general AC kernel (test infrastructure: AM_ERR_UNSUPPORTED unless libam_check.so
+ * is loaded), 2 = force the suffix-filter kernel, 3 = force the table-walk kernel (AM_ERR_UNSUPPORTED at run time when the image has no DFA section).
+ * All routes report the same matches. */
 AM_API int am_automaton_set_kernel(am_automaton* a, int k);
 
 /* ---- one-shot entry points on host slices (what the Haskell shim binds) ----------------------

@@ -83,6 +83,20 @@ class ImgCheck:
             return n, None
         return n, (hay[:n], st[:n], end[:n], vl[:n])
 
+    def set(self, name, value):
+        """A switch of csrc/am_config.h inside libam_imgcheck.so's copy of the flattener (AM_DFA, AM_DFA_CHUNK, AM_SF_NO_CHILDREN ...); -1 = unset."""
+        self.lib.amchk_set.argtypes = [C.c_char_p, C.c_long]
+        assert self.lib.amchk_set(name.encode(), int(value)) == 0, name
+
+    @staticmethod
+    def dfa_header(img):
+        f = struct.unpack_from("<3Q4I", img.tobytes()[256:296])          # ImageHeader.off_dfa_next ... dfa_chunk
+        return {"off_next": f[0], "off_out": f[1], "off_cls": f[2], "n_states": f[3], "log2_classes": f[4], "warm": f[5], "chunk": f[6]}
+
+    @staticmethod
+    def set_dfa_chunk(img, chunk):
+        img[292:296] = np.frombuffer(struct.pack("<I", chunk), dtype=np.uint8)   # ImageHeader.dfa_chunk (the host interpreter takes any value >= 1)
+
     @staticmethod
     def set_ac_chunk(img, chunk):
         img[36:40] = np.frombuffer(struct.pack("<I", chunk), dtype=np.uint8)   # ImageHeader.ac_chunk

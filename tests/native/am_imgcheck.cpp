@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 
+#include "am_config.h"
 #include "am_flatten.h"
 
 using namespace am;
@@ -16,6 +17,7 @@ using namespace am;
 // which == 1 scans: candidates that passed the Bloom filter, positions the probe deferred, positions where a needle ends (measurement aid:
 // how good the probe is on a given automaton + text, without a GPU)
 static uint64_t g_stats[3] = {0, 0, 0};
+static uint64_t g_walk_hist[16] = {0};      // walk steps per deferred pair of items (the interpreter resolves two in lock step): [i] = pairs whose deeper walk took i steps (15: or more)
 
 namespace {
 struct Rec { uint32_t hay; uint32_t state; uint64_t end_pos; uint32_t vlen; };
@@ -26,6 +28,9 @@ struct Collect {
 }  // namespace
 
 extern "C" {
+void amchk_walk_hist(uint64_t* out16, int reset) { for (int i = 0; i < 16; i++) { out16[i] = g_walk_hist[i]; if (reset) g_walk_hist[i] = 0; } }
+// a switch of csrc/am_config.h for the flattener compiled into THIS library (0 = done, -1 = no such switch)
+int amchk_set(const char* name, long value) { return cfg::set(name, value) ? 0 : -1; }
 void amchk_stats(uint64_t* out3, int reset) { for (int i = 0; i < 3; i++) { out3[i] = g_stats[i]; if (reset) g_stats[i] = 0; } }
 
 
@@ -57,7 +62,7 @@ long long amchk_flatten(const uint64_t* transitions, size_t n_transitions, const
 
 // Interpret an image over a batch.  which: 0 = AC walk (general kernel's logic), 1 = SF (filter +
 // verify, fast kernel's logic), 2 = SF without the Bloom filter (every position verified: separates
-// filter bugs from table bugs).  Fills up to cap records sorted by (haystack, end_pos); returns the
+// filter bugs from table bugs), 3 = the DFA table walk (k_dfa's logic).  Fills up to cap records sorted by (haystack, end_pos); returns the
 // record count, or -2 if the image has no SF section (empty needle present).
 long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const uint64_t* offsets, uint32_t n_hay,
                      uint32_t* hay_out, uint32_t* state_out, uint64_t* end_out, uint32_t* vlen_out, size_t cap)
@@ -84,6 +89,13 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
             Collect c{&recs};
             const uint64_t units = (total + a.chunk - 1) / a.chunk;
             for (uint64_t u = 0; u < units; u++) { if (ic) ac_scan_unit<true>(a, b, u, c); else ac_scan_unit<false>(a, b, u, c); }
+        } else if (which == 3) {
+            // the table walk (k_dfa's logic): -3 when the image has no DFA section
+            if (!h.dfa_n_states) return -3;
+            DfaView d = make_dfa_view(image, h);
+            Collect c{&recs};
+            const uint64_t units = (total + d.chunk - 1) / d.chunk;
+            for (uint64_t u = 0; u < units; u++) dfa_scan_unit(d, b, u, c);
         } else {
             if (!h.sf_enabled) return -2;
             SfView s = make_sf_view(image, h);
@@ -121,8 +133,10 @@ long long amchk_scan(const uint8_t* image, int which, const uint8_t* text, const
                         for (int k = 0; k < 2; k++) if (valid[k]) { g_stats[0]++; if (defer[k]) g_stats[1]++; }
                         // phase 2, two items in lock step as in the kernel
                         bool todo[2] = {valid[0] && defer[0], valid[1] && defer[1]};
-                        if (ic) sf_resolve_n<true, 2>(s, padded.data(), g, a, todo, hint, found, st, vl);
-                        else sf_resolve_n<false, 2>(s, padded.data(), g, a, todo, hint, found, st, vl);
+                        uint64_t it[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (ic) sf_resolve_n<true, 2>(s, padded.data(), g, a, todo, hint, found, st, vl, SfNoHook(), it);
+                        else sf_resolve_n<false, 2>(s, padded.data(), g, a, todo, hint, found, st, vl, SfNoHook(), it);
+                        if (todo[0] || todo[1]) g_walk_hist[it[0] < 15 ? it[0] : 15]++;
                     } else {
                         // every position through the exact phase 2, with a slot hint that is wrong three times out of four: the
                         // probe only filters, so the answer must not depend on it (this is the path of a fingerprint collision)

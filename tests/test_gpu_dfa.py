@@ -1,0 +1,129 @@
+"""k_dfa (csrc/am_dfa.hip), the table-walk kernel for dictionaries that meet match-dense text: parity with the oracle and with the suffix-filter
+kernel through every entry point that can take the route (am_run / am_count / am_contains_any and their batch forms).  Needs an MI355X.
+
+The flattener gives an image a DFA section by itself only when the automaton is dictionary-like (heavy suffix nodes); the fragment-pool tests force one
+(AM_DFA=1) and force the route (am_automaton_set_kernel(a, 3)), so that the kernel meets Unicode case variants, ragged batches and empty haystacks."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import alfred_margaret_amd as am
+from alfred_margaret_amd import synth
+from oracle import oracle
+from tests.helpers import expand_records, fragment_case, oracle_triples
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dfa_everywhere():
+    am.debug_set("AM_DFA", 1)
+    yield
+    am.debug_set("AM_DFA", -1)
+    am.debug_set("AM_DFA_CHUNK", -1)
+
+
+def triples(a, case, hays):
+    hay, pos, val = a.run_batch_with_case(case, hays)
+    return [(int(h), int(p), int(v)) for h, p, v in zip(hay, pos, val)]
+
+
+def contains_any(a, case, hays):
+    s = am.api._Slices(hays)
+    out = np.zeros(max(s.n, 1), np.uint8)
+    am.api.check(am.api.libam().am_contains_any(a.device, case, s.arr, s.n, out.ctypes.data))
+    return [bool(x) for x in out[:s.n]]
+
+
+def check_dfa_route(needles, hays, case):
+    o = oracle.Machine(needles)
+    exp = oracle_triples(o, case, hays)
+    a = am.Automaton(needles)
+    a.set_kernel(3)
+    assert triples(a, case, hays) == exp, (case, needles, hays)
+    assert [int(c) for c in a.count_matches(case, hays)] == [o.count_matches(case, h) for h in hays], (case, needles, hays)
+    assert contains_any(a, case, hays) == [o.contains_any(case, h) for h in hays], (case, needles, hays)
+    recs = a.run_records(case, hays)
+    assert expand_records(o.values_off(), o.values(), recs["haystack"], recs["state"], recs["end_pos"]) == exp
+    keys = [(int(r["haystack"]), int(r["end_pos"])) for r in recs]
+    assert keys == sorted(set(keys))                      # one record per position, in (haystack, end_pos) order: no sort behind the two passes
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fragment_pool_on_the_table_walk(dfa_everywhere, seed):
+    rng = random.Random(4100 + seed)
+    for _ in range(12):
+        needles, hays = fragment_case(rng)
+        if "" in needles or not any(needles):
+            continue                                       # the empty needle: no DFA section (the dense route reports those)
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if (case and rng.random() < 0.8) else needles
+            check_dfa_route(ns, hays, case)
+
+
+@pytest.mark.parametrize("chunk", [64, 256])
+def test_unit_boundaries_inside_matches_and_code_points(dfa_everywhere, chunk):
+    """Small units: every haystack is cut many times, inside needles, inside code points, inside the warm-up of the next unit; haystack boundaries
+    and empty haystacks fall inside units."""
+    am.debug_set("AM_DFA_CHUNK", chunk)
+    rng = random.Random(77 + chunk)
+    for _ in range(6):
+        needles, hays = fragment_case(rng, n_hay_max=12, hay_frags=400)
+        if "" in needles or not any(needles):
+            continue
+        hays = hays + ["", hays[0][:3] if hays else "", ""]
+        for case in (0, 1):
+            ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+            check_dfa_route(ns, hays, case)
+
+
+def test_no_dfa_section_is_an_error_only_when_forced():
+    a = am.Automaton(["needle", "hay"])                   # random short needles: the flattener gives no DFA section by itself
+    assert [int(c) for c in a.count_matches(0, ["hay needle hay"])] == [3]
+    a.set_kernel(3)
+    with pytest.raises(am.AmError):
+        a.count_matches(0, ["hay needle hay"])
+
+
+def test_dictionary_takes_the_table_walk_by_itself():
+    """The natural-text workload, reduced: the flattener gives the 100k-word dictionary a DFA section, batches of 1 MiB and more take k_dfa without being
+    asked, and its records are those of the suffix-filter kernel and of the oracle."""
+    w = synth.WORKLOADS["natural_100k_10GiB"]
+    needles = synth.needles_for("natural_100k_10GiB")
+    a = am.Automaton(needles)
+    o = oracle.Machine(needles)
+    cells = 192
+    hays = [bytes(synth.haystacks_host(needles, w["mixed"], 7 + i * cells, cells, natural=True)) for i in range(8)]      # 8 x 192 KiB = 1.5 MiB
+    lib = am.api.libam()
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    auto = a.run_records(w["case"], hays)
+    am.api.check(lib.am_profile_enable(0))
+    ms, n = C.c_double(0), C.c_uint64(0)
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value == 1, "records come out of ONE walk (tokens + k_dfa_place)"
+    a.set_kernel(2)
+    sf = a.run_records(w["case"], hays)
+    assert np.array_equal(auto, sf) and len(auto) > 100_000
+    exp = oracle_triples(o, w["case"], hays[:2])
+    sel = auto[auto["haystack"] < 2]
+    assert expand_records(o.values_off(), o.values(), sel["haystack"], sel["state"], sel["end_pos"]) == exp
+    # a token pool that is far too small: the walk is repeated with the pool the exact counts ask for, the records are the same
+    a.set_kernel(0)
+    am.debug_set("AM_SF_POOL_BLOCKS", 1)
+    try:
+        am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+        again = a.run_records(w["case"], hays)
+        am.api.check(lib.am_profile_enable(0))
+    finally:
+        am.debug_set("AM_SF_POOL_BLOCKS", -1)
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value == 2 and np.array_equal(again, sf)
+    assert [int(c) for c in a.count_matches(w["case"], hays)] == [o.count_matches(w["case"], h) for h in hays]
+    # below 1 MiB the suffix-filter route stays
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    small = a.run_records(w["case"], hays[:2])
+    am.api.check(lib.am_profile_enable(0))
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value == 0 and np.array_equal(small, sf[sf["haystack"] < 2])

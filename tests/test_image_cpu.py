@@ -31,6 +31,21 @@ def _check(chk, needles, hays, case, chunks=(None,)):
             assert n >= 0
             assert expand_records(vo, vals, recs[0], recs[1], recs[2]) == exp, (which, chunk, case, needles, hays)
             assert all(int(vo[s + 1] - vo[s]) == int(v) for s, v in zip(recs[1], recs[3]))
+    # the table walk (k_dfa's logic) on an image that was made to carry a DFA section (the flattener only gives one to dictionaries by itself)
+    if "" not in needles and any(needles):
+        chk.set("AM_DFA", 1)
+        try:
+            img = chk.flatten(p, case)
+        finally:
+            chk.set("AM_DFA", -1)
+        assert chk.dfa_header(img)["n_states"] >= 1
+        for chunk in chunks:
+            if chunk:
+                chk.set_dfa_chunk(img, chunk)
+            n, recs = chk.scan(img, 3, hays)
+            assert n >= 0
+            assert expand_records(vo, vals, recs[0], recs[1], recs[2]) == exp, ("dfa", chunk, case, needles, hays)
+            assert all(int(vo[s + 1] - vo[s]) == int(v) for s, v in zip(recs[1], recs[3]))
 
 
 def test_golden_counts_and_lists(chk, golden):
