@@ -713,7 +713,7 @@ int launch_scan_kernel(const Plan& p, int mode, const ScanOut& o, hipStream_t st
     }
     else if (p.use_dfa) {
         Prof pr("dfa", st);
-        HIP_TRY(launch_dfa(mode, p.dfa, p.bv, o, st));
+        HIP_TRY(launch_dfa(mode, p.dfa, p.bv, o, p.n_cu, st));
     }
     else {
         // the general AC-walk kernel is test infrastructure (libam_check.so, tests/native/am_ac.hip): make_plan refused the scan if it is not loaded

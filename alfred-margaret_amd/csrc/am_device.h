@@ -70,7 +70,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
 hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
 // table-walk kernel (am_dfa.hip): same two-pass protocol as the general kernel (count -> scan -> emit), unit = one lane's DfaView::chunk bytes
 uint64_t dfa_units(const DfaView& d, const BatchView& b);
-hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, hipStream_t st);
+hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 // records in ONE walk: tokens into ScanOut::pool (superblocks; ScanOut::block_next = their fill counts, zeroed before the launch; pool_ctrl[0] superblocks drawn,
 // [1] pool exhausted; n_blocks = superblocks in the pool), unit_counts as in count mode; then scan(unit_counts) and launch_dfa_place
 bool dfa_tokens_ok(const DfaView& d);

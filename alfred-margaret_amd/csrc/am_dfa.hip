@@ -76,7 +76,7 @@ struct DfaLane {
 
 // one lane's unit (see the head of the file); s_cls = the byte -> class map in LDS
 template <int MODE>
-__device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s_cls, uint64_t u)
+__device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s_cls, const uint32_t* s_rows, uint32_t hot_rows, uint64_t u)
 {
     const DfaView& d = L.d; const BatchView& b = L.b; const ScanOut& o = L.o;
     const uint32_t lc = d.log2_classes;
@@ -119,13 +119,17 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                const uint32_t e = d.next[((uint64_t)state << lc) + s_cls[byte]];
+                const uint32_t cl = s_cls[byte];
+                const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte)
+                                 : state < hot_rows ? s_rows[(state << lc) + cl] : d.next[((uint64_t)state << lc) + cl];
                 state = e & ~kDfaEnds;
                 if ((e & kDfaEnds) && mine) L.found(h, offset + (uint64_t)i, hs, state);
             }
             offset += 16;
         } else {
-            const uint32_t e = d.next[((uint64_t)state << lc) + s_cls[b.text[offset]]];
+            const uint32_t byte = b.text[offset], cl = s_cls[byte];
+            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte)
+                             : state < hot_rows ? s_rows[(state << lc) + cl] : d.next[((uint64_t)state << lc) + cl];
             state = e & ~kDfaEnds;
             offset++;
             if ((e & kDfaEnds) && offset > cs) L.found(h, offset - 1u, hs, state);
@@ -134,45 +138,39 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s
     L.flush();
 }
 
+// Persistent wavefronts: a workgroup of 16 copies the byte -> class map and the first `hot_rows` rows of the table into LDS (the flattener numbers the states so
+// that these are the root, the first letters and the heaviest prefixes: a third or more of the steps on natural text never leave the CU), then its wavefronts take
+// groups of 64 units until none is left.  Token mode: a wavefront's superblock serves all the groups it takes.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units)
+__global__ __launch_bounds__(1024, 2) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
 {
-    __shared__ uint8_t s_cls[256];
-    s_cls[threadIdx.x] = d.cls[threadIdx.x];
-    __syncthreads();
-    const uint64_t u = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    DfaLane<MODE> L{d, b, o, nullptr, nullptr, u};
-    if (u < n_units) {
-        if (MODE == kModeEmit) L.out = o.records + o.unit_offsets[u];
-        dfa_walk_unit<MODE>(L, s_cls, u);
-        if (MODE == kModeCount) o.unit_counts[u] = L.nrec;
-    }
-    if (MODE == kModeCount) {
-        const uint64_t nval = wave_sum_u64(L.nval);
-        if (lane_id() == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
-    }
-}
-
-// records in one walk: persistent wavefronts (a wavefront's superblock serves all the groups of 64 units it takes), tokens into the pool, counts per unit
-__global__ __launch_bounds__(256) void k_dfa_tokens(DfaView d, BatchView b, ScanOut o, uint64_t n_units)
-{
-    __shared__ uint8_t s_cls[256];
-    __shared__ uint32_t s_wave[4][4];                        // per wavefront: tokens in its superblock, the superblock's id, pool exhausted
-    s_cls[threadIdx.x] = d.cls[threadIdx.x];
+    extern __shared__ uint32_t s_dyn[];
+    uint32_t* s_rows = s_dyn;                                                     // hot_rows << log2_classes entries
+    uint32_t* s_wave = s_dyn + ((size_t)hot_rows << d.log2_classes);              // 16 x 4: per wavefront (token mode) tokens in its superblock, its id, pool exhausted
+    uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_wave + 64);
+    for (uint32_t i = threadIdx.x; i < (hot_rows << d.log2_classes); i += 1024u) s_rows[i] = d.next[i];
+    if (threadIdx.x < 256u) s_cls[threadIdx.x] = d.cls[threadIdx.x];
     const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    if (lane == 0) { s_wave[w][0] = 0u; s_wave[w][1] = kNone; s_wave[w][2] = 0u; }
+    if (lane == 0) { s_wave[4u * w] = 0u; s_wave[4u * w + 1u] = kNone; s_wave[4u * w + 2u] = 0u; }
     __syncthreads();
-    const uint64_t n_groups = (n_units + kWave - 1) / kWave, n_waves = (uint64_t)gridDim.x * 4u;
-    for (uint64_t g = (uint64_t)blockIdx.x * 4u + w; g < n_groups; g += n_waves) {
+    const uint64_t n_groups = (n_units + kWave - 1) / kWave, n_waves = (uint64_t)gridDim.x * 16u;
+    uint64_t nval = 0;
+    for (uint64_t g = (uint64_t)blockIdx.x * 16u + w; g < n_groups; g += n_waves) {
         const uint64_t u = g * kWave + lane;
         if (u < n_units) {
-            DfaLane<kModeTokens> L{d, b, o, nullptr, &s_wave[w][0], u};
-            dfa_walk_unit<kModeTokens>(L, s_cls, u);
-            o.unit_counts[u] = L.nrec;
+            DfaLane<MODE> L{d, b, o, nullptr, &s_wave[4u * w], u};
+            if (MODE == kModeEmit) L.out = o.records + o.unit_offsets[u];
+            dfa_walk_unit<MODE>(L, s_cls, s_rows, hot_rows, u);
+            if (MODE == kModeCount || MODE == kModeTokens) o.unit_counts[u] = L.nrec;
+            nval += L.nval;
         }
-        wave_lds_fence();                                   // (the token slots of this group are taken before the next group's first reserve looks at the fill)
+        if (MODE == kModeTokens) wave_lds_fence();          // (the token slots of this group are taken before the next group's first reserve looks at the fill)
     }
-    if (lane == 0 && s_wave[w][1] != kNone) o.block_next[s_wave[w][1]] = s_wave[w][0];      // the last superblock's fill
+    if (MODE == kModeTokens && lane == 0 && s_wave[4u * w + 1u] != kNone) o.block_next[s_wave[4u * w + 1u]] = s_wave[4u * w];      // the last superblock's fill
+    if (MODE == kModeCount) {
+        nval = wave_sum_u64(nval);
+        if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
+    }
 }
 
 // token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq
@@ -189,37 +187,42 @@ __global__ __launch_bounds__(256) void k_dfa_place(const Record* __restrict__ po
 
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
 
-hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, hipStream_t st)
+// rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
+static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_states, (64u * 1024u) >> (d.log2_classes + 2u)); }
+static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
+{
+    const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;
+    return (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2u, (n_groups + 15) / 16);
+}
+template <int MODE>
+static hipError_t launch_dfa_t(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const uint64_t n_units = dfa_units(d, b);
     if (n_units == 0) return hipSuccess;
-    const uint64_t blocks = (n_units + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if (mode == kModeCount) hipLaunchKernelGGL((k_dfa<kModeCount>), dim3((uint32_t)blocks), dim3(256), 0, st, d, b, o, n_units);
-    else if (mode == kModeEmit) hipLaunchKernelGGL((k_dfa<kModeEmit>), dim3((uint32_t)blocks), dim3(256), 0, st, d, b, o, n_units);
-    else if (mode == kModeAny) hipLaunchKernelGGL((k_dfa<kModeAny>), dim3((uint32_t)blocks), dim3(256), 0, st, d, b, o, n_units);
-    else return hipErrorInvalidValue;
+    const uint32_t hot = dfa_hot_rows(d);
+    const size_t lds = ((size_t)hot << (d.log2_classes + 2u)) + 64 * 4 + 256;
+    static bool raised[64] = {false};                        // (more than 64 KiB of dynamic LDS needs the attribute, once per instantiation and device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!raised[dev]) { const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return e; raised[dev] = true; }
+    hipLaunchKernelGGL((k_dfa<MODE>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
     return hipGetLastError();
+}
+hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+{
+    if (mode == kModeCount) return launch_dfa_t<kModeCount>(d, b, o, n_cu, st);
+    if (mode == kModeEmit) return launch_dfa_t<kModeEmit>(d, b, o, n_cu, st);
+    if (mode == kModeAny) return launch_dfa_t<kModeAny>(d, b, o, n_cu, st);
+    return hipErrorInvalidValue;
 }
 
 // records in one walk: is the unit small enough for a token's 16-bit fields, and how many wavefronts walk (= superblocks that may end up partly filled)
 bool dfa_tokens_ok(const DfaView& d) { return d.chunk != 0 && d.chunk <= 65536u; }
-uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu)
-{
-    const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;
-    const uint64_t wgs = std::min<uint64_t>((uint64_t)n_cu * 8u, (n_groups + 3) / 4);
-    return (uint32_t)(wgs * 4u);
-}
+uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu) { return dfa_workgroups(d, b, n_cu) * 16u; }
 // superblocks that hold `records` tokens whatever the split between the wavefronts: a sealed superblock holds at least kDfaSuper - kDfaSuperReserve
 uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves) { return records / (kDfaSuper - kDfaSuperReserve) + n_waves + 16; }
 uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(Record); }
-hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
-{
-    const uint64_t n_units = dfa_units(d, b);
-    if (n_units == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dfa_tokens, dim3(dfa_token_waves(d, b, n_cu) / 4u), dim3(256), 0, st, d, b, o, n_units);
-    return hipGetLastError();
-}
+hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st) { return launch_dfa_t<kModeTokens>(d, b, o, n_cu, st); }
 hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, Record* out, hipStream_t st)
 {
     if (n_super == 0) return hipSuccess;

@@ -813,13 +813,28 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     }
                 }
             }
+            // Classes: a row has a column for the COMMON bytes only -- the fewest (a power of two, with class 0) that label all but a thousandth of the edges.  In a
+            // dictionary 31 bytes do (the letters, the blank, the lead bytes of the accented ones); the bytes of a few Cyrillic words and of the upper-case spellings of
+            // non-ASCII letters would double the row twice for nothing.  A RARE byte (class kDfaRare) takes the textbook route instead: the state's own edge on it (a
+            // small hash of the rare edges) or the same question at the state's fallback (dfa_rare_step in am_image.h).
+            uint64_t edge_cnt[256] = {0};
+            for (const BEdge& e : be) edge_cnt[e.byte]++;
+            std::vector<uint32_t> by_cnt;
+            for (uint32_t b = 0; b < 256; b++) if (present[b]) by_cnt.push_back(b);
+            std::sort(by_cnt.begin(), by_cnt.end(), [&](uint32_t a, uint32_t b2) { return edge_cnt[a] != edge_cnt[b2] ? edge_cnt[a] > edge_cnt[b2] : a < b2; });
+            const uint64_t rare_permille = cfg::get(cfg::kDfaRarePermille) >= 0 ? (uint64_t)cfg::get(cfg::kDfaRarePermille) : 1ull;
+            uint32_t lc = 3;
+            for (;; lc++) {
+                uint64_t left_out = 0;
+                for (size_t k = (1u << lc) - 1u; k < by_cnt.size(); k++) left_out += edge_cnt[by_cnt[k]];
+                if (left_out * 1000ull <= be.size() * rare_permille || lc == 8) break;
+            }
             uint32_t n_cls = 1;
             std::vector<uint8_t> cls(256, 0);
-            for (uint32_t b = 0; b < 256; b++) if (present[b]) cls[b] = (uint8_t)n_cls++;
+            for (size_t k = 0; k < by_cnt.size(); k++) cls[by_cnt[k]] = k + 1u < (1u << lc) ? (uint8_t)n_cls++ : (uint8_t)kDfaRare;
             if (ic) for (uint32_t b = 'A'; b <= 'Z'; b++) cls[b] = cls[b + 0x20u];       // the kernels fold ASCII; the variants hold the folded byte only
-            const uint32_t lc = std::max(1u, log2_ceil(n_cls));
             const uint64_t table_bytes = ((uint64_t)n_nodes << lc) * 4ull;
-            if (n_cls <= 256 && n_nodes < 0x7FFFFFF0u && table_bytes <= (1ull << 30)) {
+            if (n_nodes < 0x7FFFFFF0u && table_bytes <= (1ull << 30)) {
                 // adjacency by source
                 std::vector<uint32_t> first(n_nodes + 1, 0);
                 for (const BEdge& e : be) first[e.src + 1]++;
@@ -829,20 +844,32 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 // breadth-first numbering; a node's fallback is set when it is first reached: delta(fallback(parent), byte), the root's children fall back to the root
                 std::vector<uint32_t> id(n_nodes, kNone), order; order.reserve(n_nodes);
                 std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a DFA state id
+                std::vector<uint32_t> tree_parent(n_nodes, 0);                   // the state that discovered it
                 std::vector<uint32_t> next((size_t)n_nodes << lc, 0);
                 const uint32_t C = 1u << lc;
+                std::unordered_map<uint64_t, uint32_t> rare_goto;                // (state id << 8 | byte) -> child id, the edges on rare bytes
+                auto delta_rare = [&](uint32_t st, uint32_t byte) {              // delta(st, rare byte) by the fallback chain
+                    for (;;) {
+                        const auto it = rare_goto.find(((uint64_t)st << 8) | byte);
+                        if (it != rare_goto.end()) return it->second;
+                        if (st == 0) return 0u;
+                        st = fb[st];
+                    }
+                };
                 id[0] = 0; order.push_back(0);
                 for (size_t qi = 0; qi < order.size(); qi++) {
                     const uint32_t x = order[qi], xi = (uint32_t)qi;
                     uint32_t* row = next.data() + ((size_t)xi << lc);
                     if (xi != 0) std::memcpy(row, next.data() + ((size_t)fb[xi] << lc), (size_t)C * 4);      // (the root's row starts as all-root = zeros)
                     for (uint32_t e = first[x]; e < first[x + 1]; e++) {
-                        const uint32_t y = adj[e].dst, cb = cls[adj[e].byte];
+                        const uint32_t y = adj[e].dst, byte = adj[e].byte, cb = cls[byte];
                         if (id[y] == kNone) {
                             id[y] = (uint32_t)order.size(); order.push_back(y);
-                            fb[id[y]] = xi == 0 ? 0u : next[((size_t)fb[xi] << lc) + cb];
+                            fb[id[y]] = xi == 0 ? 0u : cb == kDfaRare ? delta_rare(fb[xi], byte) : next[((size_t)fb[xi] << lc) + cb];
+                            tree_parent[id[y]] = xi;
                         }
-                        row[cb] = id[y];
+                        if (cb == kDfaRare) rare_goto[((uint64_t)xi << 8) | byte] = id[y];
+                        else row[cb] = id[y];
                     }
                 }
                 {
@@ -851,7 +878,50 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     next.resize((size_t)n_reached << lc);
                     std::vector<u32x2> out(n_reached, u32x2{0, 0});
                     for (uint32_t x = 1; x < (uint32_t)S; x++) if (vlen[x] > 0 && id[x] != kNone) out[id[x]] = u32x2{canon[x] + 1u, vlen[x]};
+                    // The states text dwells in get the smallest numbers (k_dfa keeps the first rows in LDS): after the root the 4095 states with the most needle
+                    // ends below them -- the first letters, then the heaviest prefixes --, the rest stay in breadth-first order.
+                    if (n_reached > 2) {
+                        std::vector<uint32_t> weight(n_reached, 0);
+                        for (uint32_t i = 0; i < n_reached; i++) weight[i] = out[i].x ? 1u : 0u;
+                        for (uint32_t i = n_reached; i-- > 1;) weight[tree_parent[i]] += weight[i];       // (breadth-first numbers: a node's discoverer comes before it)
+                        const uint32_t top = std::min<uint32_t>(4095u, n_reached - 1u);
+                        std::vector<uint32_t> cand(n_reached - 1u);
+                        for (uint32_t i = 1; i < n_reached; i++) cand[i - 1u] = i;
+                        auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
+                        std::partial_sort(cand.begin(), cand.begin() + top, cand.end(), heavier);
+                        std::vector<uint32_t> renum(n_reached, kNone);
+                        renum[0] = 0;
+                        for (uint32_t k = 0; k < top; k++) renum[cand[k]] = k + 1u;
+                        uint32_t nxt = top + 1u;
+                        for (uint32_t i = 1; i < n_reached; i++) if (renum[i] == kNone) renum[i] = nxt++;
+                        std::vector<uint32_t> next2(next.size());
+                        std::vector<u32x2> out2(n_reached);
+                        for (uint32_t i = 0; i < n_reached; i++) {
+                            const uint32_t* from = next.data() + ((size_t)i << lc);
+                            uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
+                            for (uint32_t c = 0; c < C; c++) to[c] = renum[from[c]];
+                            out2[renum[i]] = out[i];
+                        }
+                        next.swap(next2); out.swap(out2);
+                        std::vector<uint32_t> fb2(n_reached);
+                        for (uint32_t i = 0; i < n_reached; i++) fb2[renum[i]] = renum[fb[i]];
+                        fb.swap(fb2);
+                        std::unordered_map<uint64_t, uint32_t> rare2;
+                        for (const auto& kv : rare_goto) rare2[((uint64_t)renum[(uint32_t)(kv.first >> 8)] << 8) | (kv.first & 0xFFu)] = renum[kv.second];
+                        rare_goto.swap(rare2);
+                    }
+                    fb.resize(n_reached);
                     for (uint32_t& e : next) if (out[e].x) e |= kDfaEnds;
+                    // the rare edges: open addressing, (state, byte) -> child | kDfaEnds (dfa_rare_slot in am_image.h)
+                    uint32_t rare_lc = 4;
+                    while ((1ull << rare_lc) < 2ull * rare_goto.size() + 8ull) rare_lc++;
+                    std::vector<u32x4> rare_tab((size_t)1 << rare_lc, u32x4{0, 0, 0, 0});
+                    for (const auto& kv : rare_goto) {
+                        const uint32_t st = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFFu);
+                        uint32_t slot = dfa_rare_slot(st, byte, rare_lc);
+                        while (rare_tab[slot].w) slot = (slot + 1u) & ((1u << rare_lc) - 1u);
+                        rare_tab[slot] = u32x4{st, byte, kv.second | (out[kv.second].x ? kDfaEnds : 0u), 1u};
+                    }
                     uint32_t warm = 1;
                     for (uint32_t x = 0; x < (uint32_t)S; x++) warm = std::max(warm, bdepth[x]);
                     long chunk = cfg::get(cfg::kDfaChunk);
@@ -861,6 +931,9 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     h.off_dfa_next = blob.put(next);
                     h.off_dfa_out = blob.put(out);
                     h.off_dfa_cls = blob.put(cls);
+                    h.off_dfa_fail = blob.put(fb);
+                    h.off_dfa_rare = blob.put(rare_tab);
+                    h.dfa_rare_log2_cap = rare_lc;
                     h.dfa_n_states = n_reached; h.dfa_log2_classes = lc; h.dfa_warm = warm - 1u > 0 ? warm - 1u : 1u; h.dfa_chunk = (uint32_t)chunk;
                 }
             }
@@ -987,7 +1060,31 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         const u32x2* out = (const u32x2*)(img + h.off_dfa_out);
         const uint8_t* cls = img + h.off_dfa_cls;
         const uint32_t* vl = (const uint32_t*)(img + h.off_vlen);
-        for (uint32_t b = 0; b < 256; b++) if (cls[b] >= (1u << h.dfa_log2_classes)) { err = "image: DFA byte class out of range"; return false; }
+        for (uint32_t b = 0; b < 256; b++) if (cls[b] >= (1u << h.dfa_log2_classes) && cls[b] != kDfaRare) { err = "image: DFA byte class out of range"; return false; }
+        {
+            // the rare-byte walk: fallbacks lead towards the root (a smaller breadth-first depth is not recorded in the image: a walk of n_states steps that has not
+            // reached the root is a cycle), the hash has an empty slot, its entries stay inside the table
+            const uint32_t* fl = (const uint32_t*)(img + h.off_dfa_fail);
+            const u32x4* rt = (const u32x4*)(img + h.off_dfa_rare);
+            if (fl[0] != 0) { err = "image: DFA root fallback"; return false; }
+            for (uint32_t i = 0; i < h.dfa_n_states; i++) if (fl[i] >= h.dfa_n_states) { err = "image: DFA fallback out of range"; return false; }
+            std::vector<uint8_t> ok_root(h.dfa_n_states, 0);       // 1: the chain from here reaches the root
+            ok_root[0] = 1;
+            std::vector<uint32_t> path;
+            for (uint32_t i = 0; i < h.dfa_n_states; i++) {
+                path.clear();
+                uint32_t x = i;
+                while (!ok_root[x]) { path.push_back(x); if (path.size() > h.dfa_n_states) { err = "image: DFA fallbacks form a cycle"; return false; } x = fl[x]; }
+                for (uint32_t y : path) ok_root[y] = 1;
+            }
+            bool has_empty = false;
+            for (uint64_t i = 0; i < (1ull << h.dfa_rare_log2_cap); i++) {
+                if (!rt[i].w) { has_empty = true; continue; }
+                const uint32_t to = rt[i].z & ~kDfaEnds;
+                if (rt[i].x >= h.dfa_n_states || rt[i].y > 0xFFu || to >= h.dfa_n_states || ((rt[i].z & kDfaEnds) != 0) != (out[to].x != 0)) { err = "image: DFA rare edge out of range"; return false; }
+            }
+            if (!has_empty) { err = "image: DFA rare-edge table without an empty slot"; return false; }
+        }
         for (uint32_t i = 0; i < h.dfa_n_states; i++)
             if (out[i].x > S || (out[i].x != 0 && (canon[out[i].x - 1u] != out[i].x - 1u || vl[out[i].x - 1u] == 0 || out[i].y == 0))) { err = "image: DFA needle end out of range"; return false; }
         const uint64_t n = (uint64_t)h.dfa_n_states << h.dfa_log2_classes;
@@ -1018,9 +1115,10 @@ bool image_sections_in_bounds(const ImageHeader& h)
         }
     }
     if (h.dfa_n_states) {
-        if (h.dfa_log2_classes < 1 || h.dfa_log2_classes > 8 || h.dfa_n_states >= 0x7FFFFFF0u || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
+        if (h.dfa_log2_classes < 3 || h.dfa_log2_classes > 8 || h.dfa_n_states >= 0x7FFFFFF0u || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
         good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_states << h.dfa_log2_classes, 4) && ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&
-               (h.off_dfa_next & 15u) == 0 && (h.off_dfa_out & 7u) == 0;
+               (h.off_dfa_next & 15u) == 0 && (h.off_dfa_out & 7u) == 0 && ok(h.off_dfa_fail, h.dfa_n_states, 4) && h.dfa_rare_log2_cap >= 4 && h.dfa_rare_log2_cap <= 30 &&
+               ok(h.off_dfa_rare, 1ull << h.dfa_rare_log2_cap, 16) && (h.off_dfa_rare & 15u) == 0;
     }
     return good;
 }

@@ -76,7 +76,11 @@ struct ImageHeader {
     // a needle ends every few bytes (am_flatten.cpp decides; k_dfa in am_dfa.hip)
     uint64_t off_dfa_next;      // u32[dfa_n_states << dfa_log2_classes]: next state (bits 0-30) | bit 31: a needle ends there
     uint64_t off_dfa_out;       // u32x2[dfa_n_states] {canonical reference state + 1 (0: no needle ends), vlen}
-    uint64_t off_dfa_cls;       // u8[256]: byte -> class (IgnoreCase: the ASCII fold is part of the map); class 0 = bytes no needle contains
+    uint64_t off_dfa_cls;       // u8[256]: byte -> class (IgnoreCase: the ASCII fold is part of the map); class 0 = bytes no needle contains; kDfaRare = a byte
+                                // that few edges carry: no column, dfa_rare_step
+    uint64_t off_dfa_fail;      // u32[dfa_n_states]: fallback state (the rare-byte walk)
+    uint64_t off_dfa_rare;      // u32x4{state, byte, child | bit 31, used}[1 << dfa_rare_log2_cap]: the edges on rare bytes, open addressing
+    uint32_t dfa_rare_log2_cap, pad1;
     uint32_t dfa_n_states, dfa_log2_classes;
     uint32_t dfa_warm;          // bytes of history that determine the state: longest needle (variant) in bytes - 1
     uint32_t dfa_chunk;         // bytes of the batch one lane owns (multiple of 16)
@@ -168,9 +172,13 @@ struct DfaView {
     const uint32_t* next;
     const u32x2* out;
     const uint8_t* cls;
-    uint32_t n_states, log2_classes, warm, chunk;
+    const uint32_t* fail;
+    const u32x4* rare;
+    uint32_t n_states, log2_classes, warm, chunk, rare_log2_cap;
+    uint32_t ic;             // IgnoreCase image: haystack bytes A-Z count as a-z (the class map already says so; the rare-byte walk has to be told)
 };
 constexpr uint32_t kDfaEnds = 0x80000000u;
+constexpr uint32_t kDfaRare = 0xFFu;
 
 struct BatchView {
     const uint8_t* text;       // concatenated haystack bytes, 16-B aligned, readable up to round_up(total, 16)
@@ -200,7 +208,8 @@ inline DfaView make_dfa_view(const void* base, const ImageHeader& h)
     const uint8_t* b = (const uint8_t*)base;
     DfaView v;
     v.next = (const uint32_t*)(b + h.off_dfa_next); v.out = (const u32x2*)(b + h.off_dfa_out); v.cls = b + h.off_dfa_cls;
-    v.n_states = h.dfa_n_states; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk;
+    v.fail = (const uint32_t*)(b + h.off_dfa_fail); v.rare = (const u32x4*)(b + h.off_dfa_rare);
+    v.n_states = h.dfa_n_states; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk; v.rare_log2_cap = h.dfa_rare_log2_cap; v.ic = h.case_mode;
     return v;
 }
 
@@ -1039,6 +1048,29 @@ AM_HD void ac_scan_unit(const AcView& a, const BatchView& b, uint64_t unit, Emit
     }
 }
 
+// slot of (state, byte) in the hash of the edges on rare bytes (flattener and kernels must agree)
+AM_HD uint32_t dfa_rare_slot(uint32_t state, uint32_t byte, uint32_t log2_cap)
+{
+    uint32_t h = state * 0x9E3779B1u ^ byte * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    return (h * 0x2C1B3C6Du) >> (32u - log2_cap);
+}
+// delta(state, byte) for a byte without a column: the state's own edge on it, else the same question at its fallback, the root answering "root"
+// (Automaton.hs:489-510 as it stands; the dense rows are this loop precomputed for the common bytes).  Returns next state | kDfaEnds.
+AM_HD uint32_t dfa_rare_step(const DfaView& d, uint32_t state, uint32_t byte)
+{
+    const uint32_t mask = (1u << d.rare_log2_cap) - 1u;
+    for (;;) {
+        for (uint32_t i = dfa_rare_slot(state, byte, d.rare_log2_cap);; i = (i + 1u) & mask) {
+            const u32x4 e = load16(d.rare + i);
+            if (e.w == 0u) break;
+            if (e.x == state && e.y == byte) return e.z;
+        }
+        if (state == 0u) return 0u;
+        state = d.fail[state];
+    }
+}
+
 // One lane's unit of the DFA kernel, the plain form (the host image interpreter runs this; k_dfa in am_dfa.hip is the same walk with wide loads): bytes
 // [unit*chunk, (unit+1)*chunk) of the batch; the lane owns every match whose LAST byte lies there and warms the state up from the root over `warm` bytes
 // (any byte offset will do: a needle starts with no continuation byte, so a walk that starts inside a code point stays at the root until the next one).
@@ -1055,7 +1087,10 @@ AM_HD void dfa_scan_unit(const DfaView& d, const BatchView& b, uint64_t unit, Em
     uint32_t state = 0;
     while (offset < ce) {
         if (offset >= he) { do { h++; hs = he; he = b.offsets[h + 1]; } while (he == hs); state = 0; }
-        const uint32_t e = d.next[((uint64_t)state << d.log2_classes) + d.cls[b.text[offset]]];
+        uint32_t byte = b.text[offset];
+        const uint32_t cl = d.cls[byte];
+        if (cl == kDfaRare && d.ic && byte - 0x41u < 26u) byte += 0x20u;    // (the edges of an IgnoreCase automaton carry the folded letter)
+        const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, byte) : d.next[((uint64_t)state << d.log2_classes) + cl];
         state = e & ~kDfaEnds;
         offset++;
         if ((e & kDfaEnds) && offset > cs) { const u32x2 o = d.out[state]; emit((uint32_t)h, offset - hs, o.x - 1u, o.y); }

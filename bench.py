@@ -221,6 +221,10 @@ def main():
     if launches.value == 0:                            # automaton routed to the other kernel (e.g. empty needle)
         kname = b"ac" if kname == b"sf" else b"sf"
         am.api.check(lib.am_profile_read(kname, C.byref(ms), C.byref(launches)))
+    dfa_ms, dfa_launches = C.c_double(0), C.c_uint64(0)
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(dfa_ms), C.byref(dfa_launches)))
+    if dfa_launches.value and args.kernel == 0:        # a dictionary on the table-walk route (csrc/am_dfa.hip): one k_dfa launch per step
+        kname, ms, launches = b"dfa", dfa_ms, dfa_launches
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -232,8 +236,8 @@ def main():
         # (The general AC kernel runs a count launch and an emit launch per step: 8 B per record on average.)
         launches_n = max(int(launches.value), 1)
         per_step = launches_n / float(args.steps)
-        if kname == b"sf":
-            # the suffix-filter route: one k_sf launch per step; algorithmic bytes per launch as above
+        if kname in (b"sf", b"dfa"):
+            # the suffix-filter route: one k_sf launch per step; algorithmic bytes per launch as above (the table-walk route: one k_dfa launch)
             avg_ms = ms.value / launches_n
             alg_bytes = n_bytes + 16.0 * n_records + 16.0 * n_hay
         else:
@@ -350,12 +354,34 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
         elapsed = time.perf_counter() - t0
         am.api.check(lib.am_profile_enable(0))
         ms, launches = C.c_double(0), C.c_uint64(0)
-        am.api.check(lib.am_profile_read(b"sf", C.byref(ms), C.byref(launches)))
+        am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(launches)))            # the table-walk route (dictionaries: natural text), else the suffix filter
+        kernel = "k_dfa" if launches.value else "k_sf"
+        if not launches.value:
+            am.api.check(lib.am_profile_read(b"sf", C.byref(ms), C.byref(launches)))
         total = C.c_uint64(0)
         am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total)))          # warm
         t1 = time.perf_counter()
         am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total)))
         count_s = time.perf_counter() - t1
+        other_route = None
+        if kernel == "k_dfa":
+            # the same step on the suffix-filter route (am_automaton_set_kernel(a, 2)), so that the line shows what the choice of route is worth
+            am.api.check(lib.am_automaton_set_kernel(handle, 2))
+            try:
+                step()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    n_sf = step()
+                torch.cuda.synchronize(dev)
+                sf_s = (time.perf_counter() - t1) / 2
+                am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total)))
+                t1 = time.perf_counter()
+                am.api.check(lib.am_count_batch(handle, case, batch, None, C.byref(total)))
+                other_route = {"kernel": "k_sf", "value": round(n_bytes / float(1 << 30) / sf_s, 1), "count_only_gibps": round(n_bytes / float(1 << 30) / (time.perf_counter() - t1), 1),
+                               "same_record_count": n_sf == n_records}
+            finally:
+                am.api.check(lib.am_automaton_set_kernel(handle, 0))
         gate_args = copy.copy(args)
         gate_args.kernel, gate_args.parity_oracle_mib = 0, args.workloads_oracle_mib
         parity = parity_gate(gate_args, w, needles, machine, handle, case, batch, text, n_hay, 0, 1, dev, lib) if not args.no_parity else {}
@@ -365,13 +391,14 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
     avg_ms = ms.value / max(int(launches.value), 1)
     alg_bytes = n_bytes + 16.0 * n_records + 16.0 * n_hay                                       # 1 B per haystack byte + 16 B per record + 16 B per haystack
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    traffic, _src = pmc_traffic_entry(name, "k_sf", n_bytes)
+    traffic, _src = pmc_traffic_entry(name, kernel, n_bytes)
     gib = n_bytes / float(1 << 30)
     return {"value": round(gib * steps / elapsed, 1), "unit": "GiB/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "count_only_gibps": round(gib / count_s, 1),
             "config": {"n_needles": len(needles), "case": "IgnoreCase" if case else "CaseSensitive", "haystacks": n_hay, "haystack_bytes": w["hay_bytes"], "bytes": n_bytes},
             "records_per_step": n_records, "values_per_step": int(total.value),
-            "roofline": {"kernel": "k_sf", "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes),
+            "roofline": {"kernel": kernel, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes),
                          "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic},
+            **({"other_route": other_route} if other_route else {}),
             "parity": {k: parity.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "full_lists_checked", "matches_in_checked")},
             "build_s": round(build_s, 2), **({"contains_all": contains_all} if contains_all else {})}
 

@@ -90,12 +90,13 @@ class ImgCheck:
 
     @staticmethod
     def dfa_header(img):
-        f = struct.unpack_from("<3Q4I", img.tobytes()[256:296])          # ImageHeader.off_dfa_next ... dfa_chunk
-        return {"off_next": f[0], "off_out": f[1], "off_cls": f[2], "n_states": f[3], "log2_classes": f[4], "warm": f[5], "chunk": f[6]}
+        f = struct.unpack_from("<5Q6I", img.tobytes()[256:320])          # ImageHeader.off_dfa_next ... dfa_chunk
+        return {"off_next": f[0], "off_out": f[1], "off_cls": f[2], "off_fail": f[3], "off_rare": f[4], "rare_log2_cap": f[5], "n_states": f[7], "log2_classes": f[8],
+                "warm": f[9], "chunk": f[10]}
 
     @staticmethod
     def set_dfa_chunk(img, chunk):
-        img[292:296] = np.frombuffer(struct.pack("<I", chunk), dtype=np.uint8)   # ImageHeader.dfa_chunk (the host interpreter takes any value >= 1)
+        img[316:320] = np.frombuffer(struct.pack("<I", chunk), dtype=np.uint8)   # ImageHeader.dfa_chunk (the host interpreter takes any value >= 1)
 
     @staticmethod
     def set_ac_chunk(img, chunk):

@@ -34,10 +34,14 @@ def _check(chk, needles, hays, case, chunks=(None,)):
     # the table walk (k_dfa's logic) on an image that was made to carry a DFA section (the flattener only gives one to dictionaries by itself)
     if "" not in needles and any(needles):
         chk.set("AM_DFA", 1)
+        rare = len("".join(needles)) % 2 == 1                 # every other case: few columns, most bytes take the rare-byte walk (fallback chain + edge hash)
+        if rare:
+            chk.set("AM_DFA_RARE_PERMILLE", 400)
         try:
             img = chk.flatten(p, case)
         finally:
             chk.set("AM_DFA", -1)
+            chk.set("AM_DFA_RARE_PERMILLE", -1)
         assert chk.dfa_header(img)["n_states"] >= 1
         for chunk in chunks:
             if chunk:

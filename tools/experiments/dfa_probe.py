@@ -8,10 +8,12 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "natural_100k_10GiB"
 gib = float(sys.argv[2]) if len(sys.argv) > 2 else 2.0
 w = synth.WORKLOADS[wl]
 needles = synth.needles_for(wl)
+all_needles = needles
+if os.environ.get("AM_PROBE_NEEDLES"): needles = needles[:int(os.environ["AM_PROBE_NEEDLES"])]
 t0 = time.time(); a = am.Automaton(needles); lib = am.api.libam()
 dev = torch.device("cuda:0")
 n_hay = int(gib * (1 << 30)) // w["hay_bytes"]; cells = w["hay_bytes"] // 1024
-text, n_bytes = synth.haystacks_device(needles, w["mixed"], 0, n_hay * cells, dev, natural=bool(w.get("natural")))
+text, n_bytes = synth.haystacks_device(all_needles, w["mixed"], 0, n_hay * cells, dev, natural=bool(w.get("natural")))
 offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * w["hay_bytes"]
 b = C.c_void_p(); am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(b)))
 def timed(label, k, fn, reps=3):

@@ -16,8 +16,10 @@ for w, (n_hay, hb) in SPEC.items():
     if not os.path.exists(f):
         continue
     blocks = open(f).read().split("### ")
-    kernel = "k_rp_lds" if w.startswith("cfg5") else "k_sf"
-    emit = [b for b in blocks if re.match(r"void am::dev::k_rp_lds<false, false>" if kernel == "k_rp_lds" else r"void am::dev::k_sf<(true|false), 1,", b)]      # k_sf: MODE = 1, the match-emitting instantiation
+    kernel = "k_rp_lds" if w.startswith("cfg5") else "k_dfa" if w.startswith("natural") else "k_sf"
+    pattern = {"k_rp_lds": r"void am::dev::k_rp_lds<false, false>", "k_dfa": r"void am::dev::k_dfa<16>",           # k_dfa: MODE = 16, records in one walk (tokens)
+               "k_sf": r"void am::dev::k_sf<(true|false), 1,"}[kernel]                                                # k_sf: MODE = 1, the match-emitting instantiation
+    emit = [b for b in blocks if re.match(pattern, b)]
     if not emit:
         continue
     vals = {}
@@ -31,7 +33,7 @@ for w, (n_hay, hb) in SPEC.items():
     out["workloads"][w] = {"kernel": kernel, "launch_bytes": scanned, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                            "hbm_bytes_per_scanned_byte": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / scanned, "profile": "profiles/%s_pmc_traffic.md" % TAG}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
-lines = ["# %s -- HBM traffic of the dominant kernel per workload (k_sf; config 5: k_rp_lds, per byte of INPUT text) (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, ~2-GiB launches; tools/pmc_traffic.sh)" % TAG, "",
+lines = ["# %s -- HBM traffic of the dominant kernel per workload (k_sf; natural text: k_dfa; config 5: k_rp_lds, per byte of INPUT text) (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each, ~2-GiB launches; tools/pmc_traffic.sh)" % TAG, "",
          "| workload | launch | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes per scanned byte (2 x FETCH + WRITE) |", "|---|---|---|---|---|"]
 for w, e in out["workloads"].items():
     lines.append("| %s | %.2f GiB | %.0f | %.0f | %.3f |" % (w, e["launch_bytes"] / 2**30, e["fetch_size_kib"], e["write_size_kib"], e["hbm_bytes_per_scanned_byte"]))
