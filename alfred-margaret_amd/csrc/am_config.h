@@ -21,7 +21,7 @@ enum Key {
     kSfProbeTwo,          // AM_SF_PROBE_TWO: A/B -- automata with few 4-byte-suffix keys also take the instantiation whose probe rounds always look at two candidates per lane
     kNoSmallRun,          // AM_NO_SMALL_RUN: am_run on small batches takes the general path
     kDfa,                 // AM_DFA: 0 = no automaton gets a DFA section / none is used; 1 = every automaton whose table fits gets one (read when an image is flattened); unset: dictionaries with heavy suffix nodes
-    kDfaChunk,            // AM_DFA_CHUNK: bytes of the batch one lane of k_dfa owns (read when an image is flattened; default 512)
+    kDfaChunk,            // AM_DFA_CHUNK: bytes of the batch one lane of k_dfa owns (read when an image is flattened; default 2048)
     kDfaRarePermille,     // AM_DFA_RARE_PERMILLE: share of the edges (in thousandths; default 1) whose bytes may go without a column of the DFA table (tests: 300 makes most bytes rare)
     kNoIdsScan,           // AM_NO_IDS_SCAN: containsAll folds the records of a full scan (k_idset) instead of setting the id bits inside k_sf
     kRpFullScans, kRpSplice, kRpPieces, kRpParallelFold, kRpGroups, kRpNoFuse, kRpNoSpin, kRpMatMain, kRpNoRangeReuse, kRpTrace,

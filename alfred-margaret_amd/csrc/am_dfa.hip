@@ -142,7 +142,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s
 // that these are the root, the first letters and the heaviest prefixes: a third or more of the steps on natural text never leave the CU), then its wavefronts take
 // groups of 64 units until none is left.  Token mode: a wavefront's superblock serves all the groups it takes.
 template <int MODE>
-__global__ __launch_bounds__(1024, 2) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
+__global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
 {
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_rows = s_dyn;                                                     // hot_rows << log2_classes entries
