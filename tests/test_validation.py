@@ -100,3 +100,64 @@ def _header_size(lib, good):
         if good.find(struct.pack("<Q", x)) in range(0, size):
             return size
     raise AssertionError("header size not found")
+
+
+def _restamp(lib, good, bad):
+    """`bad` (a modified copy of the image `good`) with the checksum the library would compute for it."""
+    hsize = _header_size(lib, good)
+    stored = struct.unpack_from("<Q", good, _checksum_offset(good, _stored_checksum(good, hsize)))[0]
+    x = 0xcbf29ce484222325
+    data = bytes(bad[hsize:])
+    n8 = len(data) // 8
+    for wv in struct.unpack_from("<%dQ" % n8, data):
+        x = ((x ^ wv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    for bv in data[n8 * 8:]:
+        x = ((x ^ bv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    struct.pack_into("<Q", bad, _checksum_offset(good, stored), x)
+    return bytes(bad)
+
+
+def _stored_checksum(good, hsize):
+    x = 0xcbf29ce484222325
+    data = good[hsize:]
+    n8 = len(data) // 8
+    for wv in struct.unpack_from("<%dQ" % n8, data):
+        x = ((x ^ wv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    for bv in data[n8 * 8:]:
+        x = ((x ^ bv) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return x
+
+
+def test_damaged_dfa_section_is_refused():
+    """Image version 13: the table-walk kernel follows `next`, `out`, `cls`, `fail` and the rare-edge hash of the DFA section without bounds checks, so an
+    image from outside whose section points out of its tables (or whose fallbacks never reach the root) must be refused like a damaged suffix section."""
+    chk = ImgCheck()
+    chk.set("AM_DFA", 1)
+    chk.set("AM_DFA_RARE_PERMILLE", 300)
+    try:
+        good = bytes(chk.flatten(am.Automaton(["tshirt", "shirts", "shorts", "übergrößen", "shirt"]), 1))
+    finally:
+        chk.set("AM_DFA", -1)
+        chk.set("AM_DFA_RARE_PERMILLE", -1)
+    d = chk.dfa_header(np.frombuffer(good, dtype=np.uint8))
+    assert d["n_states"] > 20 and d["rare_log2_cap"] >= 4
+    lib = am.api.libam()
+    out = C.c_void_p()
+    rc = lib.am_automaton_from_host_image(good, len(good), C.byref(out))
+    assert rc in (am.AM_OK, am.AM_ERR_NO_DEVICE), lib.am_last_error()
+    if rc == am.AM_OK:
+        lib.am_automaton_destroy(out)
+
+    def refused(mutate, what):
+        bad = bytearray(good)
+        mutate(bad)
+        rc = lib.am_automaton_from_host_image(_restamp(lib, good, bad), len(bad), C.byref(out))
+        assert rc == am.AM_ERR_INVALID, (what, rc, lib.am_last_error())
+        assert b"DFA" in lib.am_last_error(), (what, lib.am_last_error())
+
+    refused(lambda b: struct.pack_into("<I", b, d["off_next"] + 4 * 5, d["n_states"] + 7), "a transition to a state that does not exist")
+    refused(lambda b: struct.pack_into("<I", b, d["off_next"] + 4 * 5, struct.unpack_from("<I", b, d["off_next"] + 4 * 5)[0] ^ 0x80000000), "a needle-end bit that disagrees with the target")
+    refused(lambda b: struct.pack_into("<B", b, d["off_cls"] + ord("s"), 200), "a byte class without a column")
+    refused(lambda b: struct.pack_into("<I", b, d["off_out"] + 8 * 3, 10 ** 6), "a needle end at a reference state that does not exist")
+    refused(lambda b: (struct.pack_into("<I", b, d["off_fail"] + 4 * 7, 9), struct.pack_into("<I", b, d["off_fail"] + 4 * 9, 7)), "fallbacks that go round in a circle")
+    refused(lambda b: struct.pack_into("<I", b, d["off_fail"], 3), "a root that falls back")
