@@ -74,6 +74,17 @@ struct DfaLane {
 
 }  // namespace
 
+// dfa_common_step (am_image.h) with the first rows of the table in LDS: a chain state answers with its child or hands the question to its fallback's row
+__device__ __forceinline__ uint32_t dfa_step_lds(const DfaView& d, const uint32_t* s_rows, uint32_t hot_rows, uint32_t state, uint32_t cl)
+{
+    if (state >= d.n_rows) {
+        const u32x2 r = d.chain[state - d.n_rows];
+        if ((r.y >> 24) == cl) return r.x;
+        state = r.y & 0xFFFFFFu;
+    }
+    return state < hot_rows ? s_rows[(state << d.log2_classes) + cl] : d.next[((uint64_t)state << d.log2_classes) + cl];
+}
+
 // one lane's unit (see the head of the file); s_cls = the byte -> class map in LDS
 template <int MODE>
 __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s_cls, const uint32_t* s_rows, uint32_t hot_rows, uint64_t u)
@@ -120,16 +131,14 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s
             for (int i = 0; i < 16; i++) {
                 const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 const uint32_t cl = s_cls[byte];
-                const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte)
-                                 : state < hot_rows ? s_rows[(state << lc) + cl] : d.next[((uint64_t)state << lc) + cl];
+                const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step_lds(d, s_rows, hot_rows, state, cl);
                 state = e & ~kDfaEnds;
                 if ((e & kDfaEnds) && mine) L.found(h, offset + (uint64_t)i, hs, state);
             }
             offset += 16;
         } else {
             const uint32_t byte = b.text[offset], cl = s_cls[byte];
-            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte)
-                             : state < hot_rows ? s_rows[(state << lc) + cl] : d.next[((uint64_t)state << lc) + cl];
+            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step_lds(d, s_rows, hot_rows, state, cl);
             state = e & ~kDfaEnds;
             offset++;
             if ((e & kDfaEnds) && offset > cs) L.found(h, offset - 1u, hs, state);
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(256) void k_dfa_place(const Record* __restrict__ po
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
 
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
-static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_states, (64u * 1024u) >> (d.log2_classes + 2u)); }
+static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (d.log2_classes + 2u)); }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 {
     const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;

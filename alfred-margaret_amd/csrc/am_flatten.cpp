@@ -843,11 +843,13 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 { std::vector<uint32_t> cur(first.begin(), first.end() - 1); for (const BEdge& e : be) adj[cur[e.src]++] = e; }
                 // breadth-first numbering; a node's fallback is set when it is first reached: delta(fallback(parent), byte), the root's children fall back to the root
                 std::vector<uint32_t> id(n_nodes, kNone), order; order.reserve(n_nodes);
-                std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a DFA state id
+                std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a breadth-first number
                 std::vector<uint32_t> tree_parent(n_nodes, 0);                   // the state that discovered it
-                std::vector<uint32_t> next((size_t)n_nodes << lc, 0);
+                std::vector<uint32_t> n_goto(n_nodes, 0), child_of(n_nodes, 0);  // edges of a state; the child of its last common-byte edge ...
+                std::vector<uint8_t> child_cls(n_nodes, 0), has_rare(n_nodes, 0); // ... and that edge's class; does it have an edge on a rare byte
+                std::vector<uint32_t> next((size_t)n_nodes << lc, 0);            // every state's dense row for now (what the rows of the image are cut from)
                 const uint32_t C = 1u << lc;
-                std::unordered_map<uint64_t, uint32_t> rare_goto;                // (state id << 8 | byte) -> child id, the edges on rare bytes
+                std::unordered_map<uint64_t, uint32_t> rare_goto;                // (state << 8 | byte) -> child, the edges on rare bytes
                 auto delta_rare = [&](uint32_t st, uint32_t byte) {              // delta(st, rare byte) by the fallback chain
                     for (;;) {
                         const auto it = rare_goto.find(((uint64_t)st << 8) | byte);
@@ -868,59 +870,84 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                             fb[id[y]] = xi == 0 ? 0u : cb == kDfaRare ? delta_rare(fb[xi], byte) : next[((size_t)fb[xi] << lc) + cb];
                             tree_parent[id[y]] = xi;
                         }
-                        if (cb == kDfaRare) rare_goto[((uint64_t)xi << 8) | byte] = id[y];
-                        else row[cb] = id[y];
+                        n_goto[xi]++;
+                        if (cb == kDfaRare) { rare_goto[((uint64_t)xi << 8) | byte] = id[y]; has_rare[xi] = 1; }
+                        else { row[cb] = id[y]; child_of[xi] = id[y]; child_cls[xi] = (uint8_t)cb; }
                     }
                 }
                 {
                     // (nodes no byte string reaches -- an upper-case needle letter under IgnoreCase has no spelling -- get no state: the reference never reaches them either)
                     const uint32_t n_reached = (uint32_t)order.size();
-                    next.resize((size_t)n_reached << lc);
                     std::vector<u32x2> out(n_reached, u32x2{0, 0});
                     for (uint32_t x = 1; x < (uint32_t)S; x++) if (vlen[x] > 0 && id[x] != kNone) out[id[x]] = u32x2{canon[x] + 1u, vlen[x]};
-                    // The states text dwells in get the smallest numbers (k_dfa keeps the first rows in LDS): after the root the 4095 states with the most needle
-                    // ends below them -- the first letters, then the heaviest prefixes --, the rest stay in breadth-first order.
-                    if (n_reached > 2) {
-                        std::vector<uint32_t> weight(n_reached, 0);
-                        for (uint32_t i = 0; i < n_reached; i++) weight[i] = out[i].x ? 1u : 0u;
-                        for (uint32_t i = n_reached; i-- > 1;) weight[tree_parent[i]] += weight[i];       // (breadth-first numbers: a node's discoverer comes before it)
-                        const uint32_t top = std::min<uint32_t>(4095u, n_reached - 1u);
-                        std::vector<uint32_t> cand(n_reached - 1u);
-                        for (uint32_t i = 1; i < n_reached; i++) cand[i - 1u] = i;
-                        auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
-                        std::partial_sort(cand.begin(), cand.begin() + top, cand.end(), heavier);
-                        std::vector<uint32_t> renum(n_reached, kNone);
-                        renum[0] = 0;
-                        for (uint32_t k = 0; k < top; k++) renum[cand[k]] = k + 1u;
-                        uint32_t nxt = top + 1u;
-                        for (uint32_t i = 1; i < n_reached; i++) if (renum[i] == kNone) renum[i] = nxt++;
-                        std::vector<uint32_t> next2(next.size());
-                        std::vector<u32x2> out2(n_reached);
-                        for (uint32_t i = 0; i < n_reached; i++) {
+                    // ROW states and CHAIN states.  Deep in a dictionary nearly every state has one child, and a dense row there is 256 bytes of which a visitor reads
+                    // four -- a 64-byte line fetched for every step (27 bytes per scanned byte, measured).  Such a state keeps 8 bytes instead: {its child, the child's
+                    // class, the state it falls back to}, and anything but the child's byte asks the fallback's row: delta(x, c) = delta(fallback(x), c) where x has no edge
+                    // on c.  For that to be ONE more load the fallback must have a row, so every state some chain state falls back to is a row state; so are the root, the
+                    // branching states and the states with an edge on a rare byte.  Chain states are numbered along their paths (a word's tail shares cache lines).
+                    std::vector<uint8_t> is_row(n_reached, 0);
+                    is_row[0] = 1;
+                    for (uint32_t i = 1; i < n_reached; i++) if (n_goto[i] > 1 || has_rare[i]) is_row[i] = 1;
+                    {
+                        std::vector<uint8_t> promoted(n_reached, 0);
+                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i]) promoted[fb[i]] = 1;     // (decided on the candidates: a promoted candidate's own fallback may be promoted needlessly)
+                        for (uint32_t i = 1; i < n_reached; i++) if (promoted[i]) is_row[i] = 1;
+                    }
+                    if (cfg::get(cfg::kDfaNoChains) > 0) std::fill(is_row.begin(), is_row.end(), 1);      // A/B: dense rows for every state (round 5's first layout)
+                    // numbers: the root, the 4 095 row states with the most needle ends below them (k_dfa keeps the first rows in LDS), the other row states in
+                    // breadth-first order; then the chain states, path by path
+                    std::vector<uint32_t> weight(n_reached, 0);
+                    for (uint32_t i = 0; i < n_reached; i++) weight[i] = out[i].x ? 1u : 0u;
+                    for (uint32_t i = n_reached; i-- > 1;) weight[tree_parent[i]] += weight[i];       // (breadth-first numbers: a node's discoverer comes before it)
+                    std::vector<uint32_t> rows;
+                    for (uint32_t i = 1; i < n_reached; i++) if (is_row[i]) rows.push_back(i);
+                    const uint32_t top = std::min<uint32_t>(4095u, (uint32_t)rows.size());
+                    auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
+                    std::vector<uint32_t> cand(rows);
+                    std::partial_sort(cand.begin(), cand.begin() + top, cand.end(), heavier);
+                    std::vector<uint32_t> renum(n_reached, kNone);
+                    renum[0] = 0;
+                    uint32_t nxt = 1;
+                    for (uint32_t k = 0; k < top; k++) renum[cand[k]] = nxt++;
+                    for (uint32_t i : rows) if (renum[i] == kNone) renum[i] = nxt++;
+                    const uint32_t n_rows = nxt;
+                    for (uint32_t i = 1; i < n_reached; i++) {
+                        if (renum[i] != kNone) continue;                                  // (a chain state not yet on a path: the head of one, breadth-first order sees heads first)
+                        for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
+                            renum[y] = nxt++;
+                            if (n_goto[y] != 1) break;
+                            y = child_of[y];
+                        }
+                    }
+                    if (n_rows >= (1u << 24)) { /* a chain record holds its fallback row in 24 bits: no DFA section for this automaton */ }
+                    else {
+                    std::vector<uint32_t> next2((size_t)n_rows << lc);
+                    std::vector<u32x2> chain(n_reached - n_rows), out2(n_reached);
+                    std::vector<uint32_t> fb2(n_reached);
+                    for (uint32_t i = 0; i < n_reached; i++) {
+                        out2[renum[i]] = out[i];
+                        fb2[renum[i]] = renum[fb[i]];
+                    }
+                    for (uint32_t i = 0; i < n_reached; i++) {
+                        if (is_row[i]) {
                             const uint32_t* from = next.data() + ((size_t)i << lc);
                             uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
-                            for (uint32_t c = 0; c < C; c++) to[c] = renum[from[c]];
-                            out2[renum[i]] = out[i];
+                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[c] = t | (out2[t].x ? kDfaEnds : 0u); }
+                        } else {
+                            const uint32_t ch = n_goto[i] == 1 ? renum[child_of[i]] : 0u;
+                            chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | (out2[ch].x ? kDfaEnds : 0u)) : 0u,
+                                                             ((n_goto[i] == 1 ? (uint32_t)child_cls[i] : kDfaNoChild) << 24) | renum[fb[i]]};
                         }
-                        next.swap(next2); out.swap(out2);
-                        std::vector<uint32_t> fb2(n_reached);
-                        for (uint32_t i = 0; i < n_reached; i++) fb2[renum[i]] = renum[fb[i]];
-                        fb.swap(fb2);
-                        std::unordered_map<uint64_t, uint32_t> rare2;
-                        for (const auto& kv : rare_goto) rare2[((uint64_t)renum[(uint32_t)(kv.first >> 8)] << 8) | (kv.first & 0xFFu)] = renum[kv.second];
-                        rare_goto.swap(rare2);
                     }
-                    fb.resize(n_reached);
-                    for (uint32_t& e : next) if (out[e].x) e |= kDfaEnds;
                     // the rare edges: open addressing, (state, byte) -> child | kDfaEnds (dfa_rare_slot in am_image.h)
                     uint32_t rare_lc = 4;
                     while ((1ull << rare_lc) < 2ull * rare_goto.size() + 8ull) rare_lc++;
                     std::vector<u32x4> rare_tab((size_t)1 << rare_lc, u32x4{0, 0, 0, 0});
                     for (const auto& kv : rare_goto) {
-                        const uint32_t st = (uint32_t)(kv.first >> 8), byte = (uint32_t)(kv.first & 0xFFu);
+                        const uint32_t st = renum[(uint32_t)(kv.first >> 8)], byte = (uint32_t)(kv.first & 0xFFu), to = renum[kv.second];
                         uint32_t slot = dfa_rare_slot(st, byte, rare_lc);
                         while (rare_tab[slot].w) slot = (slot + 1u) & ((1u << rare_lc) - 1u);
-                        rare_tab[slot] = u32x4{st, byte, kv.second | (out[kv.second].x ? kDfaEnds : 0u), 1u};
+                        rare_tab[slot] = u32x4{st, byte, to | (out2[to].x ? kDfaEnds : 0u), 1u};
                     }
                     uint32_t warm = 1;
                     for (uint32_t x = 0; x < (uint32_t)S; x++) warm = std::max(warm, bdepth[x]);
@@ -928,13 +955,16 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     if (chunk < 64 || chunk > (1 << 20)) chunk = 2048;          // (512: 10 % of the steps are warm-up; measured 131 / 136 / 139 / 139 GiB/s counting at 512 / 1024 / 2048 / 4096)
                     chunk = (chunk + 15) & ~15L;
                     while ((uint64_t)chunk < 4ull * warm && chunk < (1 << 20)) chunk *= 2;          // the warm-up stays a fraction of the lane's own bytes
-                    h.off_dfa_next = blob.put(next);
-                    h.off_dfa_out = blob.put(out);
+                    h.off_dfa_next = blob.put(next2);
+                    h.off_dfa_chain = blob.put(chain);
+                    h.off_dfa_out = blob.put(out2);
                     h.off_dfa_cls = blob.put(cls);
-                    h.off_dfa_fail = blob.put(fb);
+                    h.off_dfa_fail = blob.put(fb2);
                     h.off_dfa_rare = blob.put(rare_tab);
                     h.dfa_rare_log2_cap = rare_lc;
+                    h.dfa_n_rows = n_rows;
                     h.dfa_n_states = n_reached; h.dfa_log2_classes = lc; h.dfa_warm = warm - 1u > 0 ? warm - 1u : 1u; h.dfa_chunk = (uint32_t)chunk;
+                    }
                 }
             }
         }
@@ -1087,10 +1117,16 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
         }
         for (uint32_t i = 0; i < h.dfa_n_states; i++)
             if (out[i].x > S || (out[i].x != 0 && (canon[out[i].x - 1u] != out[i].x - 1u || vl[out[i].x - 1u] == 0 || out[i].y == 0))) { err = "image: DFA needle end out of range"; return false; }
-        const uint64_t n = (uint64_t)h.dfa_n_states << h.dfa_log2_classes;
+        const uint64_t n = (uint64_t)h.dfa_n_rows << h.dfa_log2_classes;
         for (uint64_t i = 0; i < n; i++) {
             const uint32_t to = next[i] & ~kDfaEnds;
             if (to >= h.dfa_n_states || ((next[i] & kDfaEnds) != 0) != (out[to].x != 0)) { err = "image: DFA transition out of range"; return false; }
+        }
+        const u32x2* chain = (const u32x2*)(img + h.off_dfa_chain);
+        for (uint32_t i = 0; i < h.dfa_n_states - h.dfa_n_rows; i++) {
+            const uint32_t to = chain[i].x & ~kDfaEnds, cl = chain[i].y >> 24, fbr = chain[i].y & 0xFFFFFFu;
+            if (fbr >= h.dfa_n_rows || (cl >= (1u << h.dfa_log2_classes) && cl != kDfaNoChild) || to >= h.dfa_n_states || ((chain[i].x & kDfaEnds) != 0) != (out[to].x != 0 && cl != kDfaNoChild) ||
+                (cl == kDfaNoChild && chain[i].x != 0)) { err = "image: DFA chain record out of range"; return false; }
         }
     }
     return true;
@@ -1116,7 +1152,9 @@ bool image_sections_in_bounds(const ImageHeader& h)
     }
     if (h.dfa_n_states) {
         if (h.dfa_log2_classes < 3 || h.dfa_log2_classes > 8 || h.dfa_n_states >= 0x7FFFFFF0u || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
-        good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_states << h.dfa_log2_classes, 4) && ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&
+        if (h.dfa_n_rows == 0 || h.dfa_n_rows > h.dfa_n_states || h.dfa_n_rows >= (1u << 24)) return false;
+        good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_rows << h.dfa_log2_classes, 4) && ok(h.off_dfa_chain, h.dfa_n_states - h.dfa_n_rows, 8) && (h.off_dfa_chain & 7u) == 0 &&
+               ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&
                (h.off_dfa_next & 15u) == 0 && (h.off_dfa_out & 7u) == 0 && ok(h.off_dfa_fail, h.dfa_n_states, 4) && h.dfa_rare_log2_cap >= 4 && h.dfa_rare_log2_cap <= 30 &&
                ok(h.off_dfa_rare, 1ull << h.dfa_rare_log2_cap, 16) && (h.off_dfa_rare & 15u) == 0;
     }

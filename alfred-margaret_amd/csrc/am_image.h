@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 13;
+constexpr uint32_t kImageVersion = 14;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -74,13 +74,15 @@ struct ImageHeader {
     uint32_t sf_row_first;      // edges[sf_row_first .. n_edges): the ROWS of the nodes with more than 4 children (SfNode::label, SfEdge::pad)
     // DFA section (version 13; dfa_n_states == 0: none): the byte-level automaton with every transition resolved, for dictionaries that meet text in which
     // a needle ends every few bytes (am_flatten.cpp decides; k_dfa in am_dfa.hip)
-    uint64_t off_dfa_next;      // u32[dfa_n_states << dfa_log2_classes]: next state (bits 0-30) | bit 31: a needle ends there
+    uint64_t off_dfa_next;      // u32[dfa_n_rows << dfa_log2_classes]: next state (bits 0-30) | bit 31: a needle ends there
     uint64_t off_dfa_out;       // u32x2[dfa_n_states] {canonical reference state + 1 (0: no needle ends), vlen}
     uint64_t off_dfa_cls;       // u8[256]: byte -> class (IgnoreCase: the ASCII fold is part of the map); class 0 = bytes no needle contains; kDfaRare = a byte
                                 // that few edges carry: no column, dfa_rare_step
     uint64_t off_dfa_fail;      // u32[dfa_n_states]: fallback state (the rare-byte walk)
     uint64_t off_dfa_rare;      // u32x4{state, byte, child | bit 31, used}[1 << dfa_rare_log2_cap]: the edges on rare bytes, open addressing
-    uint32_t dfa_rare_log2_cap, pad1;
+    uint32_t dfa_rare_log2_cap;
+    uint32_t dfa_n_rows;        // states [0, dfa_n_rows) have a dense row in `next`; the others a chain record (off_dfa_chain)
+    uint64_t off_dfa_chain;     // u32x2[dfa_n_states - dfa_n_rows]: {the one child | bit 31, the child's class << 24 | the row state this one falls back to}
     uint32_t dfa_n_states, dfa_log2_classes;
     uint32_t dfa_warm;          // bytes of history that determine the state: longest needle (variant) in bytes - 1
     uint32_t dfa_chunk;         // bytes of the batch one lane owns (multiple of 16)
@@ -174,11 +176,13 @@ struct DfaView {
     const uint8_t* cls;
     const uint32_t* fail;
     const u32x4* rare;
-    uint32_t n_states, log2_classes, warm, chunk, rare_log2_cap;
+    const u32x2* chain;
+    uint32_t n_states, n_rows, log2_classes, warm, chunk, rare_log2_cap;
     uint32_t ic;             // IgnoreCase image: haystack bytes A-Z count as a-z (the class map already says so; the rare-byte walk has to be told)
 };
 constexpr uint32_t kDfaEnds = 0x80000000u;
 constexpr uint32_t kDfaRare = 0xFFu;
+constexpr uint32_t kDfaNoChild = 0xFEu;         // chain record of a state without a child: no class equals it
 
 struct BatchView {
     const uint8_t* text;       // concatenated haystack bytes, 16-B aligned, readable up to round_up(total, 16)
@@ -208,8 +212,8 @@ inline DfaView make_dfa_view(const void* base, const ImageHeader& h)
     const uint8_t* b = (const uint8_t*)base;
     DfaView v;
     v.next = (const uint32_t*)(b + h.off_dfa_next); v.out = (const u32x2*)(b + h.off_dfa_out); v.cls = b + h.off_dfa_cls;
-    v.fail = (const uint32_t*)(b + h.off_dfa_fail); v.rare = (const u32x4*)(b + h.off_dfa_rare);
-    v.n_states = h.dfa_n_states; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk; v.rare_log2_cap = h.dfa_rare_log2_cap; v.ic = h.case_mode;
+    v.fail = (const uint32_t*)(b + h.off_dfa_fail); v.rare = (const u32x4*)(b + h.off_dfa_rare); v.chain = (const u32x2*)(b + h.off_dfa_chain);
+    v.n_states = h.dfa_n_states; v.n_rows = h.dfa_n_rows; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk; v.rare_log2_cap = h.dfa_rare_log2_cap; v.ic = h.case_mode;
     return v;
 }
 
@@ -1071,6 +1075,19 @@ AM_HD uint32_t dfa_rare_step(const DfaView& d, uint32_t state, uint32_t byte)
     }
 }
 
+// delta(state, class) for a byte with a column.  A ROW state has its dense row.  A CHAIN state -- one child (or none), numbered along its path so that
+// the records of a word's tail share cache lines -- has 8 bytes: its child under the child's class, else the answer of the row state it falls back to
+// (the flattener makes every state some chain state falls back to a row state: delta(x, c) = delta(fallback(x), c) wherever x has no edge on c).
+AM_HD uint32_t dfa_common_step(const DfaView& d, uint32_t state, uint32_t cl)
+{
+    if (state >= d.n_rows) {
+        const u32x2 r = d.chain[state - d.n_rows];
+        if ((r.y >> 24) == cl) return r.x;
+        state = r.y & 0xFFFFFFu;
+    }
+    return d.next[((uint64_t)state << d.log2_classes) + cl];
+}
+
 // One lane's unit of the DFA kernel, the plain form (the host image interpreter runs this; k_dfa in am_dfa.hip is the same walk with wide loads): bytes
 // [unit*chunk, (unit+1)*chunk) of the batch; the lane owns every match whose LAST byte lies there and warms the state up from the root over `warm` bytes
 // (any byte offset will do: a needle starts with no continuation byte, so a walk that starts inside a code point stays at the root until the next one).
@@ -1090,7 +1107,7 @@ AM_HD void dfa_scan_unit(const DfaView& d, const BatchView& b, uint64_t unit, Em
         uint32_t byte = b.text[offset];
         const uint32_t cl = d.cls[byte];
         if (cl == kDfaRare && d.ic && byte - 0x41u < 26u) byte += 0x20u;    // (the edges of an IgnoreCase automaton carry the folded letter)
-        const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, byte) : d.next[((uint64_t)state << d.log2_classes) + cl];
+        const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, byte) : dfa_common_step(d, state, cl);
         state = e & ~kDfaEnds;
         offset++;
         if ((e & kDfaEnds) && offset > cs) { const u32x2 o = d.out[state]; emit((uint32_t)h, offset - hs, o.x - 1u, o.y); }

@@ -90,13 +90,13 @@ class ImgCheck:
 
     @staticmethod
     def dfa_header(img):
-        f = struct.unpack_from("<5Q6I", img.tobytes()[256:320])          # ImageHeader.off_dfa_next ... dfa_chunk
-        return {"off_next": f[0], "off_out": f[1], "off_cls": f[2], "off_fail": f[3], "off_rare": f[4], "rare_log2_cap": f[5], "n_states": f[7], "log2_classes": f[8],
-                "warm": f[9], "chunk": f[10]}
+        f = struct.unpack_from("<5Q2IQ4I", img.tobytes()[256:328])          # ImageHeader.off_dfa_next ... dfa_chunk
+        return {"off_next": f[0], "off_out": f[1], "off_cls": f[2], "off_fail": f[3], "off_rare": f[4], "rare_log2_cap": f[5], "n_rows": f[6], "off_chain": f[7],
+                "n_states": f[8], "log2_classes": f[9], "warm": f[10], "chunk": f[11]}
 
     @staticmethod
     def set_dfa_chunk(img, chunk):
-        img[316:320] = np.frombuffer(struct.pack("<I", chunk), dtype=np.uint8)   # ImageHeader.dfa_chunk (the host interpreter takes any value >= 1)
+        img[324:328] = np.frombuffer(struct.pack("<I", chunk), dtype=np.uint8)   # ImageHeader.dfa_chunk (the host interpreter takes any value >= 1)
 
     @staticmethod
     def set_ac_chunk(img, chunk):

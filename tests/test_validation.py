@@ -161,3 +161,6 @@ def test_damaged_dfa_section_is_refused():
     refused(lambda b: struct.pack_into("<I", b, d["off_out"] + 8 * 3, 10 ** 6), "a needle end at a reference state that does not exist")
     refused(lambda b: (struct.pack_into("<I", b, d["off_fail"] + 4 * 7, 9), struct.pack_into("<I", b, d["off_fail"] + 4 * 9, 7)), "fallbacks that go round in a circle")
     refused(lambda b: struct.pack_into("<I", b, d["off_fail"], 3), "a root that falls back")
+    assert d["n_rows"] < d["n_states"], "the test automaton has chain states"
+    refused(lambda b: struct.pack_into("<I", b, d["off_chain"] + 4, (struct.unpack_from("<I", b, d["off_chain"] + 4)[0] & 0xFF000000) | (d["n_rows"] + 1)), "a chain state that falls back to a state without a row")
+    refused(lambda b: struct.pack_into("<I", b, d["off_chain"], d["n_states"] + 3), "a chain state whose child does not exist")
