@@ -448,6 +448,7 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
 int am::host::finish_batch(am_batch* b)
 {
     b->hidx_ready = false;
+    b->route_image = nullptr;                  // new text: the route is asked again
     if (b->total > 0) AM_TRY(b->hidx.ensure(((b->total >> kHidxShift) + 2) * sizeof(uint32_t)));
     // the batch's block of counters is allocated HERE, once, before the batch is visible to other threads: make_plan reads its
     // address without the batch lock, so it must never be re-allocated later (every later ensure(64) is a no-op)
@@ -659,6 +660,8 @@ using AcLauncher = hipError_t (*)(bool ic, int mode, const AcView& a, const Batc
 std::atomic<AcLauncher> g_ac_launcher{nullptr};
 
 constexpr uint64_t kDfaMinBytes = 1ull << 20;      // below this the suffix-filter route (its one-document path) is the faster one whatever the text
+constexpr uint64_t kDfaSampleBytes = 64ull << 20;   // from here on a sample walk asks the text which route it wants (below: a dictionary is taken to meet its language)
+constexpr uint32_t kDfaEndsPerKiB = 48;            // needle ends per KiB from which the table walk wins (k_sf: 670 GiB/s at 10 per KiB, 215 at 63, 76 at 156; k_dfa: ~155 flat)
 
 struct Plan {
     const Flavor* f; bool ic; bool use_sf; bool nothing; uint64_t n_units; uint32_t unit_chunks; int n_cu;
@@ -681,8 +684,27 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
     if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run this automaton (empty needle with too many prefix terminals)");
     const bool has_dfa = p.f->h.dfa_n_states != 0 && p.f->h.root_vlen == 0;
     if (a->kernel_pref == 3 && !has_dfa) return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 3): this automaton's image has no DFA section");
-    p.use_dfa = has_dfa && allow_dfa && (a->kernel_pref == 3 || (a->kernel_pref == 0 && b->total >= kDfaMinBytes && cfg::get(cfg::kDfa) != 0));
     p.dfa = make_dfa_view(p.f->d_image, p.f->h);
+    p.use_dfa = has_dfa && allow_dfa && (a->kernel_pref == 3 || (a->kernel_pref == 0 && b->total >= kDfaMinBytes && cfg::get(cfg::kDfa) != 0));
+    if (p.use_dfa && a->kernel_pref == 0 && b->total >= kDfaSampleBytes) {
+        // The table walk costs the same whatever the text is; the suffix filter is 6 x faster where needles are rare and slower where one ends every few bytes.  A large batch
+        // is asked: 4 096 lanes spread over it walk 128 bytes each (0.15 ms); below kDfaEndsPerKiB needle ends per KiB the filter takes it.  Decided once per batch and image.
+        std::lock_guard<std::mutex> lk(b->mu);
+        if (b->route_image != p.f->d_image) {
+            ON_DEVICE(b->dev);
+            hipStream_t st; AM_TRY(get_stream(b->dev, &st));
+            AM_TRY(b->small.ensure(64));
+            HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
+            constexpr uint32_t kSamples = 4096, kLen = 128;
+            HIP_TRY(launch_dfa_sample(p.dfa, (const uint8_t*)b->d_text, b->total, kSamples, kLen, (uint32_t*)b->small.p, st));
+            uint32_t ends = 0;
+            HIP_TRY(hipMemcpyAsync(&ends, b->small.p, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            b->route_dfa = (uint64_t)ends * 1024u >= (uint64_t)kDfaEndsPerKiB * kSamples * kLen;
+            b->route_image = p.f->d_image;
+        }
+        p.use_dfa = b->route_dfa;
+    }
     p.use_sf = p.f->h.sf_enabled && a->kernel_pref != 1 && !p.use_dfa;
     if (!p.use_sf && !p.use_dfa && !g_ac_launcher.load(std::memory_order_acquire))
         return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 1): the general AC kernel is test infrastructure (libam_check.so) and is not loaded in this process");

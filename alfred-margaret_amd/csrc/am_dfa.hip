@@ -182,6 +182,33 @@ __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut
     }
 }
 
+// How dense are needle ends in this batch?  n_samples lanes, spread evenly over the text, each walk `len` bytes from the root (no warm-up, haystack boundaries
+// ignored: an estimate) and count the steps that land on a needle end.  What the ABI layer chooses the route of a dictionary by (am_abi.cpp make_plan).
+__global__ __launch_bounds__(256) void k_dfa_sample(DfaView d, const uint8_t* __restrict__ text, uint64_t total, uint32_t n_samples, uint32_t len, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t ends = 0;
+    if (i < n_samples) {
+        const uint64_t at = ((total / n_samples) * i) & ~15ull;
+        const uint64_t stop = at + len < total ? at + len : total;
+        uint32_t state = 0;
+        for (uint64_t p = at; p < stop; p++) {
+            const uint32_t byte = text[p], cl = d.cls[byte];
+            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_common_step(d, state, cl);
+            state = e & ~kDfaEnds;
+            ends += e >> 31;
+        }
+    }
+    const uint64_t sum = wave_sum_u64(ends);
+    if (lane_id() == 0 && sum) atomicAdd(out, (uint32_t)sum);
+}
+hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t total, uint32_t n_samples, uint32_t len, uint32_t* out, hipStream_t st)
+{
+    if (n_samples == 0 || total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dfa_sample, dim3((n_samples + 255u) / 256u), dim3(256), 0, st, d, text, total, n_samples, len, out);
+    return hipGetLastError();
+}
+
 // token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq
 __global__ __launch_bounds__(256) void k_dfa_place(const Record* __restrict__ pool, const uint32_t* __restrict__ fill, uint32_t n_super, const uint64_t* __restrict__ unit_offsets,
                                                    const uint64_t* __restrict__ hay_offsets, uint32_t chunk, Record* __restrict__ out)

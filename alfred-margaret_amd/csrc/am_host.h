@@ -148,6 +148,8 @@ struct am_batch {
     am::host::DevBuf combo;               // ... or ONE buffer [offsets | text] for small batches that went up with a single copy
     am::host::DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
     am::host::DevBuf sparse, dense_counts, dense_offsets, dense_out;      // automata with the empty needle (dense pass)
+    // the route a dictionary's image took on this batch the last time it was asked (am_abi.cpp make_plan: a sample walk decides once per batch and image)
+    const void* route_image = nullptr; bool route_dfa = false;
 };
 
 struct am_matches {

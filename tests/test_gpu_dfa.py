@@ -132,3 +132,37 @@ def test_dictionary_takes_the_table_walk_by_itself():
     am.api.check(lib.am_profile_enable(0))
     am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
     assert n.value == 0 and np.array_equal(small, sf[sf["haystack"] < 2])
+
+
+def test_large_batches_choose_their_route_by_a_sample_walk():
+    """From 64 MiB on a dictionary's batch is asked which route it wants (am_abi.cpp make_plan: 4 096 lanes walk 128 bytes each): natural-language text takes the
+    table walk, the same dictionary over text in which its words are rare takes the suffix filter; the records are the same either way."""
+    import torch
+    w = synth.WORKLOADS["natural_100k_10GiB"]
+    needles = synth.needles_for("natural_100k_10GiB")
+    a = am.Automaton(needles)
+    lib = am.api.libam()
+    dev = torch.device("cuda:0")
+    n_hay, cells = 96, 1024                                                  # 96 MiB
+    for natural, expect_dfa in ((True, True), (False, False)):
+        text, n_bytes = synth.haystacks_device(needles, w["mixed"], 0, n_hay * cells, dev, natural=natural)
+        offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * (cells * 1024)
+        b = C.c_void_p()
+        am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(b)))
+        try:
+            counts = {}
+            for k in (0, 2, 3):
+                a.set_kernel(k)
+                am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+                c = np.zeros(n_hay, np.uint64)
+                am.api.check(lib.am_count_batch(a.device, w["case"], b, c.ctypes.data, None))
+                am.api.check(lib.am_profile_enable(0))
+                ms, n = C.c_double(0), C.c_uint64(0)
+                am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+                counts[k] = c
+                if k == 0:
+                    assert (n.value == 1) == expect_dfa, ("natural" if natural else "random", n.value)
+            assert np.array_equal(counts[0], counts[2]) and np.array_equal(counts[0], counts[3]) and counts[0].sum() > 0
+        finally:
+            a.set_kernel(0)
+            lib.am_batch_destroy(b)
