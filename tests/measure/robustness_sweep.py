@@ -57,7 +57,7 @@ def measure(name, needles, case, text, n_bytes, hay_bytes=HB, steps=4, oracle_ha
             am.api.check(lib.am_count_batch(a.device, case, batch, None, C.byref(t)))
             return int(t.value)
 
-        for kernel, tag in ((2, "sf"), (1, "ac")):
+        for kernel, tag in ((0, "auto"), (2, "sf"), (1, "ac")):
             try:
                 n_rec, (hashes, counts) = run(kernel, keep=True)      # also the warm-up (pool sizing, image upload)
             except am.AmError as e:
@@ -65,7 +65,8 @@ def measure(name, needles, case, text, n_bytes, hay_bytes=HB, steps=4, oracle_ha
                     raise
                 res[tag] = None
                 continue
-            reps = steps if tag == "sf" else 1
+            reps = steps if tag != "ac" else 1
+            am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -75,9 +76,14 @@ def measure(name, needles, case, text, n_bytes, hay_bytes=HB, steps=4, oracle_ha
             for _ in range(reps):
                 total = count(kernel)
             count_s = (time.perf_counter() - t0) / reps
-            res[tag] = dict(emit=n_bytes / 2**30 / emit_s, count=n_bytes / 2**30 / count_s, records=n_rec, matches=total, hashes=hashes, counts=counts)
+            am.api.check(lib.am_profile_enable(0))
+            ms, nl = C.c_double(0), C.c_uint64(0)
+            am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(nl)))
+            res[tag] = dict(emit=n_bytes / 2**30 / emit_s, count=n_bytes / 2**30 / count_s, records=n_rec, matches=total, hashes=hashes, counts=counts, route="k_dfa" if nl.value else "k_sf")
         if res.get("sf") and res.get("ac"):
             assert np.array_equal(res["sf"]["hashes"], res["ac"]["hashes"]) and np.array_equal(res["sf"]["counts"], res["ac"]["counts"]), name
+        if res.get("auto") and res.get("ac"):
+            assert np.array_equal(res["auto"]["hashes"], res["ac"]["hashes"]) and np.array_equal(res["auto"]["counts"], res["ac"]["counts"]), name
         ref = res.get("sf") or res["ac"]
         o = oracle.Machine(needles)
         k = min(oracle_hays, n_hay)
@@ -87,14 +93,15 @@ def measure(name, needles, case, text, n_bytes, hay_bytes=HB, steps=4, oracle_ha
     finally:
         lib.am_batch_destroy(batch)
     kib = n_bytes / 1024.0
-    sf, ac = res.get("sf"), res.get("ac")
+    sf, ac, au = res.get("sf"), res.get("ac"), res.get("auto")
     fmt = lambda r, key: "%.0f" % r[key] if r else "n/a"
-    print("| %s | %.1f | %.2f | %s | %s | %s | %s | %s |" % (name, (ref["matches"] / kib), ref["records"] / kib, fmt(sf, "emit"), fmt(sf, "count"), fmt(ac, "emit"), fmt(ac, "count"), note), flush=True)
+    print("| %s | %.1f | %.2f | %s | %s | %s | %s | %s | %s | %s | %s |" % (name, (ref["matches"] / kib), ref["records"] / kib, au["route"] if au else "n/a", fmt(au, "emit"), fmt(au, "count"),
+                                                                  fmt(sf, "emit"), fmt(sf, "count"), fmt(ac, "emit"), fmt(ac, "count"), note), flush=True)
 
 
 def main():
-    print("| case | matches / KiB | records / KiB | k_sf emit GiB/s | k_sf count GiB/s | k_ac emit GiB/s | k_ac count GiB/s | note |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| case | matches / KiB | records / KiB | the library's route | emit GiB/s | count GiB/s | k_sf emit | k_sf count | k_ac emit | k_ac count | note |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     n_cells = int(GIB * (1 << 20))
     cfg3 = synth.needles_for("cfg3_runLower_100k_10GiB")
     for plants in (0, 1, 8, 64):
