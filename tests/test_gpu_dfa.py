@@ -126,6 +126,13 @@ def test_dictionary_takes_the_table_walk_by_itself():
     am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
     assert n.value == 2 and np.array_equal(again, sf)
     assert [int(c) for c in a.count_matches(w["case"], hays)] == [o.count_matches(w["case"], h) for h in hays]
+    # the serialised image carries the DFA section: an automaton attached to it (another process, another GPU: am_multi_*) walks the same table
+    attached = am.ImageAutomaton(a.image_bytes(w["case"]))
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    from_image = attached.run_records(w["case"], hays)
+    am.api.check(lib.am_profile_enable(0))
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value == 1 and np.array_equal(from_image, sf)
     # below 1 MiB the suffix-filter route stays
     am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
     small = a.run_records(w["case"], hays[:2])
@@ -166,3 +173,28 @@ def test_large_batches_choose_their_route_by_a_sample_walk():
         finally:
             a.set_kernel(0)
             lib.am_batch_destroy(b)
+
+
+def test_replacer_over_a_dictionary_scans_with_the_table_walk():
+    """A Replacer whose needles are a dictionary (the flattener gives its automaton a DFA section): the first scan of a batch of 1 MiB and more takes k_dfa, the
+    re-scans of the later passes the suffix filter; the rewritten texts are the oracle's Replacer.run (Replacer.hs:203-274)."""
+    from concurrent.futures import ThreadPoolExecutor
+    w = synth.WORKLOADS["natural_100k_10GiB"]
+    needles = synth.needles_for("natural_100k_10GiB")
+    words = [n for n in needles if " " not in n][:30000]
+    pairs = [(wd, wd[::-1].upper() if i % 3 else "") for i, wd in enumerate(words)]                  # reversed and upper-cased: replacements rarely make new needles
+    cells = 96
+    hays = [bytes(synth.haystacks_host(needles, w["mixed"], 11 + i * cells, cells, natural=True)) for i in range(16)] + [b""]      # 16 x 96 KiB = 1.5 MiB
+    r = am.Replacer(w["case"], pairs)
+    lib = am.api.libam()
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    got = r.run_batch(hays)
+    am.api.check(lib.am_profile_enable(0))
+    ms, n = C.c_double(0), C.c_uint64(0)
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value >= 1, "the first scan of the batch takes the table walk"
+    orc = oracle.Replacer(w["case"], pairs)
+    with ThreadPoolExecutor(8) as pool:
+        exp = list(pool.map(orc.run, hays))
+    assert got == exp
+    assert sum(g != h for g, h in zip(got, hays)) >= 16
