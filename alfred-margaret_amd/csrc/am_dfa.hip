@@ -52,17 +52,17 @@ struct DfaLane {
     {
         const uint64_t end_pos = g + 1u - hs;
         if (MODE == kModeAny) { o.flags[hay] = 1; return; }
-        const u32x2 e = d.out[state];
         if (MODE == kModeTokens) {
             const uint32_t sb = wv[1];
             if (sb != kNone) {
                 const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the step loop)
                 const uint64_t pos = g - unit * d.chunk;                   // offset of the match's last byte in the unit
-                o.pool[(uint64_t)sb * kDfaSuper + slot] = Record{(unit << 32) | ((uint64_t)nrec << 16) | pos, hay, e.x - 1u};
+                o.pool[(uint64_t)sb * kDfaSuper + slot] = Record{(unit << 32) | ((uint64_t)nrec << 16) | pos, hay, state};      // (the DFA state: k_dfa_place looks the reference state up, off the walk's dependent chain)
             }
             nrec++;
             return;
         }
+        const u32x2 e = d.out[state];
         if (MODE == kModeCount) {
             nrec++; nval += e.y;
             if (o.hay_counts) { if (hay != run_hay) { flush(); run_hay = hay; } run_val += e.y; }
@@ -211,14 +211,14 @@ hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t tot
 
 // token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq
 __global__ __launch_bounds__(256) void k_dfa_place(const Record* __restrict__ pool, const uint32_t* __restrict__ fill, uint32_t n_super, const uint64_t* __restrict__ unit_offsets,
-                                                   const uint64_t* __restrict__ hay_offsets, uint32_t chunk, Record* __restrict__ out)
+                                                   const uint64_t* __restrict__ hay_offsets, const u32x2* __restrict__ dfa_out, uint32_t chunk, Record* __restrict__ out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     const uint32_t sb = (uint32_t)(i / kDfaSuper), s = (uint32_t)(i % kDfaSuper);
     if (sb >= n_super || s >= fill[sb]) return;
     const Record t = pool[i];
     const uint64_t u = t.end_pos >> 32, seq = (t.end_pos >> 16) & 0xFFFFu, pos = t.end_pos & 0xFFFFu;
-    out[unit_offsets[u] + seq] = Record{u * chunk + pos + 1u - hay_offsets[t.haystack], t.haystack, t.state};
+    out[unit_offsets[u] + seq] = Record{u * chunk + pos + 1u - hay_offsets[t.haystack], t.haystack, dfa_out[t.state].x - 1u};
 }
 
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
@@ -264,7 +264,7 @@ hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut&
     if (n_super == 0) return hipSuccess;
     const uint64_t blocks = (uint64_t)n_super * (kDfaSuper / 256u);
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dfa_place, dim3((uint32_t)blocks), dim3(256), 0, st, o.pool, o.block_next, n_super, unit_offsets, b.offsets, d.chunk, out);
+    hipLaunchKernelGGL(k_dfa_place, dim3((uint32_t)blocks), dim3(256), 0, st, o.pool, o.block_next, n_super, unit_offsets, b.offsets, d.out, d.chunk, out);
     return hipGetLastError();
 }
 
