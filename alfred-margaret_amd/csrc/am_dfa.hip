@@ -48,7 +48,8 @@ struct DfaLane {
         run_val = 0;
     }
     // g = index of the match's last byte in the batch, hs = where its haystack starts
-    __device__ __forceinline__ void found(uint32_t hay, uint64_t g, uint64_t hs, uint32_t state)
+    // end = the entry's end bits: the length of the needle-end list (1..14), kDfaEndLookUp = longer (out[] knows)
+    __device__ __forceinline__ void found(uint32_t hay, uint64_t g, uint64_t hs, uint32_t state, uint32_t end)
     {
         const uint64_t end_pos = g + 1u - hs;
         if (MODE == kModeAny) { o.flags[hay] = 1; return; }
@@ -62,11 +63,12 @@ struct DfaLane {
             nrec++;
             return;
         }
-        const u32x2 e = d.out[state];
         if (MODE == kModeCount) {
-            nrec++; nval += e.y;
-            if (o.hay_counts) { if (hay != run_hay) { flush(); run_hay = hay; } run_val += e.y; }
+            const uint32_t vl = end < kDfaEndLookUp ? end : d.out[state].y;      // (a count needs no load of its own unless a position reports 15 values or more)
+            nrec++; nval += vl;
+            if (o.hay_counts) { if (hay != run_hay) { flush(); run_hay = hay; } run_val += vl; }
         } else {
+            const u32x2 e = d.out[state];
             out[nrec++] = Record{end_pos, hay, e.x - 1u};
         }
     }
@@ -132,16 +134,16 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s
                 const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 const uint32_t cl = s_cls[byte];
                 const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step_lds(d, s_rows, hot_rows, state, cl);
-                state = e & ~kDfaEnds;
-                if ((e & kDfaEnds) && mine) L.found(h, offset + (uint64_t)i, hs, state);
+                state = e & kDfaStateMask;
+                if ((e >> kDfaEndShift) && mine) L.found(h, offset + (uint64_t)i, hs, state, e >> kDfaEndShift);
             }
             offset += 16;
         } else {
             const uint32_t byte = b.text[offset], cl = s_cls[byte];
             const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step_lds(d, s_rows, hot_rows, state, cl);
-            state = e & ~kDfaEnds;
+            state = e & kDfaStateMask;
             offset++;
-            if ((e & kDfaEnds) && offset > cs) L.found(h, offset - 1u, hs, state);
+            if ((e >> kDfaEndShift) && offset > cs) L.found(h, offset - 1u, hs, state, e >> kDfaEndShift);
         }
     }
     L.flush();
@@ -195,8 +197,8 @@ __global__ __launch_bounds__(256) void k_dfa_sample(DfaView d, const uint8_t* __
         for (uint64_t p = at; p < stop; p++) {
             const uint32_t byte = text[p], cl = d.cls[byte];
             const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_common_step(d, state, cl);
-            state = e & ~kDfaEnds;
-            ends += e >> 31;
+            state = e & kDfaStateMask;
+            ends += (e >> kDfaEndShift) ? 1u : 0u;
         }
     }
     const uint64_t sum = wave_sum_u64(ends);

@@ -834,7 +834,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             for (size_t k = 0; k < by_cnt.size(); k++) cls[by_cnt[k]] = k + 1u < (1u << lc) ? (uint8_t)n_cls++ : (uint8_t)kDfaRare;
             if (ic) for (uint32_t b = 'A'; b <= 'Z'; b++) cls[b] = cls[b + 0x20u];       // the kernels fold ASCII; the variants hold the folded byte only
             const uint64_t table_bytes = ((uint64_t)n_nodes << lc) * 4ull;
-            if (n_nodes < 0x7FFFFFF0u && table_bytes <= (1ull << 30)) {
+            if (n_nodes < kDfaStateMask && table_bytes <= (1ull << 30)) {
                 // adjacency by source
                 std::vector<uint32_t> first(n_nodes + 1, 0);
                 for (const BEdge& e : be) first[e.src + 1]++;
@@ -932,14 +932,14 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                         if (is_row[i]) {
                             const uint32_t* from = next.data() + ((size_t)i << lc);
                             uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
-                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[c] = t | (out2[t].x ? kDfaEnds : 0u); }
+                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[c] = t | dfa_end_bits(out2[t]); }
                         } else {
                             const uint32_t ch = n_goto[i] == 1 ? renum[child_of[i]] : 0u;
-                            chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | (out2[ch].x ? kDfaEnds : 0u)) : 0u,
+                            chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | dfa_end_bits(out2[ch])) : 0u,
                                                              ((n_goto[i] == 1 ? (uint32_t)child_cls[i] : kDfaNoChild) << 24) | renum[fb[i]]};
                         }
                     }
-                    // the rare edges: open addressing, (state, byte) -> child | kDfaEnds (dfa_rare_slot in am_image.h)
+                    // the rare edges: open addressing, (state, byte) -> child | its end bits (dfa_rare_slot in am_image.h)
                     uint32_t rare_lc = 4;
                     while ((1ull << rare_lc) < 2ull * rare_goto.size() + 8ull) rare_lc++;
                     std::vector<u32x4> rare_tab((size_t)1 << rare_lc, u32x4{0, 0, 0, 0});
@@ -947,7 +947,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                         const uint32_t st = renum[(uint32_t)(kv.first >> 8)], byte = (uint32_t)(kv.first & 0xFFu), to = renum[kv.second];
                         uint32_t slot = dfa_rare_slot(st, byte, rare_lc);
                         while (rare_tab[slot].w) slot = (slot + 1u) & ((1u << rare_lc) - 1u);
-                        rare_tab[slot] = u32x4{st, byte, to | (out2[to].x ? kDfaEnds : 0u), 1u};
+                        rare_tab[slot] = u32x4{st, byte, to | dfa_end_bits(out2[to]), 1u};
                     }
                     uint32_t warm = 1;
                     for (uint32_t x = 0; x < (uint32_t)S; x++) warm = std::max(warm, bdepth[x]);
@@ -1110,8 +1110,8 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
             bool has_empty = false;
             for (uint64_t i = 0; i < (1ull << h.dfa_rare_log2_cap); i++) {
                 if (!rt[i].w) { has_empty = true; continue; }
-                const uint32_t to = rt[i].z & ~kDfaEnds;
-                if (rt[i].x >= h.dfa_n_states || rt[i].y > 0xFFu || to >= h.dfa_n_states || ((rt[i].z & kDfaEnds) != 0) != (out[to].x != 0)) { err = "image: DFA rare edge out of range"; return false; }
+                const uint32_t to = rt[i].z & kDfaStateMask;
+                if (rt[i].x >= h.dfa_n_states || rt[i].y > 0xFFu || to >= h.dfa_n_states || (rt[i].z & ~kDfaStateMask) != dfa_end_bits(out[to])) { err = "image: DFA rare edge out of range"; return false; }
             }
             if (!has_empty) { err = "image: DFA rare-edge table without an empty slot"; return false; }
         }
@@ -1119,13 +1119,13 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
             if (out[i].x > S || (out[i].x != 0 && (canon[out[i].x - 1u] != out[i].x - 1u || vl[out[i].x - 1u] == 0 || out[i].y == 0))) { err = "image: DFA needle end out of range"; return false; }
         const uint64_t n = (uint64_t)h.dfa_n_rows << h.dfa_log2_classes;
         for (uint64_t i = 0; i < n; i++) {
-            const uint32_t to = next[i] & ~kDfaEnds;
-            if (to >= h.dfa_n_states || ((next[i] & kDfaEnds) != 0) != (out[to].x != 0)) { err = "image: DFA transition out of range"; return false; }
+            const uint32_t to = next[i] & kDfaStateMask;
+            if (to >= h.dfa_n_states || (next[i] & ~kDfaStateMask) != dfa_end_bits(out[to])) { err = "image: DFA transition out of range"; return false; }
         }
         const u32x2* chain = (const u32x2*)(img + h.off_dfa_chain);
         for (uint32_t i = 0; i < h.dfa_n_states - h.dfa_n_rows; i++) {
-            const uint32_t to = chain[i].x & ~kDfaEnds, cl = chain[i].y >> 24, fbr = chain[i].y & 0xFFFFFFu;
-            if (fbr >= h.dfa_n_rows || (cl >= (1u << h.dfa_log2_classes) && cl != kDfaNoChild) || to >= h.dfa_n_states || ((chain[i].x & kDfaEnds) != 0) != (out[to].x != 0 && cl != kDfaNoChild) ||
+            const uint32_t to = chain[i].x & kDfaStateMask, cl = chain[i].y >> 24, fbr = chain[i].y & 0xFFFFFFu;
+            if (fbr >= h.dfa_n_rows || (cl >= (1u << h.dfa_log2_classes) && cl != kDfaNoChild) || to >= h.dfa_n_states || (chain[i].x & ~kDfaStateMask) != (cl != kDfaNoChild ? dfa_end_bits(out[to]) : 0u) ||
                 (cl == kDfaNoChild && chain[i].x != 0)) { err = "image: DFA chain record out of range"; return false; }
         }
     }
@@ -1151,7 +1151,7 @@ bool image_sections_in_bounds(const ImageHeader& h)
         }
     }
     if (h.dfa_n_states) {
-        if (h.dfa_log2_classes < 3 || h.dfa_log2_classes > 8 || h.dfa_n_states >= 0x7FFFFFF0u || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
+        if (h.dfa_log2_classes < 3 || h.dfa_log2_classes > 8 || h.dfa_n_states >= kDfaStateMask || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
         if (h.dfa_n_rows == 0 || h.dfa_n_rows > h.dfa_n_states || h.dfa_n_rows >= (1u << 24)) return false;
         good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_rows << h.dfa_log2_classes, 4) && ok(h.off_dfa_chain, h.dfa_n_states - h.dfa_n_rows, 8) && (h.off_dfa_chain & 7u) == 0 &&
                ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&

@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 14;
+constexpr uint32_t kImageVersion = 15;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -74,15 +74,15 @@ struct ImageHeader {
     uint32_t sf_row_first;      // edges[sf_row_first .. n_edges): the ROWS of the nodes with more than 4 children (SfNode::label, SfEdge::pad)
     // DFA section (version 13; dfa_n_states == 0: none): the byte-level automaton with every transition resolved, for dictionaries that meet text in which
     // a needle ends every few bytes (am_flatten.cpp decides; k_dfa in am_dfa.hip)
-    uint64_t off_dfa_next;      // u32[dfa_n_rows << dfa_log2_classes]: next state (bits 0-30) | bit 31: a needle ends there
+    uint64_t off_dfa_next;      // u32[dfa_n_rows << dfa_log2_classes]: next state (bits 0-27) | bits 28-31: the length of what ends there (kDfaEndShift)
     uint64_t off_dfa_out;       // u32x2[dfa_n_states] {canonical reference state + 1 (0: no needle ends), vlen}
     uint64_t off_dfa_cls;       // u8[256]: byte -> class (IgnoreCase: the ASCII fold is part of the map); class 0 = bytes no needle contains; kDfaRare = a byte
                                 // that few edges carry: no column, dfa_rare_step
     uint64_t off_dfa_fail;      // u32[dfa_n_states]: fallback state (the rare-byte walk)
-    uint64_t off_dfa_rare;      // u32x4{state, byte, child | bit 31, used}[1 << dfa_rare_log2_cap]: the edges on rare bytes, open addressing
+    uint64_t off_dfa_rare;      // u32x4{state, byte, child | its end bits, used}[1 << dfa_rare_log2_cap]: the edges on rare bytes, open addressing
     uint32_t dfa_rare_log2_cap;
     uint32_t dfa_n_rows;        // states [0, dfa_n_rows) have a dense row in `next`; the others a chain record (off_dfa_chain)
-    uint64_t off_dfa_chain;     // u32x2[dfa_n_states - dfa_n_rows]: {the one child | bit 31, the child's class << 24 | the row state this one falls back to}
+    uint64_t off_dfa_chain;     // u32x2[dfa_n_states - dfa_n_rows]: {the one child | its end bits, the child's class << 24 | the row state this one falls back to}
     uint32_t dfa_n_states, dfa_log2_classes;
     uint32_t dfa_warm;          // bytes of history that determine the state: longest needle (variant) in bytes - 1
     uint32_t dfa_chunk;         // bytes of the batch one lane owns (multiple of 16)
@@ -180,7 +180,9 @@ struct DfaView {
     uint32_t n_states, n_rows, log2_classes, warm, chunk, rare_log2_cap;
     uint32_t ic;             // IgnoreCase image: haystack bytes A-Z count as a-z (the class map already says so; the rare-byte walk has to be told)
 };
-constexpr uint32_t kDfaEnds = 0x80000000u;
+// a transition entry = next state (bits 0-27) | what ends there (bits 28-31): 0 nothing, 1..14 = vlen of the needle-end list (a count needs nothing else), 15 = longer, see out[]
+constexpr uint32_t kDfaStateMask = 0x0FFFFFFFu, kDfaEndShift = 28u, kDfaEndLookUp = 15u;
+AM_HD uint32_t dfa_end_bits(const u32x2& out_entry) { return out_entry.x ? (out_entry.y < kDfaEndLookUp ? out_entry.y : kDfaEndLookUp) << kDfaEndShift : 0u; }
 constexpr uint32_t kDfaRare = 0xFFu;
 constexpr uint32_t kDfaNoChild = 0xFEu;         // chain record of a state without a child: no class equals it
 
@@ -1060,7 +1062,7 @@ AM_HD uint32_t dfa_rare_slot(uint32_t state, uint32_t byte, uint32_t log2_cap)
     return (h * 0x2C1B3C6Du) >> (32u - log2_cap);
 }
 // delta(state, byte) for a byte without a column: the state's own edge on it, else the same question at its fallback, the root answering "root"
-// (Automaton.hs:489-510 as it stands; the dense rows are this loop precomputed for the common bytes).  Returns next state | kDfaEnds.
+// (Automaton.hs:489-510 as it stands; the dense rows are this loop precomputed for the common bytes).  Returns the transition entry (next state | end bits).
 AM_HD uint32_t dfa_rare_step(const DfaView& d, uint32_t state, uint32_t byte)
 {
     const uint32_t mask = (1u << d.rare_log2_cap) - 1u;
@@ -1108,9 +1110,9 @@ AM_HD void dfa_scan_unit(const DfaView& d, const BatchView& b, uint64_t unit, Em
         const uint32_t cl = d.cls[byte];
         if (cl == kDfaRare && d.ic && byte - 0x41u < 26u) byte += 0x20u;    // (the edges of an IgnoreCase automaton carry the folded letter)
         const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, byte) : dfa_common_step(d, state, cl);
-        state = e & ~kDfaEnds;
+        state = e & kDfaStateMask;
         offset++;
-        if ((e & kDfaEnds) && offset > cs) { const u32x2 o = d.out[state]; emit((uint32_t)h, offset - hs, o.x - 1u, o.y); }
+        if ((e >> kDfaEndShift) && offset > cs) { const u32x2 o = d.out[state]; emit((uint32_t)h, offset - hs, o.x - 1u, o.y); }
     }
 }
 

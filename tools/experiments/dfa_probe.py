@@ -33,5 +33,5 @@ timed("build+first", 2, count, 1); print("build %.2f s, image %d MiB" % (time.ti
 for name, k in (("sf", 2), ("dfa", 3)):
     timed(name + " count", k, count); timed(name + " emit", k, run); timed(name + " any", k, anyf)
 am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1)); a.set_kernel(3); run(); torch.cuda.synchronize(); am.api.check(lib.am_profile_enable(0))
-for k in (b"dfa", b"scan", b"hidx"):
+for k in (b"dfa", b"dfa_place", b"scan", b"hidx"):
     ms, n = C.c_double(0), C.c_uint64(0); lib.am_profile_read(k, C.byref(ms), C.byref(n)); print(k.decode(), round(ms.value, 3), "ms in", n.value, "launches")
