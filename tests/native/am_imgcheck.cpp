@@ -60,6 +60,32 @@ long long amchk_flatten(const uint64_t* transitions, size_t n_transitions, const
     return amchk_flatten_ex(transitions, n_transitions, offsets, n_states, root_ascii, values_len, case_mode, nullptr, nullptr, 0, image_out, image_cap, err_out, err_cap);
 }
 
+// Where do the steps of the table walk go?  One walk over `text` from the root; out[0] = steps at one of the first `hot_rows` row states (k_dfa keeps those rows in LDS),
+// [1] = at the other row states (a 4-byte load from the table), [2] = at chain states that answer themselves (8 bytes, shared lines along a path), [3] = at chain states that ask
+// their fallback's row (two loads), [4] = rare bytes, [5] = steps that land on a needle end.  -3: no DFA section.
+long long amchk_dfa_stats(const uint8_t* image, const uint8_t* text, uint64_t n, uint32_t hot_rows, uint64_t* out6)
+{
+    ImageHeader h; std::memcpy(&h, image, sizeof(h));
+    if (h.magic != kImageMagic || !h.dfa_n_states) return -3;
+    const DfaView d = make_dfa_view(image, h);
+    for (int i = 0; i < 6; i++) out6[i] = 0;
+    uint32_t state = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        uint32_t byte = text[p];
+        const uint32_t cl = d.cls[byte];
+        uint32_t e;
+        if (cl == kDfaRare) { if (d.ic && byte - 0x41u < 26u) byte += 0x20u; e = dfa_rare_step(d, state, byte); out6[4]++; }
+        else {
+            if (state < d.n_rows) out6[state < hot_rows ? 0 : 1]++;
+            else out6[(d.chain[state - d.n_rows].y >> 24) == cl ? 2 : 3]++;
+            e = dfa_common_step(d, state, cl);
+        }
+        state = e & kDfaStateMask;
+        if (e >> kDfaEndShift) out6[5]++;
+    }
+    return 0;
+}
+
 // Interpret an image over a batch.  which: 0 = AC walk (general kernel's logic), 1 = SF (filter +
 // verify, fast kernel's logic), 2 = SF without the Bloom filter (every position verified: separates
 // filter bugs from table bugs), 3 = the DFA table walk (k_dfa's logic).  Fills up to cap records sorted by (haystack, end_pos); returns the
