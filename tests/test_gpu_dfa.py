@@ -198,3 +198,35 @@ def test_replacer_over_a_dictionary_scans_with_the_table_walk():
         exp = list(pool.map(orc.run, hays))
     assert got == exp
     assert sum(g != h for g, h in zip(got, hays)) >= 16
+
+
+def test_ragged_batch_of_tiny_haystacks_on_the_table_walk():
+    """2 MiB of natural text cut into 120 000 haystacks of 0-40 bytes: a unit of 2 048 bytes spans a hundred haystacks, most steps take the byte-wise path
+    and reset at a boundary.  Records, counts and flags of the table walk (the route such a batch takes by itself) == the suffix filter's; the first haystacks == the oracle."""
+    w = synth.WORKLOADS["natural_100k_10GiB"]
+    needles = synth.needles_for("natural_100k_10GiB")
+    text = bytes(synth.haystacks_host(needles, w["mixed"], 3, 2048, natural=True))
+    rng = random.Random(5)
+    hays, p = [], 0
+    while p < len(text):
+        n = rng.choice((0, 0, 3, 7, 16, 17, 31, 40))
+        hays.append(text[p:p + n]); p += n
+    a = am.Automaton(needles)
+    lib = am.api.libam()
+    am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+    auto = a.run_records(w["case"], hays)
+    am.api.check(lib.am_profile_enable(0))
+    ms, n = C.c_double(0), C.c_uint64(0)
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value == 1
+    counts_auto = a.count_matches(w["case"], hays)
+    any_auto = contains_any(a, w["case"], hays)
+    a.set_kernel(2)
+    sf = a.run_records(w["case"], hays)
+    assert np.array_equal(auto, sf) and len(auto) > 10_000
+    assert np.array_equal(counts_auto, a.count_matches(w["case"], hays))
+    assert any_auto == contains_any(a, w["case"], hays)
+    o = oracle.Machine(needles)
+    k = 2000
+    sel = auto[auto["haystack"] < k]
+    assert expand_records(o.values_off(), o.values(), sel["haystack"], sel["state"], sel["end_pos"]) == oracle_triples(o, w["case"], hays[:k])
