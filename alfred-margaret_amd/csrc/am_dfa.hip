@@ -211,16 +211,69 @@ hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t tot
     return hipGetLastError();
 }
 
-// token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq
-__global__ __launch_bounds__(256) void k_dfa_place(const Record* __restrict__ pool, const uint32_t* __restrict__ fill, uint32_t n_super, const uint64_t* __restrict__ unit_offsets,
-                                                   const uint64_t* __restrict__ hay_offsets, const u32x2* __restrict__ dfa_out, uint32_t chunk, Record* __restrict__ out)
+// token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq.  One workgroup per superblock.  A superblock's tokens come from ONE wavefront, in the
+// order it made them (step by step over the 64 units of a group, then the next group it took): written out token by token that is a 16-byte write scattered over 64
+// stretches of the result, and the kernel is bound by the address units like everything else here.  So the workgroup first sorts the superblock in LDS by (unit, seq) --
+// a counting sort: a unit's tokens in one superblock have consecutive seq, so slot = bucket start + seq - the bucket's smallest seq -- and then neighbouring lanes write
+// neighbouring records.  Buckets: 64 units x the first 4 groups the superblock holds tokens of; tokens of later groups (text with few matches: a superblock spans
+// hundreds of groups) are placed directly.
+constexpr uint32_t kPlaceBuckets = 256;
+__device__ __forceinline__ void dfa_place_one(const Record& t, const uint64_t* __restrict__ unit_offsets, const uint64_t* __restrict__ hay_offsets,
+                                              const u32x2* __restrict__ dfa_out, uint32_t chunk, Record* __restrict__ out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    const uint32_t sb = (uint32_t)(i / kDfaSuper), s = (uint32_t)(i % kDfaSuper);
-    if (sb >= n_super || s >= fill[sb]) return;
-    const Record t = pool[i];
     const uint64_t u = t.end_pos >> 32, seq = (t.end_pos >> 16) & 0xFFFFu, pos = t.end_pos & 0xFFFFu;
     out[unit_offsets[u] + seq] = Record{u * chunk + pos + 1u - hay_offsets[t.haystack], t.haystack, dfa_out[t.state].x - 1u};
+}
+__global__ __launch_bounds__(1024) void k_dfa_place(const Record* __restrict__ pool, const uint32_t* __restrict__ fill, uint32_t n_super, const uint64_t* __restrict__ unit_offsets,
+                                                    const uint64_t* __restrict__ hay_offsets, const u32x2* __restrict__ dfa_out, uint32_t chunk, uint32_t n_waves,
+                                                    Record* __restrict__ out)
+{
+    __shared__ Record s_tok[kDfaSuper];
+    __shared__ uint32_t s_cnt[kPlaceBuckets], s_min[kPlaceBuckets], s_base[kPlaceBuckets + 1];
+    const uint32_t sb = blockIdx.x;
+    if (sb >= n_super) return;
+    const uint32_t n = fill[sb];
+    if (n == 0) return;
+    const Record* tok = pool + (uint64_t)sb * kDfaSuper;
+    if (threadIdx.x < kPlaceBuckets) { s_cnt[threadIdx.x] = 0u; s_min[threadIdx.x] = 0xFFFFFFFFu; }
+    __syncthreads();
+    const uint64_t g_first = tok[0].end_pos >> 38;              // the first group's number (unit >> 6); the wavefront's later groups follow at a stride of n_waves
+    Record t[kDfaSuper / 1024];
+    uint32_t bucket[kDfaSuper / 1024];
+#pragma unroll
+    for (uint32_t k = 0; k < kDfaSuper / 1024; k++) {
+        const uint32_t i = threadIdx.x + k * 1024u;
+        bucket[k] = kNone;
+        if (i < n) {
+            t[k] = tok[i];
+            const uint64_t ord = ((t[k].end_pos >> 38) - g_first) / n_waves;
+            if (ord < kPlaceBuckets / 64u) {
+                bucket[k] = (uint32_t)ord * 64u + (uint32_t)((t[k].end_pos >> 32) & 63u);
+                atomicAdd(&s_cnt[bucket[k]], 1u);
+                atomicMin(&s_min[bucket[k]], (uint32_t)((t[k].end_pos >> 16) & 0xFFFFu));
+            } else dfa_place_one(t[k], unit_offsets, hay_offsets, dfa_out, chunk, out);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWave) {                                   // exclusive sums of 256 counts by one wavefront: 4 per lane
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { c[j] = s_cnt[threadIdx.x * 4u + j]; sum += c[j]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if ((int)threadIdx.x >= off) incl += v; }
+        uint32_t run = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s_base[threadIdx.x * 4u + j] = run; run += c[j]; }
+        if (threadIdx.x == 63u) s_base[kPlaceBuckets] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kDfaSuper / 1024; k++)
+        if (bucket[k] != kNone) s_tok[s_base[bucket[k]] + (uint32_t)((t[k].end_pos >> 16) & 0xFFFFu) - s_min[bucket[k]]] = t[k];
+    __syncthreads();
+    const uint32_t n_sorted = s_base[kPlaceBuckets];
+    for (uint32_t i = threadIdx.x; i < n_sorted; i += 1024u) dfa_place_one(s_tok[i], unit_offsets, hay_offsets, dfa_out, chunk, out);
 }
 
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
@@ -261,12 +314,10 @@ uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu) { retur
 uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves) { return records / (kDfaSuper - kDfaSuperReserve) + n_waves + 16; }
 uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(Record); }
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st) { return launch_dfa_t<kModeTokens>(d, b, o, n_cu, st); }
-hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, Record* out, hipStream_t st)
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, Record* out, hipStream_t st)
 {
     if (n_super == 0) return hipSuccess;
-    const uint64_t blocks = (uint64_t)n_super * (kDfaSuper / 256u);
-    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dfa_place, dim3((uint32_t)blocks), dim3(256), 0, st, o.pool, o.block_next, n_super, unit_offsets, b.offsets, d.out, d.chunk, out);
+    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, o.pool, o.block_next, n_super, unit_offsets, b.offsets, d.out, d.chunk, dfa_token_waves(d, b, n_cu), out);
     return hipGetLastError();
 }
 
