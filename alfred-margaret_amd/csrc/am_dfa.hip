@@ -77,6 +77,8 @@ struct DfaLane {
 }  // namespace
 
 // dfa_common_step (am_image.h) with the first rows of the table in LDS: a chain state answers with its child or hands the question to its fallback's row
+// (LDS holds the first min(32, classes) columns of the first hot_rows rows: the classes are numbered by frequency, the 31 most frequent bytes are 98 % of natural text)
+constexpr uint32_t kDfaHotLog2Classes = 5;
 __device__ __forceinline__ uint32_t dfa_step_lds(const DfaView& d, const uint32_t* s_rows, uint32_t hot_rows, uint32_t state, uint32_t cl)
 {
     if (state >= d.n_rows) {
@@ -84,7 +86,8 @@ __device__ __forceinline__ uint32_t dfa_step_lds(const DfaView& d, const uint32_
         if ((r.y >> 24) == cl) return r.x;
         state = r.y & 0xFFFFFFu;
     }
-    return state < hot_rows ? s_rows[(state << d.log2_classes) + cl] : d.next[((uint64_t)state << d.log2_classes) + cl];
+    const uint32_t hlc = d.log2_classes < kDfaHotLog2Classes ? d.log2_classes : kDfaHotLog2Classes;
+    return (state < hot_rows && cl < (1u << hlc)) ? s_rows[(state << hlc) + cl] : d.next[((uint64_t)state << d.log2_classes) + cl];
 }
 
 // one lane's unit (see the head of the file); s_cls = the byte -> class map in LDS
@@ -156,10 +159,11 @@ template <int MODE>
 __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
 {
     extern __shared__ uint32_t s_dyn[];
-    uint32_t* s_rows = s_dyn;                                                     // hot_rows << log2_classes entries
-    uint32_t* s_wave = s_dyn + ((size_t)hot_rows << d.log2_classes);              // 16 x 4: per wavefront (token mode) tokens in its superblock, its id, pool exhausted
+    const uint32_t hlc = d.log2_classes < kDfaHotLog2Classes ? d.log2_classes : kDfaHotLog2Classes;
+    uint32_t* s_rows = s_dyn;                                                     // hot_rows << hlc entries: the first columns of the first rows
+    uint32_t* s_wave = s_dyn + ((size_t)hot_rows << hlc);                         // 16 x 4: per wavefront (token mode) tokens in its superblock, its id, pool exhausted
     uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_wave + 64);
-    for (uint32_t i = threadIdx.x; i < (hot_rows << d.log2_classes); i += 1024u) s_rows[i] = d.next[i];
+    for (uint32_t i = threadIdx.x; i < (hot_rows << hlc); i += 1024u) s_rows[i] = d.next[((uint64_t)(i >> hlc) << d.log2_classes) + (i & ((1u << hlc) - 1u))];
     if (threadIdx.x < 256u) s_cls[threadIdx.x] = d.cls[threadIdx.x];
     const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x % kWave;
     if (lane == 0) { s_wave[4u * w] = 0u; s_wave[4u * w + 1u] = kNone; s_wave[4u * w + 2u] = 0u; }
@@ -279,7 +283,8 @@ __global__ __launch_bounds__(1024) void k_dfa_place(const Record* __restrict__ p
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
 
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
-static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (d.log2_classes + 2u)); }
+static uint32_t dfa_hot_log2_classes(const DfaView& d) { return std::min<uint32_t>(d.log2_classes, kDfaHotLog2Classes); }
+static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (dfa_hot_log2_classes(d) + 2u)); }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 {
     const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;
@@ -291,7 +296,7 @@ static hipError_t launch_dfa_t(const DfaView& d, const BatchView& b, const ScanO
     const uint64_t n_units = dfa_units(d, b);
     if (n_units == 0) return hipSuccess;
     const uint32_t hot = dfa_hot_rows(d);
-    const size_t lds = ((size_t)hot << (d.log2_classes + 2u)) + 64 * 4 + 256;
+    const size_t lds = ((size_t)hot << (dfa_hot_log2_classes(d) + 2u)) + 64 * 4 + 256;
     static bool raised[64] = {false};                        // (more than 64 KiB of dynamic LDS needs the attribute, once per instantiation and device)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
