@@ -939,11 +939,19 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
     auto body_dfa = [&]() -> int {
         const uint32_t n_waves = dfa_token_waves(p.dfa, p.bv, p.n_cu);
         const uint64_t sb_bytes = dfa_superblock_bytes();
+        // (the guess stays below 32 GiB of pool; a batch that needs more finds out with exact counts in hand, and one that needs more than the device has left
+        // takes the plain count -> scan -> emit protocol, which needs no pool)
+        constexpr uint64_t kFirstPoolBytes = 32ull << 30;
         uint64_t want = dfa_token_superblocks(b->total / 6u, n_waves);
+        if (want * sb_bytes > kFirstPoolBytes) want = std::max<uint64_t>(kFirstPoolBytes / sb_bytes, (uint64_t)n_waves + 16);
         if (b->pool.cap / sb_bytes > want) want = b->pool.cap / sb_bytes;
         if (cfg::get(cfg::kSfPoolBlocks) > 0) want = (uint64_t)cfg::get(cfg::kSfPoolBlocks);       // tests: force the exhausted-pool path
         for (int attempt = 0; attempt < 3; attempt++) {
-            if (want >= (1ull << 31)) return fail(AM_ERR_UNSUPPORTED, "too many match records for one call; split the batch");
+            if (want >= (1ull << 31)) return body_ac();
+            if (want * sb_bytes > b->pool.cap) {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want * sb_bytes + (want * sb_bytes) / 8 + (1ull << 30) > (uint64_t)free_b + b->pool.cap) return body_ac();
+            }
             AM_TRY(b->pool.ensure(want * sb_bytes));
             AM_TRY(b->block_next.ensure(want * sizeof(uint32_t)));
             ScanOut o{};

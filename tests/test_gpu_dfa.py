@@ -68,10 +68,10 @@ def test_fragment_pool_on_the_table_walk(dfa_everywhere, seed):
             check_dfa_route(ns, hays, case)
 
 
-@pytest.mark.parametrize("chunk", [64, 256])
+@pytest.mark.parametrize("chunk", [64, 256, 131072])
 def test_unit_boundaries_inside_matches_and_code_points(dfa_everywhere, chunk):
     """Small units: every haystack is cut many times, inside needles, inside code points, inside the warm-up of the next unit; haystack boundaries
-    and empty haystacks fall inside units."""
+    and empty haystacks fall inside units.  Units beyond 65 536 bytes (a token's fields are 16 bits): records by count -> scan -> emit, two walks."""
     am.debug_set("AM_DFA_CHUNK", chunk)
     rng = random.Random(77 + chunk)
     for _ in range(6):
@@ -125,6 +125,18 @@ def test_dictionary_takes_the_table_walk_by_itself():
         am.debug_set("AM_SF_POOL_BLOCKS", -1)
     am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
     assert n.value == 2 and np.array_equal(again, sf)
+    # a token pool the device cannot hold (a batch of hundreds of GiB would ask for one): count -> scan -> emit instead, two walks and no pool
+    am.debug_set("AM_SF_POOL_BLOCKS", 1 << 23)
+    try:
+        am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+        two_pass = a.run_records(w["case"], hays)
+        am.api.check(lib.am_profile_enable(0))
+    finally:
+        am.debug_set("AM_SF_POOL_BLOCKS", -1)
+    am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
+    assert n.value == 2 and np.array_equal(two_pass, sf)
+    am.api.check(lib.am_profile_read(b"dfa_place", C.byref(ms), C.byref(n)))
+    assert n.value == 0
     assert [int(c) for c in a.count_matches(w["case"], hays)] == [o.count_matches(w["case"], h) for h in hays]
     # the serialised image carries the DFA section: an automaton attached to it (another process, another GPU: am_multi_*) walks the same table
     attached = am.ImageAutomaton(a.image_bytes(w["case"]))
