@@ -1,6 +1,7 @@
 // am_dfa.hip -- k_dfa: the byte-level Aho-Corasick automaton with every transition resolved (ImageHeader::off_dfa_next, built by am_flatten.cpp for
 // dictionaries that meet match-dense text), walked one lane per stretch of the batch.  Reference semantics: Automaton.hs:482-520 (followCodePoint /
-// collectMatches) -- the fallback loop is folded into the table, so a step is ONE dependent 4-byte load: next = table[state << log2_classes | class(byte)].
+// collectMatches) -- the fallback loop is folded into the table, so a step is ONE dependent load: next = table[state << log2_classes | class(byte)] for the states that
+// have a dense row, an 8-byte chain record {child, its class, fallback row} for the single-child states of a word's tail (image layout: am_image.h, DfaView).
 //
 // Why a second scan kernel: k_sf is a filter.  On natural-language text against a 100k-word dictionary four positions in ten pass its LDS filter and a needle
 // ends every 6.6 bytes; its resolve phase then costs ~19 divergent 16-byte loads and ~22 VALU instructions per deferred position and the kernel runs at the
@@ -12,11 +13,12 @@
 // Bytes are read 16 at a time (aligned, nontemporal: the text is a stream, the table is what the caches are for); the byte -> class map sits in LDS.
 //   count / any  one launch; unit_counts[u] = the unit's records (what the exclusive scan turns into the records' final places).
 //   records      ONE walk as well (kModeEmit with ScanOut::pool set): a lane knows the running number `seq` of each of its matches, so it drops a 16-byte TOKEN
-//                {unit, seq, offset in the unit, haystack, state} into its wavefront's current superblock of the pool (slot = one LDS atomic; a superblock = 4096
+//                {unit, seq, offset in the unit, haystack, DFA state} into its wavefront's current superblock of the pool (slot = one LDS atomic; a superblock = 4096
 //                tokens, one device atomic each; order inside does not matter), and after the scan k_dfa_place puts token (u, seq) at unit_offsets[u] + seq as the
 //                record it stands for: position order without a sort and without walking the text a second time.  A pool that turns out too small only costs the
 //                tokens (the counts stay exact): the host repeats the call with the size the kernel reports, as for k_sf's record blocks.
-//                (kModeEmit with ScanOut::records set is the second pass of the plain count -> scan -> emit protocol, kept for chunks beyond 65536 bytes.)
+//                (kModeEmit with ScanOut::records set is the second pass of the plain count -> scan -> emit protocol, kept for chunks beyond 65536 bytes and for
+//                batches whose tokens the device could not hold.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
