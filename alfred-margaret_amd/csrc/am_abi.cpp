@@ -659,7 +659,7 @@ namespace {
 using AcLauncher = hipError_t (*)(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
 std::atomic<AcLauncher> g_ac_launcher{nullptr};
 
-constexpr uint64_t kDfaMinBytes = 1ull << 20;      // below this the suffix-filter route (its one-document path) is the faster one whatever the text
+constexpr uint64_t kDfaMinBytes = 32ull << 20;     // below this the suffix-filter route is the faster one even on natural text: a lane's walk of its unit (>= 128 bytes + warm-up, ~1 us per step) has a floor of 0.3 ms (natural text, 16 MiB: k_sf 0.26 / 0.36 ms counting / emitting, k_dfa 0.29 / 0.41; 32 MiB: 0.44 / 0.57 against 0.33 / 0.47)
 constexpr uint64_t kDfaSampleBytes = 64ull << 20;   // from here on a sample walk asks the text which route it wants (below: a dictionary is taken to meet its language)
 constexpr uint32_t kDfaEndsPerKiB = 48;            // needle ends per KiB from which the table walk wins (k_sf: 670 GiB/s at 10 per KiB, 215 at 63, 76 at 156; k_dfa: ~155 flat)
 
@@ -685,7 +685,19 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
     const bool has_dfa = p.f->h.dfa_n_states != 0 && p.f->h.root_vlen == 0;
     if (a->kernel_pref == 3 && !has_dfa) return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 3): this automaton's image has no DFA section");
     p.dfa = make_dfa_view(p.f->d_image, p.f->h);
-    p.use_dfa = has_dfa && allow_dfa && (a->kernel_pref == 3 || (a->kernel_pref == 0 && b->total >= kDfaMinBytes && cfg::get(cfg::kDfa) != 0));
+    if (has_dfa) {
+        // A lane walks its unit byte after byte (~1 us per step): a unit of 2 048 bytes takes milliseconds however small the batch is.  The image's unit is for batches that
+        // fill the machine (n_cu x 32 wavefronts x 64 lanes) with it; smaller batches get smaller units, down to 128 bytes (where the warm-up is a third of the walk).
+        const long forced = cfg::get(cfg::kDfaChunk);
+        if (forced < 64) {
+            const uint64_t lanes = (uint64_t)g_rt.dev[b->dev].n_cu * 32u * 64u;
+            uint64_t unit = ((b->total / (lanes ? lanes : 1)) + 15u) & ~15ull;
+            if (unit < 128) unit = 128;
+            if (unit < 4ull * p.dfa.warm) unit = (4ull * p.dfa.warm + 15u) & ~15ull;
+            if (unit < p.dfa.chunk) p.dfa.chunk = (uint32_t)unit;
+        }
+    }
+    p.use_dfa = has_dfa && allow_dfa && (a->kernel_pref == 3 || (a->kernel_pref == 0 && b->total >= (cfg::get(cfg::kDfaMinKiB) >= 0 ? (uint64_t)cfg::get(cfg::kDfaMinKiB) << 10 : kDfaMinBytes) && cfg::get(cfg::kDfa) != 0));
     if (p.use_dfa && a->kernel_pref == 0 && b->total >= kDfaSampleBytes) {
         // The table walk costs the same whatever the text is; the suffix filter is 6 x faster where needles are rare and slower where one ends every few bytes.  A large batch
         // is asked: 4 096 lanes spread over it walk 128 bytes each (0.15 ms); below kDfaEndsPerKiB needle ends per KiB the filter takes it.  Decided once per batch and image.

@@ -119,7 +119,7 @@ AM_API uint32_t am_automaton_lower_hash(const am_automaton* a);
 AM_API uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32_t* lower_to, size_t n_pairs);   /* NULL: the built-in table's; 0 on error */
 AM_API void am_automaton_destroy(am_automaton* a);
 /* Route k: 0 = automatic (the suffix-filter kernel; the table-walk kernel k_dfa for automata whose image carries a DFA section -- dictionaries with
- * heavy suffix nodes -- on batches of 1 MiB and more, from 64 MiB on only where a sample walk finds a needle end every few bytes), 1 = force the general AC kernel (test infrastructure: AM_ERR_UNSUPPORTED unless libam_check.so
+ * heavy suffix nodes -- on batches of 32 MiB and more, from 64 MiB on only where a sample walk finds a needle end every few bytes), 1 = force the general AC kernel (test infrastructure: AM_ERR_UNSUPPORTED unless libam_check.so
  * is loaded), 2 = force the suffix-filter kernel, 3 = force the table-walk kernel (AM_ERR_UNSUPPORTED at run time when the image has no DFA section).
  * All routes report the same matches. */
 AM_API int am_automaton_set_kernel(am_automaton* a, int k);

@@ -26,6 +26,14 @@ def dfa_everywhere():
     am.debug_set("AM_DFA_RARE_PERMILLE", -1)
 
 
+@pytest.fixture()
+def dfa_from_one_mib():
+    """The table walk for batches of 1 MiB and more (the library's own threshold is 32 MiB: below, a unit's walk costs more than the filter's whole scan)."""
+    am.debug_set("AM_DFA_MIN_KIB", 1024)
+    yield
+    am.debug_set("AM_DFA_MIN_KIB", -1)
+
+
 def triples(a, case, hays):
     hay, pos, val = a.run_batch_with_case(case, hays)
     return [(int(h), int(p), int(v)) for h, p, v in zip(hay, pos, val)]
@@ -92,9 +100,9 @@ def test_no_dfa_section_is_an_error_only_when_forced():
         a.count_matches(0, ["hay needle hay"])
 
 
-def test_dictionary_takes_the_table_walk_by_itself():
+def test_dictionary_takes_the_table_walk_by_itself(dfa_from_one_mib):
     """The natural-text workload, reduced: the flattener gives the 100k-word dictionary a DFA section, batches of 1 MiB and more take k_dfa without being
-    asked, and its records are those of the suffix-filter kernel and of the oracle."""
+    asked (here from 1 MiB on), and its records are those of the suffix-filter kernel and of the oracle."""
     w = synth.WORKLOADS["natural_100k_10GiB"]
     needles = synth.needles_for("natural_100k_10GiB")
     a = am.Automaton(needles)
@@ -145,7 +153,7 @@ def test_dictionary_takes_the_table_walk_by_itself():
     am.api.check(lib.am_profile_enable(0))
     am.api.check(lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n)))
     assert n.value == 1 and np.array_equal(from_image, sf)
-    # below 1 MiB the suffix-filter route stays
+    # below the threshold the suffix-filter route stays
     am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
     small = a.run_records(w["case"], hays[:2])
     am.api.check(lib.am_profile_enable(0))
@@ -187,7 +195,7 @@ def test_large_batches_choose_their_route_by_a_sample_walk():
             lib.am_batch_destroy(b)
 
 
-def test_replacer_over_a_dictionary_scans_with_the_table_walk():
+def test_replacer_over_a_dictionary_scans_with_the_table_walk(dfa_from_one_mib):
     """A Replacer whose needles are a dictionary (the flattener gives its automaton a DFA section): the first scan of a batch of 1 MiB and more takes k_dfa, the
     re-scans of the later passes the suffix filter; the rewritten texts are the oracle's Replacer.run (Replacer.hs:203-274)."""
     from concurrent.futures import ThreadPoolExecutor
@@ -212,7 +220,7 @@ def test_replacer_over_a_dictionary_scans_with_the_table_walk():
     assert sum(g != h for g, h in zip(got, hays)) >= 16
 
 
-def test_ragged_batch_of_tiny_haystacks_on_the_table_walk():
+def test_ragged_batch_of_tiny_haystacks_on_the_table_walk(dfa_from_one_mib):
     """2 MiB of natural text cut into 120 000 haystacks of 0-40 bytes: a unit of 2 048 bytes spans a hundred haystacks, most steps take the byte-wise path
     and reset at a boundary.  Records, counts and flags of the table walk (the route such a batch takes by itself) == the suffix filter's; the first haystacks == the oracle."""
     w = synth.WORKLOADS["natural_100k_10GiB"]
