@@ -40,7 +40,7 @@ template <int MODE>
 struct DfaLane {
     const DfaView& d; const BatchView& b; const ScanOut& o;
     Record* out;                              // emit mode: where this unit's next record goes
-    uint32_t* wv;                             // token mode: this wavefront's {fill, superblock id} in LDS
+    uint32_t* wv;                             // token mode: this wavefront's {tokens in its superblock, the superblock's id, pool exhausted} in LDS
     uint64_t unit;
     uint32_t nrec = 0; uint64_t nval = 0;
     uint32_t run_hay = kNone; uint64_t run_val = 0;      // count mode: values of the haystack the lane is in, added with one atomic when it leaves it
@@ -97,7 +97,6 @@ template <int MODE>
 __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s_cls, const uint32_t* s_rows, uint32_t hot_rows, uint64_t u)
 {
     const DfaView& d = L.d; const BatchView& b = L.b; const ScanOut& o = L.o;
-    const uint32_t lc = d.log2_classes;
     const uint64_t cs = u * d.chunk;
     const uint64_t ce = (cs + d.chunk < b.total) ? cs + d.chunk : b.total;
     uint32_t h = find_haystack(b, cs);
