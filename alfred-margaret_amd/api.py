@@ -61,6 +61,8 @@ ABI = {
     "am_matches_size": (C.c_uint64, [_vp]),
     "am_matches_data": (_vp, [_vp]),
     "am_matches_device_data": (_vp, [_vp]),
+    "am_matches_haystack_range": (C.c_int, [_vp, C.c_uint32, _u64p, _u64p]),
+    "am_matches_copy": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp]),
     "am_matches_free": (None, [_vp]),
     "am_matches_fold_hash": (C.c_int, [_vp, _vp, _sz, _vp, _vp]),
     "am_needle_ids_create": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_vp)]),
@@ -477,6 +479,16 @@ def matches_to_numpy(m):
     return np.frombuffer((C.c_char * (n * MATCH_DTYPE.itemsize)).from_address(p), dtype=MATCH_DTYPE).copy()
 
 
+def matches_of_haystack(m, haystack):
+    """The records of ONE haystack of a (possibly huge, device-resident) result as a numpy array: binary search + one small copy (am_matches_haystack_range / am_matches_copy)."""
+    first, count = C.c_uint64(0), C.c_uint64(0)
+    check(libam().am_matches_haystack_range(m, int(haystack), C.byref(first), C.byref(count)))
+    out = np.zeros(count.value, MATCH_DTYPE)
+    if count.value:
+        check(libam().am_matches_copy(m, first.value, count.value, out.ctypes.data))
+    return out
+
+
 class Searcher:
     def __init__(self, case, needles):
         blob, offs = pack_texts(needles)
@@ -653,7 +665,7 @@ class Splitter:
         return self.split_batch([text], True)[0]
 
 
-DEBUG_SWITCHES = ("AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_NO_CHAINS", "AM_NO_IDS_SCAN",
+DEBUG_SWITCHES = ("AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_TUNE", "AM_DFA_HOT_LOG2", "AM_DFA_NO_CHAINS", "AM_NO_IDS_SCAN",
                   "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
                   "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_LOOP")
 

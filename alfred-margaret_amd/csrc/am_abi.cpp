@@ -250,6 +250,8 @@ ThreadState::~ThreadState()
 
 // ------------------------------------------------------------------ automaton
 
+uint64_t am::host::next_image_generation() { static std::atomic<uint64_t> g{0}; return g.fetch_add(1, std::memory_order_relaxed) + 1u; }
+
 int am::host::prepare(const am_automaton* ca, int case_mode, const Flavor** out)
 {
     if (!ca) return fail(AM_ERR_INVALID, "null automaton");
@@ -273,7 +275,7 @@ int am::host::prepare(const am_automaton* ca, int case_mode, const Flavor** out)
         e = hipMemcpy(d, img.data(), img.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(d); return fail(AM_ERR_HIP, std::string("hipMemcpy(image): ") + hipGetErrorString(e)); }
         std::memcpy(&f.h, img.data(), sizeof(ImageHeader));
-        f.d_image = d; f.bytes = img.size(); f.ready = true;
+        f.d_image = d; f.bytes = img.size(); f.generation = next_image_generation(); f.ready = true;
     }
     *out = &f;
     return AM_OK;
@@ -394,7 +396,7 @@ extern "C" int am_automaton_from_image(const void* d_image, size_t nbytes, am_au
     am_automaton* a = new am_automaton();
     a->dev = dev;
     Flavor& f = a->fl[h.case_mode];
-    f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.ready = true;
+    f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.generation = next_image_generation(); f.ready = true;
     *out = a;
     return AM_OK;
 }
@@ -438,7 +440,7 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
     am_automaton* a = new am_automaton();
     a->dev = dev;
     Flavor& f = a->fl[h.case_mode];
-    f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.ready = true;
+    f.h = h; f.d_image = d; f.bytes = h.total_bytes; f.generation = next_image_generation(); f.ready = true;
     *out = a;
     return AM_OK;
 }
@@ -448,7 +450,7 @@ extern "C" int am_automaton_from_host_image(const void* image, size_t nbytes, am
 int am::host::finish_batch(am_batch* b)
 {
     b->hidx_ready = false;
-    b->route_image = nullptr;                  // new text: the route is asked again
+    b->route_image = 0;                        // new text: the route is asked again
     if (b->total > 0) AM_TRY(b->hidx.ensure(((b->total >> kHidxShift) + 2) * sizeof(uint32_t)));
     // the batch's block of counters is allocated HERE, once, before the batch is visible to other threads: make_plan reads its
     // address without the batch lock, so it must never be re-allocated later (every later ensure(64) is a no-op)
@@ -674,7 +676,8 @@ struct Plan {
 };
 
 // allow_dfa: the caller's route works for the general two-pass protocol (am_count_batch, am_contains_any_batch, run_records)
-int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool allow_dfa = false)
+// have_lock: the caller holds b->mu already (run_records under reduce_dense)
+int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool allow_dfa = false, bool have_lock = false)
 {
     if (!b) return fail(AM_ERR_INVALID, "null batch");
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
@@ -701,8 +704,9 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
     if (p.use_dfa && a->kernel_pref == 0 && b->total >= kDfaSampleBytes) {
         // The table walk costs the same whatever the text is; the suffix filter is 6 x faster where needles are rare and slower where one ends every few bytes.  A large batch
         // is asked: 4 096 lanes spread over it walk 128 bytes each (0.15 ms); below kDfaEndsPerKiB needle ends per KiB the filter takes it.  Decided once per batch and image.
-        std::lock_guard<std::mutex> lk(b->mu);
-        if (b->route_image != p.f->d_image) {
+        std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
+        if (!have_lock) lk.lock();
+        if (b->route_image != p.f->generation) {
             ON_DEVICE(b->dev);
             hipStream_t st; AM_TRY(get_stream(b->dev, &st));
             AM_TRY(b->small.ensure(64));
@@ -713,7 +717,8 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
             HIP_TRY(hipMemcpyAsync(&ends, b->small.p, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             b->route_dfa = (uint64_t)ends * 1024u >= (uint64_t)kDfaEndsPerKiB * kSamples * kLen;
-            b->route_image = p.f->d_image;
+            b->route_ends_per_kib = (uint32_t)(((uint64_t)ends * 1024u + (uint64_t)kSamples * kLen - 1u) / ((uint64_t)kSamples * kLen));
+            b->route_image = p.f->generation;
         }
         p.use_dfa = b->route_dfa;
     }
@@ -903,7 +908,7 @@ int am::host::scan_needle_ids(const am_automaton* a, int case_mode, am_batch* b,
 int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, const std::function<int(uint64_t, Record**)>& sink_final, uint64_t* n_out, bool have_lock)
 {
     *n_out = 0;
-    Plan p; AM_TRY(make_plan(a, case_mode, b, p, true));
+    Plan p; AM_TRY(make_plan(a, case_mode, b, p, true, have_lock));
     if (p.nothing) return AM_OK;
     std::unique_lock<std::mutex> lk(b->mu, std::defer_lock);
     if (!have_lock) lk.lock();
@@ -953,8 +958,10 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
         const uint64_t sb_bytes = dfa_superblock_bytes();
         // (the guess stays below 32 GiB of pool; a batch that needs more finds out with exact counts in hand, and one that needs more than the device has left
         // takes the plain count -> scan -> emit protocol, which needs no pool)
-        constexpr uint64_t kFirstPoolBytes = 32ull << 30;
-        uint64_t want = dfa_token_superblocks(b->total / 6u, n_waves);
+        constexpr uint64_t kFirstPoolBytes = 16ull << 30;
+        // (the sample walk of make_plan has counted the needle ends of this batch: a quarter above its estimate; a batch too small to have been asked: a record per 6 bytes)
+        const uint64_t guess = b->route_image == p.f->generation && b->route_ends_per_kib ? (b->total >> 10) * b->route_ends_per_kib * 5u / 4u + 4096u : b->total / 6u;
+        uint64_t want = dfa_token_superblocks(guess, n_waves, p.n_units);
         if (want * sb_bytes > kFirstPoolBytes) want = std::max<uint64_t>(kFirstPoolBytes / sb_bytes, (uint64_t)n_waves + 16);
         if (b->pool.cap / sb_bytes > want) want = b->pool.cap / sb_bytes;
         if (cfg::get(cfg::kSfPoolBlocks) > 0) want = (uint64_t)cfg::get(cfg::kSfPoolBlocks);       // tests: force the exhausted-pool path
@@ -965,11 +972,11 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
                 if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || want * sb_bytes + (want * sb_bytes) / 8 + (1ull << 30) > (uint64_t)free_b + b->pool.cap) return body_ac();
             }
             AM_TRY(b->pool.ensure(want * sb_bytes));
-            AM_TRY(b->block_next.ensure(want * sizeof(uint32_t)));
+            AM_TRY(b->block_next.ensure(2 * want * sizeof(uint32_t)));
             ScanOut o{};
             o.unit_counts = (uint32_t*)b->unit_counts.p;
             o.pool = (Record*)b->pool.p;
-            o.block_next = (uint32_t*)b->block_next.p;           // here: tokens in each superblock
+            o.block_next = (uint32_t*)b->block_next.p;           // here: tokens in each superblock, then each superblock's first group
             o.pool_ctrl = (uint32_t*)b->small.p + 4;             // small: [4] superblocks drawn, [5] pool exhausted
             o.n_blocks = (uint32_t)want;
             HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
@@ -982,7 +989,7 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
             HIP_TRY(hipMemcpyAsync(&total, (uint64_t*)b->unit_offsets.p + p.n_units, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(ctrl, o.pool_ctrl, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (ctrl[1]) { want = dfa_token_superblocks(total, n_waves); continue; }
+            if (ctrl[1]) { want = dfa_token_superblocks(total, n_waves, p.n_units); continue; }
             *n_scan = total;
             if (total == 0) return AM_OK;
             AM_TRY(sink(total, &d_records));
@@ -1480,6 +1487,43 @@ extern "C" const am_match* am_matches_data(am_matches* m)
 }
 
 extern "C" const void* am_matches_device_data(const am_matches* m) { return m ? (m->d_records ? m->d_records + m->first : nullptr) : nullptr; }
+
+// A slice of a result without bringing all of it to the host: the records are sorted by (haystack, end_pos), so one haystack's records are a contiguous run.
+// The run is found by a binary search over the records in HBM (4-byte probes of the haystack field: ~2 log2(n) small copies), the copy is one DMA.
+extern "C" int am_matches_haystack_range(const am_matches* m, uint32_t haystack, uint64_t* first_out, uint64_t* count_out)
+{
+    if (!m || !first_out || !count_out) return fail(AM_ERR_INVALID, "am_matches_haystack_range: null argument");
+    *first_out = 0; *count_out = 0;
+    if (m->n == 0) return AM_OK;
+    OnDevice od(m->dev);
+    const Record* r = m->d_records + m->first;
+    auto lower = [&](uint64_t key, uint64_t* out) -> int {        // first index whose haystack >= key
+        uint64_t lo = 0, hi = m->n;
+        while (lo < hi) {
+            const uint64_t mid = lo + (hi - lo) / 2;
+            uint32_t h = 0;
+            HIP_TRY(hipMemcpy(&h, &r[mid].haystack, sizeof(h), hipMemcpyDeviceToHost));
+            if (h < key) lo = mid + 1; else hi = mid;
+        }
+        *out = lo;
+        return AM_OK;
+    };
+    uint64_t a = 0, b = 0;
+    AM_TRY(lower(haystack, &a));
+    AM_TRY(lower((uint64_t)haystack + 1u, &b));
+    *first_out = a; *count_out = b - a;
+    return AM_OK;
+}
+
+extern "C" int am_matches_copy(const am_matches* m, uint64_t first, uint64_t count, am_match* out)
+{
+    if (!m || (count && !out)) return fail(AM_ERR_INVALID, "am_matches_copy: null argument");
+    if (first > m->n || count > m->n - first) return fail(AM_ERR_INVALID, "am_matches_copy: range outside the result");
+    if (count == 0) return AM_OK;
+    OnDevice od(m->dev);
+    HIP_TRY(hipMemcpy(out, m->d_records + m->first + first, (size_t)count * sizeof(Record), hipMemcpyDeviceToHost));
+    return AM_OK;
+}
 
 extern "C" void am_matches_free(am_matches* m)
 {

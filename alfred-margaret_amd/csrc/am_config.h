@@ -24,6 +24,8 @@ enum Key {
     kDfaChunk,            // AM_DFA_CHUNK: bytes of the batch one lane of k_dfa owns (read when an image is flattened; default 2048)
     kDfaRarePermille,     // AM_DFA_RARE_PERMILLE: share of the edges (in thousandths; default 1) whose bytes may go without a column of the DFA table (tests: 300 makes most bytes rare)
     kDfaMinKiB,           // AM_DFA_MIN_KIB: batch size from which a dictionary's scans take the table walk by themselves (default 32 768: below, a unit's walk costs more than the filter's whole scan)
+    kDfaTune,             // AM_DFA_TUNE: launch parameters of k_dfa for A/B measurements (am_dfa.hip dfa_tune)
+    kDfaHotLog2,          // AM_DFA_HOT_LOG2: columns of the DFA section's hot table, as a power of two (read when an image is flattened; default 4 = 16 columns, two rows per 128-byte line)
     kDfaNoChains,         // AM_DFA_NO_CHAINS: every state of the DFA section gets a dense row (A/B against the chain records; read when an image is flattened)
     kNoIdsScan,           // AM_NO_IDS_SCAN: containsAll folds the records of a full scan (k_idset) instead of setting the id bits inside k_sf
     kRpFullScans, kRpSplice, kRpPieces, kRpParallelFold, kRpGroups, kRpNoFuse, kRpNoSpin, kRpMatMain, kRpNoRangeReuse, kRpTrace,
@@ -40,7 +42,7 @@ struct Table {
 inline Table& table() { static Table t; return t; }
 inline const char* name_of(int k)
 {
-    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_NO_CHAINS", "AM_NO_IDS_SCAN",
+    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_TUNE", "AM_DFA_HOT_LOG2", "AM_DFA_NO_CHAINS", "AM_NO_IDS_SCAN",
                                               "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
                                               "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_LOOP"};
     return names[k];

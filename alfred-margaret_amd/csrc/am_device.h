@@ -71,13 +71,13 @@ hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, con
 // table-walk kernel (am_dfa.hip): same two-pass protocol as the general kernel (count -> scan -> emit), unit = one lane's DfaView::chunk bytes
 uint64_t dfa_units(const DfaView& d, const BatchView& b);
 hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
-// records in ONE walk: tokens into ScanOut::pool (superblocks; ScanOut::block_next = their fill counts, zeroed before the launch; pool_ctrl[0] superblocks drawn,
-// [1] pool exhausted; n_blocks = superblocks in the pool), unit_counts as in count mode; then scan(unit_counts) and launch_dfa_place
+// records in ONE walk: 8-byte tokens into ScanOut::pool (superblocks; ScanOut::block_next = 2 x n_blocks words: their fill counts, zeroed before the launch, then their
+// first groups; pool_ctrl[0] superblocks drawn, [1] pool exhausted; n_blocks = superblocks in the pool), unit_counts as in count mode; then scan(unit_counts) and launch_dfa_place
 // an estimate of the needle ends per byte of a batch: n_samples lanes spread over the text walk len bytes each and add their count to *out (zeroed by the caller)
 hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t total, uint32_t n_samples, uint32_t len, uint32_t* out, hipStream_t st);
 bool dfa_tokens_ok(const DfaView& d);
 uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu);
-uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves);
+uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves, uint64_t n_units);
 uint64_t dfa_superblock_bytes();
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, Record* out, hipStream_t st);

@@ -5,24 +5,33 @@
 //
 // Why a second scan kernel: k_sf is a filter.  On natural-language text against a 100k-word dictionary four positions in ten pass its LDS filter and a needle
 // ends every 6.6 bytes; its resolve phase then costs ~19 divergent 16-byte loads and ~22 VALU instructions per deferred position and the kernel runs at the
-// issue limit of the CUs' address units and vector ALUs (profiles/r05_pmc_natural_units.md).  A table walk costs one 4-byte load and ~8 instructions per BYTE
+// issue limit of the CUs' address units and vector ALUs (profiles/r05_pmc_natural_units.md).  A table walk costs one 4-byte load and a few instructions per BYTE
 // whatever the text is -- slower than k_sf where matches are rare (it cannot skip anything), several times faster where they are dense.
+//
+// What bounds it (round 6, profiles/r06_pmc_dfa.md): the wavefronts wait 92 % of their time, and not for latency -- half the wavefronts per CU give 86 % of the rate.  Every
+// lane-load is an L2 request (2 048 lanes per CU touch 2 048 different lines between two visits of one lane: the 32-KiB L1 holds nothing, 97 % of its accesses go on), and a
+// request that misses the XCD's 4-MiB L2 moves a whole line over the fabric.  So the kernel is written to the two currencies "L2 requests per byte" and "lines per
+// byte": the byte class and the hottest rows in LDS, a chain record in ONE 8-byte load, a byte no needle contains answered without any load (it leads to the root from
+// everywhere), text asked for 64 bytes at a time, and the first 16 columns of every row a second time in a table of their own where two rows share a line (am_flatten.cpp).
 //
 // Work split: unit u = bytes [u * chunk, (u + 1) * chunk) of the concatenated batch, one lane each; the lane owns the matches whose LAST byte lies in its unit and
 // warms its state up from the root over the `warm` bytes before it (clipped to the haystack start; a haystack boundary inside the unit resets the state).
-// Bytes are read 16 at a time (aligned, nontemporal: the text is a stream, the table is what the caches are for); the byte -> class map sits in LDS.
+// A wavefront takes GROUPS of 64 consecutive units; inside a group every position is a 32-bit offset from the group's start minus the warm-up (one 64-bit base in scalar
+// registers: the text loads are saddr + 32-bit lane offset, and so are the table loads -- the DFA section is < 4 GiB).
 //   count / any  one launch; unit_counts[u] = the unit's records (what the exclusive scan turns into the records' final places).
-//   records      ONE walk as well (kModeEmit with ScanOut::pool set): a lane knows the running number `seq` of each of its matches, so it drops a 16-byte TOKEN
-//                {unit, seq, offset in the unit, haystack, DFA state} into its wavefront's current superblock of the pool (slot = one LDS atomic; a superblock = 4096
-//                tokens, one device atomic each; order inside does not matter), and after the scan k_dfa_place puts token (u, seq) at unit_offsets[u] + seq as the
-//                record it stands for: position order without a sort and without walking the text a second time.  A pool that turns out too small only costs the
-//                tokens (the counts stay exact): the host repeats the call with the size the kernel reports, as for k_sf's record blocks.
-//                (kModeEmit with ScanOut::records set is the second pass of the plain count -> scan -> emit protocol, kept for chunks beyond 65536 bytes and for
-//                batches whose tokens the device could not hold.)
+//   records      ONE walk as well (kModeTokens): a lane knows the running number `seq` of each of its matches, so it drops an 8-byte TOKEN
+//                {DFA state | group ordinal, offset in the unit | seq | lane} into its wavefront's current superblock of the pool (slot = one LDS atomic; a superblock =
+//                4096 tokens, one device atomic each; order inside does not matter), and after the scan k_dfa_place puts the token of (unit, seq) at unit_offsets[unit] +
+//                seq as the record it stands for: position order without a sort and without walking the text a second time.  A pool that turns out too small only costs
+//                the tokens (the counts stay exact): the host repeats the call with the size the kernel reports, as for k_sf's record blocks.
+//                (kModeEmit is the second pass of the plain count -> scan -> emit protocol, kept for units beyond 8192 bytes and for batches whose tokens the device
+//                could not hold.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
+#include "am_config.h"
 #include "am_device.h"
 #include "am_wave.h"
 
@@ -32,43 +41,60 @@ namespace dev {
 namespace {
 
 constexpr uint32_t kWave = 64;
-constexpr int kModeTokens = 16;               // template value only: kModeEmit with a token pool
-constexpr uint32_t kDfaSuper = 4096;          // tokens per superblock (64 KiB)
+constexpr int kModeTokens = 16;               // template value only: records in one walk, tokens into the pool
+constexpr uint32_t kDfaSuper = 4096;          // tokens per superblock (32 KiB)
 constexpr uint32_t kDfaSuperReserve = 1024;   // free slots a wavefront makes sure of before 64 lanes take (at most) 16 steps
+// a token: w0 = DFA state (28 bits) | the group's ordinal in its superblock << 28 (a superblock holds tokens of at most 16 groups of its wavefront),
+//          w1 = offset of the match's last byte in its unit (13 bits) | seq << 13 (13 bits) | lane << 26 -- hence units of at most 8192 bytes on this route
+constexpr uint32_t kTokPosBits = 13, kTokOrdShift = 28, kTokMaxOrd = 16, kTokMaxChunk = 1u << kTokPosBits;
+constexpr uint32_t kLdsLog2Cols = 5;          // LDS holds columns 1 .. 32 of the first rows (the classes are numbered by the dictionary's use of them: 31 are 98 % of natural text)
+
+typedef uint32_t u32x2_v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
+__device__ __forceinline__ uint32_t lds_read_u8(uint32_t byte_addr) { return *reinterpret_cast<const lds_u8_t*>((uintptr_t)byte_addr); }
+
+// hot table and chain records as byte offsets from `next` (the flattener puts them behind the rows; launch_dfa_tw checks that the section spans < 4 GiB)
+struct DfaDev { const uint8_t* base; uint32_t off_hot, off_chain; };
 
 template <int MODE>
 struct DfaLane {
     const DfaView& d; const BatchView& b; const ScanOut& o;
-    Record* out;                              // emit mode: where this unit's next record goes
-    uint32_t* wv;                             // token mode: this wavefront's {tokens in its superblock, the superblock's id, pool exhausted} in LDS
-    uint64_t unit;
-    uint32_t nrec = 0; uint64_t nval = 0;
-    uint32_t run_hay = kNone; uint64_t run_val = 0;      // count mode: values of the haystack the lane is in, added with one atomic when it leaves it
+    uint32_t* wv;                             // token mode: this wavefront's words in LDS: [0] tokens in its superblock, [1] the superblock's id, [2] pool exhausted,
+                                              // [3] the ordinal (k) of the superblock's first group, [4] the current group, [5] its ordinal
+    uint32_t nrec = 0;
+    // count mode: the unit's values, and those of the haystack the lane is in (added with one atomic when it leaves it), in 32 bits: lists of fewer than 15 values (the end
+    // bits of the entry) add up here -- at most 14 per byte of a unit --, a longer list goes to the 64-bit sums in memory at once
+    uint32_t nval = 0, run_hay = kNone, run_val = 0;
+    Record* out = nullptr;                    // emit mode: where this unit's next record goes
+    uint32_t ord = 0, sb = kNone;             // token mode: what the block's tokens carry / go to (read from LDS after the reserve at the top of a block)
     __device__ __forceinline__ void flush()
     {
         if (MODE == kModeCount && o.hay_counts && run_hay != kNone && run_val) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + run_hay), (unsigned long long)run_val);
         run_val = 0;
     }
-    // g = index of the match's last byte in the batch, hs = where its haystack starts
-    // end = the entry's end bits: the length of the needle-end list (1..14), kDfaEndLookUp = longer (out[] knows)
-    __device__ __forceinline__ void found(uint32_t hay, uint64_t g, uint64_t hs, uint32_t state, uint32_t end)
+    // in_unit = offset of the match's last byte in the unit; end = the entry's end bits: the length of the needle-end list (1..14), kDfaEndLookUp = longer (out[] knows)
+    __device__ __forceinline__ void found(uint32_t hay, uint32_t in_unit, uint64_t end_pos, uint32_t state, uint32_t end)
     {
-        const uint64_t end_pos = g + 1u - hs;
         if (MODE == kModeAny) { o.flags[hay] = 1; return; }
         if (MODE == kModeTokens) {
-            const uint32_t sb = wv[1];
             if (sb != kNone) {
-                const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the step loop)
-                const uint64_t pos = g - unit * d.chunk;                   // offset of the match's last byte in the unit
-                o.pool[(uint64_t)sb * kDfaSuper + slot] = Record{(unit << 32) | ((uint64_t)nrec << 16) | pos, hay, state};      // (the DFA state: k_dfa_place looks the reference state up, off the walk's dependent chain)
+                const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the block)
+                u32x2_v t; t.x = state | (ord << kTokOrdShift); t.y = in_unit | (nrec << kTokPosBits) | (lane_id() << 26);
+                reinterpret_cast<u32x2_v*>(o.pool)[(uint64_t)sb * kDfaSuper + slot] = t;      // (the DFA state: k_dfa_place looks the reference state up, off the walk's dependent chain)
             }
             nrec++;
             return;
         }
         if (MODE == kModeCount) {
-            const uint32_t vl = end < kDfaEndLookUp ? end : d.out[state].y;      // (a count needs no load of its own unless a position reports 15 values or more)
-            nrec++; nval += vl;
-            if (o.hay_counts) { if (hay != run_hay) { flush(); run_hay = hay; } run_val += vl; }
+            nrec++;
+            if (end < kDfaEndLookUp) {                                 // (a count needs no load of its own unless a position reports 15 values or more)
+                nval += end;
+                if (o.hay_counts) { if (hay != run_hay) { flush(); run_hay = hay; } run_val += end; }
+            } else {
+                const unsigned long long vl = d.out[state].y;
+                atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), vl);
+                if (o.hay_counts) atomicAdd(reinterpret_cast<unsigned long long*>(o.hay_counts + hay), vl);
+            }
         } else {
             const u32x2 e = d.out[state];
             out[nrec++] = Record{end_pos, hay, e.x - 1u};
@@ -76,39 +102,56 @@ struct DfaLane {
     }
 };
 
-}  // namespace
-
-// dfa_common_step (am_image.h) with the first rows of the table in LDS: a chain state answers with its child or hands the question to its fallback's row
-// (LDS holds the first min(32, classes) columns of the first hot_rows rows: the classes are numbered by frequency, the 31 most frequent bytes are 98 % of natural text)
-constexpr uint32_t kDfaHotLog2Classes = 5;
-__device__ __forceinline__ uint32_t dfa_step_lds(const DfaView& d, const uint32_t* s_rows, uint32_t hot_rows, uint32_t state, uint32_t cl)
+// delta(state, class) for a byte with a column (dfa_common_step in am_image.h is the plain form): a chain state answers with its child or hands the question to its
+// fallback's row -- ONE 8-byte load; a byte no needle contains (class 0) leads to the root; the first rows' first columns sit in LDS; the first columns of every row in
+// the hot table; one global load serves the hot and the cold case (both tables lie behind `next`).
+__device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, uint32_t lds_rows_addr, uint32_t hot_rows, uint32_t state, uint32_t cl)
 {
+    if (cl == 0u) return 0u;
     if (state >= d.n_rows) {
-        const u32x2 r = d.chain[state - d.n_rows];
+        const u32x2_v r = *reinterpret_cast<const u32x2_v*>(v.base + v.off_chain + ((state - d.n_rows) << 3));
         if ((r.y >> 24) == cl) return r.x;
         state = r.y & 0xFFFFFFu;
     }
-    const uint32_t hlc = d.log2_classes < kDfaHotLog2Classes ? d.log2_classes : kDfaHotLog2Classes;
-    return (state < hot_rows && cl < (1u << hlc)) ? s_rows[(state << hlc) + cl] : d.next[((uint64_t)state << d.log2_classes) + cl];
+    const bool in_lds = state < hot_rows && cl <= (1u << kLdsLog2Cols);
+    uint32_t e;
+    if (in_lds) e = lds_read_u32(lds_rows_addr + (((state << kLdsLog2Cols) + cl - 1u) << 2));
+    else {
+        const uint32_t off = cl <= (1u << d.hot_log2) ? v.off_hot + (((state << d.hot_log2) + cl - 1u) << 2) : (((state << d.log2_classes) + cl) << 2);
+        e = *reinterpret_cast<const uint32_t*>(v.base + off);
+    }
+    return e;
 }
 
-// one lane's unit (see the head of the file); s_cls = the byte -> class map in LDS
-template <int MODE>
-__device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s_cls, const uint32_t* s_rows, uint32_t hot_rows, uint64_t u)
+// One lane's unit.  All positions are 32-bit offsets from tp = text + (first byte of the group) - W, W = the warm-up rounded up to 16 (so offsets keep the
+// alignment of the text).  TW = bytes of text a lane asks for at a time (16 or 64): a lane's unit lies `chunk` bytes from its neighbour's, so a 16-byte load touches 64
+// different lines and uses an eighth of each; the other pieces come 16, 32, ... steps (tens of microseconds) later, by when the line has long left the L2 (an XCD's L2
+// turns over every ~5 us here): eight L2 misses per line of text.  With TW = 64 a lane asks for half a line at once (four loads issued back to back, held in registers:
+// buf[0] = the next block, the blocks move down one place per 16 steps): two.
+template <int MODE, int TW>
+__device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v, const uint8_t* tp, uint64_t tp_off, uint32_t lds_cls_addr, uint32_t lds_rows_addr,
+                                              uint32_t hot_rows, uint32_t W, uint32_t end_r)
 {
+    constexpr int NV = TW / 16;
     const DfaView& d = L.d; const BatchView& b = L.b; const ScanOut& o = L.o;
-    const uint64_t cs = u * d.chunk;
-    const uint64_t ce = (cs + d.chunk < b.total) ? cs + d.chunk : b.total;
+    // where the lane's unit starts and ends: recomputed from the lane number where they are needed (two registers less to hold; W and end_r -- the end of the batch -- are uniform)
+#define cs_r (lane_id() * d.chunk + W)
+#define ce_r (cs_r + d.chunk < end_r ? cs_r + d.chunk : end_r)
+    // tp_off = the batch offset tp stands for (for the first group it is "negative", i.e. wraps: nothing is read there, and the sums below wrap back)
+    const uint64_t cs = tp_off + cs_r;
     uint32_t h = find_haystack(b, cs);
-    uint64_t hs = b.offsets[h], he = b.offsets[h + 1];
-    uint64_t offset = hs;
-    if (cs - hs > d.warm) { offset = (cs - d.warm) & ~15ull; if (offset < hs) offset = hs; }      // a longer warm-up is as exact; 16-byte blocks from the start
+    uint64_t hs = b.offsets[h];
+    const uint64_t he64 = b.offsets[h + 1];
+    uint32_t pos = (cs - hs > d.warm) ? ((cs_r - d.warm) & ~15u) : (uint32_t)(hs - tp_off);      // a longer warm-up is as exact; 16-byte blocks from the start
+    uint32_t he_r = he64 - tp_off < 0xFFFFFFFFull ? (uint32_t)(he64 - tp_off) : 0xFFFFFFFFu;
     uint32_t state = 0;
-    typedef uint32_t u32x4_n __attribute__((ext_vector_type(4)));
-    while (offset < ce) {
+    u32x4_n buf[NV];
+    uint32_t avail = 0;                                     // blocks in buf (only blocks that lie wholly inside the haystack and the unit are ever asked for)
+    bool rare_next = false;                                 // the byte at pos has no column: the byte-by-byte path takes it (and the bytes up to the next block)
+    while (pos < ce_r) {
         if (MODE == kModeTokens) {
             // the lanes that are still walking agree (they read the same LDS words) on whether their wavefront's superblock can take what the next
-            // step may produce (64 lanes x 16 bytes); if not, the first of them seals it and draws the next one
+            // block may produce (64 lanes x 16 bytes); if not, the first of them seals it and draws the next one
             volatile uint32_t* wv = L.wv;
             const uint32_t fill = wv[0], sb = wv[1], exhausted = wv[2];
             if (!exhausted && (sb == kNone || fill + kDfaSuperReserve > kDfaSuper)) {
@@ -117,76 +160,134 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const uint8_t* s
                     if (sb != kNone) o.block_next[sb] = fill;
                     const uint32_t id = atomicAdd(o.pool_ctrl, 1u);
                     if (id >= o.n_blocks) { o.pool_ctrl[1] = 1u; wv[1] = kNone; wv[2] = 1u; }      // the counts stay exact; the host repeats the call with a pool sized by them
-                    else wv[1] = id;
+                    else { wv[1] = id; o.block_next[o.n_blocks + id] = wv[4]; wv[3] = wv[5]; }     // (its first group, for k_dfa_place; the ordinal its tokens count from)
                     wv[0] = 0u;
                 }
                 wave_lds_fence();
             }
+            L.sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv[1]); L.ord = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wv[5] - wv[3]));      // (uniform: scalar registers)
         }
-        if (offset >= he) {                                 // the next non-empty haystack starts here
-            do { h++; hs = he; he = b.offsets[h + 1]; } while (he == hs);
+        if (pos >= he_r) {                                  // the next non-empty haystack starts here
+            uint64_t e64 = tp_off + he_r, s64;
+            do { h++; s64 = e64; e64 = b.offsets[h + 1]; } while (e64 == s64);
+            hs = s64;
+            he_r = e64 - tp_off < 0xFFFFFFFFull ? (uint32_t)(e64 - tp_off) : 0xFFFFFFFFu;
             state = 0;
         }
-        const uint64_t lim = he < ce ? he : ce;
-        if ((offset & 15u) == 0 && offset + 16 <= lim) {
-            const u32x4_n t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_n*>(b.text + offset));
-            const uint32_t w[4] = {t.x, t.y, t.z, t.w};
-            const bool mine = offset >= cs;                 // (cs is a multiple of 16: a block lies on one side of it)
-            if (MODE == kModeAny && mine && o.flags[h]) { offset = he; continue; }      // the haystack is already flagged: on to the next one
+        const uint32_t lim = he_r < ce_r ? he_r : ce_r;
+        if ((pos & 15u) == 0 && pos + 16u <= lim && !rare_next) {
+            const bool mine = pos >= cs_r;                  // (cs_r is a multiple of 16: a block lies on one side of it)
+            if (MODE == kModeAny && mine && o.flags[h]) { pos = lim; avail = 0; continue; }      // the haystack is already flagged: on to the next one
+            if (avail == 0) {                               // a whole TW-byte piece when it lies inside the haystack and the unit, one block otherwise (the ends of a unit)
+                if (NV > 1 && (pos & (uint32_t)(TW - 1)) == 0 && pos + (uint32_t)TW <= lim) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const uint32_t byte = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                const uint32_t cl = s_cls[byte];
-                const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step_lds(d, s_rows, hot_rows, state, cl);
-                state = e & kDfaStateMask;
-                if ((e >> kDfaEndShift) && mine) L.found(h, offset + (uint64_t)i, hs, state, e >> kDfaEndShift);
+                    for (int j = 0; j < NV; j++) buf[j] = *reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j);
+                    avail = NV;
+                } else {
+                    buf[0] = *reinterpret_cast<const u32x4_n*>(tp + pos);
+                    avail = 1;
+                }
             }
-            offset += 16;
+            // A byte without a column (a byte in a thousand, by the flattener's choice of the columns) ends the lane's block: the byte-by-byte path below walks it, and the
+            // fall-back walk's registers stay out of this loop.
+            uint32_t done = 16u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t cur = q == 0 ? buf[0].x : q == 1 ? buf[0].y : q == 2 ? buf[0].z : buf[0].w;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t byte = (cur >> (8 * i)) & 0xFFu;
+                    const uint32_t cl = lds_read_u8(lds_cls_addr + byte);
+                    if (done == 16u) {
+                        if (cl == kDfaRare) done = (uint32_t)(4 * q + i);
+                        else {
+                            const uint32_t e = dfa_step(d, v, lds_rows_addr, hot_rows, state, cl);
+                            state = e & kDfaStateMask;
+                            if ((e >> kDfaEndShift) && mine) L.found(h, pos + (uint32_t)(4 * q + i) - cs_r, tp_off + pos + (uint64_t)(4 * q + i) + 1u - hs, state, e >> kDfaEndShift);
+                        }
+                    }
+                }
+                asm volatile("" ::: "memory");              // (keeps the class look-ups of later words behind this word's steps: they would each hold a register)
+            }
+#pragma unroll
+            for (int j = 0; j + 1 < NV; j++) buf[j] = buf[j + 1];
+            avail--;
+            pos += done;
+            if (done != 16u) { avail = 0; rare_next = true; }
         } else {
-            const uint32_t byte = b.text[offset], cl = s_cls[byte];
-            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step_lds(d, s_rows, hot_rows, state, cl);
+            rare_next = false;
+            const uint32_t byte = tp[pos], cl = lds_read_u8(lds_cls_addr + byte);
+            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step(d, v, lds_rows_addr, hot_rows, state, cl);
             state = e & kDfaStateMask;
-            offset++;
-            if ((e >> kDfaEndShift) && offset > cs) L.found(h, offset - 1u, hs, state, e >> kDfaEndShift);
+            pos++;
+            if ((e >> kDfaEndShift) && pos > cs_r) L.found(h, pos - 1u - cs_r, tp_off + pos - hs, state, e >> kDfaEndShift);
         }
     }
     L.flush();
+#undef cs_r
+#undef ce_r
 }
+
+}  // namespace
 
 // Persistent wavefronts: a workgroup of 16 copies the byte -> class map and the first `hot_rows` rows of the table into LDS (the flattener numbers the states so
 // that these are the root, the first letters and the heaviest prefixes: a third or more of the steps on natural text never leave the CU), then its wavefronts take
-// groups of 64 units until none is left.  Token mode: a wavefront's superblock serves all the groups it takes.
-template <int MODE>
+// groups of 64 units until none is left.  Token mode: a wavefront's superblock serves the groups it takes until it is full or 16 groups old.
+template <int MODE, int TW>
 __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
 {
     extern __shared__ uint32_t s_dyn[];
-    const uint32_t hlc = d.log2_classes < kDfaHotLog2Classes ? d.log2_classes : kDfaHotLog2Classes;
-    uint32_t* s_rows = s_dyn;                                                     // hot_rows << hlc entries: the first columns of the first rows
-    uint32_t* s_wave = s_dyn + ((size_t)hot_rows << hlc);                         // 16 x 4: per wavefront (token mode) tokens in its superblock, its id, pool exhausted
-    uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_wave + 64);
-    for (uint32_t i = threadIdx.x; i < (hot_rows << hlc); i += 1024u) s_rows[i] = d.next[((uint64_t)(i >> hlc) << d.log2_classes) + (i & ((1u << hlc) - 1u))];
+    uint32_t* s_rows = s_dyn;                                                     // hot_rows << 5 entries: columns 1 .. 32 of the first rows
+    uint32_t* s_wave = s_dyn + ((size_t)hot_rows << kLdsLog2Cols);                // 16 x 8: per wavefront, token mode (DfaLane::wv)
+    uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_wave + 128);
+    const uint32_t n_cls = 1u << d.log2_classes;
+    for (uint32_t i = threadIdx.x; i < (hot_rows << kLdsLog2Cols); i += 1024u) {
+        const uint32_t c = (i & ((1u << kLdsLog2Cols) - 1u)) + 1u;
+        s_rows[i] = c < n_cls ? d.next[((uint64_t)(i >> kLdsLog2Cols) << d.log2_classes) + c] : 0u;
+    }
     if (threadIdx.x < 256u) s_cls[threadIdx.x] = d.cls[threadIdx.x];
-    const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x % kWave;
-    if (lane == 0) { s_wave[4u * w] = 0u; s_wave[4u * w + 1u] = kNone; s_wave[4u * w + 2u] = 0u; }
+    // (the wavefront's number goes through readfirstlane: everything derived from it -- the group, the text base, the wavefront's LDS words -- is then uniform for
+    // the compiler as well and lives in scalar registers)
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)), lane = threadIdx.x % kWave;
+    uint32_t* wv = &s_wave[8u * w];
+    if (lane < 8u) wv[lane] = lane == 1u ? kNone : 0u;
     __syncthreads();
+    DfaDev v;
+    v.base = reinterpret_cast<const uint8_t*>(d.next);
+    v.off_hot = (uint32_t)(reinterpret_cast<const uint8_t*>(d.hot) - v.base);
+    v.off_chain = (uint32_t)(reinterpret_cast<const uint8_t*>(d.chain) - v.base);
+    const uint32_t lds_rows_addr = (uint32_t)(uintptr_t)s_rows, lds_cls_addr = (uint32_t)(uintptr_t)s_cls;       // (the kernel has no static LDS: the dynamic block starts at 0)
     const uint64_t n_groups = (n_units + kWave - 1) / kWave, n_waves = (uint64_t)gridDim.x * 16u;
-    uint64_t nval = 0;
-    for (uint64_t g = (uint64_t)blockIdx.x * 16u + w; g < n_groups; g += n_waves) {
+    const uint32_t W = (d.warm + 15u) & ~15u;
+    uint32_t k = 0;                                                               // this wavefront's k-th group
+    for (uint64_t g = (uint64_t)blockIdx.x * 16u + w; g < n_groups; g += n_waves, k++) {
         const uint64_t u = g * kWave + lane;
+        uint32_t group_values = 0;
+        if (MODE == kModeTokens) {
+            // a superblock older than 16 groups is sealed (a token names its group by a 4-bit ordinal); the next block's reserve draws a new one
+            if (lane == 0) {
+                if (wv[1] != kNone && k - wv[3] >= kTokMaxOrd) { o.block_next[wv[1]] = wv[0]; wv[1] = kNone; wv[0] = 0u; }
+                wv[4] = (uint32_t)g; wv[5] = k;
+            }
+            wave_lds_fence();
+        }
         if (u < n_units) {
-            DfaLane<MODE> L{d, b, o, nullptr, &s_wave[4u * w], u};
+            const uint64_t tp_off = g * kWave * d.chunk - W;                      // (wraps below zero for g = 0: an offset, never an address that is read)
+            const uint8_t* tp = b.text + tp_off;
+            const uint32_t end_r = b.total - tp_off < 0xFFFFFFFFull ? (uint32_t)(b.total - tp_off) : 0xFFFFFFFFu;      // the end of the batch, as an offset like the others
+            DfaLane<MODE> L{d, b, o, wv};
             if (MODE == kModeEmit) L.out = o.records + o.unit_offsets[u];
-            dfa_walk_unit<MODE>(L, s_cls, s_rows, hot_rows, u);
+            dfa_walk_unit<MODE, TW>(L, v, tp, tp_off, lds_cls_addr, lds_rows_addr, hot_rows, W, end_r);
             if (MODE == kModeCount || MODE == kModeTokens) o.unit_counts[u] = L.nrec;
-            nval += L.nval;
+            group_values = L.nval;
+        }
+        if (MODE == kModeCount) {                           // the group's values: one atomic per wavefront and group (at most 14 x 64 x chunk: 32 bits hold it)
+            const uint32_t sum = wave_inclusive_sum(group_values, lane);
+            if (lane == kWave - 1u && sum) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)sum);
         }
         if (MODE == kModeTokens) wave_lds_fence();          // (the token slots of this group are taken before the next group's first reserve looks at the fill)
     }
-    if (MODE == kModeTokens && lane == 0 && s_wave[4u * w + 1u] != kNone) o.block_next[s_wave[4u * w + 1u]] = s_wave[4u * w];      // the last superblock's fill
-    if (MODE == kModeCount) {
-        nval = wave_sum_u64(nval);
-        if (lane == 0 && nval) atomicAdd(reinterpret_cast<unsigned long long*>(o.total_values), (unsigned long long)nval);
-    }
+    if (MODE == kModeTokens && lane == 0 && wv[1] != kNone) o.block_next[wv[1]] = wv[0];      // the last superblock's fill
 }
 
 // How dense are needle ends in this batch?  n_samples lanes, spread evenly over the text, each walk `len` bytes from the root (no warm-up, haystack boundaries
@@ -216,94 +317,112 @@ hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t tot
     return hipGetLastError();
 }
 
-// token (unit, seq) -> the record it stands for, at unit_offsets[unit] + seq.  One workgroup per superblock.  A superblock's tokens come from ONE wavefront, in the
-// order it made them (step by step over the 64 units of a group, then the next group it took): written out token by token that is a 16-byte write scattered over 64
-// stretches of the result, and the kernel is bound by the address units like everything else here.  So the workgroup first sorts the superblock in LDS by (unit, seq) --
-// a counting sort: a unit's tokens in one superblock have consecutive seq, so slot = bucket start + seq - the bucket's smallest seq -- and then neighbouring lanes write
-// neighbouring records.  Buckets: 64 units x the first 4 groups the superblock holds tokens of; tokens of later groups (text with few matches: a superblock spans
-// hundreds of groups) are placed directly.
-constexpr uint32_t kPlaceBuckets = 256;
-__device__ __forceinline__ void dfa_place_one(const Record& t, const uint64_t* __restrict__ unit_offsets, const uint64_t* __restrict__ hay_offsets,
-                                              const u32x2* __restrict__ dfa_out, uint32_t chunk, Record* __restrict__ out)
-{
-    const uint64_t u = t.end_pos >> 32, seq = (t.end_pos >> 16) & 0xFFFFu, pos = t.end_pos & 0xFFFFu;
-    out[unit_offsets[u] + seq] = Record{u * chunk + pos + 1u - hay_offsets[t.haystack], t.haystack, dfa_out[t.state].x - 1u};
-}
-__global__ __launch_bounds__(1024) void k_dfa_place(const Record* __restrict__ pool, const uint32_t* __restrict__ fill, uint32_t n_super, const uint64_t* __restrict__ unit_offsets,
-                                                    const uint64_t* __restrict__ hay_offsets, const u32x2* __restrict__ dfa_out, uint32_t chunk, uint32_t n_waves,
+// token -> the record it stands for, at unit_offsets[unit] + seq.  One workgroup per superblock.  A superblock's tokens come from ONE wavefront, in the order it
+// made them (step by step over the 64 units of a group, then the next group it took): written out token by token that is a 16-byte write scattered over 64 stretches
+// of the result, one L2 request each.  So the workgroup first sorts the superblock in LDS by (group ordinal, lane, seq) -- a counting sort: a unit's tokens in one
+// superblock have consecutive seq, so slot = bucket start + seq - the bucket's smallest seq -- and then neighbouring lanes write neighbouring records.  The haystack of a
+// token is looked up from its position (the per-KiB haystack index of the batch; neighbouring records ask for neighbouring entries), the reference state from the DFA state.
+constexpr uint32_t kPlaceBuckets = kTokMaxOrd * kWave;
+__global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ pool, const uint32_t* __restrict__ fill, const uint32_t* __restrict__ first_group, uint32_t n_super,
+                                                    const uint64_t* __restrict__ unit_offsets, BatchView b, const u32x2* __restrict__ dfa_out, uint32_t chunk, uint32_t n_waves,
                                                     Record* __restrict__ out)
 {
-    __shared__ Record s_tok[kDfaSuper];
-    __shared__ uint32_t s_cnt[kPlaceBuckets], s_min[kPlaceBuckets], s_base[kPlaceBuckets + 1];
+    __shared__ u32x2_v s_tok[kDfaSuper];
+    __shared__ uint32_t s_cnt[kPlaceBuckets], s_min[kPlaceBuckets], s_base[kPlaceBuckets];
+    static_assert(kPlaceBuckets == 1024, "one bucket per thread of the workgroup");
     const uint32_t sb = blockIdx.x;
     if (sb >= n_super) return;
     const uint32_t n = fill[sb];
     if (n == 0) return;
-    const Record* tok = pool + (uint64_t)sb * kDfaSuper;
-    if (threadIdx.x < kPlaceBuckets) { s_cnt[threadIdx.x] = 0u; s_min[threadIdx.x] = 0xFFFFFFFFu; }
+    const u32x2_v* tok = pool + (uint64_t)sb * kDfaSuper;
+    s_cnt[threadIdx.x] = 0u; s_min[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
-    const uint64_t g_first = tok[0].end_pos >> 38;              // the first group's number (unit >> 6); the wavefront's later groups follow at a stride of n_waves
-    Record t[kDfaSuper / 1024];
-    uint32_t bucket[kDfaSuper / 1024];
+    u32x2_v t[kDfaSuper / 1024];
 #pragma unroll
     for (uint32_t k = 0; k < kDfaSuper / 1024; k++) {
         const uint32_t i = threadIdx.x + k * 1024u;
-        bucket[k] = kNone;
         if (i < n) {
-            t[k] = tok[i];
-            const uint64_t ord = ((t[k].end_pos >> 38) - g_first) / n_waves;
-            if (ord < kPlaceBuckets / 64u) {
-                bucket[k] = (uint32_t)ord * 64u + (uint32_t)((t[k].end_pos >> 32) & 63u);
-                atomicAdd(&s_cnt[bucket[k]], 1u);
-                atomicMin(&s_min[bucket[k]], (uint32_t)((t[k].end_pos >> 16) & 0xFFFFu));
-            } else dfa_place_one(t[k], unit_offsets, hay_offsets, dfa_out, chunk, out);
+            t[k] = __builtin_nontemporal_load(tok + i);
+            const uint32_t bucket = ((t[k].x >> kTokOrdShift) << 6) | (t[k].y >> 26);
+            atomicAdd(&s_cnt[bucket], 1u);
+            atomicMin(&s_min[bucket], (t[k].y >> kTokPosBits) & (kTokMaxChunk - 1u));
         }
     }
     __syncthreads();
-    if (threadIdx.x < kWave) {                                   // exclusive sums of 256 counts by one wavefront: 4 per lane
-        uint32_t c[4], sum = 0;
+    if (threadIdx.x < kWave) {                                   // exclusive sums of 1024 counts by one wavefront: 16 per lane
+        uint32_t c[16], sum = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { c[j] = s_cnt[threadIdx.x * 4u + j]; sum += c[j]; }
-        uint32_t incl = sum;
+        for (int j = 0; j < 16; j++) { c[j] = s_cnt[threadIdx.x * 16u + j]; sum += c[j]; }
+        uint32_t run = wave_inclusive_sum(sum, threadIdx.x) - sum;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if ((int)threadIdx.x >= off) incl += v; }
-        uint32_t run = incl - sum;
-#pragma unroll
-        for (int j = 0; j < 4; j++) { s_base[threadIdx.x * 4u + j] = run; run += c[j]; }
-        if (threadIdx.x == 63u) s_base[kPlaceBuckets] = run;
+        for (int j = 0; j < 16; j++) { s_base[threadIdx.x * 16u + j] = run; run += c[j]; }
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t k = 0; k < kDfaSuper / 1024; k++)
-        if (bucket[k] != kNone) s_tok[s_base[bucket[k]] + (uint32_t)((t[k].end_pos >> 16) & 0xFFFFu) - s_min[bucket[k]]] = t[k];
+    for (uint32_t k = 0; k < kDfaSuper / 1024; k++) {
+        const uint32_t i = threadIdx.x + k * 1024u;
+        if (i < n) {
+            const uint32_t bucket = ((t[k].x >> kTokOrdShift) << 6) | (t[k].y >> 26);
+            s_tok[s_base[bucket] + ((t[k].y >> kTokPosBits) & (kTokMaxChunk - 1u)) - s_min[bucket]] = t[k];
+        }
+    }
     __syncthreads();
-    const uint32_t n_sorted = s_base[kPlaceBuckets];
-    for (uint32_t i = threadIdx.x; i < n_sorted; i += 1024u) dfa_place_one(s_tok[i], unit_offsets, hay_offsets, dfa_out, chunk, out);
+    const uint64_t g_first = first_group[sb];
+    for (uint32_t i = threadIdx.x; i < n; i += 1024u) {
+        const u32x2_v q = s_tok[i];
+        const uint64_t u = (g_first + (uint64_t)(q.x >> kTokOrdShift) * n_waves) * kWave + (q.y >> 26);
+        const uint64_t g = u * chunk + (q.y & (kTokMaxChunk - 1u));
+        const uint32_t h = find_haystack(b, g);
+        u32x4_n r;
+        const uint64_t end_pos = g + 1u - b.offsets[h];
+        r.x = (uint32_t)end_pos; r.y = (uint32_t)(end_pos >> 32); r.z = h; r.w = dfa_out[q.x & kDfaStateMask].x - 1u;
+        __builtin_nontemporal_store(r, reinterpret_cast<u32x4_n*>(out + unit_offsets[u] + ((q.y >> kTokPosBits) & (kTokMaxChunk - 1u))));
+    }
 }
 
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
 
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
-static uint32_t dfa_hot_log2_classes(const DfaView& d) { return std::min<uint32_t>(d.log2_classes, kDfaHotLog2Classes); }
-static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (dfa_hot_log2_classes(d) + 2u)); }
+static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (kLdsLog2Cols + 2u)); }
+// AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = bytes of text a lane asks for at a time (1: 16, 2: 64; 0: the default),
+// bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits)
+static uint32_t dfa_tune() { const long v = cfg::get(cfg::kDfaTune); return v > 0 ? (uint32_t)v : 0u; }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 {
     const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;
-    return (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2u, (n_groups + 15) / 16);
+    const uint32_t per_cu = (dfa_tune() >> 4) & 15u ? (dfa_tune() >> 4) & 15u : 2u;
+    return (uint32_t)std::min<uint64_t>((uint64_t)n_cu * per_cu, (n_groups + 15) / 16);
+}
+template <int MODE, int TW>
+static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
+{
+    const uint64_t n_units = dfa_units(d, b);
+    if (n_units == 0) return hipSuccess;
+    // (the walk addresses hot table and chain records as 32-bit offsets from the rows, and a group's text as 32-bit offsets from its start)
+    const uint8_t *p_next = reinterpret_cast<const uint8_t*>(d.next), *p_hot = reinterpret_cast<const uint8_t*>(d.hot), *p_chain = reinterpret_cast<const uint8_t*>(d.chain);
+    if (p_hot < p_next || p_chain < p_next || (uint64_t)(p_chain - p_next) + (uint64_t)(d.n_states - d.n_rows) * 8u >= (1ull << 32) ||
+        (uint64_t)(p_hot - p_next) + ((uint64_t)d.n_rows << (d.hot_log2 + 2u)) >= (1ull << 32) || (uint64_t)d.chunk * kWave + d.warm + 16u >= (1ull << 31)) return hipErrorInvalidValue;
+    uint32_t hot = dfa_hot_rows(d);
+    if ((dfa_tune() >> 8) & 0xFFFFu) hot = std::min<uint32_t>(hot, ((dfa_tune() >> 8) & 0xFFFFu) - 1u);
+    const size_t lds = ((size_t)dfa_hot_rows(d) << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
+    static std::atomic<bool> raised[64];                     // (more than 64 KiB of dynamic LDS needs the attribute, once per instantiation and device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (!raised[dev].load(std::memory_order_acquire)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        if (e != hipSuccess) return e;
+        raised[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((k_dfa<MODE, TW>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
+    return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_dfa_t(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
-    const uint64_t n_units = dfa_units(d, b);
-    if (n_units == 0) return hipSuccess;
-    const uint32_t hot = dfa_hot_rows(d);
-    const size_t lds = ((size_t)hot << (dfa_hot_log2_classes(d) + 2u)) + 64 * 4 + 256;
-    static bool raised[64] = {false};                        // (more than 64 KiB of dynamic LDS needs the attribute, once per instantiation and device)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!raised[dev]) { const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); if (e != hipSuccess) return e; raised[dev] = true; }
-    hipLaunchKernelGGL((k_dfa<MODE>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
-    return hipGetLastError();
+    switch (dfa_tune() & 15u) {
+    case 1: return launch_dfa_tw<MODE, 16>(d, b, o, n_cu, st);
+    default: return launch_dfa_tw<MODE, 64>(d, b, o, n_cu, st);
+    }
 }
 hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
@@ -313,17 +432,20 @@ hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const Scan
     return hipErrorInvalidValue;
 }
 
-// records in one walk: is the unit small enough for a token's 16-bit fields, and how many wavefronts walk (= superblocks that may end up partly filled)
-bool dfa_tokens_ok(const DfaView& d) { return d.chunk != 0 && d.chunk <= 65536u; }
+// records in one walk: is the unit small enough for a token's 13-bit fields, and how many wavefronts walk (= superblocks that may end up partly filled)
+bool dfa_tokens_ok(const DfaView& d) { return d.chunk != 0 && d.chunk <= kTokMaxChunk; }
 uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu) { return dfa_workgroups(d, b, n_cu) * 16u; }
-// superblocks that hold `records` tokens whatever the split between the wavefronts: a sealed superblock holds at least kDfaSuper - kDfaSuperReserve
-uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves) { return records / (kDfaSuper - kDfaSuperReserve) + n_waves + 16; }
-uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(Record); }
+// superblocks that hold `records` tokens whatever the split between the wavefronts: a sealed superblock holds at least kDfaSuper - kDfaSuperReserve tokens unless it was
+// sealed for its age -- after 16 groups of its wavefront, so at most one such per 16 groups
+uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves, uint64_t n_units) { return records / (kDfaSuper - kDfaSuperReserve) + n_waves + 16 + n_units / (kWave * kTokMaxOrd); }
+uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(u32x2_v); }
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st) { return launch_dfa_t<kModeTokens>(d, b, o, n_cu, st); }
+// o.block_next = [n_blocks fill counts | n_blocks first groups]
 hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, Record* out, hipStream_t st)
 {
     if (n_super == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, o.pool, o.block_next, n_super, unit_offsets, b.offsets, d.out, d.chunk, dfa_token_waves(d, b, n_cu), out);
+    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.chunk,
+                       dfa_token_waves(d, b, n_cu), out);
     return hipGetLastError();
 }
 

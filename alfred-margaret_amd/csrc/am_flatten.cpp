@@ -844,7 +844,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 // breadth-first numbering; a node's fallback is set when it is first reached: delta(fallback(parent), byte), the root's children fall back to the root
                 std::vector<uint32_t> id(n_nodes, kNone), order; order.reserve(n_nodes);
                 std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a breadth-first number
-                std::vector<uint32_t> tree_parent(n_nodes, 0);                   // the state that discovered it
+                std::vector<uint32_t> tree_parent(n_nodes, 0);                   // the state that discovered it ...
+                std::vector<uint8_t> tree_byte(n_nodes, 0);                      // ... and the byte of that edge
                 std::vector<uint32_t> n_goto(n_nodes, 0), child_of(n_nodes, 0);  // edges of a state; the child of its last common-byte edge ...
                 std::vector<uint8_t> child_cls(n_nodes, 0), has_rare(n_nodes, 0); // ... and that edge's class; does it have an edge on a rare byte
                 std::vector<uint32_t> next((size_t)n_nodes << lc, 0);            // every state's dense row for now (what the rows of the image are cut from)
@@ -868,7 +869,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                         if (id[y] == kNone) {
                             id[y] = (uint32_t)order.size(); order.push_back(y);
                             fb[id[y]] = xi == 0 ? 0u : cb == kDfaRare ? delta_rare(fb[xi], byte) : next[((size_t)fb[xi] << lc) + cb];
-                            tree_parent[id[y]] = xi;
+                            tree_parent[id[y]] = xi; tree_byte[id[y]] = (uint8_t)byte;
                         }
                         n_goto[xi]++;
                         if (cb == kDfaRare) { rare_goto[((uint64_t)xi << 8) | byte] = id[y]; has_rare[xi] = 1; }
@@ -894,23 +895,53 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                         for (uint32_t i = 1; i < n_reached; i++) if (promoted[i]) is_row[i] = 1;
                     }
                     if (cfg::get(cfg::kDfaNoChains) > 0) std::fill(is_row.begin(), is_row.end(), 1);      // A/B: dense rows for every state (round 5's first layout)
-                    // numbers: the root, the 4 095 row states with the most needle ends below them (k_dfa keeps the first rows in LDS), the other row states in
-                    // breadth-first order; then the chain states, path by path
+                    // numbers: the root, then the row states by weight (k_dfa keeps the first rows in LDS; breadth-first order among equals); then the chain states, path by path
+                    // How often will text visit a state?  The dictionary is the one sample of its language the flattener has: the needles, one after the other with a
+                    // blank between them, are walked through the automaton and the visits counted (weight[state] = steps that START there; col_use[class] = bytes).
+                    // That sees what the number of needles below a state does not: the states "word + blank" that every dictionary word of the text leads to when
+                    // some phrase starts with it, and the states a needle's tail falls back to.  (Measured on the natural-text workload, tools/experiments/dfa_visits.py:
+                    // the first 1 024 / 16 384 rows by this weight take 44.8 / 73.8 % of the steps, by needles below 41.2 / 65.7 %, by the text's own counts 46.7 / 76.2 %.)
                     std::vector<uint32_t> weight(n_reached, 0);
-                    for (uint32_t i = 0; i < n_reached; i++) weight[i] = out[i].x ? 1u : 0u;
-                    for (uint32_t i = n_reached; i-- > 1;) weight[tree_parent[i]] += weight[i];       // (breadth-first numbers: a node's discoverer comes before it)
+                    std::vector<uint64_t> col_use(C, 0);
+                    {
+                        std::vector<uint8_t> spell;
+                        uint32_t st = 0;
+                        auto walk = [&](uint32_t byte) {
+                            const uint32_t cb = cls[byte];
+                            weight[st]++;
+                            if (cb != kDfaRare) col_use[cb]++;
+                            st = cb == kDfaRare ? delta_rare(st, byte) : next[((size_t)st << lc) + cb];
+                        };
+                        for (uint32_t i = 1; i < n_reached; i++) {
+                            if (!out[i].x || out[i].y <= out[fb[i]].y) continue;          // no needle of its own ends here (values = own ++ the fallback's, Automaton.hs:367-380)
+                            spell.clear();
+                            for (uint32_t y = i; y != 0; y = tree_parent[y]) spell.push_back(tree_byte[y]);
+                            for (size_t k = spell.size(); k-- > 0;) walk(spell[k]);
+                            walk(0x20u);
+                        }
+                    }
                     std::vector<uint32_t> rows;
                     for (uint32_t i = 1; i < n_reached; i++) if (is_row[i]) rows.push_back(i);
-                    const uint32_t top = std::min<uint32_t>(4095u, (uint32_t)rows.size());
                     auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
-                    std::vector<uint32_t> cand(rows);
-                    std::partial_sort(cand.begin(), cand.begin() + top, cand.end(), heavier);
+                    std::sort(rows.begin(), rows.end(), heavier);          // ALL of them (image version 16): neighbours in the table are about equally hot, and two rows share a line of the hot table
                     std::vector<uint32_t> renum(n_reached, kNone);
                     renum[0] = 0;
                     uint32_t nxt = 1;
-                    for (uint32_t k = 0; k < top; k++) renum[cand[k]] = nxt++;
-                    for (uint32_t i : rows) if (renum[i] == kNone) renum[i] = nxt++;
+                    for (uint32_t i : rows) renum[i] = nxt++;
                     const uint32_t n_rows = nxt;
+                    // Columns by how often the dictionary itself uses them (image version 16): a class's weight = its bytes in the walk above.
+                    // Until here the classes were numbered by the number of EDGES (what decides which bytes get a column at all); the blank of a dictionary with phrases
+                    // labels few edges and is every sixth byte of the text.  The first 2^dfa_hot_log2 columns after column 0 form the hot table (below).
+                    std::vector<uint32_t> col_new(C);
+                    {
+                        const std::vector<uint64_t>& col_weight = col_use;
+                        std::vector<uint32_t> by_w;
+                        for (uint32_t c = 1; c < C; c++) by_w.push_back(c);
+                        std::stable_sort(by_w.begin(), by_w.end(), [&](uint32_t a, uint32_t b2) { return col_weight[a] > col_weight[b2]; });
+                        col_new[0] = 0;
+                        for (uint32_t k = 0; k < by_w.size(); k++) col_new[by_w[k]] = k + 1u;
+                        for (uint32_t b = 0; b < 256; b++) if (cls[b] != kDfaRare) cls[b] = (uint8_t)col_new[cls[b]];
+                    }
                     for (uint32_t i = 1; i < n_reached; i++) {
                         if (renum[i] != kNone) continue;                                  // (a chain state not yet on a path: the head of one, breadth-first order sees heads first)
                         for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
@@ -932,11 +963,11 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                         if (is_row[i]) {
                             const uint32_t* from = next.data() + ((size_t)i << lc);
                             uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
-                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[c] = t | dfa_end_bits(out2[t]); }
+                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[col_new[c]] = t | dfa_end_bits(out2[t]); }
                         } else {
                             const uint32_t ch = n_goto[i] == 1 ? renum[child_of[i]] : 0u;
                             chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | dfa_end_bits(out2[ch])) : 0u,
-                                                             ((n_goto[i] == 1 ? (uint32_t)child_cls[i] : kDfaNoChild) << 24) | renum[fb[i]]};
+                                                             ((n_goto[i] == 1 ? col_new[child_cls[i]] : kDfaNoChild) << 24) | renum[fb[i]]};
                         }
                     }
                     // the rare edges: open addressing, (state, byte) -> child | its end bits (dfa_rare_slot in am_image.h)
@@ -955,7 +986,19 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     if (chunk < 64 || chunk > (1 << 20)) chunk = 2048;          // (512: 10 % of the steps are warm-up; measured 131 / 136 / 139 / 139 GiB/s counting at 512 / 1024 / 2048 / 4096)
                     chunk = (chunk + 15) & ~15L;
                     while ((uint64_t)chunk < 4ull * warm && chunk < (1 << 20)) chunk *= 2;          // the warm-up stays a fraction of the lane's own bytes
+                    // The HOT table (image version 16): columns 1 .. 2^hot_log2 of every row once more, dense -- hot[(row << hot_log2) + class - 1].  A row of the full table is
+                    // 256 bytes of which text touches the first half; here two rows (hot_log2 = 4) share a 128-byte line, and rows of about the same weight are neighbours,
+                    // so the L2 of an XCD holds twice the rows per MiB for the classes that are 85 % of natural text.  (Column 0 -- bytes no needle contains -- leads to the
+                    // root from everywhere and is in neither LDS nor the hot table: the walk answers it without a load.)
+                    long hot_cfg = cfg::get(cfg::kDfaHotLog2);
+                    uint32_t hot_lc = hot_cfg >= 1 && hot_cfg <= 8 ? (uint32_t)hot_cfg : 4u;
+                    while (hot_lc > 0 && (1u << hot_lc) > C - 1u) hot_lc--;
+                    std::vector<uint32_t> hot2((size_t)n_rows << hot_lc);
+                    for (uint32_t r = 0; r < n_rows; r++)
+                        for (uint32_t c = 0; c < (1u << hot_lc); c++) hot2[((size_t)r << hot_lc) + c] = next2[((size_t)r << lc) + c + 1u];
                     h.off_dfa_next = blob.put(next2);
+                    h.off_dfa_hot = blob.put(hot2);
+                    h.dfa_hot_log2 = hot_lc;
                     h.off_dfa_chain = blob.put(chain);
                     h.off_dfa_out = blob.put(out2);
                     h.off_dfa_cls = blob.put(cls);
@@ -1122,11 +1165,20 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
             const uint32_t to = next[i] & kDfaStateMask;
             if (to >= h.dfa_n_states || (next[i] & ~kDfaStateMask) != dfa_end_bits(out[to])) { err = "image: DFA transition out of range"; return false; }
         }
+        {
+            // column 0 (bytes no needle contains) leads to the root from every row (the walk answers it without looking); the hot table repeats columns 1 .. 2^hot_log2
+            const uint32_t* hot = (const uint32_t*)(img + h.off_dfa_hot);
+            for (uint32_t r = 0; r < h.dfa_n_rows; r++) {
+                if (next[(uint64_t)r << h.dfa_log2_classes] != 0u) { err = "image: DFA column 0 does not lead to the root"; return false; }
+                for (uint32_t c = 0; c < (1u << h.dfa_hot_log2); c++)
+                    if (hot[((uint64_t)r << h.dfa_hot_log2) + c] != next[((uint64_t)r << h.dfa_log2_classes) + c + 1u]) { err = "image: DFA hot table differs from the rows"; return false; }
+            }
+        }
         const u32x2* chain = (const u32x2*)(img + h.off_dfa_chain);
         for (uint32_t i = 0; i < h.dfa_n_states - h.dfa_n_rows; i++) {
             const uint32_t to = chain[i].x & kDfaStateMask, cl = chain[i].y >> 24, fbr = chain[i].y & 0xFFFFFFu;
             if (fbr >= h.dfa_n_rows || (cl >= (1u << h.dfa_log2_classes) && cl != kDfaNoChild) || to >= h.dfa_n_states || (chain[i].x & ~kDfaStateMask) != (cl != kDfaNoChild ? dfa_end_bits(out[to]) : 0u) ||
-                (cl == kDfaNoChild && chain[i].x != 0)) { err = "image: DFA chain record out of range"; return false; }
+                (cl == kDfaNoChild && chain[i].x != 0) || cl == 0u) { err = "image: DFA chain record out of range"; return false; }
         }
     }
     return true;
@@ -1153,6 +1205,8 @@ bool image_sections_in_bounds(const ImageHeader& h)
     if (h.dfa_n_states) {
         if (h.dfa_log2_classes < 3 || h.dfa_log2_classes > 8 || h.dfa_n_states >= kDfaStateMask || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
         if (h.dfa_n_rows == 0 || h.dfa_n_rows > h.dfa_n_states || h.dfa_n_rows >= (1u << 24)) return false;
+        if ((1u << h.dfa_hot_log2) > (1u << h.dfa_log2_classes) - 1u || h.dfa_hot_log2 > 8) return false;
+        good = good && ok(h.off_dfa_hot, (uint64_t)h.dfa_n_rows << h.dfa_hot_log2, 4) && (h.off_dfa_hot & 15u) == 0;
         good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_rows << h.dfa_log2_classes, 4) && ok(h.off_dfa_chain, h.dfa_n_states - h.dfa_n_rows, 8) && (h.off_dfa_chain & 7u) == 0 &&
                ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&
                (h.off_dfa_next & 15u) == 0 && (h.off_dfa_out & 7u) == 0 && ok(h.off_dfa_fail, h.dfa_n_states, 4) && h.dfa_rare_log2_cap >= 4 && h.dfa_rare_log2_cap <= 30 &&

@@ -119,8 +119,10 @@ struct Flavor {
     bool ready = false;
     void* d_image = nullptr;
     size_t bytes = 0;
+    uint64_t generation = 0;     // unique per uploaded image (an address can be reused): what a batch remembers its route by
     ImageHeader h;
 };
+uint64_t next_image_generation();
 
 }  // namespace host
 }  // namespace am
@@ -149,7 +151,8 @@ struct am_batch {
     am::host::DevBuf hidx, unit_counts, unit_offsets, scan_tmp, small, hay_counts, flags, unit_first, pool, block_next;
     am::host::DevBuf sparse, dense_counts, dense_offsets, dense_out;      // automata with the empty needle (dense pass)
     // the route a dictionary's image took on this batch the last time it was asked (am_abi.cpp make_plan: a sample walk decides once per batch and image)
-    const void* route_image = nullptr; bool route_dfa = false;
+    uint64_t route_image = 0; bool route_dfa = false;        // (the image's generation; 0: not asked)
+    uint32_t route_ends_per_kib = 0;                         // what the sample walk counted: sizes the token pool's first guess
 };
 
 struct am_matches {

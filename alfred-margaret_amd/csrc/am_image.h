@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 15;
+constexpr uint32_t kImageVersion = 16;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -86,6 +86,9 @@ struct ImageHeader {
     uint32_t dfa_n_states, dfa_log2_classes;
     uint32_t dfa_warm;          // bytes of history that determine the state: longest needle (variant) in bytes - 1
     uint32_t dfa_chunk;         // bytes of the batch one lane owns (multiple of 16)
+    // (version 16) rows are numbered by weight, columns by the dictionary's own use of them, and the first columns of every row exist a second time, dense:
+    uint64_t off_dfa_hot;       // u32[dfa_n_rows << dfa_hot_log2]: hot[(row << dfa_hot_log2) + class - 1] = next[(row << dfa_log2_classes) + class] for 1 <= class <= 2^dfa_hot_log2
+    uint32_t dfa_hot_log2, dfa_pad;
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -177,6 +180,8 @@ struct DfaView {
     const uint32_t* fail;
     const u32x4* rare;
     const u32x2* chain;
+    const uint32_t* hot;     // columns 1 .. 2^hot_log2 of every row, dense (ImageHeader::off_dfa_hot)
+    uint32_t hot_log2;
     uint32_t n_states, n_rows, log2_classes, warm, chunk, rare_log2_cap;
     uint32_t ic;             // IgnoreCase image: haystack bytes A-Z count as a-z (the class map already says so; the rare-byte walk has to be told)
 };
@@ -216,6 +221,7 @@ inline DfaView make_dfa_view(const void* base, const ImageHeader& h)
     v.next = (const uint32_t*)(b + h.off_dfa_next); v.out = (const u32x2*)(b + h.off_dfa_out); v.cls = b + h.off_dfa_cls;
     v.fail = (const uint32_t*)(b + h.off_dfa_fail); v.rare = (const u32x4*)(b + h.off_dfa_rare); v.chain = (const u32x2*)(b + h.off_dfa_chain);
     v.n_states = h.dfa_n_states; v.n_rows = h.dfa_n_rows; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk; v.rare_log2_cap = h.dfa_rare_log2_cap; v.ic = h.case_mode;
+    v.hot = (const uint32_t*)(b + h.off_dfa_hot); v.hot_log2 = h.dfa_hot_log2;
     return v;
 }
 
@@ -1087,6 +1093,8 @@ AM_HD uint32_t dfa_common_step(const DfaView& d, uint32_t state, uint32_t cl)
         if ((r.y >> 24) == cl) return r.x;
         state = r.y & 0xFFFFFFu;
     }
+    if (cl == 0u) return 0u;                                                        // a byte no needle contains: the root, nothing ends (the image check holds every row to it)
+    if (cl <= (1u << d.hot_log2)) return d.hot[((uint64_t)state << d.hot_log2) + cl - 1u];
     return d.next[((uint64_t)state << d.log2_classes) + cl];
 }
 

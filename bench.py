@@ -917,20 +917,31 @@ def parity_gate(args, w, needles, machine, handle, case, batch, text, n_hay, ran
     table = C.c_void_p()
     am.api.check(lib.am_needle_ids_create(handle, voff.ctypes.data, vals.ctypes.data, 0, C.byref(table)))
 
-    def fold(kernel, b=batch, n=n_hay, keep_records=False):
+    def fold(kernel, b=batch, n=n_hay, keep_records=False, keep_handle=False):
         am.api.check(lib.am_automaton_set_kernel(handle, kernel))
         m = C.c_void_p()
         am.api.check(lib.am_run_batch(handle, case, b, C.byref(m)))
         h, c = np.zeros(max(n, 1), np.uint64), np.zeros(max(n, 1), np.uint64)
         am.api.check(lib.am_matches_fold_hash(m, table, n, h.ctypes.data, c.ctypes.data))
         recs = am.api.matches_to_numpy(m) if keep_records else None
+        if keep_handle:
+            return h[:n], c[:n], m
         lib.am_matches_free(m)
         return h[:n], c[:n], recs
 
+    def expand(rs):
+        """records -> the (matchPos, value) sequence the reference folds: every record's value list in its order"""
+        st = rs["state"].astype(np.int64)
+        lens = (voff[st + 1] - voff[st]).astype(np.int64)
+        gpos = np.repeat(rs["end_pos"], lens)
+        gval = np.concatenate([vals[int(voff[x]):int(voff[x + 1])] for x in st]) if len(rs) else np.zeros(0, np.uint32)
+        return gpos, gval
+
     t0 = time.perf_counter()
     primary = args.kernel if args.kernel in (1, 2) else 0
+    m1 = None                                                   # rank 0 keeps the primary route's whole result: the full-list checks read single haystacks out of it IN PLACE
     try:
-        h1, c1, _ = fold(primary)
+        h1, c1, m1 = fold(primary, keep_handle=(rank == 0))
         other = 2 if primary == 1 else 1
         try:
             h2, c2, _ = fold(other)
@@ -953,60 +964,118 @@ def parity_gate(args, w, needles, machine, handle, case, batch, text, n_hay, ran
         hb = w["hay_bytes"]
         budget = args.parity_oracle_mib << 20
         threads = min(host_cores(), 256)
-
-        def sub_batch(k, size):
-            """The first k * size bytes of the batch's text as k haystacks of `size` bytes: a batch of its own over the same device memory."""
-            offs = torch.arange(k + 1, dtype=torch.int64, device=dev) * size
-            sb = C.c_void_p()
-            am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), k, k * size, C.byref(sb)))
-            return sb, offs
-
-        if hb <= budget:
-            k, size = max(1, min(n_hay, budget // hb)), hb
-            got = [(int(a), int(b)) for a, b in zip(h1[:k], c1[:k])]
-            what = "first %d haystacks" % k
-        else:
-            # ONE document larger than the budget: its first min(budget, 32 MiB), cut on a code point boundary, scanned as a haystack of its own
-            # (what runWithCase reports on a prefix is what it reports on the whole text up to there); one oracle thread
-            k, size = 1, boundary_at_or_before(lambda i: int(text[i]), min(budget, 32 << 20), hb)
-            sb, keep = sub_batch(1, size)
-            try:
-                hp, cp, _ = fold(primary, sb, 1)
-            finally:
-                am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
-                lib.am_batch_destroy(sb)
-            got = [(int(hp[0]), int(cp[0]))]
-            what = "the first %d bytes of the one haystack, as a haystack" % size
-        host = text[:k * size].cpu().numpy()
-        t1 = time.perf_counter()
-        with ThreadPoolExecutor(threads) as pool:
-            exp = list(pool.map(lambda i: o.fold_hash(case, host[i * size:(i + 1) * size]), range(k)))
-        oracle_s = time.perf_counter() - t1
-        if got != exp:
-            bad = next(i for i in range(k) if got[i] != exp[i])
-            raise SystemExit("PARITY FAILURE: device fold checksum differs from the oracle's at haystack %d" % bad)
-        # full lists on 1 % of the checked haystacks: those haystacks (at most 1 MiB of a huge one) scanned again as a batch of their own, so that
-        # only their records travel to the host
-        k1, size1 = (max(1, k // 100), size) if hb <= budget else (1, boundary_at_or_before(lambda i: int(host[i]), min(size, 1 << 20), size))
-        sb, keep = sub_batch(k1, size1)
         try:
-            _, _, recs = fold(primary, sb, k1, keep_records=True)
+            if hb <= budget:
+                # A SPREAD sample of the batch that was timed (not its first haystacks): haystack 0, the last one, the haystacks around every 2^32-byte offset of the
+                # batch (where a 32-bit truncation in the shared indexing code -- offsets, the per-KiB haystack index, the unit counter -- would first show) and evenly
+                # spaced others, budget // hay_bytes in all; every one is compared through the whole-batch result, nothing is scanned again in a smaller batch.
+                k = max(1, min(n_hay, budget // hb))
+                idx, special = spread_sample(n_hay, hb, k)
+                got = [(int(h1[i]), int(c1[i])) for i in idx]
+                host = {i: text[i * hb:(i + 1) * hb].cpu().numpy() for i in idx}
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(threads) as pool:
+                    exp = list(pool.map(lambda i: o.fold_hash(case, host[i]), idx))
+                oracle_s = time.perf_counter() - t1
+                if got != exp:
+                    bad = next(idx[j] for j in range(len(idx)) if got[j] != exp[j])
+                    raise SystemExit("PARITY FAILURE: device fold checksum differs from the oracle's at haystack %d" % bad)
+                what = "%d haystacks spread over the batch: 0, %d, %d around the 2^32-byte offsets, the rest evenly spaced" % (len(idx), n_hay - 1, max(0, len(special) - 2))
+                # full lists: the special ones (at most 12) + 1 % of the others, each read out of the whole-batch result where it lies
+                others = [i for i in idx if i not in special]
+                lists = sorted(set(special[:12]) | set(others[::100][:max(1, len(idx) // 100)]))
+                for i in lists:
+                    pos, val = o.run_list(case, host[i])
+                    gpos, gval = expand(am.api.matches_of_haystack(m1, i))
+                    if not (np.array_equal(gpos, pos) and np.array_equal(gval, val)):
+                        raise SystemExit("PARITY FAILURE: match list of haystack %d differs from the oracle's" % i)
+                out.update({"oracle_checked": len(idx), "oracle_bytes": int(len(idx) * hb), "oracle_what": what, "oracle_cores": threads, "oracle_s": round(oracle_s, 2),
+                            "oracle_max_byte_offset": int((max(idx) + 1) * hb), "full_lists_checked": len(lists), "full_lists_what": "read in place out of the whole-batch result (am_matches_haystack_range)",
+                            "matches_in_checked": int(sum(c for _, c in exp)), "kernels_s": round(kernels_s, 2)})
+            else:
+                # ONE document larger than the budget.  (a) its first min(budget, 32 MiB), cut on a code point boundary, scanned as a haystack of its own (what
+                # runWithCase reports on a prefix is what it reports on the whole text up to there): fold checksum; (b) its LAST 32 MiB, out of the whole-document
+                # result in place: the oracle walks text[tail - 64 KiB:] (a needle is far shorter than that, so every match that ends inside the tail is seen whole and
+                # no other state of the automaton matters) and its matches with end positions in the tail must be the records with end_pos > tail, one by one;
+                # (c) the full list of the first MiB.  One oracle thread each.
+                size = boundary_at_or_before(lambda i: int(text[i]), min(budget, 32 << 20), hb)
+                offs = torch.tensor([0, size], dtype=torch.int64, device=dev)
+                sb = C.c_void_p()
+                am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), 1, size, C.byref(sb)))
+                try:
+                    hp, cp, _ = fold(primary, sb, 1)
+                finally:
+                    am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
+                    lib.am_batch_destroy(sb)
+                host = text[:size].cpu().numpy()
+                t1 = time.perf_counter()
+                exp = [o.fold_hash(case, host)]
+                if [(int(hp[0]), int(cp[0]))] != exp:
+                    raise SystemExit("PARITY FAILURE: device fold checksum differs from the oracle's on the first %d bytes" % size)
+                n_rec = int(lib.am_matches_size(m1))
+
+                def record_at(j):
+                    one = np.zeros(1, am.api.MATCH_DTYPE)
+                    am.api.check(lib.am_matches_copy(m1, j, 1, one.ctypes.data))
+                    return one[0]
+
+                def first_after(pos):
+                    """index of the first record of the (one-haystack) result whose end_pos > pos"""
+                    lo, hi = 0, n_rec
+                    while lo < hi:
+                        mid = (lo + hi) // 2
+                        if int(record_at(mid)["end_pos"]) <= pos: lo = mid + 1
+                        else: hi = mid
+                    return lo
+
+                tail = boundary_at_or_before(lambda i: int(text[i]), hb - min(32 << 20, hb // 2), hb)
+                start = boundary_at_or_before(lambda i: int(text[i]), max(0, tail - (64 << 10)), hb)
+                pos, val = o.run_list(case, text[start:hb].cpu().numpy())
+                keep = pos + start > tail
+                j0 = first_after(tail)
+                rs = np.zeros(n_rec - j0, am.api.MATCH_DTYPE)
+                if len(rs):
+                    am.api.check(lib.am_matches_copy(m1, j0, len(rs), rs.ctypes.data))
+                gpos, gval = expand(rs)
+                if not (np.array_equal(gpos, pos[keep] + start) and np.array_equal(gval, val[keep])):
+                    raise SystemExit("PARITY FAILURE: the match list of the document's last %d bytes differs from the oracle's" % (hb - tail))
+                size1 = boundary_at_or_before(lambda i: int(host[i]), min(size, 1 << 20), size)
+                pos1, val1 = o.run_list(case, host[:size1])
+                j1 = first_after(size1)
+                rs1 = np.zeros(j1, am.api.MATCH_DTYPE)
+                if j1:
+                    am.api.check(lib.am_matches_copy(m1, 0, j1, rs1.ctypes.data))
+                gpos1, gval1 = expand(rs1)
+                if not (np.array_equal(gpos1, pos1) and np.array_equal(gval1, val1)):
+                    raise SystemExit("PARITY FAILURE: the match list of the document's first %d bytes differs from the oracle's" % size1)
+                oracle_s = time.perf_counter() - t1
+                out.update({"oracle_checked": 1, "oracle_bytes": int(size + (hb - start)),
+                            "oracle_what": "the one haystack: its first %d bytes as a haystack of their own (checksum) + the full lists of its first %d and its LAST %d bytes read in place out of the whole-document result" % (size, size1, hb - tail),
+                            "oracle_max_byte_offset": int(hb), "oracle_cores": 1, "oracle_s": round(oracle_s, 2), "full_lists_checked": 2,
+                            "matches_in_checked": int(exp[0][1]) + int(keep.sum()), "kernels_s": round(kernels_s, 2)})
         finally:
-            am.api.check(lib.am_automaton_set_kernel(handle, args.kernel))
-            lib.am_batch_destroy(sb)
-        first = np.searchsorted(recs["haystack"], np.arange(k1 + 1))
-        for i in range(k1):
-            pos, val = o.run_list(case, host[i * size1:(i + 1) * size1])
-            rs = recs[first[i]:first[i + 1]]
-            lens = (voff[rs["state"].astype(np.int64) + 1] - voff[rs["state"].astype(np.int64)]).astype(np.int64)
-            gpos = np.repeat(rs["end_pos"], lens)
-            gval = np.concatenate([vals[int(voff[st]):int(voff[st + 1])] for st in rs["state"]]) if len(rs) else np.zeros(0, np.uint32)
-            if not (np.array_equal(gpos, pos) and np.array_equal(gval, val)):
-                raise SystemExit("PARITY FAILURE: match list of haystack %d differs from the oracle's" % i)
-        out.update({"oracle_checked": k, "oracle_bytes": int(k * size), "oracle_what": what, "oracle_cores": threads if k > 1 else 1, "oracle_s": round(oracle_s, 2),
-                    "full_lists_checked": k1, "matches_in_checked": int(sum(c for _, c in exp)), "kernels_s": round(kernels_s, 2)})
+            if m1 is not None:
+                lib.am_matches_free(m1)
     lib.am_needle_ids_destroy(table)
     return out
+
+
+def spread_sample(n_hay, hay_bytes, k):
+    """Haystack indices for the oracle: (sorted sample, the special ones first-to-last) -- 0, n_hay - 1, the haystacks around every multiple of 2^32 bytes of the batch, and
+    evenly spaced others up to k in all (the special ones are never dropped)."""
+    import numpy as np
+    special = {0, n_hay - 1}
+    total = n_hay * hay_bytes
+    for m in range(1, (total >> 32) + 1):
+        i = (m << 32) // hay_bytes
+        for j in (i - 1, i, i + 1):
+            if 0 <= j < n_hay and j * hay_bytes < total:
+                special.add(j)
+    idx = set(special)
+    rest = k - len(idx)
+    if rest > 0:
+        idx.update(int(x) for x in np.linspace(0, n_hay - 1, rest + 2)[1:-1])
+    return sorted(idx), sorted(special)
 
 
 def boundary_at_or_before(byte_at, size, total):

@@ -163,6 +163,11 @@ AM_API int am_run_batch(const am_automaton* a, int case_mode, const am_batch* b,
 AM_API uint64_t am_matches_size(const am_matches* m);
 AM_API const am_match* am_matches_data(am_matches* m);           /* host pointer, owned by m; NULL on error */
 AM_API const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
+/* One haystack's records of a large result, without copying all of it: the records are sorted by (haystack, end_pos), so they are the contiguous run
+ * [*first_out, *first_out + *count_out) (count 0: no match in that haystack); am_matches_copy brings records [first, first + count) to caller memory.
+ * What a lazy fold over one document of a big batch consumes (Automaton.hs:522-534 folds a haystack's matches in order). */
+AM_API int am_matches_haystack_range(const am_matches* m, uint32_t haystack, uint64_t* first_out, uint64_t* count_out);
+AM_API int am_matches_copy(const am_matches* m, uint64_t first, uint64_t count, am_match* out);
 AM_API void am_matches_free(am_matches* m);
 
 /* ---- Searcher.containsAll (src/Data/Text/AhoCorasick/Searcher.hs:167-187) ------------------------

@@ -86,6 +86,26 @@ long long amchk_dfa_stats(const uint8_t* image, const uint8_t* text, uint64_t n,
     return 0;
 }
 
+// Which states does the table walk visit?  visits[state] += 1 for the state a step STARTS from (one walk over `text` from the root); what an ordering of the rows by
+// measured frequency would buy (tools/experiments/dfa_visits.py).  -3: no DFA section.
+long long amchk_dfa_visits(const uint8_t* image, const uint8_t* text, uint64_t n, uint32_t* visits)
+{
+    ImageHeader h; std::memcpy(&h, image, sizeof(h));
+    if (h.magic != kImageMagic || !h.dfa_n_states) return -3;
+    const DfaView d = make_dfa_view(image, h);
+    uint32_t state = 0;
+    for (uint64_t p = 0; p < n; p++) {
+        uint32_t byte = text[p];
+        const uint32_t cl = d.cls[byte];
+        visits[state]++;
+        uint32_t e;
+        if (cl == kDfaRare) { if (d.ic && byte - 0x41u < 26u) byte += 0x20u; e = dfa_rare_step(d, state, byte); }
+        else e = dfa_common_step(d, state, cl);
+        state = e & kDfaStateMask;
+    }
+    return 0;
+}
+
 // Interpret an image over a batch.  which: 0 = AC walk (general kernel's logic), 1 = SF (filter +
 // verify, fast kernel's logic), 2 = SF without the Bloom filter (every position verified: separates
 // filter bugs from table bugs), 3 = the DFA table walk (k_dfa's logic).  Fills up to cap records sorted by (haystack, end_pos); returns the
