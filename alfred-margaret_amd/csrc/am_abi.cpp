@@ -265,6 +265,11 @@ int am::host::prepare(const am_automaton* ca, int case_mode, const Flavor** out)
         ON_DEVICE(a->dev);
         std::vector<uint8_t> img; std::string err;
         if (case_mode == AM_CASE_SENSITIVE && !a->cs_image.empty()) img.swap(a->cs_image);
+        else if (case_mode == AM_IGNORE_CASE && a->ic_pending.valid()) {
+            am_automaton::Flat fl = a->ic_pending.get();                // made since am_automaton_create, on a thread of its own
+            if (fl.rc != 0) return fail(AM_ERR_INVALID, fl.err);
+            img.swap(fl.img);
+        }
         else {
             RefArrays ref{a->transitions.data(), a->transitions.size(), a->offsets.data(), a->offsets.size() - 1, a->root_ascii.data(), a->values_len.data()};
             if (flatten(ref, case_mode, img, err, a->lower.get()) != 0) return fail(AM_ERR_INVALID, err);
@@ -301,25 +306,31 @@ extern "C" int am_automaton_create_ex(const uint64_t* transitions, size_t n_tran
         if (LowerTable::make(lower_from, lower_to, n_lower_pairs, *lt, err) != 0) return fail(AM_ERR_INVALID, err);
         if (lt->hash != builtin_lower_table().hash) lower = lt;            // the built-in table handed back to us: nothing to keep
     }
-    // validate on the host right away (flatten checks every index); the image is uploaded on first use
-    std::vector<uint8_t> img;
-    {
-        std::string err;
-        RefArrays ref{transitions, n_transitions, offsets, n_states, root_ascii, values_len};
-        if (flatten(ref, AM_CASE_SENSITIVE, img, err, lower.get()) != 0) return fail(AM_ERR_INVALID, err);
-    }
-    am_automaton* a = new am_automaton();
+    // validate on the host right away (flatten checks every index); the images are uploaded on first use.  The handle's own copy of the arrays is what both
+    // flattens read: the IgnoreCase one runs on a thread of its own while this thread makes (and thereby validates) the CaseSensitive one.
+    std::unique_ptr<am_automaton> a(new am_automaton());
     a->lower = lower;
-    a->cs_image.swap(img);
     a->transitions.assign(transitions, transitions + n_transitions);
     a->offsets.assign(offsets, offsets + n_states + 1);
     a->root_ascii.assign(root_ascii, root_ascii + 128);
     a->values_len.assign(values_len, values_len + n_states);
+    const RefArrays ref{a->transitions.data(), n_transitions, a->offsets.data(), n_states, a->root_ascii.data(), a->values_len.data()};
+    const LowerTable* lt = lower.get();
+    if (!cfg::on(cfg::kFlattenSerial)) try {
+        a->ic_pending = std::async(std::launch::async, [ref, lt] { am_automaton::Flat f; f.rc = flatten(ref, AM_IGNORE_CASE, f.img, f.err, lt); return f; });
+    } catch (const std::system_error&) { /* no thread to be had: prepare() flattens the IgnoreCase image when it is asked for */ }
+    {
+        std::string err;
+        if (flatten(ref, AM_CASE_SENSITIVE, a->cs_image, err, lt) != 0) {
+            if (a->ic_pending.valid()) a->ic_pending.wait();          // (it reads the arrays of the handle that is about to go)
+            return fail(AM_ERR_INVALID, err);
+        }
+    }
     a->has_ref = true;
     // the automaton belongs to the device that is current now (its images are uploaded there on first use); without a
     // device the handle can still be made and inspected, every run entry point then fails with AM_ERR_NO_DEVICE
     { int d = 0; if (current_device(&d) == AM_OK) a->dev = d; else g_err.clear(); }
-    *out = a;
+    *out = a.release();
     return AM_OK;
 }
 
@@ -350,6 +361,7 @@ extern "C" uint32_t am_lower_table_hash(const uint32_t* lower_from, const uint32
 extern "C" void am_automaton_destroy(am_automaton* a)
 {
     if (!a) return;
+    if (a->ic_pending.valid()) a->ic_pending.wait();                      // (the flatten thread reads the handle's arrays)
     for (Flavor& f : a->fl) if (f.d_image) (void)hipFree(f.d_image);      // hipFree finds the owning device itself
     delete a;
 }

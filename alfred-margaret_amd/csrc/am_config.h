@@ -27,6 +27,8 @@ enum Key {
     kDfaTune,             // AM_DFA_TUNE: launch parameters of k_dfa for A/B measurements (am_dfa.hip dfa_tune)
     kDfaHotLog2,          // AM_DFA_HOT_LOG2: columns of the DFA section's hot table, as a power of two (read when an image is flattened; default 4 = 16 columns, two rows per 128-byte line)
     kDfaNoChains,         // AM_DFA_NO_CHAINS: every state of the DFA section gets a dense row (A/B against the chain records; read when an image is flattened)
+    kFlattenTrace,        // AM_FLATTEN_TRACE: the flattener prints its phases with their wall time on stderr
+    kFlattenSerial,       // AM_FLATTEN_SERIAL: the flattener starts no task (tests: the images are the same byte for byte; am_automaton_create flattens IgnoreCase on first use)
     kNoIdsScan,           // AM_NO_IDS_SCAN: containsAll folds the records of a full scan (k_idset) instead of setting the id bits inside k_sf
     kRpFullScans, kRpSplice, kRpPieces, kRpParallelFold, kRpGroups, kRpNoFuse, kRpNoSpin, kRpMatMain, kRpNoRangeReuse, kRpTrace,
     kRpLoopWaves,         // AM_RP_LOOP_WAVES: wavefronts per SIMD k_rp_loop's register budget is cut for (4, 5, 6, 8)
@@ -42,7 +44,7 @@ struct Table {
 inline Table& table() { static Table t; return t; }
 inline const char* name_of(int k)
 {
-    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_TUNE", "AM_DFA_HOT_LOG2", "AM_DFA_NO_CHAINS", "AM_NO_IDS_SCAN",
+    static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_TUNE", "AM_DFA_HOT_LOG2", "AM_DFA_NO_CHAINS", "AM_FLATTEN_TRACE", "AM_FLATTEN_SERIAL", "AM_NO_IDS_SCAN",
                                               "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
                                               "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_LOOP"};
     return names[k];

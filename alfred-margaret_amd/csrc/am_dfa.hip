@@ -128,7 +128,7 @@ __device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, 
 // different lines and uses an eighth of each; the other pieces come 16, 32, ... steps (tens of microseconds) later, by when the line has long left the L2 (an XCD's L2
 // turns over every ~5 us here): eight L2 misses per line of text.  With TW = 64 a lane asks for half a line at once (four loads issued back to back, held in registers:
 // buf[0] = the next block, the blocks move down one place per 16 steps): two.
-template <int MODE, int TW>
+template <int MODE, int TW, bool NT>
 __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v, const uint8_t* tp, uint64_t tp_off, uint32_t lds_cls_addr, uint32_t lds_rows_addr,
                                               uint32_t hot_rows, uint32_t W, uint32_t end_r)
 {
@@ -181,7 +181,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
             if (avail == 0) {                               // a whole TW-byte piece when it lies inside the haystack and the unit, one block otherwise (the ends of a unit)
                 if (NV > 1 && (pos & (uint32_t)(TW - 1)) == 0 && pos + (uint32_t)TW <= lim) {
 #pragma unroll
-                    for (int j = 0; j < NV; j++) buf[j] = *reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j);
+                    for (int j = 0; j < NV; j++) buf[j] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j)) : *reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j);
                     avail = NV;
                 } else {
                     buf[0] = *reinterpret_cast<const u32x4_n*>(tp + pos);
@@ -233,7 +233,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
 // Persistent wavefronts: a workgroup of 16 copies the byte -> class map and the first `hot_rows` rows of the table into LDS (the flattener numbers the states so
 // that these are the root, the first letters and the heaviest prefixes: a third or more of the steps on natural text never leave the CU), then its wavefronts take
 // groups of 64 units until none is left.  Token mode: a wavefront's superblock serves the groups it takes until it is full or 16 groups old.
-template <int MODE, int TW>
+template <int MODE, int TW, bool NT>
 __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
 {
     extern __shared__ uint32_t s_dyn[];
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut
             const uint32_t end_r = b.total - tp_off < 0xFFFFFFFFull ? (uint32_t)(b.total - tp_off) : 0xFFFFFFFFu;      // the end of the batch, as an offset like the others
             DfaLane<MODE> L{d, b, o, wv};
             if (MODE == kModeEmit) L.out = o.records + o.unit_offsets[u];
-            dfa_walk_unit<MODE, TW>(L, v, tp, tp_off, lds_cls_addr, lds_rows_addr, hot_rows, W, end_r);
+            dfa_walk_unit<MODE, TW, NT>(L, v, tp, tp_off, lds_cls_addr, lds_rows_addr, hot_rows, W, end_r);
             if (MODE == kModeCount || MODE == kModeTokens) o.unit_counts[u] = L.nrec;
             group_values = L.nval;
         }
@@ -384,7 +384,7 @@ uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.t
 
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
 static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (kLdsLog2Cols + 2u)); }
-// AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = bytes of text a lane asks for at a time (1: 16, 2: 64; 0: the default),
+// AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = bytes of text a lane asks for at a time (1: 16, 2: 64, 3: 64 with nontemporal loads; 0: the default),
 // bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits)
 static uint32_t dfa_tune() { const long v = cfg::get(cfg::kDfaTune); return v > 0 ? (uint32_t)v : 0u; }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
@@ -393,7 +393,7 @@ static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
     const uint32_t per_cu = (dfa_tune() >> 4) & 15u ? (dfa_tune() >> 4) & 15u : 2u;
     return (uint32_t)std::min<uint64_t>((uint64_t)n_cu * per_cu, (n_groups + 15) / 16);
 }
-template <int MODE, int TW>
+template <int MODE, int TW, bool NT>
 static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const uint64_t n_units = dfa_units(d, b);
@@ -409,19 +409,20 @@ static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const Scan
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
     if (!raised[dev].load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         if (e != hipSuccess) return e;
         raised[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((k_dfa<MODE, TW>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
+    hipLaunchKernelGGL((k_dfa<MODE, TW, NT>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
     return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_dfa_t(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     switch (dfa_tune() & 15u) {
-    case 1: return launch_dfa_tw<MODE, 16>(d, b, o, n_cu, st);
-    default: return launch_dfa_tw<MODE, 64>(d, b, o, n_cu, st);
+    case 1: return launch_dfa_tw<MODE, 16, false>(d, b, o, n_cu, st);
+    case 3: return launch_dfa_tw<MODE, 64, true>(d, b, o, n_cu, st);
+    default: return launch_dfa_tw<MODE, 64, false>(d, b, o, n_cu, st);
     }
 }
 hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)

@@ -8,6 +8,9 @@
 #include "am_config.h"
 
 #include <algorithm>
+#include <chrono>
+#include <future>
+#include <system_error>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -143,8 +146,23 @@ struct TierEntry { uint32_t key, node; };
 
 }  // namespace
 
+// AM_FLATTEN_TRACE=1: the phases of a flatten with their wall time on stderr (measurements; bench.py's build split)
+struct FlattenTrace {
+    bool on; std::chrono::steady_clock::time_point t0, last;
+    FlattenTrace() : on(cfg::on(cfg::kFlattenTrace)), t0(std::chrono::steady_clock::now()), last(t0) {}
+    void mark(const char* what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flatten] %-28s %8.1f ms (at %8.1f)\n", what, std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
+
 int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, std::string& err, const LowerTable* lower_table)
 {
+    FlattenTrace tr;
+    struct JoinOnExit { std::future<void>& f; ~JoinOnExit() { if (f.valid()) f.wait(); } };      // a task reads this function's locals: no return leaves it running
     const LowerTable& lt = lower_table ? *lower_table : builtin_lower_table();
     const size_t S = ref.n_states;
     const bool ic = case_mode == 1;
@@ -223,27 +241,35 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     std::memcpy(blob.bytes.data() + h.off_root_ascii, ref.root_ascii, 128 * 8);
     h.off_canon = blob.put(canon);
     h.off_vlen = blob.put(vlen);
+    // goto hash + fallback array: what the general kernel walks instead of the reference's per-state edge lists.  Their place in the image is reserved here; the
+    // table is filled on a thread of its own while this one builds the suffix structure, and copied in before the checksum.
+    std::vector<u32x4> goto_tab; std::vector<uint32_t> goto_fail;
+    std::future<void> goto_task;
+    JoinOnExit goto_join{goto_task};
     {
-        // goto hash + fallback array: what the kernel walks instead of the reference's per-state edge lists
         const uint64_t n_edges = S - 1;                       // one goto edge per non-root state (checked above: the edges form a trie)
         uint32_t lc = 4;
         while ((1ull << lc) < 2 * n_edges + 8) lc++;
         if (lc > 31) { err = "automaton too large for the goto table"; return -1; }
-        std::vector<u32x4> tab((size_t)1 << lc, u32x4{0, 0, 0, 0});
-        std::vector<uint32_t> fail(S, 0);
-        const uint32_t mask = (1u << lc) - 1u;
-        for (uint32_t st = 0; st < (uint32_t)S; st++) {
-            for (uint64_t i = ref.offsets[st];; i++) {
-                const uint64_t t = ref.transitions[i];
-                if (t & kWildcard) { fail[st] = (uint32_t)(t >> 32); break; }
-                uint32_t slot = ac_goto_slot(st, (uint32_t)(t & 0x1fffffu), lc);
-                while (tab[slot].w) slot = (slot + 1u) & mask;
-                tab[slot] = u32x4{st, (uint32_t)(t & 0x1fffffu), (uint32_t)(t >> 32), 1u};
-            }
-        }
         h.ac_goto_log2_cap = lc;
-        h.off_goto = blob.put(tab);
-        h.off_fail = blob.put(fail);
+        h.off_goto = blob.reserve_section(((size_t)1 << lc) * sizeof(u32x4));
+        h.off_fail = blob.reserve_section(S * sizeof(uint32_t));
+        auto fill = [&ref, &goto_tab, &goto_fail, S, lc] {
+            goto_tab.assign((size_t)1 << lc, u32x4{0, 0, 0, 0});
+            goto_fail.assign(S, 0);
+            const uint32_t mask = (1u << lc) - 1u;
+            for (uint32_t st = 0; st < (uint32_t)S; st++) {
+                for (uint64_t i = ref.offsets[st];; i++) {
+                    const uint64_t t = ref.transitions[i];
+                    if (t & kWildcard) { goto_fail[st] = (uint32_t)(t >> 32); break; }
+                    uint32_t slot = ac_goto_slot(st, (uint32_t)(t & 0x1fffffu), lc);
+                    while (goto_tab[slot].w) slot = (slot + 1u) & mask;
+                    goto_tab[slot] = u32x4{st, (uint32_t)(t & 0x1fffffu), (uint32_t)(t >> 32), 1u};
+                }
+            }
+        };
+        if (cfg::on(cfg::kFlattenSerial)) fill();
+        else try { goto_task = std::async(std::launch::async, fill); } catch (const std::system_error&) { fill(); }
     }
     if (ic) {
         const uint32_t n_lower = (lt.from.back() + 256u) & ~255u;                 // (never empty: the ASCII pairs are always there)
@@ -256,6 +282,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         h.off_lower = blob.reserve_section(16);
     }
 
+    tr.mark("trie + AC section");
     // ---- SF section.  The suffix filter answers "which is the deepest needle that ENDS at this position".  With the
     // empty needle among the needles the root owns values, every state's list contains them (Automaton.hs:373-376), and the
     // reference folds them wherever the automaton is not at the root after a code point (collectMatches runs after every
@@ -528,6 +555,279 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         }
     }
 
+    tr.mark("suffix trie");
+    struct DfaOut {
+        bool made = false;
+        std::vector<uint32_t> next2, hot2, fb2; std::vector<u32x2> chain, out2; std::vector<uint8_t> cls; std::vector<u32x4> rare_tab;
+        uint32_t hot_lc = 0, rare_lc = 0, n_rows = 0, n_states = 0, lc = 0, warm = 0, chunk = 0;
+    };
+    // (reads what the trie phase left -- bfs, edge_begin / edge_count, vlen, canon, the reference's arrays -- and nothing the suffix structure makes: it runs on a thread
+    // of its own next to the filter and suffix tables, started as soon as the automaton is known to be a dictionary)
+    auto make_dfa = [&](DfaOut& o) {
+        FlattenTrace dtr;
+        if (vlen[0] == 0 && S > 1) {
+            struct BEdge { uint32_t src, byte, dst; };
+            std::vector<BEdge> be; be.reserve(S + S / 8);
+            uint32_t n_nodes = (uint32_t)S;
+            std::vector<uint32_t> bdepth(S, 0);                                  // longest spelling of the state's string, in bytes
+            std::unordered_map<uint32_t, std::vector<std::string>> vcache;
+            std::vector<BEdge> local;
+            bool present[256] = {false};
+            for (uint32_t u : bfs) {
+                local.clear();
+                for (uint32_t k = 0; k < edge_count[u]; k++) {
+                    const uint64_t t = ref.transitions[edge_begin[u] + k];
+                    const uint32_t c = (uint32_t)(t & 0x1fffffu), v = (uint32_t)(t >> 32);
+                    auto it = vcache.find(c);
+                    if (it == vcache.end()) { std::vector<std::string> vs; variants_of(lt, c, ic, vs); it = vcache.emplace(c, std::move(vs)).first; }
+                    for (const std::string& var : it->second) {
+                        uint32_t cur = u;
+                        for (size_t j = 0; j + 1 < var.size(); j++) {
+                            const uint32_t b = (uint8_t)var[j];
+                            uint32_t nx = kNone;
+                            for (const BEdge& le : local) if (le.src == cur && le.byte == b) { nx = le.dst; break; }
+                            if (nx == kNone) { nx = n_nodes++; local.push_back({cur, b, nx}); be.push_back({cur, b, nx}); present[b] = true; }
+                            cur = nx;
+                        }
+                        be.push_back({cur, (uint32_t)(uint8_t)var.back(), v});
+                        present[(uint8_t)var.back()] = true;
+                        bdepth[v] = std::max(bdepth[v], bdepth[u] + (uint32_t)var.size());
+                    }
+                }
+            }
+            dtr.mark("dfa: byte edges");
+            // Classes: a row has a column for the COMMON bytes only -- the fewest (a power of two, with class 0) that label all but a thousandth of the edges.  In a
+            // dictionary 31 bytes do (the letters, the blank, the lead bytes of the accented ones); the bytes of a few Cyrillic words and of the upper-case spellings of
+            // non-ASCII letters would double the row twice for nothing.  A RARE byte (class kDfaRare) takes the textbook route instead: the state's own edge on it (a
+            // small hash of the rare edges) or the same question at the state's fallback (dfa_rare_step in am_image.h).
+            uint64_t edge_cnt[256] = {0};
+            for (const BEdge& e : be) edge_cnt[e.byte]++;
+            std::vector<uint32_t> by_cnt;
+            for (uint32_t b = 0; b < 256; b++) if (present[b]) by_cnt.push_back(b);
+            std::sort(by_cnt.begin(), by_cnt.end(), [&](uint32_t a, uint32_t b2) { return edge_cnt[a] != edge_cnt[b2] ? edge_cnt[a] > edge_cnt[b2] : a < b2; });
+            const uint64_t rare_permille = cfg::get(cfg::kDfaRarePermille) >= 0 ? (uint64_t)cfg::get(cfg::kDfaRarePermille) : 1ull;
+            uint32_t lc = 3;
+            for (;; lc++) {
+                uint64_t left_out = 0;
+                for (size_t k = (1u << lc) - 1u; k < by_cnt.size(); k++) left_out += edge_cnt[by_cnt[k]];
+                if (left_out * 1000ull <= be.size() * rare_permille || lc == 8) break;
+            }
+            uint32_t n_cls = 1;
+            std::vector<uint8_t> cls(256, 0);
+            for (size_t k = 0; k < by_cnt.size(); k++) cls[by_cnt[k]] = k + 1u < (1u << lc) ? (uint8_t)n_cls++ : (uint8_t)kDfaRare;
+            if (ic) for (uint32_t b = 'A'; b <= 'Z'; b++) cls[b] = cls[b + 0x20u];       // the kernels fold ASCII; the variants hold the folded byte only
+            const uint64_t table_bytes = ((uint64_t)n_nodes << lc) * 4ull;
+            if (n_nodes < kDfaStateMask && table_bytes <= (1ull << 30)) {
+                dtr.mark("dfa: classes");
+                // adjacency by source
+                std::vector<uint32_t> first(n_nodes + 1, 0);
+                for (const BEdge& e : be) first[e.src + 1]++;
+                for (uint32_t i = 0; i < n_nodes; i++) first[i + 1] += first[i];
+                std::vector<BEdge> adj(be.size());
+                { std::vector<uint32_t> cur(first.begin(), first.end() - 1); for (const BEdge& e : be) adj[cur[e.src]++] = e; }
+                // breadth-first numbering; a node's fallback is set when it is first reached: delta(fallback(parent), byte), the root's children fall back to the root
+                std::vector<uint32_t> id(n_nodes, kNone), order; order.reserve(n_nodes);
+                std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a breadth-first number
+                std::vector<uint32_t> tree_parent(n_nodes, 0);                   // the state that discovered it ...
+                std::vector<uint8_t> tree_byte(n_nodes, 0);                      // ... and the byte of that edge
+                std::vector<uint32_t> n_goto(n_nodes, 0), child_of(n_nodes, 0);  // edges of a state; the child of its last common-byte edge ...
+                std::vector<uint8_t> child_cls(n_nodes, 0), has_rare(n_nodes, 0); // ... and that edge's class; does it have an edge on a rare byte
+                std::vector<uint32_t> next((size_t)n_nodes << lc, 0);            // every state's dense row for now (what the rows of the image are cut from)
+                const uint32_t C = 1u << lc;
+                std::unordered_map<uint64_t, uint32_t> rare_goto;                // (state << 8 | byte) -> child, the edges on rare bytes
+                auto delta_rare = [&](uint32_t st, uint32_t byte) {              // delta(st, rare byte) by the fallback chain
+                    for (;;) {
+                        const auto it = rare_goto.find(((uint64_t)st << 8) | byte);
+                        if (it != rare_goto.end()) return it->second;
+                        if (st == 0) return 0u;
+                        st = fb[st];
+                    }
+                };
+                id[0] = 0; order.push_back(0);
+                for (size_t qi = 0; qi < order.size(); qi++) {
+                    const uint32_t x = order[qi], xi = (uint32_t)qi;
+                    uint32_t* row = next.data() + ((size_t)xi << lc);
+                    if (xi != 0) std::memcpy(row, next.data() + ((size_t)fb[xi] << lc), (size_t)C * 4);      // (the root's row starts as all-root = zeros)
+                    for (uint32_t e = first[x]; e < first[x + 1]; e++) {
+                        const uint32_t y = adj[e].dst, byte = adj[e].byte, cb = cls[byte];
+                        if (id[y] == kNone) {
+                            id[y] = (uint32_t)order.size(); order.push_back(y);
+                            fb[id[y]] = xi == 0 ? 0u : cb == kDfaRare ? delta_rare(fb[xi], byte) : next[((size_t)fb[xi] << lc) + cb];
+                            tree_parent[id[y]] = xi; tree_byte[id[y]] = (uint8_t)byte;
+                        }
+                        n_goto[xi]++;
+                        if (cb == kDfaRare) { rare_goto[((uint64_t)xi << 8) | byte] = id[y]; has_rare[xi] = 1; }
+                        else { row[cb] = id[y]; child_of[xi] = id[y]; child_cls[xi] = (uint8_t)cb; }
+                    }
+                }
+                dtr.mark("dfa: rows of all states (breadth-first)");
+                {
+                    // (nodes no byte string reaches -- an upper-case needle letter under IgnoreCase has no spelling -- get no state: the reference never reaches them either)
+                    const uint32_t n_reached = (uint32_t)order.size();
+                    std::vector<u32x2> out(n_reached, u32x2{0, 0});
+                    for (uint32_t x = 1; x < (uint32_t)S; x++) if (vlen[x] > 0 && id[x] != kNone) out[id[x]] = u32x2{canon[x] + 1u, vlen[x]};
+                    // ROW states and CHAIN states.  Deep in a dictionary nearly every state has one child, and a dense row there is 256 bytes of which a visitor reads
+                    // four -- a 64-byte line fetched for every step (27 bytes per scanned byte, measured).  Such a state keeps 8 bytes instead: {its child, the child's
+                    // class, the state it falls back to}, and anything but the child's byte asks the fallback's row: delta(x, c) = delta(fallback(x), c) where x has no edge
+                    // on c.  For that to be ONE more load the fallback must have a row, so every state some chain state falls back to is a row state; so are the root, the
+                    // branching states and the states with an edge on a rare byte.  Chain states are numbered along their paths (a word's tail shares cache lines).
+                    std::vector<uint8_t> is_row(n_reached, 0);
+                    is_row[0] = 1;
+                    for (uint32_t i = 1; i < n_reached; i++) if (n_goto[i] > 1 || has_rare[i]) is_row[i] = 1;
+                    {
+                        std::vector<uint8_t> promoted(n_reached, 0);
+                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i]) promoted[fb[i]] = 1;     // (decided on the candidates: a promoted candidate's own fallback may be promoted needlessly)
+                        for (uint32_t i = 1; i < n_reached; i++) if (promoted[i]) is_row[i] = 1;
+                    }
+                    if (cfg::get(cfg::kDfaNoChains) > 0) std::fill(is_row.begin(), is_row.end(), 1);      // A/B: dense rows for every state (round 5's first layout)
+                    // numbers: the root, then the row states by weight (k_dfa keeps the first rows in LDS; breadth-first order among equals); then the chain states, path by path
+                    // How often will text visit a state?  The dictionary is the one sample of its language the flattener has: the needles, one after the other with a
+                    // blank between them, are walked through the automaton and the visits counted (weight[state] = steps that START there; col_use[class] = bytes).
+                    // That sees what the number of needles below a state does not: the states "word + blank" that every dictionary word of the text leads to when
+                    // some phrase starts with it, and the states a needle's tail falls back to.  (Measured on the natural-text workload, tools/experiments/dfa_visits.py:
+                    // the first 1 024 / 16 384 rows by this weight take 44.8 / 73.8 % of the steps, by needles below 41.2 / 65.7 %, by the text's own counts 46.7 / 76.2 %.)
+                    std::vector<uint32_t> weight(n_reached, 0);
+                    std::vector<uint64_t> col_use(C, 0);
+                    {
+                        std::vector<uint8_t> spell;
+                        uint32_t st = 0;
+                        auto walk = [&](uint32_t byte) {
+                            const uint32_t cb = cls[byte];
+                            weight[st]++;
+                            if (cb != kDfaRare) col_use[cb]++;
+                            st = cb == kDfaRare ? delta_rare(st, byte) : next[((size_t)st << lc) + cb];
+                        };
+                        for (uint32_t i = 1; i < n_reached; i++) {
+                            if (!out[i].x || out[i].y <= out[fb[i]].y) continue;          // no needle of its own ends here (values = own ++ the fallback's, Automaton.hs:367-380)
+                            spell.clear();
+                            for (uint32_t y = i; y != 0; y = tree_parent[y]) spell.push_back(tree_byte[y]);
+                            for (size_t k = spell.size(); k-- > 0;) walk(spell[k]);
+                            walk(0x20u);
+                        }
+                    }
+                    dtr.mark("dfa: row states + weights");
+                    std::vector<uint32_t> rows;
+                    for (uint32_t i = 1; i < n_reached; i++) if (is_row[i]) rows.push_back(i);
+                    auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
+                    std::sort(rows.begin(), rows.end(), heavier);          // ALL of them (image version 16): neighbours in the table are about equally hot, and two rows share a line of the hot table
+                    std::vector<uint32_t> renum(n_reached, kNone);
+                    renum[0] = 0;
+                    uint32_t nxt = 1;
+                    for (uint32_t i : rows) renum[i] = nxt++;
+                    const uint32_t n_rows = nxt;
+                    // Columns by how often the dictionary itself uses them (image version 16): a class's weight = its bytes in the walk above.
+                    // Until here the classes were numbered by the number of EDGES (what decides which bytes get a column at all); the blank of a dictionary with phrases
+                    // labels few edges and is every sixth byte of the text.  The first 2^dfa_hot_log2 columns after column 0 form the hot table (below).
+                    std::vector<uint32_t> col_new(C);
+                    {
+                        const std::vector<uint64_t>& col_weight = col_use;
+                        std::vector<uint32_t> by_w;
+                        for (uint32_t c = 1; c < C; c++) by_w.push_back(c);
+                        std::stable_sort(by_w.begin(), by_w.end(), [&](uint32_t a, uint32_t b2) { return col_weight[a] > col_weight[b2]; });
+                        col_new[0] = 0;
+                        for (uint32_t k = 0; k < by_w.size(); k++) col_new[by_w[k]] = k + 1u;
+                        for (uint32_t b = 0; b < 256; b++) if (cls[b] != kDfaRare) cls[b] = (uint8_t)col_new[cls[b]];
+                    }
+                    // the chain paths by the weight of their heads (image version 16): the tails of the words text is made of share lines with each other, not with the
+                    // tails of words that never come (the hottest 4k lines of the chain records took 43 % of the chain steps in breadth-first order; 63 % is what an
+                    // ordering by the text's own counts would give) -- then, in breadth-first order, whatever is left
+                    {
+                        std::vector<uint32_t> heads;
+                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i] && is_row[tree_parent[i]]) heads.push_back(i);
+                        std::stable_sort(heads.begin(), heads.end(), [&](uint32_t a, uint32_t b2) { return weight[a] > weight[b2]; });
+                        for (uint32_t i : heads)
+                            for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
+                                renum[y] = nxt++;
+                                if (n_goto[y] != 1) break;
+                                y = child_of[y];
+                            }
+                    }
+                    for (uint32_t i = 1; i < n_reached; i++) {
+                        if (renum[i] != kNone) continue;                                  // (a chain state not yet on a path: the head of one, breadth-first order sees heads first)
+                        for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
+                            renum[y] = nxt++;
+                            if (n_goto[y] != 1) break;
+                            y = child_of[y];
+                        }
+                    }
+                    if (n_rows >= (1u << 24)) { /* a chain record holds its fallback row in 24 bits: no DFA section for this automaton */ }
+                    else {
+                    dtr.mark("dfa: numbering");
+                    std::vector<uint32_t> next2((size_t)n_rows << lc);
+                    std::vector<u32x2> chain(n_reached - n_rows), out2(n_reached);
+                    std::vector<uint32_t> fb2(n_reached);
+                    for (uint32_t i = 0; i < n_reached; i++) {
+                        out2[renum[i]] = out[i];
+                        fb2[renum[i]] = renum[fb[i]];
+                    }
+                    for (uint32_t i = 0; i < n_reached; i++) {
+                        if (is_row[i]) {
+                            const uint32_t* from = next.data() + ((size_t)i << lc);
+                            uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
+                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[col_new[c]] = t | dfa_end_bits(out2[t]); }
+                        } else {
+                            const uint32_t ch = n_goto[i] == 1 ? renum[child_of[i]] : 0u;
+                            chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | dfa_end_bits(out2[ch])) : 0u,
+                                                             ((n_goto[i] == 1 ? col_new[child_cls[i]] : kDfaNoChild) << 24) | renum[fb[i]]};
+                        }
+                    }
+                    dtr.mark("dfa: tables out");
+                    // the rare edges: open addressing, (state, byte) -> child | its end bits (dfa_rare_slot in am_image.h)
+                    uint32_t rare_lc = 4;
+                    while ((1ull << rare_lc) < 2ull * rare_goto.size() + 8ull) rare_lc++;
+                    std::vector<u32x4> rare_tab((size_t)1 << rare_lc, u32x4{0, 0, 0, 0});
+                    for (const auto& kv : rare_goto) {
+                        const uint32_t st = renum[(uint32_t)(kv.first >> 8)], byte = (uint32_t)(kv.first & 0xFFu), to = renum[kv.second];
+                        uint32_t slot = dfa_rare_slot(st, byte, rare_lc);
+                        while (rare_tab[slot].w) slot = (slot + 1u) & ((1u << rare_lc) - 1u);
+                        rare_tab[slot] = u32x4{st, byte, to | dfa_end_bits(out2[to]), 1u};
+                    }
+                    uint32_t warm = 1;
+                    for (uint32_t x = 0; x < (uint32_t)S; x++) warm = std::max(warm, bdepth[x]);
+                    long chunk = cfg::get(cfg::kDfaChunk);
+                    if (chunk < 64 || chunk > (1 << 20)) chunk = 2048;          // (512: 10 % of the steps are warm-up; measured 131 / 136 / 139 / 139 GiB/s counting at 512 / 1024 / 2048 / 4096)
+                    chunk = (chunk + 15) & ~15L;
+                    while ((uint64_t)chunk < 4ull * warm && chunk < (1 << 20)) chunk *= 2;          // the warm-up stays a fraction of the lane's own bytes
+                    // The HOT table (image version 16): columns 1 .. 2^hot_log2 of every row once more, dense -- hot[(row << hot_log2) + class - 1].  A row of the full table is
+                    // 256 bytes of which text touches the first half; here two rows (hot_log2 = 4) share a 128-byte line, and rows of about the same weight are neighbours,
+                    // so the L2 of an XCD holds twice the rows per MiB for the classes that are 85 % of natural text.  (Column 0 -- bytes no needle contains -- leads to the
+                    // root from everywhere and is in neither LDS nor the hot table: the walk answers it without a load.)
+                    long hot_cfg = cfg::get(cfg::kDfaHotLog2);
+                    uint32_t hot_lc = hot_cfg >= 1 && hot_cfg <= 8 ? (uint32_t)hot_cfg : 4u;
+                    while (hot_lc > 0 && (1u << hot_lc) > C - 1u) hot_lc--;
+                    std::vector<uint32_t> hot2((size_t)n_rows << hot_lc);
+                    for (uint32_t r = 0; r < n_rows; r++)
+                        for (uint32_t c = 0; c < (1u << hot_lc); c++) hot2[((size_t)r << hot_lc) + c] = next2[((size_t)r << lc) + c + 1u];
+                    o.next2.swap(next2); o.hot2.swap(hot2); o.chain.swap(chain); o.out2.swap(out2); o.cls.swap(cls); o.fb2.swap(fb2); o.rare_tab.swap(rare_tab);
+                    o.hot_lc = hot_lc; o.rare_lc = rare_lc; o.n_rows = n_rows; o.n_states = n_reached; o.lc = lc; o.warm = warm - 1u > 0 ? warm - 1u : 1u; o.chunk = (uint32_t)chunk;
+                    o.made = true;
+                    }
+                }
+            }
+        }
+    };
+    DfaOut dfa_early;
+    std::future<void> dfa_task;
+    JoinOnExit dfa_join{dfa_task};                          // (an early return must not leave the task with dangling references)
+    {
+        // will the automaton get a DFA section?  AM_DFA decides, or -- unset -- whether the suffix tables below give heavy depth-4 nodes their children (sf_t4_children > 0):
+        // the same test the tables make, made here so that the section's work starts now and not behind them
+        const long dfa_cfg = cfg::get(cfg::kDfa);
+        bool likely = dfa_cfg != cfg::kUnset ? dfa_cfg != 0 : false;
+        if (dfa_cfg == cfg::kUnset && !cfg::on(cfg::kSfNoChildren)) {
+            size_t keys = 0, potential = 0;
+            for (int t = 0; t < 4; t++) keys += tier_entries[t].size();
+            uint32_t max_lw = 15;
+            { const long v = cfg::get(cfg::kSfMaxBloomLog2Words); if (v >= 8 && v <= 15) max_lw = (uint32_t)v; }
+            if (std::max(8u, std::min(max_lw, log2_ceil((keys * 16 + 31) / 32))) < 15) {
+                for (const TierEntry& e : tier_entries[3]) { const SfNode& nd = nodes[e.node]; const uint32_t c = nd.w & 0xFFFFu; if (!nd.x && c >= 2) potential += c; }
+                likely = potential >= tier_entries[3].size() && potential > 0;
+            }
+        }
+        if (likely && !cfg::on(cfg::kFlattenSerial)) {
+            try { dfa_task = std::async(std::launch::async, [&] { make_dfa(dfa_early); }); } catch (const std::system_error&) { /* no thread: made in place below */ }
+        }
+    }
     h.sf_n_nodes = (uint32_t)nodes.size();
     h.n_edges = edges_out.size();
     h.n_edge_maps = 0; h.sf_row_first = row_first;
@@ -770,6 +1070,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     h.off_nodes = blob.put(nodes);
     h.off_edges = blob.put(edges_out);
     h.off_edge_maps = 0;
+    tr.mark("filter + suffix tables");
 
     // ---- DFA section.  A dictionary of natural-language words meets text in which a needle ends every few bytes: there the suffix filter filters nothing
     // (four positions in ten pass it) and k_sf is bound by the divergent loads and the instructions of its resolve phase (LABNOTES R5.7).  For such an automaton
@@ -780,243 +1081,37 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     //              automaton is a DAG: both spellings of a letter lead to the same state.  Its fallback is that of the reference (a property of the folded string);
     //   classes  = the bytes that occur on some edge (IgnoreCase: upper-case ASCII shares the class of its fold); every other byte leads to the root from anywhere;
     //   needle ends: only at the reference's states (a needle ends with a whole code point): vlen[s] > 0, reported as canon[s] like everywhere else.
+    // the DFA section: made by the task started below the suffix trie (or here, when it was not started), kept only if the automaton turned out to be a dictionary
     {
         const long dfa_cfg = cfg::get(cfg::kDfa);
         const bool want = dfa_cfg == cfg::kUnset ? h.sf_t4_children > 0 : dfa_cfg != 0;
-        if (want && vlen[0] == 0 && S > 1) {
-            struct BEdge { uint32_t src, byte, dst; };
-            std::vector<BEdge> be; be.reserve(S + S / 8);
-            uint32_t n_nodes = (uint32_t)S;
-            std::vector<uint32_t> bdepth(S, 0);                                  // longest spelling of the state's string, in bytes
-            std::unordered_map<uint32_t, std::vector<std::string>> vcache;
-            std::vector<BEdge> local;
-            bool present[256] = {false};
-            for (uint32_t u : bfs) {
-                local.clear();
-                for (uint32_t k = 0; k < edge_count[u]; k++) {
-                    const uint64_t t = ref.transitions[edge_begin[u] + k];
-                    const uint32_t c = (uint32_t)(t & 0x1fffffu), v = (uint32_t)(t >> 32);
-                    auto it = vcache.find(c);
-                    if (it == vcache.end()) { std::vector<std::string> vs; variants_of(lt, c, ic, vs); it = vcache.emplace(c, std::move(vs)).first; }
-                    for (const std::string& var : it->second) {
-                        uint32_t cur = u;
-                        for (size_t j = 0; j + 1 < var.size(); j++) {
-                            const uint32_t b = (uint8_t)var[j];
-                            uint32_t nx = kNone;
-                            for (const BEdge& le : local) if (le.src == cur && le.byte == b) { nx = le.dst; break; }
-                            if (nx == kNone) { nx = n_nodes++; local.push_back({cur, b, nx}); be.push_back({cur, b, nx}); present[b] = true; }
-                            cur = nx;
-                        }
-                        be.push_back({cur, (uint32_t)(uint8_t)var.back(), v});
-                        present[(uint8_t)var.back()] = true;
-                        bdepth[v] = std::max(bdepth[v], bdepth[u] + (uint32_t)var.size());
-                    }
-                }
-            }
-            // Classes: a row has a column for the COMMON bytes only -- the fewest (a power of two, with class 0) that label all but a thousandth of the edges.  In a
-            // dictionary 31 bytes do (the letters, the blank, the lead bytes of the accented ones); the bytes of a few Cyrillic words and of the upper-case spellings of
-            // non-ASCII letters would double the row twice for nothing.  A RARE byte (class kDfaRare) takes the textbook route instead: the state's own edge on it (a
-            // small hash of the rare edges) or the same question at the state's fallback (dfa_rare_step in am_image.h).
-            uint64_t edge_cnt[256] = {0};
-            for (const BEdge& e : be) edge_cnt[e.byte]++;
-            std::vector<uint32_t> by_cnt;
-            for (uint32_t b = 0; b < 256; b++) if (present[b]) by_cnt.push_back(b);
-            std::sort(by_cnt.begin(), by_cnt.end(), [&](uint32_t a, uint32_t b2) { return edge_cnt[a] != edge_cnt[b2] ? edge_cnt[a] > edge_cnt[b2] : a < b2; });
-            const uint64_t rare_permille = cfg::get(cfg::kDfaRarePermille) >= 0 ? (uint64_t)cfg::get(cfg::kDfaRarePermille) : 1ull;
-            uint32_t lc = 3;
-            for (;; lc++) {
-                uint64_t left_out = 0;
-                for (size_t k = (1u << lc) - 1u; k < by_cnt.size(); k++) left_out += edge_cnt[by_cnt[k]];
-                if (left_out * 1000ull <= be.size() * rare_permille || lc == 8) break;
-            }
-            uint32_t n_cls = 1;
-            std::vector<uint8_t> cls(256, 0);
-            for (size_t k = 0; k < by_cnt.size(); k++) cls[by_cnt[k]] = k + 1u < (1u << lc) ? (uint8_t)n_cls++ : (uint8_t)kDfaRare;
-            if (ic) for (uint32_t b = 'A'; b <= 'Z'; b++) cls[b] = cls[b + 0x20u];       // the kernels fold ASCII; the variants hold the folded byte only
-            const uint64_t table_bytes = ((uint64_t)n_nodes << lc) * 4ull;
-            if (n_nodes < kDfaStateMask && table_bytes <= (1ull << 30)) {
-                // adjacency by source
-                std::vector<uint32_t> first(n_nodes + 1, 0);
-                for (const BEdge& e : be) first[e.src + 1]++;
-                for (uint32_t i = 0; i < n_nodes; i++) first[i + 1] += first[i];
-                std::vector<BEdge> adj(be.size());
-                { std::vector<uint32_t> cur(first.begin(), first.end() - 1); for (const BEdge& e : be) adj[cur[e.src]++] = e; }
-                // breadth-first numbering; a node's fallback is set when it is first reached: delta(fallback(parent), byte), the root's children fall back to the root
-                std::vector<uint32_t> id(n_nodes, kNone), order; order.reserve(n_nodes);
-                std::vector<uint32_t> fb(n_nodes, 0);                            // fallback, as a breadth-first number
-                std::vector<uint32_t> tree_parent(n_nodes, 0);                   // the state that discovered it ...
-                std::vector<uint8_t> tree_byte(n_nodes, 0);                      // ... and the byte of that edge
-                std::vector<uint32_t> n_goto(n_nodes, 0), child_of(n_nodes, 0);  // edges of a state; the child of its last common-byte edge ...
-                std::vector<uint8_t> child_cls(n_nodes, 0), has_rare(n_nodes, 0); // ... and that edge's class; does it have an edge on a rare byte
-                std::vector<uint32_t> next((size_t)n_nodes << lc, 0);            // every state's dense row for now (what the rows of the image are cut from)
-                const uint32_t C = 1u << lc;
-                std::unordered_map<uint64_t, uint32_t> rare_goto;                // (state << 8 | byte) -> child, the edges on rare bytes
-                auto delta_rare = [&](uint32_t st, uint32_t byte) {              // delta(st, rare byte) by the fallback chain
-                    for (;;) {
-                        const auto it = rare_goto.find(((uint64_t)st << 8) | byte);
-                        if (it != rare_goto.end()) return it->second;
-                        if (st == 0) return 0u;
-                        st = fb[st];
-                    }
-                };
-                id[0] = 0; order.push_back(0);
-                for (size_t qi = 0; qi < order.size(); qi++) {
-                    const uint32_t x = order[qi], xi = (uint32_t)qi;
-                    uint32_t* row = next.data() + ((size_t)xi << lc);
-                    if (xi != 0) std::memcpy(row, next.data() + ((size_t)fb[xi] << lc), (size_t)C * 4);      // (the root's row starts as all-root = zeros)
-                    for (uint32_t e = first[x]; e < first[x + 1]; e++) {
-                        const uint32_t y = adj[e].dst, byte = adj[e].byte, cb = cls[byte];
-                        if (id[y] == kNone) {
-                            id[y] = (uint32_t)order.size(); order.push_back(y);
-                            fb[id[y]] = xi == 0 ? 0u : cb == kDfaRare ? delta_rare(fb[xi], byte) : next[((size_t)fb[xi] << lc) + cb];
-                            tree_parent[id[y]] = xi; tree_byte[id[y]] = (uint8_t)byte;
-                        }
-                        n_goto[xi]++;
-                        if (cb == kDfaRare) { rare_goto[((uint64_t)xi << 8) | byte] = id[y]; has_rare[xi] = 1; }
-                        else { row[cb] = id[y]; child_of[xi] = id[y]; child_cls[xi] = (uint8_t)cb; }
-                    }
-                }
-                {
-                    // (nodes no byte string reaches -- an upper-case needle letter under IgnoreCase has no spelling -- get no state: the reference never reaches them either)
-                    const uint32_t n_reached = (uint32_t)order.size();
-                    std::vector<u32x2> out(n_reached, u32x2{0, 0});
-                    for (uint32_t x = 1; x < (uint32_t)S; x++) if (vlen[x] > 0 && id[x] != kNone) out[id[x]] = u32x2{canon[x] + 1u, vlen[x]};
-                    // ROW states and CHAIN states.  Deep in a dictionary nearly every state has one child, and a dense row there is 256 bytes of which a visitor reads
-                    // four -- a 64-byte line fetched for every step (27 bytes per scanned byte, measured).  Such a state keeps 8 bytes instead: {its child, the child's
-                    // class, the state it falls back to}, and anything but the child's byte asks the fallback's row: delta(x, c) = delta(fallback(x), c) where x has no edge
-                    // on c.  For that to be ONE more load the fallback must have a row, so every state some chain state falls back to is a row state; so are the root, the
-                    // branching states and the states with an edge on a rare byte.  Chain states are numbered along their paths (a word's tail shares cache lines).
-                    std::vector<uint8_t> is_row(n_reached, 0);
-                    is_row[0] = 1;
-                    for (uint32_t i = 1; i < n_reached; i++) if (n_goto[i] > 1 || has_rare[i]) is_row[i] = 1;
-                    {
-                        std::vector<uint8_t> promoted(n_reached, 0);
-                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i]) promoted[fb[i]] = 1;     // (decided on the candidates: a promoted candidate's own fallback may be promoted needlessly)
-                        for (uint32_t i = 1; i < n_reached; i++) if (promoted[i]) is_row[i] = 1;
-                    }
-                    if (cfg::get(cfg::kDfaNoChains) > 0) std::fill(is_row.begin(), is_row.end(), 1);      // A/B: dense rows for every state (round 5's first layout)
-                    // numbers: the root, then the row states by weight (k_dfa keeps the first rows in LDS; breadth-first order among equals); then the chain states, path by path
-                    // How often will text visit a state?  The dictionary is the one sample of its language the flattener has: the needles, one after the other with a
-                    // blank between them, are walked through the automaton and the visits counted (weight[state] = steps that START there; col_use[class] = bytes).
-                    // That sees what the number of needles below a state does not: the states "word + blank" that every dictionary word of the text leads to when
-                    // some phrase starts with it, and the states a needle's tail falls back to.  (Measured on the natural-text workload, tools/experiments/dfa_visits.py:
-                    // the first 1 024 / 16 384 rows by this weight take 44.8 / 73.8 % of the steps, by needles below 41.2 / 65.7 %, by the text's own counts 46.7 / 76.2 %.)
-                    std::vector<uint32_t> weight(n_reached, 0);
-                    std::vector<uint64_t> col_use(C, 0);
-                    {
-                        std::vector<uint8_t> spell;
-                        uint32_t st = 0;
-                        auto walk = [&](uint32_t byte) {
-                            const uint32_t cb = cls[byte];
-                            weight[st]++;
-                            if (cb != kDfaRare) col_use[cb]++;
-                            st = cb == kDfaRare ? delta_rare(st, byte) : next[((size_t)st << lc) + cb];
-                        };
-                        for (uint32_t i = 1; i < n_reached; i++) {
-                            if (!out[i].x || out[i].y <= out[fb[i]].y) continue;          // no needle of its own ends here (values = own ++ the fallback's, Automaton.hs:367-380)
-                            spell.clear();
-                            for (uint32_t y = i; y != 0; y = tree_parent[y]) spell.push_back(tree_byte[y]);
-                            for (size_t k = spell.size(); k-- > 0;) walk(spell[k]);
-                            walk(0x20u);
-                        }
-                    }
-                    std::vector<uint32_t> rows;
-                    for (uint32_t i = 1; i < n_reached; i++) if (is_row[i]) rows.push_back(i);
-                    auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
-                    std::sort(rows.begin(), rows.end(), heavier);          // ALL of them (image version 16): neighbours in the table are about equally hot, and two rows share a line of the hot table
-                    std::vector<uint32_t> renum(n_reached, kNone);
-                    renum[0] = 0;
-                    uint32_t nxt = 1;
-                    for (uint32_t i : rows) renum[i] = nxt++;
-                    const uint32_t n_rows = nxt;
-                    // Columns by how often the dictionary itself uses them (image version 16): a class's weight = its bytes in the walk above.
-                    // Until here the classes were numbered by the number of EDGES (what decides which bytes get a column at all); the blank of a dictionary with phrases
-                    // labels few edges and is every sixth byte of the text.  The first 2^dfa_hot_log2 columns after column 0 form the hot table (below).
-                    std::vector<uint32_t> col_new(C);
-                    {
-                        const std::vector<uint64_t>& col_weight = col_use;
-                        std::vector<uint32_t> by_w;
-                        for (uint32_t c = 1; c < C; c++) by_w.push_back(c);
-                        std::stable_sort(by_w.begin(), by_w.end(), [&](uint32_t a, uint32_t b2) { return col_weight[a] > col_weight[b2]; });
-                        col_new[0] = 0;
-                        for (uint32_t k = 0; k < by_w.size(); k++) col_new[by_w[k]] = k + 1u;
-                        for (uint32_t b = 0; b < 256; b++) if (cls[b] != kDfaRare) cls[b] = (uint8_t)col_new[cls[b]];
-                    }
-                    for (uint32_t i = 1; i < n_reached; i++) {
-                        if (renum[i] != kNone) continue;                                  // (a chain state not yet on a path: the head of one, breadth-first order sees heads first)
-                        for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
-                            renum[y] = nxt++;
-                            if (n_goto[y] != 1) break;
-                            y = child_of[y];
-                        }
-                    }
-                    if (n_rows >= (1u << 24)) { /* a chain record holds its fallback row in 24 bits: no DFA section for this automaton */ }
-                    else {
-                    std::vector<uint32_t> next2((size_t)n_rows << lc);
-                    std::vector<u32x2> chain(n_reached - n_rows), out2(n_reached);
-                    std::vector<uint32_t> fb2(n_reached);
-                    for (uint32_t i = 0; i < n_reached; i++) {
-                        out2[renum[i]] = out[i];
-                        fb2[renum[i]] = renum[fb[i]];
-                    }
-                    for (uint32_t i = 0; i < n_reached; i++) {
-                        if (is_row[i]) {
-                            const uint32_t* from = next.data() + ((size_t)i << lc);
-                            uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
-                            for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[col_new[c]] = t | dfa_end_bits(out2[t]); }
-                        } else {
-                            const uint32_t ch = n_goto[i] == 1 ? renum[child_of[i]] : 0u;
-                            chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | dfa_end_bits(out2[ch])) : 0u,
-                                                             ((n_goto[i] == 1 ? col_new[child_cls[i]] : kDfaNoChild) << 24) | renum[fb[i]]};
-                        }
-                    }
-                    // the rare edges: open addressing, (state, byte) -> child | its end bits (dfa_rare_slot in am_image.h)
-                    uint32_t rare_lc = 4;
-                    while ((1ull << rare_lc) < 2ull * rare_goto.size() + 8ull) rare_lc++;
-                    std::vector<u32x4> rare_tab((size_t)1 << rare_lc, u32x4{0, 0, 0, 0});
-                    for (const auto& kv : rare_goto) {
-                        const uint32_t st = renum[(uint32_t)(kv.first >> 8)], byte = (uint32_t)(kv.first & 0xFFu), to = renum[kv.second];
-                        uint32_t slot = dfa_rare_slot(st, byte, rare_lc);
-                        while (rare_tab[slot].w) slot = (slot + 1u) & ((1u << rare_lc) - 1u);
-                        rare_tab[slot] = u32x4{st, byte, to | dfa_end_bits(out2[to]), 1u};
-                    }
-                    uint32_t warm = 1;
-                    for (uint32_t x = 0; x < (uint32_t)S; x++) warm = std::max(warm, bdepth[x]);
-                    long chunk = cfg::get(cfg::kDfaChunk);
-                    if (chunk < 64 || chunk > (1 << 20)) chunk = 2048;          // (512: 10 % of the steps are warm-up; measured 131 / 136 / 139 / 139 GiB/s counting at 512 / 1024 / 2048 / 4096)
-                    chunk = (chunk + 15) & ~15L;
-                    while ((uint64_t)chunk < 4ull * warm && chunk < (1 << 20)) chunk *= 2;          // the warm-up stays a fraction of the lane's own bytes
-                    // The HOT table (image version 16): columns 1 .. 2^hot_log2 of every row once more, dense -- hot[(row << hot_log2) + class - 1].  A row of the full table is
-                    // 256 bytes of which text touches the first half; here two rows (hot_log2 = 4) share a 128-byte line, and rows of about the same weight are neighbours,
-                    // so the L2 of an XCD holds twice the rows per MiB for the classes that are 85 % of natural text.  (Column 0 -- bytes no needle contains -- leads to the
-                    // root from everywhere and is in neither LDS nor the hot table: the walk answers it without a load.)
-                    long hot_cfg = cfg::get(cfg::kDfaHotLog2);
-                    uint32_t hot_lc = hot_cfg >= 1 && hot_cfg <= 8 ? (uint32_t)hot_cfg : 4u;
-                    while (hot_lc > 0 && (1u << hot_lc) > C - 1u) hot_lc--;
-                    std::vector<uint32_t> hot2((size_t)n_rows << hot_lc);
-                    for (uint32_t r = 0; r < n_rows; r++)
-                        for (uint32_t c = 0; c < (1u << hot_lc); c++) hot2[((size_t)r << hot_lc) + c] = next2[((size_t)r << lc) + c + 1u];
-                    h.off_dfa_next = blob.put(next2);
-                    h.off_dfa_hot = blob.put(hot2);
-                    h.dfa_hot_log2 = hot_lc;
-                    h.off_dfa_chain = blob.put(chain);
-                    h.off_dfa_out = blob.put(out2);
-                    h.off_dfa_cls = blob.put(cls);
-                    h.off_dfa_fail = blob.put(fb2);
-                    h.off_dfa_rare = blob.put(rare_tab);
-                    h.dfa_rare_log2_cap = rare_lc;
-                    h.dfa_n_rows = n_rows;
-                    h.dfa_n_states = n_reached; h.dfa_log2_classes = lc; h.dfa_warm = warm - 1u > 0 ? warm - 1u : 1u; h.dfa_chunk = (uint32_t)chunk;
-                    }
-                }
-            }
+        DfaOut o;
+        if (dfa_task.valid()) { dfa_task.get(); if (want) o = std::move(dfa_early); }
+        else if (want) make_dfa(o);
+        if (o.made) {
+            h.off_dfa_next = blob.put(o.next2);
+            h.off_dfa_hot = blob.put(o.hot2);
+            h.dfa_hot_log2 = o.hot_lc;
+            h.off_dfa_chain = blob.put(o.chain);
+            h.off_dfa_out = blob.put(o.out2);
+            h.off_dfa_cls = blob.put(o.cls);
+            h.off_dfa_fail = blob.put(o.fb2);
+            h.off_dfa_rare = blob.put(o.rare_tab);
+            h.dfa_rare_log2_cap = o.rare_lc;
+            h.dfa_n_rows = o.n_rows;
+            h.dfa_n_states = o.n_states; h.dfa_log2_classes = o.lc; h.dfa_warm = o.warm; h.dfa_chunk = o.chunk;
         }
     }
+    tr.mark("DFA section");
+    if (goto_task.valid()) goto_task.get();
+    std::memcpy(blob.bytes.data() + h.off_goto, goto_tab.data(), goto_tab.size() * sizeof(u32x4));
+    std::memcpy(blob.bytes.data() + h.off_fail, goto_fail.data(), goto_fail.size() * sizeof(uint32_t));
     blob.reserve_section(16);      // tail padding
     h.total_bytes = blob.bytes.size();
     h.checksum = image_checksum(blob.bytes.data() + sizeof(h), blob.bytes.size() - sizeof(h));
     std::memcpy(blob.bytes.data(), &h, sizeof(h));
     image.swap(blob.bytes);
+    tr.mark("checksum");
     return 0;
 }
 

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -134,6 +135,10 @@ struct am_automaton {
     bool has_ref = false;        // false for handles attached to a received image
     std::shared_ptr<const am::LowerTable> lower;   // the caller's lower-case table (am_automaton_create_ex); null: the built-in one
     std::vector<uint8_t> cs_image;   // CaseSensitive image flattened (= validated) at creation, uploaded on first use
+    // the IgnoreCase image is flattened on a thread of its own WHILE am_automaton_create flattens (= validates) the CaseSensitive one: whichever mode the first scan
+    // asks for, its image is there or nearly there (the reference's protocol times build + run together, benchmark/haskell/app/Main.hs:62-64,73)
+    struct Flat { int rc = 0; std::string err; std::vector<uint8_t> img; };
+    std::future<Flat> ic_pending;
     int kernel_pref = 0;
     std::mutex mu;
     am::host::Flavor fl[2];

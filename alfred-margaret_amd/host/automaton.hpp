@@ -54,50 +54,86 @@ struct Packed {
     std::vector<std::vector<uint32_t>> valueIdx;   // per state: needle indices in report order
 };
 
+// (state << 21 | code point) -> next state: open addressing over two flat arrays (the IntMap-of-IntMaps of the reference, :249-292, is what `build` spends its time in;
+// a node-based map made a 100k-needle build 0.65 s where this takes a third)
+struct EdgeMap {
+    std::vector<uint64_t> keys; std::vector<uint32_t> vals; size_t n = 0, mask = 0;
+    static constexpr uint64_t kEmpty = ~0ull;
+    explicit EdgeMap(size_t expect) { size_t cap = 1024; while (cap < 2 * expect) cap <<= 1; keys.assign(cap, kEmpty); vals.assign(cap, 0); mask = cap - 1; }
+    static size_t slot(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return (size_t)(k ^ (k >> 29)); }
+    // the value of k, or -1
+    int64_t find(uint64_t k) const
+    {
+        for (size_t i = slot(k) & mask;; i = (i + 1) & mask) { if (keys[i] == k) return vals[i]; if (keys[i] == kEmpty) return -1; }
+    }
+    void insert(uint64_t k, uint32_t v)          // (k is not in the map)
+    {
+        if (2 * (n + 1) > keys.size()) {
+            std::vector<uint64_t> ok; std::vector<uint32_t> ov; ok.swap(keys); ov.swap(vals);
+            keys.assign(ok.size() * 2, kEmpty); vals.assign(ok.size() * 2, 0); mask = keys.size() - 1;
+            for (size_t i = 0; i < ok.size(); i++) if (ok[i] != kEmpty) { size_t j = slot(ok[i]) & mask; while (keys[j] != kEmpty) j = (j + 1) & mask; keys[j] = ok[i]; vals[j] = ov[i]; }
+        }
+        size_t i = slot(k) & mask;
+        while (keys[i] != kEmpty) i = (i + 1) & mask;
+        keys[i] = k; vals[i] = v; n++;
+    }
+};
+
 // Automaton.hs:176-200 build and its helpers (:249-292, :336-362, :367-380, :166-172, :301-306).
 // State ids are allocated in needle order, depth first along each needle, exactly as the reference.
 inline Packed buildPacked(const std::vector<Text>& needles)
 {
-    struct StateTmp { std::vector<std::pair<uint32_t, uint32_t>> kids; };   // (code point, next), unsorted
-    std::vector<StateTmp> st(1);
-    std::unordered_map<uint64_t, uint32_t> edge;    // (state << 21 | cp) -> next
-    edge.reserve(needles.size() * 8);
-    std::vector<std::vector<uint32_t>> own(1);
+    // flat arrays throughout (a vector per state -- children, own needles -- was most of the time of a 100k-needle build):
+    // the goto edges in creation order, the needles that end at a state as a linked list, newest first (insertWith (++), :263)
+    struct Edge { uint32_t src, cp, dst; };
+    constexpr uint32_t kNoNeedle = 0xFFFFFFFFu;
+    size_t total_len = 0;
+    for (const Text& t : needles) total_len += t.len;
+    EdgeMap edge(total_len + 16);                   // (state << 21 | cp) -> next; at most one edge per needle byte
+    std::vector<Edge> edges; edges.reserve(total_len + 16);
+    std::vector<uint32_t> own_head(1, kNoNeedle), own_next(needles.size(), kNoNeedle);
+    own_head.reserve(total_len + 16);
     for (size_t i = 0; i < needles.size(); i++) {
         const uint8_t* d = needles[i].begin(); const size_t n = needles[i].len;
         uint32_t s = 0;
         for (size_t k = 0; k < n;) {
             size_t u; const uint32_t cp = utf8::decodeAt(d, k, n, u);
             const uint64_t key = ((uint64_t)s << 21) | cp;
-            auto it = edge.find(key);
-            if (it != edge.end()) s = it->second;
+            const int64_t hit = edge.find(key);
+            if (hit >= 0) s = (uint32_t)hit;
             else {
-                const uint32_t nx = (uint32_t)st.size();
-                st.emplace_back(); own.emplace_back();
-                st[s].kids.emplace_back(cp, nx);
-                edge.emplace(key, nx);
+                const uint32_t nx = (uint32_t)own_head.size();
+                own_head.push_back(kNoNeedle);
+                edges.push_back(Edge{s, cp, nx});
+                edge.insert(key, nx);
                 s = nx;
             }
             k += u;
         }
-        own[s].insert(own[s].begin(), (uint32_t)i);      // insertWith (++): newest first (:263)
+        own_next[i] = own_head[s]; own_head[s] = (uint32_t)i;      // newest first
     }
-    const size_t S = st.size();
-    for (auto& x : st) std::sort(x.kids.begin(), x.kids.end());
-    auto findKid = [&](uint32_t s, uint32_t cp) -> int64_t {
-        auto it = edge.find(((uint64_t)s << 21) | cp);
-        return it == edge.end() ? -1 : (int64_t)it->second;
-    };
+    const size_t S = own_head.size();
+    // a state's children: its run of `kids`, ascending code point
+    std::vector<uint32_t> kid_first(S + 1, 0);
+    for (const Edge& e : edges) kid_first[e.src + 1]++;
+    for (size_t s = 0; s < S; s++) kid_first[s + 1] += kid_first[s];
+    std::vector<std::pair<uint32_t, uint32_t>> kids(edges.size());           // (code point, next)
+    {
+        std::vector<uint32_t> cur(kid_first.begin(), kid_first.end() - 1);
+        for (const Edge& e : edges) kids[cur[e.src]++] = {e.cp, e.dst};
+    }
+    for (size_t s = 0; s < S; s++) if (kid_first[s + 1] - kid_first[s] > 1) std::sort(kids.begin() + kid_first[s], kids.begin() + kid_first[s + 1]);
+    auto findKid = [&](uint32_t s, uint32_t cp) -> int64_t { return edge.find(((uint64_t)s << 21) | cp); };
     // level order: fallbacks (:336-362) and values (:367-380) only look at shallower states
     std::vector<uint32_t> order; order.reserve(S); order.push_back(0);
     std::vector<uint32_t> fallback(S, 0);
     Packed p;
     p.valueIdx.resize(S);
-    p.valueIdx[0] = own[0];
+    for (uint32_t i = own_head[0]; i != kNoNeedle; i = own_next[i]) p.valueIdx[0].push_back(i);
     for (size_t q = 0; q < order.size(); q++) {
         const uint32_t s = order[q];
-        for (auto& kid : st[s].kids) {
-            const uint32_t cp = kid.first, nx = kid.second;
+        for (uint32_t e = kid_first[s]; e < kid_first[s + 1]; e++) {
+            const uint32_t cp = kids[e].first, nx = kids[e].second;
             uint32_t fb = 0;
             for (uint32_t t = s; t != 0;) {               // getFallback (:342-352)
                 const uint32_t f = fallback[t];
@@ -106,24 +142,25 @@ inline Packed buildPacked(const std::vector<Text>& needles)
                 t = f;
             }
             fallback[nx] = fb;
-            p.valueIdx[nx] = own[nx];
-            p.valueIdx[nx].insert(p.valueIdx[nx].end(), p.valueIdx[fb].begin(), p.valueIdx[fb].end());
+            if (own_head[nx] != kNoNeedle || !p.valueIdx[fb].empty()) {          // values = own ++ the fallback's (:367-380)
+                std::vector<uint32_t>& v = p.valueIdx[nx];
+                for (uint32_t i = own_head[nx]; i != kNoNeedle; i = own_next[i]) v.push_back(i);
+                v.insert(v.end(), p.valueIdx[fb].begin(), p.valueIdx[fb].end());
+            }
             order.push_back(nx);
         }
     }
     // makeTransitions + packTransitions (:190-192, :166-172): descending code point, wildcard last
     p.offsets.resize(S + 1);
-    size_t total = 0;
-    for (size_t s = 0; s < S; s++) total += st[s].kids.size() + 1;
-    p.transitions.reserve(total);
+    p.transitions.reserve(edges.size() + S);
     for (size_t s = 0; s < S; s++) {
         p.offsets[s] = (uint32_t)p.transitions.size();
-        for (size_t k = st[s].kids.size(); k-- > 0;) p.transitions.push_back(((uint64_t)st[s].kids[k].second << 32) | st[s].kids[k].first);
+        for (uint32_t e = kid_first[s + 1]; e-- > kid_first[s];) p.transitions.push_back(((uint64_t)kids[e].second << 32) | kids[e].first);
         p.transitions.push_back(((uint64_t)fallback[s] << 32) | kWildcard);
     }
     p.offsets[S] = (uint32_t)p.transitions.size();
     p.rootAscii.assign(128, kWildcard);                    // wildcard -> state 0 (:301-306)
-    for (auto& kid : st[0].kids) if (kid.first < 128) p.rootAscii[kid.first] = ((uint64_t)kid.second << 32) | kid.first;
+    for (uint32_t e = kid_first[0]; e < kid_first[1]; e++) if (kids[e].first < 128) p.rootAscii[kids[e].first] = ((uint64_t)kids[e].second << 32) | kids[e].first;
     return p;
 }
 

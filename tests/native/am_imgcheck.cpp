@@ -5,6 +5,7 @@
 // container.  It is NOT part of libam.so and no product entry point reaches it: the product has no
 // CPU execution path at all (am_abi.cpp fails with AM_ERR_NO_DEVICE without a GPU).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -102,6 +103,73 @@ long long amchk_dfa_visits(const uint8_t* image, const uint8_t* text, uint64_t n
         if (cl == kDfaRare) { if (d.ic && byte - 0x41u < 26u) byte += 0x20u; e = dfa_rare_step(d, state, byte); }
         else e = dfa_common_step(d, state, cl);
         state = e & kDfaStateMask;
+    }
+    return 0;
+}
+
+// A model of what ONE XCD's L2 sees of the table walk (tools/experiments/dfa_l2sim.py): `lanes` lanes, lane i walking text[i * unit, (i + 1) * unit) from the root, take
+// their steps round-robin; every lane-load that k_dfa would send to L2 -- a chain record, an entry of a row that is not in LDS (hot or cold table), a 64-byte piece of
+// text -- looks its 128-byte line up in a set-associative LRU cache of l2_bytes.  out[2 * c] / out[2 * c + 1] = requests / misses of category c: 0 text, 1 chain
+// records, 2 hot table, 3 cold columns of the rows, 4 rare-byte walk (hash + fail), 5 steps answered in LDS or without a load (requests only).  -3: no DFA section.
+long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t lanes, uint32_t unit, uint32_t hot_rows, uint64_t l2_bytes, uint32_t ways, uint32_t hot16_limit, uint64_t* out12)
+{
+    ImageHeader h; std::memcpy(&h, image, sizeof(h));
+    if (h.magic != kImageMagic || !h.dfa_n_states) return -3;
+    const DfaView d = make_dfa_view(image, h);
+    for (int i = 0; i < 12; i++) out12[i] = 0;
+    const uint64_t n_sets = l2_bytes / 128u / ways;
+    std::vector<uint64_t> tag((size_t)(n_sets * ways), ~0ull);
+    std::vector<uint32_t> age((size_t)(n_sets * ways), 0);
+    uint32_t clock = 0;
+    const bool text_no_alloc = std::getenv("SIM_TEXT_NO_ALLOC") != nullptr;
+    auto touch = [&](int cat, uint64_t addr) {
+        const uint64_t line = addr >> 7, set = (line * 0x9E3779B97F4A7C15ull >> 20) % n_sets;
+        out12[2 * cat]++;
+        uint64_t* t = &tag[(size_t)(set * ways)]; uint32_t* a = &age[(size_t)(set * ways)];
+        uint32_t victim = 0;
+        for (uint32_t w = 0; w < ways; w++) { if (t[w] == line) { a[w] = ++clock; return; } if (a[w] < a[victim]) victim = w; }
+        out12[2 * cat + 1]++;
+        if (cat == 0 && text_no_alloc) return;                  // (what-if: text lines do not stay in the cache)
+        t[victim] = line; a[victim] = ++clock;
+    };
+    // address spaces: image offsets for the tables, 2^40 + offset for the text
+    std::vector<uint32_t> state((size_t)lanes, 0);
+    for (uint32_t p = 0; p < unit; p++) {
+        for (uint64_t l = 0; l < lanes; l++) {
+            const uint64_t at = l * unit + p;
+            if ((p & 63u) == 0) touch(0, (1ull << 40) + at);
+            uint32_t byte = text[at];
+            const uint32_t cl = d.cls[byte];
+            uint32_t st = state[l], e;
+            if (cl == kDfaRare) {
+                if (d.ic && byte - 0x41u < 26u) byte += 0x20u;
+                touch(4, h.off_dfa_rare + (uint64_t)dfa_rare_slot(st, byte, d.rare_log2_cap) * 16u);
+                e = dfa_rare_step(d, st, byte);
+            } else {
+                if (cl == 0u) out12[10]++;
+                else {
+                    if (st >= d.n_rows) {
+                        touch(1, h.off_dfa_chain + (uint64_t)(st - d.n_rows) * 8u);
+                        const u32x2 r = d.chain[st - d.n_rows];
+                        st = (r.y >> 24) == cl ? kNone : (r.y & 0xFFFFFFu);
+                    }
+                    if (st != kNone) {
+                        if (st < hot_rows && cl <= 32u) out12[10]++;
+                        else if (cl <= (1u << d.hot_log2)) {
+                            // (what-if, hot16_limit != 0: 16-bit entries for targets below the limit with at most two needle ends, a second request into the 32-bit table otherwise)
+                            const uint32_t e32 = d.hot[((uint64_t)st << d.hot_log2) + cl - 1u];
+                            if (hot16_limit) {
+                                touch(2, (2ull << 40) + (((uint64_t)st << d.hot_log2) + cl - 1u) * 2u);
+                                if ((e32 & kDfaStateMask) >= hot16_limit || (e32 >> kDfaEndShift) > 2u) touch(3, h.off_dfa_hot + (((uint64_t)st << d.hot_log2) + cl - 1u) * 4u);
+                            } else touch(2, h.off_dfa_hot + (((uint64_t)st << d.hot_log2) + cl - 1u) * 4u);
+                        }
+                        else touch(3, h.off_dfa_next + (((uint64_t)st << d.log2_classes) + cl) * 4u);
+                    }
+                }
+                e = dfa_common_step(d, state[l], cl);
+            }
+            state[l] = e & kDfaStateMask;
+        }
     }
     return 0;
 }

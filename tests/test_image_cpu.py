@@ -246,3 +246,35 @@ def test_heavy_suffix_nodes_get_five_byte_child_entries():
     # the benchmark automata (random needles: branching suffixes are the exception) get none
     img3 = chk.flatten(oracle.Machine(synth.needles_for("cfg3_runLower_100k_10GiB")[:20000]), 1)
     assert struct.unpack_from("<I", img3[:256].tobytes(), 248)[0] == 0
+
+
+def test_the_flatteners_tasks_change_no_byte(chk):
+    """Round 6: the goto hash and the DFA section are made on threads of their own next to the suffix structure (am_flatten.cpp).  The image must not know:
+    byte for byte the one a flatten without tasks (AM_FLATTEN_SERIAL) makes -- for fragment automata that are forced to carry a DFA section, and for a dictionary large
+    enough to get one by itself."""
+    import numpy as np
+    from alfred_margaret_amd import synth
+    rng = random.Random(99)
+    cases = []
+    for _ in range(25):
+        needles, _hays = fragment_case(rng)
+        if "" not in needles and any(needles):
+            cases.append((needles, True))
+    cases.append((synth.vocabulary().needles(6000), False))
+    for needles, force in cases:
+        a = am.Automaton(needles)
+        if force:
+            chk.set("AM_DFA", 1)
+        try:
+            for case in (0, 1):
+                chk.set("AM_FLATTEN_SERIAL", 1)
+                serial = chk.flatten(a, case)
+                chk.set("AM_FLATTEN_SERIAL", -1)
+                tasks = chk.flatten(a, case)
+                assert np.array_equal(serial, tasks), (len(needles), case)
+                if force:
+                    assert chk.dfa_header(serial)["n_states"] >= 1
+        finally:
+            chk.set("AM_DFA", -1)
+            chk.set("AM_FLATTEN_SERIAL", -1)
+    assert chk.dfa_header(chk.flatten(am.Automaton(cases[-1][0]), 1))["n_states"] > 1000      # (the dictionary got its section unasked: the speculative task was the one kept)

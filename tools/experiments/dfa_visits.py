@@ -57,3 +57,10 @@ for name, v in (("suffix corpus", pv2), ("both", pv2.astype(np.int64) + 4 * pv.a
     order2 = np.argsort(-v[:nr].astype(np.int64), kind="stable")
     prox2 = np.cumsum(rows[order2])
     print(name + ": " + ", ".join("%d: %.1f %%" % (k, 100.0 * prox2[k - 1] / n) for k in (256, 512, 1024, 2048, 4096, 16384, 32768)))
+# chain records: how concentrated are the visits?  (8 bytes each; a 128-byte line holds 16)
+cv = np.sort(chains)[::-1]; cc = np.cumsum(cv); tot = max(1, chains.sum())
+lines_cur = chains[: (len(chains) // 16) * 16].reshape(-1, 16).sum(axis=1)
+lc_sorted = np.cumsum(np.sort(lines_cur)[::-1])
+print("chain states %d (%.1f MB), visited %d; the hottest 32k / 64k / 128k records take %.1f / %.1f / %.1f %% of the chain steps; in the current numbering the hottest 2k / 4k / 8k / 16k LINES take %.1f / %.1f / %.1f / %.1f %%" % (
+    len(chains), len(chains) * 8 / 1e6, (chains > 0).sum(), 100.0 * cc[32767] / tot, 100.0 * cc[65535] / tot, 100.0 * cc[131071] / tot,
+    100.0 * lc_sorted[2047] / tot, 100.0 * lc_sorted[4095] / tot, 100.0 * lc_sorted[8191] / tot, 100.0 * lc_sorted[16383] / tot))
