@@ -260,7 +260,7 @@ def test_the_flatteners_tasks_change_no_byte(chk):
         needles, _hays = fragment_case(rng)
         if "" not in needles and any(needles):
             cases.append((needles, True))
-    cases.append((synth.vocabulary().needles(6000), False))
+    cases.append((synth.vocabulary().needles(20000), False))
     for needles, force in cases:
         a = am.Automaton(needles)
         if force:
