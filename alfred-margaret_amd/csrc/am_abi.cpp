@@ -674,7 +674,8 @@ using AcLauncher = hipError_t (*)(bool ic, int mode, const AcView& a, const Batc
 std::atomic<AcLauncher> g_ac_launcher{nullptr};
 
 constexpr uint64_t kDfaMinBytes = 32ull << 20;     // below this the suffix-filter route is the faster one even on natural text: a lane's walk of its unit (>= 128 bytes + warm-up, ~1 us per step) has a floor of 0.3 ms (natural text, 16 MiB: k_sf 0.26 / 0.36 ms counting / emitting, k_dfa 0.29 / 0.41; 32 MiB: 0.44 / 0.57 against 0.33 / 0.47)
-constexpr uint64_t kDfaSampleBytes = 64ull << 20;   // from here on a sample walk asks the text which route it wants (below: a dictionary is taken to meet its language)
+constexpr uint64_t kDfaSampleBytes = 32ull << 20;   // from here on -- i.e. whenever the table walk is in question -- a sample walk asks the text which route it wants (round 5 asked from
+                                                    // 64 MiB on: a dictionary over text that is not its language took the table walk at 32-64 MiB, 6 x slower than the filter there)
 constexpr uint32_t kDfaEndsPerKiB = 48;            // needle ends per KiB from which the table walk wins (k_sf: 670 GiB/s at 10 per KiB, 215 at 63, 76 at 156; k_dfa: ~155 flat)
 
 struct Plan {
@@ -697,9 +698,16 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
     AM_TRY(prepare(a, case_mode, &p.f));
     p.ic = case_mode == AM_IGNORE_CASE;
     if (a->kernel_pref == 2 && !p.f->h.sf_enabled) return fail(AM_ERR_UNSUPPORTED, "suffix-filter kernel cannot run this automaton (empty needle with too many prefix terminals)");
-    const bool has_dfa = p.f->h.dfa_n_states != 0 && p.f->h.root_vlen == 0;
-    if (a->kernel_pref == 3 && !has_dfa) return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 3): this automaton's image has no DFA section");
     p.dfa = make_dfa_view(p.f->d_image, p.f->h);
+    bool has_dfa = p.f->h.dfa_n_states != 0 && p.f->h.root_vlen == 0;
+    if (a->kernel_pref == 3 && !has_dfa) return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 3): this automaton's image has no DFA section");
+    if (has_dfa) {
+        ON_DEVICE(b->dev);
+        if (!dfa_usable(p.dfa)) {                            // (a section this device cannot walk -- its LDS attribute refused, offsets beyond 32 bits -- is no error: the filter takes the batch)
+            if (a->kernel_pref == 3) return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 3): the table-walk kernel cannot run this image on this device");
+            has_dfa = false;
+        }
+    }
     if (has_dfa) {
         // A lane walks its unit byte after byte (~1 us per step): a unit of 2 048 bytes takes milliseconds however small the batch is.  The image's unit is for batches that
         // fill the machine (n_cu x 32 wavefronts x 64 lanes) with it; smaller batches get smaller units, down to 128 bytes (where the warm-up is a third of the walk).
@@ -723,7 +731,7 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
             hipStream_t st; AM_TRY(get_stream(b->dev, &st));
             AM_TRY(b->small.ensure(64));
             HIP_TRY(hipMemsetAsync(b->small.p, 0, 64, st));
-            constexpr uint32_t kSamples = 4096, kLen = 128;
+            const uint32_t kSamples = b->total >= (64ull << 20) ? 4096u : 1024u, kLen = 128;       // (a smaller batch is asked with fewer lanes: 0.05 ms of a 0.3-ms scan)
             HIP_TRY(launch_dfa_sample(p.dfa, (const uint8_t*)b->d_text, b->total, kSamples, kLen, (uint32_t*)b->small.p, st));
             uint32_t ends = 0;
             HIP_TRY(hipMemcpyAsync(&ends, b->small.p, 4, hipMemcpyDeviceToHost, st));
@@ -736,7 +744,8 @@ int make_plan(const am_automaton* a, int case_mode, am_batch* b, Plan& p, bool a
     }
     p.use_sf = p.f->h.sf_enabled && a->kernel_pref != 1 && !p.use_dfa;
     if (!p.use_sf && !p.use_dfa && !g_ac_launcher.load(std::memory_order_acquire))
-        return fail(AM_ERR_UNSUPPORTED, "am_automaton_set_kernel(a, 1): the general AC kernel is test infrastructure (libam_check.so) and is not loaded in this process");
+        return fail(AM_ERR_UNSUPPORTED, a->kernel_pref == 1 ? "am_automaton_set_kernel(a, 1): the general AC kernel is test infrastructure (libam_check.so) and is not loaded in this process"
+                                                           : "this image has no suffix-filter section (sf_enabled == 0) and no table-walk section this batch could take: no kernel of the library can scan with it");
     p.dense = p.use_sf && p.f->h.root_vlen > 0;
     p.ac = make_ac_view(p.f->d_image, p.f->h);
     p.sf = make_sf_view(p.f->d_image, p.f->h);
@@ -1005,7 +1014,7 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
             *n_scan = total;
             if (total == 0) return AM_OK;
             AM_TRY(sink(total, &d_records));
-            { Prof pr("dfa_place", st); HIP_TRY(launch_dfa_place(p.dfa, p.bv, o, ctrl[0] < o.n_blocks ? ctrl[0] : o.n_blocks, (const uint64_t*)b->unit_offsets.p, p.n_cu, d_records, st)); }
+            { Prof pr("dfa_place", st); HIP_TRY(launch_dfa_place(p.dfa, p.bv, o, ctrl[0] < o.n_blocks ? ctrl[0] : o.n_blocks, (const uint64_t*)b->unit_offsets.p, p.n_cu, n_waves, d_records, st)); }
             HIP_TRY(hipStreamSynchronize(st));
             return AM_OK;
         }

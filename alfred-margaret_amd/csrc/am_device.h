@@ -70,6 +70,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
 hipError_t launch_ac(bool ic, int mode, const AcView& a, const BatchView& b, const ScanOut& o, hipStream_t st);
 // table-walk kernel (am_dfa.hip): same two-pass protocol as the general kernel (count -> scan -> emit), unit = one lane's DfaView::chunk bytes
 uint64_t dfa_units(const DfaView& d, const BatchView& b);
+bool dfa_usable(const DfaView& d);      // on the current device: offsets fit, the LDS attribute could be raised (checked once per device)
 hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
 // records in ONE walk: 8-byte tokens into ScanOut::pool (superblocks; ScanOut::block_next = 2 x n_blocks words: their fill counts, zeroed before the launch, then their
 // first groups; pool_ctrl[0] superblocks drawn, [1] pool exhausted; n_blocks = superblocks in the pool), unit_counts as in count mode; then scan(unit_counts) and launch_dfa_place
@@ -80,7 +81,7 @@ uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu);
 uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves, uint64_t n_units);
 uint64_t dfa_superblock_bytes();
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
-hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, Record* out, hipStream_t st);
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, uint32_t n_waves, Record* out, hipStream_t st);
 hipError_t read_sf_phase_cycles(uint64_t* out5);
 hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);

@@ -393,26 +393,41 @@ static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
     const uint32_t per_cu = (dfa_tune() >> 4) & 15u ? (dfa_tune() >> 4) & 15u : 2u;
     return (uint32_t)std::min<uint64_t>((uint64_t)n_cu * per_cu, (n_groups + 15) / 16);
 }
+// Can this device walk this section at all?  The walk addresses hot table and chain records as 32-bit offsets from the rows and a group's text as 32-bit offsets
+// from its start, and a workgroup wants more than 64 KiB of dynamic LDS (an attribute per instantiation and device, raised here once).  make_plan asks before it
+// chooses the route: a section that cannot be walked is not an error, the suffix filter takes the batch.
+template <int MODE, int TW, bool NT>
+static bool dfa_raise_lds(int dev)
+{
+    static std::atomic<int> state[64];                       // 0: not tried, 1: raised, 2: refused
+    int s = state[dev].load(std::memory_order_acquire);
+    if (s == 0) {
+        s = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 1 : 2;
+        if (s == 2) (void)hipGetLastError();
+        state[dev].store(s, std::memory_order_release);
+    }
+    return s == 1;
+}
+template <int MODE>
+static bool dfa_raise_lds_mode(int dev) { return dfa_raise_lds<MODE, 16, false>(dev) && dfa_raise_lds<MODE, 64, false>(dev) && dfa_raise_lds<MODE, 64, true>(dev); }
+bool dfa_usable(const DfaView& d)
+{
+    const uint8_t *p_next = reinterpret_cast<const uint8_t*>(d.next), *p_hot = reinterpret_cast<const uint8_t*>(d.hot), *p_chain = reinterpret_cast<const uint8_t*>(d.chain);
+    if (p_hot < p_next || p_chain < p_next || (uint64_t)(p_chain - p_next) + (uint64_t)(d.n_states - d.n_rows) * 8u >= (1ull << 32) ||
+        (uint64_t)(p_hot - p_next) + ((uint64_t)d.n_rows << (d.hot_log2 + 2u)) >= (1ull << 32) || (uint64_t)d.chunk * kWave + d.warm + 16u >= (1ull << 31)) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    return dfa_raise_lds_mode<kModeCount>(dev) && dfa_raise_lds_mode<kModeEmit>(dev) && dfa_raise_lds_mode<kModeAny>(dev) && dfa_raise_lds_mode<kModeTokens>(dev);
+}
 template <int MODE, int TW, bool NT>
 static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const uint64_t n_units = dfa_units(d, b);
     if (n_units == 0) return hipSuccess;
-    // (the walk addresses hot table and chain records as 32-bit offsets from the rows, and a group's text as 32-bit offsets from its start)
-    const uint8_t *p_next = reinterpret_cast<const uint8_t*>(d.next), *p_hot = reinterpret_cast<const uint8_t*>(d.hot), *p_chain = reinterpret_cast<const uint8_t*>(d.chain);
-    if (p_hot < p_next || p_chain < p_next || (uint64_t)(p_chain - p_next) + (uint64_t)(d.n_states - d.n_rows) * 8u >= (1ull << 32) ||
-        (uint64_t)(p_hot - p_next) + ((uint64_t)d.n_rows << (d.hot_log2 + 2u)) >= (1ull << 32) || (uint64_t)d.chunk * kWave + d.warm + 16u >= (1ull << 31)) return hipErrorInvalidValue;
+    if (!dfa_usable(d)) return hipErrorInvalidValue;         // (make_plan does not come here with such a section)
     uint32_t hot = dfa_hot_rows(d);
     if ((dfa_tune() >> 8) & 0xFFFFu) hot = std::min<uint32_t>(hot, ((dfa_tune() >> 8) & 0xFFFFu) - 1u);
     const size_t lds = ((size_t)dfa_hot_rows(d) << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
-    static std::atomic<bool> raised[64];                     // (more than 64 KiB of dynamic LDS needs the attribute, once per instantiation and device)
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    if (!raised[dev].load(std::memory_order_acquire)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        if (e != hipSuccess) return e;
-        raised[dev].store(true, std::memory_order_release);
-    }
     hipLaunchKernelGGL((k_dfa<MODE, TW, NT>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
     return hipGetLastError();
 }
@@ -442,11 +457,12 @@ uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves, uint64_t n_un
 uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(u32x2_v); }
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st) { return launch_dfa_t<kModeTokens>(d, b, o, n_cu, st); }
 // o.block_next = [n_blocks fill counts | n_blocks first groups]
-hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, Record* out, hipStream_t st)
+// n_waves = dfa_token_waves() as it was when the walk was launched: a token names its group by an ordinal counted in steps of it
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, uint32_t n_waves, Record* out, hipStream_t st)
 {
     if (n_super == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.chunk,
-                       dfa_token_waves(d, b, n_cu), out);
+    if (n_waves != dfa_token_waves(d, b, n_cu)) return hipErrorInvalidValue;       // (the launch parameters changed between the walk and the placement)
+    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.chunk, n_waves, out);
     return hipGetLastError();
 }
 

@@ -106,12 +106,12 @@ def main():
     needles = synth.needles_for(args.workload)
     t0 = time.time()
     machine = None
+    build = None
     if rank == 0:
-        machine = am.Automaton(needles)
+        machine, build = timed_build(needles, case)
         machine.set_kernel(args.kernel)
         handle = C.c_void_p(machine.device)
-        nbytes = C.c_size_t(0)
-        am.api.check(lib.am_automaton_image_size(handle, case, C.byref(nbytes)))
+        nbytes = C.c_size_t(build["image_bytes"])
     build_s = time.time() - t0
     multi = None
     rccl_ms = {}
@@ -256,6 +256,7 @@ def main():
                        "haystacks_per_gpu": n_hay, "haystack_bytes": w["hay_bytes"], "bytes_per_gpu": n_bytes,
                        "parallelism": "haystack-sharded x%d%s" % (world, ", automaton broadcast + count all-reduce by libam (am_multi_*, RCCL)" if multi is not None else ""), "kernel": kname.decode(),
                        "automaton_image_bytes": image_bytes, "build_s": round(build_s, 2)},
+            "build": build, "gpu_build_plus_run": build_plus_run(n_bytes, build, ms_per_step) if build else None,
             "matches_per_s": round(total_matches * args.steps / elapsed, 1),
             "matches_per_step": total_matches, "records_per_step": total_records,
             "count_only_gibps": round(n_bytes / float(1 << 30) / count_only_s, 3),
@@ -294,6 +295,28 @@ def main():
 EXTRA_WORKLOADS = ("cfg2_runText_10k_1GiB", "cfg2_single_1GiB", "cfg4_100k_1M_haystacks", "natural_100k_10GiB", "cfg5_replacer_50k_1GiB")
 
 
+def timed_build(needles, case):
+    """`build` as the reference's benchmark times it -- together with the run (benchmark/haskell/app/Main.hs:62-64,73): (machine, split).  automaton_s = the host mirror of
+    Automaton.build + am_automaton_create (which validates by flattening the CaseSensitive image; the IgnoreCase image is flattened on a thread of its own meanwhile);
+    first_use_s = until the image of the workload's case mode lies in HBM (the rest of its flatten, the upload)."""
+    import alfred_margaret_amd as am
+    t0 = time.perf_counter()
+    machine = am.Automaton(needles)
+    t1 = time.perf_counter()
+    nbytes = C.c_size_t(0)
+    am.api.check(am.api.libam().am_automaton_image_size(C.c_void_p(machine.device), case, C.byref(nbytes)))
+    t2 = time.perf_counter()
+    return machine, {"automaton_s": round(t1 - t0, 3), "first_use_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3), "image_bytes": int(nbytes.value),
+                     "what": "automaton_s: host build (mirror of Automaton.build) + am_automaton_create (validation = CaseSensitive flatten, IgnoreCase flatten on its own thread); "
+                             "first_use_s: the case mode's image in HBM (rest of its flatten + upload)"}
+
+
+def build_plus_run(n_bytes, build, ms_per_step):
+    """One batch scanned by a freshly built automaton, every record written: GiB/s over build + one step (what cpu_baseline.value_build_plus_run is for the oracle)."""
+    total = build["total_s"] + ms_per_step * 1e-3
+    return {"value": round(n_bytes / float(1 << 30) / total, 2), "unit": "GiB/s", "seconds": round(total, 3), "what": "bytes of ONE batch / (build.total_s + ms_per_step)"}
+
+
 def pmc_traffic_entry(workload, kernel, n_bytes):
     """HBM traffic of one launch from the committed PMC profile of the same kernel + workload (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), scaled to this launch's bytes; (None, None) without such a profile.
@@ -324,8 +347,9 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
     t0 = time.time()
     if needles is None:
         needles = synth.needles_for(name)
+    build = None
     if machine is None:
-        machine = am.Automaton(needles)
+        machine, build = timed_build(needles, case)
     handle = C.c_void_p(machine.device)
     build_s = time.time() - t0
     n_hay = n_hay or w["n_hay"]
@@ -400,7 +424,8 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
                          "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic},
             **({"other_route": other_route} if other_route else {}),
             "parity": {k: parity.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "full_lists_checked", "matches_in_checked")},
-            "build_s": round(build_s, 2), **({"contains_all": contains_all} if contains_all else {})}
+            "build_s": round(build_s, 2), **({"build": build, "gpu_build_plus_run": build_plus_run(n_bytes, build, elapsed / steps * 1e3)} if build else {}),
+            **({"contains_all": contains_all} if contains_all else {})}
 
 
 def contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib):

@@ -13,12 +13,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _checker_kernel():
+@pytest.fixture(autouse=True)
+def _checker_kernel(request):
     """The general AC-walk kernel k_ac -- the tests' independent second algorithm, Automaton.set_kernel(1) -- is test infrastructure: it lives
-    in libam_check.so (tests/native/am_ac.hip), not in the product library, and registers itself with libam when loaded."""
-    import alfred_margaret_amd as am
-    am.api.load_check()
+    in libam_check.so (tests/native/am_ac.hip), not in the product library, and registers itself with libam when loaded.  Only the GPU tests run it: they get it
+    loaded (once); the CPU suites (the oracle, the host mirror, the host interpreter of the image) run on a box without hipcc / the HIP runtime as they are."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import alfred_margaret_amd as am
+        am.api.load_check()
     yield
 
 
