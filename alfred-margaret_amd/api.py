@@ -165,6 +165,7 @@ _HOST = {
 DEBUG_ABI = {
     "am_debug_set": (C.c_int, [C.c_char_p, C.c_long]),
     "am_debug_pinned_bytes": (C.c_uint64, []),
+    "am_debug_bounds_report": (C.c_int, [_u64p, _u32p, _u32p]),
     "am_debug_sf_phase_cycles": (C.c_int, [_vp]),
     "am_debug_sf_wave_records": (C.c_int, [_vp, _sz]),
     "am_debug_set_general_kernel": (C.c_int, [_vp, C.c_uint32]),
@@ -678,6 +679,13 @@ def debug_set(name, value):
 def debug_reset():
     for name in DEBUG_SWITCHES:
         debug_set(name, -1)
+
+
+def bounds_report():
+    """(failed index assertions, line of the first, translation units that carry assertions) of a -DAM_BOUNDS_CHECK build; (0, 0, 0) in the product build."""
+    f, l, u = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+    check(libam().am_debug_bounds_report(C.byref(f), C.byref(l), C.byref(u)))
+    return int(f.value), int(l.value), int(u.value)
 
 
 def image_version():

@@ -19,9 +19,23 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 HOST = os.path.join(PKG, "host")
 NATIVE_TESTS = os.path.join(ROOT, "tests", "native")
-LIB = os.path.join(PKG, "lib")
+# AM_LIB_DIR: build into / load from another directory (tools/sanitize.sh keeps its instrumented libraries apart from the product's)
+LIB = os.environ.get("AM_LIB_DIR") or os.path.join(PKG, "lib")
 ARCH = "gfx950"
 LINK_EXTRA = ["-ldl"]        # RCCL (am_multi_*) is bound with dlopen at first use, not at link time
+# AM_SANITIZE=1 (tools/sanitize.sh): every HOST translation unit -- the C ABI's runtime, the flattener, the Replacer's and multi-GPU host code, the host mirror, the
+# image interpreter -- with AddressSanitizer + UndefinedBehaviorSanitizer (clang's, shared runtime: python is not instrumented and gets it through LD_PRELOAD).  The
+# kernels are compiled as always: GPU sanitizers are not available on this pool.
+SANITIZE = bool(os.environ.get("AM_SANITIZE"))
+# AM_BOUNDS_CHECK=1 (tools/bounds_check.sh): the kernels compiled with their index assertions (csrc/am_bounds.h); run on the GPU box over the parity tests
+BOUNDS = ["-DAM_BOUNDS_CHECK"] if os.environ.get("AM_BOUNDS_CHECK") else []
+SAN_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined", "-shared-libsan", "-fno-omit-frame-pointer", "-g", "-O1"] if SANITIZE else []
+CLANGXX = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _host_cxx():
+    """g++ for the host-only libraries; clang++ under AM_SANITIZE (one sanitizer runtime for every library of the process)."""
+    return CLANGXX if SANITIZE else "g++"
 
 
 def _hipcc():
@@ -62,14 +76,16 @@ def build_libam(force=False):
     def compile_one(pair):
         src, obj = pair
         if force or _stale(obj, [src] + headers):
-            subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip", "-c", src, "-o", obj + ".tmp"])
+            san = SAN_FLAGS if src.endswith(".cpp") else []          # host translation units only
+            subprocess.check_call([_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", *san, *BOUNDS, "-x", "hip", "-c", src, "-o", obj + ".tmp"])
             os.replace(obj + ".tmp", obj)
         return obj
 
     with ThreadPoolExecutor(len(srcs)) as pool:
         list(pool.map(compile_one, zip(srcs, objs)))
     if force or _stale(target, objs + [os.path.join(CSRC, "libam.map")]):
-        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *objs, "-Wl,--version-script=" + os.path.join(CSRC, "libam.map"), "-o", target + ".tmp"] + LINK_EXTRA
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-fPIC", "-shared", *objs, "-Wl,--version-script=" + os.path.join(CSRC, "libam.map"), "-o", target + ".tmp"] + LINK_EXTRA + \
+              (["-fsanitize=address,undefined", "-shared-libsan"] if SANITIZE else [])
         subprocess.check_call(cmd)
         os.replace(target + ".tmp", target)
     return target
@@ -80,7 +96,7 @@ def build_imgcheck(force=False):
     target = os.path.join(LIB, "libam_imgcheck.so")
     srcs = [os.path.join(NATIVE_TESTS, "am_imgcheck.cpp"), os.path.join(CSRC, "am_flatten.cpp")]
     if force or _stale(target, _glob_deps(CSRC) + srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, *srcs, "-o", target + ".tmp"])
+        subprocess.check_call([_host_cxx(), "-O2", "-std=c++17", "-fPIC", "-shared", *SAN_FLAGS, "-I", CSRC, *srcs, "-o", target + ".tmp"])
         os.replace(target + ".tmp", target)
     return target
 
@@ -119,7 +135,7 @@ def build_host(force=False):
     srcs = [os.path.join(HOST, f) for f in sorted(os.listdir(HOST)) if f.endswith(".cpp")]
     deps = _glob_deps(HOST) + [libam, os.path.join(ROOT, "include", "am.h")]
     if force or _stale(target, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), *srcs,
+        cmd = [_host_cxx(), "-O2", "-std=c++17", "-fPIC", "-shared", *SAN_FLAGS, "-I", os.path.join(ROOT, "include"), *srcs,
                "-L", LIB, "-lam", "-Wl,-rpath,$ORIGIN", "-o", target + ".tmp"]
         subprocess.check_call(cmd)
         os.replace(target + ".tmp", target)

@@ -1622,6 +1622,29 @@ extern "C" int am_debug_set(const char* name, long value)
     return AM_OK;
 }
 
+// index assertions of a -DAM_BOUNDS_CHECK build (am_bounds.h): every kernel translation unit that carries them registers a reader of its device-side words at load time
+namespace {
+struct BoundsUnit { const char* file; hipError_t (*read)(uint32_t*); };
+std::vector<BoundsUnit>& bounds_units() { static std::vector<BoundsUnit> v; return v; }
+}  // namespace
+namespace am { namespace dev { void bounds_register(const char* file, hipError_t (*read)(uint32_t* out2)) { bounds_units().push_back(BoundsUnit{file, read}); } } }
+
+extern "C" int am_debug_bounds_report(uint64_t* failed_out, uint32_t* first_line_out, uint32_t* checked_units_out)
+{
+    uint64_t failed = 0; uint32_t line = 0;
+    if (!bounds_units().empty()) HIP_TRY(hipDeviceSynchronize());
+    for (const BoundsUnit& u : bounds_units()) {
+        uint32_t w[2] = {0, 0};
+        HIP_TRY(u.read(w));
+        if (w[0] && !failed) { line = w[1]; g_err = std::string("first failed index assertion: ") + u.file + ":" + std::to_string(w[1]); }
+        failed += w[0];
+    }
+    if (failed_out) *failed_out = failed;
+    if (first_line_out) *first_line_out = line;
+    if (checked_units_out) *checked_units_out = (uint32_t)bounds_units().size();
+    return AM_OK;
+}
+
 extern "C" uint64_t am_debug_pinned_bytes(void) { return (uint64_t)g_pinned_staging_bytes.load(std::memory_order_relaxed); }
 
 extern "C" int am_debug_sf_wave_records(uint64_t* out, size_t n_waves)

@@ -31,9 +31,12 @@
 #include <algorithm>
 #include <atomic>
 
+#include "am_bounds.h"
 #include "am_config.h"
 #include "am_device.h"
 #include "am_wave.h"
+
+AM_BOUNDS_TU("am_dfa.hip")
 
 namespace am {
 namespace dev {
@@ -79,6 +82,7 @@ struct DfaLane {
         if (MODE == kModeTokens) {
             if (sb != kNone) {
                 const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the block)
+                AM_BOUNDS(slot < kDfaSuper && sb < o.n_blocks && ord < kTokMaxOrd && in_unit < kTokMaxChunk && nrec < kTokMaxChunk && state < d.n_states);
                 u32x2_v t; t.x = state | (ord << kTokOrdShift); t.y = in_unit | (nrec << kTokPosBits) | (lane_id() << 26);
                 reinterpret_cast<u32x2_v*>(o.pool)[(uint64_t)sb * kDfaSuper + slot] = t;      // (the DFA state: k_dfa_place looks the reference state up, off the walk's dependent chain)
             }
@@ -97,6 +101,7 @@ struct DfaLane {
             }
         } else {
             const u32x2 e = d.out[state];
+            AM_BOUNDS(e.x != 0u && hay < b.n_hay && end_pos != 0u && end_pos <= b.offsets[hay + 1] - b.offsets[hay]);
             out[nrec++] = Record{end_pos, hay, e.x - 1u};
         }
     }
@@ -108,8 +113,10 @@ struct DfaLane {
 __device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, uint32_t lds_rows_addr, uint32_t hot_rows, uint32_t state, uint32_t cl)
 {
     if (cl == 0u) return 0u;
+    AM_BOUNDS(state < d.n_states && cl < (1u << d.log2_classes));
     if (state >= d.n_rows) {
         const u32x2_v r = *reinterpret_cast<const u32x2_v*>(v.base + v.off_chain + ((state - d.n_rows) << 3));
+        AM_BOUNDS((r.y & 0xFFFFFFu) < d.n_rows);
         if ((r.y >> 24) == cl) return r.x;
         state = r.y & 0xFFFFFFu;
     }
@@ -143,6 +150,8 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
     uint64_t hs = b.offsets[h];
     const uint64_t he64 = b.offsets[h + 1];
     uint32_t pos = (cs - hs > d.warm) ? ((cs_r - d.warm) & ~15u) : (uint32_t)(hs - tp_off);      // a longer warm-up is as exact; 16-byte blocks from the start
+    if (cs - hs > d.warm && tp_off + pos < hs) pos = (uint32_t)(hs - tp_off);                    // (never before the haystack: found by the index assertions of round 6 -- harmless, the
+                                                                                                 // state at cs depends on the `warm` bytes before it only, but the plain form does not either)
     uint32_t he_r = he64 - tp_off < 0xFFFFFFFFull ? (uint32_t)(he64 - tp_off) : 0xFFFFFFFFu;
     uint32_t state = 0;
     u32x4_n buf[NV];
@@ -179,6 +188,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
             const bool mine = pos >= cs_r;                  // (cs_r is a multiple of 16: a block lies on one side of it)
             if (MODE == kModeAny && mine && o.flags[h]) { pos = lim; avail = 0; continue; }      // the haystack is already flagged: on to the next one
             if (avail == 0) {                               // a whole TW-byte piece when it lies inside the haystack and the unit, one block otherwise (the ends of a unit)
+                AM_BOUNDS(tp_off + pos + 16u <= ((b.total + 15u) & ~15ull) && tp_off + pos >= hs && pos < ce_r);
                 if (NV > 1 && (pos & (uint32_t)(TW - 1)) == 0 && pos + (uint32_t)TW <= lim) {
 #pragma unroll
                     for (int j = 0; j < NV; j++) buf[j] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j)) : *reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j);
@@ -324,7 +334,7 @@ hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t tot
 // token is looked up from its position (the per-KiB haystack index of the batch; neighbouring records ask for neighbouring entries), the reference state from the DFA state.
 constexpr uint32_t kPlaceBuckets = kTokMaxOrd * kWave;
 __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ pool, const uint32_t* __restrict__ fill, const uint32_t* __restrict__ first_group, uint32_t n_super,
-                                                    const uint64_t* __restrict__ unit_offsets, BatchView b, const u32x2* __restrict__ dfa_out, uint32_t chunk, uint32_t n_waves,
+                                                    const uint64_t* __restrict__ unit_offsets, BatchView b, const u32x2* __restrict__ dfa_out, uint32_t n_states, uint32_t chunk, uint32_t n_waves,
                                                     Record* __restrict__ out)
 {
     __shared__ u32x2_v s_tok[kDfaSuper];
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ 
         const uint32_t i = threadIdx.x + k * 1024u;
         if (i < n) {
             const uint32_t bucket = ((t[k].x >> kTokOrdShift) << 6) | (t[k].y >> 26);
+            AM_BOUNDS(s_base[bucket] + ((t[k].y >> kTokPosBits) & (kTokMaxChunk - 1u)) - s_min[bucket] < n);
             s_tok[s_base[bucket] + ((t[k].y >> kTokPosBits) & (kTokMaxChunk - 1u)) - s_min[bucket]] = t[k];
         }
     }
@@ -373,6 +384,8 @@ __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ 
         const uint64_t u = (g_first + (uint64_t)(q.x >> kTokOrdShift) * n_waves) * kWave + (q.y >> 26);
         const uint64_t g = u * chunk + (q.y & (kTokMaxChunk - 1u));
         const uint32_t h = find_haystack(b, g);
+        AM_BOUNDS(g < b.total && h < b.n_hay && b.offsets[h] <= g && g < b.offsets[h + 1] && (q.x & kDfaStateMask) < n_states && dfa_out[q.x & kDfaStateMask].x != 0u &&
+                  unit_offsets[u] + ((q.y >> kTokPosBits) & (kTokMaxChunk - 1u)) < unit_offsets[u + 1]);
         u32x4_n r;
         const uint64_t end_pos = g + 1u - b.offsets[h];
         r.x = (uint32_t)end_pos; r.y = (uint32_t)(end_pos >> 32); r.z = h; r.w = dfa_out[q.x & kDfaStateMask].x - 1u;
@@ -462,7 +475,7 @@ hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut&
 {
     if (n_super == 0) return hipSuccess;
     if (n_waves != dfa_token_waves(d, b, n_cu)) return hipErrorInvalidValue;       // (the launch parameters changed between the walk and the placement)
-    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.chunk, n_waves, out);
+    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.n_states, d.chunk, n_waves, out);
     return hipGetLastError();
 }
 

@@ -22,9 +22,12 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "am_bounds.h"
 #include "am_config.h"
 #include "am_device.h"
 #include "am_wave.h"
+
+AM_BOUNDS_TU("am_kernels.hip")
 
 namespace am {
 namespace dev {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         if (timing) n_found += (uint32_t)__popcll(__ballot(found && prior == 0u));
         if (MODE == kModeCount) add_counts(found, hay, best_vlen[0]);
         else if (MODE == kModeEmit) {
-            if (found && best_state[0] != prior && pool_ok) o.pool[slot].state = best_state[0] - 1u;      // the batch wrote end_pos and haystack into the walker's slot
+            if (found && best_state[0] != prior && pool_ok) { AM_BOUNDS(slot < (uint64_t)o.n_blocks * kPoolBlock); o.pool[slot].state = best_state[0] - 1u; }      // the batch wrote end_pos and haystack into the walker's slot
             unit_count += (uint32_t)__popcll(__ballot(found && prior == 0u));
         } else if (MODE == kModeAny && found) atomicOr(reinterpret_cast<uint32_t*>(o.flags) + (hay >> 2), 1u << (8u * (hay & 3u)));      // (the flag modes have no walker queue: not reached)
     };
@@ -295,6 +298,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                     if ((found[0] || parked[0]) && pool_ok) {
                         const uint32_t p = r + (uint32_t)__popcll(take_mask & ((1ull << lane) - 1ull));
                         slot[0] = (r != 0u && p < kPoolBlock) ? cur_block * kPoolBlock + p : new_block * kPoolBlock + (r != 0u ? p - kPoolBlock : p);
+                        AM_BOUNDS(slot[0] < (uint64_t)o.n_blocks * kPoolBlock && hay[0] < b.n_hay);
                         o.pool[slot[0]] = Record{end_pos[0], hay[0], found[0] ? best_state[0] - 1u : kNone};
                     }
                     if (need_new && pool_ok) cur_block = new_block;
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
 #pragma unroll
                             for (int t = 0; t < RN + 1; t++) if (q == have + (uint32_t)t) blk = ids[t];
                             slot[k] = blk * kPoolBlock + (si & (kPoolBlock - 1u));
+                            AM_BOUNDS(slot[k] < (uint64_t)o.n_blocks * kPoolBlock && hay[k] < b.n_hay);
                             o.pool[slot[k]] = Record{end_pos[k], hay[k], found[k] ? best_state[k] - 1u : kNone};
                         }
                     }
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                         if (wq_n + n_park <= wq_cap) {           // (wq_cap >= 64 whenever a queue exists: after a walk there is room)
                             if (parked[k]) {
                                 const uint32_t e = wq + (wq_n + (uint32_t)__popcll(pm[k] & ((1ull << lane) - 1ull))) * 64u;
+                                AM_BOUNDS(e + 64u <= wq + wq_cap * 64u);
                                 lds_write_u32x4(e, make_uint4((uint32_t)gpos[k], (uint32_t)(gpos[k] >> 32), avail[k], slot[k]));
                                 lds_write_u32x4(e + 16u, make_uint4(depth[k], best_state[k], best_vlen[k], w2[k]));
                                 lds_write_u32x4(e + 32u, make_uint4(rec[k].z, rec[k].w, rec[k].label[0], rec[k].label[1]));
@@ -437,6 +443,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
         auto park = [&](bool defer, uint32_t hint, uint32_t pos) {
             const uint64_t m = __ballot(defer);
             // (CH: epochs of 8 chunks leave bit 15 for "the slot of a child entry", hint bit 2)
+            AM_BOUNDS(q2_tail - q2_head + (uint32_t)__popcll(m) <= (uint32_t)kSfQ2);       // the ring of deferred positions is never overrun
             if (defer) lds_write_u16(q2 + 2u * ((q2_tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) % kSfQ2), (p_ci << 12) | ((hint & 3u) << 10) | (pos & 1023u) | (CH ? (hint & 4u) << 13 : 0u));      // (hint bit 2 is only ever set with child entries)
             q2_tail += (uint32_t)__popcll(m);
             if (timing) n_defer += (uint32_t)__popcll(m);
@@ -664,6 +671,7 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                 while (cand && idx < (uint32_t)kSfQ1) {
                     const uint32_t k = __builtin_ctz(cand);
                     cand &= cand - 1u;
+                    AM_BOUNDS(idx < (uint32_t)kSfQ1);
                     lds_write_u16(q1 + 2u * idx++, lane * 16u + k);
                 }
                 const uint32_t n_q1 = total < (uint32_t)kSfQ1 ? total : (uint32_t)kSfQ1;

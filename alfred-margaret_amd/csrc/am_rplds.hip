@@ -23,7 +23,10 @@
 #include <hip/hip_runtime.h>
 
 #include "am_device.h"
+#include "am_bounds.h"
 #include "am_wave.h"
+
+AM_BOUNDS_TU("am_rplds.hip")
 
 namespace am {
 namespace dev {
@@ -88,6 +91,7 @@ __device__ __forceinline__ void ld_move(uint32_t* A, uint32_t from, uint32_t to,
         uint32_t x = 0;
         if (i < to) x = A[i];
         wave_lds_fence();
+        AM_BOUNDS(i >= to || ((int32_t)i + g >= 0 && (uint32_t)((int32_t)i + g) < kLdsRec));
         if (i < to) A[(uint32_t)((int32_t)i + g)] = x + add;
         wave_lds_fence();
     }
@@ -373,6 +377,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     uint32_t x = 0, y = 0;
                     if (k < to) { x = L.psrc[k]; y = L.pls[k]; }
                     wave_lds_fence();
+                    AM_BOUNDS(k >= to || ((int32_t)k + s >= 0 && (uint32_t)((int32_t)k + s) < kLdsPc + 2u));
                     if (k < to) { L.psrc[(uint32_t)((int32_t)k + s)] = x; L.pls[(uint32_t)((int32_t)k + s)] = y + (uint32_t)delta; }
                     wave_lds_fence();
                 }
@@ -381,6 +386,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             }
             if (lane == 0) {
                 uint32_t at = i + keep_head;
+                AM_BOUNDS(at + (has_repl ? 1u : 0u) + (has_tail ? 1u : 0u) <= kLdsPc + 2u);
                 if (has_repl) { L.psrc[at] = kReplBit | repl_off; L.pls[at] = ms; at++; }
                 if (has_tail) { L.psrc[at] = pj_src + (me - pj_ls); L.pls[at] = ms + rl; }
             }
@@ -414,6 +420,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                             pls = L.pls[idx]; psr = L.psrc[idx];
                         }
                         const uint8_t* base = (psr & kReplBit) ? a.t.repl + (psr & ~kReplBit) : htext + psr;
+                        AM_BOUNDS(x < kLdsWin + 16u);
                         L.win[x] = base[p - pls];
                     }
                 }
@@ -447,6 +454,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                         if (nf + nfb > (uint32_t)kWave || nr + nf + nfb > kLdsRec) { redo = true; break; }
                         if (found) {                                     // staged behind the list; they move into the dead slots below
                             const uint32_t at = nr + nf + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull));
+                            AM_BOUNDS(at < kLdsRec);
                             L.end[at] = ws + g + 1u;
                             L.prio[at] = one.payload != kRpWalkList ? one.priority : (int32_t)state;
                             L.pl[at] = one.payload;
@@ -476,6 +484,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     ld_move(L.pl, c_gone, nr, g, 0u, lane);
                     nr = (uint32_t)((int32_t)nr + g);
                 }
+                AM_BOUNDS(c_before + nf <= kLdsRec && staged + nf <= kLdsRec);
                 if ((uint32_t)lane < nf) { L.end[c_before + lane] = s_end; L.prio[c_before + lane] = s_prio; L.pl[c_before + lane] = s_pl; }
                 wave_lds_fence();
             }

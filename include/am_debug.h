@@ -26,6 +26,10 @@ AM_API uint32_t am_debug_rp_lds_haystacks(void);
  * (image_version must equal am_image_version()), NULL takes it away again.  Without a launcher am_automaton_set_kernel(a, 1) makes every
  * scan of `a` fail with AM_ERR_UNSUPPORTED. */
 AM_API int am_debug_set_general_kernel(void* launcher, uint32_t image_version);
+/* A -DAM_BOUNDS_CHECK build of the library (tools/bounds_check.sh) compiles index assertions into its kernels (csrc/am_bounds.h: LDS queue indices, pool slots,
+ * image offsets).  *failed_out = assertions that failed on the current device since the library was loaded, *first_line_out = source line of the first one (0: none),
+ * *checked_units_out = translation units that carry assertions: 0 in the product build, where the call reports nothing and costs nothing. */
+AM_API int am_debug_bounds_report(uint64_t* failed_out, uint32_t* first_line_out, uint32_t* checked_units_out);
 
 #ifdef __cplusplus
 }

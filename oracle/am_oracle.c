@@ -267,8 +267,8 @@ orc_machine* orc_build(const uint8_t* bytes, const uint64_t* offs, size_t n_need
         uint32_t n = initial[state].n + fbn;
         if (n) {
             values[state].v = (uint32_t*)malloc(n * sizeof(uint32_t));
-            memcpy(values[state].v, initial[state].v, initial[state].n * sizeof(uint32_t));
-            memcpy(values[state].v + initial[state].n, fbv->v, fbn * sizeof(uint32_t));
+            if (initial[state].n) memcpy(values[state].v, initial[state].v, initial[state].n * sizeof(uint32_t));      /* (memcpy of zero bytes from NULL is undefined: UBSan, round 6) */
+            if (fbn) memcpy(values[state].v + initial[state].n, fbv->v, fbn * sizeof(uint32_t));
         }
         values[state].n = n;
     }

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libam_oracle.so")
+_LIB_PATH = os.environ.get("AM_ORACLE_LIB") or os.path.join(_HERE, "_build", "libam_oracle.so")       # (AM_ORACLE_LIB: tools/sanitize.sh's instrumented build)
 
 CASE_SENSITIVE = 0
 IGNORE_CASE = 1
@@ -21,7 +21,8 @@ IGNORE_CASE = 1
 
 def build_library():
     """Compile the C restatement (gcc only; called by __graft_entry__.build())."""
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    if not os.environ.get("AM_ORACLE_LIB"):
+        subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
 
 

@@ -40,3 +40,16 @@ def _reset_debug_switches():
     import alfred_margaret_amd as am
     if am.api._libam is not None:
         am.debug_reset()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """tools/bounds_check.sh: a -DAM_BOUNDS_CHECK build of libam counts the index assertions its kernels failed (csrc/am_bounds.h); any count fails the session."""
+    if not os.environ.get("AM_BOUNDS_CHECK"):
+        return
+    import alfred_margaret_amd as am
+    if am.api._libam is None:
+        return
+    failed, line, units = am.api.bounds_report()
+    print("\n[bounds] %d translation units carry index assertions; %d assertions failed%s" % (units, failed, "" if not failed else " -- " + (am.api.libam().am_last_error() or b"").decode()))
+    if failed or units == 0:
+        session.exitstatus = 1
