@@ -135,6 +135,8 @@ int finish_create(am_multi* m)
     return AM_OK;
 }
 
+int rccl_self_check(am_multi* m);      // (below, behind allreduce_flagged)
+
 int sync_all(const am_multi* m)
 {
     for (size_t i = 0; i < m->devs.size(); i++) { HIP_TRY(hipSetDevice(m->devs[i])); HIP_TRY(hipStreamSynchronize(m->streams[i])); }
@@ -168,7 +170,8 @@ extern "C" int am_multi_create(int n_devices, am_multi** out)
     m->comms.assign(n_devices, nullptr);
     ncclResult_t r = ncclCommInitAll(m->comms.data(), n_devices, m->devs.data());
     if (r != ncclSuccess) { m->comms.clear(); am_multi_destroy(m); return abi_fail(AM_ERR_HIP, std::string("ncclCommInitAll: ") + ncclGetErrorString(r)); }
-    const int rc = finish_create(m);
+    int rc = finish_create(m);
+    if (rc == AM_OK) rc = rccl_self_check(m);
     if (rc != AM_OK) { am_multi_destroy(m); return rc; }
     *out = m;
     return AM_OK;
@@ -190,7 +193,8 @@ extern "C" int am_multi_create_rank(int n_ranks, int rank, const uint8_t id[AM_U
     std::memcpy(&uid, id, AM_UNIQUE_ID_BYTES);
     ncclResult_t r = ncclCommInitRank(&m->comms[0], n_ranks, uid, rank);
     if (r != ncclSuccess) { m->comms.clear(); am_multi_destroy(m); return abi_fail(AM_ERR_HIP, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
-    const int rc = finish_create(m);
+    int rc = finish_create(m);
+    if (rc == AM_OK) rc = rccl_self_check(m);
     if (rc != AM_OK) { am_multi_destroy(m); return rc; }
     *out = m;
     return AM_OK;
@@ -328,6 +332,25 @@ extern "C" int am_multi_broadcast_automaton(am_multi* m, const am_automaton* a, 
     if (rc != AM_OK) for (int i = 0; i < n; i++) { am_automaton_destroy(autos_out[i]); autos_out[i] = nullptr; }
     return rc;
 }
+
+namespace {
+// A handle is only handed out when its communicator has carried one collective whose answer is known: every rank adds (its number + 1) in a one-word all-reduce and
+// must read world * (world + 1) / 2 on every local device.  A communicator that connects the wrong ranks, sums on the wrong stream or returns before the data has
+// arrived fails here, loudly, and not as a wrong match count at the end of a job (the real ncclAllReduce had never run with more than one rank before round 6's 8-GPU run).
+int rccl_self_check(am_multi* m)
+{
+    const int n = (int)m->devs.size();
+    std::vector<uint64_t> v((size_t)n);
+    for (int i = 0; i < n; i++) v[(size_t)i] = (uint64_t)(m->first_rank + i) + 1u;
+    AM_TRY(allreduce_flagged(m, v.data(), 1, AM_OK));
+    const uint64_t want = (uint64_t)m->world * ((uint64_t)m->world + 1u) / 2u;
+    for (int i = 0; i < n; i++)
+        if (v[(size_t)i] != want)
+            return abi_fail(AM_ERR_HIP, "RCCL self-check failed: the all-reduce of (rank + 1) over " + std::to_string(m->world) + " ranks gave " + std::to_string(v[(size_t)i]) +
+                                        " on local device " + std::to_string(i) + ", not " + std::to_string(want));
+    return AM_OK;
+}
+}  // namespace
 
 extern "C" int am_multi_allreduce_sum(am_multi* m, uint64_t* values, size_t count)
 {

@@ -407,7 +407,8 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
             finally:
                 am.api.check(lib.am_automaton_set_kernel(handle, 0))
         gate_args = copy.copy(args)
-        gate_args.kernel, gate_args.parity_oracle_mib = 0, args.workloads_oracle_mib
+        # (natural text runs the table walk, the route with the most intricate bookkeeping -- tokens, superblocks, k_dfa_place's sort --: its oracle sample is 512 spread haystacks)
+        gate_args.kernel, gate_args.parity_oracle_mib = 0, (max(args.workloads_oracle_mib, 512) if w.get("natural") and args.workloads_oracle_mib else args.workloads_oracle_mib)
         parity = parity_gate(gate_args, w, needles, machine, handle, case, batch, text, n_hay, 0, 1, dev, lib) if not args.no_parity else {}
         contains_all = contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib) if name == "cfg2_runText_10k_1GiB" and not args.no_parity else None
     finally:
@@ -423,7 +424,7 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
             "roofline": {"kernel": kernel, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value), "alg_bytes_per_launch": int(alg_bytes),
                          "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic},
             **({"other_route": other_route} if other_route else {}),
-            "parity": {k: parity.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "full_lists_checked", "matches_in_checked")},
+            "parity": {k: parity.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "oracle_max_byte_offset", "oracle_what", "full_lists_checked", "matches_in_checked")},
             "build_s": round(build_s, 2), **({"build": build, "gpu_build_plus_run": build_plus_run(n_bytes, build, elapsed / steps * 1e3)} if build else {}),
             **({"contains_all": contains_all} if contains_all else {})}
 
@@ -616,7 +617,22 @@ def bench_single_process(args, w):
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4), "launches": int(launches.value),
                      "alg_bytes_per_launch": int(alg_bytes)},
         "collectives": "libam-rccl",
+        "rccl": {"ranks": N, "self_check": "am_multi_create: one-word all-reduce of (rank + 1) verified on every device", "data_path_collectives": 0},
     }
+    if not args.no_parity:
+        # the same gate as the one-process-per-GPU path, device by device: on every device the route's kernel == k_ac on every haystack of its batch; the oracle's spread
+        # sample in full on device 0, a few haystacks of each of the others
+        import copy
+        blocks = []
+        for i in range(N):
+            torch.cuda.set_device(i)
+            a_i = copy.copy(args)
+            if i:
+                a_i.parity_oracle_mib = max(4, (4 * w["hay_bytes"]) >> 20)
+            blocks.append(parity_gate(a_i, w, needles, machine, C.c_void_p(autos[i]), case, batches[i], texts[i][0], hays[i], 0, 1, torch.device("cuda", i), lib))
+        torch.cuda.set_device(0)
+        out["parity"] = {"per_device": [{k: b.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "oracle_max_byte_offset", "full_lists_checked")} for b in blocks],
+                         "hashed": sum(b["hashed"] for b in blocks), "kernels_agree": all(b["kernels_agree"] is not False for b in blocks), "oracle_what": blocks[0].get("oracle_what")}
     print(json.dumps(out), flush=True)
     for i in range(N):
         lib.am_batch_destroy(batches[i])
