@@ -159,7 +159,8 @@ struct RpLoop {
     RpLoopOut* out;
     uint32_t* ctrl;                                         // [0] overflow, [1] passes (max), [2..3] window bytes scanned, [5] watchdog: the loop that ran out of time (100 +: in k_rp_lds), [6] the longest record list of the batch (k_rp_loop_caps), [7] haystacks k_rp_lds finished, [8..23] eight 64-bit phase sums of the instrumented instantiation
     uint32_t* redo;                                         // per haystack: 1 = k_rp_lds (LDS-resident lists, am_rplds.hip) gave it up, k_rp_loop runs it; null: k_rp_loop runs every haystack
-    uint32_t h_first, pad2;                                 // the launch covers haystacks h_first + blockIdx.x (groups of a batch, one launch each)
+    uint32_t h_first, pl_implicit;                          // the launch covers haystacks h_first + blockIdx.x (groups of a batch, one launch each); pl_implicit: every payload's
+                                                            // priority is minus its index (Replacer.hs:100-104): k_rp_lds needs no payload column (am_rplds.hip, PLI)
 };
 hipError_t launch_rp_loop_caps(const uint64_t* rec_first, uint32_t n_hay, uint32_t* cap_r2, uint32_t* cap_p2, uint32_t* max_records /* atomic max, cleared by the caller */, hipStream_t st);
 hipError_t launch_rp_loop(bool ic, const RpLoop& a, uint32_t n /* haystacks from a.h_first */, int waves_per_simd, hipStream_t st);

@@ -20,6 +20,7 @@ struct am_replacer {
     RpTables t{};
     uint32_t max_repl_len = 0;                        // longest replacement (bounds the re-scan window of the one-kernel loop)
     uint64_t n_repl_bytes = 0;                        // size of the replacement blob
+    bool pl_implicit = false;                         // payloads[i].priority == -i for every i (Replacer.hs:100-104): k_rp_lds runs without its payload column (am_rplds.hip, PLI)
     uint32_t max_needle_bytes = 0;                    // longest needle of the AUTOMATON in bytes (depth of its trie in UTF-8 bytes; 0: unknown) = the longest CaseSensitive match
     // the workspace of the last run (device buffers, pinned scratch, copy stream) is kept for the next one: a caller that
     // rewrites one document per call would otherwise pay ~40 hipMalloc/hipFree (4 ms) each time
@@ -147,6 +148,8 @@ extern "C" int am_replacer_create(const am_automaton* a, int case_mode, const ui
         if (bytes) HIP_TRY(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
         return AM_OK;
     };
+    r->pl_implicit = n_payloads > 0 && n_payloads < (1ull << 31);
+    for (uint64_t i = 0; i < n_payloads && r->pl_implicit; i++) r->pl_implicit = payloads[i].priority == -(int64_t)i;
     int rc = up(r->vals_off, values_offsets, (n_states + 1) * sizeof(uint64_t));
     if (rc == AM_OK) rc = up(r->vals, values, n_values * sizeof(uint32_t));
     if (rc == AM_OK) rc = up(r->payloads, payloads, n_payloads * sizeof(am_payload));
@@ -961,7 +964,7 @@ static int replacer_run_loop(const am_replacer* r, const am_batch* in, uint64_t 
     // right behind, runs exactly those haystacks (lists in global memory).  AM_RP_LDS=0 (A/B, tests), the instrumented instantiation and replacement
     // blobs beyond 2 GiB (piece sources are 31-bit offsets in LDS): k_rp_loop alone.
     const bool use_lds = cfg::get(cfg::kRpLds) != 0 && r->n_repl_bytes < (1ull << 31);
-    a.redo = nullptr; a.h_first = 0;
+    a.redo = nullptr; a.h_first = 0; a.pl_implicit = r->pl_implicit ? 1u : 0u;
     if (use_lds) {
         AM_TRY(s.lp_redo.ensure((size_t)n_hay * 4 + 64));
         HIP_TRY(hipMemsetAsync(s.lp_redo.p, 0, (size_t)n_hay * 4, st));

@@ -24,6 +24,7 @@
 
 #include "am_device.h"
 #include "am_bounds.h"
+#include "am_config.h"
 #include "am_wave.h"
 
 AM_BOUNDS_TU("am_rplds.hip")
@@ -40,8 +41,12 @@ constexpr uint32_t kLdsPc = 448;                          // pieces (+ the senti
 constexpr uint32_t kReplBit = 0x80000000u;                // piece source: offset into the replacement blob instead of the haystack
 constexpr uint32_t kLdsWin = 448;                         // bytes of a re-scan window (the replacement and `ov` bytes either side of it); a longer one: k_rp_loop
 
+// PLI ("payload implicit", round 6): the replacer's payloads carry priority = -index -- what Replacer.build makes of a needle list (Replacer.hs:100-104) --, so a record's
+// payload is its priority negated and the list needs no payload column: 8 160 instead of 10 208 bytes of LDS per haystack and eight registers less in the fold, which is
+// what a FIFTH wavefront per SIMD needs (20 haystacks per CU instead of 16).  A caller's own priorities (am_replacer_create takes any distinct ones) keep the column.
+template <bool PLI>
 struct LpLds {
-    uint32_t end[kLdsRec]; int32_t prio[kLdsRec]; uint32_t pl[kLdsRec];
+    uint32_t end[kLdsRec]; int32_t prio[kLdsRec]; uint32_t pl[PLI ? 1 : kLdsRec];
     uint32_t psrc[kLdsPc + 2]; uint32_t pls[kLdsPc + 2];
     alignas(16) uint8_t win[kLdsWin + 16];                // the window's text: gathered through the piece list, read back by the probe / resolve lanes
 };
@@ -101,9 +106,12 @@ constexpr uint64_t kLdMaxTicks = 4000000000ull;           // watchdog, as in k_r
 
 // DBG (AM_RP_TRACE >= 3): s_memtime per phase of every pass, summed over all haystacks into ctrl[8..27] (64-bit: records in + fold, select + payload, overlap removal,
 // counts + dead slots, piece list, gather, window scan, inserts, the whole run, passes)
-template <bool IC, bool DBG>
-__device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const uint32_t h, const int lane)
+template <bool IC, bool DBG, bool PLI>
+__device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds<PLI>& L, const uint32_t h, const int lane)
 {
+    // the payload of record slot r, given its priority (a state with several values holds its -- positive -- state id there; kDead: no record)
+    auto set_pl = [&](uint32_t r, uint32_t v) { if (!PLI) L.pl[r] = v; };
+    auto pl_of = [&](int32_t pr, uint32_t column) -> uint32_t { return !PLI ? column : pr > 0 ? kRpWalkList : (uint32_t)(-pr); };
     const uint64_t deadline = __builtin_amdgcn_s_memtime() + kLdMaxTicks;
     uint64_t t_mark = DBG ? __builtin_amdgcn_s_memtime() : 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t t_begin = t_mark;
@@ -145,7 +153,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                 e = (uint32_t)rec.end_pos; pl = one.payload;
                 pr = one.payload != kRpWalkList ? one.priority : (int32_t)rec.state;      // several values: the state (> 0, never below a threshold), its list is walked
             }
-            L.end[r] = e; L.prio[r] = pr; L.pl[r] = pl;
+            L.end[r] = e; L.prio[r] = pr; set_pl(r, pl);
             has_walk = has_walk || __ballot(pl == kRpWalkList) != 0ull;
         }
 #pragma unroll
@@ -167,7 +175,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
         // the counts of the first replacement; nothing below reads a record from LDS again unless a pass keeps several matches
         uint32_t e_[kLdsBlocks], l_[kLdsBlocks]; int32_t p_[kLdsBlocks];
 #pragma unroll
-        for (uint32_t b = 0; b < kLdsBlocks; b++) { const uint32_t r = b * kWave + (uint32_t)lane; e_[b] = L.end[r]; p_[b] = L.prio[r]; l_[b] = L.pl[r]; }
+        for (uint32_t b = 0; b < kLdsBlocks; b++) { const uint32_t r = b * kWave + (uint32_t)lane; e_[b] = L.end[r]; p_[b] = L.prio[r]; l_[b] = PLI ? 0u : L.pl[r]; }
         // ---- prependMatch, first half (Replacer.hs:255-258): the best priority below the threshold.  Priorities of single-valued states are 32-bit and
         // <= 0, dead and unused slots hold kDead, states with several values hold their (positive) state id: one compare + select + max per block
         const int32_t thr32 = threshold < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)threshold;      // (threshold <= 1)
@@ -180,7 +188,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             int64_t bw = INT64_MIN;
 #pragma unroll
             for (uint32_t b = 0; b < kLdsBlocks; b++) {
-                if (l_[b] == kRpWalkList && p_[b] != kDead) {
+                if (pl_of(p_[b], l_[b]) == kRpWalkList && p_[b] != kDead) {
                     const uint32_t st = (uint32_t)p_[b];
                     for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
                         const int64_t p = a.t.payloads[a.t.vals[k]].priority;
@@ -202,14 +210,14 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
 #pragma unroll
         for (uint32_t b = 0; b < kLdsBlocks; b++) {
             selmask[b] = __ballot(p_[b] == best32);
-            if (selmask[b]) payload = (uint32_t)__builtin_amdgcn_readlane((int)l_[b], __ffsll((unsigned long long)selmask[b]) - 1);
+            if (selmask[b]) payload = PLI ? (uint32_t)(-best32) : (uint32_t)__builtin_amdgcn_readlane((int)l_[b], __ffsll((unsigned long long)selmask[b]) - 1);
         }
         if (has_walk) {
             uint32_t pw = 0;
 #pragma unroll
             for (uint32_t b = 0; b < kLdsBlocks; b++) {
                 bool sel = false;
-                if (l_[b] == kRpWalkList && p_[b] != kDead) {
+                if (pl_of(p_[b], l_[b]) == kRpWalkList && p_[b] != kDead) {
                     const uint32_t st = (uint32_t)p_[b];
                     for (uint64_t k = a.t.vals_off[st], ke = a.t.vals_off[st + 1]; k < ke; k++) {
                         const uint32_t v = a.t.vals[k];
@@ -335,7 +343,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                     if (r0 >= nr || r0 + kWave <= c_before) continue;    // (uniform) nothing of this block changes
                     const uint32_t r = r0 + (uint32_t)lane;
                     if (r0 < c_gone) {                                   // the block holds dead slots (end = the window's upper bound: the list stays sorted)
-                        if (r >= c_before && r < c_gone) { L.end[r] = hi; L.prio[r] = kDead; L.pl[r] = 0u; }
+                        if (r >= c_before && r < c_gone) { L.end[r] = hi; L.prio[r] = kDead; set_pl(r, 0u); }
                         else if (r >= c_gone && r < nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
                     } else if (delta != 0) {
                         if (r0 + kWave <= nr) L.end[r] = (uint32_t)((int32_t)e_[b] + delta);
@@ -457,7 +465,7 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
                             AM_BOUNDS(at < kLdsRec);
                             L.end[at] = ws + g + 1u;
                             L.prio[at] = one.payload != kRpWalkList ? one.priority : (int32_t)state;
-                            L.pl[at] = one.payload;
+                            set_pl(at, one.payload);
                         }
                         has_walk = has_walk || __ballot(found && one.payload == kRpWalkList) != 0ull;
                         nf += nfb;
@@ -472,20 +480,20 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
             if (nf) {
                 const uint32_t room = c_gone - c_before, staged = nr;
                 uint32_t s_end = 0, s_pl = 0; int32_t s_prio = 0;
-                if ((uint32_t)lane < nf) { s_end = L.end[staged + lane]; s_prio = L.prio[staged + lane]; s_pl = L.pl[staged + lane]; }
+                if ((uint32_t)lane < nf) { s_end = L.end[staged + lane]; s_prio = L.prio[staged + lane]; s_pl = PLI ? 0u : L.pl[staged + lane]; }
                 wave_lds_fence();
-                if ((uint32_t)lane < nf) { L.end[staged + lane] = kNoPos; L.prio[staged + lane] = kDead; L.pl[staged + lane] = 0u; }      // (unused slots again, unless the list grows into them)
+                if ((uint32_t)lane < nf) { L.end[staged + lane] = kNoPos; L.prio[staged + lane] = kDead; set_pl(staged + lane, 0u); }      // (unused slots again, unless the list grows into them)
                 wave_lds_fence();
                 if (nf > room) {
                     const int32_t g = (int32_t)(nf - room);
                     if ((int64_t)nr + g > (int64_t)kLdsRec) { redo = true; break; }
                     ld_move(L.end, c_gone, nr, g, 0u, lane);
                     ld_move(reinterpret_cast<uint32_t*>(L.prio), c_gone, nr, g, 0u, lane);
-                    ld_move(L.pl, c_gone, nr, g, 0u, lane);
+                    if (!PLI) ld_move(L.pl, c_gone, nr, g, 0u, lane);
                     nr = (uint32_t)((int32_t)nr + g);
                 }
                 AM_BOUNDS(c_before + nf <= kLdsRec && staged + nf <= kLdsRec);
-                if ((uint32_t)lane < nf) { L.end[c_before + lane] = s_end; L.prio[c_before + lane] = s_prio; L.pl[c_before + lane] = s_pl; }
+                if ((uint32_t)lane < nf) { L.end[c_before + lane] = s_end; L.prio[c_before + lane] = s_prio; set_pl(c_before + lane, s_pl); }
                 wave_lds_fence();
             }
             curlen = newlen;
@@ -526,20 +534,21 @@ __device__ __forceinline__ void ld_run_haystack(const RpLoop& a, LpLds& L, const
 
 }  // namespace
 
-template <bool IC, bool DBG = false>
-__global__ void __launch_bounds__(64, 4) k_rp_lds(RpLoop a)
+template <bool IC, bool DBG = false, bool PLI = false>
+__global__ void __launch_bounds__(64, PLI ? 5 : 4) k_rp_lds(RpLoop a)
 {
-    __shared__ LpLds L;
+    __shared__ LpLds<PLI> L;
     const uint32_t h = a.h_first + blockIdx.x;
-    ld_run_haystack<IC, DBG>(a, L, h, (int)(threadIdx.x & (kWave - 1)));
+    ld_run_haystack<IC, DBG, PLI>(a, L, h, (int)(threadIdx.x & (kWave - 1)));
 }
 
 hipError_t launch_rp_lds(bool ic, const RpLoop& a, uint32_t n, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
-    if (ic) hipLaunchKernelGGL((k_rp_lds<true>), dim3(n), dim3(64), 0, st, a);
-    else if (a.pad) hipLaunchKernelGGL((k_rp_lds<false, true>), dim3(n), dim3(64), 0, st, a);          // per-phase cycle sums (AM_RP_TRACE >= 3)
-    else hipLaunchKernelGGL((k_rp_lds<false>), dim3(n), dim3(64), 0, st, a);
+    const bool pli = a.pl_implicit != 0 && !cfg::on(cfg::kRpNoPli);
+    if (a.pad) { if (ic) hipLaunchKernelGGL((k_rp_lds<true, true>), dim3(n), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_rp_lds<false, true>), dim3(n), dim3(64), 0, st, a); }      // per-phase cycle sums (AM_RP_TRACE >= 3)
+    else if (ic) { if (pli) hipLaunchKernelGGL((k_rp_lds<true, false, true>), dim3(n), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_rp_lds<true>), dim3(n), dim3(64), 0, st, a); }
+    else { if (pli) hipLaunchKernelGGL((k_rp_lds<false, false, true>), dim3(n), dim3(64), 0, st, a); else hipLaunchKernelGGL((k_rp_lds<false>), dim3(n), dim3(64), 0, st, a); }
     return hipGetLastError();
 }
 

@@ -14,7 +14,7 @@ for spec in cfg3_runLower_100k_10GiB:2048 cfg2_runText_10k_1GiB:32768 cfg4_100k_
     timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$OUT/$W/$C" -o p -- python "$R/bench.py" --workload $W --hay-count $N --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-h2d > "$OUT/$W.$C.log" 2>&1
     echo "$W $C rc=$?"
   done
-  K=k_sf; [ "$W" = natural_100k_10GiB ] && K=k_dfa        # the dictionary takes the table-walk route (csrc/am_dfa.hip)
+  K=k_sf; [ "$W" = natural_100k_10GiB ] && K=k_dfa        # the dictionary takes the table-walk route (csrc/am_dfa.hip): k_dfa<...> and k_dfa_place both match
   python "$R/tools/pmc_summary.py" "$OUT/$W" "$K" > "$OUT/$W.txt" 2>&1
   rm -rf "$OUT/$W"
 done
