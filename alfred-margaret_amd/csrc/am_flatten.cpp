@@ -143,6 +143,7 @@ struct Blob {
 uint32_t log2_ceil(uint64_t n) { uint32_t l = 0; while ((1ull << l) < n) l++; return l; }
 
 struct TierEntry { uint32_t key, node; };
+constexpr size_t kDfaSmallStates = 32768;     // automata up to this many states get a DFA section unasked (am_flatten.cpp, DFA section)
 
 }  // namespace
 
@@ -813,7 +814,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         // will the automaton get a DFA section?  AM_DFA decides, or -- unset -- whether the suffix tables below give heavy depth-4 nodes their children (sf_t4_children > 0):
         // the same test the tables make, made here so that the section's work starts now and not behind them
         const long dfa_cfg = cfg::get(cfg::kDfa);
-        bool likely = dfa_cfg != cfg::kUnset ? dfa_cfg != 0 : false;
+        bool likely = dfa_cfg != cfg::kUnset ? dfa_cfg != 0 : S <= kDfaSmallStates;
         if (dfa_cfg == cfg::kUnset && !cfg::on(cfg::kSfNoChildren)) {
             size_t keys = 0, potential = 0;
             for (int t = 0; t < 4; t++) keys += tier_entries[t].size();
@@ -1084,7 +1085,10 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     // the DFA section: made by the task started below the suffix trie (or here, when it was not started), kept only if the automaton turned out to be a dictionary
     {
         const long dfa_cfg = cfg::get(cfg::kDfa);
-        const bool want = dfa_cfg == cfg::kUnset ? h.sf_t4_children > 0 : dfa_cfg != 0;
+        // unset: dictionaries (the suffix tables gave heavy depth-4 nodes their children), and every SMALL automaton -- its table costs nothing (32k states x 64 classes = 8 MiB
+        // at most) and whether a batch takes it is the sample walk's decision (am_abi.cpp make_plan): three needles that end at every position of the text (needles a, aa, aaa
+        // over a...a: 43 GiB/s on the filter, output-bound) are the table walk's case as much as a dictionary over its language
+        const bool want = dfa_cfg == cfg::kUnset ? (h.sf_t4_children > 0 || S <= kDfaSmallStates) : dfa_cfg != 0;
         DfaOut o;
         if (dfa_task.valid()) { dfa_task.get(); if (want) o = std::move(dfa_early); }
         else if (want) make_dfa(o);

@@ -93,11 +93,57 @@ def test_unit_boundaries_inside_matches_and_code_points(dfa_everywhere, chunk):
 
 
 def test_no_dfa_section_is_an_error_only_when_forced():
-    a = am.Automaton(["needle", "hay"])                   # random short needles: the flattener gives no DFA section by itself
+    am.debug_set("AM_DFA", 0)                             # (unset, a small automaton gets a DFA section since round 6; a large set of random needles does not: this makes one without)
+    a = am.Automaton(["needle", "hay"])
     assert [int(c) for c in a.count_matches(0, ["hay needle hay"])] == [3]
     a.set_kernel(3)
     with pytest.raises(am.AmError):
         a.count_matches(0, ["hay needle hay"])
+
+
+def test_small_automata_get_the_table_walk_for_match_dense_batches():
+    """Round 6: an automaton of up to 32k states carries a DFA section unasked (its table is at most 8 MiB), and a batch of 32 MiB and more is routed by the sample walk: three
+    needles that end at EVERY position (a, aa, aaa over a...a: a record per byte, 16 output bytes per input byte) take k_dfa -- tokens for every byte of every unit, the pool's first
+    guess from the sample's density --, the same needles over text without them stay on the filter; both equal the oracle on sampled haystacks and the filter on all."""
+    import torch
+    a = am.Automaton(["a", "aa", "aaa"])
+    o = oracle.Machine(["a", "aa", "aaa"])
+    dev = torch.device("cuda:0")
+    n_hay, hb = 48, 1 << 20
+    lib = am.api.libam()
+    for fill, want_dfa in ((ord("a"), True), (ord("b"), False)):
+        text = torch.full((n_hay * hb + 64,), fill, dtype=torch.uint8, device=dev)
+        text[n_hay * hb:] = 0
+        offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * hb
+        b = C.c_void_p()
+        am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_hay * hb, C.byref(b)))
+        try:
+            res = {}
+            for kernel in (0, 2):
+                a.set_kernel(kernel)
+                am.api.check(lib.am_profile_reset()); am.api.check(lib.am_profile_enable(1))
+                m = C.c_void_p()
+                am.api.check(lib.am_run_batch(a.device, 0, b, C.byref(m)))
+                torch.cuda.synchronize()
+                am.api.check(lib.am_profile_enable(0))
+                ms, n = C.c_double(0), C.c_uint64(0)
+                lib.am_profile_read(b"dfa", C.byref(ms), C.byref(n))
+                if kernel == 0:
+                    assert (n.value > 0) == want_dfa
+                rs = am.api.matches_of_haystack(m, n_hay - 1)
+                res[kernel] = (int(lib.am_matches_size(m)), rs.copy())
+                lib.am_matches_free(m)
+            assert res[0][0] == res[2][0] == (n_hay * hb if want_dfa else 0)
+            assert np.array_equal(res[0][1], res[2][1])
+            if want_dfa:
+                pos, val = o.run_list(0, bytes([fill]) * 4096)
+                st = res[0][1]["state"][:4096].astype(np.int64)
+                vo, vals = a.values_off(), a.values()
+                got = [(int(p), int(v)) for p, s_ in zip(res[0][1]["end_pos"][:4096], st) for v in vals[int(vo[s_]):int(vo[s_ + 1])]]
+                assert got == list(zip(pos.tolist(), val.tolist()))
+        finally:
+            a.set_kernel(0)
+            lib.am_batch_destroy(b)
 
 
 def test_dictionary_takes_the_table_walk_by_itself(dfa_from_one_mib):
