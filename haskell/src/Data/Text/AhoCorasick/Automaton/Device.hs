@@ -76,7 +76,8 @@ instance Storable AmMatch where
   poke p (AmMatch e h s) = pokeByteOff p 0 e >> pokeByteOff p 8 h >> pokeByteOff p 12 s
 
 -- am_automaton_create_ex = am_automaton_create + the host's own lower-casing as data (see 'lowerPairs')
-foreign import ccall unsafe "am_automaton_create_ex"
+-- safe: the call flattens the automaton (hundreds of milliseconds for 100k needles, a DFA table of up to 1 GiB for a dictionary): unsafe would block the capability and GC
+foreign import ccall safe "am_automaton_create_ex"
   c_am_automaton_create_ex :: Ptr Word64 -> CSize -> Ptr Word32 -> CSize -> Ptr Word64 -> Ptr Word32
                            -> Ptr Word32 -> Ptr Word32 -> CSize -> Ptr (Ptr AmAutomaton) -> IO CInt
 foreign import ccall unsafe "&am_automaton_destroy"

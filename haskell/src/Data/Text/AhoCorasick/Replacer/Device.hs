@@ -20,6 +20,7 @@ import Foreign.C.Types
 
 import qualified Data.Primitive.ByteArray as BA
 import qualified Data.Text.Array as TextArray
+import qualified Data.IntMap.Strict as IntMap
 import qualified Data.Vector as Vector
 
 import Data.Text.AhoCorasick.Automaton (AcMachine (..), CodeUnitIndex (..))
@@ -43,7 +44,8 @@ instance Storable AmPayload where
     pokeByteOff p 0 pr >> pokeByteOff p 8 lb >> pokeByteOff p 12 lc >> pokeByteOff p 16 off >> pokeByteOff p 24 len >> pokeByteOff p 28 (0 :: Word32)
   peek p = AmPayload <$> peekByteOff p 0 <*> peekByteOff p 8 <*> peekByteOff p 12 <*> peekByteOff p 16 <*> peekByteOff p 24
 
-foreign import ccall unsafe "am_replacer_create"
+-- safe: the call flattens nothing itself but uploads tables and may wait for the IgnoreCase image (milliseconds to a second): an unsafe call would hold the capability and stall GC
+foreign import ccall safe "am_replacer_create"
   c_am_replacer_create :: Ptr Dev.AmAutomaton -> CInt -> Ptr Word64 -> Ptr Word32 -> Ptr AmPayload -> CSize
                        -> Ptr Word8 -> CSize -> Int64 -> Ptr (Ptr AmReplacer) -> IO CInt
 foreign import ccall unsafe "&am_replacer_destroy"
@@ -68,8 +70,10 @@ toDevice (Replacer.Replacer s) = do
   dm <- Dev.toDevice (Searcher.automaton s)
   let values   = machineValues (Dev.dmMachine dm)
       payloads = map snd (Searcher.needles s)
-      -- priorities are distinct (build: 0, -1, -2, ...; compose keeps them distinct): the index of a payload = its rank by priority
-      indexOf p = length (takeWhile ((/= Replacer.needlePriority p) . Replacer.needlePriority) payloads)
+      -- priorities are distinct (build: 0, -1, -2, ...; compose keeps them distinct): a payload's index is looked up by its priority in a map built once
+      -- (a linear search per value made a 100k-needle replacer quadratic: ADVICE r5)
+      prioIndex = IntMap.fromList (zip (map (fromIntegral . Replacer.needlePriority) payloads) [0 :: Int ..])
+      indexOf p = IntMap.findWithDefault (error "Replacer.toDevice: a value's payload is not among the needles") (fromIntegral (Replacer.needlePriority p)) prioIndex
       offsets  = scanl (+) 0 (map (fromIntegral . length) (Vector.toList values)) :: [Word64]
       flat     = [ fromIntegral (indexOf p) | ps <- Vector.toList values, p <- ps ] :: [Word32]
       repls    = map (Utf8.unpackUtf8 . Replacer.needleReplacement) payloads
