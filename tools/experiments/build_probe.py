@@ -8,8 +8,12 @@ from alfred_margaret_amd import synth
 
 lib = am.api.libam()
 for wl in sys.argv[1:] or ["cfg3_runLower_100k_10GiB", "natural_100k_10GiB"]:
-    w = synth.WORKLOADS[wl]
-    needles = synth.needles_for(wl)
+    if wl.startswith("n="):                       # n=<count>: that many random mixed-case needles, lower-cased, IgnoreCase (the scale check: 1 000 000)
+        w = {"case": am.IGNORE_CASE}
+        needles = [am.lower_utf8(s).decode("utf-8") for s in synth.make_needles(int(wl[2:]), True)]
+    else:
+        w = synth.WORKLOADS[wl]
+        needles = synth.needles_for(wl)
     for serial in (1, -1, 1, -1):
         am.api.debug_set("AM_FLATTEN_SERIAL", serial)
         t0 = time.perf_counter(); a = am.Automaton(needles); t1 = time.perf_counter()
