@@ -18,7 +18,7 @@ for w, (n_hay, hb) in SPEC.items():
     blocks = open(f).read().split("### ")
     kernel = "k_rp_lds" if w.startswith("cfg5") else "k_dfa + k_dfa_place" if w.startswith("natural") else "k_sf"
     # k_dfa: MODE = 16, records in one walk (tokens) -- and k_dfa_place, which turns the tokens into the records: the step's bytes are the pair's; k_sf: MODE = 1, the match-emitting instantiation
-    patterns = {"k_rp_lds": [r"void am::dev::k_rp_lds<false, false>"], "k_dfa + k_dfa_place": [r"void am::dev::k_dfa<16,", r"am::dev::k_dfa_place"],
+    patterns = {"k_rp_lds": [r"void am::dev::k_rp_lds<false, false"], "k_dfa + k_dfa_place": [r"void am::dev::k_dfa<16,", r"am::dev::k_dfa_place"],
                 "k_sf": [r"void am::dev::k_sf<(true|false), 1,"]}[kernel]
     vals, per_kernel = {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, {}
     for pattern in patterns:
