@@ -5,6 +5,7 @@
 // container.  It is NOT part of libam.so and no product entry point reaches it: the product has no
 // CPU execution path at all (am_abi.cpp fails with AM_ERR_NO_DEVICE without a GPU).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -122,6 +123,8 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
     std::vector<uint32_t> age((size_t)(n_sets * ways), 0);
     uint32_t clock = 0;
     const bool text_no_alloc = std::getenv("SIM_TEXT_NO_ALLOC") != nullptr;
+    const uint32_t what_if_class = std::getenv("SIM_RESET_BYTE") ? d.cls[(uint8_t)std::atoi(std::getenv("SIM_RESET_BYTE"))] : 0u;
+    uint64_t wi[2] = {0, 0};
     auto touch = [&](int cat, uint64_t addr) {
         const uint64_t line = addr >> 7, set = (line * 0x9E3779B97F4A7C15ull >> 20) % n_sets;
         out12[2 * cat]++;
@@ -167,10 +170,20 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
                     }
                 }
                 e = dfa_common_step(d, state[l], cl);
+                if (what_if_class && cl == what_if_class && e == 0u) {      // (what-if: steps on this class that lead to the root, and the requests they cost today)
+                    wi[0]++;
+                    const uint32_t s0 = state[l];
+                    uint32_t req = 0, row = s0;
+                    if (s0 >= d.n_rows) { req++; row = d.chain[s0 - d.n_rows].y & 0xFFFFFFu; }
+                    if (!(row < hot_rows && cl <= 32u)) req++;
+                    wi[1] += req;
+                }
             }
             state[l] = e & kDfaStateMask;
         }
     }
+    if (what_if_class) std::fprintf(stderr, "[l2sim] class %u: %llu steps lead to the root (%.4f per step), costing %llu requests today (%.4f per step)\n", what_if_class,
+                                    (unsigned long long)wi[0], (double)wi[0] / ((double)lanes * unit), (unsigned long long)wi[1], (double)wi[1] / ((double)lanes * unit));
     return 0;
 }
 
