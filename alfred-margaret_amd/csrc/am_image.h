@@ -457,7 +457,7 @@ AM_HD uint32_t t4_slot_diff(uint32_t slot, uint32_t expect)
 // two 8-byte buckets.
 template <int N>
 AM_HD void sf_probe_issue(const SfView& s, const uint32_t (&w)[N], const uint32_t (&nbs)[N], const uint64_t (&avail)[N], const bool (&valid)[N],
-                          u32x2 (&ba)[N], u32x2 (&bb)[N], uint32_t (&expect)[N])
+                          u32x2 (&ba)[N], u32x2 (&bb)[N], uint32_t (&expect)[N], const bool one_bucket = false /* timing experiment (AM_SF_ABLATE=12): the second load asks for the first bucket again; wrong results */)
 {
     const uint32_t lb = s.tier_log2_cap[3];
 #pragma unroll
@@ -468,7 +468,7 @@ AM_HD void sf_probe_issue(const SfView& s, const uint32_t (&w)[N], const uint32_
         ba[k] = u32x2{0, 0}; bb[k] = ba[k];                      // empty buckets for the lanes that do not probe
         if (probe) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const uint2 ra = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(ha, lb)), rb = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(hb, lb));
+            const uint2 ra = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(ha, lb)), rb = *reinterpret_cast<const uint2*>(s.t4_hot + t4_bucket(one_bucket ? ha : hb, lb));
             ba[k] = u32x2{ra.x, ra.y}; bb[k] = u32x2{rb.x, rb.y};
 #else
             ba[k] = s.t4_hot[t4_bucket(ha, lb)]; bb[k] = s.t4_hot[t4_bucket(hb, lb)];

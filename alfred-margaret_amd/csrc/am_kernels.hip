@@ -724,13 +724,13 @@ __global__ __launch_bounds__(NT) void k_sf(SfView s, BatchView b, ScanOut o, uin
                         if (valid[k] && !single) avail[k] = gpos - b.offsets[find_haystack(b, gpos)] + 1;
                         p_pos[k] = valid[k] ? (pos | 0x8000u) : 0u;
                     }
-                    if (two) sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e);
+                    if (two) sf_probe_issue<2>(s, w, nb, avail, valid, p_a, p_b, p_e, ablate == 12);
                     else {
                         const uint32_t w1[1] = {w[0]}, nb1[1] = {nb[0]};
                         const uint64_t av1[1] = {avail[0]};
                         const bool v1[1] = {valid[0]};
                         u32x2 a1[1], b1[1]; uint32_t e1[1];
-                        sf_probe_issue<1>(s, w1, nb1, av1, v1, a1, b1, e1);
+                        sf_probe_issue<1>(s, w1, nb1, av1, v1, a1, b1, e1, ablate == 12);
                         p_a[0] = a1[0]; p_b[0] = b1[0]; p_e[0] = e1[0];
                     }
                     p_two = two;
@@ -958,7 +958,7 @@ hipError_t launch_sf(bool ic, int mode, const SfView& s, const BatchView& b, con
     o.ablate = ablate;
     o.probe_two = cfg::on(cfg::kSfProbeTwo) ? 1u : 0u;
     static uint64_t* dbg = nullptr;
-    if (ablate >= 8) {
+    if (ablate >= 8 && ablate != 12) {                     // (12: the one-bucket timing experiment, no phase sums)
         if (!dbg) { if (hipMalloc((void**)&dbg, 256 + 16 * 8192) != hipSuccess) dbg = nullptr; else (void)hipMemset(dbg, 0, 256 + 16 * 8192); }
         o.dbg = dbg;
         g_sf_dbg = dbg;
