@@ -296,3 +296,56 @@ def test_ragged_batch_of_tiny_haystacks_on_the_table_walk(dfa_from_one_mib):
     k = 2000
     sel = auto[auto["haystack"] < k]
     assert expand_records(o.values_off(), o.values(), sel["haystack"], sel["state"], sel["end_pos"]) == oracle_triples(o, w["case"], hays[:k])
+
+
+@pytest.mark.parametrize("chunk", [64, 2048])
+def test_sparse_matches_over_many_groups_seal_superblocks_by_age(dfa_everywhere, chunk):
+    """A token names its group by a 4-bit ordinal counted from its superblock's first group, so a wavefront's superblock is sealed after 16 of its groups however empty it is
+    (k_dfa, round 6).  Text with few matches and small units makes every wavefront take dozens of groups per superblock: cfg3's kind of needles over random text, 1 GiB in units
+    of 64 bytes = 262 144 groups of 4 KiB over 8 192 wavefronts, 32 groups each (and 96 MiB in units of 2 048 bytes: superblocks that live for a wavefront's whole share), forced onto
+    the table walk -- the records, counts and flags must be the suffix filter's, and the oracle's on sampled haystacks.  Ragged haystacks (1 KiB ... 300 KiB, some empty) put haystack
+    boundaries into most groups."""
+    import torch
+    am.debug_set("AM_DFA_CHUNK", chunk)
+    needles = [am.lower_utf8(n).decode("utf-8") for n in synth.make_needles(3000, True)]
+    a, o = am.Automaton(needles), oracle.Machine(needles)
+    dev = torch.device("cuda:0")
+    n_cells = (1024 if chunk == 64 else 96) * 1024
+    text, n_bytes = synth.haystacks_device(needles, True, 0, n_cells, dev)
+    sizes, at, k = [0], 0, 0
+    pattern = (1, 300, 0, 7, 64, 0, 0, 129, 2, 33)
+    while at < n_cells:
+        at = min(n_cells, at + pattern[k % len(pattern)]); sizes.append(at << 10); k += 1
+    offs_h = np.asarray(sizes, dtype=np.int64)
+    n_hay = len(offs_h) - 1
+    offs = torch.from_numpy(offs_h).to(dev)
+    lib = am.api.libam()
+    b = C.c_void_p()
+    am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(b)))
+    try:
+        got = {}
+        for kernel in (3, 2):
+            a.set_kernel(kernel)
+            m = C.c_void_p()
+            am.api.check(lib.am_run_batch(a.device, 1, b, C.byref(m)))
+            recs = am.api.matches_to_numpy(m)
+            lib.am_matches_free(m)
+            counts = np.zeros(n_hay, np.uint64); tot = C.c_uint64(0)
+            am.api.check(lib.am_count_batch(a.device, 1, b, counts.ctypes.data, C.byref(tot)))
+            flags = np.zeros(n_hay, np.uint8)
+            am.api.check(lib.am_contains_any_batch(a.device, 1, b, flags.ctypes.data))
+            got[kernel] = (recs, counts, flags, tot.value)
+        assert len(got[3][0]) > 100000
+        assert np.array_equal(got[3][0], got[2][0]) and np.array_equal(got[3][1], got[2][1]) and np.array_equal(got[3][2], got[2][2]) and got[3][3] == got[2][3]
+        recs = got[3][0]
+        first = np.searchsorted(recs["haystack"], np.arange(n_hay + 1))
+        vo, vals = a.values_off(), a.values()
+        for i in list(range(0, n_hay, max(1, n_hay // 12))) + [n_hay - 1]:
+            h = text[int(offs_h[i]):int(offs_h[i + 1])].cpu().numpy()
+            pos, val = o.run_list(1, h)
+            rs = recs[first[i]:first[i + 1]]
+            exp = expand_records(vo, vals, rs["haystack"], rs["state"], rs["end_pos"])
+            assert exp == [(i, int(p), int(v)) for p, v in zip(pos, val)], (chunk, i)
+    finally:
+        a.set_kernel(0)
+        lib.am_batch_destroy(b)
