@@ -11,7 +11,7 @@
 // What bounds it (round 6, profiles/r06_pmc_dfa.md): the wavefronts wait 92 % of their time, and not for latency -- half the wavefronts per CU give 86 % of the rate.  Every
 // lane-load is an L2 request (2 048 lanes per CU touch 2 048 different lines between two visits of one lane: the 32-KiB L1 holds nothing, 97 % of its accesses go on), and a
 // request that misses the XCD's 4-MiB L2 moves a whole line over the fabric.  So the kernel is written to the two currencies "L2 requests per byte" and "lines per
-// byte": the byte class and the hottest rows in LDS, a chain record in ONE 8-byte load, a byte no needle contains answered without any load (it leads to the root from
+// byte": the byte class and the hottest rows in LDS, a record in ONE 8- or 16-byte load, a byte no needle contains answered without any load (it leads to the root from
 // everywhere), text asked for 64 bytes at a time, and the first 16 columns of every row a second time in a table of their own where two rows share a line (am_flatten.cpp).
 //
 // Work split: unit u = bytes [u * chunk, (u + 1) * chunk) of the concatenated batch, one lane each; the lane owns the matches whose LAST byte lies in its unit and
@@ -53,11 +53,12 @@ constexpr uint32_t kTokPosBits = 13, kTokOrdShift = 28, kTokMaxOrd = 16, kTokMax
 constexpr uint32_t kLdsLog2Cols = 5;          // LDS holds columns 1 .. 32 of the first rows (the classes are numbered by the dictionary's use of them: 31 are 98 % of natural text)
 
 typedef uint32_t u32x2_v __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(8)));      // a record read: 16 bytes from an 8-byte boundary
 typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 __device__ __forceinline__ uint32_t lds_read_u8(uint32_t byte_addr) { return *reinterpret_cast<const lds_u8_t*>((uintptr_t)byte_addr); }
 
 // hot table and chain records as byte offsets from `next` (the flattener puts them behind the rows; launch_dfa_tw checks that the section spans < 4 GiB)
-struct DfaDev { const uint8_t* base; uint32_t off_hot, off_chain; };
+struct DfaDev { const uint8_t* base; uint32_t off_hot, off_chain, off_chain2; };
 
 template <int MODE>
 struct DfaLane {
@@ -81,7 +82,8 @@ struct DfaLane {
         if (MODE == kModeAny) { o.flags[hay] = 1; return; }
         if (MODE == kModeTokens) {
             if (sb != kNone) {
-                const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the block)
+                const uint32_t slot = atomicAdd(&wv[0], 1u);          // (LDS; < kDfaSuper by the reserve made at the top of the block.  A rank from the ballot of the finders + one
+                                                                      // write by the first of them instead of the atomic: measured, no faster -- LABNOTES R6.8)
                 AM_BOUNDS(slot < kDfaSuper && sb < o.n_blocks && ord < kTokMaxOrd && in_unit < kTokMaxChunk && nrec < kTokMaxChunk && state < d.n_states);
                 u32x2_v t; t.x = state | (ord << kTokOrdShift); t.y = in_unit | (nrec << kTokPosBits) | (lane_id() << 26);
                 reinterpret_cast<u32x2_v*>(o.pool)[(uint64_t)sb * kDfaSuper + slot] = t;      // (the DFA state: k_dfa_place looks the reference state up, off the walk's dependent chain)
@@ -107,18 +109,30 @@ struct DfaLane {
     }
 };
 
-// delta(state, class) for a byte with a column (dfa_common_step in am_image.h is the plain form): a chain state answers with its child or hands the question to its
-// fallback's row -- ONE 8-byte load; a byte no needle contains (class 0) leads to the root; the first rows' first columns sit in LDS; the first columns of every row in
+// delta(state, class) for a byte with a column (dfa_common_step in am_image.h is the plain form): a record state answers with a child or hands the question to the state
+// it falls back to -- ONE 8- or 16-byte load per record; a byte no needle contains (class 0) leads to the root; the first rows' first columns sit in LDS; the first columns of every row in
 // the hot table; one global load serves the hot and the cold case (both tables lie behind `next`).
-__device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, uint32_t lds_rows_addr, uint32_t hot_rows, uint32_t state, uint32_t cl)
+// (pf: the 16 bytes read at a single-entry record hold the next record of its path as well; a lane that follows the path finds it here and asks for nothing)
+struct DfaAhead { uint32_t state = kNone, x = 0, y = 0; };
+__device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, uint32_t lds_rows_addr, uint32_t hot_rows, uint32_t state, uint32_t cl, DfaAhead& pf)
 {
     if (cl == 0u) return 0u;
     AM_BOUNDS(state < d.n_states && cl < (1u << d.log2_classes));
-    if (state >= d.n_rows) {
-        const u32x2_v r = *reinterpret_cast<const u32x2_v*>(v.base + v.off_chain + ((state - d.n_rows) << 3));
-        AM_BOUNDS((r.y & 0xFFFFFFu) < d.n_rows);
-        if ((r.y >> 24) == cl) return r.x;
-        state = r.y & 0xFFFFFFu;
+    if (state >= d.n_rows) {                                // a record state (at most two entries): an entry answers, else the row state it leans on
+        // ONE 16-byte load for both kinds (a divergent if / else would be two dependent trips per turn): a single-child record is the first half of what is read
+        // (the flattener pads the table by a record), a two-children record all of it
+        const bool two = state >= d.n_rows + d.n_single;
+        const uint32_t at = two ? v.off_chain2 + ((state - d.n_rows - d.n_single) << 4) : v.off_chain + ((state - d.n_rows) << 3);
+        u32x4_u q;
+        if (!two && state == pf.state) { q.x = pf.x; q.y = pf.y; q.z = 0u; q.w = 0u; pf.state = kNone; }
+        else {
+            q = *reinterpret_cast<const u32x4_u*>(v.base + at);
+            if (!two) { pf.state = state + 1u; pf.x = q.z; pf.y = q.w; }      // (state + 1 may be the first two-entry record: what was read there is the table's pad, and `two` keeps it from being used)
+        }
+        if ((q.y >> 24) == cl) return q.x;
+        if (two && (q.w >> 24) == cl) return q.z;
+        state = q.y & 0xFFFFFFu;
+        AM_BOUNDS(state < d.n_rows);
     }
     const bool in_lds = state < hot_rows && cl <= (1u << kLdsLog2Cols);
     uint32_t e;
@@ -135,7 +149,7 @@ __device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, 
 // different lines and uses an eighth of each; the other pieces come 16, 32, ... steps (tens of microseconds) later, by when the line has long left the L2 (an XCD's L2
 // turns over every ~5 us here): eight L2 misses per line of text.  With TW = 64 a lane asks for half a line at once (four loads issued back to back, held in registers:
 // buf[0] = the next block, the blocks move down one place per 16 steps): two.
-template <int MODE, int TW, bool NT>
+template <int MODE, int TW, int VAR>
 __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v, const uint8_t* tp, uint64_t tp_off, uint32_t lds_cls_addr, uint32_t lds_rows_addr,
                                               uint32_t hot_rows, uint32_t W, uint32_t end_r)
 {
@@ -154,6 +168,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
                                                                                                  // state at cs depends on the `warm` bytes before it only, but the plain form does not either)
     uint32_t he_r = he64 - tp_off < 0xFFFFFFFFull ? (uint32_t)(he64 - tp_off) : 0xFFFFFFFFu;
     uint32_t state = 0;
+    DfaAhead pf;
     u32x4_n buf[NV];
     uint32_t avail = 0;                                     // blocks in buf (only blocks that lie wholly inside the haystack and the unit are ever asked for)
     bool rare_next = false;                                 // the byte at pos has no column: the byte-by-byte path takes it (and the bytes up to the next block)
@@ -191,7 +206,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
                 AM_BOUNDS(tp_off + pos + 16u <= ((b.total + 15u) & ~15ull) && tp_off + pos >= hs && pos < ce_r);
                 if (NV > 1 && (pos & (uint32_t)(TW - 1)) == 0 && pos + (uint32_t)TW <= lim) {
 #pragma unroll
-                    for (int j = 0; j < NV; j++) buf[j] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j)) : *reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j);
+                    for (int j = 0; j < NV; j++) buf[j] = *reinterpret_cast<const u32x4_n*>(tp + pos + 16u * j);
                     avail = NV;
                 } else {
                     buf[0] = *reinterpret_cast<const u32x4_n*>(tp + pos);
@@ -201,6 +216,41 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
             // A byte without a column (a byte in a thousand, by the flattener's choice of the columns) ends the lane's block: the byte-by-byte path below walks it, and the
             // fall-back walk's registers stay out of this loop.
             uint32_t done = 16u;
+            if (VAR == 1) {
+                // The lanes of a wavefront do not keep step inside a block: a lane whose byte needs a second trip (a record that hands the question on) takes it in the
+                // next turn while its neighbours go on to their next byte, and the wavefront waits for ONE load per turn -- the same instruction for a record and for an
+                // entry of a row (16 aligned bytes; what was asked for is picked out of them).  A block costs the turns of its slowest lane, not 16 x the slowest step.
+                uint32_t cur = 0;
+                while (cur < 16u) {
+                    const uint32_t word = cur < 8u ? (cur < 4u ? buf[0].x : buf[0].y) : (cur < 12u ? buf[0].z : buf[0].w);
+                    const uint32_t cl = lds_read_u8(lds_cls_addr + ((word >> ((cur & 3u) << 3)) & 0xFFu));
+                    if (cl == kDfaRare) { done = cur; break; }
+                    uint32_t e = 0u;
+                    bool adv = true;
+                    if (cl != 0u) {
+                        AM_BOUNDS(state < d.n_states && cl < (1u << d.log2_classes));
+                        const bool rec = state >= d.n_rows, two = state >= d.n_rows + d.n_single;
+                        const bool in_lds = state < hot_rows && cl <= (1u << kLdsLog2Cols);
+                        const uint32_t off = rec ? (two ? v.off_chain2 + ((state - d.n_rows - d.n_single) << 4) : v.off_chain + ((state - d.n_rows) << 3))
+                                                 : (cl <= (1u << d.hot_log2) ? v.off_hot + (((state << d.hot_log2) + cl - 1u) << 2) : (((state << d.log2_classes) + cl) << 2));
+                        u32x4_n q = {0u, 0u, 0u, 0u};
+                        if (!in_lds) q = *reinterpret_cast<const u32x4_n*>(v.base + (off & ~15u));
+                        if (in_lds) e = lds_read_u32(lds_rows_addr + (((state << kLdsLog2Cols) + cl - 1u) << 2));
+                        else {
+                            const uint32_t lo = (off & 8u) ? q.z : q.x, hi = (off & 8u) ? q.w : q.y;      // the 8 bytes the offset names
+                            if (!rec) e = (off & 4u) ? hi : lo;
+                            else if ((hi >> 24) == cl) e = lo;
+                            else if (two && (q.w >> 24) == cl) e = q.z;
+                            else { state = hi & 0xFFFFFFu; adv = false; AM_BOUNDS(state < d.n_rows); }
+                        }
+                    }
+                    if (adv) {
+                        state = e & kDfaStateMask;
+                        if ((e >> kDfaEndShift) && mine) L.found(h, pos + cur - cs_r, tp_off + pos + (uint64_t)cur + 1u - hs, state, e >> kDfaEndShift);
+                        cur++;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t cur = q == 0 ? buf[0].x : q == 1 ? buf[0].y : q == 2 ? buf[0].z : buf[0].w;
@@ -211,13 +261,14 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
                     if (done == 16u) {
                         if (cl == kDfaRare) done = (uint32_t)(4 * q + i);
                         else {
-                            const uint32_t e = dfa_step(d, v, lds_rows_addr, hot_rows, state, cl);
+                            const uint32_t e = dfa_step(d, v, lds_rows_addr, hot_rows, state, cl, pf);
                             state = e & kDfaStateMask;
                             if ((e >> kDfaEndShift) && mine) L.found(h, pos + (uint32_t)(4 * q + i) - cs_r, tp_off + pos + (uint64_t)(4 * q + i) + 1u - hs, state, e >> kDfaEndShift);
                         }
                     }
                 }
                 asm volatile("" ::: "memory");              // (keeps the class look-ups of later words behind this word's steps: they would each hold a register)
+            }
             }
 #pragma unroll
             for (int j = 0; j + 1 < NV; j++) buf[j] = buf[j + 1];
@@ -227,7 +278,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
         } else {
             rare_next = false;
             const uint32_t byte = tp[pos], cl = lds_read_u8(lds_cls_addr + byte);
-            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step(d, v, lds_rows_addr, hot_rows, state, cl);
+            const uint32_t e = cl == kDfaRare ? dfa_rare_step(d, state, (d.ic && byte - 0x41u < 26u) ? byte + 0x20u : byte) : dfa_step(d, v, lds_rows_addr, hot_rows, state, cl, pf);
             state = e & kDfaStateMask;
             pos++;
             if ((e >> kDfaEndShift) && pos > cs_r) L.found(h, pos - 1u - cs_r, tp_off + pos - hs, state, e >> kDfaEndShift);
@@ -243,7 +294,7 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
 // Persistent wavefronts: a workgroup of 16 copies the byte -> class map and the first `hot_rows` rows of the table into LDS (the flattener numbers the states so
 // that these are the root, the first letters and the heaviest prefixes: a third or more of the steps on natural text never leave the CU), then its wavefronts take
 // groups of 64 units until none is left.  Token mode: a wavefront's superblock serves the groups it takes until it is full or 16 groups old.
-template <int MODE, int TW, bool NT>
+template <int MODE, int TW, int VAR>
 __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
 {
     extern __shared__ uint32_t s_dyn[];
@@ -266,6 +317,7 @@ __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut
     v.base = reinterpret_cast<const uint8_t*>(d.next);
     v.off_hot = (uint32_t)(reinterpret_cast<const uint8_t*>(d.hot) - v.base);
     v.off_chain = (uint32_t)(reinterpret_cast<const uint8_t*>(d.chain) - v.base);
+    v.off_chain2 = (uint32_t)(reinterpret_cast<const uint8_t*>(d.chain2) - v.base);
     const uint32_t lds_rows_addr = (uint32_t)(uintptr_t)s_rows, lds_cls_addr = (uint32_t)(uintptr_t)s_cls;       // (the kernel has no static LDS: the dynamic block starts at 0)
     const uint64_t n_groups = (n_units + kWave - 1) / kWave, n_waves = (uint64_t)gridDim.x * 16u;
     const uint32_t W = (d.warm + 15u) & ~15u;
@@ -287,7 +339,7 @@ __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut
             const uint32_t end_r = b.total - tp_off < 0xFFFFFFFFull ? (uint32_t)(b.total - tp_off) : 0xFFFFFFFFu;      // the end of the batch, as an offset like the others
             DfaLane<MODE> L{d, b, o, wv};
             if (MODE == kModeEmit) L.out = o.records + o.unit_offsets[u];
-            dfa_walk_unit<MODE, TW, NT>(L, v, tp, tp_off, lds_cls_addr, lds_rows_addr, hot_rows, W, end_r);
+            dfa_walk_unit<MODE, TW, VAR>(L, v, tp, tp_off, lds_cls_addr, lds_rows_addr, hot_rows, W, end_r);
             if (MODE == kModeCount || MODE == kModeTokens) o.unit_counts[u] = L.nrec;
             group_values = L.nval;
         }
@@ -397,7 +449,7 @@ uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.t
 
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
 static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (kLdsLog2Cols + 2u)); }
-// AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = bytes of text a lane asks for at a time (1: 16, 2: 64, 3: 64 with nontemporal loads; 0: the default),
+// AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = the walk (1: 16 bytes of text per request, lanes in step; 2: 64 bytes, lanes in step; 3: 64 bytes, lanes out of step; 0: the default),
 // bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits)
 static uint32_t dfa_tune() { const long v = cfg::get(cfg::kDfaTune); return v > 0 ? (uint32_t)v : 0u; }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
@@ -409,30 +461,33 @@ static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 // Can this device walk this section at all?  The walk addresses hot table and chain records as 32-bit offsets from the rows and a group's text as 32-bit offsets
 // from its start, and a workgroup wants more than 64 KiB of dynamic LDS (an attribute per instantiation and device, raised here once).  make_plan asks before it
 // chooses the route: a section that cannot be walked is not an error, the suffix filter takes the batch.
-template <int MODE, int TW, bool NT>
+template <int MODE, int TW, int VAR>
 static bool dfa_raise_lds(int dev)
 {
     static std::atomic<int> state[64];                       // 0: not tried, 1: raised, 2: refused
     int s = state[dev].load(std::memory_order_acquire);
     if (s == 0) {
-        s = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 1 : 2;
+        s = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 1 : 2;
         if (s == 2) (void)hipGetLastError();
         state[dev].store(s, std::memory_order_release);
     }
     return s == 1;
 }
 template <int MODE>
-static bool dfa_raise_lds_mode(int dev) { return dfa_raise_lds<MODE, 16, false>(dev) && dfa_raise_lds<MODE, 64, false>(dev) && dfa_raise_lds<MODE, 64, true>(dev); }
+static bool dfa_raise_lds_mode(int dev) { return dfa_raise_lds<MODE, 16, 0>(dev) && dfa_raise_lds<MODE, 64, 0>(dev) && dfa_raise_lds<MODE, 64, 1>(dev); }
 bool dfa_usable(const DfaView& d)
 {
-    const uint8_t *p_next = reinterpret_cast<const uint8_t*>(d.next), *p_hot = reinterpret_cast<const uint8_t*>(d.hot), *p_chain = reinterpret_cast<const uint8_t*>(d.chain);
-    if (p_hot < p_next || p_chain < p_next || (uint64_t)(p_chain - p_next) + (uint64_t)(d.n_states - d.n_rows) * 8u >= (1ull << 32) ||
+    const uint8_t *p_next = reinterpret_cast<const uint8_t*>(d.next), *p_hot = reinterpret_cast<const uint8_t*>(d.hot), *p_chain = reinterpret_cast<const uint8_t*>(d.chain),
+                  *p_chain2 = reinterpret_cast<const uint8_t*>(d.chain2);
+    if (d.n_single > d.n_states - d.n_rows) return false;
+    if (p_hot < p_next || p_chain < p_next || p_chain2 < p_next || (uint64_t)(p_chain - p_next) + ((uint64_t)d.n_single + 1u) * 8u >= (1ull << 32) ||
+        (uint64_t)(p_chain2 - p_next) + (uint64_t)(d.n_states - d.n_rows - d.n_single) * 16u >= (1ull << 32) ||
         (uint64_t)(p_hot - p_next) + ((uint64_t)d.n_rows << (d.hot_log2 + 2u)) >= (1ull << 32) || (uint64_t)d.chunk * kWave + d.warm + 16u >= (1ull << 31)) return false;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
     return dfa_raise_lds_mode<kModeCount>(dev) && dfa_raise_lds_mode<kModeEmit>(dev) && dfa_raise_lds_mode<kModeAny>(dev) && dfa_raise_lds_mode<kModeTokens>(dev);
 }
-template <int MODE, int TW, bool NT>
+template <int MODE, int TW, int VAR>
 static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     const uint64_t n_units = dfa_units(d, b);
@@ -441,16 +496,16 @@ static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const Scan
     uint32_t hot = dfa_hot_rows(d);
     if ((dfa_tune() >> 8) & 0xFFFFu) hot = std::min<uint32_t>(hot, ((dfa_tune() >> 8) & 0xFFFFu) - 1u);
     const size_t lds = ((size_t)dfa_hot_rows(d) << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
-    hipLaunchKernelGGL((k_dfa<MODE, TW, NT>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
+    hipLaunchKernelGGL((k_dfa<MODE, TW, VAR>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
     return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_dfa_t(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)
 {
     switch (dfa_tune() & 15u) {
-    case 1: return launch_dfa_tw<MODE, 16, false>(d, b, o, n_cu, st);
-    case 3: return launch_dfa_tw<MODE, 64, true>(d, b, o, n_cu, st);
-    default: return launch_dfa_tw<MODE, 64, false>(d, b, o, n_cu, st);
+    case 1: return launch_dfa_tw<MODE, 16, 0>(d, b, o, n_cu, st);
+    case 3: return launch_dfa_tw<MODE, 64, 1>(d, b, o, n_cu, st);
+    default: return launch_dfa_tw<MODE, 64, 0>(d, b, o, n_cu, st);
     }
 }
 hipError_t launch_dfa(int mode, const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st)

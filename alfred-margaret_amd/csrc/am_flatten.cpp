@@ -559,7 +559,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     tr.mark("suffix trie");
     struct DfaOut {
         bool made = false;
-        std::vector<uint32_t> next2, hot2, fb2; std::vector<u32x2> chain, out2; std::vector<uint8_t> cls; std::vector<u32x4> rare_tab;
+        std::vector<uint32_t> next2, hot2, fb2; std::vector<u32x2> chain, out2; std::vector<uint8_t> cls; std::vector<u32x4> rare_tab, chain2; uint32_t n_single = 0;
         uint32_t hot_lc = 0, rare_lc = 0, n_rows = 0, n_states = 0, lc = 0, warm = 0, chunk = 0;
     };
     // (reads what the trie phase left -- bfs, edge_begin / edge_count, vlen, canon, the reference's arrays -- and nothing the suffix structure makes: it runs on a thread
@@ -667,20 +667,31 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     const uint32_t n_reached = (uint32_t)order.size();
                     std::vector<u32x2> out(n_reached, u32x2{0, 0});
                     for (uint32_t x = 1; x < (uint32_t)S; x++) if (vlen[x] > 0 && id[x] != kNone) out[id[x]] = u32x2{canon[x] + 1u, vlen[x]};
-                    // ROW states and CHAIN states.  Deep in a dictionary nearly every state has one child, and a dense row there is 256 bytes of which a visitor reads
-                    // four -- a 64-byte line fetched for every step (27 bytes per scanned byte, measured).  Such a state keeps 8 bytes instead: {its child, the child's
-                    // class, the state it falls back to}, and anything but the child's byte asks the fallback's row: delta(x, c) = delta(fallback(x), c) where x has no edge
-                    // on c.  For that to be ONE more load the fallback must have a row, so every state some chain state falls back to is a row state; so are the root, the
-                    // branching states and the states with an edge on a rare byte.  Chain states are numbered along their paths (a word's tail shares cache lines).
+                    // ROW states and RECORD states.  A dense row is 256 bytes of which a visitor reads four, and deep in a dictionary a state's row differs from the row of a
+                    // state it falls back to in an entry or two (its own child; a child one of the states on the way there has).  Such a state keeps a RECORD instead: the row
+                    // state R it leans on -- the nearest one on its chain of fallbacks -- and the one or two classes on which it differs from R's row, with where they lead
+                    // (8 or 16 bytes); any other byte is answered by R's row: delta(x, c) = delta(R, c).  A step is a record and, at most, one row entry.
+                    // (Image version 17.  Until then a chain state had one child and leaned on the state it falls back to, which for that was given a row: 125k of the
+                    // dictionary's 143k rows were rows of states with at most two children -- 88 % of the rows for 19 % of the steps, and most of the walk's L2 misses.
+                    // Records that lean on records, followed hop by hop, have the fewest rows of all and were measured first: the hops are dependent trips, 10.1 ms against
+                    // 8.1 per 2 GiB -- LABNOTES R6.8.)  Rows: the root, the states that differ from their R in three entries or more, the states with an edge on a rare byte.
+                    // Single-child records are numbered along their paths (a word's tail shares cache lines).
+                    struct Rec { uint32_t n = 0, cls[2] = {0, 0}, to[2] = {0, 0}; };
                     std::vector<uint8_t> is_row(n_reached, 0);
+                    std::vector<uint32_t> near_row(n_reached, 0);                     // R(x): the nearest row state on the chain of fallbacks (x itself excluded)
+                    std::vector<Rec> rec(n_reached);
                     is_row[0] = 1;
-                    for (uint32_t i = 1; i < n_reached; i++) if (n_goto[i] > 1 || has_rare[i]) is_row[i] = 1;
-                    {
-                        std::vector<uint8_t> promoted(n_reached, 0);
-                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i]) promoted[fb[i]] = 1;     // (decided on the candidates: a promoted candidate's own fallback may be promoted needlessly)
-                        for (uint32_t i = 1; i < n_reached; i++) if (promoted[i]) is_row[i] = 1;
+                    const bool no_chains = cfg::get(cfg::kDfaNoChains) > 0;           // A/B: dense rows for every state (round 5's first layout)
+                    for (uint32_t i = 1; i < n_reached; i++) {                        // breadth-first order: fb[i] < i
+                        const uint32_t r = is_row[fb[i]] ? fb[i] : near_row[fb[i]];
+                        near_row[i] = r;
+                        if (has_rare[i] || no_chains) { is_row[i] = 1; continue; }
+                        const uint32_t *mine = next.data() + ((size_t)i << lc), *theirs = next.data() + ((size_t)r << lc);
+                        Rec q;
+                        for (uint32_t c = 1; c < C && q.n <= 2; c++)
+                            if (mine[c] != theirs[c]) { if (q.n < 2) { q.cls[q.n] = c; q.to[q.n] = mine[c]; } q.n++; }
+                        if (q.n > 2) is_row[i] = 1; else rec[i] = q;
                     }
-                    if (cfg::get(cfg::kDfaNoChains) > 0) std::fill(is_row.begin(), is_row.end(), 1);      // A/B: dense rows for every state (round 5's first layout)
                     // numbers: the root, then the row states by weight (k_dfa keeps the first rows in LDS; breadth-first order among equals); then the chain states, path by path
                     // How often will text visit a state?  The dictionary is the one sample of its language the flattener has: the needles, one after the other with a
                     // blank between them, are walked through the automaton and the visits counted (weight[state] = steps that START there; col_use[class] = bytes).
@@ -729,33 +740,41 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                         for (uint32_t k = 0; k < by_w.size(); k++) col_new[by_w[k]] = k + 1u;
                         for (uint32_t b = 0; b < 256; b++) if (cls[b] != kDfaRare) cls[b] = (uint8_t)col_new[cls[b]];
                     }
-                    // the chain paths by the weight of their heads (image version 16): the tails of the words text is made of share lines with each other, not with the
-                    // tails of words that never come (the hottest 4k lines of the chain records took 43 % of the chain steps in breadth-first order; 63 % is what an
-                    // ordering by the text's own counts would give) -- then, in breadth-first order, whatever is left
+                    // the single-child records (and the childless ones) path by path, the paths by the weight of their heads: the tails of the words text is made of share lines
+                    // with each other, not with the tails of words that never come; then the two-children records by weight
+                    auto is_single = [&](uint32_t y) { return !is_row[y] && rec[y].n <= 1; };
                     {
                         std::vector<uint32_t> heads;
-                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i] && is_row[tree_parent[i]]) heads.push_back(i);
+                        for (uint32_t i = 1; i < n_reached; i++) if (is_single(i) && !is_single(tree_parent[i])) heads.push_back(i);
                         std::stable_sort(heads.begin(), heads.end(), [&](uint32_t a, uint32_t b2) { return weight[a] > weight[b2]; });
                         for (uint32_t i : heads)
-                            for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
+                            for (uint32_t y = i; is_single(y) && renum[y] == kNone;) {
                                 renum[y] = nxt++;
-                                if (n_goto[y] != 1) break;
-                                y = child_of[y];
+                                if (rec[y].n != 1) break;
+                                y = rec[y].to[0];
                             }
                     }
                     for (uint32_t i = 1; i < n_reached; i++) {
-                        if (renum[i] != kNone) continue;                                  // (a chain state not yet on a path: the head of one, breadth-first order sees heads first)
-                        for (uint32_t y = i; !is_row[y] && renum[y] == kNone;) {
+                        if (renum[i] != kNone || !is_single(i)) continue;                 // (a single not yet on a path -- an IgnoreCase DAG reaches a state by several parents: breadth-first order)
+                        for (uint32_t y = i; is_single(y) && renum[y] == kNone;) {
                             renum[y] = nxt++;
-                            if (n_goto[y] != 1) break;
-                            y = child_of[y];
+                            if (rec[y].n != 1) break;
+                            y = rec[y].to[0];
                         }
                     }
-                    if (n_rows >= (1u << 24)) { /* a chain record holds its fallback row in 24 bits: no DFA section for this automaton */ }
+                    const uint32_t n_single = nxt - n_rows;
+                    {
+                        std::vector<uint32_t> doubles;
+                        for (uint32_t i = 1; i < n_reached; i++) if (!is_row[i] && rec[i].n == 2) doubles.push_back(i);
+                        std::sort(doubles.begin(), doubles.end(), heavier);
+                        for (uint32_t i : doubles) renum[i] = nxt++;
+                    }
+                    if (n_rows >= (1u << 24)) { /* a record holds the row state it leans on in 24 bits: no DFA section for this automaton */ }
                     else {
                     dtr.mark("dfa: numbering");
                     std::vector<uint32_t> next2((size_t)n_rows << lc);
-                    std::vector<u32x2> chain(n_reached - n_rows), out2(n_reached);
+                    std::vector<u32x2> chain(n_single + 1u, u32x2{0, 0}), out2(n_reached);       // (+ 1: the device reads 16 bytes at a record)
+                    std::vector<u32x4> chain2(n_reached - n_rows - n_single);
                     std::vector<uint32_t> fb2(n_reached);
                     for (uint32_t i = 0; i < n_reached; i++) {
                         out2[renum[i]] = out[i];
@@ -766,10 +785,14 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                             const uint32_t* from = next.data() + ((size_t)i << lc);
                             uint32_t* to = next2.data() + ((size_t)renum[i] << lc);
                             for (uint32_t c = 0; c < C; c++) { const uint32_t t = renum[from[c]]; to[col_new[c]] = t | dfa_end_bits(out2[t]); }
+                        } else if (rec[i].n <= 1) {
+                            const uint32_t ch = rec[i].n == 1 ? renum[rec[i].to[0]] : 0u;
+                            chain[renum[i] - n_rows] = u32x2{rec[i].n == 1 ? (ch | dfa_end_bits(out2[ch])) : 0u,
+                                                             ((rec[i].n == 1 ? col_new[rec[i].cls[0]] : kDfaNoChild) << 24) | renum[near_row[i]]};
                         } else {
-                            const uint32_t ch = n_goto[i] == 1 ? renum[child_of[i]] : 0u;
-                            chain[renum[i] - n_rows] = u32x2{n_goto[i] == 1 ? (ch | dfa_end_bits(out2[ch])) : 0u,
-                                                             ((n_goto[i] == 1 ? col_new[child_cls[i]] : kDfaNoChild) << 24) | renum[fb[i]]};
+                            // two entries: {target a, class a << 24 | R, target b, class b << 24} -- a single-child record and a second entry
+                            const uint32_t ta = renum[rec[i].to[0]], tb = renum[rec[i].to[1]];
+                            chain2[renum[i] - n_rows - n_single] = u32x4{ta | dfa_end_bits(out2[ta]), (col_new[rec[i].cls[0]] << 24) | renum[near_row[i]], tb | dfa_end_bits(out2[tb]), col_new[rec[i].cls[1]] << 24};
                         }
                     }
                     dtr.mark("dfa: tables out");
@@ -799,7 +822,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     std::vector<uint32_t> hot2((size_t)n_rows << hot_lc);
                     for (uint32_t r = 0; r < n_rows; r++)
                         for (uint32_t c = 0; c < (1u << hot_lc); c++) hot2[((size_t)r << hot_lc) + c] = next2[((size_t)r << lc) + c + 1u];
-                    o.next2.swap(next2); o.hot2.swap(hot2); o.chain.swap(chain); o.out2.swap(out2); o.cls.swap(cls); o.fb2.swap(fb2); o.rare_tab.swap(rare_tab);
+                    o.next2.swap(next2); o.hot2.swap(hot2); o.chain.swap(chain); o.chain2.swap(chain2); o.n_single = n_single; o.out2.swap(out2); o.cls.swap(cls); o.fb2.swap(fb2); o.rare_tab.swap(rare_tab);
                     o.hot_lc = hot_lc; o.rare_lc = rare_lc; o.n_rows = n_rows; o.n_states = n_reached; o.lc = lc; o.warm = warm - 1u > 0 ? warm - 1u : 1u; o.chunk = (uint32_t)chunk;
                     o.made = true;
                     }
@@ -1097,6 +1120,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             h.off_dfa_hot = blob.put(o.hot2);
             h.dfa_hot_log2 = o.hot_lc;
             h.off_dfa_chain = blob.put(o.chain);
+            h.off_dfa_chain2 = blob.put(o.chain2);
+            h.dfa_n_single = o.n_single;
             h.off_dfa_out = blob.put(o.out2);
             h.off_dfa_cls = blob.put(o.cls);
             h.off_dfa_fail = blob.put(o.fb2);
@@ -1273,11 +1298,28 @@ bool image_body_valid(const uint8_t* img, const ImageHeader& h, std::string& err
                     if (hot[((uint64_t)r << h.dfa_hot_log2) + c] != next[((uint64_t)r << h.dfa_log2_classes) + c + 1u]) { err = "image: DFA hot table differs from the rows"; return false; }
             }
         }
+        // records: the entries' classes and end bits, and the state a record leans on: a ROW state on the record state's chain of fallbacks (fail[] was checked above to
+        // lead to the root without a cycle)
+        const uint32_t* fl = (const uint32_t*)(img + h.off_dfa_fail);
+        auto leans_on = [&](uint32_t state, uint32_t r) {
+            if (r >= h.dfa_n_rows) return false;
+            for (uint32_t s = state; s != 0u;) { s = fl[s]; if (s == r) return true; }
+            return false;
+        };
         const u32x2* chain = (const u32x2*)(img + h.off_dfa_chain);
-        for (uint32_t i = 0; i < h.dfa_n_states - h.dfa_n_rows; i++) {
-            const uint32_t to = chain[i].x & kDfaStateMask, cl = chain[i].y >> 24, fbr = chain[i].y & 0xFFFFFFu;
-            if (fbr >= h.dfa_n_rows || (cl >= (1u << h.dfa_log2_classes) && cl != kDfaNoChild) || to >= h.dfa_n_states || (chain[i].x & ~kDfaStateMask) != (cl != kDfaNoChild ? dfa_end_bits(out[to]) : 0u) ||
+        for (uint32_t i = 0; i < h.dfa_n_single; i++) {
+            const uint32_t to = chain[i].x & kDfaStateMask, cl = chain[i].y >> 24, fbs = chain[i].y & 0xFFFFFFu;
+            if (!leans_on(h.dfa_n_rows + i, fbs) || (cl >= (1u << h.dfa_log2_classes) && cl != kDfaNoChild) || to >= h.dfa_n_states || (chain[i].x & ~kDfaStateMask) != (cl != kDfaNoChild ? dfa_end_bits(out[to]) : 0u) ||
                 (cl == kDfaNoChild && chain[i].x != 0) || cl == 0u) { err = "image: DFA chain record out of range"; return false; }
+        }
+        const u32x4* chain2 = (const u32x4*)(img + h.off_dfa_chain2);
+        for (uint32_t i = 0; i < h.dfa_n_states - h.dfa_n_rows - h.dfa_n_single; i++) {
+            const u32x4& q = chain2[i];
+            const uint32_t ta = q.x & kDfaStateMask, tb = q.z & kDfaStateMask, ca = q.y >> 24, cb = q.w >> 24;
+            if (!leans_on(h.dfa_n_rows + h.dfa_n_single + i, q.y & 0xFFFFFFu) || (q.w & 0xFFFFFFu) != 0u || ca == 0u || cb == 0u || ca == cb || ca >= (1u << h.dfa_log2_classes) || cb >= (1u << h.dfa_log2_classes) ||
+                ta >= h.dfa_n_states || tb >= h.dfa_n_states || (q.x & ~kDfaStateMask) != dfa_end_bits(out[ta]) || (q.z & ~kDfaStateMask) != dfa_end_bits(out[tb])) {
+                err = "image: DFA two-children record out of range"; return false;
+            }
         }
     }
     return true;
@@ -1303,10 +1345,11 @@ bool image_sections_in_bounds(const ImageHeader& h)
     }
     if (h.dfa_n_states) {
         if (h.dfa_log2_classes < 3 || h.dfa_log2_classes > 8 || h.dfa_n_states >= kDfaStateMask || h.dfa_chunk < 64 || (h.dfa_chunk & 15u) || h.dfa_warm == 0 || h.root_vlen != 0) return false;
-        if (h.dfa_n_rows == 0 || h.dfa_n_rows > h.dfa_n_states || h.dfa_n_rows >= (1u << 24)) return false;
+        if (h.dfa_n_rows == 0 || h.dfa_n_rows > h.dfa_n_states || h.dfa_n_rows >= (1u << 24) || h.dfa_n_single > h.dfa_n_states - h.dfa_n_rows) return false;
+        good = good && ok(h.off_dfa_chain2, h.dfa_n_states - h.dfa_n_rows - h.dfa_n_single, 16) && (h.off_dfa_chain2 & 15u) == 0;
         if ((1u << h.dfa_hot_log2) > (1u << h.dfa_log2_classes) - 1u || h.dfa_hot_log2 > 8) return false;
         good = good && ok(h.off_dfa_hot, (uint64_t)h.dfa_n_rows << h.dfa_hot_log2, 4) && (h.off_dfa_hot & 15u) == 0;
-        good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_rows << h.dfa_log2_classes, 4) && ok(h.off_dfa_chain, h.dfa_n_states - h.dfa_n_rows, 8) && (h.off_dfa_chain & 7u) == 0 &&
+        good = good && ok(h.off_dfa_next, (uint64_t)h.dfa_n_rows << h.dfa_log2_classes, 4) && ok(h.off_dfa_chain, (uint64_t)h.dfa_n_single + 1u, 8) && (h.off_dfa_chain & 7u) == 0 &&
                ok(h.off_dfa_out, h.dfa_n_states, 8) && ok(h.off_dfa_cls, 256, 1) &&
                (h.off_dfa_next & 15u) == 0 && (h.off_dfa_out & 7u) == 0 && ok(h.off_dfa_fail, h.dfa_n_states, 4) && h.dfa_rare_log2_cap >= 4 && h.dfa_rare_log2_cap <= 30 &&
                ok(h.off_dfa_rare, 1ull << h.dfa_rare_log2_cap, 16) && (h.off_dfa_rare & 15u) == 0;

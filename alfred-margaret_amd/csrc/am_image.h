@@ -34,7 +34,7 @@
 namespace am {
 
 constexpr uint32_t kImageMagic = 0x31474D41u;   // "AMG1"
-constexpr uint32_t kImageVersion = 16;
+constexpr uint32_t kImageVersion = 17;
 constexpr uint32_t kUnicodeLowerVersion = 0x0E00;   // Unicode 14.0 (major << 8 | minor): the simple-lowercase table baked into IgnoreCase images (ImageHeader::flags bits 0-15)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kWildcard = 0x200000ull;     // Automaton.hs:130-131
@@ -82,13 +82,16 @@ struct ImageHeader {
     uint64_t off_dfa_rare;      // u32x4{state, byte, child | its end bits, used}[1 << dfa_rare_log2_cap]: the edges on rare bytes, open addressing
     uint32_t dfa_rare_log2_cap;
     uint32_t dfa_n_rows;        // states [0, dfa_n_rows) have a dense row in `next`; the others a chain record (off_dfa_chain)
-    uint64_t off_dfa_chain;     // u32x2[dfa_n_states - dfa_n_rows]: {the one child | its end bits, the child's class << 24 | the row state this one falls back to}
+    uint64_t off_dfa_chain;     // u32x2[dfa_n_single + 1]: {target | its end bits, its class << 24 | the row state R this one leans on: the nearest row state on its chain of fallbacks; any other class is answered by R's row}
     uint32_t dfa_n_states, dfa_log2_classes;
     uint32_t dfa_warm;          // bytes of history that determine the state: longest needle (variant) in bytes - 1
     uint32_t dfa_chunk;         // bytes of the batch one lane owns (multiple of 16)
     // (version 16) rows are numbered by weight, columns by the dictionary's own use of them, and the first columns of every row exist a second time, dense:
     uint64_t off_dfa_hot;       // u32[dfa_n_rows << dfa_hot_log2]: hot[(row << dfa_hot_log2) + class - 1] = next[(row << dfa_log2_classes) + class] for 1 <= class <= 2^dfa_hot_log2
-    uint32_t dfa_hot_log2, dfa_pad;
+    uint32_t dfa_hot_log2;
+    // (version 17) states [dfa_n_rows, dfa_n_rows + dfa_n_single) have a single-child record (off_dfa_chain), the rest a two-children record:
+    uint32_t dfa_n_single;
+    uint64_t off_dfa_chain2;    // u32x4[dfa_n_states - dfa_n_rows - dfa_n_single]: {target a | its end bits, class a << 24 | the row state R this one leans on, target b | its end bits, class b << 24}
 };
 
 // Resolved pointers, passed to kernels by value (SGPRs).
@@ -182,6 +185,8 @@ struct DfaView {
     const u32x2* chain;
     const uint32_t* hot;     // columns 1 .. 2^hot_log2 of every row, dense (ImageHeader::off_dfa_hot)
     uint32_t hot_log2;
+    const u32x4* chain2;     // two-children records (ImageHeader::off_dfa_chain2)
+    uint32_t n_single;       // states [n_rows, n_rows + n_single): single-child records
     uint32_t n_states, n_rows, log2_classes, warm, chunk, rare_log2_cap;
     uint32_t ic;             // IgnoreCase image: haystack bytes A-Z count as a-z (the class map already says so; the rare-byte walk has to be told)
 };
@@ -222,6 +227,7 @@ inline DfaView make_dfa_view(const void* base, const ImageHeader& h)
     v.fail = (const uint32_t*)(b + h.off_dfa_fail); v.rare = (const u32x4*)(b + h.off_dfa_rare); v.chain = (const u32x2*)(b + h.off_dfa_chain);
     v.n_states = h.dfa_n_states; v.n_rows = h.dfa_n_rows; v.log2_classes = h.dfa_log2_classes; v.warm = h.dfa_warm; v.chunk = h.dfa_chunk; v.rare_log2_cap = h.dfa_rare_log2_cap; v.ic = h.case_mode;
     v.hot = (const uint32_t*)(b + h.off_dfa_hot); v.hot_log2 = h.dfa_hot_log2;
+    v.chain2 = (const u32x4*)(b + h.off_dfa_chain2); v.n_single = h.dfa_n_single;
     return v;
 }
 
@@ -1083,17 +1089,24 @@ AM_HD uint32_t dfa_rare_step(const DfaView& d, uint32_t state, uint32_t byte)
     }
 }
 
-// delta(state, class) for a byte with a column.  A ROW state has its dense row.  A CHAIN state -- one child (or none), numbered along its path so that
-// the records of a word's tail share cache lines -- has 8 bytes: its child under the child's class, else the answer of the row state it falls back to
-// (the flattener makes every state some chain state falls back to a row state: delta(x, c) = delta(fallback(x), c) wherever x has no edge on c).
+// delta(state, class) for a byte with a column.  A ROW state has its dense row.  A RECORD state -- one whose row would differ in at most two entries from the row of
+// R, the nearest row state on its chain of fallbacks; the single-entry ones numbered along their paths so that the records of a word's tail share cache lines -- has 8
+// or 16 bytes: where its one or two classes lead, and R for every other class (delta(x, c) = delta(R, c) there).
 AM_HD uint32_t dfa_common_step(const DfaView& d, uint32_t state, uint32_t cl)
 {
-    if (state >= d.n_rows) {
-        const u32x2 r = d.chain[state - d.n_rows];
-        if ((r.y >> 24) == cl) return r.x;
-        state = r.y & 0xFFFFFFu;
-    }
     if (cl == 0u) return 0u;                                                        // a byte no needle contains: the root, nothing ends (the image check holds every row to it)
+    if (state >= d.n_rows) {                                                        // a record state: one of its entries answers, else the row state it leans on
+        if (state < d.n_rows + d.n_single) {
+            const u32x2 r = d.chain[state - d.n_rows];
+            if ((r.y >> 24) == cl) return r.x;
+            state = r.y & 0xFFFFFFu;
+        } else {
+            const u32x4 q = load16(d.chain2 + (state - d.n_rows - d.n_single));
+            if ((q.y >> 24) == cl) return q.x;
+            if ((q.w >> 24) == cl) return q.z;
+            state = q.y & 0xFFFFFFu;
+        }
+    }
     if (cl <= (1u << d.hot_log2)) return d.hot[((uint64_t)state << d.hot_log2) + cl - 1u];
     return d.next[((uint64_t)state << d.log2_classes) + cl];
 }

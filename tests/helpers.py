@@ -90,9 +90,9 @@ class ImgCheck:
 
     @staticmethod
     def dfa_header(img):
-        f = struct.unpack_from("<5Q2IQ4I", img.tobytes()[256:328])          # ImageHeader.off_dfa_next ... dfa_chunk
+        f = struct.unpack_from("<5Q2IQ4IQ2IQ", img.tobytes()[256:352])      # ImageHeader.off_dfa_next ... off_dfa_chain2
         return {"off_next": f[0], "off_out": f[1], "off_cls": f[2], "off_fail": f[3], "off_rare": f[4], "rare_log2_cap": f[5], "n_rows": f[6], "off_chain": f[7],
-                "n_states": f[8], "log2_classes": f[9], "warm": f[10], "chunk": f[11]}
+                "n_states": f[8], "log2_classes": f[9], "warm": f[10], "chunk": f[11], "off_hot": f[12], "hot_log2": f[13], "n_single": f[14], "off_chain2": f[15]}
 
     @staticmethod
     def set_dfa_chunk(img, chunk):

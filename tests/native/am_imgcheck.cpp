@@ -117,6 +117,9 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
     ImageHeader h; std::memcpy(&h, image, sizeof(h));
     if (h.magic != kImageMagic || !h.dfa_n_states) return -3;
     const DfaView d = make_dfa_view(image, h);
+    std::fprintf(stderr, "[l2sim] image version %u: %u states, %u rows (%u columns, %.1f MB; hot table %.1f MB), %u single records, %u double records (%.1f MB)\n", h.version, d.n_states, d.n_rows,
+                 1u << d.log2_classes, (double)((uint64_t)d.n_rows << d.log2_classes) * 4e-6, (double)((uint64_t)d.n_rows << d.hot_log2) * 4e-6, d.n_single, d.n_states - d.n_rows - d.n_single,
+                 (double)d.n_single * 8e-6 + (double)(d.n_states - d.n_rows - d.n_single) * 16e-6);
     for (int i = 0; i < 12; i++) out12[i] = 0;
     const uint64_t n_sets = l2_bytes / 128u / ways;
     std::vector<uint64_t> tag((size_t)(n_sets * ways), ~0ull);
@@ -135,8 +138,29 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
         if (cat == 0 && text_no_alloc) return;                  // (what-if: text lines do not stay in the cache)
         t[victim] = line; a[victim] = ++clock;
     };
+    // what-if (SIM_SPARSE=k): row states with at most k children of their own (entries that differ from their fallback's row) keep a compact record -- 8 bytes for one
+    // child, 16 for two -- instead of a row, and a byte that is no child asks the fallback (which may be such a record again): more requests, fewer lines
+    const uint32_t sparse_k = std::getenv("SIM_SPARSE") ? (uint32_t)std::atoi(std::getenv("SIM_SPARSE")) : 0u;
+    std::vector<uint8_t> n_own; std::vector<uint64_t> rec_at;
+    if (sparse_k) {
+        n_own.assign(d.n_rows, 255); rec_at.assign(d.n_rows, 0);
+        uint64_t at = 0;
+        for (uint32_t r = 1; r < d.n_rows; r++) {
+            const uint32_t f = d.fail[r];
+            if (f >= d.n_rows) continue;
+            uint32_t k = 0;
+            for (uint32_t c = 1; c < (1u << d.log2_classes); c++) k += d.next[((uint64_t)r << d.log2_classes) + c] != d.next[((uint64_t)f << d.log2_classes) + c];
+            if (k <= sparse_k && r >= hot_rows) { n_own[r] = (uint8_t)k; rec_at[r] = at; at += k <= 1 ? 8 : 16; }
+        }
+        std::fprintf(stderr, "[l2sim] sparse records: %.2f MB\n", (double)at / 1e6);
+    }
     // address spaces: image offsets for the tables, 2^40 + offset for the text
     std::vector<uint32_t> state((size_t)lanes, 0);
+    uint64_t trips_hist[16] = {0}, lane_hist[16] = {0}; uint32_t wave_max = 0;
+    double rec_stat[6] = {0, 0, 0, 0, 0, 0};
+    const uint32_t sim_window = std::getenv("SIM_WINDOW") ? (uint32_t)std::atoi(std::getenv("SIM_WINDOW")) : 0u;
+    const uint32_t sim_window_bytes = std::getenv("SIM_WINDOW_BYTES") ? (uint32_t)std::atoi(std::getenv("SIM_WINDOW_BYTES")) : 16u;
+    std::vector<uint32_t> win((size_t)lanes, 0), win_at((size_t)lanes, 0); uint64_t wfree = 0;
     for (uint32_t p = 0; p < unit; p++) {
         for (uint64_t l = 0; l < lanes; l++) {
             const uint64_t at = l * unit + p;
@@ -144,6 +168,8 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
             uint32_t byte = text[at];
             const uint32_t cl = d.cls[byte];
             uint32_t st = state[l], e;
+            if ((l & 63u) == 0) { if (p || l) { trips_hist[wave_max < 15u ? wave_max : 15u]++; } wave_max = 0; }
+            const uint64_t req_before = out12[2] + out12[4] + out12[6];
             if (cl == kDfaRare) {
                 if (d.ic && byte - 0x41u < 26u) byte += 0x20u;
                 touch(4, h.off_dfa_rare + (uint64_t)dfa_rare_slot(st, byte, d.rare_log2_cap) * 16u);
@@ -151,10 +177,36 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
             } else {
                 if (cl == 0u) out12[10]++;
                 else {
-                    if (st >= d.n_rows) {
-                        touch(1, h.off_dfa_chain + (uint64_t)(st - d.n_rows) * 8u);
-                        const u32x2 r = d.chain[st - d.n_rows];
-                        st = (r.y >> 24) == cl ? kNone : (r.y & 0xFFFFFFu);
+                    while (st != kNone && st >= d.n_rows) {                                     // record states (image version 17): a child answers, else on to the fallback
+                        if (st < d.n_rows + d.n_single) {
+                            const u32x2 r = d.chain[st - d.n_rows];
+                            // what-if (SIM_WINDOW=k): a single-child record is 16 bytes and also names the classes of the next k states of its path (numbered consecutively):
+                            // a lane that came along the path and has the window in registers steps on without a load while the text follows the path
+                            if (sim_window) {
+                                const bool on_path = (r.x & kDfaStateMask) == st + 1u;
+                                if (win[l] > 0 && st == win_at[l]) {
+                                    if (on_path && (r.y >> 24) == cl) { win[l]--; win_at[l] = st + 1u; st = kNone; wfree++; continue; }
+                                    win[l] = 0;                                                   // the text leaves the path (or the path ends here): this state's own record is read
+                                }
+                                touch(1, (3ull << 40) + (uint64_t)(st - d.n_rows) * (uint64_t)sim_window_bytes);
+                                if ((r.y >> 24) == cl) { if (on_path) { win[l] = sim_window; win_at[l] = st + 1u; } st = kNone; }
+                                else st = r.y & 0xFFFFFFu;
+                                continue;
+                            }
+                            touch(1, h.off_dfa_chain + (uint64_t)(st - d.n_rows) * 8u);
+                            st = (r.y >> 24) == cl ? kNone : (r.y & 0xFFFFFFu);
+                            rec_stat[0]++; if (st != kNone) { rec_stat[1]++; if (st < hot_rows && cl <= 32u) rec_stat[2]++; if (cl == d.cls[0x20]) rec_stat[3]++; if ((r.y >> 24) == kDfaNoChild) rec_stat[4]++; }
+                        } else {
+                            rec_stat[5]++;
+                            touch(1, h.off_dfa_chain2 + (uint64_t)(st - d.n_rows - d.n_single) * 16u);
+                            const u32x4 q = d.chain2[st - d.n_rows - d.n_single];
+                            st = ((q.y >> 24) == cl || (q.w >> 24) == cl) ? kNone : (q.y & 0xFFFFFFu);
+                        }
+                    }
+                    while (sparse_k && st != kNone && st < d.n_rows && n_own[st] != 255) {      // a compact record: the child, or on to the fallback
+                        touch(1, (3ull << 40) + rec_at[st]);
+                        const uint32_t f = d.fail[st];
+                        if (d.next[((uint64_t)st << d.log2_classes) + cl] != d.next[((uint64_t)f << d.log2_classes) + cl]) st = kNone; else st = f;
                     }
                     if (st != kNone) {
                         if (st < hot_rows && cl <= 32u) out12[10]++;
@@ -180,7 +232,18 @@ long long amchk_dfa_l2sim(const uint8_t* image, const uint8_t* text, uint64_t la
                 }
             }
             state[l] = e & kDfaStateMask;
+            { const uint32_t tr = (uint32_t)(out12[2] + out12[4] + out12[6] - req_before); lane_hist[tr < 15u ? tr : 15u]++; if (tr > wave_max) wave_max = tr; }
         }
+    }
+    if (sim_window) std::fprintf(stderr, "[l2sim] window of %u: %.4f steps per step follow a path without a load\n", sim_window, (double)wfree / ((double)lanes * unit));
+    std::fprintf(stderr, "[l2sim] per step: single-record reads %.4f, of them not answered by the record %.4f (the row it leans on is in LDS: %.4f; the byte is a blank: %.4f; the record has no entry: %.4f); double-record reads %.4f\n",
+                 rec_stat[0] / ((double)lanes * unit), rec_stat[1] / ((double)lanes * unit), rec_stat[2] / ((double)lanes * unit), rec_stat[3] / ((double)lanes * unit), rec_stat[4] / ((double)lanes * unit), rec_stat[5] / ((double)lanes * unit));
+    if (std::getenv("SIM_TRIPS")) {
+        std::fprintf(stderr, "[l2sim] dependent table trips per lane step / max over the 64 lanes of a wavefront step:\n");
+        uint64_t a = 0, b = 0; for (int i = 0; i < 16; i++) { a += lane_hist[i]; b += trips_hist[i]; }
+        double ma = 0, mb = 0;
+        for (int i = 0; i < 16; i++) { std::fprintf(stderr, "  %2d  %.4f  %.4f\n", i, (double)lane_hist[i] / a, (double)trips_hist[i] / b); ma += (double)i * lane_hist[i] / a; mb += (double)i * trips_hist[i] / b; }
+        std::fprintf(stderr, "  mean %.3f  %.3f\n", ma, mb);
     }
     if (what_if_class) std::fprintf(stderr, "[l2sim] class %u: %llu steps lead to the root (%.4f per step), costing %llu requests today (%.4f per step)\n", what_if_class,
                                     (unsigned long long)wi[0], (double)wi[0] / ((double)lanes * unit), (unsigned long long)wi[1], (double)wi[1] / ((double)lanes * unit));

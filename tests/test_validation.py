@@ -164,3 +164,17 @@ def test_damaged_dfa_section_is_refused():
     assert d["n_rows"] < d["n_states"], "the test automaton has chain states"
     refused(lambda b: struct.pack_into("<I", b, d["off_chain"] + 4, (struct.unpack_from("<I", b, d["off_chain"] + 4)[0] & 0xFF000000) | (d["n_rows"] + 1)), "a chain state that falls back to a state without a row")
     refused(lambda b: struct.pack_into("<I", b, d["off_chain"], d["n_states"] + 3), "a chain state whose child does not exist")
+    # image version 17: a record leans on a ROW state of its own chain of fallbacks; two-entry records
+    n_two = d["n_states"] - d["n_rows"] - d["n_single"]
+    assert d["n_single"] > 0 and n_two > 0, "the test automaton has records of both kinds"
+    lean = struct.unpack_from("<I", good, d["off_chain"] + 4)[0]
+    fail = struct.unpack_from("<%dI" % d["n_states"], good, d["off_fail"])
+    on_chain = set()
+    s = d["n_rows"]
+    while s:
+        s = fail[s]; on_chain.add(s)
+    stranger = next(r for r in range(d["n_rows"]) if r not in on_chain)
+    refused(lambda b: struct.pack_into("<I", b, d["off_chain"] + 4, (lean & 0xFF000000) | stranger), "a record that leans on a row state it never falls back to")
+    refused(lambda b: struct.pack_into("<I", b, d["off_chain2"] + 8, d["n_states"] + 1), "a two-entry record whose second target does not exist")
+    refused(lambda b: struct.pack_into("<I", b, d["off_chain2"] + 12, struct.unpack_from("<I", b, d["off_chain2"] + 4)[0] & 0xFF000000), "a two-entry record with the same class twice")
+    refused(lambda b: struct.pack_into("<I", b, d["off_chain2"] + 4, struct.unpack_from("<I", b, d["off_chain2"] + 4)[0] | 0x00FFFFFF), "a two-entry record that leans on a state without a row")
