@@ -1,18 +1,21 @@
 // am_dfa.hip -- k_dfa: the byte-level Aho-Corasick automaton with every transition resolved (ImageHeader::off_dfa_next, built by am_flatten.cpp for
 // dictionaries that meet match-dense text), walked one lane per stretch of the batch.  Reference semantics: Automaton.hs:482-520 (followCodePoint /
 // collectMatches) -- the fallback loop is folded into the table, so a step is ONE dependent load: next = table[state << log2_classes | class(byte)] for the states that
-// have a dense row, an 8-byte chain record {child, its class, fallback row} for the single-child states of a word's tail (image layout: am_image.h, DfaView).
+// have a dense row; the others -- states whose row would differ in one or two entries from the row of R, the nearest row state on their chain of fallbacks -- keep an 8- or
+// 16-byte RECORD {where those classes lead, R}, and a byte the record does not name is answered by R's row: at most two trips (image layout: am_image.h, DfaView; version 17).
 //
 // Why a second scan kernel: k_sf is a filter.  On natural-language text against a 100k-word dictionary four positions in ten pass its LDS filter and a needle
 // ends every 6.6 bytes; its resolve phase then costs ~19 divergent 16-byte loads and ~22 VALU instructions per deferred position and the kernel runs at the
 // issue limit of the CUs' address units and vector ALUs (profiles/r05_pmc_natural_units.md).  A table walk costs one 4-byte load and a few instructions per BYTE
 // whatever the text is -- slower than k_sf where matches are rare (it cannot skip anything), several times faster where they are dense.
 //
-// What bounds it (round 6, profiles/r06_pmc_dfa.md): the wavefronts wait 92 % of their time, and not for latency -- half the wavefronts per CU give 86 % of the rate.  Every
-// lane-load is an L2 request (2 048 lanes per CU touch 2 048 different lines between two visits of one lane: the 32-KiB L1 holds nothing, 97 % of its accesses go on), and a
-// request that misses the XCD's 4-MiB L2 moves a whole line over the fabric.  So the kernel is written to the two currencies "L2 requests per byte" and "lines per
-// byte": the byte class and the hottest rows in LDS, a record in ONE 8- or 16-byte load, a byte no needle contains answered without any load (it leads to the root from
-// everywhere), text asked for 64 bytes at a time, and the first 16 columns of every row a second time in a table of their own where two rows share a line (am_flatten.cpp).
+// What bounds it (round 6, profiles/r06_pmc_dfa.md, LABNOTES R6.1 / R6.8): the wavefronts wait 85-90 % of their time, and not for latency -- half the wavefronts per CU give 86 % of
+// the rate.  Every lane-load is an L2 request (2 048 lanes per CU touch 2 048 different lines between two visits of one lane: the 32-KiB L1 holds nothing), and the L2s take about
+// 300 G requests/s from full wavefronts of dependent random loads (16 channels x 8 XCDs x a line per clock; tools/microbench/l2_curve.hip), 190 G/s from this kernel's loads with a
+// third of their lanes active; whether a request hits or misses its XCD's 4-MiB L2 matters little next to that (a fit over two layouts: 1 / 200 G/s against 1 / 135 G/s).  So the
+// kernel is written to the currency "L2 requests per byte": the byte class, the hottest rows and the hottest records in LDS, a record in ONE 16-byte load (which brings the next
+// record of its path along: a lane that follows the path asks for nothing), a byte no needle contains answered without any load (it leads to the root from everywhere), text asked
+// for 64 bytes at a time, and the first 16 columns of every row a second time in a table of their own where two rows share a line (am_flatten.cpp).
 //
 // Work split: unit u = bytes [u * chunk, (u + 1) * chunk) of the concatenated batch, one lane each; the lane owns the matches whose LAST byte lies in its unit and
 // warms its state up from the root over the `warm` bytes before it (clipped to the haystack start; a haystack boundary inside the unit resets the state).
@@ -58,7 +61,9 @@ typedef __attribute__((address_space(3))) uint8_t lds_u8_t;
 __device__ __forceinline__ uint32_t lds_read_u8(uint32_t byte_addr) { return *reinterpret_cast<const lds_u8_t*>((uintptr_t)byte_addr); }
 
 // hot table and chain records as byte offsets from `next` (the flattener puts them behind the rows; launch_dfa_tw checks that the section spans < 4 GiB)
-struct DfaDev { const uint8_t* base; uint32_t off_hot, off_chain, off_chain2; };
+// lds_rec1 / lds_rec2: LDS addresses of the first lds_n1 single-entry and lds_n2 two-entry records (the flattener numbers both kinds by weight: the first are the hottest)
+struct DfaDev { const uint8_t* base; uint32_t off_hot, off_chain, off_chain2, lds_rec1, lds_rec2, lds_n1, lds_n2; };
+typedef __attribute__((address_space(3))) u32x4_u lds_u32x4_u_t;
 
 template <int MODE>
 struct DfaLane {
@@ -122,9 +127,11 @@ __device__ __forceinline__ uint32_t dfa_step(const DfaView& d, const DfaDev& v, 
         // ONE 16-byte load for both kinds (a divergent if / else would be two dependent trips per turn): a single-child record is the first half of what is read
         // (the flattener pads the table by a record), a two-children record all of it
         const bool two = state >= d.n_rows + d.n_single;
-        const uint32_t at = two ? v.off_chain2 + ((state - d.n_rows - d.n_single) << 4) : v.off_chain + ((state - d.n_rows) << 3);
+        const uint32_t idx = two ? state - d.n_rows - d.n_single : state - d.n_rows;
+        const uint32_t at = two ? v.off_chain2 + (idx << 4) : v.off_chain + (idx << 3);
         u32x4_u q;
-        if (!two && state == pf.state) { q.x = pf.x; q.y = pf.y; q.z = 0u; q.w = 0u; pf.state = kNone; }
+        if (idx < (two ? v.lds_n2 : v.lds_n1)) q = *reinterpret_cast<const lds_u32x4_u_t*>((uintptr_t)(two ? v.lds_rec2 + (idx << 4) : v.lds_rec1 + (idx << 3)));      // the hottest records: LDS
+        else if (!two && state == pf.state) { q.x = pf.x; q.y = pf.y; q.z = 0u; q.w = 0u; pf.state = kNone; }
         else {
             q = *reinterpret_cast<const u32x4_u*>(v.base + at);
             if (!two) { pf.state = state + 1u; pf.x = q.z; pf.y = q.w; }      // (state + 1 may be the first two-entry record: what was read there is the table's pad, and `two` keeps it from being used)
@@ -295,18 +302,22 @@ __device__ __forceinline__ void dfa_walk_unit(DfaLane<MODE>& L, const DfaDev& v,
 // that these are the root, the first letters and the heaviest prefixes: a third or more of the steps on natural text never leave the CU), then its wavefronts take
 // groups of 64 units until none is left.  Token mode: a wavefront's superblock serves the groups it takes until it is full or 16 groups old.
 template <int MODE, int TW, int VAR>
-__global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows)
+__global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut o, uint64_t n_units, uint32_t hot_rows, uint32_t lds_n1, uint32_t lds_n2)
 {
     extern __shared__ uint32_t s_dyn[];
     uint32_t* s_rows = s_dyn;                                                     // hot_rows << 5 entries: columns 1 .. 32 of the first rows
     uint32_t* s_wave = s_dyn + ((size_t)hot_rows << kLdsLog2Cols);                // 16 x 8: per wavefront, token mode (DfaLane::wv)
     uint8_t* s_cls = reinterpret_cast<uint8_t*>(s_wave + 128);
+    uint32_t* s_rec1 = reinterpret_cast<uint32_t*>(s_cls + 256);                  // lds_n1 single-entry records (+ one of padding: a record is read as 16 bytes), then lds_n2 two-entry records
+    uint32_t* s_rec2 = s_rec1 + 2u * (lds_n1 + 2u);
     const uint32_t n_cls = 1u << d.log2_classes;
     for (uint32_t i = threadIdx.x; i < (hot_rows << kLdsLog2Cols); i += 1024u) {
         const uint32_t c = (i & ((1u << kLdsLog2Cols) - 1u)) + 1u;
         s_rows[i] = c < n_cls ? d.next[((uint64_t)(i >> kLdsLog2Cols) << d.log2_classes) + c] : 0u;
     }
     if (threadIdx.x < 256u) s_cls[threadIdx.x] = d.cls[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < 2u * (lds_n1 + 2u); i += 1024u) s_rec1[i] = i < 2u * (lds_n1 + 1u) ? reinterpret_cast<const uint32_t*>(d.chain)[i] : 0u;      // (chain[] is padded by one record)
+    for (uint32_t i = threadIdx.x; i < 4u * lds_n2; i += 1024u) s_rec2[i] = reinterpret_cast<const uint32_t*>(d.chain2)[i];
     // (the wavefront's number goes through readfirstlane: everything derived from it -- the group, the text base, the wavefront's LDS words -- is then uniform for
     // the compiler as well and lives in scalar registers)
     const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave)), lane = threadIdx.x % kWave;
@@ -318,6 +329,7 @@ __global__ __launch_bounds__(1024, 8) void k_dfa(DfaView d, BatchView b, ScanOut
     v.off_hot = (uint32_t)(reinterpret_cast<const uint8_t*>(d.hot) - v.base);
     v.off_chain = (uint32_t)(reinterpret_cast<const uint8_t*>(d.chain) - v.base);
     v.off_chain2 = (uint32_t)(reinterpret_cast<const uint8_t*>(d.chain2) - v.base);
+    v.lds_rec1 = (uint32_t)(uintptr_t)s_rec1; v.lds_rec2 = (uint32_t)(uintptr_t)s_rec2; v.lds_n1 = lds_n1; v.lds_n2 = lds_n2;
     const uint32_t lds_rows_addr = (uint32_t)(uintptr_t)s_rows, lds_cls_addr = (uint32_t)(uintptr_t)s_cls;       // (the kernel has no static LDS: the dynamic block starts at 0)
     const uint64_t n_groups = (n_units + kWave - 1) / kWave, n_waves = (uint64_t)gridDim.x * 16u;
     const uint32_t W = (d.warm + 15u) & ~15u;
@@ -450,7 +462,7 @@ uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.t
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
 static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (kLdsLog2Cols + 2u)); }
 // AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = the walk (1: 16 bytes of text per request, lanes in step; 2: 64 bytes, lanes in step; 3: 64 bytes, lanes out of step; 0: the default),
-// bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits)
+// bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits), bit 24 = no records in LDS
 static uint32_t dfa_tune() { const long v = cfg::get(cfg::kDfaTune); return v > 0 ? (uint32_t)v : 0u; }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 {
@@ -495,8 +507,13 @@ static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const Scan
     if (!dfa_usable(d)) return hipErrorInvalidValue;         // (make_plan does not come here with such a section)
     uint32_t hot = dfa_hot_rows(d);
     if ((dfa_tune() >> 8) & 0xFFFFu) hot = std::min<uint32_t>(hot, ((dfa_tune() >> 8) & 0xFFFFu) - 1u);
-    const size_t lds = ((size_t)dfa_hot_rows(d) << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
-    hipLaunchKernelGGL((k_dfa<MODE, TW, VAR>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot);
+    // what is left of a workgroup's 80 KiB after the rows: the hottest records (measured on the natural-text workload: the first 640 single-entry records take 1.9 % of the steps,
+    // the first 640 two-entry ones 1.9 %; a row more takes 0.01 %)
+    const size_t lds_fixed = ((size_t)dfa_hot_rows(d) << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
+    uint32_t n1 = std::min<uint32_t>(d.n_single, 640u), n2 = std::min<uint32_t>(d.n_states - d.n_rows - d.n_single, 640u);
+    if ((dfa_tune() >> 24) & 1u) n1 = n2 = 0u;
+    const size_t lds = lds_fixed + 8u * (n1 + 2u) + 16u * n2;
+    hipLaunchKernelGGL((k_dfa<MODE, TW, VAR>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot, n1, n2);
     return hipGetLastError();
 }
 template <int MODE>
