@@ -2,6 +2,9 @@
 // There is deliberately no CPU execution path here: every run entry point needs a HIP device.
 #include "am_host.h"
 
+#include <condition_variable>
+#include <sys/mman.h>
+
 using namespace am;
 using namespace am::dev;
 using namespace am::host;
@@ -626,8 +629,19 @@ void oneshot_trim(int dev)
 {
     am_batch*& b = tl_state.oneshot[dev];
     if (!b) return;
+    // What a thread's one-shot batch may keep between calls: a sixteenth of the device's memory (18 GB of 288), at least 256 MiB.  (Until round 6: 256 MiB -- every
+    // large call then freed and re-allocated its text and pools, and amdgpu wipes freed VRAM through the SDMA engines that the records' copy to the host uses
+    // right afterwards: 29 GB/s instead of 50, tools/experiments/host_results/README.md.)
+    static std::atomic<size_t> keep[kMaxDev];
+    size_t limit = keep[dev].load(std::memory_order_relaxed);
+    if (limit == 0) {
+        size_t free_b = 0, total_b = 0;
+        OnDevice od(dev);
+        limit = (od.rc == AM_OK && hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? std::max<size_t>(total_b / 16, (size_t)256 << 20) : (size_t)256 << 20;
+        keep[dev].store(limit, std::memory_order_relaxed);
+    }
     const size_t held = b->text_buf.cap + b->pool.cap + b->hidx.cap + b->unit_offsets.cap + b->hay_counts.cap;
-    if (held > (256ull << 20)) { am_batch_destroy(b); b = nullptr; }
+    if (held > limit) { am_batch_destroy(b); b = nullptr; }
 }
 }  // namespace
 
@@ -1359,7 +1373,8 @@ extern "C" int am_count_range(const am_automaton* a, int case_mode, const am_sli
 
 // ------------------------------------------------------------------ results
 
-// one host block of a freed large result is kept for the next one (up to 256 MiB; larger ones go back to the allocator)
+// one host block of a freed large result is kept for the next one (up to 8 GiB; larger ones go back to the allocator): mapping, first touch and release of a
+// 5-GB block cost as much as copying the records into it (0.18 s + 0.18 s, measured)
 struct HostCache {
     std::mutex mu; void* p = nullptr; size_t cap = 0;
     void* take(size_t need, size_t* cap_out)
@@ -1370,7 +1385,7 @@ struct HostCache {
     }
     void give(void* q, size_t c)
     {
-        if (c > ((size_t)256 << 20)) { std::free(q); return; }
+        if (c > ((size_t)8 << 30)) { std::free(q); return; }
         void* old = nullptr;
         { std::lock_guard<std::mutex> lk(mu); old = p; p = q; cap = c; }
         std::free(old);
@@ -1448,6 +1463,79 @@ static int fetch_through_pinned(void* dst, const void* d_src, size_t bytes, int 
     return AM_OK;
 }
 
+// device -> a pageable host block of several GiB (a match-dense result: natural text yields 2.5 x its own size in records).  Page-locking such a block costs more than
+// moving it (hipHostMalloc of 5.5 GB: 1.1 s, hipHostFree 0.7 s, measured in round 6 -- the whole call ran at 1.7 GiB/s of text), so the records cross PCIe into three
+// page-locked 32-MiB pieces that take turns (kept per device), and a few threads copy each piece out while the next two are on their way; the block itself is
+// asked for in huge pages (its first touch and its release are then cheap).
+static int fetch_parallel(void* dst, const void* d_src, size_t bytes, int dev)
+{
+    struct DownloadStage { std::mutex mu; uint8_t* buf[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; };
+    static DownloadStage per_device[kMaxDev];
+    DownloadStage& ds = per_device[dev];
+    constexpr size_t kPiece = 32u << 20;                         // (8 ... 128 MiB: the same rate)
+    std::lock_guard<std::mutex> stage_lk(ds.mu);                 // big downloads from one device take turns (they share its PCIe link anyway)
+    if (!ds.buf[0]) {
+        bool good = true;
+        for (int k = 0; k < 3 && good; k++) good = hipHostMalloc((void**)&ds.buf[k], kPiece, hipHostMallocPortable) == hipSuccess && hipEventCreateWithFlags(&ds.ev[k], hipEventDisableTiming) == hipSuccess;
+        if (!good) {
+            (void)hipGetLastError();
+            for (int k = 0; k < 3; k++) { if (ds.buf[k]) (void)hipHostFree(ds.buf[k]); if (ds.ev[k]) (void)hipEventDestroy(ds.ev[k]); ds.buf[k] = nullptr; ds.ev[k] = nullptr; }
+            return fail(AM_ERR_OOM, "pinned pieces for a large download could not be created");
+        }
+    }
+    hipStream_t st; AM_TRY(get_stream(dev, &st));                // the calling thread's stream: behind the kernels that wrote the records
+    const size_t n_pieces = (bytes + kPiece - 1) / kPiece;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = std::max(1u, std::min(16u, hw ? hw / 2u : 1u));      // (8 threads copy 29 GB/s out of the pieces, the wire brings 50)
+    std::mutex mu; std::condition_variable cv;
+    size_t ready = 0;                                            // pieces whose DMA has finished
+    bool failed = false;
+    std::vector<unsigned> copied(n_pieces, 0);                   // threads that have copied their share of piece i out
+    auto worker = [&](unsigned t) {
+        for (size_t i = 0; i < n_pieces; i++) {
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return ready > i || failed; }); if (failed) return; }
+            const size_t lo = i * kPiece, len = std::min(kPiece, bytes - lo);
+            const size_t step = ((len + n_threads - 1) / n_threads + 4095) & ~(size_t)4095, a = std::min(len, t * step), z = std::min(len, a + step);
+            if (a < z) std::memcpy((uint8_t*)dst + lo + a, ds.buf[i % 3] + a, z - a);
+            { std::lock_guard<std::mutex> lk(mu); if (++copied[i] == n_threads) cv.notify_all(); }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < n_threads; t++) pool.emplace_back(worker, t);
+    hipError_t e = hipSuccess;
+    auto issue = [&](size_t i) {
+        const size_t lo = i * kPiece, len = std::min(kPiece, bytes - lo);
+        e = hipMemcpyAsync(ds.buf[i % 3], (const uint8_t*)d_src + lo, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(ds.ev[i % 3], st);
+    };
+    for (size_t i = 0; i < std::min<size_t>(3, n_pieces) && e == hipSuccess; i++) issue(i);
+    for (size_t i = 0; i < n_pieces && e == hipSuccess; i++) {
+        e = hipEventSynchronize(ds.ev[i % 3]);
+        if (e != hipSuccess) break;
+        { std::lock_guard<std::mutex> lk(mu); ready = i + 1; }
+        cv.notify_all();
+        if (i + 3 < n_pieces) {                                  // its buffer takes piece i + 3 once every thread has copied its share of piece i out
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return copied[i] == n_threads; }); }
+            issue(i + 3);
+        }
+    }
+    if (e != hipSuccess) { { std::lock_guard<std::mutex> lk(mu); failed = true; } cv.notify_all(); }
+    for (auto& th : pool) th.join();
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); return fail(AM_ERR_HIP, std::string("copying the match records to the host: ") + hipGetErrorString(e)); }
+    return AM_OK;
+}
+// a host block for a large result: 2-MiB aligned and advised into huge pages (first touch and release of several GiB of 4-KiB pages cost tenths of a second)
+static void* big_block_alloc(size_t bytes)
+{
+    constexpr size_t kHuge = (size_t)2 << 20;
+    if (bytes < 8 * kHuge) return std::malloc(bytes);
+    void* q = std::aligned_alloc(kHuge, (bytes + kHuge - 1) & ~(kHuge - 1));
+#ifdef MADV_HUGEPAGE
+    if (q) (void)madvise(q, (bytes + kHuge - 1) & ~(kHuge - 1), MADV_HUGEPAGE);
+#endif
+    return q;
+}
+
 extern "C" int am_release_host_memory(void)
 {
     pinned_cache().trim();
@@ -1475,7 +1563,7 @@ extern "C" const am_match* am_matches_data(am_matches* m)
             if (bytes > kFetchPiece) {
                 // page-locked block + one DMA (in 256-MiB requests, so that a huge result does not sit in one multi-second call of the runtime)
                 m->big = (am_match*)pinned_cache().take(bytes, &m->big_cap);
-                if (!m->big) {
+                if (!m->big && bytes <= kPinnedKeep) {              // (a block that would not be kept is not page-locked either: fetch_parallel below)
                     void* q = nullptr;
                     const size_t want = bytes + bytes / 16 + 4096;
                     if (hipHostMalloc(&q, want, hipHostMallocPortable) == hipSuccess) { m->big = (am_match*)q; m->big_cap = want; }
@@ -1495,12 +1583,14 @@ extern "C" const am_match* am_matches_data(am_matches* m)
                 }
             }
             m->big = (am_match*)g_host_cache.take(bytes, &m->big_cap);      // (a block used before has its pages: a fresh 100-MB block costs 10 ms of page faults)
-            if (!m->big) { m->big_cap = bytes + bytes / 16; m->big = (am_match*)std::malloc(m->big_cap); }
+            if (!m->big) { m->big_cap = bytes + bytes / 16; m->big = (am_match*)big_block_alloc(m->big_cap); }
             if (!m->big) { fail(AM_ERR_OOM, "out of host memory for the match records"); return nullptr; }
             if (bytes <= kFetchPiece) {                       // a few MiB: the runtime's own staged copy is faster than two pieces of ours (1.8 MB: 290 against 410 us per am_run)
                 hipError_t e = hipMemcpy(m->big, m->d_records + m->first, bytes, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { fail(AM_ERR_HIP, std::string("hipMemcpy(records): ") + hipGetErrorString(e)); std::free(m->big); m->big = nullptr; return nullptr; }
-            } else if (fetch_through_pinned(m->big, m->d_records + m->first, bytes, m->dev) != AM_OK) { std::free(m->big); m->big = nullptr; return nullptr; }
+            } else if ((bytes > kPinnedKeep ? fetch_parallel(m->big, m->d_records + m->first, bytes, m->dev) : fetch_through_pinned(m->big, m->d_records + m->first, bytes, m->dev)) != AM_OK) {
+                std::free(m->big); m->big = nullptr; return nullptr;
+            }
         }
         m->fetched = true;
     }

@@ -347,7 +347,8 @@ AM_API int am_set_stream(void* hip_stream);   /* hipStream_t for all subsequent 
 AM_API int am_get_stream(void** hip_stream);  /* the stream the calling thread's launches on the current device go to (to order other work after them) */
 AM_API int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_cap);
 /* Host blocks of large results are the library's own (am_matches_data); one freed block -- page-locked, up to 1 GiB -- is kept for the next
- * large result.  This gives it back to the system now (page-locked memory is a shared, limited resource). */
+ * large result, and so is one pageable block of a result beyond that (up to 8 GiB: its pages are there, the next result of that size is
+ * copied into it at the speed of the wire).  This gives both back to the system now (page-locked memory is a shared, limited resource). */
 AM_API int am_release_host_memory(void);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 AM_API int am_profile_enable(int on);

@@ -108,3 +108,41 @@ def test_five_gib_table_walk_route_equals_the_oracle_around_4_gib():
     # kernel 0: the library's own choice (the sample walk sends a dictionary over its language to k_dfa); 3: the table walk forced; 2: the same batch on the suffix filter
     n_hay, n_checked = check_large("natural_100k_10GiB", kernels=(0, 3, 2))
     assert n_checked >= 40
+
+
+def test_a_result_beyond_one_gib_reaches_the_host_whole():
+    """am_matches_data of a result larger than the page-locked block the library keeps (1 GiB): the records cross PCIe through three page-locked pieces and a few
+    copying threads (am_abi.cpp fetch_parallel, round 6).  Compared record for record with the same result read in plain copies (am_matches_copy), twice: the
+    second call finds the kept host block."""
+    import torch
+    wl = "natural_100k_10GiB"
+    w = synth.WORKLOADS[wl]
+    needles = synth.needles_for(wl)
+    a = am.Automaton(needles)
+    lib = am.api.libam()
+    dev = torch.device("cuda:0")
+    n_hay = 512
+    text, n_bytes = synth.haystacks_device(needles, w["mixed"], 0, n_hay * (w["hay_bytes"] // synth.CELL), dev, natural=True)
+    offs = torch.arange(n_hay + 1, dtype=torch.int64, device=dev) * w["hay_bytes"]
+    b = C.c_void_p()
+    am.api.check(lib.am_batch_from_device(text.data_ptr(), offs.data_ptr(), n_hay, n_bytes, C.byref(b)))
+    lib.am_matches_data.restype = C.c_void_p
+    try:
+        for _ in range(2):
+            m = C.c_void_p()
+            am.api.check(lib.am_run_batch(a.device, w["case"], b, C.byref(m)))
+            n = int(lib.am_matches_size(m))
+            assert n * 16 > (1 << 30) + (64 << 20), n
+            p = lib.am_matches_data(m)
+            assert p, lib.am_last_error()
+            got = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n * 2,))
+            step = 4 << 20                                    # records per plain copy
+            ref = np.empty(step * 2, dtype=np.uint64)
+            for first in range(0, n, step):
+                k = min(step, n - first)
+                am.api.check(lib.am_matches_copy(m, C.c_uint64(first), C.c_uint64(k), ref.ctypes.data_as(C.c_void_p)))
+                assert np.array_equal(got[first * 2:(first + k) * 2], ref[:k * 2]), first
+            lib.am_matches_free(m)
+    finally:
+        lib.am_batch_destroy(b)
+        lib.am_release_host_memory()
