@@ -632,6 +632,8 @@ void oneshot_trim(int dev)
     // What a thread's one-shot batch may keep between calls: a sixteenth of the device's memory (18 GB of 288), at least 256 MiB.  (Until round 6: 256 MiB -- every
     // large call then freed and re-allocated its text and pools, and amdgpu wipes freed VRAM through the SDMA engines that the records' copy to the host uses
     // right afterwards: 29 GB/s instead of 50, tools/experiments/host_results/README.md.)
+    const size_t held = b->text_buf.cap + b->pool.cap + b->hidx.cap + b->unit_offsets.cap + b->hay_counts.cap;
+    if (held <= ((size_t)256 << 20)) return;
     static std::atomic<size_t> keep[kMaxDev];
     size_t limit = keep[dev].load(std::memory_order_relaxed);
     if (limit == 0) {
@@ -640,7 +642,6 @@ void oneshot_trim(int dev)
         limit = (od.rc == AM_OK && hipMemGetInfo(&free_b, &total_b) == hipSuccess) ? std::max<size_t>(total_b / 16, (size_t)256 << 20) : (size_t)256 << 20;
         keep[dev].store(limit, std::memory_order_relaxed);
     }
-    const size_t held = b->text_buf.cap + b->pool.cap + b->hidx.cap + b->unit_offsets.cap + b->hay_counts.cap;
     if (held > limit) { am_batch_destroy(b); b = nullptr; }
 }
 }  // namespace
