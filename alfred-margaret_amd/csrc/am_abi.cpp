@@ -3,6 +3,7 @@
 #include "am_host.h"
 
 #include <condition_variable>
+#include <deque>
 #include <sys/mman.h>
 
 using namespace am;
@@ -162,19 +163,34 @@ struct ResultCopies {
 // and not more than twice what is needed): a caller that scans batch after batch does not pay hipMalloc/hipFree of
 // hundreds of megabytes per call.
 namespace {
+// Device arrays of freed results, kept for the next ones: up to four (a segmented am_run has three in flight), 16 GiB in all; the oldest goes first.  (One block until
+// round 6.  Every hipFree of a large array is followed by amdgpu's wipe of the freed VRAM on the SDMA engines, which halves the rate of the copies to the host for about a
+// second -- tools/experiments/host_results/README.md -- so arrays that will be wanted again in a moment are not freed.)
 struct RecordCache {
-    std::mutex mu; void* p = nullptr; size_t cap = 0;
+    struct Block { void* p; size_t cap; };
+    std::mutex mu; std::vector<Block> kept;
     void* take(size_t need, size_t* cap_out)
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (p && cap >= need && cap <= 2 * need + (1u << 20)) { void* r = p; *cap_out = cap; p = nullptr; cap = 0; return r; }
-        return nullptr;
+        size_t best = kept.size();
+        for (size_t i = 0; i < kept.size(); i++)
+            if (kept[i].cap >= need && kept[i].cap <= 2 * need + (1u << 20) && (best == kept.size() || kept[i].cap < kept[best].cap)) best = i;
+        if (best == kept.size()) return nullptr;
+        void* r = kept[best].p; *cap_out = kept[best].cap;
+        kept.erase(kept.begin() + (std::ptrdiff_t)best);
+        return r;
     }
     void give(void* q, size_t c)
     {
-        void* old = nullptr;
-        { std::lock_guard<std::mutex> lk(mu); old = p; p = q; cap = c; }
-        if (old) (void)hipFree(old);
+        std::vector<Block> out;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            kept.push_back(Block{q, c});
+            size_t total = 0;
+            for (const Block& b : kept) total += b.cap;
+            while (kept.size() > 4 || (kept.size() > 1 && total > ((size_t)16 << 30))) { total -= kept.front().cap; out.push_back(kept.front()); kept.erase(kept.begin()); }
+        }
+        for (const Block& b : out) (void)hipFree(b.p);
     }
 };
 RecordCache g_record_cache[kMaxDev];
@@ -1278,9 +1294,23 @@ extern "C" int am_contains_any(const am_automaton* a, int case_mode, const am_sl
     return rc;
 }
 
+static int run_segmented(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t total, am_matches** out);
+constexpr uint64_t kRunSegmentedFrom = 1ull << 30;        // host batches from here on are scanned in segments whose records travel back while the next segment goes up
+constexpr uint64_t kRunSegment = 256ull << 20;
+
 extern "C" int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out)
 {
     if (!a) return fail(AM_ERR_INVALID, "null automaton");
+    if (n_hay >= 2 && hay && out && cfg::get(cfg::kRunSegments) != 0) {
+        uint64_t total = 0;
+        bool sound = true;
+        for (size_t i = 0; i < n_hay && sound; i++) { sound = !(hay[i].len && !hay[i].ptr); total += hay[i].len; }
+        // (only automata whose image carries a DFA section -- dictionaries, small automata: the ones that meet match-dense text; for the others a result is a few per
+        // cent of its text, the upload is the bound, and a first segment scanned apart costs 4-15 % of the call: 46 against 48 GiB/s on cfg2's 2 GiB, measured)
+        const Flavor* f = nullptr;
+        if (sound && n_hay < 0xFFFFFFFFull && (cfg::get(cfg::kRunSegments) > 0 || (total >= kRunSegmentedFrom && prepare(a, case_mode, &f) == AM_OK && f->h.dfa_n_states != 0)))
+            return run_segmented(a, case_mode, hay, n_hay, total, out);
+    }
     am_batch* b = oneshot_get(a->dev);                    // this thread's batch on the automaton's device
     int rc = upload_slices(hay, n_hay, b, true);
     if (rc == AM_OK) rc = am_run_batch(a, case_mode, b, out);
@@ -1537,6 +1567,98 @@ static void* big_block_alloc(size_t bytes)
     return q;
 }
 
+// am_run on host slices of 1 GiB and more.  A call used to be upload -> scan -> (am_matches_data) download, one after the other, and on match-dense text the records
+// are several times the text (natural language against a dictionary: 2.5 x): the wire stood still in one direction while the other worked.  Here the haystacks go up in
+// segments of >= 256 MiB (whole haystacks); a segment is scanned as a batch of its own, its records get their haystack numbers rebased on the device, and a second thread
+// brings them into their place in the host block (fetch_parallel, on its own stream) while the calling thread gathers, uploads and scans the next segment -- PCIe is full
+// duplex.  The block is sized from the first segment's density (and grown if the text turns denser).  A first segment with few records (< 1/8 of its text in bytes: the
+// upload is the bound, nothing to overlap) sends all the rest up as ONE segment.  The result lives on the host only: am_matches_data is immediate, am_matches_device_data
+// is NULL, am_matches_haystack_range / am_matches_copy search and copy the host block.
+static int run_segmented(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t total, am_matches** out)
+{
+    *out = nullptr;
+    const int dev = a->dev;
+    AM_TRY(ensure_runtime());
+    ON_DEVICE(dev);
+    am_batch* b = oneshot_get(dev);
+    struct Job { am_matches* m; uint64_t at; };
+    static const bool trace = std::getenv("AM_RUN_TRACE") != nullptr;      // (measurements: when each segment's steps begin and end, ms since the call began, on stderr)
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Job> jobs; bool closing = false; int dl_rc = AM_OK; std::string dl_err;
+    am_match* block = nullptr; size_t block_cap = 0;              // bytes
+    std::thread downloader([&] {
+        OnDevice od(dev);
+        for (;;) {
+            Job j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closing || !jobs.empty(); }); if (jobs.empty()) return; j = jobs.front(); }
+            int rc = od.rc;
+            const double t0 = now_ms();
+            if (rc == AM_OK && j.m->n) rc = fetch_parallel(block + j.at, j.m->d_records + j.m->first, (size_t)j.m->n * sizeof(Record), dev);      // (block is not moved while a job is queued)
+            const std::string msg = rc != AM_OK ? std::string(am_last_error()) : std::string();
+            const double t1 = now_ms();
+            const uint64_t n_j = j.m->n;
+            am_matches_free(j.m);
+            if (trace) std::fprintf(stderr, "[am_run] download of %llu records: %.1f .. %.1f ms, freed at %.1f\n", (unsigned long long)n_j, t0, t1, now_ms());
+            { std::lock_guard<std::mutex> lk(mu); jobs.pop_front(); if (rc != AM_OK && dl_rc == AM_OK) { dl_rc = rc; dl_err = msg; } }
+            cv.notify_all();
+        }
+    });
+    auto drain = [&] { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return jobs.empty(); }); };
+    int rc = AM_OK;
+    uint64_t n_total = 0;
+    bool rest_at_once = false;
+    const uint64_t segment = cfg::get(cfg::kRunSegments) > 0 ? (uint64_t)cfg::get(cfg::kRunSegments) << 10 : kRunSegment;
+    hipStream_t st = nullptr;
+    rc = get_stream(dev, &st);
+    for (size_t i = 0; i < n_hay && rc == AM_OK;) {
+        size_t j = i; uint64_t bytes = 0;
+        while (j < n_hay && (rest_at_once || bytes < segment)) bytes += hay[j++].len;
+        const double t_up = now_ms();
+        rc = upload_slices(hay + i, j - i, b, true);
+        const double t_scan = now_ms();
+        am_matches* m = nullptr;
+        { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return jobs.size() < 2; }); }      // at most three record arrays alive: one on its way, one waiting, this one
+        if (rc == AM_OK) rc = run_batch_impl(a, case_mode, b, &m, false);
+        if (rc != AM_OK) break;
+        if (trace) std::fprintf(stderr, "[am_run] segment of %zu haystacks, %llu bytes: upload %.1f .. %.1f, scan .. %.1f ms\n", j - i, (unsigned long long)bytes, t_up, t_scan, now_ms());
+        hipError_t e = m->n ? launch_hay_rebase(m->d_records + m->first, m->n, (uint32_t)i, st) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(st);          // the records are final before another thread's stream reads them
+        if (e != hipSuccess) { am_matches_free(m); rc = fail(AM_ERR_HIP, std::string("am_run (segments): ") + hipGetErrorString(e)); break; }
+        const size_t need = (size_t)(n_total + m->n) * sizeof(Record);
+        if (need > block_cap) {
+            // the first segment's density, carried over the whole batch, + a fifth; later: half as much again
+            const double scale = i == 0 && bytes ? (double)total / (double)bytes * 1.2 : 1.5;
+            const size_t want = std::max<size_t>((size_t)((double)need * scale) + ((size_t)1 << 20), need);
+            drain();                                                // nothing copies into the old block while it moves
+            size_t got_cap = 0;
+            am_match* nb = (am_match*)g_host_cache.take(want, &got_cap);
+            if (!nb) { got_cap = want; nb = (am_match*)big_block_alloc(want); }
+            if (!nb) { am_matches_free(m); rc = fail(AM_ERR_OOM, "out of host memory for the match records"); break; }
+            if (block) { std::memcpy(nb, block, (size_t)n_total * sizeof(Record)); g_host_cache.give(block, block_cap); }
+            block = nb; block_cap = got_cap;
+        }
+        if (i == 0 && (uint64_t)m->n * sizeof(Record) * 8u < bytes) rest_at_once = true;
+        { std::lock_guard<std::mutex> lk(mu); jobs.push_back(Job{m, n_total}); }
+        cv.notify_all();
+        n_total += m->n;
+        i = j;
+    }
+    { std::lock_guard<std::mutex> lk(mu); closing = true; }
+    cv.notify_all();
+    downloader.join();
+    oneshot_trim(dev);
+    if (rc == AM_OK && dl_rc != AM_OK) rc = fail(dl_rc, dl_err);
+    if (rc != AM_OK) { if (block) g_host_cache.give(block, block_cap); return rc; }
+    am_matches* res = new am_matches();
+    res->dev = dev; res->n = n_total; res->fetched = true;
+    if (n_total) { res->big = block; res->big_cap = block_cap; res->big_pinned = false; }
+    else if (block) g_host_cache.give(block, block_cap);
+    *out = res;
+    return AM_OK;
+}
+
 extern "C" int am_release_host_memory(void)
 {
     pinned_cache().trim();
@@ -1607,6 +1729,13 @@ extern "C" int am_matches_haystack_range(const am_matches* m, uint32_t haystack,
     if (!m || !first_out || !count_out) return fail(AM_ERR_INVALID, "am_matches_haystack_range: null argument");
     *first_out = 0; *count_out = 0;
     if (m->n == 0) return AM_OK;
+    if (!m->d_records) {                                          // a result assembled on the host (am_run on a large host batch)
+        if (!m->big) return fail(AM_ERR_INVALID, "am_matches_haystack_range: the result has no records");
+        const am_match* lo = std::lower_bound(m->big, m->big + m->n, haystack, [](const am_match& r, uint32_t h) { return r.haystack < h; });
+        const am_match* hi = std::upper_bound(lo, (const am_match*)(m->big + m->n), haystack, [](uint32_t h, const am_match& r) { return h < r.haystack; });
+        *first_out = (uint64_t)(lo - m->big); *count_out = (uint64_t)(hi - lo);
+        return AM_OK;
+    }
     OnDevice od(m->dev);
     const Record* r = m->d_records + m->first;
     auto lower = [&](uint64_t key, uint64_t* out) -> int {        // first index whose haystack >= key
@@ -1632,6 +1761,11 @@ extern "C" int am_matches_copy(const am_matches* m, uint64_t first, uint64_t cou
     if (!m || (count && !out)) return fail(AM_ERR_INVALID, "am_matches_copy: null argument");
     if (first > m->n || count > m->n - first) return fail(AM_ERR_INVALID, "am_matches_copy: range outside the result");
     if (count == 0) return AM_OK;
+    if (!m->d_records) {                                          // a result assembled on the host
+        if (!m->big) return fail(AM_ERR_INVALID, "am_matches_copy: the result has no records");
+        std::memcpy(out, m->big + first, (size_t)count * sizeof(Record));
+        return AM_OK;
+    }
     OnDevice od(m->dev);
     HIP_TRY(hipMemcpy(out, m->d_records + m->first + first, (size_t)count * sizeof(Record), hipMemcpyDeviceToHost));
     return AM_OK;

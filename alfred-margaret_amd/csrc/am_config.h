@@ -35,6 +35,7 @@ enum Key {
     kRpLds,               // AM_RP_LDS: 0 = the one-kernel loop never keeps a haystack's lists in LDS (k_rp_loop alone, round 4's kernel); unset / 1: k_rp_lds first, k_rp_loop for what it gives up
     kRpNoPli,             // AM_RP_NO_PLI: k_rp_lds keeps its payload column also for replacers whose priorities are minus the payload index (A/B: 4 instead of 5 wavefronts per SIMD)
     kRpLoop,              // AM_RP_LOOP: all passes of a haystack in one kernel (am_rploop.hip): 0 = never, 1 = whenever the replacer allows it; unset: many documents
+    kRunSegments,         // AM_RUN_SEGMENTS: am_run on host slices in segments whose records come back while the next segment goes up: 0 = never (the call in one piece), k > 0 = always, in segments of k KiB (tests); unset: from 1 GiB on, 256-MiB segments
     kCount
 };
 
@@ -47,7 +48,7 @@ inline const char* name_of(int k)
 {
     static const char* const names[kCount] = {"AM_SF_ABLATE", "AM_SF_POOL_BLOCKS", "AM_SF_WQ", "AM_SF_WQ_ITERS", "AM_SF_MAX_BLOOM_LOG2_WORDS", "AM_SF_NO_CHILDREN", "AM_SF_PROBE_TWO", "AM_NO_SMALL_RUN", "AM_DFA", "AM_DFA_CHUNK", "AM_DFA_RARE_PERMILLE", "AM_DFA_MIN_KIB", "AM_DFA_TUNE", "AM_DFA_HOT_LOG2", "AM_DFA_NO_CHAINS", "AM_FLATTEN_TRACE", "AM_FLATTEN_SERIAL", "AM_NO_IDS_SCAN",
                                               "AM_RP_FULL_SCANS", "AM_RP_SPLICE", "AM_RP_PIECES", "AM_RP_PARALLEL_FOLD", "AM_RP_GROUPS", "AM_RP_NO_FUSE", "AM_RP_NO_SPIN",
-                                              "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_NO_PLI", "AM_RP_LOOP"};
+                                              "AM_RP_MAT_MAIN", "AM_RP_NO_RANGE_REUSE", "AM_RP_TRACE", "AM_RP_LOOP_WAVES", "AM_RP_LDS", "AM_RP_NO_PLI", "AM_RP_LOOP", "AM_RUN_SEGMENTS"};
     return names[k];
 }
 constexpr long kUnset = -1;

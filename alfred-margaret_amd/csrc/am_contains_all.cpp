@@ -112,6 +112,7 @@ extern "C" int am_matches_fold_hash(const am_matches* m, const am_needle_ids* id
     if (n_hay && !hash_out) return fail(AM_ERR_INVALID, "hash_out is null");
     if (n_hay >= 0xFFFFFFFFull) return fail(AM_ERR_INVALID, "too many haystacks");
     if (n_hay == 0) return AM_OK;
+    if (m->n && !m->d_records) return fail(AM_ERR_UNSUPPORTED, "am_matches_fold_hash: the result was assembled on the host (am_run on a large host batch) and has no records in HBM");
     AM_TRY(ensure_runtime());
     if (m->dev != ids->a->dev) return fail(AM_ERR_INVALID, "result and values table live on different devices");
     ON_DEVICE(m->dev);

@@ -185,6 +185,18 @@ __global__ void k_range_rebase(Record* __restrict__ recs, uint64_t n, uint64_t a
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) recs[i].end_pos += add;
 }
+// a segment of a host batch scanned on its own (am_run on 1 GiB of slices and more): its haystack numbers count from the segment's first haystack
+__global__ void k_hay_rebase(Record* __restrict__ recs, uint64_t n, uint32_t add)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) recs[i].haystack += add;
+}
+hipError_t launch_hay_rebase(Record* recs, uint64_t n, uint32_t add, hipStream_t st)
+{
+    if (n == 0 || add == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hay_rebase, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, recs, n, add);
+    return hipGetLastError();
+}
 hipError_t launch_range_bounds(const Record* recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* out2, hipStream_t st)
 {
     hipLaunchKernelGGL(k_range_bounds, dim3(1), dim3(64), 0, st, recs, n, x0, x1, out2);

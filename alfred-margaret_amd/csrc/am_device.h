@@ -95,6 +95,7 @@ hipError_t launch_records_reduce(const Record* recs, uint64_t n, const uint32_t*
 // one haystack scanned in ranges (am_run_range): out2 = {records with end_pos <= x0, records with end_pos <= x1}; end_pos += add
 hipError_t launch_range_bounds(const Record* recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* out2, hipStream_t st);
 hipError_t launch_range_rebase(Record* recs, uint64_t n, uint64_t add, hipStream_t st);
+hipError_t launch_hay_rebase(Record* recs, uint64_t n, uint32_t add, hipStream_t st);
 
 // ---- Replacer pass (am_replace.hip) ----------------------------------------------------------
 // same layout as am_payload in include/am.h (Replacer.hs:59-70 Payload, replacement text as a slice of one blob)

@@ -424,6 +424,9 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
         gate_args.kernel, gate_args.parity_oracle_mib = 0, (max(args.workloads_oracle_mib, 512) if w.get("natural") and args.workloads_oracle_mib else args.workloads_oracle_mib)
         parity = parity_gate(gate_args, w, needles, machine, handle, case, batch, text, n_hay, 0, 1, dev, lib) if not args.no_parity else {}
         contains_all = contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib) if name == "cfg2_runText_10k_1GiB" and not args.no_parity else None
+        # natural text from HOST slices: the result is 2.5 x its text, so the call is bound by the records' way back -- am_run goes up in segments and brings a segment's
+        # records down while the next one is uploaded and scanned (csrc/am_abi.cpp run_segmented)
+        host_slices = h2d_inclusive(args, w, handle, case, text, n_hay, lib) if w.get("natural") and not args.no_h2d else None
     finally:
         lib.am_batch_destroy(batch)
     avg_ms = ms.value / max(int(launches.value), 1)
@@ -439,7 +442,7 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
             **({"other_route": other_route} if other_route else {}),
             "parity": {k: parity.get(k) for k in ("hashed", "kernels_agree", "oracle_checked", "oracle_bytes", "oracle_max_byte_offset", "oracle_what", "full_lists_checked", "matches_in_checked")},
             "build_s": round(build_s, 2), **({"build": build, "gpu_build_plus_run": build_plus_run(n_bytes, build, elapsed / steps * 1e3)} if build else {}),
-            **({"contains_all": contains_all} if contains_all else {})}
+            **({"contains_all": contains_all} if contains_all else {}), **({"h2d_inclusive": host_slices} if host_slices else {})}
 
 
 def contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib):

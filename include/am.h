@@ -128,7 +128,10 @@ AM_API int am_automaton_set_kernel(am_automaton* a, int k);
  * am_count:        runWithCase cs 0 (\n _ -> Step (n+1))  per haystack
  *                  (benchmark/haskell/app/Main.hs:67-76 countMatches; counts VALUES, i.e. fold calls)
  * am_contains_any: Searcher.containsAny (Searcher.hs:156-164) per haystack
- * am_run:          runWithCase / runText / runLower (Automaton.hs:442-553): all records */
+ * am_run:          runWithCase / runText / runLower (Automaton.hs:442-553): all records.  A batch of 1 GiB and more against an automaton that may meet
+ *                  match-dense text (a dictionary, a small automaton) goes up in segments of whole haystacks, and a segment's records travel to the host
+ *                  while the next one is uploaded and scanned; such a result lives on the host only (am_matches_data is immediate,
+ *                  am_matches_device_data is NULL, am_matches_fold_hash is not available).  Use am_batch_upload + am_run_batch to keep records in HBM. */
 AM_API int am_count(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint64_t* counts_out);
 AM_API int am_contains_any(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, uint8_t* flags_out);
 AM_API int am_run(const am_automaton* a, int case_mode, const am_slice* hay, size_t n_hay, am_matches** out);
@@ -162,7 +165,7 @@ AM_API int am_run_batch(const am_automaton* a, int case_mode, const am_batch* b,
  * Records are produced in HBM; am_matches_data copies them to the host on first use. */
 AM_API uint64_t am_matches_size(const am_matches* m);
 AM_API const am_match* am_matches_data(am_matches* m);           /* host pointer, owned by m; NULL on error */
-AM_API const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m */
+AM_API const void* am_matches_device_data(const am_matches* m);  /* am_match[size] in HBM, owned by m; NULL for a result assembled on the host (am_run on a large host batch) */
 /* One haystack's records of a large result, without copying all of it: the records are sorted by (haystack, end_pos), so they are the contiguous run
  * [*first_out, *first_out + *count_out) (count 0: no match in that haystack); am_matches_copy brings records [first, first + count) to caller memory.
  * What a lazy fold over one document of a big batch consumes (Automaton.hs:522-534 folds a haystack's matches in order). */

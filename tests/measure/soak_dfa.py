@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU-box soak of the table-walk route (k_dfa, csrc/am_dfa.hip): random fragment automata (Unicode case variants, duplicates, shared prefixes and suffixes), every one
-forced to carry a DFA section (AM_DFA=1) and forced onto the route (am_automaton_set_kernel(a, 3)), with random unit sizes and, every other case, most bytes
-made rare; records, counts and flags against the oracle.  Usage: python tests/measure/soak_dfa.py [cases, default 1500] [seed]"""
+forced to carry a DFA section (AM_DFA=1) and forced onto the route (am_automaton_set_kernel(a, 3)), with random unit sizes, the walk's variants (AM_DFA_TUNE) and,
+every other case, most bytes made rare; records, counts and flags against the oracle.  Usage: python tests/measure/soak_dfa.py [cases, default 1500] [seed]"""
 import os
 import random
 import sys
@@ -28,6 +28,7 @@ for it in range(N):
     am.debug_set("AM_DFA_CHUNK", rng.choice((-1, 64, 80, 256, 4096, 131072)))
     am.debug_set("AM_DFA_RARE_PERMILLE", rng.choice((-1, 400)))
     am.debug_set("AM_DFA_NO_CHAINS", rng.choice((-1, -1, 1)))
+    am.debug_set("AM_DFA_TUNE", rng.choice((-1, -1, 3, 1, 0x1000000)))      # the default walk; lanes out of step; 16 bytes of text per request; no records in LDS
     hays = hays + rng.choice(([], [""], ["", hays[0][:5] if hays else ""]))
     o = oracle.Machine(ns)
     a = am.Automaton(ns)

@@ -76,6 +76,25 @@ def test_fragment_pool_on_the_table_walk(dfa_everywhere, seed):
             check_dfa_route(ns, hays, case)
 
 
+@pytest.mark.parametrize("tune", [3, 1, 0x1000000, 0x103])
+def test_the_walks_variants_report_the_same_records(dfa_everywhere, tune):
+    """AM_DFA_TUNE (am_dfa.hip dfa_tune): lanes out of step inside a 16-byte block (3), 16 bytes of text per request (1), no records in LDS (bit 24), no rows in LDS
+    with lanes out of step (0x103) -- measurement switches, each the same walk by other loads: records, counts and flags against the oracle, image version 17's
+    records (one and two entries, leaning on a row state) on every path."""
+    am.debug_set("AM_DFA_TUNE", tune)
+    try:
+        rng = random.Random(9100 + tune)
+        for _ in range(10):
+            needles, hays = fragment_case(rng, n_hay_max=8, hay_frags=300)
+            if "" in needles or not any(needles):
+                continue
+            for case in (0, 1):
+                ns = [oracle.lower_utf8(n).decode() for n in needles] if case else needles
+                check_dfa_route(ns, hays, case)
+    finally:
+        am.debug_set("AM_DFA_TUNE", -1)
+
+
 @pytest.mark.parametrize("chunk", [64, 256, 131072])
 def test_unit_boundaries_inside_matches_and_code_points(dfa_everywhere, chunk):
     """Small units: every haystack is cut many times, inside needles, inside code points, inside the warm-up of the next unit; haystack boundaries

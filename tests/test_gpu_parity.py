@@ -911,3 +911,55 @@ def test_threads_started_per_call_do_not_leak_pinned_memory():
         seen.append(int(fn()))
     assert seen[-1] == seen[2], seen                     # flat after the first calls (the pool of parked buffers has reached its size)
     assert seen[-1] < (256 << 20)
+
+
+@pytest.mark.parametrize("segment_kib", [64, 300])
+def test_am_run_in_segments_equals_the_call_in_one_piece(segment_kib):
+    """am_run on a large host batch goes up in segments of whole haystacks; a segment's records are rebased on the device and travel back while the next segment is
+    uploaded and scanned (am_abi.cpp run_segmented, round 6).  AM_RUN_SEGMENTS = k forces the path on a small input, in segments of k KiB: ragged haystacks (empty
+    ones, one larger than a segment), against the same call in one piece and against the oracle; the result lives on the host -- am_matches_haystack_range and
+    am_matches_copy answer from there, am_matches_device_data is NULL."""
+    rng = random.Random(600 + segment_kib)
+    needles = synth.make_needles(3000, True)
+    needles = [am.lower_utf8(n).decode("utf-8") for n in needles]
+    text = synth.haystacks_host(needles, True, 0, 6000)
+    sizes = [rng.choice((0, 1, 700, 5000, 40000, 90000)) for _ in range(60)] + [400 << 10]
+    hays, at = [], 0
+    for sz in sizes:
+        hays.append(bytes(text[at:at + sz])); at += sz
+    assert at <= len(text)
+    a = am.Automaton(needles)
+    o = oracle.Machine(needles)
+    lib = am.api.libam()
+    s = am.api._Slices(hays)
+    lib.am_matches_data.restype = C.c_void_p
+    lib.am_matches_device_data.restype = C.c_void_p
+
+    def run(segments):
+        am.debug_set("AM_RUN_SEGMENTS", segments)
+        try:
+            m = C.c_void_p()
+            am.api.check(lib.am_run(a.device, 1, s.arr, s.n, C.byref(m)))
+            n = int(lib.am_matches_size(m))
+            p = lib.am_matches_data(m)
+            rec = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(n * 2,)).copy() if n else np.zeros(0, np.uint64)
+            return m, n, rec
+        finally:
+            am.debug_set("AM_RUN_SEGMENTS", -1)
+
+    m0, n0, rec0 = run(0)
+    m1, n1, rec1 = run(segment_kib)
+    try:
+        assert n0 == n1 and n0 > 1000 and np.array_equal(rec0, rec1)
+        assert lib.am_matches_device_data(m0) and not lib.am_matches_device_data(m1)
+        # the oracle, haystack by haystack, through the host result's own accessors
+        for h in (0, 5, 17, len(hays) - 1):
+            first, count = C.c_uint64(0), C.c_uint64(0)
+            am.api.check(lib.am_matches_haystack_range(m1, h, C.byref(first), C.byref(count)))
+            got = np.zeros(count.value * 2, np.uint64)
+            am.api.check(lib.am_matches_copy(m1, first, count, got.ctypes.data_as(C.c_void_p)))
+            pos, _ = o.run_list(1, hays[h])
+            assert sorted(set(int(x) for x in pos)) == [int(x) for x in got[0::2]], h
+            assert all(int(x) & 0xFFFFFFFF == h for x in got[1::2])
+    finally:
+        lib.am_matches_free(m0); lib.am_matches_free(m1)
