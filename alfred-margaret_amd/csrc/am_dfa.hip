@@ -391,24 +391,29 @@ hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t tot
     return hipGetLastError();
 }
 
-// token -> the record it stands for, at unit_offsets[unit] + seq.  One workgroup per superblock.  A superblock's tokens come from ONE wavefront, in the order it
+// token -> the record it stands for, at unit_offsets[unit] + seq.  A workgroup takes superblock after superblock (a persistent grid: what it learns about the states stays).  A superblock's tokens come from ONE wavefront, in the order it
 // made them (step by step over the 64 units of a group, then the next group it took): written out token by token that is a 16-byte write scattered over 64 stretches
 // of the result, one L2 request each.  So the workgroup first sorts the superblock in LDS by (group ordinal, lane, seq) -- a counting sort: a unit's tokens in one
 // superblock have consecutive seq, so slot = bucket start + seq - the bucket's smallest seq -- and then neighbouring lanes write neighbouring records.  The haystack of a
-// token is looked up from its position (the per-KiB haystack index of the batch; neighbouring records ask for neighbouring entries), the reference state from the DFA state.
+// token is looked up from its position (the per-KiB haystack index of the batch; neighbouring records ask for neighbouring entries), the reference state from the DFA state:
+// a random 8-byte read per record -- most of this kernel's L2 requests (2.6 of 2.8 x 10^8 per 2 GiB of natural text) -- which a direct-mapped table in LDS answers for the
+// states it has seen (text repeats its words: the workgroup keeps the table from superblock to superblock).
 constexpr uint32_t kPlaceBuckets = kTokMaxOrd * kWave;
+constexpr uint32_t kPlaceCacheLog2 = 12;
 __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ pool, const uint32_t* __restrict__ fill, const uint32_t* __restrict__ first_group, uint32_t n_super,
                                                     const uint64_t* __restrict__ unit_offsets, BatchView b, const u32x2* __restrict__ dfa_out, uint32_t n_states, uint32_t chunk, uint32_t n_waves,
                                                     Record* __restrict__ out)
 {
     __shared__ u32x2_v s_tok[kDfaSuper];
     __shared__ uint32_t s_cnt[kPlaceBuckets], s_min[kPlaceBuckets], s_base[kPlaceBuckets];
+    __shared__ u32x2_v s_seen[1u << kPlaceCacheLog2];              // {DFA state, its reference state + 1}: one 8-byte word, written and read whole
     static_assert(kPlaceBuckets == 1024, "one bucket per thread of the workgroup");
-    const uint32_t sb = blockIdx.x;
-    if (sb >= n_super) return;
+    for (uint32_t i = threadIdx.x; i < (1u << kPlaceCacheLog2); i += 1024u) { u32x2_v e; e.x = kNone; e.y = 0u; s_seen[i] = e; }
+    for (uint32_t sb = blockIdx.x; sb < n_super; sb += gridDim.x) {
     const uint32_t n = fill[sb];
-    if (n == 0) return;
+    if (n == 0) continue;                                        // (uniform: the whole workgroup goes on)
     const u32x2_v* tok = pool + (uint64_t)sb * kDfaSuper;
+    __syncthreads();                                             // (the previous superblock's records are out of s_tok)
     s_cnt[threadIdx.x] = 0u; s_min[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
     u32x2_v t[kDfaSuper / 1024];
@@ -450,10 +455,15 @@ __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ 
         const uint32_t h = find_haystack(b, g);
         AM_BOUNDS(g < b.total && h < b.n_hay && b.offsets[h] <= g && g < b.offsets[h + 1] && (q.x & kDfaStateMask) < n_states && dfa_out[q.x & kDfaStateMask].x != 0u &&
                   unit_offsets[u] + ((q.y >> kTokPosBits) & (kTokMaxChunk - 1u)) < unit_offsets[u + 1]);
+        const uint32_t st = q.x & kDfaStateMask, slot = (st * 0x9E3779B1u) >> (32u - kPlaceCacheLog2);
+        const u32x2_v seen = s_seen[slot];
+        uint32_t ref1 = seen.y;
+        if (seen.x != st) { ref1 = dfa_out[st].x; u32x2_v e; e.x = st; e.y = ref1; s_seen[slot] = e; }      // (lanes that race for a slot each write a whole, valid pair)
         u32x4_n r;
         const uint64_t end_pos = g + 1u - b.offsets[h];
-        r.x = (uint32_t)end_pos; r.y = (uint32_t)(end_pos >> 32); r.z = h; r.w = dfa_out[q.x & kDfaStateMask].x - 1u;
+        r.x = (uint32_t)end_pos; r.y = (uint32_t)(end_pos >> 32); r.z = h; r.w = ref1 - 1u;
         __builtin_nontemporal_store(r, reinterpret_cast<u32x4_n*>(out + unit_offsets[u] + ((q.y >> kTokPosBits) & (kTokMaxChunk - 1u))));
+    }
     }
 }
 
@@ -547,7 +557,7 @@ hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut&
 {
     if (n_super == 0) return hipSuccess;
     if (n_waves != dfa_token_waves(d, b, n_cu)) return hipErrorInvalidValue;       // (the launch parameters changed between the walk and the placement)
-    hipLaunchKernelGGL(k_dfa_place, dim3(n_super), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.n_states, d.chunk, n_waves, out);
+    hipLaunchKernelGGL(k_dfa_place, dim3(std::min<uint32_t>(n_super, (uint32_t)n_cu * 2u)), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.n_states, d.chunk, n_waves, out);
     return hipGetLastError();
 }
 
