@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(AcView a, BatchView b, 
                                                         const uint64_t* __restrict__ out_offsets, Record* __restrict__ out)
 {
     __shared__ uint32_t sp_bits[kDenseWords], un_bits[kDenseWords];
+    __shared__ uint32_t un_pre[WRITE ? kDenseWords : 1], sp_pre[WRITE ? kDenseWords : 1];      // write pass: records (all / sparse) of the unit before word w
     __shared__ uint32_t first_ascii[4];
     __shared__ uint32_t scratch[kDenseThreads + 1];
     const uint64_t u = blockIdx.x;
@@ -66,22 +67,40 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(AcView a, BatchView b, 
         atomicOr(&sp_bits[bit >> 5], 1u << (bit & 31u));
     }
     __syncthreads();
-    // classify: word w covers bytes unit_start + 32 w ..
+    // classify: word w covers bytes unit_start + 32 w ..  Two steps per word.  ASCII bytes are answered from the 128-bit mask; a byte that ENDS a longer code point (a
+    // continuation byte with no continuation byte behind it) is only marked.  Then the marked positions -- one or two per word in cfg3's text -- take the long way
+    // (decode, lower-case, the root's goto probe: half a dozen dependent loads).  Until round 6 the long way sat inside the byte loop: with 64 lanes per wavefront some lane
+    // took it at nearly every one of the 32 turns and all waited -- 2.6 ms per 256 MiB and pass, most of this path's time (LABNOTES R6.10).
     uint32_t mine = 0, mine_sp = 0;
     for (uint32_t w = t; w < n_words; w += kDenseThreads) {
         const uint64_t g0 = unit_start + 32ull * w;
         uint32_t hay = find_haystack(b, g0);
-        uint64_t hs = b.offsets[hay], he = b.offsets[hay + 1];
-        uint32_t bits = 0;
+        uint64_t he = b.offsets[hay + 1];
+        const uint32_t n_in = unit_end - g0 < 32u ? (uint32_t)(unit_end - g0) : 32u;
+        // the word's 32 bytes + the one behind them (the text is padded by 16 zero bytes and g0 is a multiple of 32)
+        // (a borrowed batch is readable up to round_up(total, 16): the second half of the last word may lie beyond that)
+        const uint64_t readable = (b.total + 15u) & ~15ull;
+        const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+        const u32x4 lo = load16(reinterpret_cast<const u32x4*>(b.text + g0)), hi = g0 + 32u <= readable ? load16(reinterpret_cast<const u32x4*>(b.text + g0 + 16)) : zero4;
+        const uint32_t behind = g0 + 32u < b.total ? b.text[g0 + 32u] : 0u;
+        const uint32_t wd[9] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w, behind};
+        uint32_t bits = 0, cand = 0;
+#pragma unroll
         for (uint32_t j = 0; j < 32; j++) {
             const uint64_t g = g0 + j;
-            if (g >= unit_end) break;
-            while (g >= he) { hay++; hs = he; he = b.offsets[hay + 1]; }
-            const uint32_t b0 = b.text[g];
-            bool f;
-            if (b0 < 0x80u) { const uint32_t c = IC ? fold_byte(b0) : b0; f = (first_ascii[c >> 5] >> (c & 31u)) & 1u; }
-            else f = ends_first_code_point(a, IC, b.text, hs, he, g);
-            bits |= (uint32_t)f << j;
+            const uint32_t b0 = (wd[j >> 2] >> (8u * (j & 3u))) & 0xFFu, b1 = (wd[(j + 1u) >> 2] >> (8u * ((j + 1u) & 3u))) & 0xFFu;
+            if (j < n_in) {
+                while (g >= he) { hay++; he = b.offsets[hay + 1]; }
+                if (b0 < 0x80u) { const uint32_t c = IC ? fold_byte(b0) : b0; bits |= ((first_ascii[c >> 5] >> (c & 31u)) & 1u) << j; }
+                else if ((b0 & 0xC0u) == 0x80u && !(g + 1 < he && (b1 & 0xC0u) == 0x80u)) cand |= 1u << j;
+            }
+        }
+        while (cand) {
+            const uint32_t j = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const uint64_t g = g0 + j;
+            const uint32_t h2 = find_haystack(b, g);
+            bits |= (uint32_t)ends_first_code_point(a, IC, b.text, b.offsets[h2], b.offsets[h2 + 1], g) << j;
         }
         const uint32_t un = bits | sp_bits[w];
         un_bits[w] = un;
@@ -94,30 +113,30 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(AcView a, BatchView b, 
         if (t == 0) unit_totals[u] = total;
         return;
     }
-    // thread t owns words t, t + 256, ...: an exclusive scan over (thread, word) order would not be position order, so the
-    // write pass walks the words in order: thread t takes the CONTIGUOUS block of words [t * per, (t + 1) * per)
+    // The write pass.  Where every record goes: word w's records start at un_pre[w] (sparse ones among them: sp_pre[w]) -- exclusive sums over the words in position
+    // order (thread t sums the contiguous words [t * per, (t + 1) * per), a scan over the threads, the words' own sums on top).  Then the workgroup walks the POSITIONS
+    // 256 at a time: neighbouring lanes hold neighbouring positions, so (nearly) neighbouring records -- until round 6 each thread wrote its own 8 words' records one after
+    // the other, 64 lanes of a store 3.7 KB apart: 16 bytes per L2 request, 0.56 TB/s of records, the one robustness row below 60 GiB/s.
     const uint32_t per = (n_words + kDenseThreads - 1) / kDenseThreads;
     const uint32_t w0 = t * per < n_words ? t * per : n_words, w1 = (t + 1) * per < n_words ? (t + 1) * per : n_words;
     uint32_t cu = 0, cs = 0;
     for (uint32_t w = w0; w < w1; w++) { cu += __popc(un_bits[w]); cs += __popc(sp_bits[w]); }
-    const uint32_t before_un = block_exclusive_scan(cu, scratch, nullptr);
-    const uint32_t before_sp = block_exclusive_scan(cs, scratch, nullptr);
-    uint64_t at = out_offsets[u] + before_un, at_sp = s0 + before_sp;
-    for (uint32_t w = w0; w < w1; w++) {
-        uint32_t un = un_bits[w];
+    uint32_t run_un = block_exclusive_scan(cu, scratch, nullptr);
+    uint32_t run_sp = block_exclusive_scan(cs, scratch, nullptr);
+    for (uint32_t w = w0; w < w1; w++) { un_pre[w] = run_un; sp_pre[w] = run_sp; run_un += __popc(un_bits[w]); run_sp += __popc(sp_bits[w]); }
+    __syncthreads();
+    const uint64_t base = out_offsets[u];
+    const uint32_t n_pos = (uint32_t)(unit_end - unit_start);
+    for (uint32_t p = t; p < n_pos; p += kDenseThreads) {
+        const uint32_t w = p >> 5, j = p & 31u, un = un_bits[w];
+        if (!((un >> j) & 1u)) continue;
+        const uint32_t below = (1u << j) - 1u;
+        const uint64_t at = base + un_pre[w] + __popc(un & below);
         const uint32_t sp = sp_bits[w];
-        if (!un) continue;
-        const uint64_t g0 = unit_start + 32ull * w;
-        uint32_t hay = find_haystack(b, g0);
-        uint64_t hs = b.offsets[hay], he = b.offsets[hay + 1];
-        while (un) {
-            const uint32_t j = (uint32_t)__builtin_ctz(un);
-            un &= un - 1u;
-            if ((sp >> j) & 1u) { out[at++] = sparse[at_sp++]; continue; }
-            const uint64_t g = g0 + j;
-            while (g >= he) { hay++; hs = he; he = b.offsets[hay + 1]; }
-            out[at++] = Record{g - hs + 1, hay, 0u};
-        }
+        if ((sp >> j) & 1u) { out[at] = sparse[s0 + sp_pre[w] + __popc(sp & below)]; continue; }
+        const uint64_t g = unit_start + p;
+        const uint32_t hay = find_haystack(b, g);
+        out[at] = Record{g - b.offsets[hay] + 1, hay, 0u};
     }
 }
 
