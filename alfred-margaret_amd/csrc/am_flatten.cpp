@@ -150,13 +150,22 @@ constexpr size_t kDfaSmallStates = 32768;     // automata up to this many states
 // AM_FLATTEN_TRACE=1: the phases of a flatten with their wall time on stderr (measurements; bench.py's build split)
 struct FlattenTrace {
     bool on; std::chrono::steady_clock::time_point t0, last;
+    std::chrono::steady_clock::time_point sub_last = std::chrono::steady_clock::now();
     FlattenTrace() : on(cfg::on(cfg::kFlattenTrace)), t0(std::chrono::steady_clock::now()), last(t0) {}
     void mark(const char* what)
     {
         if (!on) return;
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[flatten] %-28s %8.1f ms (at %8.1f)\n", what, std::chrono::duration<double, std::milli>(now - last).count(), std::chrono::duration<double, std::milli>(now - t0).count());
-        last = now;
+        last = now; sub_last = now;
+    }
+    // a step inside a phase (AM_FLATTEN_TRACE=2): its own time; the phase's mark() still reports the whole phase
+    void sub(const char* what)
+    {
+        if (!on || cfg::get(cfg::kFlattenTrace) < 2) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[flatten]     %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - sub_last).count());
+        sub_last = now;
     }
 };
 
@@ -323,11 +332,22 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         }
         std::vector<uint32_t> order(terminals.size());
         for (size_t k = 0; k < order.size(); k++) order[k] = (uint32_t)k;
+        // (lexicographic order of the code point strings; the first three code points of a string, 21 bits each, decide most comparisons as one integer -- a code point
+        // + 1 each, so that "no third code point" sorts before every code point, as a shorter string does)
+        std::vector<uint64_t> head(terminals.size());
+        for (size_t k = 0; k < head.size(); k++) {
+            const size_t len = (size_t)(str_off[k + 1] - str_off[k]);
+            uint64_t key = 0;
+            for (size_t j = 0; j < 3; j++) key = (key << 21) | (j < len ? (uint64_t)pool[str_off[k] + j] + 1u : 0u);
+            head[k] = key;
+        }
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            if (head[a] != head[b]) return head[a] < head[b];
             return std::lexicographical_compare(pool.begin() + str_off[a], pool.begin() + str_off[a + 1],
                                                 pool.begin() + str_off[b], pool.begin() + str_off[b + 1]);
         });
 
+        tr.sub("sf: reversed needles sorted");
         // code-point trie of the reversed needles, nodes created in preorder
         struct CpEdge { uint32_t src, cp, dst; };
         std::vector<CpEdge> cp_edges;
@@ -358,6 +378,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         { std::vector<uint32_t> cur(cp_first.begin(), cp_first.end() - 1);
           for (const CpEdge& e : cp_edges) cp_sorted[cur[e.src]++] = e; }
 
+        tr.sub("sf: code-point trie");
         // expand every code point edge into its (reversed, folded) UTF-8 variants
         struct ByteEdge { uint32_t src, byte, dst; };
         std::vector<ByteEdge> bedges; bedges.reserve(cp_edges.size() + cp_edges.size() / 4);
@@ -385,6 +406,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         }
         if (n_byte_nodes >= 0xFFFFFFF0u) { err = "automaton too large for 32-bit node ids"; return -1; }
 
+        tr.sub("sf: byte variants");
         // adjacency of the byte graph, children sorted by byte
         std::vector<uint32_t> b_first(n_byte_nodes + 1, 0);
         for (const ByteEdge& e : bedges) b_first[e.src + 1]++;
@@ -393,9 +415,11 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         { std::vector<uint32_t> cur(b_first.begin(), b_first.end() - 1);
           for (const ByteEdge& e : bedges) b_sorted[cur[e.src]++] = e; }
         for (size_t i = 0; i < n_byte_nodes; i++)
-            std::sort(b_sorted.begin() + b_first[i], b_sorted.begin() + b_first[i + 1],
-                      [](const ByteEdge& a, const ByteEdge& b) { return a.byte < b.byte; });
+            if (b_first[i + 1] - b_first[i] > 1)
+                std::sort(b_sorted.begin() + b_first[i], b_sorted.begin() + b_first[i + 1],
+                          [](const ByteEdge& a, const ByteEdge& b) { return a.byte < b.byte; });
 
+        tr.sub("sf: byte adjacency");
         // ---- path compression.  A node is absorbed into its incoming edge when it has exactly one
         // parent, exactly one child, no needle ends at it, and no path reaches it with <= 4 bytes
         // (every node within 4 bytes of the root stays explicit: the suffix tables point at them).
@@ -415,7 +439,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         auto mergeable = [&](uint32_t x) {
             return indeg[x] == 1 && b_first[x + 1] - b_first[x] == 1 && !is_terminal(x) && min_depth[x] != 0xFFFFFFFFu && min_depth[x] > 4;
         };
-        struct CEdge { uint32_t src, byte, dst; std::vector<uint8_t> skip; };    // skip bytes in walk order
+        struct CEdge { uint32_t src, byte, dst; uint8_t skip[kMaxSkip]; uint32_t n_skip; };    // skip bytes in walk order (in the edge itself: a vector each was a million allocations)
         std::vector<CEdge> cedges;
         std::vector<uint8_t> explicit_node(n_byte_nodes, 0);
         {
@@ -423,17 +447,18 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             while (!work.empty()) {
                 const uint32_t u = work.back(); work.pop_back();
                 for (uint32_t e = b_first[u]; e < b_first[u + 1]; e++) {
-                    CEdge ce{u, b_sorted[e].byte, b_sorted[e].dst, {}};
-                    while (mergeable(ce.dst) && ce.skip.size() < kMaxSkip) {
+                    CEdge ce{u, b_sorted[e].byte, b_sorted[e].dst, {0}, 0u};
+                    while (mergeable(ce.dst) && ce.n_skip < kMaxSkip) {
                         const ByteEdge& nx = b_sorted[b_first[ce.dst]];
-                        ce.skip.push_back((uint8_t)nx.byte);
+                        ce.skip[ce.n_skip++] = (uint8_t)nx.byte;
                         ce.dst = nx.dst;
                     }
                     if (!explicit_node[ce.dst]) { explicit_node[ce.dst] = 1; work.push_back(ce.dst); }
-                    cedges.push_back(std::move(ce));
+                    cedges.push_back(ce);
                 }
             }
         }
+        tr.sub("sf: path compression");
         // adjacency of the compressed graph (edges of one source stay in selector-byte order)
         std::vector<uint32_t> c_first(n_byte_nodes + 1, 0);
         for (const CEdge& e : cedges) c_first[e.src + 1]++;
@@ -442,8 +467,10 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
         { std::vector<uint32_t> cur(c_first.begin(), c_first.end() - 1);
           for (uint32_t i = 0; i < cedges.size(); i++) c_order[cur[cedges[i].src]++] = i; }
         for (size_t i = 0; i < n_byte_nodes; i++)
-            std::sort(c_order.begin() + c_first[i], c_order.begin() + c_first[i + 1], [&](uint32_t a, uint32_t b) { return cedges[a].byte < cedges[b].byte; });
+            if (c_first[i + 1] - c_first[i] > 1)
+                std::sort(c_order.begin() + c_first[i], c_order.begin() + c_first[i + 1], [&](uint32_t a, uint32_t b) { return cedges[a].byte < cedges[b].byte; });
 
+        tr.sub("sf: compressed adjacency");
         // renumber explicit nodes in DFS preorder (a needle's tail is a run of consecutive records)
         std::vector<uint32_t> new_id(n_byte_nodes, kNone), stack;
         uint32_t next_id = 0;
@@ -454,10 +481,11 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             new_id[x] = next_id++;
             for (uint32_t e = c_first[x + 1]; e-- > c_first[x];) { const uint32_t y = cedges[c_order[e]].dst; if (new_id[y] == kNone) stack.push_back(y); }
         }
-        auto pack_label = [](const std::vector<uint8_t>& skip, uint32_t (&label)[4]) {
+        auto pack_label = [](const CEdge& ce, uint32_t (&label)[4]) {
             // walk order = backwards in the haystack; store in text order, right-aligned in 16 bytes
             uint8_t bytes[kMaxSkip] = {0};
-            const size_t n = skip.size();
+            const uint8_t* skip = ce.skip;
+            const size_t n = ce.n_skip;
             for (size_t j = 0; j < n; j++) bytes[kMaxSkip - 1 - j] = skip[j];
             for (int i = 0; i < 4; i++) label[i] = (uint32_t)bytes[4 * i] | ((uint32_t)bytes[4 * i + 1] << 8) | ((uint32_t)bytes[4 * i + 2] << 16) | ((uint32_t)bytes[4 * i + 3] << 24);
         };
@@ -471,8 +499,8 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             if (n == 1) {
                 const CEdge& ce = cedges[c_order[c_first[x]]];
                 rec.z = new_id[ce.dst];
-                rec.w = 1u | (ce.byte << 16) | ((uint32_t)ce.skip.size() << 24);
-                pack_label(ce.skip, rec.label);
+                rec.w = 1u | (ce.byte << 16) | (ce.n_skip << 24);
+                pack_label(ce, rec.label);
             } else if (n > 1) {
                 rec.z = (uint32_t)edges_out.size();
                 rec.w = n;
@@ -491,17 +519,21 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                 }
                 for (uint32_t e = c_first[x]; e < c_first[x + 1]; e++) {
                     const CEdge& ce = cedges[c_order[e]];
-                    SfEdge ed{ce.byte, new_id[ce.dst], (uint32_t)ce.skip.size(), 0, {0, 0, 0, 0}, SfNode{0, 0, 0, 0, {0, 0, 0, 0}}};
-                    pack_label(ce.skip, ed.label);
+                    SfEdge ed{ce.byte, new_id[ce.dst], ce.n_skip, 0, {0, 0, 0, 0}, SfNode{0, 0, 0, 0, {0, 0, 0, 0}}};
+                    pack_label(ce, ed.label);
                     edges_out.push_back(ed);
                 }
             }
         }
+        tr.sub("sf: node and edge records");
         // Row displacement for the nodes with more than 4 children: node -> row offset r such that the lines r + b of all its selector bytes b are free
         // (first fit, largest nodes first); the edge of byte b is then ONE load away, edges[label[0] + b], and that line names its owner (SfEdge::pad).
         row_first = (uint32_t)edges_out.size();
         std::vector<uint32_t> row_of(many_nodes.size(), 0);
-        std::vector<uint8_t> occ;
+        // (which lines are taken: a bit each, and the number of lines the table has so far -- a line beyond it is free)
+        std::vector<uint64_t> occ_bits(64, 0);
+        size_t occ_n = 0;
+        auto occ_reserve = [&](size_t lines) { const size_t w = (lines >> 6) + 8; if (occ_bits.size() < w) occ_bits.resize(2 * w, 0); };
         {
             std::vector<uint32_t> order(many_nodes.size());
             for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
@@ -510,25 +542,42 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             for (uint32_t oi : order) {
                 const SfNode& nd = nodes[many_nodes[oi]];
                 const uint32_t n = nd.w & 0xFFFFu, b_min = edges_out[nd.z].byte, b_max = edges_out[nd.z + n - 1].byte;
-                while (first_free < occ.size() && occ[first_free]) first_free++;
+                while (first_free < occ_n && ((occ_bits[first_free >> 6] >> (first_free & 63u)) & 1u)) first_free++;
                 size_t r = first_free > b_min ? first_free - b_min : 0;
-                for (uint32_t tries = 0;; r++, tries++) {
-                    if (tries == 8192) { r = occ.size(); break; }                     // (a crowded table: open a fresh stretch instead of searching on)
-                    bool fits = true;
-                    for (uint32_t i = 0; i < n && fits; i++) { const size_t at = r + edges_out[nd.z + i].byte; fits = at >= occ.size() || !occ[at]; }
-                    if (fits) break;
+                // first fit within 8192 rows, 64 rows at a time: row base + k fits iff the line base + k + b is free for every selector byte b, i.e. bit k of the AND over b of
+                // ~(the bitset shifted to base + b).  The same row as testing one row after the other (what this replaces: 270 of the phase's 560 ms at 100k needles).
+                {
+                    const size_t r_first = r;
+                    bool found = false;
+                    for (size_t base = r_first; base < r_first + 8192 && !found; base += 64) {
+                        occ_reserve(base + 64 + 256 + 128);
+                        uint64_t fits = ~0ull;
+                        for (uint32_t i = 0; i < n && fits; i++) {
+                            const size_t x = base + (edges_out[nd.z + i].byte & 0xFFu);
+                            const uint32_t sh = (uint32_t)(x & 63u);
+                            const uint64_t taken = sh ? (occ_bits[x >> 6] >> sh) | (occ_bits[(x >> 6) + 1] << (64u - sh)) : occ_bits[x >> 6];      // (no bit is set beyond occ_n: free)
+                            fits &= ~taken;
+                        }
+                        const size_t left = r_first + 8192 - base;                   // rows of this block that are still among the 8192
+                        if (left < 64) fits &= (1ull << left) - 1ull;
+                        if (fits) { r = base + (size_t)__builtin_ctzll(fits); found = true; }
+                    }
+                    if (!found) r = occ_n;                                            // (a crowded table: open a fresh stretch instead of searching on)
                 }
-                if (occ.size() < r + b_max + 1) occ.resize(r + b_max + 1, 0);
-                for (uint32_t i = 0; i < n; i++) occ[r + edges_out[nd.z + i].byte] = 1;
+                if (occ_n < r + b_max + 1) occ_n = r + b_max + 1;
+                occ_reserve(occ_n + 320);
+                for (uint32_t i = 0; i < n; i++) { const size_t at = r + edges_out[nd.z + i].byte; occ_bits[at >> 6] |= 1ull << (at & 63u); }
                 row_of[oi] = (uint32_t)r;
             }
-            if (!many_nodes.empty()) occ.resize(occ.size() + 256, 0);             // label[0] + b stays inside the array for every byte b
-            if ((uint64_t)row_first + occ.size() >= 0xFFFFFFF0ull) { err = "too many edge lines"; return -1; }
+            if (!many_nodes.empty()) occ_n += 256;                                // label[0] + b stays inside the array for every byte b
+            if ((uint64_t)row_first + occ_n >= 0xFFFFFFF0ull) { err = "too many edge lines"; return -1; }
             for (uint32_t i = 0; i < many_nodes.size(); i++) nodes[many_nodes[i]].label[0] = row_first + row_of[i];
         }
+        tr.sub("sf: row displacement (first fit)");
         for (SfEdge& ed : edges_out) ed.to = nodes[ed.child];          // every edge's line carries its child's (now final) record
+        tr.sub("sf: children's records into the edges");
         if (!many_nodes.empty()) {
-            edges_out.resize((size_t)row_first + occ.size(), SfEdge{0, 0, 0, kNone, {0, 0, 0, 0}, SfNode{0, 0, 0, 0, {0, 0, 0, 0}}});
+            edges_out.resize((size_t)row_first + occ_n, SfEdge{0, 0, 0, kNone, {0, 0, 0, 0}, SfNode{0, 0, 0, 0, {0, 0, 0, 0}}});
             for (uint32_t i = 0; i < many_nodes.size(); i++) {
                 const SfNode& nd = nodes[many_nodes[i]];
                 for (uint32_t e = 0; e < (nd.w & 0xFFFFu); e++) {
@@ -539,6 +588,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             }
         }
 
+        tr.sub("sf: displaced rows written");
         // suffix tables: every byte path of length <= 4 from the root (never inside a compressed edge)
         struct Frame { uint32_t node, depth, key; };
         std::vector<Frame> fs; fs.push_back({0, 0, 0});
@@ -546,7 +596,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
             const Frame f = fs.back(); fs.pop_back();
             for (uint32_t e = c_first[f.node]; e < c_first[f.node + 1]; e++) {
                 const CEdge& ce = cedges[c_order[e]];
-                if (!ce.skip.empty()) { err = "compressed edge within 4 bytes of the root (internal error)"; return -1; }
+                if (ce.n_skip) { err = "compressed edge within 4 bytes of the root (internal error)"; return -1; }
                 const uint32_t d = f.depth + 1, child = ce.dst;
                 const uint32_t key = f.key | (ce.byte << (32u - 8u * d));
                 if (d == 4) { tier_entries[3].push_back({key, new_id[child]}); continue; }
