@@ -304,6 +304,11 @@ def timed_build(needles, case):
     Automaton.build + am_automaton_create (which validates by flattening the CaseSensitive image; the IgnoreCase image is flattened on a thread of its own meanwhile);
     first_use_s = until the image of the workload's case mode lies in HBM (the rest of its flatten, the upload)."""
     import alfred_margaret_amd as am
+    if not timed_build.warm:                      # the HIP runtime's start (context, first allocation, the library's streams: 0.1-0.15 s) is the process's, not the build's
+        tiny = am.Automaton(["warm-up"]); n0 = C.c_size_t(0)
+        am.api.check(am.api.libam().am_automaton_image_size(C.c_void_p(tiny.device), case, C.byref(n0)))
+        del tiny
+        timed_build.warm = True
     t0 = time.perf_counter()
     machine = am.Automaton(needles)
     t1 = time.perf_counter()
@@ -312,7 +317,10 @@ def timed_build(needles, case):
     t2 = time.perf_counter()
     return machine, {"automaton_s": round(t1 - t0, 3), "first_use_s": round(t2 - t1, 3), "total_s": round(t2 - t0, 3), "image_bytes": int(nbytes.value),
                      "what": "automaton_s: host build (mirror of Automaton.build) + am_automaton_create (validation = CaseSensitive flatten, IgnoreCase flatten on its own thread); "
-                             "first_use_s: the case mode's image in HBM (rest of its flatten + upload)"}
+                             "first_use_s: the case mode's image in HBM (rest of its flatten + upload); after a one-needle warm-up automaton (the HIP runtime's start is the process's)"}
+
+
+timed_build.warm = False
 
 
 def build_plus_run(n_bytes, build, ms_per_step):
