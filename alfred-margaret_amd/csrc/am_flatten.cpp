@@ -239,6 +239,9 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
     }
 
     Blob blob;
+    // (address space for the whole image up front -- about 190 bytes per state at 100k needles, 225 for a dictionary with its DFA section: the sections are appended one
+    // after the other, and a vector that grows by doubling copies what it holds, and faults its pages in, again and again)
+    blob.bytes.reserve(std::min<size_t>((size_t)1 << 31, S * 256 + ref.n_transitions * 8 + ((size_t)16 << 20)));
     blob.reserve_section(sizeof(ImageHeader));
 
     // ---- AC section: the reference's arrays verbatim
