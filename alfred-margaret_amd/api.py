@@ -243,7 +243,7 @@ def pack_texts(texts):
     bs = [_as_bytes(t) for t in texts]
     offs = np.zeros(len(bs) + 1, dtype=np.uint64)
     if bs:
-        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        offs[1:] = np.cumsum(np.fromiter(map(len, bs), dtype=np.uint64, count=len(bs)))
     return b"".join(bs), offs
 
 
@@ -296,8 +296,8 @@ class Automaton:
 
     def __init__(self, needles, values=None, lower_pairs=None):
         """lower_pairs: the caller's lower-casing as [(c, toLower c)] (am_automaton_create_ex); None = the built-in Unicode 14.0 table."""
-        blob, offs = pack_texts(needles)
-        self.needles = [_as_bytes(n) for n in needles]
+        self.needles = [_as_bytes(n) for n in needles]            # (encoded once: 100k needles are 20 ms of the build per pass over them)
+        blob, offs = pack_texts(self.needles)
         vptr = None
         if values is not None:
             self._vals = np.ascontiguousarray(values, dtype=np.uint32)
