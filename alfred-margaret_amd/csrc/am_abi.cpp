@@ -1614,7 +1614,8 @@ static int run_segmented(const am_automaton* a, int case_mode, const am_slice* h
     rc = get_stream(dev, &st);
     for (size_t i = 0; i < n_hay && rc == AM_OK;) {
         size_t j = i; uint64_t bytes = 0;
-        while (j < n_hay && (rest_at_once || bytes < segment)) bytes += hay[j++].len;
+        // (the first segment a quarter of the others: its upload and scan are the only ones no download runs beside)
+        while (j < n_hay && (rest_at_once || bytes < (i == 0 ? segment / 4 : segment))) bytes += hay[j++].len;
         const double t_up = now_ms();
         rc = upload_slices(hay + i, j - i, b, true);
         const double t_scan = now_ms();
