@@ -1045,7 +1045,7 @@ int am::host::run_records(const am_automaton* a, int case_mode, am_batch* b, con
             *n_scan = total;
             if (total == 0) return AM_OK;
             AM_TRY(sink(total, &d_records));
-            { Prof pr("dfa_place", st); HIP_TRY(launch_dfa_place(p.dfa, p.bv, o, ctrl[0] < o.n_blocks ? ctrl[0] : o.n_blocks, (const uint64_t*)b->unit_offsets.p, p.n_cu, n_waves, d_records, st)); }
+            { Prof pr("dfa_place", st); HIP_TRY(launch_dfa_place(p.dfa, p.bv, o, ctrl[0] < o.n_blocks ? ctrl[0] : o.n_blocks, (const uint64_t*)b->unit_offsets.p, p.n_cu, n_waves, p.f->h.n_states, d_records, st)); }
             HIP_TRY(hipStreamSynchronize(st));
             return AM_OK;
         }

@@ -81,7 +81,7 @@ uint32_t dfa_token_waves(const DfaView& d, const BatchView& b, int n_cu);
 uint64_t dfa_token_superblocks(uint64_t records, uint32_t n_waves, uint64_t n_units);
 uint64_t dfa_superblock_bytes();
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st);
-hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, uint32_t n_waves, Record* out, hipStream_t st);
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, uint32_t n_waves, uint32_t n_ref_states, Record* out, hipStream_t st);
 hipError_t read_sf_phase_cycles(uint64_t* out5);
 hipError_t read_sf_wave_records(uint64_t* out, size_t n_waves);
 hipError_t scan_temp_bytes(uint64_t n, size_t* bytes);

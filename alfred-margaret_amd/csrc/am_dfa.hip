@@ -399,16 +399,16 @@ hipError_t launch_dfa_sample(const DfaView& d, const uint8_t* text, uint64_t tot
 // a random 8-byte read per record -- most of this kernel's L2 requests (2.6 of 2.8 x 10^8 per 2 GiB of natural text) -- which a direct-mapped table in LDS answers for the
 // states it has seen (text repeats its words: the workgroup keeps the table from superblock to superblock).
 constexpr uint32_t kPlaceBuckets = kTokMaxOrd * kWave;
-constexpr uint32_t kPlaceCacheLog2 = 12;
+constexpr uint32_t kPlaceCacheLog2 = 12;         // 4 096 entries of 8 bytes -- or 8 192 of 4 where a state's tag and its reference state share a word (ref_bits != 0)
 __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ pool, const uint32_t* __restrict__ fill, const uint32_t* __restrict__ first_group, uint32_t n_super,
                                                     const uint64_t* __restrict__ unit_offsets, BatchView b, const u32x2* __restrict__ dfa_out, uint32_t n_states, uint32_t chunk, uint32_t n_waves,
-                                                    Record* __restrict__ out)
+                                                    uint32_t ref_bits, Record* __restrict__ out)
 {
     __shared__ u32x2_v s_tok[kDfaSuper];
     __shared__ uint32_t s_cnt[kPlaceBuckets], s_min[kPlaceBuckets], s_base[kPlaceBuckets];
     __shared__ u32x2_v s_seen[1u << kPlaceCacheLog2];              // {DFA state, its reference state + 1}: one 8-byte word, written and read whole
     static_assert(kPlaceBuckets == 1024, "one bucket per thread of the workgroup");
-    for (uint32_t i = threadIdx.x; i < (1u << kPlaceCacheLog2); i += 1024u) { u32x2_v e; e.x = kNone; e.y = 0u; s_seen[i] = e; }
+    for (uint32_t i = threadIdx.x; i < (1u << kPlaceCacheLog2); i += 1024u) { u32x2_v e; e.x = ref_bits ? 0u : kNone; e.y = 0u; s_seen[i] = e; }      // (4-byte entries: 0 = empty, a reference state + 1 is never 0)
     for (uint32_t sb = blockIdx.x; sb < n_super; sb += gridDim.x) {
     const uint32_t n = fill[sb];
     if (n == 0) continue;                                        // (uniform: the whole workgroup goes on)
@@ -455,10 +455,21 @@ __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ 
         const uint32_t h = find_haystack(b, g);
         AM_BOUNDS(g < b.total && h < b.n_hay && b.offsets[h] <= g && g < b.offsets[h + 1] && (q.x & kDfaStateMask) < n_states && dfa_out[q.x & kDfaStateMask].x != 0u &&
                   unit_offsets[u] + ((q.y >> kTokPosBits) & (kTokMaxChunk - 1u)) < unit_offsets[u + 1]);
-        const uint32_t st = q.x & kDfaStateMask, slot = (st * 0x9E3779B1u) >> (32u - kPlaceCacheLog2);
-        const u32x2_v seen = s_seen[slot];
-        uint32_t ref1 = seen.y;
-        if (seen.x != st) { ref1 = dfa_out[st].x; u32x2_v e; e.x = st; e.y = ref1; s_seen[slot] = e; }      // (lanes that race for a slot each write a whole, valid pair)
+        const uint32_t st = q.x & kDfaStateMask;
+        uint32_t ref1;
+        if (ref_bits) {
+            // 4-byte entries, twice as many, found by the state's low bits: the states are numbered by weight, so the hottest of a kind do not collide with each other
+            // (a simulation over the text's own counts: 47 % of the look-ups answered where the hashed 4 096 answer 34 %)
+            uint32_t* seen4 = reinterpret_cast<uint32_t*>(s_seen);
+            const uint32_t slot = st & ((2u << kPlaceCacheLog2) - 1u), tag = st >> (kPlaceCacheLog2 + 1u), e = seen4[slot];
+            ref1 = e & ((1u << ref_bits) - 1u);
+            if (e == 0u || (e >> ref_bits) != tag) { ref1 = dfa_out[st].x; seen4[slot] = (tag << ref_bits) | ref1; }
+        } else {
+            const uint32_t slot = (st * 0x9E3779B1u) >> (32u - kPlaceCacheLog2);
+            const u32x2_v seen = s_seen[slot];
+            ref1 = seen.y;
+            if (seen.x != st) { ref1 = dfa_out[st].x; u32x2_v e; e.x = st; e.y = ref1; s_seen[slot] = e; }      // (lanes that race for a slot each write a whole, valid pair)
+        }
         u32x4_n r;
         const uint64_t end_pos = g + 1u - b.offsets[h];
         r.x = (uint32_t)end_pos; r.y = (uint32_t)(end_pos >> 32); r.z = h; r.w = ref1 - 1u;
@@ -472,7 +483,7 @@ uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.t
 // rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
 static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (kLdsLog2Cols + 2u)); }
 // AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = the walk (1: 16 bytes of text per request, lanes in step; 2: 64 bytes, lanes in step; 3: 64 bytes, lanes out of step; 0: the default),
-// bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits), bit 24 = no records in LDS
+// bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits), bit 24 = no records in LDS, bit 25 = k_dfa_place's table of seen states with 8-byte entries
 static uint32_t dfa_tune() { const long v = cfg::get(cfg::kDfaTune); return v > 0 ? (uint32_t)v : 0u; }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 {
@@ -553,11 +564,16 @@ uint64_t dfa_superblock_bytes() { return (uint64_t)kDfaSuper * sizeof(u32x2_v); 
 hipError_t launch_dfa_tokens(const DfaView& d, const BatchView& b, const ScanOut& o, int n_cu, hipStream_t st) { return launch_dfa_t<kModeTokens>(d, b, o, n_cu, st); }
 // o.block_next = [n_blocks fill counts | n_blocks first groups]
 // n_waves = dfa_token_waves() as it was when the walk was launched: a token names its group by an ordinal counted in steps of it
-hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, uint32_t n_waves, Record* out, hipStream_t st)
+hipError_t launch_dfa_place(const DfaView& d, const BatchView& b, const ScanOut& o, uint32_t n_super, const uint64_t* unit_offsets, int n_cu, uint32_t n_waves, uint32_t n_ref_states, Record* out, hipStream_t st)
 {
     if (n_super == 0) return hipSuccess;
     if (n_waves != dfa_token_waves(d, b, n_cu)) return hipErrorInvalidValue;       // (the launch parameters changed between the walk and the placement)
-    hipLaunchKernelGGL(k_dfa_place, dim3(std::min<uint32_t>(n_super, (uint32_t)n_cu * 2u)), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.n_states, d.chunk, n_waves, out);
+    // a table entry of 4 bytes = the state's bits above the slot index | its reference state + 1, where both fit (645k states, 640k reference states: 7 + 20 bits)
+    uint32_t rb = 1; while ((1ull << rb) <= (uint64_t)n_ref_states + 1u) rb++;
+    uint32_t sb = 1; while ((1ull << sb) < (uint64_t)d.n_states) sb++;
+    const uint32_t tag_bits = sb > kPlaceCacheLog2 + 1u ? sb - (kPlaceCacheLog2 + 1u) : 0u;
+    const uint32_t ref_bits = (rb < 32u && rb + tag_bits <= 32u && !((dfa_tune() >> 25) & 1u)) ? rb : 0u;
+    hipLaunchKernelGGL(k_dfa_place, dim3(std::min<uint32_t>(n_super, (uint32_t)n_cu * 2u)), dim3(1024), 0, st, reinterpret_cast<const u32x2_v*>(o.pool), o.block_next, o.block_next + o.n_blocks, n_super, unit_offsets, b, d.out, d.n_states, d.chunk, n_waves, ref_bits, out);
     return hipGetLastError();
 }
 
