@@ -275,7 +275,7 @@ def main():
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_h2d:
-            out["h2d_inclusive"] = h2d_inclusive(args, w, handle, case, text, n_hay, lib)
+            out["h2d_inclusive"] = h2d_inclusive(args, w, handle, case, text, n_hay, lib, settle=VRAM_WIPE_SETTLE_S if w.get("natural") else 0.0)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, w, needles, case, hay_cells, handle, batch, lib)
         if args.workloads is None:
@@ -434,7 +434,9 @@ def measure_scan_workload(args, name, dev, lib, machine=None, needles=None, n_ha
         contains_all = contains_all_row(args, w, needles, machine, handle, case, batch, text, n_hay, n_bytes, lib) if name == "cfg2_runText_10k_1GiB" and not args.no_parity else None
         # natural text from HOST slices: the result is 2.5 x its text, so the call is bound by the records' way back -- am_run goes up in segments and brings a segment's
         # records down while the next one is uploaded and scanned (csrc/am_abi.cpp run_segmented)
-        host_slices = h2d_inclusive(args, w, handle, case, text, n_hay, lib) if w.get("natural") and not args.no_h2d else None
+        host_slices = None
+        if w.get("natural") and not args.no_h2d:
+            host_slices = h2d_inclusive(args, w, handle, case, text, n_hay, lib, settle=VRAM_WIPE_SETTLE_S)
     finally:
         lib.am_batch_destroy(batch)
     avg_ms = ms.value / max(int(launches.value), 1)
@@ -874,7 +876,7 @@ def replacer_parity(args, w, pairs, case, rdev, batch, text, n_hay, n_bytes, res
                              "sample": "the first haystack (%d KiB) through the oracle's Replacer.run on one core; %d haystacks on %d cores identical to the device's" % (hb >> 10, k, threads)}}
 
 
-def h2d_inclusive(args, w, handle, case, text, n_hay, lib):
+def h2d_inclusive(args, w, handle, case, text, n_hay, lib, settle=0.0):
     """What a Haskell `runText` caller gets through the shim of INTEGRATION.md (SURVEY 7.4 H4 / 8d "reported separately"): the one-shot
     entry points am_count / am_run on HOST slices -- gather into pinned staging, DMA over PCIe, scan, results back -- timed on the first
     --h2d-mib MiB of the benchmark batch, copied to pinned host memory first.  Never `value`."""
@@ -901,6 +903,11 @@ def h2d_inclusive(args, w, handle, case, text, n_hay, lib):
     m = C.c_void_p()
     am.api.check(lib.am_run(handle, case, slices, k, C.byref(m)))
     lib.am_matches_data(m); lib.am_matches_free(m)
+    if settle:
+        # the warm-up call's first freed record array pushes the previous steps' whole-batch array (tens of GB) out of the library's cache of freed arrays: a hipFree, and
+        # amdgpu wipes the VRAM through the SDMA engines -- D2H copies run at 27 instead of 42-50 GB/s until it is done (LABNOTES R5.6, R6.9)
+        time.sleep(settle)
+        out["settled_s"] = settle
     t_run = float("inf")
     for _ in range(2):
         t0 = time.perf_counter()
