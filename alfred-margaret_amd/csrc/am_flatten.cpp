@@ -745,6 +745,7 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                             if (mine[c] != theirs[c]) { if (q.n < 2) { q.cls[q.n] = c; q.to[q.n] = mine[c]; } q.n++; }
                         if (q.n > 2) is_row[i] = 1; else rec[i] = q;
                     }
+                    dtr.mark("dfa: row and record states");
                     // numbers: the root, then the row states by weight (k_dfa keeps the first rows in LDS; breadth-first order among equals); then the chain states, path by path
                     // How often will text visit a state?  The dictionary is the one sample of its language the flattener has: the needles, one after the other with a
                     // blank between them, are walked through the automaton and the visits counted (weight[state] = steps that START there; col_use[class] = bytes).
@@ -754,23 +755,61 @@ int flatten(const RefArrays& ref, int case_mode, std::vector<uint8_t>& image, st
                     std::vector<uint32_t> weight(n_reached, 0);
                     std::vector<uint64_t> col_use(C, 0);
                     {
-                        std::vector<uint8_t> spell;
-                        uint32_t st = 0;
-                        auto walk = [&](uint32_t byte) {
-                            const uint32_t cb = cls[byte];
-                            weight[st]++;
-                            if (cb != kDfaRare) col_use[cb]++;
-                            st = cb == kDfaRare ? delta_rare(st, byte) : next[((size_t)st << lc) + cb];
+                        // The walk is one chain of dependent look-ups in a table of 250 bytes per state (95 ms of a dictionary's 270-ms DFA section), so it is cut into
+                        // stretches of needles that threads walk side by side.  The state an automaton is in depends on the last `deepest` bytes it has read and on nothing
+                        // before them, so a stretch first walks -- without counting -- the needles in front of it that make up that many bytes, and is then in the state the
+                        // one walk would be in: the counts add up to the same numbers, whatever the number of threads.
+                        std::vector<uint32_t> items;
+                        for (uint32_t i = 1; i < n_reached; i++)
+                            if (out[i].x && out[i].y > out[fb[i]].y) items.push_back(i);          // a needle of its own ends here (values = own ++ the fallback's, Automaton.hs:367-380)
+                        uint32_t deepest = 1;
+                        for (uint32_t x = 0; x < (uint32_t)S; x++) deepest = std::max(deepest, bdepth[x]);
+                        auto walk_stretch = [&](size_t a, size_t z, uint32_t* w, uint64_t* cu) {
+                            std::vector<uint8_t> spell;
+                            size_t from = a, have = 0;
+                            while (from > 0 && have < deepest) {
+                                from--;
+                                for (uint32_t y = items[from]; y != 0; y = tree_parent[y]) have++;
+                                have++;                                                       // (the blank behind it)
+                            }
+                            uint32_t st = 0;
+                            for (size_t k = from; k < z; k++) {
+                                const bool counted = k >= a;
+                                spell.clear();
+                                spell.push_back(0x20u);
+                                for (uint32_t y = items[k]; y != 0; y = tree_parent[y]) spell.push_back(tree_byte[y]);
+                                for (size_t j = spell.size(); j-- > 0;) {
+                                    const uint32_t byte = spell[j], cb = cls[byte];
+                                    if (counted) { w[st]++; if (cb != kDfaRare) cu[cb]++; }
+                                    st = cb == kDfaRare ? delta_rare(st, byte) : next[((size_t)st << lc) + cb];
+                                }
+                            }
                         };
-                        for (uint32_t i = 1; i < n_reached; i++) {
-                            if (!out[i].x || out[i].y <= out[fb[i]].y) continue;          // no needle of its own ends here (values = own ++ the fallback's, Automaton.hs:367-380)
-                            spell.clear();
-                            for (uint32_t y = i; y != 0; y = tree_parent[y]) spell.push_back(tree_byte[y]);
-                            for (size_t k = spell.size(); k-- > 0;) walk(spell[k]);
-                            walk(0x20u);
+                        const unsigned hw = std::thread::hardware_concurrency();
+                        const size_t n_thr = (cfg::on(cfg::kFlattenSerial) || items.size() < 8192) ? 1 : std::max<size_t>(1, std::min<size_t>(8, hw / 2));
+                        if (n_thr == 1) walk_stretch(0, items.size(), weight.data(), col_use.data());
+                        else {
+                            std::vector<std::vector<uint32_t>> ws(n_thr - 1, std::vector<uint32_t>(n_reached, 0));
+                            std::vector<std::vector<uint64_t>> cs(n_thr - 1, std::vector<uint64_t>(C, 0));
+                            std::vector<std::thread> pool;
+                            const size_t per = (items.size() + n_thr - 1) / n_thr;
+                            bool threads_ok = true;
+                            for (size_t t = 1; t < n_thr && threads_ok; t++) {
+                                const size_t a = std::min(items.size(), t * per), z = std::min(items.size(), a + per);
+                                try { pool.emplace_back(walk_stretch, a, z, ws[t - 1].data(), cs[t - 1].data()); } catch (const std::system_error&) { threads_ok = false; }
+                            }
+                            // (a thread that could not be started: its stretch and the ones behind it are walked here)
+                            const size_t started = pool.size() + 1;
+                            walk_stretch(0, std::min(items.size(), per), weight.data(), col_use.data());
+                            if (!threads_ok) walk_stretch(std::min(items.size(), started * per), items.size(), weight.data(), col_use.data());
+                            for (auto& th : pool) th.join();
+                            for (size_t t = 0; t + 1 < started; t++) {
+                                for (uint32_t i = 0; i < n_reached; i++) weight[i] += ws[t][i];
+                                for (uint32_t c = 0; c < C; c++) col_use[c] += cs[t][c];
+                            }
                         }
                     }
-                    dtr.mark("dfa: row states + weights");
+                    dtr.mark("dfa: weights (the needles walked)");
                     std::vector<uint32_t> rows;
                     for (uint32_t i = 1; i < n_reached; i++) if (is_row[i]) rows.push_back(i);
                     auto heavier = [&](uint32_t a, uint32_t b2) { return weight[a] != weight[b2] ? weight[a] > weight[b2] : a < b2; };
