@@ -249,7 +249,8 @@ def test_heavy_suffix_nodes_get_five_byte_child_entries():
 
 
 def test_the_flatteners_tasks_change_no_byte(chk):
-    """Round 6: the goto hash and the DFA section are made on threads of their own next to the suffix structure (am_flatten.cpp).  The image must not know:
+    """Round 6: the goto hash and the DFA section are made on threads of their own next to the suffix structure, and the walk that weighs a dictionary's DFA states runs in
+    stretches on several threads (am_flatten.cpp; the 20 000-word dictionary below is large enough for that).  The image must not know:
     byte for byte the one a flatten without tasks (AM_FLATTEN_SERIAL) makes -- for fragment automata that are forced to carry a DFA section, and for a dictionary large
     enough to get one by itself."""
     import numpy as np
