@@ -114,6 +114,7 @@ ABI = {
     "am_get_stream": (C.c_int, [C.POINTER(_vp)]),
     "am_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(_sz), C.c_char_p, _sz]),
     "am_release_host_memory": (C.c_int, []),
+    "am_release_device_memory": (C.c_int, []),
     "am_profile_enable": (C.c_int, [C.c_int]),
     "am_profile_reset": (C.c_int, []),
     "am_profile_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_double), _u64p]),

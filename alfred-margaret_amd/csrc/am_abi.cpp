@@ -180,6 +180,12 @@ struct RecordCache {
         kept.erase(kept.begin() + (std::ptrdiff_t)best);
         return r;
     }
+    void trim()
+    {
+        std::vector<Block> out;
+        { std::lock_guard<std::mutex> lk(mu); out.swap(kept); }
+        for (const Block& b : out) (void)hipFree(b.p);
+    }
     void give(void* q, size_t c)
     {
         std::vector<Block> out;
@@ -1657,6 +1663,21 @@ static int run_segmented(const am_automaton* a, int case_mode, const am_slice* h
     if (n_total) { res->big = block; res->big_cap = block_cap; res->big_pinned = false; }
     else if (block) g_host_cache.give(block, block_cap);
     *out = res;
+    return AM_OK;
+}
+
+extern "C" int am_release_device_memory(void)
+{
+    if (ensure_runtime() != AM_OK) return AM_OK;                 // (no device: nothing is held)
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+    for (int d = 0; d < n_dev && d < kMaxDev; d++) {
+        OnDevice od(d);
+        if (od.rc != AM_OK) continue;
+        g_record_cache[d].trim();
+        am_batch*& b = tl_state.oneshot[d];
+        if (b) { am_batch_destroy(b); b = nullptr; }
+    }
     return AM_OK;
 }
 

@@ -353,6 +353,11 @@ AM_API int am_device_info(int* n_cu, size_t* hbm_bytes, char* name, size_t name_
  * large result, and so is one pageable block of a result beyond that (up to 8 GiB: its pages are there, the next result of that size is
  * copied into it at the speed of the wire).  This gives both back to the system now (page-locked memory is a shared, limited resource). */
 AM_API int am_release_host_memory(void);
+/* Device memory the library keeps between calls: up to four device arrays of freed results per device (16 GiB in all) and, per calling thread and device, the
+ * one-shot batch of am_run / am_count / am_contains_any (text + workspaces, up to a sixteenth of the device's memory) -- freeing VRAM is not free (the driver wipes it
+ * on the engines the host copies use), so arrays that will be wanted again are kept.  This frees the kept result arrays of every device and the CALLING thread's
+ * one-shot batches now. */
+AM_API int am_release_device_memory(void);
 /* Per-kernel timing with HIP events on the launch stream (off by default). */
 AM_API int am_profile_enable(int on);
 AM_API int am_profile_reset(void);

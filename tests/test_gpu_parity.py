@@ -963,3 +963,19 @@ def test_am_run_in_segments_equals_the_call_in_one_piece(segment_kib):
             assert all(int(x) & 0xFFFFFFFF == h for x in got[1::2])
     finally:
         lib.am_matches_free(m0); lib.am_matches_free(m1)
+
+
+def test_release_device_memory_between_calls():
+    """am_release_device_memory frees what the library keeps in HBM between calls (the arrays of freed results, the calling thread's one-shot batch); the next call
+    allocates afresh and reports the same records."""
+    needles = ["tshirt", "shirts", "shorts", "übergrößen"]
+    hays = ["short tshirts and shorts " * 4000, "", "Übergrößen übergrößen"]
+    a = am.Automaton(needles)
+    o = oracle.Machine(needles)
+    lib = am.api.libam()
+    exp = oracle_triples(o, 1, hays)
+    for _ in range(3):
+        recs = a.run_records(1, hays)
+        assert expand_records(o.values_off(), o.values(), recs["haystack"], recs["state"], recs["end_pos"]) == exp
+        am.api.check(lib.am_release_device_memory())
+        am.api.check(lib.am_release_host_memory())
