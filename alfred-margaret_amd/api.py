@@ -169,6 +169,7 @@ DEBUG_ABI = {
     "am_debug_bounds_report": (C.c_int, [_u64p, _u32p, _u32p]),
     "am_debug_sf_phase_cycles": (C.c_int, [_vp]),
     "am_debug_sf_wave_records": (C.c_int, [_vp, _sz]),
+    "am_debug_resident_waves": (C.c_int, [_vp, _vp]),
     "am_debug_set_general_kernel": (C.c_int, [_vp, C.c_uint32]),
     "am_debug_rp_lds_haystacks": (C.c_uint32, []),
 }
@@ -680,6 +681,14 @@ def debug_set(name, value):
 def debug_reset():
     for name in DEBUG_SWITCHES:
         debug_set(name, -1)
+
+
+def resident_waves():
+    """am_debug_resident_waves: (wavefronts a CU of the current device really runs at once -- 32 by the architecture, 16 on boxes where a second set of 16 waits for the
+    first --, ms of the 16-per-CU launch, ms of the 32-per-CU launch)."""
+    one, two = C.c_float(0), C.c_float(0)
+    check(libam().am_debug_resident_waves(C.byref(one), C.byref(two)))
+    return (32 if two.value < 1.5 * one.value else 16), round(one.value, 3), round(two.value, 3)
 
 
 def bounds_report():

@@ -1894,6 +1894,37 @@ extern "C" int am_debug_bounds_report(uint64_t* failed_out, uint32_t* first_line
 
 extern "C" uint64_t am_debug_pinned_bytes(void) { return (uint64_t)g_pinned_staging_bytes.load(std::memory_order_relaxed); }
 
+extern "C" int am_debug_resident_waves(float* one_ms_out, float* two_ms_out)
+{
+    if (!one_ms_out || !two_ms_out) return fail(AM_ERR_INVALID, "null argument");
+    AM_TRY(ensure_runtime());
+    int dev = 0; AM_TRY(current_device(&dev));
+    hipDeviceProp_t prop; HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const uint32_t n_cu = (uint32_t)prop.multiProcessorCount;
+    hipStream_t st; AM_TRY(get_stream(dev, &st));
+    uint32_t* d = nullptr; HIP_TRY(hipMalloc((void**)&d, 64));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipEventCreate(&a); if (e == hipSuccess) e = hipEventCreate(&b);
+    float ms[2] = {0, 0};
+    const uint64_t cycles = 1000000;                             // ~0.4 ms
+    for (int k = 0; k < 2 && e == hipSuccess; k++) {
+        // 16 wavefronts per CU: one workgroup of 1024 threads each; 32: eight workgroups of 256 threads each
+        const uint32_t wgs = k == 0 ? n_cu : 8u * n_cu, threads = k == 0 ? 1024u : 256u;
+        e = launch_spin(wgs, threads, 1000, d, st);              // (warm-up)
+        if (e == hipSuccess) e = hipEventRecord(a, st);
+        if (e == hipSuccess) e = launch_spin(wgs, threads, cycles, d, st);
+        if (e == hipSuccess) e = hipEventRecord(b, st);
+        if (e == hipSuccess) e = hipEventSynchronize(b);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms[k], a, b);
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(AM_ERR_HIP, std::string("am_debug_resident_waves: ") + hipGetErrorString(e));
+    *one_ms_out = ms[0]; *two_ms_out = ms[1];
+    return AM_OK;
+}
+
 extern "C" int am_debug_sf_wave_records(uint64_t* out, size_t n_waves)
 {
     HIP_TRY(hipDeviceSynchronize());

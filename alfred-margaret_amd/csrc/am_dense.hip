@@ -216,6 +216,20 @@ hipError_t launch_hay_rebase(Record* recs, uint64_t n, uint32_t add, hipStream_t
     hipLaunchKernelGGL(k_hay_rebase, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, recs, n, add);
     return hipGetLastError();
 }
+// am_debug_resident_waves: every wavefront spins for `cycles` of the shader clock
+__global__ void __launch_bounds__(1024) k_spin(uint64_t cycles, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s[1024];
+    s[threadIdx.x] = threadIdx.x;
+    const uint64_t t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < cycles) { }
+    if (s[(threadIdx.x + 1u) % blockDim.x] == 0xFFFFFFFFu) out[0] = 1u;
+}
+hipError_t launch_spin(uint32_t workgroups, uint32_t threads, uint64_t cycles, uint32_t* out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_spin, dim3(workgroups), dim3(threads), 0, st, cycles, out);
+    return hipGetLastError();
+}
 hipError_t launch_range_bounds(const Record* recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* out2, hipStream_t st)
 {
     hipLaunchKernelGGL(k_range_bounds, dim3(1), dim3(64), 0, st, recs, n, x0, x1, out2);

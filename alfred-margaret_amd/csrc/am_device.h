@@ -96,6 +96,7 @@ hipError_t launch_records_reduce(const Record* recs, uint64_t n, const uint32_t*
 hipError_t launch_range_bounds(const Record* recs, uint64_t n, uint64_t x0, uint64_t x1, uint64_t* out2, hipStream_t st);
 hipError_t launch_range_rebase(Record* recs, uint64_t n, uint64_t add, hipStream_t st);
 hipError_t launch_hay_rebase(Record* recs, uint64_t n, uint32_t add, hipStream_t st);
+hipError_t launch_spin(uint32_t workgroups, uint32_t threads, uint64_t cycles, uint32_t* out, hipStream_t st);      // am_debug_resident_waves
 
 // ---- Replacer pass (am_replace.hip) ----------------------------------------------------------
 // same layout as am_payload in include/am.h (Replacer.hs:59-70 Payload, replacement text as a slice of one blob)

@@ -862,12 +862,18 @@ __device__ __forceinline__ void pt_gather(const RpPiece* __restrict__ P, uint32_
     }
 }
 
-// finished haystacks: their text, once (one workgroup per haystack; 16-byte copies where source and destination allow)
+// finished haystacks: their text, once.  One workgroup per haystack, a wavefront per piece -- and a piece is a few hundred bytes reached through its list entry, so a
+// wavefront that takes piece after piece waits out two dependent trips (entry, bytes) 65 times: 0.98 ms per GiB where a plain copy takes 0.40 (tools/microbench/
+// copy_rate.hip).  So the list is read ONCE into LDS by the whole workgroup, and a wavefront has FOUR pieces in flight: their first KiB each is asked for before any of it
+// is stored (16-byte copies, the last bytes one by one; what a piece has beyond a KiB follows in a loop of its own).
+constexpr uint32_t kMatPieces = 1024;                 // list entries a workgroup keeps in LDS (a longer list is read from memory entry by entry)
+constexpr uint32_t kMatFlight = 4;
 __global__ void __launch_bounds__(256) k_pt_materialise(const RpPiece* __restrict__ pieces, const uint64_t* __restrict__ fin_start, const uint32_t* __restrict__ fin_cnt,
                                                         const RpFin* __restrict__ fin, const uint8_t* __restrict__ text, const uint8_t* __restrict__ repl,
                                                         uint8_t* __restrict__ text_fin)
 {
     typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(1)));
+    __shared__ RpPiece s_p[kMatPieces + 1];
     const uint32_t f = blockIdx.x;
     const RpFin m = fin[f];
     if (m.status == kRpNothing || m.len == 0) return;
@@ -875,13 +881,49 @@ __global__ void __launch_bounds__(256) k_pt_materialise(const RpPiece* __restric
     const uint32_t n = fin_cnt[f];
     uint8_t* dst = text_fin + m.off;
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    for (uint32_t i = wave; i < n; i += 256 / kWave) {           // a piece is a few hundred bytes: one wavefront each, four at a time
-        const uint64_t ls = P[i].lstart, len = P[i + 1].lstart - ls, s = P[i].src;
-        const uint8_t* from = (s & kPieceRepl) ? repl + (s & ~kPieceRepl) : text + s;
-        uint8_t* to = dst + ls;
-        const uint64_t n16 = len / 16;
-        for (uint64_t x = lane; x < n16; x += kWave) *reinterpret_cast<u32x4_u*>(to + 16 * x) = *reinterpret_cast<const u32x4_u*>(from + 16 * x);
-        for (uint64_t x = n16 * 16 + lane; x < len; x += kWave) to[x] = from[x];
+    const bool staged = n <= kMatPieces;
+    if (staged) {
+        for (uint32_t i = threadIdx.x; i <= n; i += 256) s_p[i] = P[i];
+        __syncthreads();
+    }
+    for (uint32_t i0 = wave * kMatFlight; i0 < n; i0 += (256 / kWave) * kMatFlight) {
+        const uint8_t* from[kMatFlight]; uint8_t* to[kMatFlight]; uint64_t len[kMatFlight];
+        u32x4_u v[kMatFlight]; uint32_t tail[kMatFlight];
+#pragma unroll
+        for (uint32_t u = 0; u < kMatFlight; u++) {
+            const uint32_t i = i0 + u;
+            len[u] = 0;
+            if (i < n) {
+                const RpPiece a = staged ? s_p[i] : P[i], b = staged ? s_p[i + 1] : P[i + 1];
+                len[u] = b.lstart - a.lstart;
+                from[u] = (a.src & kPieceRepl) ? repl + (a.src & ~kPieceRepl) : text + a.src;
+                to[u] = dst + a.lstart;
+            }
+        }
+        // first KiB of each: lanes below n16 take 16 bytes, the first `rest` lanes one of the last bytes each as well
+#pragma unroll
+        for (uint32_t u = 0; u < kMatFlight; u++) {
+            const uint64_t head = len[u] < 1024u ? len[u] : 1024u;
+            const uint32_t n16 = (uint32_t)(head / 16u), rest = (uint32_t)(head & 15u);
+            if (lane < n16) v[u] = *reinterpret_cast<const u32x4_u*>(from[u] + 16u * lane);
+            tail[u] = 0;
+            if (lane < rest && len[u] <= 1024u) tail[u] = from[u][16u * n16 + lane];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < kMatFlight; u++) {
+            const uint64_t head = len[u] < 1024u ? len[u] : 1024u;
+            const uint32_t n16 = (uint32_t)(head / 16u), rest = (uint32_t)(head & 15u);
+            if (lane < n16) *reinterpret_cast<u32x4_u*>(to[u] + 16u * lane) = v[u];
+            if (lane < rest && len[u] <= 1024u) to[u][16u * n16 + lane] = (uint8_t)tail[u];
+        }
+        // what a piece has beyond its first KiB (untouched stretches of the text between two replacements)
+#pragma unroll
+        for (uint32_t u = 0; u < kMatFlight; u++) {
+            if (len[u] <= 1024u) continue;
+            const uint64_t n16 = len[u] / 16;
+            for (uint64_t x = 64u + lane; x < n16; x += kWave) *reinterpret_cast<u32x4_u*>(to[u] + 16 * x) = *reinterpret_cast<const u32x4_u*>(from[u] + 16 * x);
+            for (uint64_t x = n16 * 16 + lane; x < len[u]; x += kWave) to[u][x] = from[u][x];
+        }
     }
 }
 

@@ -272,6 +272,11 @@ def main():
         if multi is not None:
             out["rccl"] = dict(rccl_ms, ranks=int(lib.am_multi_world_size(multi)), image_bytes=image_bytes,
                                data_path_collectives=0, what="am_multi_create_rank + am_multi_broadcast_automaton + am_multi_count_batch / am_multi_allreduce_sum (csrc/am_multi.cpp)")
+        if rank == 0:
+            # what the box gives: the kernels that count on two workgroups per CU (k_dfa, k_rp_lds, the small-filter k_sf) lose 10-45 % where a CU runs 16 wavefronts at a time
+            waves, one_ms, two_ms = am.api.resident_waves()
+            out["machine"] = {"resident_waves_per_cu": waves, "spin_16_per_cu_ms": one_ms, "spin_32_per_cu_ms": two_ms,
+                              "what": "am_debug_resident_waves: a spinning kernel with 16 and with 32 wavefronts per CU; equal times = 32 resident (the architecture's number), twice = 16"}
         if parity is not None:
             out["parity"] = parity
         if world == 1 and not args.no_h2d:

@@ -30,6 +30,11 @@ AM_API int am_debug_set_general_kernel(void* launcher, uint32_t image_version);
  * image offsets).  *failed_out = assertions that failed on the current device since the library was loaded, *first_line_out = source line of the first one (0: none),
  * *checked_units_out = translation units that carry assertions: 0 in the product build, where the call reports nothing and costs nothing. */
 AM_API int am_debug_bounds_report(uint64_t* failed_out, uint32_t* first_line_out, uint32_t* checked_units_out);
+/* How many wavefronts does a CU of the current device really run at the same time?  A spinning kernel is launched with 16 and with 32 wavefronts per CU (workgroups of 1024 and of
+ * 256 threads, 4 KiB of LDS, a handful of registers): *one_ms_out / *two_ms_out = the launch times.  Equal times: 32 are resident, as the architecture says; twice the time: the
+ * second half waited for the first (seen on the GPU pool during round 6: k_dfa, k_rp_lds and the small-filter k_sf, which count on two workgroups per CU, lose 10-45 % there).
+ * bench.py prints the answer as `machine.resident_waves_per_cu`. */
+AM_API int am_debug_resident_waves(float* one_ms_out, float* two_ms_out);
 
 #ifdef __cplusplus
 }
