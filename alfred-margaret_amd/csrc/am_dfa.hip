@@ -480,15 +480,71 @@ __global__ __launch_bounds__(1024) void k_dfa_place(const u32x2_v* __restrict__ 
 
 uint64_t dfa_units(const DfaView& d, const BatchView& b) { return d.chunk ? (b.total + d.chunk - 1) / d.chunk : 0; }
 
-// rows of the table a workgroup keeps in LDS: what fits into 64 KiB (two workgroups of 16 wavefronts share a CU's 160 KiB)
-static uint32_t dfa_hot_rows(const DfaView& d) { return std::min<uint32_t>(d.n_rows, (64u * 1024u) >> (kLdsLog2Cols + 2u)); }
+// How many wavefronts does a CU of this device run at a time?  32 by the architecture -- two workgroups of 16 share a CU and its 160 KiB of LDS --, but boxes were met on which the second
+// 16 wait for the first (LABNOTES R6.13: k_dfa 7.4 -> 10.9 ms per 2 GiB there).  On such a device ONE workgroup per CU is launched and given all of the LDS: twice the rows, three times the
+// records -- fewer L2 requests for the wavefronts that do run.  The probe (am_debug_resident_waves' spinning kernel, 16 against 32 wavefronts per CU, twice; ~2 ms, once per device and
+// process) must say "twice the time" both times.
+static uint32_t dfa_resident_sets(int dev)
+{
+    static std::atomic<int> state[64];                       // 0: not asked, 1: one set of 16 wavefronts at a time, 2: two
+    if (dev < 0 || dev >= 64) return 2;
+    int s = state[dev].load(std::memory_order_acquire);
+    if (s == 0) {
+        s = 2;
+        int n_cu = 0;
+        uint32_t* d_out = nullptr;
+        hipEvent_t a = nullptr, b = nullptr;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0 && hipMalloc((void**)&d_out, 64) == hipSuccess &&
+            hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+            int slow = 0;
+            for (int round = 0; round < 2; round++) {
+                float ms[2] = {0, 0};
+                bool good = true;
+                for (int k = 0; k < 2 && good; k++) {
+                    const uint32_t wgs = k == 0 ? (uint32_t)n_cu : 8u * (uint32_t)n_cu, threads = k == 0 ? 1024u : 256u;
+                    good = launch_spin(wgs, threads, 1000, d_out, nullptr) == hipSuccess && hipEventRecord(a, nullptr) == hipSuccess && launch_spin(wgs, threads, 600000, d_out, nullptr) == hipSuccess &&
+                           hipEventRecord(b, nullptr) == hipSuccess && hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms[k], a, b) == hipSuccess;
+                }
+                if (good && ms[1] > 1.7f * ms[0]) slow++;
+            }
+            if (slow == 2) s = 1;
+        }
+        (void)hipGetLastError();
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        if (d_out) (void)hipFree(d_out);
+        state[dev].store(s, std::memory_order_release);
+    }
+    return (uint32_t)s;
+}
+static uint32_t dfa_tune();
+static uint32_t dfa_per_cu()
+{
+    const uint32_t asked = (dfa_tune() >> 4) & 15u;
+    if (asked) return asked;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 2;
+    return dfa_resident_sets(dev);
+}
+// what a workgroup keeps in LDS.  Two workgroups per CU (80 KiB each): the first 512 rows (64 KiB) and the 640 hottest records of either kind (measured on the natural-text workload:
+// the first 640 single-entry records take 1.9 % of the steps, the first 640 two-entry ones 1.9 %; a row more takes 0.01 %).  One workgroup per CU: 1 008 rows, 2 048 + 1 024 records.
+struct DfaLds { uint32_t rows, n1, n2; };
+static DfaLds dfa_lds(const DfaView& d, uint32_t per_cu)
+{
+    const bool all = per_cu == 1u;
+    DfaLds l;
+    l.rows = std::min<uint32_t>(d.n_rows, all ? 1008u : 512u);
+    l.n1 = std::min<uint32_t>(d.n_single, all ? 2048u : 640u);
+    l.n2 = std::min<uint32_t>(d.n_states - d.n_rows - d.n_single, all ? 1024u : 640u);
+    return l;
+}
 // AM_DFA_TUNE (measurements only; no value changes a result): bits 0-3 = the walk (1: 16 bytes of text per request, lanes in step; 2: 64 bytes, lanes in step; 3: 64 bytes, lanes out of step; 0: the default),
-// bits 4-7 = workgroups per CU (0: two), bits 8-23 = rows kept in LDS + 1 (0: what fits), bit 24 = no records in LDS, bit 25 = k_dfa_place's table of seen states with 8-byte entries
+// bits 4-7 = workgroups per CU (0: two, or one with all of the LDS where the device runs 16 wavefronts per CU at a time), bits 8-23 = rows kept in LDS + 1 (0: what fits), bit 24 = no records in LDS, bit 25 = k_dfa_place's table of seen states with 8-byte entries
 static uint32_t dfa_tune() { const long v = cfg::get(cfg::kDfaTune); return v > 0 ? (uint32_t)v : 0u; }
 static uint32_t dfa_workgroups(const DfaView& d, const BatchView& b, int n_cu)
 {
     const uint64_t n_groups = (dfa_units(d, b) + kWave - 1) / kWave;
-    const uint32_t per_cu = (dfa_tune() >> 4) & 15u ? (dfa_tune() >> 4) & 15u : 2u;
+    const uint32_t per_cu = dfa_per_cu();
     return (uint32_t)std::min<uint64_t>((uint64_t)n_cu * per_cu, (n_groups + 15) / 16);
 }
 // Can this device walk this section at all?  The walk addresses hot table and chain records as 32-bit offsets from the rows and a group's text as 32-bit offsets
@@ -500,7 +556,7 @@ static bool dfa_raise_lds(int dev)
     static std::atomic<int> state[64];                       // 0: not tried, 1: raised, 2: refused
     int s = state[dev].load(std::memory_order_acquire);
     if (s == 0) {
-        s = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess ? 1 : 2;
+        s = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dfa<MODE, TW, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 1 : 2;
         if (s == 2) (void)hipGetLastError();
         state[dev].store(s, std::memory_order_release);
     }
@@ -526,12 +582,11 @@ static hipError_t launch_dfa_tw(const DfaView& d, const BatchView& b, const Scan
     const uint64_t n_units = dfa_units(d, b);
     if (n_units == 0) return hipSuccess;
     if (!dfa_usable(d)) return hipErrorInvalidValue;         // (make_plan does not come here with such a section)
-    uint32_t hot = dfa_hot_rows(d);
+    const DfaLds l = dfa_lds(d, dfa_per_cu());
+    uint32_t hot = l.rows;
     if ((dfa_tune() >> 8) & 0xFFFFu) hot = std::min<uint32_t>(hot, ((dfa_tune() >> 8) & 0xFFFFu) - 1u);
-    // what is left of a workgroup's 80 KiB after the rows: the hottest records (measured on the natural-text workload: the first 640 single-entry records take 1.9 % of the steps,
-    // the first 640 two-entry ones 1.9 %; a row more takes 0.01 %)
-    const size_t lds_fixed = ((size_t)dfa_hot_rows(d) << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
-    uint32_t n1 = std::min<uint32_t>(d.n_single, 640u), n2 = std::min<uint32_t>(d.n_states - d.n_rows - d.n_single, 640u);
+    const size_t lds_fixed = ((size_t)l.rows << (kLdsLog2Cols + 2u)) + 128 * 4 + 256;
+    uint32_t n1 = l.n1, n2 = l.n2;
     if ((dfa_tune() >> 24) & 1u) n1 = n2 = 0u;
     const size_t lds = lds_fixed + 8u * (n1 + 2u) + 16u * n2;
     hipLaunchKernelGGL((k_dfa<MODE, TW, VAR>), dim3(dfa_workgroups(d, b, n_cu)), dim3(1024), lds, st, d, b, o, n_units, hot, n1, n2);

@@ -76,10 +76,10 @@ def test_fragment_pool_on_the_table_walk(dfa_everywhere, seed):
             check_dfa_route(ns, hays, case)
 
 
-@pytest.mark.parametrize("tune", [3, 1, 0x1000000, 0x103])
+@pytest.mark.parametrize("tune", [3, 1, 0x1000000, 0x103, 0x10, 0x13])
 def test_the_walks_variants_report_the_same_records(dfa_everywhere, tune):
     """AM_DFA_TUNE (am_dfa.hip dfa_tune): lanes out of step inside a 16-byte block (3), 16 bytes of text per request (1), no records in LDS (bit 24), no rows in LDS
-    with lanes out of step (0x103) -- measurement switches, each the same walk by other loads: records, counts and flags against the oracle, image version 17's
+    with lanes out of step (0x103), one workgroup per CU with all of its LDS (0x10, 0x13: what a device that runs 16 wavefronts per CU at a time gets) -- measurement switches, each the same walk by other loads: records, counts and flags against the oracle, image version 17's
     records (one and two entries, leaning on a row state) on every path."""
     am.debug_set("AM_DFA_TUNE", tune)
     try:
